@@ -1,0 +1,340 @@
+"""ORACLE — test infrastructure only, never the product path.
+
+A vectorised torch-CPU (fp32) restatement of the ray-marching hot path of
+zhangkai0425/mipnerf360, written from the math in SURVEY.md §8a. Each function
+cites the reference file:line whose behaviour it reproduces. Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this
+module; `mipnerf360_amd/` must never do so.
+
+Parity status: PINNED. `tests/golden/*.npz` were produced by importing the
+reference itself in the authoring container (`tests/golden/make_golden.py`) and
+`tests/test_oracle_golden.py` checks every function below against them
+(<= 1e-6 abs on O(1) quantities).
+
+Reference behaviours reproduced on purpose:
+  * `contract()` uses the Frobenius norm of the WHOLE [B,N,3] tensor
+    (intern/parameterization.py:23-29 called at :75),
+  * the per-sample Jacobian loop (intern/parameterization.py:76-79) is replaced
+    by its closed form  J = I                      if |y| <= 1
+                        J = (2/r - 1/r^2) I + (2/r^4 - 2/r^3) y y^T   otherwise,
+  * `g(x)` adds 1e-6 in place (intern/parameterization.py:15-21); this module
+    never mutates its inputs but applies the same offsets.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping, NamedTuple, Optional, Tuple
+
+import numpy as np
+import torch
+
+EPS_G = 1e-6  # intern/parameterization.py:18
+
+
+class Rays(NamedTuple):  # intern/ray.py:6
+    origins: torch.Tensor
+    directions: torch.Tensor
+    viewdirs: torch.Tensor
+    radii: torch.Tensor
+    near: torch.Tensor
+    far: torch.Tensor
+
+
+def rays_from_numpy(d: Mapping[str, np.ndarray]) -> Rays:
+    return Rays(*[torch.from_numpy(np.ascontiguousarray(d[k])).float().clone() for k in Rays._fields])
+
+
+# 21 unit directions of the icosahedron/dodecahedron basis, intern/encoding.py:9-30
+_A, _B, _C, _D = 0.8506508, 0.5257311, 0.809017, 0.309017
+IPE_BASIS = torch.tensor([
+    [_A, 0, _B], [_C, 0.5, _D], [_B, _A, 0], [1, 0, 0], [_C, 0.5, -_D], [_A, 0, -_B],
+    [_D, _C, -0.5], [0, _B, -_A], [0.5, _D, -_C], [0, 1, 0], [-_B, _A, 0], [-_D, _C, -0.5],
+    [0, _B, _A], [-_D, _C, 0.5], [_D, _C, 0.5], [0.5, _D, _C], [0.5, -_D, _C], [0, 0, 1],
+    [-0.5, _D, _C], [-_C, 0.5, _D], [-_C, 0.5, -_D]], dtype=torch.float32)
+
+
+# --------------------------------------------------------------------------- t <-> s
+def disparity_eps(x: torch.Tensor, times: int = 1) -> torch.Tensor:
+    """1/(x + times*1e-6): value `g` returns on its `times`-th call on the same tensor
+    (intern/parameterization.py:15-21, in-place `x += eps`)."""
+    y = x
+    for _ in range(times):
+        y = y + EPS_G
+    return 1.0 / y
+
+
+def sample_t(near: torch.Tensor, far: torch.Tensor, num_samples: int) -> torch.Tensor:
+    """Deterministic t_vals [B,N+1] of intern/ray.py:99-101,110:
+    t = g(s*g(far) + (1-s)*g(near)), each g adding 1e-6 first."""
+    s = torch.linspace(0.0, 1.0, num_samples + 1)
+    mix = s * disparity_eps(far) + (1 - s) * disparity_eps(near)
+    return 1.0 / (mix + EPS_G)
+
+
+def jitter_t(t_vals: torch.Tensor, t_rand: torch.Tensor) -> torch.Tensor:
+    """Stratified jitter of intern/ray.py:103-108 with caller-supplied uniforms."""
+    mids = 0.5 * (t_vals[..., 1:] + t_vals[..., :-1])
+    upper = torch.cat([mids, t_vals[..., -1:]], -1)
+    lower = torch.cat([t_vals[..., :1], mids], -1)
+    return lower + (upper - lower) * t_rand
+
+
+def t_to_s(t_vals, near, far, near_calls_before: int = 1, far_calls_before: int = 1):
+    """s_vals of intern/parameterization.py:5-8 as evaluated inside
+    nerf_net.forward (model.py:196): by then `g` has already been applied
+    `*_calls_before` times to near/far by sample_along_rays, and t_to_s itself
+    calls g(t), g(near), g(far), g(near) in that order."""
+    gt = disparity_eps(t_vals, 1)
+    gn1 = disparity_eps(near, near_calls_before + 1)
+    gf = disparity_eps(far, far_calls_before + 1)
+    gn2 = disparity_eps(near, near_calls_before + 2)
+    return (gt - gn1) / (gf - gn2)
+
+
+# --------------------------------------------------------------------------- frustum -> gaussian
+def frustum_moments(t0, t1, radii):
+    """Stable conical-frustum moments, intern/parameterization.py:99-107."""
+    mu = (t0 + t1) / 2
+    hw = (t1 - t0) / 2
+    den = 3 * mu ** 2 + hw ** 2
+    t_mean = mu + (2 * mu * hw ** 2) / den
+    t_var = (hw ** 2) / 3 - (4 / 15) * ((hw ** 4 * (12 * mu ** 2 - hw ** 2)) / den ** 2)
+    r_var = radii ** 2 * ((mu ** 2) / 4 + (5 / 12) * hw ** 2 - 4 / 15 * (hw ** 4) / den)
+    return t_mean, t_var, r_var
+
+
+def lift_to_xyz(d, t_mean, t_var, r_var):
+    """Full-covariance lift, intern/parameterization.py:44-46,55-62 (diag=False)."""
+    mean = d[..., None, :] * t_mean[..., None]
+    d_mag_sq = torch.clamp_min(torch.sum(d ** 2, dim=-1, keepdim=True), 1e-10)
+    d_outer = d[..., :, None] * d[..., None, :]
+    eye = torch.eye(3)
+    null_outer = eye - d[..., :, None] * (d / d_mag_sq)[..., None, :]
+    cov = t_var[..., None, None] * d_outer[..., None, :, :] + r_var[..., None, None] * null_outer[..., None, :, :]
+    return mean, cov
+
+
+def contract_global(x: torch.Tensor) -> torch.Tensor:
+    """intern/parameterization.py:23-29 — norm over the whole tensor."""
+    n = torch.linalg.vector_norm(x)
+    if n <= 1:
+        return x
+    return (2 - 1 / n) * (x / n)
+
+
+def contract_jacobian(y: torch.Tensor) -> torch.Tensor:
+    """Closed form of jacobian(contract, y) for 3-vectors y[...,3]
+    (what intern/parameterization.py:76-79 computes per sample)."""
+    r = torch.linalg.vector_norm(y, dim=-1)[..., None, None]
+    eye = torch.eye(3).expand(y.shape[:-1] + (3, 3))
+    rs = torch.where(r > 1, r, torch.ones_like(r))
+    a = 2 / rs - 1 / rs ** 2
+    b = 2 / rs ** 4 - 2 / rs ** 3
+    J = a * eye + b * (y[..., :, None] * y[..., None, :])
+    return torch.where(r > 1, J, eye)
+
+
+def gaussian_contract(mean, cov):
+    """intern/parameterization.py:64-83."""
+    mean_c = contract_global(mean)
+    J = contract_jacobian(mean_c)
+    cov_c = torch.matmul(torch.matmul(J, cov), J.transpose(-1, -2))
+    return mean_c, cov_c
+
+
+def para_rays(t_vals, origins, directions, radii):
+    """intern/parameterization.py:119-135 (origins added AFTER contraction)."""
+    t0, t1 = t_vals[..., :-1], t_vals[..., 1:]
+    t_mean, t_var, r_var = frustum_moments(t0, t1, radii)
+    mean, cov = lift_to_xyz(directions, t_mean, t_var, r_var)
+    mean, cov = gaussian_contract(mean, cov)
+    return mean + origins[..., None, :], cov
+
+
+# --------------------------------------------------------------------------- encodings
+def ipe(mean, cov):
+    """intern/encoding.py:33-56 (single-scale integrated positional encoding)."""
+    P = IPE_BASIS
+    gamma = torch.matmul(mean, P.T)                     # [...,21]
+    A = torch.matmul(cov, P.T)                          # [...,3,21]
+    sigma = torch.sum(P.T * A, dim=-2)                  # [...,21]
+    damp = torch.exp(-0.5 * sigma)
+    return torch.cat((damp * torch.sin(gamma), damp * torch.cos(gamma)), -1)
+
+
+def viewdir_enc(viewdirs, min_deg: int = 0, max_deg: int = 4):
+    """intern/encoding.py:69-90 (theta/phi encoding; atan, not atan2)."""
+    scales = torch.tensor([2.0 ** i for i in range(min_deg, max_deg)], dtype=torch.float32)
+    x, y, z = viewdirs[..., 0:1], viewdirs[..., 1:2], viewdirs[..., 2:3]
+    theta = torch.arccos(z) * scales
+    phi = torch.arctan(y / (x + 1e-6)) * scales
+    return torch.cat((torch.sin(theta), torch.cos(theta), torch.sin(phi), torch.cos(phi)), -1)
+
+
+def encode_inputs(mean, cov, viewdirs, min_deg=0, max_deg=4):
+    """model.py:85-88 / :173-176 — [B,N,42+16]."""
+    enc = ipe(mean, cov)
+    vd = viewdir_enc(viewdirs, min_deg, max_deg)[:, None, :].expand(-1, enc.shape[1], -1)
+    return torch.cat((enc, vd), -1)
+
+
+# --------------------------------------------------------------------------- weights / resampling / compositing
+def density_to_weight(t_vals, density, dirs):
+    """model.py:59-78. density [B,N,1] or [B,N]."""
+    if density.dim() == 3:
+        density = density[..., 0]
+    delta = (t_vals[..., 1:] - t_vals[..., :-1]) * torch.linalg.norm(dirs[..., None, :], dim=-1)
+    x = density * delta
+    alpha = 1 - torch.exp(-x)
+    excl = torch.cat([torch.zeros_like(x[..., :1]), torch.cumsum(x[..., :-1], dim=-1)], dim=-1)
+    return alpha * torch.exp(-excl)
+
+
+def blur_weights(weights, resample_padding):
+    """intern/ray.py:137-142."""
+    wp = torch.cat([weights[..., :1], weights, weights[..., -1:]], dim=-1)
+    wm = torch.maximum(wp[..., :-1], wp[..., 1:])
+    return 0.5 * (wm[..., :-1] + wm[..., 1:]) + resample_padding
+
+
+def sorted_piecewise_constant_pdf(bins, weights, num_samples, u_rand: Optional[torch.Tensor] = None):
+    """intern/ray.py:12-57. Deterministic u unless `u_rand` ([B,num_samples]
+    uniforms in [0,1)) is given, in which case the randomized branch (:30-35,
+    including its `u + u` doubling) is followed with those uniforms.
+    The O(N^2) mask is replaced by a sorted search (same bracket: the last
+    cdf_i <= u)."""
+    eps = 1e-5
+    f32eps = float(torch.finfo(torch.float32).eps)
+    wsum = torch.sum(weights, dim=-1, keepdim=True)
+    pad = torch.clamp_min(eps - wsum, 0)
+    weights = weights + pad / weights.shape[-1]
+    wsum = wsum + pad
+    pdf = weights / wsum
+    cdf = torch.clamp_max(torch.cumsum(pdf[..., :-1], dim=-1), 1.0)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf, torch.ones_like(cdf[..., :1])], dim=-1)
+    if u_rand is None:
+        u = torch.linspace(0.0, 1.0 - f32eps, num_samples)
+        u = u.expand(cdf.shape[:-1] + (num_samples,)).contiguous()
+    else:
+        s = 1 / num_samples
+        base = (torch.arange(num_samples) * s)[None, :]
+        u = base + base + u_rand * (s - f32eps)
+        u = torch.clamp_max(u, 1.0 - f32eps)
+    idx = torch.searchsorted(cdf.contiguous(), u, right=True) - 1
+    last = cdf.shape[-1] - 1
+    i0 = idx.clamp(0, last)
+    i1 = (idx + 1).clamp(0, last)
+    b0, b1 = torch.gather(bins, -1, i0), torch.gather(bins, -1, i1)
+    c0, c1 = torch.gather(cdf, -1, i0), torch.gather(cdf, -1, i1)
+    tt = torch.clip(torch.nan_to_num((u - c0) / (c1 - c0), 0), 0, 1)
+    return b0 + tt * (b1 - b0)
+
+
+def resample_t(t_vals, weights, resample_padding, u_rand=None):
+    """intern/ray.py:136-149 (new t only)."""
+    w = blur_weights(weights, resample_padding)
+    return sorted_piecewise_constant_pdf(t_vals, w, t_vals.shape[-1], u_rand)
+
+
+def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd):
+    """intern/ray.py:155-191."""
+    t_mids = 0.5 * (t_vals[..., :-1] + t_vals[..., 1:])
+    weights = density_to_weight(t_vals, density, dirs)
+    comp_rgb = (weights[..., None] * rgb).sum(dim=-2)
+    acc = weights.sum(dim=-1)
+    distance = (weights * t_mids).sum(dim=-1) / acc
+    distance = torch.clamp(torch.nan_to_num(distance), t_vals[:, 0], t_vals[:, -1])
+    if white_bkgd:
+        comp_rgb = comp_rgb + (1.0 - acc[..., None])
+    return comp_rgb, distance, acc, weights
+
+
+# --------------------------------------------------------------------------- MLPs
+def _lin(x, sd, prefix):
+    return torch.nn.functional.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def prop_mlp(x, sd):
+    """model.py:43-53."""
+    for i in (0, 2, 4):
+        x = torch.relu(_lin(x, sd, f"prop_net.model.{i}"))
+    x = torch.sigmoid(_lin(x, sd, "prop_net.model.6"))
+    return _lin(x, sd, "prop_net.model.8")
+
+
+def nerf_mlp(x, sd):
+    """model.py:131-158."""
+    for i in range(0, 14, 2):
+        x = torch.relu(_lin(x, sd, f"nerf_net.model.{i}"))
+    x = torch.sigmoid(_lin(x, sd, "nerf_net.model.14"))
+    raw_density = torch.sigmoid(_lin(x, sd, "nerf_net.final_density.0"))
+    raw_rgb = torch.sigmoid(_lin(x, sd, "nerf_net.final_color.0"))
+    return raw_density, raw_rgb
+
+
+def to_torch_state_dict(sd: Mapping[str, np.ndarray]) -> Dict[str, torch.Tensor]:
+    return {k: (torch.from_numpy(np.ascontiguousarray(v)).float() if isinstance(v, np.ndarray) else v.detach().float().cpu())
+            for k, v in sd.items()}
+
+
+# --------------------------------------------------------------------------- stages
+class Hyper(NamedTuple):
+    num_samples: int = 128
+    density_bias: float = -1.0
+    rgb_padding: float = 0.001
+    resample_padding: float = 0.01
+    white_bkgd: bool = False
+    viewdir_min_deg: int = 0
+    viewdir_max_deg: int = 4
+
+
+def prop_forward(rays: Rays, sd, hp: Hyper, t_rand=None):
+    """prop_net.forward, model.py:80-94 -> (t_vals[B,N+1], weights[B,N])."""
+    t_vals = sample_t(rays.near, rays.far, hp.num_samples)
+    if t_rand is not None:
+        t_vals = jitter_t(t_vals, t_rand)
+    t_vals = t_vals.expand(rays.origins.shape[0], -1).contiguous()
+    mean, cov = para_rays(t_vals, rays.origins, rays.directions, rays.radii)
+    x = encode_inputs(mean, cov, rays.viewdirs, hp.viewdir_min_deg, hp.viewdir_max_deg)
+    raw = prop_mlp(x, sd)
+    density = torch.nn.functional.softplus(raw + hp.density_bias)
+    return t_vals, density_to_weight(t_vals, density, rays.directions)
+
+
+def nerf_forward(rays: Rays, t_vals, coarse_weights, sd, hp: Hyper, u_rand=None):
+    """nerf_net.forward, model.py:163-200 -> (rgb, dist, acc, t_vals+1e-6, weights, s_vals)."""
+    t_new = resample_t(t_vals, coarse_weights, hp.resample_padding, u_rand)
+    mean, cov = para_rays(t_new, rays.origins, rays.directions, rays.radii)
+    x = encode_inputs(mean, cov, rays.viewdirs, hp.viewdir_min_deg, hp.viewdir_max_deg)
+    raw_density, raw_rgb = nerf_mlp(x, sd)
+    rgb = raw_rgb * (1 + 2 * hp.rgb_padding) - hp.rgb_padding
+    density = torch.nn.functional.softplus(raw_density + hp.density_bias)
+    comp_rgb, distance, acc, weights = volumetric_rendering(rgb, density, t_new, rays.directions, hp.white_bkgd)
+    s_vals = t_to_s(t_new, rays.near, rays.far)
+    return comp_rgb, distance, acc, t_new + EPS_G, weights, s_vals
+
+
+def forward(rays: Rays, sd, hp: Hyper):
+    """mipNeRF360.forward, model.py:247-252."""
+    with torch.no_grad():
+        t_hat, w_hat = prop_forward(rays, sd, hp)
+        out = nerf_forward(rays, t_hat, w_hat, sd, hp)
+    return out[0], out[1], out[2]
+
+
+def to8b(img: np.ndarray) -> np.ndarray:
+    """intern/utils.py:17-20."""
+    return (255 * np.clip(np.nan_to_num(img), 0, 1)).astype(np.uint8)
+
+
+def render_image(rays: Rays, height: int, width: int, sd, hp: Hyper, chunks: int = 4096):
+    """mipNeRF360.render_image, model.py:254-274 (chunk partition preserved —
+    the global contraction norm makes results chunk-dependent)."""
+    n = rays.origins.shape[0]
+    rgbs, dists, accs = [], [], []
+    for i in range(0, n, chunks):
+        chunk = Rays(*[f[i:i + chunks] for f in rays])
+        r, d, a = forward(chunk, sd, hp)
+        rgbs.append(r), dists.append(d), accs.append(a)
+    rgb8 = to8b(torch.cat(rgbs, 0).reshape(height, width, 3).numpy())
+    return rgb8, torch.cat(dists, 0).reshape(height, width).numpy(), torch.cat(accs, 0).reshape(height, width).numpy()

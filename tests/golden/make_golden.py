@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE itself.
+
+Run in the authoring container only (needs /root/reference, CPU is enough):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference (zhangkai0425/mipnerf360, pure PyTorch) is imported unmodified
+from /root/reference with device=cpu; this script only calls its public
+functions on seeded inputs and stores inputs + outputs as small .npz files.
+Nothing of the reference's source travels: fixtures are data.
+
+Because the reference's `g()` mutates near/far/t_vals in place
+(intern/parameterization.py:15-21) every call below receives fresh clones and
+the fixture stores the ORIGINAL (un-mutated) inputs.
+
+Fixture ids follow SURVEY.md §8c (G1..G9).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+sys.path.insert(1, ROOT)
+
+import torch  # noqa: E402
+
+import model as ref_model  # noqa: E402  (the reference)
+from intern import encoding as ref_enc  # noqa: E402
+from intern import parameterization as ref_par  # noqa: E402
+from intern import ray as ref_ray  # noqa: E402
+
+from mipnerf360_amd import synthetic  # noqa: E402  (build-owned generators)
+
+CPU = torch.device("cpu")
+torch.set_num_threads(8)
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).float().clone()
+
+
+def N(x):
+    return x.detach().cpu().numpy().copy()
+
+
+def ref_rays(d):
+    return ref_ray.Rays(*[T(d[k]) for k in synthetic.RAY_FIELDS])
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------- G1 + G2
+def g1_g2():
+    out = {}
+    for kind in ("lego", "garden"):
+        for n in (8, 64, 128):
+            r = synthetic.make_rays(kind, 6, seed=11)
+            t0 = time.time()
+            t_vals, (means, covs) = ref_ray.sample_along_rays(
+                T(r["origins"]), T(r["directions"]), T(r["radii"]), n, T(r["near"]), T(r["far"]), False)
+            key = f"{kind}_{n}"
+            out[key + "_t"] = N(t_vals)
+            if n == 8:  # full contracted gaussians only for the small case (python jacobian loop)
+                out[key + "_means"] = N(means)
+                out[key + "_covs"] = N(covs)
+            # pre-contraction lift (G2)
+            # the frustum moments are only INPUTS of the reference's gaussian_to_xyz here; they
+            # are pinned end-to-end by the contracted means/covs of sample_along_rays above
+            tv = t_vals.clone()
+            d = T(r["directions"])
+            mu = (tv[..., :-1] + tv[..., 1:]) / 2
+            hw = (tv[..., 1:] - tv[..., :-1]) / 2
+            t_mean = mu + (2 * mu * hw ** 2) / (3 * mu ** 2 + hw ** 2)
+            t_var = (hw ** 2) / 3 - (4 / 15) * ((hw ** 4 * (12 * mu ** 2 - hw ** 2)) / (3 * mu ** 2 + hw ** 2) ** 2)
+            r_var = T(r["radii"]) ** 2 * ((mu ** 2) / 4 + (5 / 12) * hw ** 2 - 4 / 15 * (hw ** 4) / (3 * mu ** 2 + hw ** 2))
+            xyz_mean, xyz_cov = ref_par.gaussian_to_xyz(d, t_mean, t_var, r_var, diag=False)
+            out[key + "_tmean"], out[key + "_tvar"], out[key + "_rvar"] = N(t_mean), N(t_var), N(r_var)
+            out[key + "_xyzmean"], out[key + "_xyzcov"] = N(xyz_mean), N(xyz_cov)
+            print(f"  G1/G2 {key}: {time.time() - t0:.2f}s")
+        for k in synthetic.RAY_FIELDS:
+            out[f"{kind}_{k}"] = synthetic.make_rays(kind, 6, seed=11)[k]
+    save("g1_g2_sampling", **out)
+
+
+# ----------------------------------------------------------------------------- G3
+def g3():
+    g = np.random.Generator(np.random.PCG64(33))
+    out = {}
+
+    def spd(shape):
+        a = g.normal(size=shape + (3, 3)).astype(np.float32) * 0.1
+        return a @ np.swapaxes(a, -1, -2) + 1e-3 * np.eye(3, dtype=np.float32)
+
+    cases = {
+        "big": g.normal(size=(8, 16, 3)).astype(np.float32) * 2.0,          # ||M||_F >> 1 -> J = I
+        "tiny": g.normal(size=(1, 2, 3)).astype(np.float32) * 40.0,         # contracted points with |y| > 1 -> J != I
+        "inside": g.normal(size=(2, 3, 3)).astype(np.float32) * 0.05,       # ||M||_F <= 1 -> identity
+    }
+    for name, mean in cases.items():
+        cov = spd(mean.shape[:2])
+        m, c = ref_par.gaussian_contract(T(mean), T(cov))
+        out[name + "_mean_in"], out[name + "_cov_in"] = mean, cov
+        out[name + "_mean_out"], out[name + "_cov_out"] = N(m), N(c)
+    save("g3_contract", **out)
+
+
+# ----------------------------------------------------------------------------- G4
+def g4():
+    g = np.random.Generator(np.random.PCG64(44))
+    mean = g.normal(size=(5, 7, 3)).astype(np.float32)
+    a = g.normal(size=(5, 7, 3, 3)).astype(np.float32) * 0.3
+    cov = a @ np.swapaxes(a, -1, -2)
+    pe = ref_enc.PositionalEncoding()
+    enc = pe(T(mean), T(cov))
+    v = g.normal(size=(12, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    v = v.astype(np.float32)
+    # edge rows: x ~ 0 (atan blow-up guarded by +1e-6), z = +-1
+    v[0] = [0.0, 1.0, 0.0]
+    v[1] = [0.0, 0.0, 1.0]
+    v[2] = [0.0, 0.0, -1.0]
+    v[3] = [-1e-6, 0.6, 0.8]
+    out = dict(mean=mean, cov=cov, ipe=N(enc), viewdirs=v)
+    for lo, hi in ((0, 4), (1, 3)):
+        vd = ref_enc.ViewdirectionEncoding(lo, hi)
+        out[f"vd_{lo}_{hi}"] = N(vd(T(v)))
+    save("g4_encoding", **out)
+
+
+# ----------------------------------------------------------------------------- G5
+def g5():
+    g = np.random.Generator(np.random.PCG64(55))
+    B, n = 7, 32
+    out = {}
+    for kind in ("lego", "garden"):
+        r = synthetic.make_rays(kind, B, seed=5)
+        t_vals = ref_ray.sample_along_rays(T(r["origins"]), T(r["directions"]), T(r["radii"]), 2,
+                                           T(r["near"]), T(r["far"]), False)[0]  # cheap call, only for near/far eps
+        s = np.sort(g.uniform(0, 1, size=(B, n + 1)), axis=1).astype(np.float32)
+        lo, hi = float(r["near"][0, 0]) + 1e-3, float(r["far"][0, 0])
+        t = (lo + s * (hi - lo)).astype(np.float32)
+        density = (g.gamma(0.6, 4.0, size=(B, n, 1))).astype(np.float32)
+        density[0] = 0.0            # zero-density ray -> acc 0, distance NaN -> nan_to_num -> clamp
+        density[1] = 1e4            # saturated ray
+        rgb = g.uniform(0, 1, size=(B, n, 3)).astype(np.float32)
+        dirs = r["directions"]
+        pn = ref_model.prop_net(num_samples=n, hidden_proposal=8, device=CPU)
+        w = pn.density_to_weight(T(t), T(density), T(dirs))
+        out[f"{kind}_t"], out[f"{kind}_density"], out[f"{kind}_rgb"], out[f"{kind}_dirs"] = t, density, rgb, dirs
+        out[f"{kind}_w"] = N(w)
+        for wb in (False, True):
+            c, d, a, ww = ref_ray.volumetric_rendering(T(rgb), T(density), T(t), T(dirs), wb)
+            tag = f"{kind}_wb{int(wb)}"
+            out[tag + "_rgb"], out[tag + "_dist"], out[tag + "_acc"], out[tag + "_w"] = N(c), N(d), N(a), N(ww)
+    save("g5_weights_composite", **out)
+
+
+# ----------------------------------------------------------------------------- G6
+def g6():
+    g = np.random.Generator(np.random.PCG64(66))
+    out = {}
+    B, n = 6, 48
+    t = np.sort(g.uniform(2, 6, size=(B, n + 1)), axis=1).astype(np.float32)
+    w = g.uniform(0, 1, size=(B, n)).astype(np.float32)
+    w[0] = 1.0 / n                                  # uniform
+    w[1] = 0.0
+    w[1, 17] = 1.0                                  # single peak
+    w[2] = 0.0                                      # all-zero -> eps padding branch
+    w[3] = np.exp(-0.5 * ((np.arange(n) - 30) / 2.0) ** 2)
+    out["t"], out["w"] = t, w
+    # bare pdf sampler (weights are modified in place by the reference -> clone)
+    for ns in (n + 1, 16):
+        smp = ref_ray.sorted_piecewise_constant_pdf(T(t), T(w) + 0.01, ns, randomized=False)
+        out[f"pdf_samples_{ns}"] = N(smp)
+    out["pdf_zero_samples"] = N(ref_ray.sorted_piecewise_constant_pdf(T(t), T(np.zeros_like(w)), n + 1, randomized=False))
+    # blur + padding + sampler + gaussians (small: python jacobian loop)
+    r = synthetic.make_rays("lego", B, seed=6)
+    for pad in (0.01, 0.0):
+        new_t, (means, covs) = ref_ray.resample_along_rays(T(r["origins"]), T(r["directions"]), T(r["radii"]),
+                                                           T(t), T(w), False, pad)
+        out[f"resample_t_pad{pad}"] = N(new_t)
+        if pad == 0.01:
+            out["resample_means"], out["resample_covs"] = N(means), N(covs)
+    for k in synthetic.RAY_FIELDS:
+        out["rays_" + k] = r[k]
+    save("g6_resample", **out)
+
+
+# ----------------------------------------------------------------------------- G7 / G8 / G9 helpers
+def build_ref_model(sd_np, n, hp, hn, white_bkgd, **kw):
+    m = ref_model.mipNeRF360(randomized=False, num_samples=n, hidden_proposal=hp, hidden_nerf=hn,
+                             white_bkgd=white_bkgd, device=CPU, **kw)
+    m.load_state_dict({k: T(v) for k, v in sd_np.items()})
+    return m
+
+
+def g7():
+    out = {}
+    hp_, hn_ = 32, 64
+    sd = synthetic.make_state_dict(hp_, hn_, seed=7)
+    for k, v in sd.items():
+        out["sd." + k] = v
+    for kind, B, n, wb in (("lego", 12, 16, True), ("garden", 10, 24, False)):
+        r = synthetic.make_rays(kind, B, seed=70 + n)
+        m = build_ref_model(sd, n, hp_, hn_, wb)
+        t0 = time.time()
+        with torch.no_grad():
+            rays = ref_rays(r)
+            t_hat, w_hat = m.prop_net.forward(rays)
+            t_hat_np, w_hat_np = N(t_hat), N(w_hat)
+            o = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        tag = f"{kind}"
+        for k in synthetic.RAY_FIELDS:
+            out[f"{tag}_rays_{k}"] = r[k]
+        out[tag + "_cfg"] = np.array([B, n, int(wb)])
+        out[tag + "_t_hat"], out[tag + "_w_hat"] = t_hat_np, w_hat_np
+        for nm, v in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), o):
+            out[f"{tag}_{nm}"] = N(v)
+        print(f"  G7 {kind}: {time.time() - t0:.1f}s")
+    save("g7_stages_small", **out)
+
+
+def g8():
+    out = {"weights_seed": np.array([0]), "rays_seed": np.array([1])}
+    sd = synthetic.make_state_dict(256, 1024, seed=0)
+    for kind, B, n, wb in (("lego", 256, 64, True), ("garden", 256, 128, False)):
+        r = synthetic.make_rays(kind, B, seed=1)
+        m = build_ref_model(sd, n, 256, 1024, wb)
+        t0 = time.time()
+        with torch.no_grad():
+            rgb, dist, acc = m(ref_rays(r))
+        out[f"{kind}_{n}_rgb"], out[f"{kind}_{n}_dist"], out[f"{kind}_{n}_acc"] = N(rgb), N(dist), N(acc)
+        out[f"{kind}_{n}_cfg"] = np.array([B, n, int(wb)])
+        print(f"  G8 {kind} B={B} N={n}: {time.time() - t0:.1f}s  ({B / (time.time() - t0):.1f} rays/s reference CPU)")
+    save("g8_end_to_end_fullwidth", **out)
+
+
+def g9():
+    import contextlib
+    import io
+    out = {}
+    hp_, hn_, n = 32, 64, 16
+    h, w = 24, 32
+    sd = synthetic.make_state_dict(hp_, hn_, seed=9)
+    for k, v in sd.items():
+        out["sd." + k] = v
+    r = synthetic.make_rays("garden", h * w, seed=9)
+    for k in synthetic.RAY_FIELDS:
+        out["rays_" + k] = r[k]
+    out["cfg"] = np.array([h, w, n])
+    m = build_ref_model(sd, n, hp_, hn_, False)
+    for chunks in (128, 4096):
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            rgb8, dist, acc = m.render_image(ref_rays(r), h, w, chunks=chunks)
+        assert rgb8.dtype == np.uint8 and dist.dtype == np.float32
+        out[f"c{chunks}_rgb8"], out[f"c{chunks}_dist"], out[f"c{chunks}_acc"] = rgb8, dist, acc
+        print(f"  G9 chunks={chunks}: {time.time() - t0:.1f}s")
+    save("g9_render_image", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9)
+    for k in which:
+        print(k)
+        table[k]()

@@ -1,0 +1,131 @@
+"""CPU: the oracle (oracle/ref_path.py) against fixtures produced by the reference itself
+(tests/golden/make_golden.py). This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from mipnerf360_amd import synthetic
+from oracle import ref_path as O
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()  # noqa: E731
+TOL = 1e-6
+
+
+def close(a, b, atol=TOL, rtol=1e-5):
+    a = a.numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("kind", ["lego", "garden"])
+@pytest.mark.parametrize("n", [8, 64, 128])
+def test_g1_t_sampling_and_g2_lift(golden, kind, n):
+    g = golden("g1_g2_sampling")
+    near, far = T(g[f"{kind}_near"]), T(g[f"{kind}_far"])
+    t = O.sample_t(near, far, n)
+    close(t, g[f"{kind}_{n}_t"], atol=0, rtol=2e-6)
+    d, radii = T(g[f"{kind}_directions"]), T(g[f"{kind}_radii"])
+    t_mean, t_var, r_var = O.frustum_moments(t[..., :-1], t[..., 1:], radii)
+    close(t_mean, g[f"{kind}_{n}_tmean"], atol=0, rtol=1e-5)
+    mean, cov = O.lift_to_xyz(d, T(g[f"{kind}_{n}_tmean"]), T(g[f"{kind}_{n}_tvar"]), T(g[f"{kind}_{n}_rvar"]))
+    close(mean, g[f"{kind}_{n}_xyzmean"], atol=1e-7)
+    close(cov, g[f"{kind}_{n}_xyzcov"], atol=1e-9, rtol=1e-5)
+    if n == 8:
+        m, c = O.para_rays(t, T(g[f"{kind}_origins"]), d, radii)
+        close(m, g[f"{kind}_{n}_means"])
+        close(c, g[f"{kind}_{n}_covs"], atol=1e-9, rtol=2e-4)
+
+
+@pytest.mark.parametrize("case", ["big", "tiny", "inside"])
+def test_g3_contraction(golden, case):
+    g = golden("g3_contract")
+    m, c = O.gaussian_contract(T(g[case + "_mean_in"]), T(g[case + "_cov_in"]))
+    close(m, g[case + "_mean_out"])
+    close(c, g[case + "_cov_out"], atol=1e-7, rtol=1e-5)
+    if case == "tiny":  # the J != I branch must really be exercised
+        assert np.abs(g[case + "_cov_out"] - g[case + "_cov_in"]).max() > 1e-3
+
+
+def test_g4_encodings(golden):
+    g = golden("g4_encoding")
+    close(O.ipe(T(g["mean"]), T(g["cov"])), g["ipe"])
+    for lo, hi in ((0, 4), (1, 3)):
+        close(O.viewdir_enc(T(g["viewdirs"]), lo, hi), g[f"vd_{lo}_{hi}"], atol=2e-6)
+
+
+@pytest.mark.parametrize("kind", ["lego", "garden"])
+def test_g5_weights_and_composite(golden, kind):
+    g = golden("g5_weights_composite")
+    t, dens, rgb, dirs = (T(g[f"{kind}_{k}"]) for k in ("t", "density", "rgb", "dirs"))
+    close(O.density_to_weight(t, dens, dirs), g[f"{kind}_w"])
+    for wb in (0, 1):
+        c, d, a, w = O.volumetric_rendering(rgb, dens, t, dirs, bool(wb))
+        tag = f"{kind}_wb{wb}"
+        close(c, g[tag + "_rgb"]), close(d, g[tag + "_dist"]), close(a, g[tag + "_acc"]), close(w, g[tag + "_w"])
+    assert g[f"{kind}_wb0_acc"][0] == 0.0  # the zero-density ray really hits the nan_to_num/clamp branch
+
+
+def test_g6_resampling(golden):
+    g = golden("g6_resample")
+    t, w = T(g["t"]), T(g["w"])
+    n = w.shape[-1]
+    for ns in (n + 1, 16):
+        close(O.sorted_piecewise_constant_pdf(t, w + 0.01, ns), g[f"pdf_samples_{ns}"], atol=2e-6)
+    close(O.sorted_piecewise_constant_pdf(t, torch.zeros_like(w), n + 1), g["pdf_zero_samples"], atol=2e-6)
+    for pad in (0.01, 0.0):
+        close(O.resample_t(t, w, pad), g[f"resample_t_pad{pad}"], atol=2e-6)
+    new_t = O.resample_t(t, w, 0.01)
+    m, c = O.para_rays(new_t, T(g["rays_origins"]), T(g["rays_directions"]), T(g["rays_radii"]))
+    close(m, g["resample_means"], atol=2e-6)
+    close(c, g["resample_covs"], atol=1e-9, rtol=1e-3)
+
+
+def _sd(g):
+    return O.to_torch_state_dict({k[3:]: v for k, v in g.items() if k.startswith("sd.")})
+
+
+@pytest.mark.parametrize("kind", ["lego", "garden"])
+def test_g7_stage_outputs(golden, kind):
+    g = golden("g7_stages_small")
+    sd = _sd(g)
+    B, n, wb = (int(x) for x in g[kind + "_cfg"])
+    rays = O.rays_from_numpy({k: g[f"{kind}_rays_{k}"] for k in synthetic.RAY_FIELDS})
+    hp = O.Hyper(num_samples=n, white_bkgd=bool(wb))
+    with torch.no_grad():
+        t_hat, w_hat = O.prop_forward(rays, sd, hp)
+        out = O.nerf_forward(rays, t_hat, w_hat, sd, hp)
+    close(t_hat, g[kind + "_t_hat"], atol=0, rtol=2e-6)
+    close(w_hat, g[kind + "_w_hat"])
+    for nm, v in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), out):
+        close(v, g[f"{kind}_{nm}"], atol=2e-6, rtol=2e-5)
+
+
+@pytest.mark.parametrize("kind,n", [("lego", 64), ("garden", 128)])
+def test_g8_end_to_end_full_width(golden, kind, n):
+    g = golden("g8_end_to_end_fullwidth")
+    B, n_, wb = (int(x) for x in g[f"{kind}_{n}_cfg"])
+    sd = O.to_torch_state_dict(synthetic.make_state_dict(256, 1024, seed=int(g["weights_seed"][0])))
+    rays = O.rays_from_numpy(synthetic.make_rays(kind, B, seed=int(g["rays_seed"][0])))
+    rgb, dist, acc = O.forward(rays, sd, O.Hyper(num_samples=n_, white_bkgd=bool(wb)))
+    close(rgb, g[f"{kind}_{n}_rgb"], atol=2e-6)
+    close(acc, g[f"{kind}_{n}_acc"], atol=2e-6)
+    close(dist, g[f"{kind}_{n}_dist"], atol=2e-6, rtol=2e-5)
+
+
+@pytest.mark.parametrize("chunks", [128, 4096])
+def test_g9_render_image(golden, chunks):
+    g = golden("g9_render_image")
+    h, w, n = (int(x) for x in g["cfg"])
+    rays = O.rays_from_numpy({k: g["rays_" + k] for k in synthetic.RAY_FIELDS})
+    rgb8, dist, acc = O.render_image(rays, h, w, _sd(g), O.Hyper(num_samples=n), chunks=chunks)
+    assert rgb8.dtype == np.uint8 and rgb8.shape == (h, w, 3)
+    assert dist.dtype == np.float32 and dist.shape == (h, w) and acc.shape == (h, w)
+    assert np.abs(rgb8.astype(int) - g[f"c{chunks}_rgb8"].astype(int)).max() <= 1
+    assert (rgb8 != g[f"c{chunks}_rgb8"]).mean() < 0.01
+    close(dist, g[f"c{chunks}_dist"], atol=2e-6, rtol=2e-5)
+    close(acc, g[f"c{chunks}_acc"], atol=2e-6)
+
+
+def test_g9_chunk_dependence_is_real(golden):
+    """The reference's global-norm contraction makes results depend on the chunk partition."""
+    g = golden("g9_render_image")
+    assert np.abs(g["c128_acc"] - g["c4096_acc"]).max() > 1e-5
