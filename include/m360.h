@@ -1,0 +1,255 @@
+/*
+ * m360.h — C-ABI of libm360.so: the MI355X (gfx950) native ray-marching hot path of
+ * mip-NeRF 360 as implemented by zhangkai0425/mipnerf360.
+ *
+ * Every entry point replaces one function (or one fused group of functions) of the
+ * reference's Python hot path; the reference file:line is cited on each declaration
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM) unless the name ends in `_host`;
+ *   - all tensors are fp32, contiguous, row-major, shapes as written in brackets;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - the library never allocates device memory and never synchronises: scratch is a
+ *     caller-provided `workspace` (size from the matching *_workspace_bytes query);
+ *   - return value: M360_OK (0) or a negative M360_ERR_* code; `m360_last_error()` gives
+ *     a thread-local human readable message for the last failure on the calling thread;
+ *   - inputs are never written (the reference's in-place `g()` mutation of near/far/t_vals,
+ *     intern/parameterization.py:15-21, is reproduced numerically, not physically).
+ */
+#ifndef M360_H_
+#define M360_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M360_VERSION 100 /* 0.1.0 */
+
+typedef void *m360_stream_t;
+
+enum {
+    M360_OK = 0,
+    M360_ERR_INVALID_ARGUMENT = -1,
+    M360_ERR_LAUNCH = -2,
+    M360_ERR_WORKSPACE_TOO_SMALL = -3,
+    M360_ERR_NO_DEVICE = -4
+};
+
+enum { M360_ACT_NONE = 0, M360_ACT_RELU = 1, M360_ACT_SIGMOID = 2 };
+
+int m360_version(void);
+const char *m360_last_error(void);
+/* number of HIP devices visible (0 when none) — lets hosts fail loudly and early */
+int m360_device_count(void);
+
+/* ------------------------------------------------------------------ sampling ---------- */
+
+/* t_vals[B,N+1] = g(s*g(far) + (1-s)*g(near)), s = linspace(0,1,N+1), each g() adding 1e-6
+ * first; optional stratified jitter with caller-supplied uniforms t_rand[B,N+1] (NULL =
+ * deterministic).  Replaces intern/ray.py:99-110 (sample_along_rays, t part). */
+int m360_sample_t(const float *near /*[B]*/, const float *far /*[B]*/, const float *t_rand,
+                  int B, int N, float *t_vals, m360_stream_t stream);
+
+/* y = g(x) = 1/(x + 1e-6), elementwise, x untouched.  Replaces intern/parameterization.py:15-21. */
+int m360_g(const float *x, long n, float *y, m360_stream_t stream);
+
+/* t_vals[B,M] = g(s*g(far) + (1-s)*g(near)) for caller-provided s_vals[B,M].
+ * Replaces intern/parameterization.py:10-13 (s_to_t). */
+int m360_s_to_t(const float *s_vals, const float *near, const float *far, int B, int M,
+                float *t_vals, m360_stream_t stream);
+
+/* s_vals[B,M] of t_to_s as evaluated by nerf_net.forward: near/far have already been through
+ * g() `near_calls`/`far_calls` times.  Replaces intern/parameterization.py:5-8 at model.py:196. */
+int m360_t_to_s(const float *t_vals /*[B,M]*/, const float *near, const float *far, int B, int M,
+                int near_calls, int far_calls, float *s_vals, m360_stream_t stream);
+
+/* ------------------------------------------------------------------ gaussians --------- */
+
+/* stable conical-frustum moments.  Replaces intern/parameterization.py:99-107. */
+int m360_frustum_moments(const float *t0 /*[B,N]*/, const float *t1 /*[B,N]*/,
+                         const float *radii /*[B]*/, int B, int N, float *t_mean, float *t_var,
+                         float *r_var, m360_stream_t stream);
+
+/* lift to xyz, full covariance.  Replaces intern/parameterization.py:31-62 (diag=False). */
+int m360_gaussian_to_xyz(const float *d /*[B,3]*/, const float *t_mean /*[B,N]*/,
+                         const float *t_var, const float *r_var, int B, int N,
+                         float *mean /*[B,N,3]*/, float *cov /*[B,N,3,3]*/, m360_stream_t stream);
+
+size_t m360_contract_workspace_bytes(void);
+
+/* y = contract(x): x if ||x||_F <= 1 else (2 - 1/||x||)(x/||x||), norm over ALL n elements.
+ * Replaces intern/parameterization.py:23-29. */
+int m360_contract(const float *x, long n, float *y, void *workspace, size_t workspace_bytes,
+                  m360_stream_t stream);
+
+/* whole-tensor-norm contraction of the means + J cov J^T with the closed-form Jacobian.
+ * Replaces intern/parameterization.py:23-29,64-83 (the per-sample autograd loop). */
+int m360_gaussian_contract(const float *mean_in /*[S,3]*/, const float *cov_in /*[S,3,3]*/, long S,
+                           float *mean_out, float *cov_out, void *workspace, size_t workspace_bytes,
+                           m360_stream_t stream);
+
+/* t_vals -> contracted gaussians (+origins).  Replaces intern/parameterization.py:119-135. */
+int m360_para_rays(const float *t_vals /*[B,N+1]*/, const float *origins /*[B,3]*/,
+                   const float *directions /*[B,3]*/, const float *radii /*[B]*/, int B, int N,
+                   float *means /*[B,N,3]*/, float *covs /*[B,N,3,3]*/, void *workspace,
+                   size_t workspace_bytes, m360_stream_t stream);
+
+/* ------------------------------------------------------------------ encodings --------- */
+
+/* 21-direction integrated positional encoding -> enc[S,42]; cov == NULL gives the plain
+ * positional encoding branch.  Replaces intern/encoding.py:33-61. */
+int m360_ipe(const float *mean /*[S,3]*/, const float *cov /*[S,3,3] or NULL*/, long S,
+             float *enc /*[S,42]*/, m360_stream_t stream);
+
+/* theta/phi view-direction encoding -> enc[B,4*(max_deg-min_deg)].
+ * Replaces intern/encoding.py:69-90. */
+int m360_viewdir_enc(const float *viewdirs /*[B,3]*/, int B, int min_deg, int max_deg, float *enc,
+                     m360_stream_t stream);
+
+/* fused: t_vals + rays (+ per-ray view-direction encoding vdenc[B,vd_ch]) -> MLP input rows
+ * feat[B*N, ld_feat] = [ipe(42) | vdenc(vd_ch) | zero pad].  No means/covs are materialised.
+ * Replaces model.py:82-88 / :167-176 minus the t sampling (fused para_rays + IPE + repeat + cat). */
+int m360_encode_features(const float *t_vals /*[B,N+1]*/, const float *origins,
+                         const float *directions, const float *radii, const float *vdenc, int vd_ch,
+                         int B, int N, float *feat, int ld_feat, void *workspace,
+                         size_t workspace_bytes, m360_stream_t stream);
+
+/* ------------------------------------------------------------------ MLP --------------- */
+
+/* zero-pad a PyTorch Linear ([n_out,k_in] weight, [n_out] bias or NULL) to [n_pad,k_pad] /
+ * [n_pad]; n_pad, k_pad multiples of 32.  The packed layout keeps k contiguous. */
+int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
+                     float *w_packed, float *b_packed, m360_stream_t stream);
+
+/* y[M,n_pad] = act(x[M,k_pad] * w_packed^T + b_packed) on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * One nn.Linear + activation of model.py:43-53 / :131-148. */
+int m360_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
+                int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t stream);
+
+/* ------------------------------------------------------------------ per-ray scans ----- */
+
+/* model.py:59-78 (prop_net.density_to_weight); density[B,N]. */
+int m360_density_to_weight(const float *t_vals /*[B,N+1]*/, const float *density,
+                           const float *dirs /*[B,3]*/, int B, int N, float *weights,
+                           m360_stream_t stream);
+
+/* intern/ray.py:12-57; bins[B,nb], weights[B,nb-1], samples[B,num_samples];
+ * u_rand[B,num_samples] uniforms for the randomized branch or NULL. */
+int m360_sorted_pdf(const float *bins, const float *weights, const float *u_rand, int B, int nb,
+                    int num_samples, float *samples, m360_stream_t stream);
+
+/* intern/ray.py:136-149: max-blur + padding + inverse-CDF -> t_new[B,N+1]. */
+int m360_resample_t(const float *t_vals /*[B,N+1]*/, const float *weights /*[B,N]*/,
+                    const float *u_rand, int B, int N, float resample_padding, float *t_new,
+                    m360_stream_t stream);
+
+/* intern/ray.py:155-191; rgb[B,N,3], density[B,N]; weights may be NULL. */
+int m360_volumetric_rendering(const float *rgb, const float *density, const float *t_vals,
+                              const float *dirs, int B, int N, int white_bkgd, float *comp_rgb,
+                              float *distance, float *acc, float *weights, m360_stream_t stream);
+
+/* float -> uint8 image quantisation.  Replaces intern/utils.py:17-20. */
+int m360_to8b(const float *x, long n, uint8_t *out, m360_stream_t stream);
+
+/* ------------------------------------------------------------------ fused stages ------ */
+
+/* last proposal layer (hidden -> 1) + softplus(raw + density_bias) + density_to_weight +
+ * resample: act[B*N, ld] is the sigmoid output of the 4th proposal layer.
+ * Replaces model.py:52 (Linear(h,1)), :92-93 and intern/ray.py:136-149. */
+int m360_prop_finish(const float *act, int ld, const float *head_w /*[k_pad]*/,
+                     const float *head_b /*[1]*/, int k_pad, float density_bias,
+                     const float *t_vals, const float *dirs, const float *u_rand, int B, int N,
+                     float resample_padding, float *weights /*[B,N]*/, float *t_new /*[B,N+1] or NULL*/,
+                     m360_stream_t stream);
+
+/* density/colour heads + activations + alpha composite: head_w[4,k_pad] rows = (density, r, g, b).
+ * Replaces model.py:150-158,180-186 and intern/ray.py:155-191. */
+int m360_nerf_finish(const float *act, int ld, const float *head_w, const float *head_b /*[4]*/,
+                     int k_pad, float density_bias, float rgb_padding, const float *t_vals,
+                     const float *dirs, int B, int N, int white_bkgd, float *comp_rgb,
+                     float *distance, float *acc, float *weights /*or NULL*/, m360_stream_t stream);
+
+/* ------------------------------------------------------------------ whole forward ----- */
+
+typedef struct {
+    const float *origins;    /* [B,3] */
+    const float *directions; /* [B,3] */
+    const float *viewdirs;   /* [B,3] */
+    const float *radii;      /* [B]   */
+    const float *near;       /* [B]   */
+    const float *far;        /* [B]   */
+} m360_rays_t; /* intern/ray.py:6 */
+
+typedef struct {
+    int in_ch;  /* 42 + 4*(viewdir_max_deg - viewdir_min_deg) */
+    int in_pad; /* in_ch rounded up to 32 */
+    int hp_pad; /* proposal width rounded up to 32 */
+    int hn_pad; /* nerf width rounded up to 32 */
+    const float *prop_w[4];   /* packed [hp_pad,in_pad], [hp_pad,hp_pad] x3 */
+    const float *prop_b[4];   /* [hp_pad] */
+    const float *prop_head_w; /* [hp_pad] */
+    const float *prop_head_b; /* [1] */
+    const float *nerf_w[8];   /* packed [hn_pad,in_pad], [hn_pad,hn_pad] x7 */
+    const float *nerf_b[8];
+    const float *nerf_head_w; /* [4,hn_pad]: final_density row, final_color rows */
+    const float *nerf_head_b; /* [4] */
+} m360_model_t; /* packed form of the state_dict of model.py:43-53,131-158 */
+
+typedef struct {
+    int num_samples;
+    int viewdir_min_deg, viewdir_max_deg;
+    int white_bkgd;
+    float density_bias, rgb_padding, resample_padding;
+} m360_hyper_t; /* ctor arguments of model.py:203-215 */
+
+typedef struct {
+    float *rgb;      /* [B,3] */
+    float *distance; /* [B]   */
+    float *acc;      /* [B]   */
+    /* optional (NULL to skip): */
+    float *t_hat;    /* [B,N+1] proposal t_vals            (model.py:94)  */
+    float *w_hat;    /* [B,N]   proposal weights           (model.py:94)  */
+    float *t_vals;   /* [B,N+1] resampled t_vals + 1e-6    (model.py:194,196) */
+    float *fine_w;   /* [B,N]   nerf weights               (model.py:193) */
+    float *s_vals;   /* [B,N+1]                            (model.py:196) */
+} m360_outputs_t;
+
+size_t m360_forward_workspace_bytes(int B, int N, const m360_model_t *model_host);
+
+/* prop_net.forward, model.py:80-94 -> out->t_hat, out->w_hat (both required).
+ * t_rand: optional uniforms [B,N+1] for randomized=True. */
+int m360_prop_forward(const m360_rays_t *rays_host, const m360_model_t *model_host,
+                      const m360_hyper_t *hyper_host, int B, const float *t_rand, float *t_hat,
+                      float *w_hat, void *workspace, size_t workspace_bytes, m360_stream_t stream);
+
+/* nerf_net.forward, model.py:163-200 (t_hat/w_hat from the proposal stage). */
+int m360_nerf_forward(const m360_rays_t *rays_host, const m360_model_t *model_host,
+                      const m360_hyper_t *hyper_host, int B, const float *t_hat, const float *w_hat,
+                      const float *u_rand, const m360_outputs_t *out_host, void *workspace,
+                      size_t workspace_bytes, m360_stream_t stream);
+
+/* mipNeRF360.forward, model.py:247-252: both stages back to back on one stream. */
+int m360_forward(const m360_rays_t *rays_host, const m360_model_t *model_host,
+                 const m360_hyper_t *hyper_host, int B, const m360_outputs_t *out_host,
+                 void *workspace, size_t workspace_bytes, m360_stream_t stream);
+
+/* ------------------------------------------------------------------ measurement ------ */
+
+/* Optional HIP-event timing of every m360_linear launch (the MFMA kernel that bounds the path),
+ * recorded on the launch stream itself.  Not part of the reference; used by bench.py's roofline.
+ * m360_prof_enable(capacity > 0) starts recording up to `capacity` launches (0 disables and frees
+ * the events); m360_prof_read() synchronises on record i's stop event (the only call in this
+ * library that blocks) and returns its duration and GEMM shape.  Single-threaded use only. */
+int m360_prof_enable(int capacity);
+int m360_prof_count(void);
+int m360_prof_reset(void);
+int m360_prof_read(int i, float *ms, long *M, int *n_pad, int *k_pad);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M360_H_ */

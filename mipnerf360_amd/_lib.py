@@ -1,0 +1,123 @@
+"""ctypes binding of libm360.so (C-ABI declared in include/m360.h).
+
+There is NO fallback: if the shared object is missing or a call fails, a
+RuntimeError is raised.  Build with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C mipnerf360_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libm360.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+M360_OK = 0
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+_f = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+class RaysStruct(C.Structure):  # m360_rays_t
+    _fields_ = [(n, _vp) for n in ("origins", "directions", "viewdirs", "radii", "near", "far")]
+
+
+class ModelStruct(C.Structure):  # m360_model_t
+    _fields_ = [("in_ch", C.c_int), ("in_pad", C.c_int), ("hp_pad", C.c_int), ("hn_pad", C.c_int),
+                ("prop_w", _vp * 4), ("prop_b", _vp * 4), ("prop_head_w", _vp), ("prop_head_b", _vp),
+                ("nerf_w", _vp * 8), ("nerf_b", _vp * 8), ("nerf_head_w", _vp), ("nerf_head_b", _vp)]
+
+
+class HyperStruct(C.Structure):  # m360_hyper_t
+    _fields_ = [("num_samples", C.c_int), ("viewdir_min_deg", C.c_int), ("viewdir_max_deg", C.c_int),
+                ("white_bkgd", C.c_int), ("density_bias", C.c_float), ("rgb_padding", C.c_float),
+                ("resample_padding", C.c_float)]
+
+
+class OutputsStruct(C.Structure):  # m360_outputs_t
+    _fields_ = [(n, _vp) for n in ("rgb", "distance", "acc", "t_hat", "w_hat", "t_vals", "fine_w", "s_vals")]
+
+
+_i, _l, _fl, _sz = C.c_int, C.c_long, C.c_float, C.c_size_t
+_P = C.POINTER
+
+# name -> (restype, argtypes); mirrors include/m360.h one to one
+SIGNATURES = {
+    "m360_version": (_i, []),
+    "m360_last_error": (C.c_char_p, []),
+    "m360_device_count": (_i, []),
+    "m360_sample_t": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "m360_g": (_i, [_vp, _l, _vp, _vp]),
+    "m360_s_to_t": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "m360_contract": (_i, [_vp, _l, _vp, _vp, _sz, _vp]),
+    "m360_t_to_s": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "m360_frustum_moments": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "m360_gaussian_to_xyz": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "m360_contract_workspace_bytes": (_sz, []),
+    "m360_gaussian_contract": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _sz, _vp]),
+    "m360_para_rays": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "m360_ipe": (_i, [_vp, _vp, _l, _vp, _vp]),
+    "m360_viewdir_enc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "m360_encode_features": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "m360_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "m360_linear": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "m360_density_to_weight": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "m360_sorted_pdf": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "m360_resample_t": (_i, [_vp, _vp, _vp, _i, _i, _fl, _vp, _vp]),
+    "m360_volumetric_rendering": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "m360_to8b": (_i, [_vp, _l, _vp, _vp]),
+    "m360_prop_finish": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _fl, _vp, _vp, _vp]),
+    "m360_nerf_finish": (_i, [_vp, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "m360_forward_workspace_bytes": (_sz, [_i, _i, _P(ModelStruct)]),
+    "m360_prop_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m360_nerf_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp,
+                               _P(OutputsStruct), _vp, _sz, _vp]),
+    "m360_prof_enable": (_i, [_i]),
+    "m360_prof_count": (_i, []),
+    "m360_prof_reset": (_i, []),
+    "m360_prof_read": (_i, [_i, _P(C.c_float), _P(C.c_long), _P(_i), _P(_i)]),
+    "m360_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _P(OutputsStruct), _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libm360.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j4"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libm360.so failed (see output above)")
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is required and there is no CPU fallback. "
+                "Build it with `make -C mipnerf360_amd/csrc` (needs hipcc, gfx950).")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().m360_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != M360_OK:
+        raise RuntimeError(f"libm360 {what} failed with code {rc}: {last_error()}")

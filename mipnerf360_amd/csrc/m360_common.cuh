@@ -1,0 +1,166 @@
+// Shared device helpers for libm360 (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/m360.h"
+
+namespace m360 {
+
+constexpr int kWave = 64;
+constexpr float kEpsG = 1e-6f;       // g(): intern/parameterization.py:18
+constexpr int kIpeDirs = 21;         // intern/encoding.py:9-30
+constexpr int kIpeCh = 2 * kIpeDirs; // 42
+
+// host-side error plumbing (m360_capi.hip)
+int fail(int code, const char *fmt, ...);
+int check_launch(const char *what);
+// optional event timing of m360_linear launches (m360_capi.hip)
+int prof_begin(hipStream_t st, long M, int n_pad, int k_pad);
+void prof_end(int idx, hipStream_t st);
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// ---- scalar math matching torch's fp32 semantics -------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// torch.nn.Softplus(beta=1, threshold=20)
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+// torch.nan_to_num default: nan -> 0, +inf -> FLT_MAX, -inf -> -FLT_MAX
+__device__ __forceinline__ float nan_to_numf_(float x) {
+    if (isnan(x)) return 0.0f;
+    if (isinf(x)) return x > 0 ? FLT_MAX : -FLT_MAX;
+    return x;
+}
+// value returned by the reference's g() on its `calls`-th application to the same tensor
+__device__ __forceinline__ float g_calls(float x, int calls) {
+    for (int i = 0; i < calls; ++i) x = x + kEpsG;
+    return 1.0f / x;
+}
+// torch.linspace(start, end, steps)[i] (symmetric two-sided evaluation, fp32 step)
+__device__ __forceinline__ float linspacef_(float start, float end, int steps, int i) {
+    if (steps <= 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
+}
+
+// ---- wave-level reductions / scans (64 lanes) ---------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+// inclusive Hillis-Steele scan in fp64: torch's CPU cumsum accumulates fp32 inputs in double
+// and rounds every prefix once, which also keeps the CDF monotone.
+__device__ __forceinline__ double wave_incl_scan_d(double v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        double n = __shfl_up(v, o, kWave);
+        if (l >= o) v += n;
+    }
+    return v;
+}
+
+// ---- frustum -> gaussian ------------------------------------------------------------------
+// intern/parameterization.py:99-107
+__device__ __forceinline__ void frustum_moments(float t0, float t1, float radius, float &t_mean,
+                                                float &t_var, float &r_var) {
+    const float mu = (t0 + t1) / 2.0f;
+    const float hw = (t1 - t0) / 2.0f;
+    const float mu2 = mu * mu, hw2 = hw * hw;
+    const float hw4 = hw2 * hw2;
+    const float den = 3.0f * mu2 + hw2;
+    t_mean = mu + (2.0f * mu * hw2) / den;
+    t_var = hw2 / 3.0f - (4.0f / 15.0f) * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));
+    r_var = (radius * radius) * (mu2 / 4.0f + (5.0f / 12.0f) * hw2 - (4.0f / 15.0f) * hw4 / den);
+}
+
+// intern/parameterization.py:44-46,55-62: mean = d t_mean, cov = t_var d d^T + r_var (I - d (d/|d|^2)^T)
+__device__ __forceinline__ void lift_to_xyz(const float d[3], float t_mean, float t_var, float r_var,
+                                            float mean[3], float cov[9]) {
+    const float mag = fmaxf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1e-10f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        mean[i] = d[i] * t_mean;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float null_ij = (i == j ? 1.0f : 0.0f) - d[i] * (d[j] / mag);
+            cov[3 * i + j] = t_var * (d[i] * d[j]) + r_var * null_ij;
+        }
+    }
+}
+
+// global contraction scale (intern/parameterization.py:23-29 applied to the whole tensor)
+__device__ __forceinline__ void contract_mean(float mean[3], float gnorm) {
+    if (gnorm <= 1.0f) return;
+    const float s = 2.0f - 1.0f / gnorm;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mean[i] = s * (mean[i] / gnorm);
+}
+
+// cov <- J cov J^T with J = d contract / dy at the (already contracted) mean y; closed form of
+// what intern/parameterization.py:76-81 obtains from autograd per sample.
+__device__ __forceinline__ void contract_cov(const float y[3], float cov[9]) {
+    const float r = sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+    if (!(r > 1.0f)) return;  // J = I
+    const float r2 = r * r;
+    const float a = 2.0f / r - 1.0f / r2;
+    const float b = 2.0f / (r2 * r2) - 2.0f / (r2 * r);
+    float J[9], M[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) J[3 * i + j] = (i == j ? a : 0.0f) + b * (y[i] * y[j]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            M[3 * i + j] = J[3 * i] * cov[j] + J[3 * i + 1] * cov[3 + j] + J[3 * i + 2] * cov[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            cov[3 * i + j] = M[3 * i] * J[3 * j] + M[3 * i + 1] * J[3 * j + 1] + M[3 * i + 2] * J[3 * j + 2];
+}
+
+// 21 unit directions, intern/encoding.py:9-30
+__device__ static const float kIpeBasis[kIpeDirs][3] = {
+    {0.8506508f, 0.f, 0.5257311f},   {0.809017f, 0.5f, 0.309017f},    {0.5257311f, 0.8506508f, 0.f},
+    {1.f, 0.f, 0.f},                 {0.809017f, 0.5f, -0.309017f},   {0.8506508f, 0.f, -0.5257311f},
+    {0.309017f, 0.809017f, -0.5f},   {0.f, 0.5257311f, -0.8506508f},  {0.5f, 0.309017f, -0.809017f},
+    {0.f, 1.f, 0.f},                 {-0.5257311f, 0.8506508f, 0.f},  {-0.309017f, 0.809017f, -0.5f},
+    {0.f, 0.5257311f, 0.8506508f},   {-0.309017f, 0.809017f, 0.5f},   {0.309017f, 0.809017f, 0.5f},
+    {0.5f, 0.309017f, 0.809017f},    {0.5f, -0.309017f, 0.809017f},   {0.f, 0.f, 1.f},
+    {-0.5f, 0.309017f, 0.809017f},   {-0.809017f, 0.5f, 0.309017f},   {-0.809017f, 0.5f, -0.309017f}};
+
+// intern/encoding.py:43-56 for one sample: out[k] = exp(-sigma_k/2) sin(gamma_k), out[21+k] = ... cos
+template <bool HAS_COV, typename Store>
+__device__ __forceinline__ void ipe_sample(const float mean[3], const float cov[9], Store &&store) {
+#pragma unroll
+    for (int k = 0; k < kIpeDirs; ++k) {
+        const float p0 = kIpeBasis[k][0], p1 = kIpeBasis[k][1], p2 = kIpeBasis[k][2];
+        const float gamma = p0 * mean[0] + p1 * mean[1] + p2 * mean[2];
+        float sn, cs;
+        sincosf(gamma, &sn, &cs);
+        if (HAS_COV) {
+            const float a0 = cov[0] * p0 + cov[1] * p1 + cov[2] * p2;
+            const float a1 = cov[3] * p0 + cov[4] * p1 + cov[5] * p2;
+            const float a2 = cov[6] * p0 + cov[7] * p1 + cov[8] * p2;
+            const float sigma = p0 * a0 + p1 * a1 + p2 * a2;
+            const float damp = expf(-0.5f * sigma);
+            sn *= damp;
+            cs *= damp;
+        }
+        store(k, sn);
+        store(kIpeDirs + k, cs);
+    }
+}
+
+}  // namespace m360

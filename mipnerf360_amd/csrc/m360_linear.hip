@@ -1,0 +1,239 @@
+// y[M,Np] = act(x[M,Kp] * W^T + b) on the CDNA4 matrix cores with exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: bitwise a k-ordered fmaf chain, 64 FLOP/clk/SIMD => 157.3 TFLOP/s).
+// This kernel carries ~100 % of the path's FLOPs (model.py:43-53 and :131-148 of the reference).
+//
+// Tiling (wave64, 8 waves = 2 per SIMD, one workgroup per CU):
+//   workgroup tile 256(M) x 256(N), K-step 32, waves arranged 2(M) x 4(N), wave tile 128 x 64
+//   = 4 x 2 MFMA tiles of 32x32 -> 128 accumulator registers per lane.
+//   A (activations, [M][K] k-contiguous) and B (PyTorch weight, [N][K] k-contiguous) tiles are
+//   staged global -> registers -> LDS with 16-byte accesses, double-buffered in LDS, ONE barrier
+//   per K-step; the global loads of step t+1 are issued before the 128 MFMAs of step t.
+//   LDS rows are padded 128 B -> 144 B so every ds_read_b128 lane group hits 16 distinct
+//   4-bank slots (conflict-free; MI355X LDS: 64 banks for b128).
+//   The K index inside each group of 8 is permuted (lane half h takes k = 8g+4h+s for MFMA
+//   step s) so one ds_read_b128 feeds four consecutive MFMAs for A and for B alike.
+//   Workgroup ids are remapped so the 4 N-tiles of one M-tile run on the same XCD (shared L2).
+#include "m360_common.cuh"
+
+namespace m360 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 256, BN = 256, BK = 32;
+constexpr int LDS_LD = BK + 4;  // floats per padded LDS row (144 B)
+constexpr int kThreads = 512;
+constexpr int TM = 4, TN = 2;   // 32x32 MFMA tiles per wave (M, N)
+
+template <int ACT>
+__device__ __forceinline__ float activate(float v) {
+    if (ACT == M360_ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == M360_ACT_SIGMOID) return sigmoidf_(v);
+    return v;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(kThreads, 2) void linear_f32_mfma_kernel(
+    const float *__restrict__ X, long M, int ldx, const float *__restrict__ W,
+    const float *__restrict__ bias, int Np, int Kp, float *__restrict__ Y, int ldy, int tiles_n) {
+    __shared__ float As[2][BM * LDS_LD];
+    __shared__ float Bs[2][BN * LDS_LD];
+
+    // ---- XCD-aware tile mapping: consecutive ids on one XCD walk the N-tiles of one M-tile
+    const long tiles_m = (M + BM - 1) / BM;
+    const long nwg = tiles_m * tiles_n;
+    long tile_m, tile_n;
+    {
+        const long bid = blockIdx.x;
+        const long full = (nwg / 8) * 8;  // ids covered by the bijective 8-way remap
+        if (bid < full) {
+            const long xcd = bid % 8, seq = bid / 8;        // seq-th workgroup of this XCD
+            const long lin = xcd * (full / 8) + seq;        // contiguous id range per XCD
+            tile_m = lin / tiles_n;
+            tile_n = lin % tiles_n;
+        } else {
+            tile_m = bid / tiles_n;
+            tile_n = bid % tiles_n;
+        }
+    }
+    const long m0 = tile_m * BM;
+    const int n0 = (int)tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // ---- global -> register staging: thread handles float4 #c4 of rows r, r+64, r+128, r+192.
+    // Uniform tile base (SGPRs) + small per-thread 32-bit offsets; tail rows are clamped (they
+    // are computed but never stored).
+    const long rows_left = M - m0;       // >= 1
+    const int cols_left = Np - n0;       // >= 1
+    const float *__restrict__ Xt = X + m0 * ldx;
+    const float *__restrict__ Wt = W + (long)n0 * Kp;
+    const int c4 = tid & 7, r0 = tid >> 3;
+    int oa[4], ob[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 64 * i;
+        const int ra = r < rows_left ? r : (int)rows_left - 1;
+        const int rb = r < cols_left ? r : cols_left - 1;
+        oa[i] = ra * ldx + 4 * c4;
+        ob[i] = rb * Kp + 4 * c4;
+    }
+    const int st_off = r0 * LDS_LD + 4 * c4;
+    const int a_off = (wm * 128 + l31) * LDS_LD + 4 * h;
+    const int b_off = (wn * 64 + l31) * LDS_LD + 4 * h;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define M360_LOAD_GLOBAL(k0)                                                   \
+    do {                                                                       \
+        ra0 = *reinterpret_cast<const float4 *>(Xt + oa[0] + (k0));            \
+        ra1 = *reinterpret_cast<const float4 *>(Xt + oa[1] + (k0));            \
+        ra2 = *reinterpret_cast<const float4 *>(Xt + oa[2] + (k0));            \
+        ra3 = *reinterpret_cast<const float4 *>(Xt + oa[3] + (k0));            \
+        rb0 = *reinterpret_cast<const float4 *>(Wt + ob[0] + (k0));            \
+        rb1 = *reinterpret_cast<const float4 *>(Wt + ob[1] + (k0));            \
+        rb2 = *reinterpret_cast<const float4 *>(Wt + ob[2] + (k0));            \
+        rb3 = *reinterpret_cast<const float4 *>(Wt + ob[3] + (k0));            \
+    } while (0)
+#define M360_STORE_LDS(buf)                                                              \
+    do {                                                                                 \
+        *reinterpret_cast<float4 *>(&As[buf][st_off]) = ra0;                             \
+        *reinterpret_cast<float4 *>(&As[buf][st_off + 64 * LDS_LD]) = ra1;               \
+        *reinterpret_cast<float4 *>(&As[buf][st_off + 128 * LDS_LD]) = ra2;              \
+        *reinterpret_cast<float4 *>(&As[buf][st_off + 192 * LDS_LD]) = ra3;              \
+        *reinterpret_cast<float4 *>(&Bs[buf][st_off]) = rb0;                             \
+        *reinterpret_cast<float4 *>(&Bs[buf][st_off + 64 * LDS_LD]) = rb1;               \
+        *reinterpret_cast<float4 *>(&Bs[buf][st_off + 128 * LDS_LD]) = rb2;              \
+        *reinterpret_cast<float4 *>(&Bs[buf][st_off + 192 * LDS_LD]) = rb3;              \
+    } while (0)
+
+    // 128 MFMAs on one staged K-step
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float *Ab = &As[buf][a_off];
+        const float *Bb = &Bs[buf][b_off];
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(Ab + i * 32 * LDS_LD + 8 * g);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4 *>(Bb + j * 32 * LDS_LD + 8 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float av = s == 0 ? a[i].x : s == 1 ? a[i].y : s == 2 ? a[i].z : a[i].w;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float bv = s == 0 ? b[j].x : s == 1 ? b[j].y : s == 2 ? b[j].z : b[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    const int ksteps = Kp / BK;
+    M360_LOAD_GLOBAL(0);
+    M360_STORE_LDS(0);
+    __syncthreads();
+    int buf = 0;
+    for (int t = 0; t < ksteps - 1; ++t) {
+        M360_LOAD_GLOBAL((t + 1) * BK);  // in flight behind the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);  // keep the issue point: hipcc otherwise sinks the loads
+        compute(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        M360_STORE_LDS(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    compute(buf);
+#undef M360_LOAD_GLOBAL
+#undef M360_STORE_LDS
+
+    // ---- epilogue: bias + activation; lane holds column (n) l31, rows (r&3)+8(r>>2)+4h
+    const bool interior = rows_left >= BM && cols_left >= BN;  // wave-uniform
+    float *__restrict__ Yt = Y + m0 * ldy + n0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * 64 + j * 32 + l31;
+        const bool col_ok = col < cols_left;
+        const float bj = col_ok ? bias[n0 + col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = wm * 128 + i * 32 + 4 * h;
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Yt[(long)(rbase + (r & 3) + 8 * (r >> 2)) * ldy + col] = activate<ACT>(acc[i][j][r] + bj);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (col_ok && row < rows_left) Yt[(long)row * ldy + col] = activate<ACT>(acc[i][j][r] + bj);
+                }
+            }
+        }
+    }
+}
+
+__global__ void pack_linear_kernel(const float *__restrict__ w, const float *__restrict__ b, int n_out,
+                                   int k_in, int n_pad, int k_pad, float *__restrict__ wp,
+                                   float *__restrict__ bp) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)n_pad * k_pad) {
+        const int n = (int)(idx / k_pad), k = (int)(idx % k_pad);
+        wp[idx] = (n < n_out && k < k_in) ? w[(long)n * k_in + k] : 0.0f;
+    }
+    if (bp != nullptr && idx < n_pad) bp[idx] = (b != nullptr && idx < n_out) ? b[idx] : 0.0f;
+}
+
+}  // namespace m360
+
+using namespace m360;
+
+extern "C" {
+
+int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
+                     float *w_packed, float *b_packed, m360_stream_t stream) {
+    if (!w || !w_packed || n_out < 1 || k_in < 1 || n_pad < n_out || k_pad < k_in)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_pack_linear: bad argument (n_out=%d k_in=%d n_pad=%d k_pad=%d)", n_out, k_in, n_pad, k_pad);
+    const long n = (long)n_pad * k_pad;
+    hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, b, n_out, k_in, n_pad, k_pad, w_packed, b_packed);
+    return check_launch("pack_linear");
+}
+
+int m360_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
+                int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t stream) {
+    if (!x || !w_packed || !b_packed || !y || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: null pointer or negative M");
+    if (n_pad < 1 || k_pad < BK || k_pad % BK != 0 || ldx < k_pad || ldy < n_pad || ldx % 4 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad (multiple of 4), ldy=%d >= n_pad=%d", k_pad, BK, ldx, ldy, n_pad);
+    if (((uintptr_t)x | (uintptr_t)w_packed) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: x and w_packed must be 16-byte aligned");
+    if (M == 0) return M360_OK;
+    const long tiles_m = (M + BM - 1) / BM;
+    const int tiles_n = (n_pad + BN - 1) / BN;
+    const long nwg = tiles_m * tiles_n;
+    if (nwg > 0x7fffffffL) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: grid too large");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)nwg), block(kThreads);
+    const int prof = prof_begin(st, M, n_pad, k_pad);
+    switch (act) {
+        case M360_ACT_NONE: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
+        case M360_ACT_RELU: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
+        case M360_ACT_SIGMOID: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
+        default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: unknown activation %d", act);
+    }
+    prof_end(prof, st);
+    return check_launch("linear");
+}
+
+}  // extern "C"

@@ -1,0 +1,414 @@
+// Per-ray kernels: transmittance scan (density -> weights), max-blur + piecewise-constant
+// inverse-CDF resampling, alpha compositing, and the two fused "stage finishers" that also
+// apply the last (hidden -> 1 / hidden -> 4) linear heads.
+//
+// Mapping: one wavefront (64 lanes) owns one ray; per-ray arrays (t, weights, cdf, ...) live
+// in that wave's private LDS slice; prefix sums are wave-level Hillis-Steele scans in fp64
+// (torch's CPU cumsum accumulates fp32 in double; this also keeps the CDF monotone) with a
+// carry across 64-sample chunks, so any N works.  All of these kernels are HBM-bound.
+#include "m360_common.cuh"
+
+namespace m360 {
+
+// intra-wave LDS ordering: slices are wave-private, so a wave-scope fence suffices
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float dir_norm(const float *__restrict__ dirs, int b) {
+    const float x = dirs[3 * b], y = dirs[3 * b + 1], z = dirs[3 * b + 2];
+    return sqrtf(x * x + y * y + z * z);
+}
+
+// model.py:71-77 / intern/ray.py:173-183: w_i = (1 - exp(-x_i)) exp(-sum_{j<i} x_j), x = rho * (dt * |d|)
+__device__ __forceinline__ void wave_weights(const float *t, const float *rho, int rho_stride,
+                                             float dnorm, int N, float *w) {
+    const int l = lane_id();
+    double carry = 0.0;
+    for (int base = 0; base < N; base += kWave) {
+        const int i = base + l;
+        float x = 0.0f;
+        if (i < N) x = rho[i * rho_stride] * ((t[i + 1] - t[i]) * dnorm);
+        const double incl = wave_incl_scan_d((double)x);
+        const float excl = (float)(carry + incl - (double)x);
+        if (i < N) w[i] = (1.0f - expf(-x)) * expf(-excl);
+        carry += __shfl(incl, kWave - 1, kWave);
+    }
+}
+
+// intern/ray.py:137-142: replicate-pad, pairwise max, pairwise mean, + padding
+__device__ __forceinline__ void wave_blur(const float *w, int N, float padding, float *out) {
+    for (int i = lane_id(); i < N; i += kWave) {
+        const float c = w[i];
+        const float lo = fmaxf(w[i > 0 ? i - 1 : 0], c);
+        const float hi = fmaxf(c, w[i < N - 1 ? i + 1 : N - 1]);
+        out[i] = 0.5f * (lo + hi) + padding;
+    }
+}
+
+// intern/ray.py:12-57.  bins[nb] and w[nb-1] in LDS (w is overwritten), cdf[nb] LDS scratch.
+__device__ __forceinline__ void wave_sorted_pdf(const float *bins, float *w, float *cdf, int nb, int ns,
+                                                const float *__restrict__ u_rand_row,
+                                                float *__restrict__ out_row) {
+    const int l = lane_id();
+    const int nw = nb - 1;
+    float part = 0.0f;
+    for (int i = l; i < nw; i += kWave) part += w[i];
+    float wsum = wave_sum(part);
+    const float pad = fmaxf(0.0f, 1e-5f - wsum);
+    const float padw = pad / (float)nw;
+    wsum = wsum + pad;
+    // cdf[0] = 0, cdf[i+1] = min(1, cumsum(pdf)[i]) for i < nw-1, cdf[nw] = 1
+    double carry = 0.0;
+    for (int base = 0; base < nw - 1; base += kWave) {
+        const int i = base + l;
+        float pdf = 0.0f;
+        if (i < nw - 1) pdf = (w[i] + padw) / wsum;
+        const double incl = wave_incl_scan_d((double)pdf);
+        if (i < nw - 1) cdf[i + 1] = fminf(1.0f, (float)(carry + incl));
+        carry += __shfl(incl, kWave - 1, kWave);
+    }
+    if (l == 0) {
+        cdf[0] = 0.0f;
+        cdf[nw] = 1.0f;
+    }
+    wave_sync();
+    const float f32eps = 1.1920928955078125e-07f;
+    const float umax = 1.0f - f32eps;
+    for (int j = l; j < ns; j += kWave) {
+        float u;
+        if (u_rand_row == nullptr) {
+            u = linspacef_(0.0f, umax, ns, j);
+        } else {  // intern/ray.py:30-35, including the `u + u` doubling
+            const float s = 1.0f / (float)ns;
+            const float base = (float)j * s;
+            u = fminf(base + base + u_rand_row[j] * (s - f32eps), umax);
+        }
+        // last index i with cdf[i] <= u  (cdf[0] = 0 <= u always)
+        int lo = 0, hi = nb;  // invariant: cdf[lo] <= u, (hi == nb or cdf[hi] > u)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u) lo = mid; else hi = mid;
+        }
+        const int i0 = lo, i1 = lo + 1 < nb ? lo + 1 : nb - 1;
+        const float c0 = cdf[i0], c1 = cdf[i1];
+        const float b0 = bins[i0], b1 = bins[i1];
+        float tt = nan_to_numf_((u - c0) / (c1 - c0));
+        tt = fminf(fmaxf(tt, 0.0f), 1.0f);
+        out_row[j] = b0 + tt * (b1 - b0);
+    }
+}
+
+struct Composite { float r, g, b, dist, acc; };
+
+// intern/ray.py:171-191 given per-sample rgb (LDS, stride 3 floats starting at rgb[0]) and weights w (LDS)
+__device__ __forceinline__ Composite wave_composite(const float *t, const float *w, const float *rgb,
+                                                    int rgb_stride, int N, bool white_bkgd) {
+    float sr = 0, sg = 0, sb = 0, sa = 0, sd = 0;
+    for (int i = lane_id(); i < N; i += kWave) {
+        const float wi = w[i];
+        sr += wi * rgb[i * rgb_stride + 0];
+        sg += wi * rgb[i * rgb_stride + 1];
+        sb += wi * rgb[i * rgb_stride + 2];
+        sa += wi;
+        sd += wi * (0.5f * (t[i] + t[i + 1]));
+    }
+    Composite c;
+    c.r = wave_sum(sr);
+    c.g = wave_sum(sg);
+    c.b = wave_sum(sb);
+    c.acc = wave_sum(sa);
+    const float d = nan_to_numf_(wave_sum(sd) / c.acc);
+    c.dist = fminf(fmaxf(d, t[0]), t[N]);
+    if (white_bkgd) {
+        const float bg = 1.0f - c.acc;
+        c.r += bg;
+        c.g += bg;
+        c.b += bg;
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// standalone per-ray kernels: 4 waves / block, one ray per wave
+constexpr int kRayWaves = 4;
+
+__global__ __launch_bounds__(kRayWaves *kWave) void density_to_weight_kernel(
+    const float *__restrict__ t_vals, const float *__restrict__ density,
+    const float *__restrict__ dirs, int B, int N, float *__restrict__ weights) {
+    extern __shared__ float smem[];
+    const int wave = threadIdx.x >> 6, l = lane_id();
+    const int b = blockIdx.x * kRayWaves + wave;
+    if (b >= B) return;
+    float *t = smem + wave * (3 * N + 1), *rho = t + N + 1, *w = rho + N;
+    for (int i = l; i <= N; i += kWave) t[i] = t_vals[(long)b * (N + 1) + i];
+    for (int i = l; i < N; i += kWave) rho[i] = density[(long)b * N + i];
+    wave_sync();
+    wave_weights(t, rho, 1, dir_norm(dirs, b), N, w);
+    wave_sync();
+    for (int i = l; i < N; i += kWave) weights[(long)b * N + i] = w[i];
+}
+
+template <bool BLUR>
+__global__ __launch_bounds__(kRayWaves *kWave) void resample_kernel(
+    const float *__restrict__ bins_g, const float *__restrict__ weights_g,
+    const float *__restrict__ u_rand, int B, int nb, int ns, float padding,
+    float *__restrict__ samples) {
+    extern __shared__ float smem[];
+    const int wave = threadIdx.x >> 6, l = lane_id();
+    const int b = blockIdx.x * kRayWaves + wave;
+    if (b >= B) return;
+    const int nw = nb - 1;
+    float *bins = smem + wave * (4 * nb), *w = bins + nb, *w2 = w + nb, *cdf = w2 + nb;
+    for (int i = l; i < nb; i += kWave) bins[i] = bins_g[(long)b * nb + i];
+    for (int i = l; i < nw; i += kWave) w[i] = weights_g[(long)b * nw + i];
+    wave_sync();
+    float *wsrc = w;
+    if (BLUR) {
+        wave_blur(w, nw, padding, w2);
+        wave_sync();
+        wsrc = w2;
+    }
+    wave_sorted_pdf(bins, wsrc, cdf, nb, ns, u_rand ? u_rand + (long)b * ns : nullptr,
+                    samples + (long)b * ns);
+}
+
+__global__ __launch_bounds__(kRayWaves *kWave) void volumetric_rendering_kernel(
+    const float *__restrict__ rgb_g, const float *__restrict__ density,
+    const float *__restrict__ t_vals, const float *__restrict__ dirs, int B, int N, int white_bkgd,
+    float *__restrict__ comp_rgb, float *__restrict__ distance, float *__restrict__ acc,
+    float *__restrict__ weights) {
+    extern __shared__ float smem[];
+    const int wave = threadIdx.x >> 6, l = lane_id();
+    const int b = blockIdx.x * kRayWaves + wave;
+    if (b >= B) return;
+    float *t = smem + wave * (6 * N + 1), *rho = t + N + 1, *w = rho + N, *rgb = w + N;
+    for (int i = l; i <= N; i += kWave) t[i] = t_vals[(long)b * (N + 1) + i];
+    for (int i = l; i < N; i += kWave) rho[i] = density[(long)b * N + i];
+    for (int i = l; i < 3 * N; i += kWave) rgb[i] = rgb_g[(long)b * 3 * N + i];
+    wave_sync();
+    wave_weights(t, rho, 1, dir_norm(dirs, b), N, w);
+    wave_sync();
+    const Composite c = wave_composite(t, w, rgb, 3, N, white_bkgd != 0);
+    if (l == 0) {
+        comp_rgb[3 * b] = c.r;
+        comp_rgb[3 * b + 1] = c.g;
+        comp_rgb[3 * b + 2] = c.b;
+        distance[b] = c.dist;
+        acc[b] = c.acc;
+    }
+    if (weights != nullptr)
+        for (int i = l; i < N; i += kWave) weights[(long)b * N + i] = w[i];
+}
+
+// intern/utils.py:17-20
+__global__ void to8b_kernel(const float *__restrict__ x, long n, uint8_t *__restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float v = fminf(fmaxf(nan_to_numf_(x[idx]), 0.0f), 1.0f);
+    out[idx] = (uint8_t)(255.0f * v);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused stage finishers: one 256-thread workgroup per ray.  Phase 1: the 4 waves stream the
+// ray's N activation rows (k_pad floats each, 16 B per lane, fully coalesced) and reduce the
+// H head dot-products per row; head weights sit in LDS.  Phase 2: wave 0 runs the scans.
+constexpr int kFinishThreads = 256;
+
+template <int H>
+__device__ __forceinline__ void head_dots(const float *__restrict__ act_ray, int ld,
+                                          const float *hw /*LDS [H][k_pad]*/,
+                                          const float *__restrict__ hb, int k_pad, int N,
+                                          float *raw /*LDS [N][H]*/) {
+    const int wave = threadIdx.x >> 6, l = lane_id();
+    const int nwaves = blockDim.x >> 6;
+    const int k4 = k_pad >> 2;
+    float bias[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) bias[h] = hb[h];
+    for (int n = wave; n < N; n += 2 * nwaves) {
+        const int n2 = n + nwaves;
+        const bool has2 = n2 < N;
+        const float4 *x1 = reinterpret_cast<const float4 *>(act_ray + (long)n * ld);
+        const float4 *x2 = reinterpret_cast<const float4 *>(act_ray + (long)(has2 ? n2 : n) * ld);
+        float a1[H], a2[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) a1[h] = a2[h] = 0.0f;
+        for (int c = l; c < k4; c += kWave) {
+            const float4 v1 = x1[c], v2 = x2[c];
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float4 w = reinterpret_cast<const float4 *>(hw + h * k_pad)[c];
+                a1[h] += v1.x * w.x + v1.y * w.y + v1.z * w.z + v1.w * w.w;
+                a2[h] += v2.x * w.x + v2.y * w.y + v2.z * w.z + v2.w * w.w;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            a1[h] = wave_sum(a1[h]);
+            a2[h] = wave_sum(a2[h]);
+        }
+        if (l == 0) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                raw[n * H + h] = a1[h] + bias[h];
+                if (has2) raw[n2 * H + h] = a2[h] + bias[h];
+            }
+        }
+    }
+}
+
+// model.py:52,92-93 + intern/ray.py:136-149
+__global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
+    const float *__restrict__ act, int ld, const float *__restrict__ head_w,
+    const float *__restrict__ head_b, int k_pad, float density_bias, const float *__restrict__ t_vals,
+    const float *__restrict__ dirs, const float *__restrict__ u_rand, int N, float padding,
+    float *__restrict__ weights, float *__restrict__ t_new) {
+    extern __shared__ float smem[];
+    const int b = blockIdx.x, l = lane_id();
+    const int nb = N + 1;
+    float *hw = smem, *t = hw + k_pad, *rho = t + nb, *w = rho + nb, *w2 = w + nb, *cdf = w2 + nb;
+    for (int i = threadIdx.x; i < k_pad; i += blockDim.x) hw[i] = head_w[i];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
+    __syncthreads();
+    head_dots<1>(act + (long)b * N * ld, ld, hw, head_b, k_pad, N, rho);
+    __syncthreads();
+    if (threadIdx.x >= kWave) return;
+    for (int i = l; i < N; i += kWave) rho[i] = softplusf_(rho[i] + density_bias);
+    wave_sync();
+    wave_weights(t, rho, 1, dir_norm(dirs, b), N, w);
+    wave_sync();
+    for (int i = l; i < N; i += kWave) weights[(long)b * N + i] = w[i];
+    if (t_new == nullptr) return;
+    wave_blur(w, N, padding, w2);
+    wave_sync();
+    wave_sorted_pdf(t, w2, cdf, nb, nb, u_rand ? u_rand + (long)b * nb : nullptr, t_new + (long)b * nb);
+}
+
+// model.py:150-158,180-186 + intern/ray.py:155-191
+__global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
+    const float *__restrict__ act, int ld, const float *__restrict__ head_w,
+    const float *__restrict__ head_b, int k_pad, float density_bias, float rgb_padding,
+    const float *__restrict__ t_vals, const float *__restrict__ dirs, int N, int white_bkgd,
+    float *__restrict__ comp_rgb, float *__restrict__ distance, float *__restrict__ acc,
+    float *__restrict__ weights) {
+    extern __shared__ float smem[];
+    const int b = blockIdx.x, l = lane_id();
+    const int nb = N + 1;
+    float *hw = smem, *t = hw + 4 * k_pad, *raw = t + nb, *w = raw + 4 * N;
+    for (int i = threadIdx.x; i < 4 * k_pad; i += blockDim.x) hw[i] = head_w[i];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
+    __syncthreads();
+    head_dots<4>(act + (long)b * N * ld, ld, hw, head_b, k_pad, N, raw);
+    __syncthreads();
+    if (threadIdx.x >= kWave) return;
+    for (int i = l; i < N; i += kWave) {
+        raw[4 * i] = softplusf_(sigmoidf_(raw[4 * i]) + density_bias);
+#pragma unroll
+        for (int c = 1; c < 4; ++c)
+            raw[4 * i + c] = sigmoidf_(raw[4 * i + c]) * (1.0f + 2.0f * rgb_padding) - rgb_padding;
+    }
+    wave_sync();
+    wave_weights(t, raw, 4, dir_norm(dirs, b), N, w);
+    wave_sync();
+    const Composite c = wave_composite(t, w, raw + 1, 4, N, white_bkgd != 0);
+    if (l == 0) {
+        comp_rgb[3 * b] = c.r;
+        comp_rgb[3 * b + 1] = c.g;
+        comp_rgb[3 * b + 2] = c.b;
+        distance[b] = c.dist;
+        acc[b] = c.acc;
+    }
+    if (weights != nullptr)
+        for (int i = l; i < N; i += kWave) weights[(long)b * N + i] = w[i];
+}
+
+}  // namespace m360
+
+// =========================================================================================
+using namespace m360;
+
+static inline hipStream_t S_(m360_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static constexpr size_t kMaxDynLds = 64 * 1024;
+
+extern "C" {
+
+int m360_density_to_weight(const float *t_vals, const float *density, const float *dirs, int B, int N,
+                           float *weights, m360_stream_t stream) {
+    if (!t_vals || !density || !dirs || !weights || B < 0 || N < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_density_to_weight: bad argument");
+    if (B == 0) return M360_OK;
+    const size_t lds = (size_t)kRayWaves * (3 * N + 1) * sizeof(float);
+    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_density_to_weight: N=%d too large for LDS", N);
+    hipLaunchKernelGGL(density_to_weight_kernel, dim3((B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * kWave), lds, S_(stream), t_vals, density, dirs, B, N, weights);
+    return check_launch("density_to_weight");
+}
+
+int m360_sorted_pdf(const float *bins, const float *weights, const float *u_rand, int B, int nb,
+                    int num_samples, float *samples, m360_stream_t stream) {
+    if (!bins || !weights || !samples || B < 0 || nb < 2 || num_samples < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_sorted_pdf: bad argument");
+    if (B == 0) return M360_OK;
+    const size_t lds = (size_t)kRayWaves * 4 * nb * sizeof(float);
+    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_sorted_pdf: nb=%d too large for LDS", nb);
+    hipLaunchKernelGGL(resample_kernel<false>, dim3((B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * kWave), lds, S_(stream), bins, weights, u_rand, B, nb, num_samples, 0.0f, samples);
+    return check_launch("sorted_pdf");
+}
+
+int m360_resample_t(const float *t_vals, const float *weights, const float *u_rand, int B, int N,
+                    float resample_padding, float *t_new, m360_stream_t stream) {
+    if (!t_vals || !weights || !t_new || B < 0 || N < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_resample_t: bad argument");
+    if (B == 0) return M360_OK;
+    const int nb = N + 1;
+    const size_t lds = (size_t)kRayWaves * 4 * nb * sizeof(float);
+    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_resample_t: N=%d too large for LDS", N);
+    hipLaunchKernelGGL(resample_kernel<true>, dim3((B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * kWave), lds, S_(stream), t_vals, weights, u_rand, B, nb, nb, resample_padding, t_new);
+    return check_launch("resample_t");
+}
+
+int m360_volumetric_rendering(const float *rgb, const float *density, const float *t_vals,
+                              const float *dirs, int B, int N, int white_bkgd, float *comp_rgb,
+                              float *distance, float *acc, float *weights, m360_stream_t stream) {
+    if (!rgb || !density || !t_vals || !dirs || !comp_rgb || !distance || !acc || B < 0 || N < 1)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_volumetric_rendering: bad argument");
+    if (B == 0) return M360_OK;
+    const size_t lds = (size_t)kRayWaves * (6 * N + 1) * sizeof(float);
+    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_volumetric_rendering: N=%d too large for LDS", N);
+    hipLaunchKernelGGL(volumetric_rendering_kernel, dim3((B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * kWave), lds, S_(stream), rgb, density, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights);
+    return check_launch("volumetric_rendering");
+}
+
+int m360_to8b(const float *x, long n, uint8_t *out, m360_stream_t stream) {
+    if (!x || !out || n < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_to8b: bad argument");
+    if (n == 0) return M360_OK;
+    hipLaunchKernelGGL(to8b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), x, n, out);
+    return check_launch("to8b");
+}
+
+int m360_prop_finish(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
+                     float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
+                     int B, int N, float resample_padding, float *weights, float *t_new,
+                     m360_stream_t stream) {
+    if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < 4 || k_pad % 4 != 0 || ld < k_pad || ld % 4 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: bad argument");
+    if (B == 0) return M360_OK;
+    const size_t lds = ((size_t)k_pad + 5 * (N + 1)) * sizeof(float);
+    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
+    hipLaunchKernelGGL(prop_finish_kernel, dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, resample_padding, weights, t_new);
+    return check_launch("prop_finish");
+}
+
+int m360_nerf_finish(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
+                     float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
+                     int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
+                     m360_stream_t stream) {
+    if (!act || !head_w || !head_b || !t_vals || !dirs || !comp_rgb || !distance || !acc || B < 0 || N < 1 || k_pad < 4 || k_pad % 4 != 0 || ld < k_pad || ld % 4 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: bad argument");
+    if (B == 0) return M360_OK;
+    const size_t lds = ((size_t)4 * k_pad + (N + 1) + 5 * N) * sizeof(float);
+    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
+    hipLaunchKernelGGL(nerf_finish_kernel, dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
+    return check_launch("nerf_finish");
+}
+
+}  // extern "C"

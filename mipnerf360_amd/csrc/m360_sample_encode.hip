@@ -1,0 +1,441 @@
+// Sampling, conical-frustum gaussians, the reference's whole-tensor "contraction" and the
+// encodings.  All kernels here are HBM/VALU-bound elementwise or
+// reduction kernels: one thread per sample, coalesced SoA ray loads, LDS-staged feature rows.
+#include "m360_common.cuh"
+
+namespace m360 {
+
+constexpr int kNormPartials = 1024;  // fixed partition => deterministic reduction order
+
+struct NormScratch {  // layout of the contraction workspace
+    double partial[kNormPartials];
+    float gnorm;  // Frobenius norm of the un-contracted means
+    float pad[15];
+};
+
+// ------------------------------------------------------------------------------------------
+// intern/ray.py:99-110
+__global__ void sample_t_kernel(const float *__restrict__ near, const float *__restrict__ far,
+                                const float *__restrict__ t_rand, int B, int N,
+                                float *__restrict__ t_vals) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = N + 1;
+    if (idx >= (long)B * M) return;
+    const int b = (int)(idx / M), i = (int)(idx % M);
+    const float gf = 1.0f / (far[b] + kEpsG), gn = 1.0f / (near[b] + kEpsG);
+    auto t_at = [&](int j) {
+        const float s = linspacef_(0.0f, 1.0f, M, j);
+        const float mix = s * gf + (1.0f - s) * gn;
+        return 1.0f / (mix + kEpsG);
+    };
+    float t = t_at(i);
+    if (t_rand != nullptr) {  // intern/ray.py:103-108
+        const float lower = (i == 0) ? t : 0.5f * (t + t_at(i - 1));
+        const float upper = (i == N) ? t : 0.5f * (t_at(i + 1) + t);
+        t = lower + (upper - lower) * t_rand[idx];
+    }
+    t_vals[idx] = t;
+}
+
+// intern/parameterization.py:5-8 as called from model.py:196
+__global__ void t_to_s_kernel(const float *__restrict__ t_vals, const float *__restrict__ near,
+                              const float *__restrict__ far, int B, int M, int near_calls,
+                              int far_calls, float *__restrict__ s_vals) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * M) return;
+    const int b = (int)(idx / M);
+    const float gt = 1.0f / (t_vals[idx] + kEpsG);
+    const float gn1 = g_calls(near[b], near_calls + 1);
+    const float gf = g_calls(far[b], far_calls + 1);
+    const float gn2 = g_calls(near[b], near_calls + 2);
+    s_vals[idx] = (gt - gn1) / (gf - gn2);
+}
+
+__global__ void g_kernel(const float *__restrict__ x, long n, float *__restrict__ y) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) y[idx] = 1.0f / (x[idx] + kEpsG);
+}
+
+// intern/parameterization.py:10-13
+__global__ void s_to_t_kernel(const float *__restrict__ s_vals, const float *__restrict__ near,
+                              const float *__restrict__ far, int B, int M, float *__restrict__ t_vals) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * M) return;
+    const int b = (int)(idx / M);
+    const float s = s_vals[idx];
+    const float gf = 1.0f / (far[b] + kEpsG), gn = 1.0f / (near[b] + kEpsG);
+    const float mix = s * gf + (1.0f - s) * gn;
+    t_vals[idx] = 1.0f / (mix + kEpsG);
+}
+
+__global__ void contract_vec_kernel(const float *__restrict__ x, long n, const NormScratch *__restrict__ ws,
+                                    float *__restrict__ y) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float gn = ws->gnorm;
+    y[idx] = gn <= 1.0f ? x[idx] : (2.0f - 1.0f / gn) * (x[idx] / gn);
+}
+
+__global__ void frustum_moments_kernel(const float *__restrict__ t0, const float *__restrict__ t1,
+                                       const float *__restrict__ radii, int B, int N,
+                                       float *__restrict__ t_mean, float *__restrict__ t_var,
+                                       float *__restrict__ r_var) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * N) return;
+    const int b = (int)(idx / N);
+    float tm, tv, rv;
+    frustum_moments(t0[idx], t1[idx], radii[b], tm, tv, rv);
+    t_mean[idx] = tm;
+    t_var[idx] = tv;
+    r_var[idx] = rv;
+}
+
+__global__ void gaussian_to_xyz_kernel(const float *__restrict__ d, const float *__restrict__ t_mean,
+                                       const float *__restrict__ t_var,
+                                       const float *__restrict__ r_var, int B, int N,
+                                       float *__restrict__ mean, float *__restrict__ cov) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * N) return;
+    const int b = (int)(idx / N);
+    const float dd[3] = {d[3 * b], d[3 * b + 1], d[3 * b + 2]};
+    float m[3], c[9];
+    lift_to_xyz(dd, t_mean[idx], t_var[idx], r_var[idx], m, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mean[3 * idx + i] = m[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cov[9 * idx + i] = c[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// Whole-tensor Frobenius norm, two deterministic passes (fixed partition, fp64 partials).
+__device__ __forceinline__ void block_store_partial(double v, double *__restrict__ partial) {
+    __shared__ double red[8];
+    v = wave_sum_d(v);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        partial[blockIdx.x] = s;
+    }
+}
+
+// sum of squares of mean = d * t_mean straight from t_vals (no means materialised)
+__global__ __launch_bounds__(256) void norm_partial_from_t_kernel(
+    const float *__restrict__ t_vals, const float *__restrict__ directions,
+    const float *__restrict__ radii, int B, int N, NormScratch *__restrict__ ws) {
+    const long S = (long)B * N;
+    double acc = 0.0;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < S;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / N), n = (int)(idx % N);
+        const float t0 = t_vals[(long)b * (N + 1) + n], t1 = t_vals[(long)b * (N + 1) + n + 1];
+        float tm, tv, rv;
+        frustum_moments(t0, t1, radii[b], tm, tv, rv);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float m = directions[3 * b + i] * tm;
+            acc += (double)m * (double)m;
+        }
+    }
+    block_store_partial(acc, ws->partial);
+}
+
+__global__ __launch_bounds__(256) void norm_partial_from_mean_kernel(const float *__restrict__ mean,
+                                                                      long count,
+                                                                      NormScratch *__restrict__ ws) {
+    double acc = 0.0;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < count;
+         idx += (long)gridDim.x * blockDim.x) {
+        const float m = mean[idx];
+        acc += (double)m * (double)m;
+    }
+    block_store_partial(acc, ws->partial);
+}
+
+__global__ __launch_bounds__(256) void norm_final_kernel(NormScratch *__restrict__ ws, int nparts) {
+    __shared__ double red[4];
+    double v = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += blockDim.x) v += ws->partial[p];
+    v = wave_sum_d(v);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) ws->gnorm = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+}
+
+// intern/parameterization.py:64-83 on materialised tensors
+__global__ void contract_apply_kernel(const float *__restrict__ mean_in,
+                                      const float *__restrict__ cov_in, long S,
+                                      const NormScratch *__restrict__ ws,
+                                      float *__restrict__ mean_out, float *__restrict__ cov_out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S) return;
+    float m[3], c[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) m[i] = mean_in[3 * idx + i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c[i] = cov_in[9 * idx + i];
+    contract_mean(m, ws->gnorm);
+    contract_cov(m, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mean_out[3 * idx + i] = m[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cov_out[9 * idx + i] = c[i];
+}
+
+// one sample: t interval + ray -> contracted gaussian (+ origin), intern/parameterization.py:119-135
+__device__ __forceinline__ void sample_gaussian(const float *__restrict__ t_vals,
+                                                const float *__restrict__ origins,
+                                                const float *__restrict__ directions,
+                                                const float *__restrict__ radii, int N, int b, int n,
+                                                float gnorm, float mean[3], float cov[9]) {
+    const float t0 = t_vals[(long)b * (N + 1) + n], t1 = t_vals[(long)b * (N + 1) + n + 1];
+    float tm, tv, rv;
+    frustum_moments(t0, t1, radii[b], tm, tv, rv);
+    const float d[3] = {directions[3 * b], directions[3 * b + 1], directions[3 * b + 2]};
+    lift_to_xyz(d, tm, tv, rv, mean, cov);
+    contract_mean(mean, gnorm);
+    contract_cov(mean, cov);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mean[i] = mean[i] + origins[3 * b + i];
+}
+
+__global__ void para_rays_kernel(const float *__restrict__ t_vals, const float *__restrict__ origins,
+                                 const float *__restrict__ directions,
+                                 const float *__restrict__ radii, int B, int N,
+                                 const NormScratch *__restrict__ ws, float *__restrict__ means,
+                                 float *__restrict__ covs) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * N) return;
+    float m[3], c[9];
+    sample_gaussian(t_vals, origins, directions, radii, N, (int)(idx / N), (int)(idx % N), ws->gnorm,
+                    m, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) means[3 * idx + i] = m[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) covs[9 * idx + i] = c[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// intern/encoding.py:33-61
+template <bool HAS_COV>
+__global__ void ipe_kernel(const float *__restrict__ mean, const float *__restrict__ cov, long S,
+                           float *__restrict__ enc) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S) return;
+    float m[3], c[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) m[i] = mean[3 * idx + i];
+    if (HAS_COV) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c[i] = cov[9 * idx + i];
+    }
+    float *row = enc + idx * kIpeCh;
+    ipe_sample<HAS_COV>(m, c, [&](int k, float v) { row[k] = v; });
+}
+
+// intern/encoding.py:69-90: theta = acos(z), phi = atan(y / (x + 1e-6)); [sin th, cos th, sin ph, cos ph]
+__global__ void viewdir_enc_kernel(const float *__restrict__ viewdirs, int B, int min_deg, int L,
+                                   float *__restrict__ enc) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float x = viewdirs[3 * b], y = viewdirs[3 * b + 1], z = viewdirs[3 * b + 2];
+    const float theta = acosf(z);
+    const float phi = atanf(y / (x + 1e-6f));
+    float *row = enc + (long)b * 4 * L;
+    for (int i = 0; i < L; ++i) {
+        const float sc = ldexpf(1.0f, min_deg + i);
+        float s, c;
+        sincosf(sc * theta, &s, &c);
+        row[i] = s;
+        row[L + i] = c;
+        sincosf(sc * phi, &s, &c);
+        row[2 * L + i] = s;
+        row[3 * L + i] = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused para_rays + IPE + view-direction repeat + concat -> MLP input rows.
+// One thread per sample; each block stages its 128 x ld_feat tile in LDS (row stride ld+1 =>
+// conflict-free per-row writes) and streams it out as whole 16-byte-per-lane coalesced stores.
+constexpr int kEncThreads = 128;
+
+__global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
+    const float *__restrict__ t_vals, const float *__restrict__ origins,
+    const float *__restrict__ directions, const float *__restrict__ radii,
+    const float *__restrict__ vdenc, int vd_ch, int B, int N, const NormScratch *__restrict__ ws,
+    float *__restrict__ feat, int ld) {
+    extern __shared__ float tile[];  // [kEncThreads][ld + 1]
+    const long S = (long)B * N;
+    const long s0 = (long)blockIdx.x * kEncThreads;
+    const long idx = s0 + threadIdx.x;
+    const int lds_ld = ld + 1;
+    float *row = tile + threadIdx.x * lds_ld;
+    if (idx < S) {
+        const int b = (int)(idx / N), n = (int)(idx % N);
+        float m[3], c[9];
+        sample_gaussian(t_vals, origins, directions, radii, N, b, n, ws->gnorm, m, c);
+        ipe_sample<true>(m, c, [&](int k, float v) { row[k] = v; });
+        for (int k = 0; k < vd_ch; ++k) row[kIpeCh + k] = vdenc[(long)b * vd_ch + k];
+        for (int k = kIpeCh + vd_ch; k < ld; ++k) row[k] = 0.0f;
+    }
+    __syncthreads();
+    const long rows = (S - s0 < kEncThreads) ? (S - s0) : kEncThreads;
+    const long total4 = rows * ld / 4;  // ld is a multiple of 32
+    float4 *out = reinterpret_cast<float4 *>(feat + s0 * ld);
+    for (long q = threadIdx.x; q < total4; q += kEncThreads) {
+        const int r = (int)((q * 4) / ld), col = (int)((q * 4) % ld);
+        const float *src = tile + r * lds_ld + col;
+        out[q] = make_float4(src[0], src[1], src[2], src[3]);
+    }
+}
+
+}  // namespace m360
+
+// =========================================================================================
+using namespace m360;
+
+static inline hipStream_t S_(m360_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline unsigned blocks_for(long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+extern "C" {
+
+int m360_sample_t(const float *near, const float *far, const float *t_rand, int B, int N,
+                  float *t_vals, m360_stream_t stream) {
+    if (!near || !far || !t_vals || B < 0 || N < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_sample_t: bad argument (B=%d N=%d)", B, N);
+    if (B == 0) return M360_OK;
+    const long n = (long)B * (N + 1);
+    hipLaunchKernelGGL(sample_t_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_(stream), near, far, t_rand, B, N, t_vals);
+    return check_launch("sample_t");
+}
+
+int m360_t_to_s(const float *t_vals, const float *near, const float *far, int B, int M,
+                int near_calls, int far_calls, float *s_vals, m360_stream_t stream) {
+    if (!t_vals || !near || !far || !s_vals || B < 0 || M < 1 || near_calls < 0 || far_calls < 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_t_to_s: bad argument");
+    if (B == 0) return M360_OK;
+    hipLaunchKernelGGL(t_to_s_kernel, dim3(blocks_for((long)B * M, 256)), dim3(256), 0, S_(stream), t_vals, near, far, B, M, near_calls, far_calls, s_vals);
+    return check_launch("t_to_s");
+}
+
+int m360_g(const float *x, long n, float *y, m360_stream_t stream) {
+    if (!x || !y || n < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_g: bad argument");
+    if (n == 0) return M360_OK;
+    hipLaunchKernelGGL(g_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_(stream), x, n, y);
+    return check_launch("g");
+}
+
+int m360_s_to_t(const float *s_vals, const float *near, const float *far, int B, int M, float *t_vals,
+                m360_stream_t stream) {
+    if (!s_vals || !near || !far || !t_vals || B < 0 || M < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_s_to_t: bad argument");
+    if (B == 0) return M360_OK;
+    hipLaunchKernelGGL(s_to_t_kernel, dim3(blocks_for((long)B * M, 256)), dim3(256), 0, S_(stream), s_vals, near, far, B, M, t_vals);
+    return check_launch("s_to_t");
+}
+
+int m360_frustum_moments(const float *t0, const float *t1, const float *radii, int B, int N,
+                         float *t_mean, float *t_var, float *r_var, m360_stream_t stream) {
+    if (!t0 || !t1 || !radii || !t_mean || !t_var || !r_var || B < 0 || N < 1)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_frustum_moments: bad argument");
+    if (B == 0) return M360_OK;
+    hipLaunchKernelGGL(frustum_moments_kernel, dim3(blocks_for((long)B * N, 256)), dim3(256), 0, S_(stream), t0, t1, radii, B, N, t_mean, t_var, r_var);
+    return check_launch("frustum_moments");
+}
+
+int m360_gaussian_to_xyz(const float *d, const float *t_mean, const float *t_var, const float *r_var,
+                         int B, int N, float *mean, float *cov, m360_stream_t stream) {
+    if (!d || !t_mean || !t_var || !r_var || !mean || !cov || B < 0 || N < 1)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_gaussian_to_xyz: bad argument");
+    if (B == 0) return M360_OK;
+    hipLaunchKernelGGL(gaussian_to_xyz_kernel, dim3(blocks_for((long)B * N, 256)), dim3(256), 0, S_(stream), d, t_mean, t_var, r_var, B, N, mean, cov);
+    return check_launch("gaussian_to_xyz");
+}
+
+size_t m360_contract_workspace_bytes(void) { return sizeof(NormScratch); }
+
+static int norm_parts(long work) {
+    long p = (work + 255) / 256;
+    return (int)(p < 1 ? 1 : (p > kNormPartials ? kNormPartials : p));
+}
+
+int m360_contract(const float *x, long n, float *y, void *workspace, size_t workspace_bytes,
+                  m360_stream_t stream) {
+    if (!x || !y || n < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_contract: bad argument");
+    if (!workspace || workspace_bytes < sizeof(NormScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_contract: workspace %zu < %zu", workspace_bytes, sizeof(NormScratch));
+    if (n == 0) return M360_OK;
+    NormScratch *ws = static_cast<NormScratch *>(workspace);
+    const int parts = norm_parts(n);
+    hipLaunchKernelGGL(norm_partial_from_mean_kernel, dim3(parts), dim3(256), 0, S_(stream), x, n, ws);
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, S_(stream), ws, parts);
+    hipLaunchKernelGGL(contract_vec_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_(stream), x, n, ws, y);
+    return check_launch("contract");
+}
+
+int m360_gaussian_contract(const float *mean_in, const float *cov_in, long S, float *mean_out,
+                           float *cov_out, void *workspace, size_t workspace_bytes,
+                           m360_stream_t stream) {
+    if (!mean_in || !cov_in || !mean_out || !cov_out || S < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_gaussian_contract: bad argument");
+    if (!workspace || workspace_bytes < sizeof(NormScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_gaussian_contract: workspace %zu < %zu", workspace_bytes, sizeof(NormScratch));
+    if (S == 0) return M360_OK;
+    NormScratch *ws = static_cast<NormScratch *>(workspace);
+    const int parts = norm_parts(3 * S);
+    hipLaunchKernelGGL(norm_partial_from_mean_kernel, dim3(parts), dim3(256), 0, S_(stream), mean_in, 3 * S, ws);
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, S_(stream), ws, parts);
+    hipLaunchKernelGGL(contract_apply_kernel, dim3(blocks_for(S, 256)), dim3(256), 0, S_(stream), mean_in, cov_in, S, ws, mean_out, cov_out);
+    return check_launch("gaussian_contract");
+}
+
+// norm pre-pass shared by para_rays / encode_features
+static void launch_norm_from_t(const float *t_vals, const float *directions, const float *radii, int B,
+                               int N, NormScratch *ws, hipStream_t st) {
+    const int parts = norm_parts((long)B * N);
+    hipLaunchKernelGGL(norm_partial_from_t_kernel, dim3(parts), dim3(256), 0, st, t_vals, directions, radii, B, N, ws);
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, ws, parts);
+}
+
+int m360_para_rays(const float *t_vals, const float *origins, const float *directions,
+                   const float *radii, int B, int N, float *means, float *covs, void *workspace,
+                   size_t workspace_bytes, m360_stream_t stream) {
+    if (!t_vals || !origins || !directions || !radii || !means || !covs || B < 0 || N < 1)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_para_rays: bad argument");
+    if (!workspace || workspace_bytes < sizeof(NormScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_para_rays: workspace %zu < %zu", workspace_bytes, sizeof(NormScratch));
+    if (B == 0) return M360_OK;
+    NormScratch *ws = static_cast<NormScratch *>(workspace);
+    launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream));
+    hipLaunchKernelGGL(para_rays_kernel, dim3(blocks_for((long)B * N, 256)), dim3(256), 0, S_(stream), t_vals, origins, directions, radii, B, N, ws, means, covs);
+    return check_launch("para_rays");
+}
+
+int m360_ipe(const float *mean, const float *cov, long S, float *enc, m360_stream_t stream) {
+    if (!mean || !enc || S < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_ipe: bad argument");
+    if (S == 0) return M360_OK;
+    if (cov) hipLaunchKernelGGL(ipe_kernel<true>, dim3(blocks_for(S, 256)), dim3(256), 0, S_(stream), mean, cov, S, enc);
+    else hipLaunchKernelGGL(ipe_kernel<false>, dim3(blocks_for(S, 256)), dim3(256), 0, S_(stream), mean, cov, S, enc);
+    return check_launch("ipe");
+}
+
+int m360_viewdir_enc(const float *viewdirs, int B, int min_deg, int max_deg, float *enc,
+                     m360_stream_t stream) {
+    if (!viewdirs || !enc || B < 0 || max_deg < min_deg) return fail(M360_ERR_INVALID_ARGUMENT, "m360_viewdir_enc: bad argument");
+    if (B == 0 || max_deg == min_deg) return M360_OK;
+    hipLaunchKernelGGL(viewdir_enc_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, S_(stream), viewdirs, B, min_deg, max_deg - min_deg, enc);
+    return check_launch("viewdir_enc");
+}
+
+int m360_encode_features(const float *t_vals, const float *origins, const float *directions,
+                         const float *radii, const float *vdenc, int vd_ch, int B, int N, float *feat,
+                         int ld_feat, void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    if (!t_vals || !origins || !directions || !radii || !feat || B < 0 || N < 1 || vd_ch < 0 || (vd_ch > 0 && !vdenc))
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: bad argument");
+    if (ld_feat % 32 != 0 || ld_feat < kIpeCh + vd_ch) return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: ld_feat=%d must be a multiple of 32 and >= %d", ld_feat, kIpeCh + vd_ch);
+    if (!workspace || workspace_bytes < sizeof(NormScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_encode_features: workspace %zu < %zu", workspace_bytes, sizeof(NormScratch));
+    if (B == 0) return M360_OK;
+    NormScratch *ws = static_cast<NormScratch *>(workspace);
+    launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream));
+    const size_t lds = (size_t)kEncThreads * (ld_feat + 1) * sizeof(float);
+    hipLaunchKernelGGL(encode_features_kernel, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat);
+    return check_launch("encode_features");
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+"""Mirror of the reference's intern/parameterization.py (same names, argument meaning).
+
+Differences, both documented in DESIGN.md:
+  * nothing is mutated in place (`g` in the reference does `x += 1e-6`); the same numeric
+    offsets are applied inside the kernels;
+  * `gaussian_contract` uses the closed-form Jacobian instead of a per-sample autograd loop.
+Tensors must live on a HIP device; there is no CPU implementation.
+"""
+from __future__ import annotations
+
+from .. import ops
+
+
+def t_to_s(t_vals, near, far):
+    """intern/parameterization.py:5-8: (g(t) - g(near)) / (g(far) - g(near)), with the
+    reference's call order (the second g(near) sees near + 2e-6)."""
+    return ops.t_to_s(t_vals, near, far, near_calls=0, far_calls=0)
+
+
+def s_to_t(s_vals, near, far):
+    """intern/parameterization.py:10-13."""
+    return ops.s_to_t(s_vals, near, far)
+
+
+def g(x):
+    """intern/parameterization.py:15-21: 1/(x + 1e-6) (x itself is left untouched)."""
+    return ops.g(x)
+
+
+def contract(x):
+    """intern/parameterization.py:23-29: norm taken over the WHOLE tensor."""
+    return ops.contract(x)
+
+
+def gaussian_to_xyz(d, t_mean, t_var, r_var, diag=False):
+    """intern/parameterization.py:31-62; only the full-covariance branch is on the hot path."""
+    if diag:
+        raise NotImplementedError("diag=True is a dead branch of the reference's hot path (never taken)")
+    return ops.gaussian_to_xyz(d, t_mean, t_var, r_var)
+
+
+def gaussian_contract(mean, cov):
+    """intern/parameterization.py:64-83."""
+    return ops.gaussian_contract(mean, cov)
+
+
+def conical_frustum_to_gaussian(d, t0, t1, base_radius, diag, stable=True):
+    """intern/parameterization.py:85-117 (stable branch)."""
+    if diag or not stable:
+        raise NotImplementedError("only diag=False, stable=True is reachable from the reference's hot path")
+    t_mean, t_var, r_var = ops.frustum_moments(t0, t1, base_radius)
+    mean, cov = ops.gaussian_to_xyz(d, t_mean, t_var, r_var)
+    return ops.gaussian_contract(mean, cov)
+
+
+def para_rays(t_vals, origins, directions, radii, diag=False):
+    """intern/parameterization.py:119-135 (origins are added after the contraction)."""
+    if diag:
+        raise NotImplementedError("diag=True is a dead branch of the reference's hot path (never taken)")
+    return ops.para_rays(t_vals, origins, directions, radii)

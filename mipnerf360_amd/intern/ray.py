@@ -1,0 +1,40 @@
+"""Mirror of the reference's intern/ray.py (hot-path functions only)."""
+from __future__ import annotations
+
+from collections import namedtuple
+
+import torch
+
+from .. import ops
+
+Rays = namedtuple("Rays", ("origins", "directions", "viewdirs", "radii", "near", "far"))  # intern/ray.py:6
+
+
+def namedtuple_map(fn, tup):
+    """intern/ray.py:8-10."""
+    return type(tup)(*map(fn, tup))
+
+
+def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized=True):
+    """intern/ray.py:12-57 (default randomized=True as in the reference; `weights` is not modified)."""
+    u = torch.rand(bins.shape[0], num_samples, device=bins.device) if randomized else None
+    return ops.sorted_pdf(bins, weights, num_samples, u)
+
+
+def sample_along_rays(origins, directions, radii, num_samples, near, far, randomized):
+    """intern/ray.py:81-116 -> (t_vals[B,N+1], (means[B,N,3], covs[B,N,3,3]))."""
+    t_rand = torch.rand(origins.shape[0], num_samples + 1, device=origins.device) if randomized else None
+    t_vals = ops.sample_t(near, far, num_samples, t_rand)
+    return t_vals, ops.para_rays(t_vals, origins, directions, radii)
+
+
+def resample_along_rays(origins, directions, radii, t_vals, weights, randomized, resample_padding):
+    """intern/ray.py:118-153."""
+    u = torch.rand(t_vals.shape, device=t_vals.device) if randomized else None
+    new_t = ops.resample_t(t_vals, weights, resample_padding, u)
+    return new_t, ops.para_rays(new_t, origins, directions, radii)
+
+
+def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd):
+    """intern/ray.py:155-191 -> (comp_rgb[B,3], distance[B], acc[B], weights[B,N])."""
+    return ops.volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd)

@@ -1,0 +1,360 @@
+"""Drop-in mirror of the reference's model.py: `prop_net`, `nerf_net`, `mipNeRF360`.
+
+Same constructor arguments, attributes, `state_dict` layout (30 tensors) and
+return values as the reference (model.py:14-283) — but `forward` / `render_image` run the
+hand-written HIP pipeline of libm360 (sampling -> contraction -> IPE -> fp32-MFMA MLPs ->
+resampling -> alpha composite) instead of eager PyTorch ops.
+
+Intentional differences:
+  * forward-only: outputs carry no autograd graph (training is out of scope);
+  * caller tensors are never mutated (the reference's `g()` bumps near/far/t_vals in place);
+  * `render_image` is silent unless `self.verbose` and keeps every chunk on the device.
+There is no CPU path: tensors must be on a HIP device and libm360.so must be built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .intern.encoding import PositionalEncoding, ViewdirectionEncoding
+from .intern.ray import Rays, namedtuple_map
+
+_WORKSPACES: Dict[torch.device, torch.Tensor] = {}
+
+
+def _kaiming_init(model):
+    """model.py:8-12."""
+    for module in model.modules():
+        if isinstance(module, nn.Linear):
+            nn.init.kaiming_uniform_(module.weight)
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device scratch buffer (single-stream use, like the reference)."""
+    device = torch.device(device)
+    ws = _WORKSPACES.get(device)
+    if ws is None or ws.numel() < nbytes:
+        _WORKSPACES.pop(device, None)
+        ws = None
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WORKSPACES[device] = ws
+    return ws
+
+
+def release_workspaces() -> None:
+    _WORKSPACES.clear()
+
+
+class _PackedMLP:
+    """Zero-padded, k-contiguous copies of a sub-network's Linear layers for m360_linear,
+    rebuilt whenever a parameter tensor is replaced or modified in place."""
+
+    def __init__(self):
+        self.key = None
+        self.w, self.b = [], []
+        self.head_w = self.head_b = None
+        self.in_pad = self.h_pad = 0
+
+    @staticmethod
+    def _key(params):
+        return tuple((p.data_ptr(), p._version, p.device) for p in params)
+
+    def refresh(self, hidden_layers, heads) -> "_PackedMLP":
+        params = [p for lin in list(hidden_layers) + list(heads) for p in (lin.weight, lin.bias)]
+        key = self._key(params)
+        if key == self.key:
+            return self
+        first = hidden_layers[0]
+        ops._require_device(first.weight, "model parameters")
+        self.in_pad = ops.round_up(first.in_features)
+        self.h_pad = ops.round_up(first.out_features)
+        self.w, self.b = [], []
+        for i, lin in enumerate(hidden_layers):
+            wp, bp = ops.pack_linear(lin.weight, lin.bias, self.h_pad, self.in_pad if i == 0 else self.h_pad)
+            self.w.append(wp), self.b.append(bp)
+        hw = torch.cat([h.weight.detach() for h in heads], 0).float()
+        hb = torch.cat([h.bias.detach() for h in heads], 0).float().contiguous()
+        self.head_w, _ = ops.pack_linear(hw, None, hw.shape[0], self.h_pad)
+        self.head_b = hb
+        self.key = key
+        return self
+
+
+def _rays_struct(rays):
+    keep = [ops.dev(getattr(rays, f), f"rays.{f}") for f in Rays._fields]
+    B = keep[0].shape[0]
+    for f, t in zip(Rays._fields, keep):
+        if t.shape[0] != B:
+            raise RuntimeError(f"rays.{f} has {t.shape[0]} rows, expected {B}")
+    return _lib.RaysStruct(*[t.data_ptr() for t in keep]), keep, B
+
+
+def _model_struct(in_ch, prop: Optional[_PackedMLP], nerf: Optional[_PackedMLP]):
+    m = _lib.ModelStruct()
+    ref = prop or nerf
+    m.in_ch, m.in_pad = in_ch, ref.in_pad
+    m.hp_pad = (prop or nerf).h_pad
+    m.hn_pad = (nerf or prop).h_pad
+    if prop is not None:
+        for i in range(4):
+            m.prop_w[i], m.prop_b[i] = prop.w[i].data_ptr(), prop.b[i].data_ptr()
+        m.prop_head_w, m.prop_head_b = prop.head_w.data_ptr(), prop.head_b.data_ptr()
+    if nerf is not None:
+        for i in range(8):
+            m.nerf_w[i], m.nerf_b[i] = nerf.w[i].data_ptr(), nerf.b[i].data_ptr()
+        m.nerf_head_w, m.nerf_head_b = nerf.head_w.data_ptr(), nerf.head_b.data_ptr()
+    return m
+
+
+def _hyper_struct(num_samples, min_deg, max_deg, white_bkgd=False, density_bias=-1.0, rgb_padding=0.001,
+                  resample_padding=0.01):
+    return _lib.HyperStruct(int(num_samples), int(min_deg), int(max_deg), int(bool(white_bkgd)), float(density_bias),
+                            float(rgb_padding), float(resample_padding))
+
+
+def _ws_for(B, N, mstruct, device):
+    nbytes = _lib.lib().m360_forward_workspace_bytes(B, N, C.byref(mstruct))
+    return _workspace(max(int(nbytes), 256), device)
+
+
+class prop_net(nn.Module):
+    """Proposal network, model.py:14-94 of the reference (4 x hidden_proposal, density only)."""
+
+    def __init__(self, randomized=False, num_samples=128, hidden_proposal=256, density_bias=-1, viewdir_min_deg=0,
+                 viewdir_max_deg=4, device=torch.device("cuda")):
+        super().__init__()
+        self.randomized = randomized
+        self.num_samples = num_samples
+        self.hidden_proposal = hidden_proposal
+        self.density_bias = density_bias
+        self.viewdir_min_deg = viewdir_min_deg
+        self.viewdir_max_deg = viewdir_max_deg
+        self.device = device
+        self.positional_encoding = PositionalEncoding()
+        self.viewdirs_encoding = ViewdirectionEncoding(self.viewdir_min_deg, self.viewdir_max_deg)
+        self.input_size = 21 * 2 + (self.viewdir_max_deg - self.viewdir_min_deg) * 2 * 2
+        self.density_activation = nn.Softplus()
+        h = self.hidden_proposal
+        self.model = nn.Sequential(
+            nn.Linear(self.input_size, h), nn.ReLU(True),
+            nn.Linear(h, h), nn.ReLU(True),
+            nn.Linear(h, h), nn.ReLU(True),
+            nn.Linear(h, h), nn.Sigmoid(),
+            nn.Linear(h, 1))
+        _kaiming_init(self)
+        self.to(device)
+        self._packed = _PackedMLP()
+
+    def _pack(self) -> _PackedMLP:
+        return self._packed.refresh([self.model[i] for i in (0, 2, 4, 6)], [self.model[8]])
+
+    def density_to_weight(self, t_vals, density, dirs):
+        """model.py:59-78."""
+        return ops.density_to_weight(t_vals, density, dirs)
+
+    def forward(self, rays):
+        """model.py:80-94 -> (t_vals[B,N+1], weights[B,N])."""
+        rstruct, keep, B = _rays_struct(rays)
+        dev = keep[0].device
+        N = self.num_samples
+        mstruct = _model_struct(self.input_size, self._pack(), None)
+        hyper = _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, density_bias=self.density_bias)
+        t_hat = torch.empty(B, N + 1, device=dev)
+        w_hat = torch.empty(B, N, device=dev)
+        t_rand = torch.rand(B, N + 1, device=dev) if self.randomized else None
+        ws = _ws_for(B, N, mstruct, dev)
+        _lib.check(_lib.lib().m360_prop_forward(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, ops.ptr(t_rand),
+                                                t_hat.data_ptr(), w_hat.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                ops.stream()), "m360_prop_forward")
+        return t_hat, w_hat
+
+
+class nerf_net(nn.Module):
+    """NeRF network, model.py:96-200 of the reference (8 x hidden_nerf, density + colour heads)."""
+
+    def __init__(self, randomized=False, num_samples=128, hidden_nerf=1024, density_bias=-1, rgb_padding=0.001,
+                 resample_padding=0.01, white_bkgd=False, viewdir_min_deg=0, viewdir_max_deg=4,
+                 device=torch.device("cuda")):
+        super().__init__()
+        self.randomized = randomized
+        self.num_samples = num_samples
+        self.hidden_nerf = hidden_nerf
+        self.density_bias = density_bias
+        self.rgb_padding = rgb_padding
+        self.resample_padding = resample_padding
+        self.white_bkgd = white_bkgd
+        self.viewdir_min_deg = viewdir_min_deg
+        self.viewdir_max_deg = viewdir_max_deg
+        self.device = device
+        self.positional_encoding = PositionalEncoding()
+        self.viewdirs_encoding = ViewdirectionEncoding(self.viewdir_min_deg, self.viewdir_max_deg)
+        self.input_size = 21 * 2 + (self.viewdir_max_deg - self.viewdir_min_deg) * 2 * 2
+        self.density_activation = nn.Softplus()
+        h = self.hidden_nerf
+        layers = [nn.Linear(self.input_size, h), nn.ReLU(True)]
+        for _ in range(6):
+            layers += [nn.Linear(h, h), nn.ReLU(True)]
+        layers += [nn.Linear(h, h), nn.Sigmoid()]
+        self.model = nn.Sequential(*layers)
+        self.final_density = nn.Sequential(nn.Linear(h, 1), nn.Sigmoid())
+        self.final_color = nn.Sequential(nn.Linear(h, 3), nn.Sigmoid())
+        _kaiming_init(self)
+        self.to(device)
+        self._packed = _PackedMLP()
+
+    def _pack(self) -> _PackedMLP:
+        return self._packed.refresh([self.model[i] for i in range(0, 16, 2)],
+                                    [self.final_density[0], self.final_color[0]])
+
+    def _hyper(self, N):
+        return _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, self.white_bkgd, self.density_bias,
+                             self.rgb_padding, self.resample_padding)
+
+    def _stash(self, outs):
+        # model.py:192-196: kept on the module for the distillation / regularisation losses
+        self.fine_weights, self.t_vals, self.s_vals = outs["fine_w"], outs["t_vals"], outs["s_vals"]
+
+    def forward(self, rays, t_vals, coarse_weights):
+        """model.py:163-200 -> (rgb[B,3], distance[B], acc[B], t_vals[B,N+1], fine_weights[B,N], s_vals[B,N+1]).
+        The number of fine samples is t_vals.shape[-1]-1, as in the reference (intern/ray.py:147)."""
+        rstruct, keep, B = _rays_struct(rays)
+        dev = keep[0].device
+        t_vals, coarse_weights = ops.dev(t_vals, "t_vals"), ops.dev(coarse_weights, "coarse_weights")
+        N = t_vals.shape[-1] - 1
+        mstruct = _model_struct(self.input_size, None, self._pack())
+        hyper = self._hyper(N)
+        outs = _alloc_outputs(B, N, dev, with_prop=False)
+        ostruct = _outputs_struct(outs)
+        u_rand = torch.rand(B, N + 1, device=dev) if self.randomized else None
+        ws = _ws_for(B, N, mstruct, dev)
+        _lib.check(_lib.lib().m360_nerf_forward(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, t_vals.data_ptr(),
+                                                coarse_weights.data_ptr(), ops.ptr(u_rand), C.byref(ostruct),
+                                                ws.data_ptr(), ws.numel(), ops.stream()), "m360_nerf_forward")
+        self._stash(outs)
+        return outs["rgb"], outs["distance"], outs["acc"], self.t_vals, self.fine_weights, self.s_vals
+
+
+def _alloc_outputs(B, N, dev, with_prop=True, rgb=None, distance=None, acc=None):
+    o = dict(rgb=rgb if rgb is not None else torch.empty(B, 3, device=dev),
+             distance=distance if distance is not None else torch.empty(B, device=dev),
+             acc=acc if acc is not None else torch.empty(B, device=dev),
+             t_vals=torch.empty(B, N + 1, device=dev), fine_w=torch.empty(B, N, device=dev),
+             s_vals=torch.empty(B, N + 1, device=dev))
+    if with_prop:
+        o["t_hat"] = torch.empty(B, N + 1, device=dev)
+        o["w_hat"] = torch.empty(B, N, device=dev)
+    return o
+
+
+def _outputs_struct(o):
+    return _lib.OutputsStruct(*[ops.ptr(o.get(k)) for k in ("rgb", "distance", "acc", "t_hat", "w_hat", "t_vals",
+                                                            "fine_w", "s_vals")])
+
+
+class mipNeRF360(nn.Module):
+    """model.py:202-283 of the reference."""
+
+    def __init__(self, randomized=False, num_samples=128, hidden_proposal=256, hidden_nerf=1024, density_bias=-1,
+                 rgb_padding=0.001, resample_padding=0.01, white_bkgd=False, viewdir_min_deg=0, viewdir_max_deg=4,
+                 device=torch.device("cuda")):
+        super().__init__()
+        self.randomized = randomized
+        self.num_samples = num_samples
+        self.hidden_proposal = hidden_proposal
+        self.hidden_nerf = hidden_nerf
+        self.density_bias = density_bias
+        self.rgb_padding = rgb_padding
+        self.resample_padding = resample_padding
+        self.white_bkgd = white_bkgd
+        self.viewdir_min_deg = viewdir_min_deg
+        self.viewdir_max_deg = viewdir_max_deg
+        self.device = device
+        self.init_randomized = randomized
+        self.verbose = False
+        self.prop_net = prop_net(randomized=self.randomized, num_samples=self.num_samples,
+                                 hidden_proposal=self.hidden_proposal, density_bias=self.density_bias,
+                                 viewdir_min_deg=self.viewdir_min_deg, viewdir_max_deg=self.viewdir_max_deg,
+                                 device=self.device)
+        self.nerf_net = nerf_net(randomized=self.randomized, num_samples=self.num_samples, hidden_nerf=self.hidden_nerf,
+                                 density_bias=self.density_bias, rgb_padding=self.rgb_padding,
+                                 resample_padding=self.resample_padding, white_bkgd=self.white_bkgd,
+                                 viewdir_min_deg=self.viewdir_min_deg, viewdir_max_deg=self.viewdir_max_deg,
+                                 device=self.device)
+        self.to(device)
+
+    # ------------------------------------------------------------------ fused two-stage forward
+    def _forward_fused(self, rays, rgb=None, distance=None, acc=None, stash=True):
+        rstruct, keep, B = _rays_struct(rays)
+        dev = keep[0].device
+        N = self.prop_net.num_samples
+        mstruct = _model_struct(self.prop_net.input_size, self.prop_net._pack(), self.nerf_net._pack())
+        hyper = self.nerf_net._hyper(N)
+        if stash:
+            outs = _alloc_outputs(B, N, dev, with_prop=False, rgb=rgb, distance=distance, acc=acc)
+        else:
+            outs = dict(rgb=rgb if rgb is not None else torch.empty(B, 3, device=dev),
+                        distance=distance if distance is not None else torch.empty(B, device=dev),
+                        acc=acc if acc is not None else torch.empty(B, device=dev))
+        ostruct = _outputs_struct(outs)
+        ws = _ws_for(B, N, mstruct, dev)
+        _lib.check(_lib.lib().m360_forward(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, C.byref(ostruct),
+                                           ws.data_ptr(), ws.numel(), ops.stream()), "m360_forward")
+        if stash:
+            self.nerf_net._stash(outs)
+        return outs["rgb"], outs["distance"], outs["acc"]
+
+    def forward(self, rays):
+        """model.py:247-252 -> (rgb[B,3], distance[B], acc[B])."""
+        if not self.prop_net.randomized and not self.nerf_net.randomized:
+            return self._forward_fused(rays)
+        t_hat, w_hat = self.prop_net.forward(rays)
+        rgb, dist, acc, _, _, _ = self.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        return rgb, dist, acc
+
+    # ------------------------------------------------------------------ chunked frame rendering
+    def render_rays(self, rays, chunks=4096):
+        """Chunk loop of model.py:261-269 with everything resident on the device: one H2D copy of the
+        ray batch, outputs written in place, no per-chunk sync.  The chunk PARTITION is the reference's
+        (consecutive blocks of `chunks` rays) because the global contraction norm makes results
+        chunk-dependent.  Returns float device tensors (rgb[n,3], distance[n], acc[n])."""
+        dev = torch.device(self.device)
+        rays = namedtuple_map(lambda r: torch.as_tensor(r).to(device=dev, dtype=torch.float32).contiguous(), rays)
+        length = rays[0].shape[0]
+        rgb = torch.empty(length, 3, device=dev)
+        dist = torch.empty(length, device=dev)
+        acc = torch.empty(length, device=dev)
+        fused = not self.prop_net.randomized and not self.nerf_net.randomized
+        with torch.no_grad():
+            for i in range(0, length, chunks):
+                chunk = namedtuple_map(lambda r: r[i:i + chunks], rays)
+                if fused:
+                    self._forward_fused(chunk, rgb[i:i + chunks], dist[i:i + chunks], acc[i:i + chunks], stash=False)
+                else:
+                    r, d, a = self(chunk)
+                    rgb[i:i + chunks], dist[i:i + chunks], acc[i:i + chunks] = r, d, a
+                if self.verbose:
+                    print("rendering,schedule:%s / %s" % (i // chunks, length // chunks))
+        return rgb, dist, acc
+
+    def render_image(self, rays, height, width, chunks=4096):
+        """model.py:254-274 -> (uint8[H,W,3], float32[H,W], float32[H,W]) NumPy arrays."""
+        rgb, dist, acc = self.render_rays(rays, chunks)
+        rgbs = ops.to8b(rgb).reshape(height, width, 3).cpu().numpy()
+        dists = dist.reshape(height, width).cpu().numpy()
+        accs = acc.reshape(height, width).cpu().numpy()
+        return rgbs, dists, accs
+
+    def train(self, mode=True):
+        """model.py:276-279 (note: sub-nets keep the `randomized` they were built with)."""
+        self.randomized = self.init_randomized
+        super().train(mode)
+        return self
+
+    def eval(self):
+        """model.py:281-283."""
+        self.randomized = False
+        return super().eval()

@@ -1,0 +1,272 @@
+"""Tensor-level wrappers over the libm360 C-ABI.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every
+function below validates its tensors, allocates outputs with torch and calls one
+`extern "C"` entry point with raw device pointers on the current stream.
+CPU tensors are rejected — there is no fallback implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+IPE_CH = 42
+
+
+def _require_device(t: torch.Tensor, name: str) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{name} is on {t.device}: mipnerf360_amd executes on HIP (MI355X) devices only; there is no CPU path")
+
+
+def dev(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    """fp32, contiguous, on a HIP device (dtype other than fp32 is an error, as in the reference
+    whose Jacobian buffer is fp32-only, intern/parameterization.py:75)."""
+    _require_device(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def round_up(v: int, m: int = 32) -> int:
+    return (v + m - 1) // m * m
+
+
+def _call(name, *args):
+    fn = getattr(_lib.lib(), name)
+    _lib.check(fn(*args), name)
+
+
+def _ws(device) -> torch.Tensor:
+    n = _lib.lib().m360_contract_workspace_bytes()
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------- sampling
+def sample_t(near, far, num_samples: int, t_rand=None) -> torch.Tensor:
+    near, far = dev(near, "near"), dev(far, "far")
+    B = near.shape[0]
+    t = torch.empty(B, num_samples + 1, device=near.device)
+    if t_rand is not None:
+        t_rand = dev(t_rand, "t_rand")
+    _call("m360_sample_t", ptr(near), ptr(far), ptr(t_rand), B, num_samples, ptr(t), stream())
+    return t
+
+
+def g(x) -> torch.Tensor:
+    x = dev(x, "x")
+    y = torch.empty_like(x)
+    _call("m360_g", ptr(x), x.numel(), ptr(y), stream())
+    return y
+
+
+def s_to_t(s_vals, near, far) -> torch.Tensor:
+    near, far = dev(near, "near"), dev(far, "far")
+    B = near.shape[0]
+    s_vals = dev(s_vals, "s_vals")
+    s2 = s_vals.expand(B, s_vals.shape[-1]).contiguous() if s_vals.dim() == 1 or s_vals.shape[0] != B else s_vals
+    t = torch.empty_like(s2)
+    _call("m360_s_to_t", ptr(s2), ptr(near), ptr(far), B, s2.shape[-1], ptr(t), stream())
+    return t
+
+
+def contract(x) -> torch.Tensor:
+    x = dev(x, "x")
+    y = torch.empty_like(x)
+    ws = _ws(x.device)
+    _call("m360_contract", ptr(x), x.numel(), ptr(y), ptr(ws), ws.numel(), stream())
+    return y
+
+
+def t_to_s(t_vals, near, far, near_calls: int = 1, far_calls: int = 1) -> torch.Tensor:
+    t_vals, near, far = dev(t_vals, "t_vals"), dev(near, "near"), dev(far, "far")
+    B, M = t_vals.shape
+    s = torch.empty_like(t_vals)
+    _call("m360_t_to_s", ptr(t_vals), ptr(near), ptr(far), B, M, near_calls, far_calls, ptr(s), stream())
+    return s
+
+
+# ----------------------------------------------------------------------------- gaussians
+def frustum_moments(t0, t1, radii):
+    t0, t1, radii = dev(t0, "t0"), dev(t1, "t1"), dev(radii, "radii")
+    B, N = t0.shape
+    outs = [torch.empty_like(t0) for _ in range(3)]
+    _call("m360_frustum_moments", ptr(t0), ptr(t1), ptr(radii), B, N, *[ptr(o) for o in outs], stream())
+    return tuple(outs)
+
+
+def gaussian_to_xyz(d, t_mean, t_var, r_var):
+    d, t_mean, t_var, r_var = dev(d, "d"), dev(t_mean, "t_mean"), dev(t_var, "t_var"), dev(r_var, "r_var")
+    B, N = t_mean.shape
+    mean = torch.empty(B, N, 3, device=d.device)
+    cov = torch.empty(B, N, 3, 3, device=d.device)
+    _call("m360_gaussian_to_xyz", ptr(d), ptr(t_mean), ptr(t_var), ptr(r_var), B, N, ptr(mean), ptr(cov), stream())
+    return mean, cov
+
+
+def gaussian_contract(mean, cov):
+    mean, cov = dev(mean, "mean"), dev(cov, "cov")
+    S = mean.numel() // 3
+    mo, co = torch.empty_like(mean), torch.empty_like(cov)
+    ws = _ws(mean.device)
+    _call("m360_gaussian_contract", ptr(mean), ptr(cov), S, ptr(mo), ptr(co), ptr(ws), ws.numel(), stream())
+    return mo, co
+
+
+def para_rays(t_vals, origins, directions, radii):
+    t_vals, origins = dev(t_vals, "t_vals"), dev(origins, "origins")
+    directions, radii = dev(directions, "directions"), dev(radii, "radii")
+    B, M = t_vals.shape
+    N = M - 1
+    means = torch.empty(B, N, 3, device=t_vals.device)
+    covs = torch.empty(B, N, 3, 3, device=t_vals.device)
+    ws = _ws(t_vals.device)
+    _call("m360_para_rays", ptr(t_vals), ptr(origins), ptr(directions), ptr(radii), B, N, ptr(means), ptr(covs),
+          ptr(ws), ws.numel(), stream())
+    return means, covs
+
+
+# ----------------------------------------------------------------------------- encodings
+def ipe(mean, cov=None) -> torch.Tensor:
+    mean = dev(mean, "mean")
+    cov = None if cov is None else dev(cov, "cov")
+    S = mean.numel() // 3
+    enc = torch.empty(mean.shape[:-1] + (IPE_CH,), device=mean.device)
+    _call("m360_ipe", ptr(mean), ptr(cov), S, ptr(enc), stream())
+    return enc
+
+
+def viewdir_enc(viewdirs, min_deg: int, max_deg: int) -> torch.Tensor:
+    viewdirs = dev(viewdirs, "viewdirs")
+    B = viewdirs.numel() // 3
+    enc = torch.empty(viewdirs.shape[:-1] + (4 * (max_deg - min_deg),), device=viewdirs.device)
+    _call("m360_viewdir_enc", ptr(viewdirs), B, min_deg, max_deg, ptr(enc), stream())
+    return enc
+
+
+def encode_features(t_vals, origins, directions, radii, vdenc, ld_feat: Optional[int] = None) -> torch.Tensor:
+    t_vals, origins = dev(t_vals, "t_vals"), dev(origins, "origins")
+    directions, radii, vdenc = dev(directions, "directions"), dev(radii, "radii"), dev(vdenc, "vdenc")
+    B, M = t_vals.shape
+    N = M - 1
+    vd_ch = vdenc.shape[-1]
+    ld = ld_feat or round_up(IPE_CH + vd_ch)
+    feat = torch.empty(B * N, ld, device=t_vals.device)
+    ws = _ws(t_vals.device)
+    _call("m360_encode_features", ptr(t_vals), ptr(origins), ptr(directions), ptr(radii), ptr(vdenc), vd_ch, B, N,
+          ptr(feat), ld, ptr(ws), ws.numel(), stream())
+    return feat
+
+
+# ----------------------------------------------------------------------------- MLP
+def pack_linear(weight, bias=None, n_pad: Optional[int] = None, k_pad: Optional[int] = None):
+    weight = dev(weight.detach(), "weight")
+    n_out, k_in = weight.shape
+    n_pad, k_pad = n_pad or round_up(n_out), k_pad or round_up(k_in)
+    wp = torch.empty(n_pad, k_pad, device=weight.device)
+    bp = torch.empty(n_pad, device=weight.device)
+    b = None if bias is None else dev(bias.detach(), "bias")
+    _call("m360_pack_linear", ptr(weight), ptr(b), n_out, k_in, n_pad, k_pad, ptr(wp), ptr(bp), stream())
+    return wp, bp
+
+
+def linear(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x, w_packed, b_packed = dev(x, "x"), dev(w_packed, "w_packed"), dev(b_packed, "b_packed")
+    M, ldx = x.shape
+    n_pad, k_pad = w_packed.shape
+    if ldx != k_pad:
+        raise RuntimeError(f"linear: x has {ldx} columns, packed weight expects {k_pad}")
+    y = out if out is not None else torch.empty(M, n_pad, device=x.device)
+    _call("m360_linear", ptr(x), M, ldx, ptr(w_packed), ptr(b_packed), n_pad, k_pad, act, ptr(y), y.shape[1], stream())
+    return y
+
+
+# ----------------------------------------------------------------------------- per-ray scans
+def _density2d(density):
+    return density[..., 0] if density.dim() == 3 else density
+
+
+def density_to_weight(t_vals, density, dirs) -> torch.Tensor:
+    t_vals, density, dirs = dev(t_vals, "t_vals"), dev(_density2d(density), "density"), dev(dirs, "dirs")
+    B, N = density.shape
+    w = torch.empty(B, N, device=t_vals.device)
+    _call("m360_density_to_weight", ptr(t_vals), ptr(density), ptr(dirs), B, N, ptr(w), stream())
+    return w
+
+
+def sorted_pdf(bins, weights, num_samples: int, u_rand=None) -> torch.Tensor:
+    bins, weights = dev(bins, "bins"), dev(weights, "weights")
+    B, nb = bins.shape
+    if weights.shape[-1] != nb - 1:
+        raise RuntimeError(f"sorted_pdf: weights must have {nb - 1} entries per ray, got {weights.shape[-1]}")
+    out = torch.empty(B, num_samples, device=bins.device)
+    u = None if u_rand is None else dev(u_rand, "u_rand")
+    _call("m360_sorted_pdf", ptr(bins), ptr(weights), ptr(u), B, nb, num_samples, ptr(out), stream())
+    return out
+
+
+def resample_t(t_vals, weights, resample_padding: float, u_rand=None) -> torch.Tensor:
+    t_vals, weights = dev(t_vals, "t_vals"), dev(weights, "weights")
+    B, M = t_vals.shape
+    out = torch.empty_like(t_vals)
+    u = None if u_rand is None else dev(u_rand, "u_rand")
+    _call("m360_resample_t", ptr(t_vals), ptr(weights), ptr(u), B, M - 1, float(resample_padding), ptr(out), stream())
+    return out
+
+
+def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd: bool):
+    rgb, density = dev(rgb, "rgb"), dev(_density2d(density), "density")
+    t_vals, dirs = dev(t_vals, "t_vals"), dev(dirs, "dirs")
+    B, N = density.shape
+    d = t_vals.device
+    comp, dist, acc, w = torch.empty(B, 3, device=d), torch.empty(B, device=d), torch.empty(B, device=d), torch.empty(B, N, device=d)
+    _call("m360_volumetric_rendering", ptr(rgb), ptr(density), ptr(t_vals), ptr(dirs), B, N, int(bool(white_bkgd)),
+          ptr(comp), ptr(dist), ptr(acc), ptr(w), stream())
+    return comp, dist, acc, w
+
+
+def to8b(x: torch.Tensor) -> torch.Tensor:
+    x = dev(x, "image")
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _call("m360_to8b", ptr(x), x.numel(), ptr(out), stream())
+    return out
+
+
+def prop_finish(act, head_w, head_b, density_bias, t_vals, dirs, resample_padding, want_t_new=True, u_rand=None):
+    act, head_w, head_b = dev(act, "act"), dev(head_w, "head_w"), dev(head_b, "head_b")
+    t_vals, dirs = dev(t_vals, "t_vals"), dev(dirs, "dirs")
+    B, M = t_vals.shape
+    N = M - 1
+    w = torch.empty(B, N, device=act.device)
+    t_new = torch.empty_like(t_vals) if want_t_new else None
+    u = None if u_rand is None else dev(u_rand, "u_rand")
+    _call("m360_prop_finish", ptr(act), act.shape[1], ptr(head_w), ptr(head_b), head_w.numel(), float(density_bias),
+          ptr(t_vals), ptr(dirs), ptr(u), B, N, float(resample_padding), ptr(w), ptr(t_new), stream())
+    return w, t_new
+
+
+def nerf_finish(act, head_w, head_b, density_bias, rgb_padding, t_vals, dirs, white_bkgd):
+    act, head_w, head_b = dev(act, "act"), dev(head_w, "head_w"), dev(head_b, "head_b")
+    t_vals, dirs = dev(t_vals, "t_vals"), dev(dirs, "dirs")
+    B, M = t_vals.shape
+    N = M - 1
+    d = act.device
+    comp, dist, acc, w = torch.empty(B, 3, device=d), torch.empty(B, device=d), torch.empty(B, device=d), torch.empty(B, N, device=d)
+    _call("m360_nerf_finish", ptr(act), act.shape[1], ptr(head_w), ptr(head_b), head_w.shape[1], float(density_bias),
+          float(rgb_padding), ptr(t_vals), ptr(dirs), B, N, int(bool(white_bkgd)), ptr(comp), ptr(dist), ptr(acc), ptr(w),
+          stream())
+    return comp, dist, acc, w
