@@ -104,6 +104,9 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP extension is required and there is no CPU fallback. "
                 "Build it with `make -C mipnerf360_amd/csrc` (needs hipcc, gfx950).")
+        # libm360 and PyTorch must share ONE HIP runtime (torch owns the device memory and the
+        # streams we launch on): load torch's bundled libamdhip64 first so the loader reuses it.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing

@@ -211,7 +211,8 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, u_rand: Optional[t
     wsum = wsum + pad
     pdf = weights / wsum
     cdf = torch.clamp_max(torch.cumsum(pdf[..., :-1], dim=-1), 1.0)
-    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf, torch.ones_like(cdf[..., :1])], dim=-1)
+    edge = torch.zeros_like(wsum)  # [...,1] even when there is a single interval (empty cumsum)
+    cdf = torch.cat([edge, cdf, edge + 1.0], dim=-1)
     if u_rand is None:
         u = torch.linspace(0.0, 1.0 - f32eps, num_samples)
         u = u.expand(cdf.shape[:-1] + (num_samples,)).contiguous()
