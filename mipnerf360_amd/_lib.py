@@ -75,6 +75,8 @@ SIGNATURES = {
     "m360_prop_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m360_nerf_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp,
                                _P(OutputsStruct), _vp, _sz, _vp]),
+    "m360_debug_set_linear_variant": (_i, [_i]),
+    "m360_debug_read_stamps": (_i, [_P(C.c_ulonglong), _i]),
     "m360_prof_enable": (_i, [_i]),
     "m360_prof_count": (_i, []),
     "m360_prof_reset": (_i, []),

@@ -14,6 +14,7 @@
 //   step s) so one ds_read_b128 feeds four consecutive MFMAs for A and for B alike.
 //   Workgroup ids are remapped so the 4 N-tiles of one M-tile run on the same XCD (shared L2).
 #include "m360_common.cuh"
+#include "m360_linear_persist.cuh"
 
 namespace m360 {
 
@@ -201,7 +202,36 @@ __global__ void pack_linear_kernel(const float *__restrict__ w, const float *__r
 
 using namespace m360;
 
+static int g_linear_variant = 2;  // 1 = one workgroup per tile (register staging), 2 = persistent + LDS-DMA
+
+static int cu_count() {
+    static int cached = -1;
+    if (cached < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        cached = n;
+    }
+    return cached;
+}
+
 extern "C" {
+
+int m360_debug_set_linear_variant(int variant) {
+    if (variant < 1 || variant > 3) return fail(M360_ERR_INVALID_ARGUMENT, "m360_debug_set_linear_variant: %d", variant);
+    g_linear_variant = variant;
+    return M360_OK;
+}
+
+// diagnostic: copy the cycle stamps of the last variant-3 (stamped) launch to the host
+int m360_debug_read_stamps(unsigned long long *out_host, int n) {
+    if (!out_host || n < 0 || n > 256 * 8) return fail(M360_ERR_INVALID_ARGUMENT, "m360_debug_read_stamps: bad argument");
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(persist::g_stamps), sizeof(unsigned long long) * n) != hipSuccess)
+        return fail(M360_ERR_LAUNCH, "m360_debug_read_stamps: copy failed");
+    return M360_OK;
+}
 
 int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                      float *w_packed, float *b_packed, m360_stream_t stream) {
@@ -224,13 +254,29 @@ int m360_linear(const float *x, long M, int ldx, const float *w_packed, const fl
     const long nwg = tiles_m * tiles_n;
     if (nwg > 0x7fffffffL) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: grid too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid((unsigned)nwg), block(kThreads);
+    if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: unknown activation %d", act);
     const int prof = prof_begin(st, M, n_pad, k_pad);
-    switch (act) {
-        case M360_ACT_NONE: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
-        case M360_ACT_RELU: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
-        case M360_ACT_SIGMOID: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
-        default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: unknown activation %d", act);
+    if (g_linear_variant == 1) {
+        dim3 grid((unsigned)nwg), block(kThreads);
+        switch (act) {
+            case M360_ACT_NONE: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
+            case M360_ACT_RELU: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
+            default: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
+        }
+    } else if (g_linear_variant == 3) {  // diagnostic build of the persistent kernel with cycle stamps (ReLU only)
+        const int cus = cu_count();
+        dim3 grid((unsigned)(nwg < cus ? nwg : cus)), block(persist::kThreads);
+        hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU, true>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n, (int)nwg);
+    } else {  // persistent: one workgroup per CU walks the tiles
+        const int cus = cu_count();
+        if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear: no HIP device");
+        dim3 grid((unsigned)(nwg < cus ? nwg : cus)), block(persist::kThreads);
+        const int ntiles = (int)nwg;
+        switch (act) {
+            case M360_ACT_NONE: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n, ntiles); break;
+            case M360_ACT_RELU: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n, ntiles); break;
+            default: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n, ntiles); break;
+        }
     }
     prof_end(prof, st);
     return check_launch("linear");

@@ -1,0 +1,288 @@
+// Second-generation fp32-MFMA linear kernel: persistent workgroups, one wave per SIMD, LDS-DMA.
+//
+//   * grid = one 256-thread workgroup (4 waves = one per SIMD, each owning the whole 512-entry
+//     register file) per CU; each workgroup walks 256 x 256 output tiles with stride gridDim.x,
+//     XCD-aware (the 32 workgroups of one XCD sweep 8 M-tiles x 4 N-tiles that share activation
+//     rows in that XCD's L2).  Wave tile 128 x 128 = 4 x 4 MFMA tiles -> 256 accumulator registers.
+//   * A/B K-step tiles (256 rows x 32 floats each) go global -> LDS directly with
+//     global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass), double-buffered.  LDS rows are
+//     unpadded 128 B; bank conflicts are removed by an XOR swizzle applied on the per-lane SOURCE
+//     address (16-B chunk c of row r lands in slot c ^ ((r>>1)&7)) and mirrored on the
+//     ds_read_b128 side.
+//   * operand fragments are double-buffered in registers: the 8 ds_read_b128 of K-group g+1 are
+//     issued before the 64 MFMAs of group g; the last group of a K-step runs AFTER the barrier and
+//     after the first reads of the next K-step were issued, so barrier skew and read latency hide
+//     behind matrix work.  The DMA of the next K-step is issued in between MFMA slices.
+//   * the first K-step of the NEXT tile is already in flight while a tile's epilogue runs.
+#pragma once
+#include "m360_common.cuh"
+
+namespace m360 {
+namespace persist {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: valid "v" asm operand (HIP float4 is a struct)
+
+constexpr int BM = 256, BN = 256, BK = 32;
+constexpr int kThreads = 256;
+constexpr int TM = 4, TN = 4;
+constexpr int kTileFloats = 256 * BK;          // one operand tile (A or B) of one K-step
+constexpr int kBufFloats = 2 * kTileFloats;    // A + B
+constexpr int kDma = 8;                        // DMA instructions per operand per wave per K-step
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+#define M360_INL __attribute__((always_inline))
+
+template <int ACT>
+__device__ __forceinline__ float act_fn(float v) {
+    if (ACT == M360_ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == M360_ACT_SIGMOID) return sigmoidf_(v);
+    return v;
+}
+
+// diagnostic cycle stamps (STAMP builds only; never used by the product path): per workgroup, summed
+// over all K-steps: [0] group0+DMA issue, [1] group1, [2] group2, [3] DMA-wait+barrier, [4] group3,
+// [5] whole K-step, [6] K-steps, [7] epilogue
+__device__ unsigned long long g_stamps[256 * 8];
+
+template <int ACT, bool STAMP = false>
+__global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
+    const float *__restrict__ X, long M, int ldx, const float *__restrict__ W,
+    const float *__restrict__ bias, int Np, int Kp, float *__restrict__ Y, int ldy, int tiles_n,
+    int ntiles) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * kBufFloats];  // 128 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int G = gridDim.x;
+    const int ksteps = Kp / BK;
+
+    auto tile_coords = [&](int lin_id, long &m0, int &n0) M360_INL {
+        // XCD-aware: ids that share id % 8 (one XCD under round-robin dispatch) cover a contiguous
+        // range of tiles, N-tiles of one M-tile adjacent (speed only, never correctness)
+        const int full = (ntiles / 8) * 8;
+        int lin = lin_id;
+        if (lin_id < full) lin = (lin_id % 8) * (full / 8) + lin_id / 8;
+        m0 = (long)(lin / tiles_n) * BM;
+        n0 = (lin % tiles_n) * BN;
+    };
+
+    // ---- LDS-DMA staging: wave w fills rows [64w, 64w+64) of A and of B, 8 instructions each
+    // (8 rows x 128 B per instruction: lane L -> row L>>3, slot L&7 holding chunk slot ^ f(row)).
+    // Per-lane state: one base pointer per operand + a 32-bit row stride; rows past the edge of a
+    // ragged tile are clamped (computed, never stored).
+    const int st_r = wave * 64 + (lane >> 3);  // row of DMA instruction q = st_r + 8 q
+    const float *ga[kDma];
+    const float *gb[kDma];
+    auto set_load_tile = [&](long m0, int n0) M360_INL {
+        const long rows_left = M - m0;
+        const int cols_left = Np - n0;
+#pragma unroll
+        for (int q = 0; q < kDma; ++q) {
+            const int r = st_r + 8 * q;
+            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+            const long ra = r < rows_left ? r : rows_left - 1;
+            const int rb = r < cols_left ? r : cols_left - 1;
+            ga[q] = X + (m0 + ra) * ldx + 4 * chunk;
+            gb[q] = W + (long)(n0 + rb) * Kp + 4 * chunk;
+        }
+    };
+    float *const dma_dst = smem + st_r * 0 + wave * 64 * BK;  // + buf * kBufFloats + q * 8 * BK
+    auto issue_dma = [&](int buf, int k0, int q) M360_INL {
+        float *dstA = dma_dst + buf * kBufFloats + q * 8 * BK;
+        __builtin_amdgcn_global_load_lds(ga[q] + k0, (lds_ptr_t)dstA, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(gb[q] + k0, (lds_ptr_t)(dstA + kTileFloats), 16, 0, 0);
+    };
+
+    // ---- operand reads: lane (l31, h), K-group g reads chunk (2g+h) of its rows = slot (2g+h)^f.
+    // The reads are inline asm with hand-counted lgkmcnt waits: with LDS-DMA in flight hipcc would
+    // otherwise put s_waitcnt vmcnt(0) / lgkmcnt(0) in front of every compiler-visible LDS read.
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    const int fsw = (l31 >> 1) & 7;
+    unsigned a_addr[4], b_addr[4];  // byte addresses in buffer 0
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int slot = ((2 * g + h) ^ fsw) * 4;
+        a_addr[g] = lds0 + 4u * ((wm * 128 + l31) * BK + slot);
+        b_addr[g] = lds0 + 4u * (kTileFloats + (wn * 128 + l31) * BK + slot);
+    }
+
+    f32x16 acc[TM][TN];
+    f32x4 fa_a[TM], fa_b[TN], fb_a[TM], fb_b[TN];
+
+#define M360_DS128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#define M360_READ(FA, FB, bufoff, g)                                   \
+    do {                                                               \
+        const unsigned aa_ = a_addr[g] + (bufoff), bb_ = b_addr[g] + (bufoff); \
+        M360_DS128(FA[0], aa_, 0);                                     \
+        M360_DS128(FA[1], aa_, 4096);                                  \
+        M360_DS128(FA[2], aa_, 8192);                                  \
+        M360_DS128(FA[3], aa_, 12288);                                 \
+        M360_DS128(FB[0], bb_, 0);                                     \
+        M360_DS128(FB[1], bb_, 4096);                                  \
+        M360_DS128(FB[2], bb_, 8192);                                  \
+        M360_DS128(FB[3], bb_, 12288);                                 \
+    } while (0)
+// the wait takes the fragment it guards as in/out operands: every later use depends on the wait,
+// so hipcc can neither hoist a use nor place a register copy of not-yet-landed data above it
+#define M360_WAIT_FRAG(n, FA, FB)                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                        \
+                 : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FB[0]), "+v"(FB[1]),    \
+                   "+v"(FB[2]), "+v"(FB[3])::"memory")
+#define M360_COMP(v, s) ((v)[s])
+#define M360_SLICE(FA, FB, s)                                                                          \
+    do {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(M360_COMP(FA[i], s), M360_COMP(FB[j], s), \
+                                                             acc[i][j], 0, 0, 0);                      \
+    } while (0)
+#define M360_GROUP(FA, FB)                                                                             \
+    do {                                                                                               \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) M360_SLICE(FA, FB, s);                           \
+    } while (0)
+#define M360_SB() __builtin_amdgcn_sched_barrier(0)
+
+#define M360_STAMP(var)                                                             \
+    do {                                                                            \
+        if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+    } while (0)
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+
+    int lin_id = blockIdx.x;
+    if (lin_id >= ntiles) return;
+    long m0;
+    int n0;
+    tile_coords(lin_id, m0, n0);
+    set_load_tile(m0, n0);
+#pragma unroll
+    for (int q = 0; q < kDma; ++q) issue_dma(0, 0, q);
+    int buf = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first K-step of the first tile has landed
+    __syncthreads();
+    M360_SB();
+    M360_READ(fa_a, fa_b, 0u, 0);  // loop invariant from here on: group 0 of the current step in flight
+    M360_SB();
+
+    for (; lin_id < ntiles; lin_id += G) {
+        tile_coords(lin_id, m0, n0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+        for (int kt = 0; kt < ksteps; ++kt) {
+            // the K-step loaded next: kt+1 of this tile, else step 0 of this workgroup's next tile
+            // (else, harmlessly, step 0 of the current tile again: nobody reads it)
+            int next_k0 = (kt + 1) * BK;
+            if (kt + 1 == ksteps) {
+                next_k0 = 0;
+                if (lin_id + G < ntiles) {
+                    long nm0;
+                    int nn0;
+                    tile_coords(lin_id + G, nm0, nn0);
+                    set_load_tile(nm0, nn0);
+                }
+            }
+            const unsigned boff = buf ? 4u * kBufFloats : 0u;
+            M360_SB();
+            M360_READ(fb_a, fb_b, boff, 1);  // outstanding: R0, R1
+            M360_STAMP(c0);
+            M360_WAIT_FRAG(8, fa_a, fa_b);   // R0 landed
+            M360_SB();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {  // group 0, DMA of the next K-step issued between slices
+                M360_SLICE(fa_a, fa_b, s);
+                issue_dma(buf ^ 1, next_k0, 2 * s);
+                issue_dma(buf ^ 1, next_k0, 2 * s + 1);
+                M360_SB();
+            }
+            M360_STAMP(c1);
+            M360_READ(fa_a, fa_b, boff, 2);  // outstanding: R1, R2
+            M360_WAIT_FRAG(8, fb_a, fb_b);   // R1 landed
+            M360_SB();
+            M360_GROUP(fb_a, fb_b);  // group 1
+            M360_SB();
+            M360_STAMP(c2);
+            M360_READ(fb_a, fb_b, boff, 3);  // outstanding: R2, R3
+            M360_WAIT_FRAG(8, fa_a, fa_b);   // R2 landed
+            M360_SB();
+            M360_GROUP(fa_a, fa_b);  // group 2
+            M360_SB();
+            M360_STAMP(c3);
+            // R3 landed => every read of `buf` by this wave is done; own DMA of the next step landed
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
+                         : "+v"(fb_a[0]), "+v"(fb_a[1]), "+v"(fb_a[2]), "+v"(fb_a[3]), "+v"(fb_b[0]), "+v"(fb_b[1]),
+                           "+v"(fb_b[2]), "+v"(fb_b[3])::"memory");
+            M360_SB();
+            M360_STAMP(c4);
+            buf ^= 1;
+            M360_READ(fa_a, fa_b, (buf ? 4u * kBufFloats : 0u), 0);  // group 0 of the next step (or next tile)
+            M360_SB();
+            M360_GROUP(fb_a, fb_b);  // group 3 of this step hides the barrier skew and the reads above
+            M360_SB();
+            M360_STAMP(c5);
+            if (STAMP) {
+                st[0] += c1 - c0; st[1] += c2 - c1; st[2] += c3 - c2; st[3] += c4 - c3; st[4] += c5 - c4;
+                st[5] += c5 - c0; st[6] += 1;
+            }
+        }
+        M360_STAMP(c0);
+
+        // ---- epilogue: bias + activation; lane holds column (n) l31, rows (r&3)+8(r>>2)+4h.
+        // Chunked per 32x32 tile so at most 16 results are live at a time.
+        {
+            const long rows_left = M - m0;
+            const int cols_left = Np - n0;
+            const bool interior = rows_left >= BM && cols_left >= BN;  // wave-uniform
+            int ldy_t = ldy;
+            asm volatile("" : "+s"(ldy_t));  // keep the address math inside the tile loop (LICM would spill it)
+            float *__restrict__ Yt = Y + m0 * ldy_t + n0;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * 128 + j * 32 + l31;
+                const bool col_ok = col < cols_left;
+                const float bj = col_ok ? bias[n0 + col] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int rbase = wm * 128 + i * 32 + 4 * h;
+                    float *__restrict__ Yc = Yt + (long)rbase * ldy_t + col;
+                    if (interior) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            Yc[(long)((r & 3) + 8 * (r >> 2)) * ldy_t] = act_fn<ACT>(acc[i][j][r] + bj);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = rbase + (r & 3) + 8 * (r >> 2);
+                            if (col_ok && row < rows_left)
+                                Yc[(long)((r & 3) + 8 * (r >> 2)) * ldy_t] = act_fn<ACT>(acc[i][j][r] + bj);
+                        }
+                    }
+                    M360_SB();
+                }
+            }
+        }
+        M360_STAMP(c1);
+        if (STAMP) st[7] += c1 - c0;
+    }
+    if (STAMP && threadIdx.x == 0 && blockIdx.x < 256) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_stamps[blockIdx.x * 8 + i] = st[i];
+    }
+#undef M360_STAMP
+#undef M360_READ
+#undef M360_DS128
+#undef M360_WAIT_FRAG
+#undef M360_COMP
+#undef M360_SLICE
+#undef M360_GROUP
+#undef M360_SB
+}
+
+}  // namespace persist
+}  // namespace m360
