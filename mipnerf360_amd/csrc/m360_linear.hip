@@ -245,9 +245,9 @@ int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_
 int m360_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
                 int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t stream) {
     if (!x || !w_packed || !b_packed || !y || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: null pointer or negative M");
-    if (n_pad < 1 || k_pad < BK || k_pad % BK != 0 || ldx < k_pad || ldy < n_pad || ldx % 4 != 0)
-        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad (multiple of 4), ldy=%d >= n_pad=%d", k_pad, BK, ldx, ldy, n_pad);
-    if (((uintptr_t)x | (uintptr_t)w_packed) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: x and w_packed must be 16-byte aligned");
+    if (n_pad < 1 || k_pad < BK || k_pad % BK != 0 || ldx < k_pad || ldy < n_pad || ldx % 4 != 0 || ldy % 4 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad, ldy=%d >= n_pad=%d, both multiples of 4", k_pad, BK, ldx, ldy, n_pad);
+    if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: x, w_packed, b_packed and y must be 16-byte aligned");
     if (M == 0) return M360_OK;
     const long tiles_m = (M + BM - 1) / BM;
     const int tiles_n = (n_pad + BN - 1) / BN;

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     __shared__ __attribute__((aligned(1024))) float smem[2 * kBufFloats];  // 128 KiB
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: keeps the DMA's LDS base (M0) in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
     const int G = gridDim.x;
@@ -90,10 +91,11 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         }
     };
     float *const dma_dst = smem + st_r * 0 + wave * 64 * BK;  // + buf * kBufFloats + q * 8 * BK
-    auto issue_dma = [&](int buf, int k0, int q) M360_INL {
+    // which: 1 = A rows, 2 = B rows, 3 = both (row-block q of this wave's 64-row slice)
+    auto issue_dma = [&](int buf, int k0, int q, int which) M360_INL {
         float *dstA = dma_dst + buf * kBufFloats + q * 8 * BK;
-        __builtin_amdgcn_global_load_lds(ga[q] + k0, (lds_ptr_t)dstA, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(gb[q] + k0, (lds_ptr_t)(dstA + kTileFloats), 16, 0, 0);
+        if (which & 1) __builtin_amdgcn_global_load_lds(ga[q] + k0, (lds_ptr_t)dstA, 16, 0, 0);
+        if (which & 2) __builtin_amdgcn_global_load_lds(gb[q] + k0, (lds_ptr_t)(dstA + kTileFloats), 16, 0, 0);
     };
 
     // ---- operand reads: lane (l31, h), K-group g reads chunk (2g+h) of its rows = slot (2g+h)^f.
@@ -143,6 +145,35 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         _Pragma("unroll") for (int s = 0; s < 4; ++s) M360_SLICE(FA, FB, s);                           \
     } while (0)
 #define M360_SB() __builtin_amdgcn_sched_barrier(0)
+// 8 MFMAs: rows i0, i0+1 of the wave tile x 4 columns, k-pair s of the current K-group
+#define M360_MFMA8(FA, FB, s, i0)                                                                      \
+    do {                                                                                               \
+        _Pragma("unroll") for (int i = (i0); i < (i0) + 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i][s], FB[j][s], acc[i][j], 0, 0, 0);  \
+    } while (0)
+// One K-group = 8 units of 8 MFMAs on fragment (FA, FB).  After each unit ONE ds_read_b128 of the NEXT
+// K-group (into the other fragment NA/NB, byte addresses na/nb) and, when DMA is 1, the two LDS-DMA
+// instruction(s) of row-block q = unit of the next K-step are issued (DMA: 1 = A half, 2 = B half,
+// 3 = both): every non-matrix instruction gets
+// its own >= 512-cycle MFMA shadow instead of being issued in bursts.
+#define M360_UNIT(FA, FB, s, i0, RD, DMA, q)            \
+    do {                                                \
+        M360_MFMA8(FA, FB, s, i0);                      \
+        RD;                                             \
+        if (DMA) issue_dma(buf ^ 1, next_k0, q, DMA);   \
+        M360_SB();                                      \
+    } while (0)
+#define M360_GROUP_PIPE(FA, FB, NA, NB, na, nb, DMA)                                 \
+    do {                                                                             \
+        M360_UNIT(FA, FB, 0, 0, M360_DS128(NA[0], na, 0), DMA, 0);                   \
+        M360_UNIT(FA, FB, 0, 2, M360_DS128(NA[1], na, 4096), DMA, 1);                \
+        M360_UNIT(FA, FB, 1, 0, M360_DS128(NA[2], na, 8192), DMA, 2);                \
+        M360_UNIT(FA, FB, 1, 2, M360_DS128(NA[3], na, 12288), DMA, 3);               \
+        M360_UNIT(FA, FB, 2, 0, M360_DS128(NB[0], nb, 0), DMA, 4);                   \
+        M360_UNIT(FA, FB, 2, 2, M360_DS128(NB[1], nb, 4096), DMA, 5);                \
+        M360_UNIT(FA, FB, 3, 0, M360_DS128(NB[2], nb, 8192), DMA, 6);                \
+        M360_UNIT(FA, FB, 3, 2, M360_DS128(NB[3], nb, 12288), DMA, 7);               \
+    } while (0)
 
 #define M360_STAMP(var)                                                             \
     do {                                                                            \
@@ -158,7 +189,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     tile_coords(lin_id, m0, n0);
     set_load_tile(m0, n0);
 #pragma unroll
-    for (int q = 0; q < kDma; ++q) issue_dma(0, 0, q);
+    for (int q = 0; q < kDma; ++q) issue_dma(0, 0, q, 3);
     int buf = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first K-step of the first tile has landed
     __syncthreads();
@@ -189,30 +220,24 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
                 }
             }
             const unsigned boff = buf ? 4u * kBufFloats : 0u;
+            const unsigned noff = buf ? 0u : 4u * kBufFloats;  // the other buffer (next K-step)
+            const unsigned a1 = a_addr[1] + boff, b1 = b_addr[1] + boff, a2 = a_addr[2] + boff, b2 = b_addr[2] + boff;
+            const unsigned a3 = a_addr[3] + boff, b3 = b_addr[3] + boff, a0n = a_addr[0] + noff, b0n = b_addr[0] + noff;
             M360_SB();
-            M360_READ(fb_a, fb_b, boff, 1);  // outstanding: R0, R1
             M360_STAMP(c0);
-            M360_WAIT_FRAG(8, fa_a, fa_b);   // R0 landed
+            // every group: wait for its own operands (the only LDS reads outstanding), then run its 64 MFMAs
+            // with the next group's 8 reads (and, in group 0, the next K-step's 16 DMA instructions) in between
+            M360_WAIT_FRAG(0, fa_a, fa_b);  // R0 landed
             M360_SB();
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {  // group 0, DMA of the next K-step issued between slices
-                M360_SLICE(fa_a, fa_b, s);
-                issue_dma(buf ^ 1, next_k0, 2 * s);
-                issue_dma(buf ^ 1, next_k0, 2 * s + 1);
-                M360_SB();
-            }
+            M360_GROUP_PIPE(fa_a, fa_b, fb_a, fb_b, a1, b1, 3);  // group 0  (+ reads R1, + the 16 DMA instructions of step t+1)
             M360_STAMP(c1);
-            M360_READ(fa_a, fa_b, boff, 2);  // outstanding: R1, R2
-            M360_WAIT_FRAG(8, fb_a, fb_b);   // R1 landed
+            M360_WAIT_FRAG(0, fb_a, fb_b);  // R1 landed
             M360_SB();
-            M360_GROUP(fb_a, fb_b);  // group 1
-            M360_SB();
+            M360_GROUP_PIPE(fb_a, fb_b, fa_a, fa_b, a2, b2, 0);  // group 1  (+ reads R2)
             M360_STAMP(c2);
-            M360_READ(fb_a, fb_b, boff, 3);  // outstanding: R2, R3
-            M360_WAIT_FRAG(8, fa_a, fa_b);   // R2 landed
+            M360_WAIT_FRAG(0, fa_a, fa_b);  // R2 landed
             M360_SB();
-            M360_GROUP(fa_a, fa_b);  // group 2
-            M360_SB();
+            M360_GROUP_PIPE(fa_a, fa_b, fb_a, fb_b, a3, b3, 0);  // group 2  (+ reads R3)
             M360_STAMP(c3);
             // R3 landed => every read of `buf` by this wave is done; own DMA of the next step landed
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
@@ -220,11 +245,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
                            "+v"(fb_b[2]), "+v"(fb_b[3])::"memory");
             M360_SB();
             M360_STAMP(c4);
+            // group 3 hides the barrier skew; its interleaved reads are group 0 of the NEXT step / tile
+            M360_GROUP_PIPE(fb_a, fb_b, fa_a, fa_b, a0n, b0n, 0);
             buf ^= 1;
-            M360_READ(fa_a, fa_b, (buf ? 4u * kBufFloats : 0u), 0);  // group 0 of the next step (or next tile)
-            M360_SB();
-            M360_GROUP(fb_a, fb_b);  // group 3 of this step hides the barrier skew and the reads above
-            M360_SB();
             M360_STAMP(c5);
             if (STAMP) {
                 st[0] += c1 - c0; st[1] += c2 - c1; st[2] += c3 - c2; st[3] += c4 - c3; st[4] += c5 - c4;
@@ -233,8 +256,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         }
         M360_STAMP(c0);
 
-        // ---- epilogue: bias + activation; lane holds column (n) l31, rows (r&3)+8(r>>2)+4h.
-        // Chunked per 32x32 tile so at most 16 results are live at a time.
+        // ---- epilogue: bias + activation.  The accumulator layout (lane = column l31, 16 registers =
+        // rows (r&3)+8(r>>2)+4h) would store 4 B per lane; interior tiles are instead transposed
+        // through the idle LDS buffer (wave-private 32 x 36 floats) so that every lane stores 16 B and one
+        // instruction writes 8 full 128-B row segments: 4x fewer, 4x wider global stores.
         {
             const long rows_left = M - m0;
             const int cols_left = Np - n0;
@@ -242,28 +267,47 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
             int ldy_t = ldy;
             asm volatile("" : "+s"(ldy_t));  // keep the address math inside the tile loop (LICM would spill it)
             float *__restrict__ Yt = Y + m0 * ldy_t + n0;
+            if (interior) {
+                float *stg = smem + (buf ^ 1) * kBufFloats + wave * (32 * 36);  // `buf` already holds the next tile
+                const int rrow = lane >> 3, rcol = 4 * (lane & 7);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = wn * 128 + j * 32 + l31;
-                const bool col_ok = col < cols_left;
-                const float bj = col_ok ? bias[n0 + col] : 0.0f;
+                for (int j = 0; j < TN; ++j) {
+                    const float4 b4 = *reinterpret_cast<const float4 *>(bias + n0 + wn * 128 + j * 32 + rcol);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int rbase = wm * 128 + i * 32 + 4 * h;
-                    float *__restrict__ Yc = Yt + (long)rbase * ldy_t + col;
-                    if (interior) {
+                    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            Yc[(long)((r & 3) + 8 * (r >> 2)) * ldy_t] = act_fn<ACT>(acc[i][j][r] + bj);
-                    } else {
+                        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = acc[i][j][r];
+                        float *__restrict__ Yc = Yt + (long)(wm * 128 + i * 32 + rrow) * ldy_t + wn * 128 + j * 32 + rcol;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            float4 v = *reinterpret_cast<const float4 *>(stg + (p * 8 + rrow) * 36 + rcol);
+                            v.x = act_fn<ACT>(v.x + b4.x);
+                            v.y = act_fn<ACT>(v.y + b4.y);
+                            v.z = act_fn<ACT>(v.z + b4.z);
+                            v.w = act_fn<ACT>(v.w + b4.w);
+                            *reinterpret_cast<float4 *>(Yc + (long)(p * 8) * ldy_t) = v;
+                        }
+                        M360_SB();
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = wn * 128 + j * 32 + l31;
+                    const bool col_ok = col < cols_left;
+                    const float bj = col_ok ? bias[n0 + col] : 0.0f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int rbase = wm * 128 + i * 32 + 4 * h;
+                        float *__restrict__ Yc = Yt + (long)rbase * ldy_t + col;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = rbase + (r & 3) + 8 * (r >> 2);
                             if (col_ok && row < rows_left)
                                 Yc[(long)((r & 3) + 8 * (r >> 2)) * ldy_t] = act_fn<ACT>(acc[i][j][r] + bj);
                         }
+                        M360_SB();
                     }
-                    M360_SB();
                 }
             }
         }
