@@ -256,26 +256,35 @@ int m360_linear(const float *x, long M, int ldx, const float *w_packed, const fl
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: unknown activation %d", act);
     const int prof = prof_begin(st, M, n_pad, k_pad);
-    if (g_linear_variant == 1) {
-        dim3 grid((unsigned)nwg), block(kThreads);
-        switch (act) {
-            case M360_ACT_NONE: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
-            case M360_ACT_RELU: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
-            default: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n); break;
-        }
-    } else if (g_linear_variant == 3) {  // diagnostic build of the persistent kernel with cycle stamps (ReLU only)
-        const int cus = cu_count();
-        dim3 grid((unsigned)(nwg < cus ? nwg : cus)), block(persist::kThreads);
-        hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU, true>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n, (int)nwg);
-    } else {  // persistent: one workgroup per CU walks the tiles
+    // Persistent LDS-DMA kernel on the full 256-row tiles when the width is a multiple of 256; ragged rows
+    // (and narrow layers) go to the workgroup-per-tile kernel.  Both produce bit-identical results.
+    const long M_full = (g_linear_variant != 1 && n_pad % persist::BN == 0) ? (M / persist::BM) * persist::BM : 0;
+    if (M_full > 0) {
         const int cus = cu_count();
         if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear: no HIP device");
-        dim3 grid((unsigned)(nwg < cus ? nwg : cus)), block(persist::kThreads);
-        const int ntiles = (int)nwg;
+        const long nt = (M_full / persist::BM) * (n_pad / persist::BN);
+        const int ntiles = (int)nt;
+        dim3 grid((unsigned)(nt < cus ? nt : cus)), block(persist::kThreads);
+        if (g_linear_variant == 3) {  // diagnostic build with cycle stamps (ReLU only)
+            hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU, true>), grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles);
+        } else {
+            switch (act) {
+                case M360_ACT_NONE: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
+                case M360_ACT_RELU: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
+                default: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
+            }
+        }
+    }
+    if (M > M_full) {
+        const float *xt = x + M_full * ldx;
+        float *yt = y + M_full * ldy;
+        const long Mt = M - M_full;
+        const long nwg_t = ((Mt + BM - 1) / BM) * tiles_n;
+        dim3 grid((unsigned)nwg_t), block(kThreads);
         switch (act) {
-            case M360_ACT_NONE: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n, ntiles); break;
-            case M360_ACT_RELU: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n, ntiles); break;
-            default: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tiles_n, ntiles); break;
+            case M360_ACT_NONE: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_NONE>, grid, block, 0, st, xt, Mt, ldx, w_packed, b_packed, n_pad, k_pad, yt, ldy, tiles_n); break;
+            case M360_ACT_RELU: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_RELU>, grid, block, 0, st, xt, Mt, ldx, w_packed, b_packed, n_pad, k_pad, yt, ldy, tiles_n); break;
+            default: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xt, Mt, ldx, w_packed, b_packed, n_pad, k_pad, yt, ldy, tiles_n); break;
         }
     }
     prof_end(prof, st);

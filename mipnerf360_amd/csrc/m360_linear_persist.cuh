@@ -74,22 +74,18 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
 
     // ---- LDS-DMA staging: wave w fills rows [64w, 64w+64) of A and of B, 8 instructions each
     // (8 rows x 128 B per instruction: lane L -> row L>>3, slot L&7 holding chunk slot ^ f(row)).
-    // Per-lane state: one base pointer per operand + a 32-bit row stride; rows past the edge of a
-    // ragged tile are clamped (computed, never stored).
+    // The kernel only ever sees FULL 256 x 256 tiles (M and Np multiples of 256): the host sends ragged
+    // rows / columns to the first-generation kernel, which is bit-identical.
     const int st_r = wave * 64 + (lane >> 3);  // row of DMA instruction q = st_r + 8 q
     const float *ga[kDma];
     const float *gb[kDma];
-    auto set_load_tile = [&](long m0, int n0) M360_INL {
-        const long rows_left = M - m0;
-        const int cols_left = Np - n0;
+    auto set_load_tile = [&](long m0, int n0) M360_INL {  // full tiles only: no row clamping needed
 #pragma unroll
         for (int q = 0; q < kDma; ++q) {
             const int r = st_r + 8 * q;
             const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-            const long ra = r < rows_left ? r : rows_left - 1;
-            const int rb = r < cols_left ? r : cols_left - 1;
-            ga[q] = X + (m0 + ra) * ldx + 4 * chunk;
-            gb[q] = W + (long)(n0 + rb) * Kp + 4 * chunk;
+            ga[q] = X + (m0 + r) * ldx + 4 * chunk;
+            gb[q] = W + (long)(n0 + r) * Kp + 4 * chunk;
         }
     };
     float *const dma_dst = smem + st_r * 0 + wave * 64 * BK;  // + buf * kBufFloats + q * 8 * BK
@@ -263,53 +259,32 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         // through the idle LDS buffer (wave-private 32 x 36 floats) so that every lane stores 16 B and one
         // instruction writes 8 full 128-B row segments: 4x fewer, 4x wider global stores.
         {
-            const long rows_left = M - m0;
-            const int cols_left = Np - n0;
-            const bool interior = rows_left >= BM && cols_left >= BN;  // wave-uniform
             int ldy_t = ldy;
             asm volatile("" : "+s"(ldy_t));  // keep the address math inside the tile loop (LICM would spill it)
             float *__restrict__ Yt = Y + m0 * ldy_t + n0;
-            if (interior) {
-                float *stg = smem + (buf ^ 1) * kBufFloats + wave * (32 * 36);  // `buf` already holds the next tile
-                const int rrow = lane >> 3, rcol = 4 * (lane & 7);
+            // staging lives in the idle buffer (`buf` already holds the next tile), INSIDE the 8 KiB slice that only
+            // this wave's own DMA instructions write: a faster wave that already streams the next K-step into the
+            // idle buffer can therefore never overwrite another wave's staging rows, and program order protects ours
+            float *stg = dma_dst + (buf ^ 1) * kBufFloats;
+            const int rrow = lane >> 3, rcol = 4 * (lane & 7);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float4 b4 = *reinterpret_cast<const float4 *>(bias + n0 + wn * 128 + j * 32 + rcol);
+            for (int j = 0; j < TN; ++j) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(bias + n0 + wn * 128 + j * 32 + rcol);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) {
+                for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = acc[i][j][r];
-                        float *__restrict__ Yc = Yt + (long)(wm * 128 + i * 32 + rrow) * ldy_t + wn * 128 + j * 32 + rcol;
+                    for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = acc[i][j][r];
+                    float *__restrict__ Yc = Yt + (long)(wm * 128 + i * 32 + rrow) * ldy_t + wn * 128 + j * 32 + rcol;
 #pragma unroll
-                        for (int p = 0; p < 4; ++p) {
-                            float4 v = *reinterpret_cast<const float4 *>(stg + (p * 8 + rrow) * 36 + rcol);
-                            v.x = act_fn<ACT>(v.x + b4.x);
-                            v.y = act_fn<ACT>(v.y + b4.y);
-                            v.z = act_fn<ACT>(v.z + b4.z);
-                            v.w = act_fn<ACT>(v.w + b4.w);
-                            *reinterpret_cast<float4 *>(Yc + (long)(p * 8) * ldy_t) = v;
-                        }
-                        M360_SB();
+                    for (int p = 0; p < 4; ++p) {
+                        float4 v = *reinterpret_cast<const float4 *>(stg + (p * 8 + rrow) * 36 + rcol);
+                        v.x = act_fn<ACT>(v.x + b4.x);
+                        v.y = act_fn<ACT>(v.y + b4.y);
+                        v.z = act_fn<ACT>(v.z + b4.z);
+                        v.w = act_fn<ACT>(v.w + b4.w);
+                        *reinterpret_cast<float4 *>(Yc + (long)(p * 8) * ldy_t) = v;
                     }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = wn * 128 + j * 32 + l31;
-                    const bool col_ok = col < cols_left;
-                    const float bj = col_ok ? bias[n0 + col] : 0.0f;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-                        const int rbase = wm * 128 + i * 32 + 4 * h;
-                        float *__restrict__ Yc = Yt + (long)rbase * ldy_t + col;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = rbase + (r & 3) + 8 * (r >> 2);
-                            if (col_ok && row < rows_left)
-                                Yc[(long)((r & 3) + 8 * (r >> 2)) * ldy_t] = act_fn<ACT>(acc[i][j][r] + bj);
-                        }
-                        M360_SB();
-                    }
+                    M360_SB();
                 }
             }
         }

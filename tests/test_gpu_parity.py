@@ -207,6 +207,28 @@ def test_linear_mfma_against_fp64(dev):
             assert torch.all(y[:, n_out:] == pad_expect)
 
 
+@pytest.mark.parametrize("M,n,k,act", [(256 * 37 + 5, 1024, 64, 1), (256 * 530, 256, 64, 0), (256 * 9, 256, 256, 1),
+                                        (256 * 64, 1024, 1024, 1)])
+def test_linear_kernel_variants_bit_identical(dev, M, n, k, act):
+    """The persistent LDS-DMA kernel (many tiles per workgroup: exercises the tile hand-over, the LDS-staged
+    epilogue and the ragged-row split) must reproduce the workgroup-per-tile kernel bit for bit, every element."""
+    from mipnerf360_amd import _lib, ops
+    g = torch.Generator(device=dev).manual_seed(M + n + k)
+    x = torch.rand(M, k, device=dev, generator=g) * 2 - 1
+    w = (torch.rand(n, k, device=dev, generator=g) * 2 - 1) * (6.0 / k) ** 0.5
+    b = torch.rand(n, device=dev, generator=g) - 0.5
+    lib = _lib.lib()
+    try:
+        _lib.check(lib.m360_debug_set_linear_variant(1), "variant")
+        y1 = ops.linear(x, w, b, act)
+        _lib.check(lib.m360_debug_set_linear_variant(2), "variant")
+        for _ in range(3):  # repeated launches: a race would not reproduce identically
+            y2 = ops.linear(x, w, b, act)
+            assert torch.equal(y1, y2)
+    finally:
+        lib.m360_debug_set_linear_variant(2)
+
+
 def test_linear_rejects_bad_arguments(dev):
     from mipnerf360_amd import ops
     x = torch.zeros(4, 48, device=dev)
