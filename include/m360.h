@@ -155,6 +155,25 @@ int m360_volumetric_rendering(const float *rgb, const float *density, const floa
 /* float -> uint8 image quantisation.  Replaces intern/utils.py:17-20. */
 int m360_to8b(const float *x, long n, uint8_t *out, m360_stream_t stream);
 
+/* ------------------------------------------------------------------ ray generation ---- */
+
+/* Pinhole rays for every pixel of n_cams cameras (cam_to_world[n_cams,3,4], row-major), flattened to
+ * [n_cams*h*w, .] like NeRFDataset.flatten_to_pytorch: origins, un-normalised directions, unit viewdirs,
+ * radii (distance to the next-row neighbour * 2/sqrt(12)), near, far.  ndc != 0 additionally converts
+ * origins/directions to NDC (near plane ndc_near, 1.0 in the reference) and takes the radii from the NDC
+ * origins of the row and column neighbours.  The last row / column repeats the SECOND-to-last neighbour
+ * distance, as the reference's `dx[:, -2:-1]` padding does; h, w >= 3.
+ * Replaces dataset.py:109-145 (NeRFDataset.generate_rays), dataset.py:364-387 (LLFF.generate_rays). */
+int m360_generate_rays(const float *cam_to_world, int n_cams, int h, int w, float focal, float near,
+                       float far, int ndc, float ndc_near, float *origins, float *directions,
+                       float *viewdirs, float *radii, float *near_out, float *far_out,
+                       m360_stream_t stream);
+
+/* NDC conversion of n rays.  Replaces intern/ray.py:59-79 (convert_to_ndc). */
+int m360_convert_to_ndc(const float *origins /*[n,3]*/, const float *directions /*[n,3]*/, long n,
+                        float focal, int w, int h, float near, float *origins_out, float *directions_out,
+                        m360_stream_t stream);
+
 /* ------------------------------------------------------------------ fused stages ------ */
 
 /* last proposal layer (hidden -> 1) + softplus(raw + density_bias) + density_to_weight +

@@ -69,6 +69,8 @@ SIGNATURES = {
     "m360_resample_t": (_i, [_vp, _vp, _vp, _i, _i, _fl, _vp, _vp]),
     "m360_volumetric_rendering": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "m360_to8b": (_i, [_vp, _l, _vp, _vp]),
+    "m360_generate_rays": (_i, [_vp, _i, _i, _i, _fl, _fl, _fl, _i, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "m360_convert_to_ndc": (_i, [_vp, _vp, _l, _fl, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_prop_finish": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_nerf_finish": (_i, [_vp, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "m360_forward_workspace_bytes": (_sz, [_i, _i, _P(ModelStruct)]),

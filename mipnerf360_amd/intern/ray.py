@@ -21,6 +21,25 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized=True):
     return ops.sorted_pdf(bins, weights, num_samples, u)
 
 
+def convert_to_ndc(origins, directions, focal, w, h, near=1.0):
+    """intern/ray.py:59-79.  NumPy in -> NumPy out like the reference; device tensors in -> device tensors out."""
+    import numpy as np
+    if isinstance(origins, np.ndarray):
+        if not torch.cuda.is_available():
+            raise RuntimeError("convert_to_ndc: no HIP device available; mipnerf360_amd has no CPU path")
+        o, d = ops.convert_to_ndc(torch.from_numpy(np.ascontiguousarray(origins, dtype=np.float32)).cuda(),
+                                  torch.from_numpy(np.ascontiguousarray(directions, dtype=np.float32)).cuda(),
+                                  focal, w, h, near)
+        return o.cpu().numpy(), d.cpu().numpy()
+    return ops.convert_to_ndc(origins, directions, focal, w, h, near)
+
+
+def generate_rays(cam_to_world, h, w, focal, near, far, ndc=False):
+    """On-device equivalent of NeRFDataset.generate_rays + flatten_to_pytorch (dataset.py:109-145,147-150)
+    and, with ndc=True, of LLFF.generate_rays (dataset.py:364-387) -> Rays of [n*h*w, .] device tensors."""
+    return Rays(*ops.generate_rays(cam_to_world, h, w, focal, near, far, ndc))
+
+
 def sample_along_rays(origins, directions, radii, num_samples, near, far, randomized):
     """intern/ray.py:81-116 -> (t_vals[B,N+1], (means[B,N,3], covs[B,N,3,3]))."""
     t_rand = torch.rand(origins.shape[0], num_samples + 1, device=origins.device) if randomized else None

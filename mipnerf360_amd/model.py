@@ -348,6 +348,17 @@ class mipNeRF360(nn.Module):
         accs = acc.reshape(height, width).cpu().numpy()
         return rgbs, dists, accs
 
+    def render_view(self, cam_to_world, height, width, focal, near, far, ndc=False, chunks=4096):
+        """Extension: render one camera pose without ever materialising rays on the host.
+        Rays are generated on the device exactly like NeRFDataset.generate_rays / LLFF.generate_rays
+        (dataset.py:109-145, :364-387; `ndc=True` for the nerf_360 / llff configuration) and fed to the same
+        chunk loop as `render_image`; only the 3x4 pose goes up and the finished frame comes down."""
+        from .intern.ray import generate_rays
+        dev = torch.device(self.device)
+        pose = torch.as_tensor(cam_to_world).to(device=dev, dtype=torch.float32)
+        rays = generate_rays(pose, height, width, focal, near, far, ndc)
+        return self.render_image(rays, height, width, chunks)
+
     def train(self, mode=True):
         """model.py:276-279 (note: sub-nets keep the `randomized` they were built with)."""
         self.randomized = self.init_randomized

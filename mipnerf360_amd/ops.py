@@ -270,3 +270,29 @@ def nerf_finish(act, head_w, head_b, density_bias, rgb_padding, t_vals, dirs, wh
           float(rgb_padding), ptr(t_vals), ptr(dirs), B, N, int(bool(white_bkgd)), ptr(comp), ptr(dist), ptr(acc), ptr(w),
           stream())
     return comp, dist, acc, w
+
+
+# ----------------------------------------------------------------------------- ray generation
+def generate_rays(cam_to_world, h: int, w: int, focal: float, near: float, far: float, ndc: bool = False,
+                  ndc_near: float = 1.0):
+    """-> 6 flattened device tensors (origins, directions, viewdirs [n*h*w,3]; radii, near, far [n*h*w,1])."""
+    c2w = dev(cam_to_world, "cam_to_world")
+    if c2w.dim() == 2:
+        c2w = c2w[None]
+    c2w = c2w[:, :3, :4].contiguous()
+    n = c2w.shape[0]
+    total = n * h * w
+    d = c2w.device
+    o, di, v = (torch.empty(total, 3, device=d) for _ in range(3))
+    r, ne, fa = (torch.empty(total, 1, device=d) for _ in range(3))
+    _call("m360_generate_rays", ptr(c2w), n, int(h), int(w), float(focal), float(near), float(far), int(bool(ndc)),
+          float(ndc_near), ptr(o), ptr(di), ptr(v), ptr(r), ptr(ne), ptr(fa), stream())
+    return o, di, v, r, ne, fa
+
+
+def convert_to_ndc(origins, directions, focal: float, w: int, h: int, near: float = 1.0):
+    origins, directions = dev(origins, "origins"), dev(directions, "directions")
+    oo, do = torch.empty_like(origins), torch.empty_like(directions)
+    _call("m360_convert_to_ndc", ptr(origins), ptr(directions), origins.numel() // 3, float(focal), int(w), int(h),
+          float(near), ptr(oo), ptr(do), stream())
+    return oo, do

@@ -339,3 +339,46 @@ def render_image(rays: Rays, height: int, width: int, sd, hp: Hyper, chunks: int
         rgbs.append(r), dists.append(d), accs.append(a)
     rgb8 = to8b(torch.cat(rgbs, 0).reshape(height, width, 3).numpy())
     return rgb8, torch.cat(dists, 0).reshape(height, width).numpy(), torch.cat(accs, 0).reshape(height, width).numpy()
+
+
+# --------------------------------------------------------------------------- ray generation (row f1)
+def convert_to_ndc(origins: np.ndarray, directions: np.ndarray, focal, w, h, near=1.0):
+    """intern/ray.py:59-79 (NumPy, fp32 arrays with Python-float scalars like the reference)."""
+    t = -(near + origins[..., 2]) / (directions[..., 2] + 1e-15)
+    p = origins + t[..., None] * directions
+    iz = p[..., 2] + 1e-15
+    dzr = directions[..., 2] + 1e-15
+    sx, sy = (2 * focal) / w, (2 * focal) / h
+    o = np.stack([-sx * (p[..., 0] / iz), -sy * (p[..., 1] / iz), 1 + 2 * near / iz], -1)
+    d = np.stack([-sx * (directions[..., 0] / dzr - p[..., 0] / iz), -sy * (directions[..., 1] / dzr - p[..., 1] / iz),
+                  -2 * near / iz], -1)
+    return o, d
+
+
+def _neighbour_dist(m: np.ndarray, axis: int) -> np.ndarray:
+    """||m[i] - m[i+1]|| along `axis` (n-1 entries) padded to n with the SECOND-to-last difference: the
+    reference appends `dx[:, -2:-1]`, i.e. entry n-3 of the n-1 differences (dataset.py:129-131)."""
+    a = np.take(m, range(0, m.shape[axis] - 1), axis=axis)
+    b = np.take(m, range(1, m.shape[axis]), axis=axis)
+    dist = np.sqrt(np.sum((a - b) ** 2, -1))
+    last = np.take(dist, [dist.shape[axis] - 2], axis=axis)
+    return np.concatenate([dist, last], axis)
+
+
+def generate_rays(cam_to_world: np.ndarray, h: int, w: int, focal, near, far, ndc: bool = False) -> Dict[str, np.ndarray]:
+    """dataset.py:109-145 (pinhole) and, for ndc=True, dataset.py:364-387; flattened to [n*h*w, .]."""
+    c2w = np.asarray(cam_to_world, dtype=np.float32)[:, :3, :4]
+    x, y = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="xy")
+    cam = np.stack([(x - w * 0.5 + 0.5) / focal, -(y - h * 0.5 + 0.5) / focal, -np.ones_like(x)], -1)
+    dirs = (cam[None, :, :, None, :] * c2w[:, None, None, :, :3]).sum(-1)
+    origins = np.broadcast_to(c2w[:, None, None, :, 3], dirs.shape)
+    viewdirs = dirs / np.linalg.norm(dirs, axis=-1, keepdims=True)
+    if ndc:
+        origins, dirs = convert_to_ndc(origins, dirs, focal, w, h)
+        spread = 0.5 * (_neighbour_dist(origins, 1) + _neighbour_dist(origins, 2))
+    else:
+        spread = _neighbour_dist(dirs, 1)
+    radii = spread[..., None] * 2 / np.sqrt(12)
+    ones = np.ones_like(radii)
+    out = dict(origins=origins, directions=dirs, viewdirs=viewdirs, radii=radii, near=ones * near, far=ones * far)
+    return {k: np.ascontiguousarray(v, dtype=np.float32).reshape(-1, v.shape[-1]) for k, v in out.items()}

@@ -269,9 +269,51 @@ def g9():
     save("g9_render_image", **out)
 
 
+def g10():
+    """Ray generation: NeRFDataset.generate_rays (dataset.py:109-145),
+    LLFF.generate_rays (dataset.py:364-387) and convert_to_ndc (intern/ray.py:59-79) on synthetic poses.
+    dataset.py imports cv2 (absent here, only used for Blender down-scaling): stubbed with an empty module."""
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    import dataset as ref_dataset
+    g = np.random.Generator(np.random.PCG64(1010))
+    out = {}
+    n_cams, h, w = 3, 13, 17
+
+    def random_pose():
+        a = g.normal(size=(3, 3))
+        q, _ = np.linalg.qr(a)
+        return np.concatenate([q, g.normal(size=(3, 1)) * 2.0], axis=1)
+
+    c2w = np.stack([random_pose() for _ in range(n_cams)], 0).astype(np.float32)
+    # LLFF-style forward-facing poses: small rotations about the identity, cameras looking down -z
+    c2w_ff = np.stack([np.concatenate([np.linalg.qr(np.eye(3) + 0.05 * g.normal(size=(3, 3)))[0] * np.array([1, 1, 1]),
+                                       g.normal(size=(3, 1)) * 0.2], axis=1) for _ in range(n_cams)], 0).astype(np.float32)
+    for i in range(n_cams):  # make sure z column points so that directions have dz < 0 (valid NDC projection)
+        if c2w_ff[i, 2, 2] < 0:
+            c2w_ff[i, :, 2] *= -1
+    out["c2w"], out["c2w_ff"] = c2w, c2w_ff
+    out["cfg"] = np.array([n_cams, h, w])
+    for name, cls, poses, focal, near, far in (("pinhole", ref_dataset.NeRFDataset, c2w, 555.5, 2.0, 6.0),
+                                               ("llff", ref_dataset.LLFF, c2w_ff, 38.25, 0.0, 1.0)):
+        obj = object.__new__(cls)
+        obj.h, obj.w, obj.focal, obj.cam_to_world, obj.near, obj.far = h, w, focal, poses, near, far
+        obj.generate_rays()
+        out[name + "_focal_near_far"] = np.array([focal, near, far], dtype=np.float64)
+        for k in synthetic.RAY_FIELDS:
+            out[f"{name}_{k}"] = np.asarray(getattr(obj.rays, k), dtype=np.float32).reshape(-1, getattr(obj.rays, k).shape[-1])
+    o, d = ref_ray.convert_to_ndc(out["pinhole_origins"].reshape(n_cams, h, w, 3) * 0 + c2w_ff[:, None, None, :, 3],
+                                  out["llff_directions"].reshape(n_cams, h, w, 3) * 0 + 1.0 * np.array([0.1, -0.2, -1.0], dtype=np.float32),
+                                  38.25, w, h, near=1.0)
+    out["ndc_in_o"] = (out["pinhole_origins"].reshape(n_cams, h, w, 3) * 0 + c2w_ff[:, None, None, :, 3]).astype(np.float32)
+    out["ndc_in_d"] = (out["llff_directions"].reshape(n_cams, h, w, 3) * 0 + np.array([0.1, -0.2, -1.0], dtype=np.float32)).astype(np.float32)
+    out["ndc_out_o"], out["ndc_out_d"] = o.astype(np.float32), d.astype(np.float32)
+    save("g10_ray_generation", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
-    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9)
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
     for k in which:
         print(k)
         table[k]()

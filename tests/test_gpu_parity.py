@@ -208,7 +208,8 @@ def test_linear_mfma_against_fp64(dev):
 
 
 @pytest.mark.parametrize("M,n,k,act", [(256 * 37 + 5, 1024, 64, 1), (256 * 530, 256, 64, 0), (256 * 9, 256, 256, 1),
-                                        (256 * 64, 1024, 1024, 1)])
+                                        (256 * 64, 1024, 1024, 1), (256, 768, 32, 1), (256 * 3, 512, 96, 0),
+                                        (256 * 21 + 255, 768, 64, 1), (256 * 300 + 1, 256, 32, 0)])
 def test_linear_kernel_variants_bit_identical(dev, M, n, k, act):
     """The persistent LDS-DMA kernel (many tiles per workgroup: exercises the tile hand-over, the LDS-staged
     epilogue and the ragged-row split) must reproduce the workgroup-per-tile kernel bit for bit, every element."""
@@ -362,6 +363,71 @@ def test_c2_full_size_properties(dev):
     rp = Rays(*[f[perm].contiguous() for f in rays])
     rgb_p, dist_p, acc_p = m(rp)
     close(rgb_p, rgb[perm], atol=2e-5), close(acc_p, acc[perm], atol=2e-5), close(dist_p, dist[perm], atol=2e-5)
+
+
+@pytest.mark.parametrize("name,ndc", [("pinhole", False), ("llff", True)])
+def test_g10_ray_generation(golden, dev, name, ndc):
+    """Row (f1): rays generated on the device vs the reference's dataset code (fixture G10) and the oracle."""
+    from mipnerf360_amd.intern import ray as R
+    from oracle import ref_path as O
+    g = golden("g10_ray_generation")
+    n, h, w = (int(x) for x in g["cfg"])
+    f, near, far = (float(x) for x in g[name + "_focal_near_far"])
+    c2w = g["c2w_ff"] if ndc else g["c2w"]
+    rays = R.generate_rays(D(c2w, dev), h, w, f, near, far, ndc)
+    for k in synthetic.RAY_FIELDS:
+        assert getattr(rays, k).shape == g[f"{name}_{k}"].shape
+        close(getattr(rays, k), g[f"{name}_{k}"], atol=2e-7, rtol=4e-5)
+    o, d = R.convert_to_ndc(D(g["ndc_in_o"], dev), D(g["ndc_in_d"], dev), 38.25, w, h, 1.0)
+    close(o, g["ndc_out_o"], atol=2e-7), close(d, g["ndc_out_d"], atol=2e-7)
+    o_np, d_np = R.convert_to_ndc(g["ndc_in_o"], g["ndc_in_d"], 38.25, w, h, 1.0)   # NumPy in -> NumPy out
+    assert isinstance(o_np, np.ndarray) and np.allclose(o_np, g["ndc_out_o"], atol=2e-7)
+    # a larger, seeded case against the oracle (ragged sizes, one camera given as a single 3x4 pose)
+    gen = np.random.Generator(np.random.PCG64(5))
+    q, _ = np.linalg.qr(np.eye(3) + 0.1 * gen.normal(size=(3, 3)))
+    pose = np.concatenate([q, gen.normal(size=(3, 1))], 1).astype(np.float32)
+    if pose[2, 2] < 0:
+        pose[:, 2] *= -1
+    ro = O.generate_rays(pose[None], 67, 131, 210.0, near, far, ndc)
+    rd = R.generate_rays(D(pose, dev), 67, 131, 210.0, near, far, ndc)
+    for k in synthetic.RAY_FIELDS:
+        close(getattr(rd, k), ro[k], atol=2e-7, rtol=1e-4)
+    with pytest.raises(RuntimeError):
+        R.generate_rays(D(pose, dev), 2, 131, 210.0, near, far, ndc)
+
+
+def test_render_view_matches_render_image(dev):
+    """Pose in -> frame out with rays generated on the device == render_image on host-generated rays."""
+    from mipnerf360_amd.intern.ray import Rays
+    from oracle import ref_path as O
+    h, w, n = 21, 30, 16
+    m = build_model(synthetic.make_state_dict(32, 64, seed=4), dev, n, 32, 64, False)
+    gen = np.random.Generator(np.random.PCG64(9))
+    q, _ = np.linalg.qr(np.eye(3) + 0.1 * gen.normal(size=(3, 3)))
+    pose = np.concatenate([q, gen.normal(size=(3, 1)) * 0.1], 1).astype(np.float32)
+    if pose[2, 2] < 0:
+        pose[:, 2] *= -1
+    r = O.generate_rays(pose[None], h, w, 40.0, 0.0, 1.0, True)
+    rays_cpu = Rays(*[torch.from_numpy(r[k]) for k in synthetic.RAY_FIELDS])
+    a = m.render_image(rays_cpu, h, w, chunks=128)
+    b = m.render_view(torch.from_numpy(pose), h, w, 40.0, 0.0, 1.0, ndc=True, chunks=128)
+    assert np.abs(a[0].astype(int) - b[0].astype(int)).max() <= 1
+    close(a[1], b[1], atol=1e-4, rtol=1e-4), close(a[2], b[2], atol=1e-4)
+
+
+def test_render_image_partial_last_chunk_vs_oracle(dev):
+    """chunks that do not divide the ray count: the reference's partition keeps a short last chunk (model.py:262)."""
+    from mipnerf360_amd.intern.ray import Rays
+    from oracle import ref_path as O
+    h, w, n = 50, 37, 24
+    sd = synthetic.make_state_dict(32, 32, seed=6)
+    m = build_model(sd, dev, n, 32, 32, True)
+    r = synthetic.make_rays("lego", h * w, seed=12)
+    rays_cpu = Rays(*[torch.from_numpy(r[k]) for k in synthetic.RAY_FIELDS])
+    rgb8, dist, acc = m.render_image(rays_cpu, h, w, chunks=512)
+    o8, od, oa = O.render_image(O.rays_from_numpy(r), h, w, O.to_torch_state_dict(sd), O.Hyper(num_samples=n, white_bkgd=True), chunks=512)
+    assert np.abs(rgb8.astype(int) - o8.astype(int)).max() <= 1 and (rgb8 != o8).mean() < 0.02
+    close(acc, oa, atol=RGB_TOL, rtol=0), close(dist, od, atol=1e-4, rtol=1e-4)
 
 
 def test_empty_batch(dev):

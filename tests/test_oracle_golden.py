@@ -125,6 +125,20 @@ def test_g9_render_image(golden, chunks):
     close(acc, g[f"c{chunks}_acc"], atol=2e-6)
 
 
+@pytest.mark.parametrize("name,ndc", [("pinhole", False), ("llff", True)])
+def test_g10_ray_generation(golden, name, ndc):
+    """Row (f1): NeRFDataset.generate_rays / LLFF.generate_rays / convert_to_ndc of the reference."""
+    g = golden("g10_ray_generation")
+    n, h, w = (int(x) for x in g["cfg"])
+    f, near, far = (float(x) for x in g[name + "_focal_near_far"])
+    r = O.generate_rays(g["c2w_ff"] if ndc else g["c2w"], h, w, f, near, far, ndc)
+    for k in synthetic.RAY_FIELDS:
+        assert r[k].shape == g[f"{name}_{k}"].shape
+        close(r[k], g[f"{name}_{k}"], atol=1e-7, rtol=2e-5)
+    o, d = O.convert_to_ndc(g["ndc_in_o"], g["ndc_in_d"], 38.25, w, h, 1.0)
+    close(o, g["ndc_out_o"], atol=1e-7), close(d, g["ndc_out_d"], atol=1e-7)
+
+
 def test_g9_chunk_dependence_is_real(golden):
     """The reference's global-norm contraction makes results depend on the chunk partition."""
     g = golden("g9_render_image")
