@@ -147,6 +147,12 @@ int m360_resample_t(const float *t_vals /*[B,N+1]*/, const float *weights /*[B,N
                     const float *u_rand, int B, int N, float resample_padding, float *t_new,
                     m360_stream_t stream);
 
+/* Extension of m360_resample_t: num_out resampled values per ray instead of N+1 (the reference cannot
+ * express different proposal / NeRF sample counts, intern/ray.py:147; used for "64+128" rendering). */
+int m360_resample_t_n(const float *t_vals, const float *weights, const float *u_rand, int B, int N,
+                      int num_out, float resample_padding, float *t_new /*[B,num_out]*/,
+                      m360_stream_t stream);
+
 /* intern/ray.py:155-191; rgb[B,N,3], density[B,N]; weights may be NULL. */
 int m360_volumetric_rendering(const float *rgb, const float *density, const float *t_vals,
                               const float *dirs, int B, int N, int white_bkgd, float *comp_rgb,
@@ -184,6 +190,12 @@ int m360_prop_finish(const float *act, int ld, const float *head_w /*[k_pad]*/,
                      const float *t_vals, const float *dirs, const float *u_rand, int B, int N,
                      float resample_padding, float *weights /*[B,N]*/, float *t_new /*[B,N+1] or NULL*/,
                      m360_stream_t stream);
+
+/* m360_prop_finish with num_out resampled values per ray (t_new[B,num_out]) instead of N+1. */
+int m360_prop_finish_n(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
+                       float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
+                       int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
+                       m360_stream_t stream);
 
 /* density/colour heads + activations + alpha composite: head_w[4,k_pad] rows = (density, r, g, b).
  * Replaces model.py:150-158,180-186 and intern/ray.py:155-191. */
@@ -223,6 +235,7 @@ typedef struct {
     int viewdir_min_deg, viewdir_max_deg;
     int white_bkgd;
     float density_bias, rgb_padding, resample_padding;
+    int num_samples_fine; /* extension: NeRF-stage samples per ray; 0 = num_samples (the reference's behaviour) */
 } m360_hyper_t; /* ctor arguments of model.py:203-215 */
 
 typedef struct {
@@ -232,9 +245,9 @@ typedef struct {
     /* optional (NULL to skip): */
     float *t_hat;    /* [B,N+1] proposal t_vals            (model.py:94)  */
     float *w_hat;    /* [B,N]   proposal weights           (model.py:94)  */
-    float *t_vals;   /* [B,N+1] resampled t_vals + 1e-6    (model.py:194,196) */
-    float *fine_w;   /* [B,N]   nerf weights               (model.py:193) */
-    float *s_vals;   /* [B,N+1]                            (model.py:196) */
+    float *t_vals;   /* [B,Nf+1] resampled t_vals + 1e-6   (model.py:194,196); Nf = fine sample count */
+    float *fine_w;   /* [B,Nf]   nerf weights              (model.py:193) */
+    float *s_vals;   /* [B,Nf+1]                           (model.py:196) */
 } m360_outputs_t;
 
 size_t m360_forward_workspace_bytes(int B, int N, const m360_model_t *model_host);

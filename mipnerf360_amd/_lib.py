@@ -34,7 +34,7 @@ class ModelStruct(C.Structure):  # m360_model_t
 class HyperStruct(C.Structure):  # m360_hyper_t
     _fields_ = [("num_samples", C.c_int), ("viewdir_min_deg", C.c_int), ("viewdir_max_deg", C.c_int),
                 ("white_bkgd", C.c_int), ("density_bias", C.c_float), ("rgb_padding", C.c_float),
-                ("resample_padding", C.c_float)]
+                ("resample_padding", C.c_float), ("num_samples_fine", C.c_int)]
 
 
 class OutputsStruct(C.Structure):  # m360_outputs_t
@@ -67,6 +67,8 @@ SIGNATURES = {
     "m360_density_to_weight": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "m360_sorted_pdf": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "m360_resample_t": (_i, [_vp, _vp, _vp, _i, _i, _fl, _vp, _vp]),
+    "m360_resample_t_n": (_i, [_vp, _vp, _vp, _i, _i, _i, _fl, _vp, _vp]),
+    "m360_prop_finish_n": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_volumetric_rendering": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "m360_to8b": (_i, [_vp, _l, _vp, _vp]),
     "m360_generate_rays": (_i, [_vp, _i, _i, _i, _fl, _fl, _fl, _i, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -79,17 +79,20 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     return L;
 }
 
+static inline int n_fine(const m360_hyper_t *h) { return h->num_samples_fine > 0 ? h->num_samples_fine : h->num_samples; }
+static inline int n_max(const m360_hyper_t *h) { return n_fine(h) > h->num_samples ? n_fine(h) : h->num_samples; }
+
 static int validate(const m360_rays_t *r, const m360_model_t *m, const m360_hyper_t *h, int B,
                     const void *ws, size_t ws_bytes, const char *who) {
     if (!r || !m || !h) return fail(M360_ERR_INVALID_ARGUMENT, "%s: null descriptor", who);
-    if (B < 0 || h->num_samples < 1) return fail(M360_ERR_INVALID_ARGUMENT, "%s: B=%d num_samples=%d", who, B, h->num_samples);
+    if (B < 0 || h->num_samples < 1 || h->num_samples_fine < 0) return fail(M360_ERR_INVALID_ARGUMENT, "%s: B=%d num_samples=%d num_samples_fine=%d", who, B, h->num_samples, h->num_samples_fine);
     if (B == 0) return M360_OK;  // empty batch: nothing is dereferenced
     if (!r->origins || !r->directions || !r->viewdirs || !r->radii || !r->near || !r->far)
         return fail(M360_ERR_INVALID_ARGUMENT, "%s: null ray field", who);
     const int vd_ch = 4 * (h->viewdir_max_deg - h->viewdir_min_deg);
     if (vd_ch < 0 || m->in_ch != kIpeCh + vd_ch || m->in_pad < m->in_ch || m->in_pad % 32 || m->hp_pad % 32 || m->hn_pad % 32 || m->hp_pad < 32 || m->hn_pad < 32)
         return fail(M360_ERR_INVALID_ARGUMENT, "%s: model dims inconsistent (in_ch=%d in_pad=%d hp_pad=%d hn_pad=%d vd_ch=%d)", who, m->in_ch, m->in_pad, m->hp_pad, m->hn_pad, vd_ch);
-    const FwdLayout L = layout_for(B, h->num_samples, m);
+    const FwdLayout L = layout_for(B, n_max(h), m);
     if (B > 0 && (!ws || ws_bytes < L.total)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "%s: workspace %zu < required %zu bytes", who, ws_bytes, L.total);
     if ((uintptr_t)ws & 255) return fail(M360_ERR_INVALID_ARGUMENT, "%s: workspace must be 256-byte aligned", who);
     return M360_OK;
@@ -106,7 +109,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
                       const float *t_rand, float *t_hat, float *w_hat, float *t_new, char *ws,
                       m360_stream_t st) {
     const int N = h->num_samples;
-    const FwdLayout L = layout_for(B, N, m);
+    const FwdLayout L = layout_for(B, n_max(h), m);
     const int vd_ch = m->in_ch - kIpeCh;
     float *vdenc = reinterpret_cast<float *>(ws + L.vdenc);
     float *feat = reinterpret_cast<float *>(ws + L.feat);
@@ -120,14 +123,14 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     M360_TRY(m360_linear(a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
     M360_TRY(m360_linear(b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
     M360_TRY(m360_linear(a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, hp, st));
-    return m360_prop_finish(b, hp, m->prop_head_w, m->prop_head_b, hp, h->density_bias, t_hat, r->directions, nullptr, B, N, h->resample_padding, w_hat, t_new, st);
+    return m360_prop_finish_n(b, hp, m->prop_head_w, m->prop_head_b, hp, h->density_bias, t_hat, r->directions, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st);
 }
 
 // resampled t -> features -> 8 NeRF layers -> heads + composite
 static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hyper_t *h, int B,
                       const float *t1, const m360_outputs_t *out, char *ws, m360_stream_t st) {
-    const int N = h->num_samples;
-    const FwdLayout L = layout_for(B, N, m);
+    const int N = n_fine(h);  // the NeRF stage runs on the resampled intervals
+    const FwdLayout L = layout_for(B, n_max(h), m);
     const int vd_ch = m->in_ch - kIpeCh;
     float *vdenc = reinterpret_cast<float *>(ws + L.vdenc);
     float *feat = reinterpret_cast<float *>(ws + L.feat);
@@ -232,9 +235,9 @@ int m360_nerf_forward(const m360_rays_t *rays, const m360_model_t *model, const 
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_forward: t_hat, w_hat, out.rgb/distance/acc are required");
     if (B == 0) return M360_OK;
     char *ws = static_cast<char *>(workspace);
-    const FwdLayout L = layout_for(B, hyper->num_samples, model);
+    const FwdLayout L = layout_for(B, n_max(hyper), model);
     float *t1 = reinterpret_cast<float *>(ws + L.t1);
-    M360_TRY(m360_resample_t(t_hat, w_hat, u_rand, B, hyper->num_samples, hyper->resample_padding, t1, stream));
+    M360_TRY(m360_resample_t_n(t_hat, w_hat, u_rand, B, hyper->num_samples, n_fine(hyper) + 1, hyper->resample_padding, t1, stream));
     return nerf_stage(rays, model, hyper, B, t1, out, ws, stream);
 }
 
@@ -246,7 +249,7 @@ int m360_forward(const m360_rays_t *rays, const m360_model_t *model, const m360_
     if (!out || !out->rgb || !out->distance || !out->acc) return fail(M360_ERR_INVALID_ARGUMENT, "m360_forward: out.rgb/distance/acc are required");
     if (B == 0) return M360_OK;
     char *ws = static_cast<char *>(workspace);
-    const FwdLayout L = layout_for(B, hyper->num_samples, model);
+    const FwdLayout L = layout_for(B, n_max(hyper), model);
     float *t0 = out->t_hat ? out->t_hat : reinterpret_cast<float *>(ws + L.t0);
     float *what = out->w_hat ? out->w_hat : reinterpret_cast<float *>(ws + L.what);
     float *t1 = reinterpret_cast<float *>(ws + L.t1);

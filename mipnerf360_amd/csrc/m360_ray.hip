@@ -264,7 +264,7 @@ __device__ __forceinline__ void head_dots(const float *__restrict__ act_ray, int
 __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     const float *__restrict__ act, int ld, const float *__restrict__ head_w,
     const float *__restrict__ head_b, int k_pad, float density_bias, const float *__restrict__ t_vals,
-    const float *__restrict__ dirs, const float *__restrict__ u_rand, int N, float padding,
+    const float *__restrict__ dirs, const float *__restrict__ u_rand, int N, int ns, float padding,
     float *__restrict__ weights, float *__restrict__ t_new) {
     extern __shared__ float smem[];
     const int b = blockIdx.x, l = lane_id();
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     if (t_new == nullptr) return;
     wave_blur(w, N, padding, w2);
     wave_sync();
-    wave_sorted_pdf(t, w2, cdf, nb, nb, u_rand ? u_rand + (long)b * nb : nullptr, t_new + (long)b * nb);
+    wave_sorted_pdf(t, w2, cdf, nb, ns, u_rand ? u_rand + (long)b * ns : nullptr, t_new + (long)b * ns);
 }
 
 // model.py:150-158,180-186 + intern/ray.py:155-191
@@ -357,12 +357,17 @@ int m360_sorted_pdf(const float *bins, const float *weights, const float *u_rand
 
 int m360_resample_t(const float *t_vals, const float *weights, const float *u_rand, int B, int N,
                     float resample_padding, float *t_new, m360_stream_t stream) {
-    if (!t_vals || !weights || !t_new || B < 0 || N < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_resample_t: bad argument");
+    return m360_resample_t_n(t_vals, weights, u_rand, B, N, N + 1, resample_padding, t_new, stream);
+}
+
+int m360_resample_t_n(const float *t_vals, const float *weights, const float *u_rand, int B, int N, int num_out,
+                      float resample_padding, float *t_new, m360_stream_t stream) {
+    if (!t_vals || !weights || !t_new || B < 0 || N < 1 || num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_resample_t: bad argument");
     if (B == 0) return M360_OK;
     const int nb = N + 1;
     const size_t lds = (size_t)kRayWaves * 4 * nb * sizeof(float);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_resample_t: N=%d too large for LDS", N);
-    hipLaunchKernelGGL(resample_kernel<true>, dim3((B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * kWave), lds, S_(stream), t_vals, weights, u_rand, B, nb, nb, resample_padding, t_new);
+    hipLaunchKernelGGL(resample_kernel<true>, dim3((B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * kWave), lds, S_(stream), t_vals, weights, u_rand, B, nb, num_out, resample_padding, t_new);
     return check_launch("resample_t");
 }
 
@@ -389,12 +394,20 @@ int m360_prop_finish(const float *act, int ld, const float *head_w, const float 
                      float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                      int B, int N, float resample_padding, float *weights, float *t_new,
                      m360_stream_t stream) {
+    return m360_prop_finish_n(act, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, N + 1, resample_padding, weights, t_new, stream);
+}
+
+int m360_prop_finish_n(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
+                       float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
+                       int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
+                       m360_stream_t stream) {
+    if (num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: num_out=%d", num_out);
     if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < 4 || k_pad % 4 != 0 || ld < k_pad || ld % 4 != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: bad argument");
     if (B == 0) return M360_OK;
     const size_t lds = ((size_t)k_pad + 5 * (N + 1)) * sizeof(float);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    hipLaunchKernelGGL(prop_finish_kernel, dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, resample_padding, weights, t_new);
+    hipLaunchKernelGGL(prop_finish_kernel, dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
     return check_launch("prop_finish");
 }
 

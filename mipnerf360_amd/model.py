@@ -210,9 +210,11 @@ class nerf_net(nn.Module):
         return self._packed.refresh([self.model[i] for i in range(0, 16, 2)],
                                     [self.final_density[0], self.final_color[0]])
 
-    def _hyper(self, N):
-        return _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, self.white_bkgd, self.density_bias,
-                             self.rgb_padding, self.resample_padding)
+    def _hyper(self, N, n_fine=0):
+        h = _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, self.white_bkgd, self.density_bias,
+                          self.rgb_padding, self.resample_padding)
+        h.num_samples_fine = int(n_fine or 0)
+        return h
 
     def _stash(self, outs):
         # model.py:192-196: kept on the module for the distillation / regularisation losses
@@ -225,12 +227,13 @@ class nerf_net(nn.Module):
         dev = keep[0].device
         t_vals, coarse_weights = ops.dev(t_vals, "t_vals"), ops.dev(coarse_weights, "coarse_weights")
         N = t_vals.shape[-1] - 1
+        Nf = getattr(self, "num_samples_fine", None) or N  # extension; None = the reference's behaviour
         mstruct = _model_struct(self.input_size, None, self._pack())
-        hyper = self._hyper(N)
-        outs = _alloc_outputs(B, N, dev, with_prop=False)
+        hyper = self._hyper(N, Nf)
+        outs = _alloc_outputs(B, Nf, dev, with_prop=False)
         ostruct = _outputs_struct(outs)
-        u_rand = torch.rand(B, N + 1, device=dev) if self.randomized else None
-        ws = _ws_for(B, N, mstruct, dev)
+        u_rand = torch.rand(B, Nf + 1, device=dev) if self.randomized else None
+        ws = _ws_for(B, max(N, Nf), mstruct, dev)
         _lib.check(_lib.lib().m360_nerf_forward(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, t_vals.data_ptr(),
                                                 coarse_weights.data_ptr(), ops.ptr(u_rand), C.byref(ostruct),
                                                 ws.data_ptr(), ws.numel(), ops.stream()), "m360_nerf_forward")
@@ -260,10 +263,14 @@ class mipNeRF360(nn.Module):
 
     def __init__(self, randomized=False, num_samples=128, hidden_proposal=256, hidden_nerf=1024, density_bias=-1,
                  rgb_padding=0.001, resample_padding=0.01, white_bkgd=False, viewdir_min_deg=0, viewdir_max_deg=4,
-                 device=torch.device("cuda")):
+                 device=torch.device("cuda"), num_samples_fine=None):
+        """Same arguments as the reference (model.py:203-215).  `num_samples_fine` is an extension (keyword,
+        last): number of NeRF-stage samples per ray when it should differ from the proposal count
+        ("64+128" rendering, BASELINE configs[2]); None keeps the reference's behaviour (equal counts)."""
         super().__init__()
         self.randomized = randomized
         self.num_samples = num_samples
+        self.num_samples_fine = num_samples_fine
         self.hidden_proposal = hidden_proposal
         self.hidden_nerf = hidden_nerf
         self.density_bias = density_bias
@@ -284,6 +291,7 @@ class mipNeRF360(nn.Module):
                                  resample_padding=self.resample_padding, white_bkgd=self.white_bkgd,
                                  viewdir_min_deg=self.viewdir_min_deg, viewdir_max_deg=self.viewdir_max_deg,
                                  device=self.device)
+        self.nerf_net.num_samples_fine = num_samples_fine
         self.to(device)
 
     # ------------------------------------------------------------------ fused two-stage forward
@@ -291,16 +299,17 @@ class mipNeRF360(nn.Module):
         rstruct, keep, B = _rays_struct(rays)
         dev = keep[0].device
         N = self.prop_net.num_samples
+        Nf = self.nerf_net.num_samples_fine or N
         mstruct = _model_struct(self.prop_net.input_size, self.prop_net._pack(), self.nerf_net._pack())
-        hyper = self.nerf_net._hyper(N)
+        hyper = self.nerf_net._hyper(N, Nf)
         if stash:
-            outs = _alloc_outputs(B, N, dev, with_prop=False, rgb=rgb, distance=distance, acc=acc)
+            outs = _alloc_outputs(B, Nf, dev, with_prop=False, rgb=rgb, distance=distance, acc=acc)
         else:
             outs = dict(rgb=rgb if rgb is not None else torch.empty(B, 3, device=dev),
                         distance=distance if distance is not None else torch.empty(B, device=dev),
                         acc=acc if acc is not None else torch.empty(B, device=dev))
         ostruct = _outputs_struct(outs)
-        ws = _ws_for(B, N, mstruct, dev)
+        ws = _ws_for(B, max(N, Nf), mstruct, dev)
         _lib.check(_lib.lib().m360_forward(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, C.byref(ostruct),
                                            ws.data_ptr(), ws.numel(), ops.stream()), "m360_forward")
         if stash:

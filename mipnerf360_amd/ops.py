@@ -219,12 +219,15 @@ def sorted_pdf(bins, weights, num_samples: int, u_rand=None) -> torch.Tensor:
     return out
 
 
-def resample_t(t_vals, weights, resample_padding: float, u_rand=None) -> torch.Tensor:
+def resample_t(t_vals, weights, resample_padding: float, u_rand=None, num_out: Optional[int] = None) -> torch.Tensor:
+    """num_out (extension): number of resampled values per ray; None = t_vals.shape[-1] as in the reference."""
     t_vals, weights = dev(t_vals, "t_vals"), dev(weights, "weights")
     B, M = t_vals.shape
-    out = torch.empty_like(t_vals)
+    n_out = M if num_out is None else int(num_out)
+    out = torch.empty(B, n_out, device=t_vals.device)
     u = None if u_rand is None else dev(u_rand, "u_rand")
-    _call("m360_resample_t", ptr(t_vals), ptr(weights), ptr(u), B, M - 1, float(resample_padding), ptr(out), stream())
+    _call("m360_resample_t_n", ptr(t_vals), ptr(weights), ptr(u), B, M - 1, n_out, float(resample_padding), ptr(out),
+          stream())
     return out
 
 

@@ -231,10 +231,11 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, u_rand: Optional[t
     return b0 + tt * (b1 - b0)
 
 
-def resample_t(t_vals, weights, resample_padding, u_rand=None):
-    """intern/ray.py:136-149 (new t only)."""
+def resample_t(t_vals, weights, resample_padding, u_rand=None, num_out=None):
+    """intern/ray.py:136-149 (new t only).  num_out: extension for unequal proposal / NeRF sample counts
+    (the reference always draws t_vals.shape[-1] values, :147)."""
     w = blur_weights(weights, resample_padding)
-    return sorted_piecewise_constant_pdf(t_vals, w, t_vals.shape[-1], u_rand)
+    return sorted_piecewise_constant_pdf(t_vals, w, num_out or t_vals.shape[-1], u_rand)
 
 
 def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd):
@@ -287,6 +288,7 @@ class Hyper(NamedTuple):
     white_bkgd: bool = False
     viewdir_min_deg: int = 0
     viewdir_max_deg: int = 4
+    num_samples_fine: int = 0  # extension ("64+128"); 0 = num_samples, the reference's behaviour
 
 
 def prop_forward(rays: Rays, sd, hp: Hyper, t_rand=None):
@@ -304,7 +306,8 @@ def prop_forward(rays: Rays, sd, hp: Hyper, t_rand=None):
 
 def nerf_forward(rays: Rays, t_vals, coarse_weights, sd, hp: Hyper, u_rand=None):
     """nerf_net.forward, model.py:163-200 -> (rgb, dist, acc, t_vals+1e-6, weights, s_vals)."""
-    t_new = resample_t(t_vals, coarse_weights, hp.resample_padding, u_rand)
+    t_new = resample_t(t_vals, coarse_weights, hp.resample_padding, u_rand,
+                       (hp.num_samples_fine + 1) if hp.num_samples_fine else None)
     mean, cov = para_rays(t_new, rays.origins, rays.directions, rays.radii)
     x = encode_inputs(mean, cov, rays.viewdirs, hp.viewdir_min_deg, hp.viewdir_max_deg)
     raw_density, raw_rgb = nerf_mlp(x, sd)

@@ -430,6 +430,32 @@ def test_render_image_partial_last_chunk_vs_oracle(dev):
     close(acc, oa, atol=RGB_TOL, rtol=0), close(dist, od, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("np_,nf", [(64, 128), (32, 16), (24, 100)])
+def test_unequal_sample_counts_extension(dev, np_, nf):
+    """BASELINE configs[2] "hierarchical 64+128": proposal and NeRF stages with different sample counts.
+    The reference cannot express this (intern/ray.py:147); parity is against the oracle's same extension."""
+    from mipnerf360_amd.model import mipNeRF360
+    from mipnerf360_amd import ops
+    from oracle import ref_path as O
+    sd = synthetic.make_state_dict(64, 128, seed=11)
+    r = synthetic.make_rays("garden", 200, seed=13)
+    m = mipNeRF360(num_samples=np_, hidden_proposal=64, hidden_nerf=128, device=dev, num_samples_fine=nf)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    rays = dev_rays(r, dev)
+    rgb, dist, acc = m(rays)
+    assert m.nerf_net.t_vals.shape == (200, nf + 1) and m.nerf_net.fine_weights.shape == (200, nf)
+    hp = O.Hyper(num_samples=np_, num_samples_fine=nf)
+    o = O.forward(O.rays_from_numpy(r), O.to_torch_state_dict(sd), hp)
+    close_render(rgb, dist, acc, *o)
+    # staged API gives the same result
+    t_hat, w_hat = m.prop_net.forward(rays)
+    assert t_hat.shape == (200, np_ + 1)
+    out = m.nerf_net.forward(rays, t_hat, w_hat)
+    close(out[0], rgb, atol=1e-6)
+    tn = ops.resample_t(t_hat, w_hat, 0.01, num_out=nf + 1)
+    close(tn, O.resample_t(t_hat.cpu(), w_hat.cpu(), 0.01, None, nf + 1), atol=8e-6)
+
+
 def test_empty_batch(dev):
     m = build_model(synthetic.make_state_dict(32, 32, seed=1), dev, 16, 32, 32, False)
     r = dev_rays(synthetic.make_rays("lego", 0, seed=1), dev)

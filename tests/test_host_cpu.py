@@ -76,9 +76,10 @@ def test_api_surface_matches_reference_signatures():
     from mipnerf360_amd import model
     from mipnerf360_amd.intern import encoding, parameterization, ray
     sig = lambda f: list(inspect.signature(f).parameters)  # noqa: E731
-    assert sig(model.mipNeRF360.__init__)[1:] == ["randomized", "num_samples", "hidden_proposal", "hidden_nerf",
-                                                  "density_bias", "rgb_padding", "resample_padding", "white_bkgd",
-                                                  "viewdir_min_deg", "viewdir_max_deg", "device"]
+    assert sig(model.mipNeRF360.__init__)[1:12] == ["randomized", "num_samples", "hidden_proposal", "hidden_nerf",
+                                                    "density_bias", "rgb_padding", "resample_padding", "white_bkgd",
+                                                    "viewdir_min_deg", "viewdir_max_deg", "device"]
+    assert sig(model.mipNeRF360.__init__)[12:] == ["num_samples_fine"]  # extension, keyword, last, default None
     assert sig(model.mipNeRF360.render_image)[1:] == ["rays", "height", "width", "chunks"]
     assert inspect.signature(model.mipNeRF360.render_image).parameters["chunks"].default == 4096
     assert sig(model.nerf_net.forward)[1:] == ["rays", "t_vals", "coarse_weights"]
