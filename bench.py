@@ -29,6 +29,7 @@ SAMPLES = 128
 HP, HN = 256, 1024
 FLOPS_PER_SAMPLE = 2 * (58 * 256 + 3 * 256 * 256 + 256) + 2 * (58 * 1024 + 7 * 1024 * 1024 + 4 * 1024)  # 15,230,464
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (never the 2:1-sparsity figure)
 
 
 def cpu_baseline(sd_np, rays_np, n_rays):
@@ -51,6 +52,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-rays", type=int, default=1024, help="rays of the batch timed on the host CPU (0 = skip)")
+    ap.add_argument("--mlp-dtype", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32 = the headline configuration (BASELINE configs[1]); bf16 = opt-in reduced-precision MLP "
+                         "(configs[4] kernel family) - reported with dtype bf16, never comparable to the fp32 line")
     args = ap.parse_args()
 
     import numpy as np
@@ -77,8 +81,9 @@ def main():
     lib = _lib.lib()
     sd_np = synthetic.make_state_dict(HP, HN, seed=0)
     rays_np = synthetic.make_rays("garden", RAYS_PER_GPU, seed=1 + rank)
+    bf16 = args.mlp_dtype == "bf16"
     model = mipNeRF360(randomized=False, num_samples=SAMPLES, hidden_proposal=HP, hidden_nerf=HN, white_bkgd=False,
-                       device=dev)
+                       device=dev, mlp_dtype=args.mlp_dtype)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     rays = Rays(*[torch.from_numpy(rays_np[k]).to(dev) for k in synthetic.RAY_FIELDS])
     gathered = torch.empty(world * RAYS_PER_GPU, 5, device=dev) if world > 1 else None
@@ -115,7 +120,7 @@ def main():
     ms, M_, n_, k_ = C.c_float(), C.c_long(), C.c_int(), C.c_int()
     for i in range(lib.m360_prof_count()):
         _lib.check(lib.m360_prof_read(i, C.byref(ms), C.byref(M_), C.byref(n_), C.byref(k_)), "m360_prof_read")
-        if n_.value == HN and k_.value == HN and M_.value == RAYS_PER_GPU * SAMPLES:
+        if n_.value == HN and abs(k_.value) == HN and M_.value == RAYS_PER_GPU * SAMPLES:  # k < 0 marks bf16 launches
             durs.append(ms.value)
     lib.m360_prof_enable(0)
     roofline = None
@@ -125,10 +130,12 @@ def main():
         achieved = flops / (avg_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from a separate rocprofv3 --pmc run
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not bf16:
             traffic = json.load(open(tpath)).get("linear_f32_mfma_1024x1024_bytes_per_launch")
-        roofline = {"bound": "mfma", "kernel": "linear_f32_mfma_kernel (1024x1024 layer, M=524288)", "achieved": round(achieved, 2),
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+        kname = "linear_bf16_mfma_persist_kernel" if bf16 else "linear_f32_mfma_persist_kernel"
+        roofline = {"bound": "mfma", "kernel": f"{kname} (1024x1024 layer, M=524288)", "achieved": round(achieved, 2),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": traffic, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),
                     "flops_per_launch": flops}
 
@@ -143,9 +150,9 @@ def main():
         "metric": "rendered rays/sec at 128 samples/ray",
         "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": "nerf_360/garden-like synthetic NDC ray batch (near 0 / far 1), 4096 rays x 128 samples/ray "
-                               "per GPU, proposal 4x256 + NeRF 8x1024 MLPs in fp32 on MFMA, random-init Kaiming weights "
+                               "per GPU, proposal 4x256 + NeRF 8x1024 MLPs in " + ("bf16 (fp32 accumulate)" if bf16 else "fp32") + " on MFMA, random-init Kaiming weights "
                                "(BASELINE.json configs[1])",
                    "rays_per_gpu": RAYS_PER_GPU, "samples_per_ray": SAMPLES,
                    "parallelism": f"rays sharded over {world} GPU(s), replicated weights" +

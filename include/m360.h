@@ -130,6 +130,18 @@ int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_
 int m360_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
                 int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t stream);
 
+/* ---- opt-in bf16 MLP (BASELINE configs[4]): bf16 inputs, fp32 accumulate on v_mfma_f32_32x32x16_bf16.
+ * bf16 tensors are passed as raw 16-bit storage (void*).  k_pad multiple of 64, ldx/ldy multiples of 8. */
+int m360_pack_linear_bf16(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
+                          void *w_packed_bf16, float *b_packed, m360_stream_t stream);
+int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_bf16, const float *b_packed,
+                     int n_pad, int k_pad, int act, void *y_bf16, int ldy, m360_stream_t stream);
+/* m360_encode_features writing bf16 rows */
+int m360_encode_features_bf16(const float *t_vals, const float *origins, const float *directions,
+                              const float *radii, const float *vdenc, int vd_ch, int B, int N,
+                              void *feat_bf16, int ld_feat, void *workspace, size_t workspace_bytes,
+                              m360_stream_t stream);
+
 /* ------------------------------------------------------------------ per-ray scans ----- */
 
 /* model.py:59-78 (prop_net.density_to_weight); density[B,N]. */
@@ -197,6 +209,16 @@ int m360_prop_finish_n(const float *act, int ld, const float *head_w, const floa
                        int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
                        m360_stream_t stream);
 
+/* m360_prop_finish_n / m360_nerf_finish reading bf16 activations (heads and scans stay fp32) */
+int m360_prop_finish_bf16(const void *act_bf16, int ld, const float *head_w, const float *head_b, int k_pad,
+                          float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
+                          int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
+                          m360_stream_t stream);
+int m360_nerf_finish_bf16(const void *act_bf16, int ld, const float *head_w, const float *head_b, int k_pad,
+                          float density_bias, float rgb_padding, const float *t_vals, const float *dirs,
+                          int B, int N, int white_bkgd, float *comp_rgb, float *distance, float *acc,
+                          float *weights, m360_stream_t stream);
+
 /* density/colour heads + activations + alpha composite: head_w[4,k_pad] rows = (density, r, g, b).
  * Replaces model.py:150-158,180-186 and intern/ray.py:155-191. */
 int m360_nerf_finish(const float *act, int ld, const float *head_w, const float *head_b /*[4]*/,
@@ -228,6 +250,9 @@ typedef struct {
     const float *nerf_b[8];
     const float *nerf_head_w; /* [4,hn_pad]: final_density row, final_color rows */
     const float *nerf_head_b; /* [4] */
+    int mlp_bf16; /* extension: 0 = fp32 MLP (default, the parity path); 1 = prop_w / nerf_w point to bf16
+                     weights from m360_pack_linear_bf16 (pads multiples of 64), features and hidden activations
+                     are bf16, accumulation / biases / heads stay fp32 */
 } m360_model_t; /* packed form of the state_dict of model.py:43-53,131-158 */
 
 typedef struct {

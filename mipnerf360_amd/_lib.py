@@ -28,7 +28,8 @@ class RaysStruct(C.Structure):  # m360_rays_t
 class ModelStruct(C.Structure):  # m360_model_t
     _fields_ = [("in_ch", C.c_int), ("in_pad", C.c_int), ("hp_pad", C.c_int), ("hn_pad", C.c_int),
                 ("prop_w", _vp * 4), ("prop_b", _vp * 4), ("prop_head_w", _vp), ("prop_head_b", _vp),
-                ("nerf_w", _vp * 8), ("nerf_b", _vp * 8), ("nerf_head_w", _vp), ("nerf_head_b", _vp)]
+                ("nerf_w", _vp * 8), ("nerf_b", _vp * 8), ("nerf_head_w", _vp), ("nerf_head_b", _vp),
+                ("mlp_bf16", C.c_int)]
 
 
 class HyperStruct(C.Structure):  # m360_hyper_t
@@ -64,6 +65,11 @@ SIGNATURES = {
     "m360_encode_features": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "m360_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "m360_pack_linear_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "m360_linear_bf16": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "m360_encode_features_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "m360_prop_finish_bf16": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _vp, _vp]),
+    "m360_nerf_finish_bf16": (_i, [_vp, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "m360_density_to_weight": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "m360_sorted_pdf": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "m360_resample_t": (_i, [_vp, _vp, _vp, _i, _i, _fl, _vp, _vp]),

@@ -92,6 +92,8 @@ static int validate(const m360_rays_t *r, const m360_model_t *m, const m360_hype
     const int vd_ch = 4 * (h->viewdir_max_deg - h->viewdir_min_deg);
     if (vd_ch < 0 || m->in_ch != kIpeCh + vd_ch || m->in_pad < m->in_ch || m->in_pad % 32 || m->hp_pad % 32 || m->hn_pad % 32 || m->hp_pad < 32 || m->hn_pad < 32)
         return fail(M360_ERR_INVALID_ARGUMENT, "%s: model dims inconsistent (in_ch=%d in_pad=%d hp_pad=%d hn_pad=%d vd_ch=%d)", who, m->in_ch, m->in_pad, m->hp_pad, m->hn_pad, vd_ch);
+    if (m->mlp_bf16 && (m->in_pad % 64 || m->hp_pad % 64 || m->hn_pad % 64))
+        return fail(M360_ERR_INVALID_ARGUMENT, "%s: the bf16 MLP needs in_pad/hp_pad/hn_pad multiples of 64", who);
     const FwdLayout L = layout_for(B, n_max(h), m);
     if (B > 0 && (!ws || ws_bytes < L.total)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "%s: workspace %zu < required %zu bytes", who, ws_bytes, L.total);
     if ((uintptr_t)ws & 255) return fail(M360_ERR_INVALID_ARGUMENT, "%s: workspace must be 256-byte aligned", who);
@@ -117,8 +119,16 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     const long S = (long)B * N;
     M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, t_hat, st));
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
-    M360_TRY(m360_encode_features(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
     const int hp = m->hp_pad;
+    if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers, half the bytes)
+        M360_TRY(m360_encode_features_bf16(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(m360_linear_bf16(feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
+        M360_TRY(m360_linear_bf16(a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
+        M360_TRY(m360_linear_bf16(b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
+        M360_TRY(m360_linear_bf16(a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, hp, st));
+        return m360_prop_finish_bf16(b, hp, m->prop_head_w, m->prop_head_b, hp, h->density_bias, t_hat, r->directions, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st);
+    }
+    M360_TRY(m360_encode_features(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(m360_linear(feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
     M360_TRY(m360_linear(a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
     M360_TRY(m360_linear(b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
@@ -137,15 +147,25 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     float *a = reinterpret_cast<float *>(ws + L.act_a), *b = reinterpret_cast<float *>(ws + L.act_b);
     const long S = (long)B * N;
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
-    M360_TRY(m360_encode_features(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
     const int hn = m->hn_pad;
-    M360_TRY(m360_linear(feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
     float *src = a, *dst = b;
+    if (m->mlp_bf16) {
+        M360_TRY(m360_encode_features_bf16(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(m360_linear_bf16(feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
+        for (int layer = 1; layer < 8; ++layer) {
+            M360_TRY(m360_linear_bf16(src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
+            float *tmp = src; src = dst; dst = tmp;
+        }
+        M360_TRY(m360_nerf_finish_bf16(src, hn, m->nerf_head_w, m->nerf_head_b, hn, h->density_bias, h->rgb_padding, t1, r->directions, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
+    } else {
+    M360_TRY(m360_encode_features(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+    M360_TRY(m360_linear(feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
     for (int layer = 1; layer < 8; ++layer) {
         M360_TRY(m360_linear(src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
         float *tmp = src; src = dst; dst = tmp;
     }
     M360_TRY(m360_nerf_finish(src, hn, m->nerf_head_w, m->nerf_head_b, hn, h->density_bias, h->rgb_padding, t1, r->directions, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
+    }
     if (out->t_vals) {  // model.py:194,196: g() inside t_to_s bumps the stored t_vals by 1e-6
         const long n = (long)B * (N + 1);
         hipLaunchKernelGGL(add_eps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(st), t1, n, out->t_vals);

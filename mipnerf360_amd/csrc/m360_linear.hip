@@ -15,6 +15,7 @@
 //   Workgroup ids are remapped so the 4 N-tiles of one M-tile run on the same XCD (shared L2).
 #include "m360_common.cuh"
 #include "m360_linear_persist.cuh"
+#include "m360_linear_bf16.cuh"
 
 namespace m360 {
 
@@ -289,6 +290,55 @@ int m360_linear(const float *x, long M, int ldx, const float *w_packed, const fl
     }
     prof_end(prof, st);
     return check_launch("linear");
+}
+
+// ---- opt-in bf16 MLP (fp32 accumulate): weights and activations as raw 16-bit bf16
+int m360_pack_linear_bf16(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
+                          void *w_packed_bf16, float *b_packed, m360_stream_t stream) {
+    if (!w || !w_packed_bf16 || n_out < 1 || k_in < 1 || n_pad < n_out || k_pad < k_in || k_pad % 64 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_pack_linear_bf16: bad argument (n_out=%d k_in=%d n_pad=%d k_pad=%d; k_pad must be a multiple of 64)", n_out, k_in, n_pad, k_pad);
+    const long n = (long)n_pad * k_pad;
+    hipLaunchKernelGGL(pbf16::pack_linear_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, b, n_out, k_in, n_pad, k_pad, static_cast<__bf16 *>(w_packed_bf16), b_packed);
+    return check_launch("pack_linear_bf16");
+}
+
+int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
+                     int k_pad, int act, void *y, int ldy, m360_stream_t stream) {
+    if (!x || !w_packed || !b_packed || !y || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: null pointer or negative M");
+    if (n_pad < 1 || k_pad < pbf16::BK || k_pad % pbf16::BK != 0 || ldx < k_pad || ldy < n_pad || ldx % 8 != 0 || ldy % 8 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad, ldy=%d >= n_pad=%d, both multiples of 8", k_pad, pbf16::BK, ldx, ldy, n_pad);
+    if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: pointers must be 16-byte aligned");
+    if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: unknown activation %d", act);
+    if (M == 0) return M360_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const __bf16 *xb = static_cast<const __bf16 *>(x), *wb = static_cast<const __bf16 *>(w_packed);
+    __bf16 *yb = static_cast<__bf16 *>(y);
+    const int prof = prof_begin(st, M, n_pad, -k_pad);  // negative k marks bf16 launches in the event records
+    const long M_full = (n_pad % pbf16::BN == 0) ? (M / pbf16::BM) * pbf16::BM : 0;
+    if (M_full > 0) {
+        const int cus = cu_count();
+        if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear_bf16: no HIP device");
+        const long nt = (M_full / pbf16::BM) * (n_pad / pbf16::BN);
+        dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pbf16::kThreads);
+        switch (act) {
+            case M360_ACT_NONE: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
+            case M360_ACT_RELU: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
+            default: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
+        }
+    }
+    if (M > M_full) {
+        const long Mt = M - M_full;
+        dim3 grid((unsigned)((n_pad + 31) / 32), (unsigned)((Mt + 31) / 32)), block(64);
+        const __bf16 *xt = xb + M_full * ldx;
+        __bf16 *yt = yb + M_full * ldy;
+        switch (act) {
+            case M360_ACT_NONE: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_NONE>, grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k_pad, yt, ldy); break;
+            case M360_ACT_RELU: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_RELU>, grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k_pad, yt, ldy); break;
+            default: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k_pad, yt, ldy); break;
+        }
+    }
+    prof_end(prof, st);
+    return check_launch("linear_bf16");
 }
 
 }  // extern "C"

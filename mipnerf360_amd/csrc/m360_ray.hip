@@ -217,32 +217,58 @@ __global__ void to8b_kernel(const float *__restrict__ x, long n, uint8_t *__rest
 // H head dot-products per row; head weights sit in LDS.  Phase 2: wave 0 runs the scans.
 constexpr int kFinishThreads = 256;
 
-template <int H>
-__device__ __forceinline__ void head_dots(const float *__restrict__ act_ray, int ld,
+// one 16-byte chunk of an activation row as floats: 4 fp32 or 8 bf16 values
+template <typename T> struct ActChunk;
+template <> struct ActChunk<float> {
+    static constexpr int kElems = 4;
+    static __device__ __forceinline__ void load(const float *row, int c, float (&v)[4]) {
+        const float4 x = reinterpret_cast<const float4 *>(row)[c];
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    }
+};
+typedef __bf16 bf16x8_r __attribute__((ext_vector_type(8)));
+template <> struct ActChunk<__bf16> {
+    static constexpr int kElems = 8;
+    static __device__ __forceinline__ void load(const __bf16 *row, int c, float (&v)[8]) {
+        const bf16x8_r x = reinterpret_cast<const bf16x8_r *>(row)[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+    }
+};
+
+template <int H, typename T>
+__device__ __forceinline__ void head_dots(const T *__restrict__ act_ray, int ld,
                                           const float *hw /*LDS [H][k_pad]*/,
                                           const float *__restrict__ hb, int k_pad, int N,
                                           float *raw /*LDS [N][H]*/) {
+    constexpr int E = ActChunk<T>::kElems;
     const int wave = threadIdx.x >> 6, l = lane_id();
     const int nwaves = blockDim.x >> 6;
-    const int k4 = k_pad >> 2;
+    const int kc = k_pad / E;
     float bias[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) bias[h] = hb[h];
     for (int n = wave; n < N; n += 2 * nwaves) {
         const int n2 = n + nwaves;
         const bool has2 = n2 < N;
-        const float4 *x1 = reinterpret_cast<const float4 *>(act_ray + (long)n * ld);
-        const float4 *x2 = reinterpret_cast<const float4 *>(act_ray + (long)(has2 ? n2 : n) * ld);
+        const T *x1 = act_ray + (long)n * ld;
+        const T *x2 = act_ray + (long)(has2 ? n2 : n) * ld;
         float a1[H], a2[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) a1[h] = a2[h] = 0.0f;
-        for (int c = l; c < k4; c += kWave) {
-            const float4 v1 = x1[c], v2 = x2[c];
+        for (int c = l; c < kc; c += kWave) {
+            float v1[E], v2[E];
+            ActChunk<T>::load(x1, c, v1);
+            ActChunk<T>::load(x2, c, v2);
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-                const float4 w = reinterpret_cast<const float4 *>(hw + h * k_pad)[c];
-                a1[h] += v1.x * w.x + v1.y * w.y + v1.z * w.z + v1.w * w.w;
-                a2[h] += v2.x * w.x + v2.y * w.y + v2.z * w.z + v2.w * w.w;
+                const float *wp = hw + h * k_pad + c * E;
+#pragma unroll
+                for (int e = 0; e < E; e += 4) {
+                    const float4 w = *reinterpret_cast<const float4 *>(wp + e);
+                    a1[h] += v1[e] * w.x + v1[e + 1] * w.y + v1[e + 2] * w.z + v1[e + 3] * w.w;
+                    a2[h] += v2[e] * w.x + v2[e + 1] * w.y + v2[e + 2] * w.z + v2[e + 3] * w.w;
+                }
             }
         }
 #pragma unroll
@@ -261,8 +287,9 @@ __device__ __forceinline__ void head_dots(const float *__restrict__ act_ray, int
 }
 
 // model.py:52,92-93 + intern/ray.py:136-149
+template <typename T>
 __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
-    const float *__restrict__ act, int ld, const float *__restrict__ head_w,
+    const T *__restrict__ act, int ld, const float *__restrict__ head_w,
     const float *__restrict__ head_b, int k_pad, float density_bias, const float *__restrict__ t_vals,
     const float *__restrict__ dirs, const float *__restrict__ u_rand, int N, int ns, float padding,
     float *__restrict__ weights, float *__restrict__ t_new) {
@@ -273,7 +300,7 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     for (int i = threadIdx.x; i < k_pad; i += blockDim.x) hw[i] = head_w[i];
     for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
     __syncthreads();
-    head_dots<1>(act + (long)b * N * ld, ld, hw, head_b, k_pad, N, rho);
+    head_dots<1, T>(act + (long)b * N * ld, ld, hw, head_b, k_pad, N, rho);
     __syncthreads();
     if (threadIdx.x >= kWave) return;
     for (int i = l; i < N; i += kWave) rho[i] = softplusf_(rho[i] + density_bias);
@@ -288,8 +315,9 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
 }
 
 // model.py:150-158,180-186 + intern/ray.py:155-191
+template <typename T>
 __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
-    const float *__restrict__ act, int ld, const float *__restrict__ head_w,
+    const T *__restrict__ act, int ld, const float *__restrict__ head_w,
     const float *__restrict__ head_b, int k_pad, float density_bias, float rgb_padding,
     const float *__restrict__ t_vals, const float *__restrict__ dirs, int N, int white_bkgd,
     float *__restrict__ comp_rgb, float *__restrict__ distance, float *__restrict__ acc,
@@ -301,7 +329,7 @@ __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
     for (int i = threadIdx.x; i < 4 * k_pad; i += blockDim.x) hw[i] = head_w[i];
     for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
     __syncthreads();
-    head_dots<4>(act + (long)b * N * ld, ld, hw, head_b, k_pad, N, raw);
+    head_dots<4, T>(act + (long)b * N * ld, ld, hw, head_b, k_pad, N, raw);
     __syncthreads();
     if (threadIdx.x >= kWave) return;
     for (int i = l; i < N; i += kWave) {
@@ -397,30 +425,72 @@ int m360_prop_finish(const float *act, int ld, const float *head_w, const float 
     return m360_prop_finish_n(act, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, N + 1, resample_padding, weights, t_new, stream);
 }
 
+static int prop_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
+                           float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
+                           int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
+                           m360_stream_t stream);
+
 int m360_prop_finish_n(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
                        float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                        int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
                        m360_stream_t stream) {
+    return prop_finish_any(act, 0, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, stream);
+}
+
+int m360_prop_finish_bf16(const void *act_bf16, int ld, const float *head_w, const float *head_b, int k_pad,
+                          float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
+                          int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
+                          m360_stream_t stream) {
+    return prop_finish_any(act_bf16, 1, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, stream);
+}
+
+static int prop_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
+                           float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
+                           int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
+                           m360_stream_t stream) {
     if (num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: num_out=%d", num_out);
-    if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < 4 || k_pad % 4 != 0 || ld < k_pad || ld % 4 != 0)
+    const int align = bf16 ? 8 : 4;
+    if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < k_pad || ld % align != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: bad argument");
     if (B == 0) return M360_OK;
     const size_t lds = ((size_t)k_pad + 5 * (N + 1)) * sizeof(float);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    hipLaunchKernelGGL(prop_finish_kernel, dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
+    if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
+    else hipLaunchKernelGGL(prop_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
     return check_launch("prop_finish");
 }
+
+static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
+                           float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
+                           int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
+                           m360_stream_t stream);
 
 int m360_nerf_finish(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
                      float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
                      int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
                      m360_stream_t stream) {
-    if (!act || !head_w || !head_b || !t_vals || !dirs || !comp_rgb || !distance || !acc || B < 0 || N < 1 || k_pad < 4 || k_pad % 4 != 0 || ld < k_pad || ld % 4 != 0)
+    return nerf_finish_any(act, 0, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, stream);
+}
+
+int m360_nerf_finish_bf16(const void *act_bf16, int ld, const float *head_w, const float *head_b, int k_pad,
+                          float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
+                          int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
+                          m360_stream_t stream) {
+    return nerf_finish_any(act_bf16, 1, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, stream);
+}
+
+static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
+                           float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
+                           int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
+                           m360_stream_t stream) {
+    const int align = bf16 ? 8 : 4;
+    if (!act || !head_w || !head_b || !t_vals || !dirs || !comp_rgb || !distance || !acc || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < k_pad || ld % align != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: bad argument");
     if (B == 0) return M360_OK;
     const size_t lds = ((size_t)4 * k_pad + (N + 1) + 5 * N) * sizeof(float);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    hipLaunchKernelGGL(nerf_finish_kernel, dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
+    if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
+    else hipLaunchKernelGGL(nerf_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
     return check_launch("nerf_finish");
 }
 

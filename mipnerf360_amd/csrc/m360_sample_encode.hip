@@ -261,11 +261,14 @@ __global__ void viewdir_enc_kernel(const float *__restrict__ viewdirs, int B, in
 // conflict-free per-row writes) and streams it out as whole 16-byte-per-lane coalesced stores.
 constexpr int kEncThreads = 128;
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <bool BF16>  // BF16: feature rows are written as bf16 (opt-in reduced-precision MLP), else fp32
 __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
     const float *__restrict__ t_vals, const float *__restrict__ origins,
     const float *__restrict__ directions, const float *__restrict__ radii,
     const float *__restrict__ vdenc, int vd_ch, int B, int N, const NormScratch *__restrict__ ws,
-    float *__restrict__ feat, int ld) {
+    void *__restrict__ feat_out, int ld) {
     extern __shared__ float tile[];  // [kEncThreads][ld + 1]
     const long S = (long)B * N;
     const long s0 = (long)blockIdx.x * kEncThreads;
@@ -282,12 +285,25 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
     }
     __syncthreads();
     const long rows = (S - s0 < kEncThreads) ? (S - s0) : kEncThreads;
-    const long total4 = rows * ld / 4;  // ld is a multiple of 32
-    float4 *out = reinterpret_cast<float4 *>(feat + s0 * ld);
-    for (long q = threadIdx.x; q < total4; q += kEncThreads) {
-        const int r = (int)((q * 4) / ld), col = (int)((q * 4) % ld);
-        const float *src = tile + r * lds_ld + col;
-        out[q] = make_float4(src[0], src[1], src[2], src[3]);
+    if (!BF16) {
+        const long total4 = rows * ld / 4;  // ld is a multiple of 32
+        float4 *out = reinterpret_cast<float4 *>(static_cast<float *>(feat_out) + s0 * ld);
+        for (long q = threadIdx.x; q < total4; q += kEncThreads) {
+            const int r = (int)((q * 4) / ld), col = (int)((q * 4) % ld);
+            const float *src = tile + r * lds_ld + col;
+            out[q] = make_float4(src[0], src[1], src[2], src[3]);
+        }
+    } else {
+        const long total8 = rows * ld / 8;
+        bf16x8_t *out = reinterpret_cast<bf16x8_t *>(static_cast<__bf16 *>(feat_out) + s0 * ld);
+        for (long q = threadIdx.x; q < total8; q += kEncThreads) {
+            const int r = (int)((q * 8) / ld), col = (int)((q * 8) % ld);
+            const float *src = tile + r * lds_ld + col;
+            bf16x8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)src[e];
+            out[q] = o;
+        }
     }
 }
 
@@ -423,9 +439,25 @@ int m360_viewdir_enc(const float *viewdirs, int B, int min_deg, int max_deg, flo
     return check_launch("viewdir_enc");
 }
 
+static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
+                               const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
+                               int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream);
+
 int m360_encode_features(const float *t_vals, const float *origins, const float *directions,
                          const float *radii, const float *vdenc, int vd_ch, int B, int N, float *feat,
                          int ld_feat, void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    return encode_features_any(t_vals, origins, directions, radii, vdenc, vd_ch, B, N, feat, ld_feat, 0, workspace, workspace_bytes, stream);
+}
+
+int m360_encode_features_bf16(const float *t_vals, const float *origins, const float *directions,
+                              const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat_bf16,
+                              int ld_feat, void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    return encode_features_any(t_vals, origins, directions, radii, vdenc, vd_ch, B, N, feat_bf16, ld_feat, 1, workspace, workspace_bytes, stream);
+}
+
+static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
+                               const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
+                               int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream) {
     if (!t_vals || !origins || !directions || !radii || !feat || B < 0 || N < 1 || vd_ch < 0 || (vd_ch > 0 && !vdenc))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: bad argument");
     if (ld_feat % 32 != 0 || ld_feat < kIpeCh + vd_ch) return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: ld_feat=%d must be a multiple of 32 and >= %d", ld_feat, kIpeCh + vd_ch);
@@ -434,7 +466,8 @@ int m360_encode_features(const float *t_vals, const float *origins, const float 
     NormScratch *ws = static_cast<NormScratch *>(workspace);
     launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream));
     const size_t lds = (size_t)kEncThreads * (ld_feat + 1) * sizeof(float);
-    hipLaunchKernelGGL(encode_features_kernel, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat);
+    if (bf16) hipLaunchKernelGGL(encode_features_kernel<true>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat);
+    else hipLaunchKernelGGL(encode_features_kernel<false>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat);
     return check_launch("encode_features");
 }
 

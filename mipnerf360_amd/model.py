@@ -63,18 +63,21 @@ class _PackedMLP:
     def _key(params):
         return tuple((p.data_ptr(), p._version, p.device) for p in params)
 
-    def refresh(self, hidden_layers, heads) -> "_PackedMLP":
+    def refresh(self, hidden_layers, heads, bf16: bool = False) -> "_PackedMLP":
         params = [p for lin in list(hidden_layers) + list(heads) for p in (lin.weight, lin.bias)]
-        key = self._key(params)
+        key = self._key(params) + (bool(bf16),)
         if key == self.key:
             return self
         first = hidden_layers[0]
         ops._require_device(first.weight, "model parameters")
-        self.in_pad = ops.round_up(first.in_features)
-        self.h_pad = ops.round_up(first.out_features)
+        pad = 64 if bf16 else 32  # the bf16 MFMA K-step is 64 elements
+        self.bf16 = bool(bf16)
+        self.in_pad = ops.round_up(first.in_features, pad)
+        self.h_pad = ops.round_up(first.out_features, pad)
+        pack = ops.pack_linear_bf16 if bf16 else ops.pack_linear
         self.w, self.b = [], []
         for i, lin in enumerate(hidden_layers):
-            wp, bp = ops.pack_linear(lin.weight, lin.bias, self.h_pad, self.in_pad if i == 0 else self.h_pad)
+            wp, bp = pack(lin.weight, lin.bias, self.h_pad, self.in_pad if i == 0 else self.h_pad)
             self.w.append(wp), self.b.append(bp)
         hw = torch.cat([h.weight.detach() for h in heads], 0).float()
         hb = torch.cat([h.bias.detach() for h in heads], 0).float().contiguous()
@@ -99,6 +102,9 @@ def _model_struct(in_ch, prop: Optional[_PackedMLP], nerf: Optional[_PackedMLP])
     m.in_ch, m.in_pad = in_ch, ref.in_pad
     m.hp_pad = (prop or nerf).h_pad
     m.hn_pad = (nerf or prop).h_pad
+    m.mlp_bf16 = int(getattr(ref, "bf16", False))
+    if prop is not None and nerf is not None and getattr(prop, "bf16", False) != getattr(nerf, "bf16", False):
+        raise RuntimeError("proposal and NeRF networks must use the same MLP precision")
     if prop is not None:
         for i in range(4):
             m.prop_w[i], m.prop_b[i] = prop.w[i].data_ptr(), prop.b[i].data_ptr()
@@ -150,7 +156,8 @@ class prop_net(nn.Module):
         self._packed = _PackedMLP()
 
     def _pack(self) -> _PackedMLP:
-        return self._packed.refresh([self.model[i] for i in (0, 2, 4, 6)], [self.model[8]])
+        return self._packed.refresh([self.model[i] for i in (0, 2, 4, 6)], [self.model[8]],
+                                    getattr(self, "mlp_bf16", False))
 
     def density_to_weight(self, t_vals, density, dirs):
         """model.py:59-78."""
@@ -208,7 +215,7 @@ class nerf_net(nn.Module):
 
     def _pack(self) -> _PackedMLP:
         return self._packed.refresh([self.model[i] for i in range(0, 16, 2)],
-                                    [self.final_density[0], self.final_color[0]])
+                                    [self.final_density[0], self.final_color[0]], getattr(self, "mlp_bf16", False))
 
     def _hyper(self, N, n_fine=0):
         h = _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, self.white_bkgd, self.density_bias,
@@ -263,10 +270,12 @@ class mipNeRF360(nn.Module):
 
     def __init__(self, randomized=False, num_samples=128, hidden_proposal=256, hidden_nerf=1024, density_bias=-1,
                  rgb_padding=0.001, resample_padding=0.01, white_bkgd=False, viewdir_min_deg=0, viewdir_max_deg=4,
-                 device=torch.device("cuda"), num_samples_fine=None):
-        """Same arguments as the reference (model.py:203-215).  `num_samples_fine` is an extension (keyword,
-        last): number of NeRF-stage samples per ray when it should differ from the proposal count
-        ("64+128" rendering, BASELINE configs[2]); None keeps the reference's behaviour (equal counts)."""
+                 device=torch.device("cuda"), num_samples_fine=None, mlp_dtype="fp32"):
+        """Same arguments as the reference (model.py:203-215), plus two keyword extensions at the end:
+        `num_samples_fine`: number of NeRF-stage samples per ray when it should differ from the proposal count
+        ("64+128" rendering, BASELINE configs[2]); None keeps the reference's behaviour (equal counts);
+        `mlp_dtype`: "fp32" (default: exact-fp32 MFMA, the parity path) or "bf16" (BASELINE configs[4]: bf16
+        weights / features / hidden activations, fp32 accumulation, heads and ray math in fp32)."""
         super().__init__()
         self.randomized = randomized
         self.num_samples = num_samples
@@ -292,6 +301,10 @@ class mipNeRF360(nn.Module):
                                  viewdir_min_deg=self.viewdir_min_deg, viewdir_max_deg=self.viewdir_max_deg,
                                  device=self.device)
         self.nerf_net.num_samples_fine = num_samples_fine
+        if mlp_dtype not in ("fp32", "bf16", torch.float32, torch.bfloat16):
+            raise ValueError(f"mlp_dtype must be 'fp32' or 'bf16', got {mlp_dtype!r}")
+        self.mlp_dtype = "bf16" if mlp_dtype in ("bf16", torch.bfloat16) else "fp32"
+        self.prop_net.mlp_bf16 = self.nerf_net.mlp_bf16 = self.mlp_dtype == "bf16"
         self.to(device)
 
     # ------------------------------------------------------------------ fused two-stage forward

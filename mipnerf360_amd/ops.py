@@ -195,6 +195,37 @@ def linear(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.
     return y
 
 
+def dev_bf16(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    _require_device(t, name)
+    if t.dtype != torch.bfloat16:
+        raise RuntimeError(f"{name} must be bfloat16, got {t.dtype}")
+    return t.contiguous()
+
+
+def pack_linear_bf16(weight, bias=None, n_pad: Optional[int] = None, k_pad: Optional[int] = None):
+    """fp32 Linear -> zero-padded bf16 weight [n_pad,k_pad] (k_pad multiple of 64) + fp32 bias [n_pad]."""
+    weight = dev(weight.detach(), "weight")
+    n_out, k_in = weight.shape
+    n_pad, k_pad = n_pad or round_up(n_out, 64), k_pad or round_up(k_in, 64)
+    wp = torch.empty(n_pad, k_pad, device=weight.device, dtype=torch.bfloat16)
+    bp = torch.empty(n_pad, device=weight.device)
+    b = None if bias is None else dev(bias.detach(), "bias")
+    _call("m360_pack_linear_bf16", ptr(weight), ptr(b), n_out, k_in, n_pad, k_pad, ptr(wp), ptr(bp), stream())
+    return wp, bp
+
+
+def linear_bf16(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 x [M,k_pad] * bf16 W^T + fp32 bias -> bf16 [M,n_pad] (fp32 accumulate on MFMA)."""
+    x, w_packed, b_packed = dev_bf16(x, "x"), dev_bf16(w_packed, "w_packed"), dev(b_packed, "b_packed")
+    M, ldx = x.shape
+    n_pad, k_pad = w_packed.shape
+    if ldx != k_pad:
+        raise RuntimeError(f"linear_bf16: x has {ldx} columns, packed weight expects {k_pad}")
+    y = out if out is not None else torch.empty(M, n_pad, device=x.device, dtype=torch.bfloat16)
+    _call("m360_linear_bf16", ptr(x), M, ldx, ptr(w_packed), ptr(b_packed), n_pad, k_pad, act, ptr(y), y.shape[1], stream())
+    return y
+
+
 # ----------------------------------------------------------------------------- per-ray scans
 def _density2d(density):
     return density[..., 0] if density.dim() == 3 else density

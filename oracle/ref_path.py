@@ -256,19 +256,41 @@ def _lin(x, sd, prefix):
     return torch.nn.functional.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
 
 
-def prop_mlp(x, sd):
-    """model.py:43-53."""
+def _r16(x):
+    """round-to-nearest-even to bf16 and back: emulates the opt-in bf16 MLP's storage precision."""
+    return x.bfloat16().float()
+
+
+def _lin16(x, sd, prefix):
+    """bf16-rounded inputs and weights, fp32 products/accumulation, fp32 bias (the bf16 MFMA contract)."""
+    return torch.nn.functional.linear(x, _r16(sd[prefix + ".weight"]), sd[prefix + ".bias"])
+
+
+def prop_mlp(x, sd, bf16=False):
+    """model.py:43-53.  bf16=True emulates the reduced-precision extension (hidden activations stored as bf16)."""
+    if bf16:
+        x = _r16(x)
+        for i in (0, 2, 4):
+            x = _r16(torch.relu(_lin16(x, sd, f"prop_net.model.{i}")))
+        x = _r16(torch.sigmoid(_lin16(x, sd, "prop_net.model.6")))
+        return _lin(x, sd, "prop_net.model.8")
     for i in (0, 2, 4):
         x = torch.relu(_lin(x, sd, f"prop_net.model.{i}"))
     x = torch.sigmoid(_lin(x, sd, "prop_net.model.6"))
     return _lin(x, sd, "prop_net.model.8")
 
 
-def nerf_mlp(x, sd):
-    """model.py:131-158."""
-    for i in range(0, 14, 2):
-        x = torch.relu(_lin(x, sd, f"nerf_net.model.{i}"))
-    x = torch.sigmoid(_lin(x, sd, "nerf_net.model.14"))
+def nerf_mlp(x, sd, bf16=False):
+    """model.py:131-158 (bf16: see prop_mlp)."""
+    if bf16:
+        x = _r16(x)
+        for i in range(0, 14, 2):
+            x = _r16(torch.relu(_lin16(x, sd, f"nerf_net.model.{i}")))
+        x = _r16(torch.sigmoid(_lin16(x, sd, "nerf_net.model.14")))
+    else:
+        for i in range(0, 14, 2):
+            x = torch.relu(_lin(x, sd, f"nerf_net.model.{i}"))
+        x = torch.sigmoid(_lin(x, sd, "nerf_net.model.14"))
     raw_density = torch.sigmoid(_lin(x, sd, "nerf_net.final_density.0"))
     raw_rgb = torch.sigmoid(_lin(x, sd, "nerf_net.final_color.0"))
     return raw_density, raw_rgb
@@ -289,6 +311,7 @@ class Hyper(NamedTuple):
     viewdir_min_deg: int = 0
     viewdir_max_deg: int = 4
     num_samples_fine: int = 0  # extension ("64+128"); 0 = num_samples, the reference's behaviour
+    mlp_bf16: bool = False     # extension: emulate the bf16 MLP mode (bf16 storage, fp32 accumulation)
 
 
 def prop_forward(rays: Rays, sd, hp: Hyper, t_rand=None):
@@ -299,7 +322,7 @@ def prop_forward(rays: Rays, sd, hp: Hyper, t_rand=None):
     t_vals = t_vals.expand(rays.origins.shape[0], -1).contiguous()
     mean, cov = para_rays(t_vals, rays.origins, rays.directions, rays.radii)
     x = encode_inputs(mean, cov, rays.viewdirs, hp.viewdir_min_deg, hp.viewdir_max_deg)
-    raw = prop_mlp(x, sd)
+    raw = prop_mlp(x, sd, hp.mlp_bf16)
     density = torch.nn.functional.softplus(raw + hp.density_bias)
     return t_vals, density_to_weight(t_vals, density, rays.directions)
 
@@ -310,7 +333,7 @@ def nerf_forward(rays: Rays, t_vals, coarse_weights, sd, hp: Hyper, u_rand=None)
                        (hp.num_samples_fine + 1) if hp.num_samples_fine else None)
     mean, cov = para_rays(t_new, rays.origins, rays.directions, rays.radii)
     x = encode_inputs(mean, cov, rays.viewdirs, hp.viewdir_min_deg, hp.viewdir_max_deg)
-    raw_density, raw_rgb = nerf_mlp(x, sd)
+    raw_density, raw_rgb = nerf_mlp(x, sd, hp.mlp_bf16)
     rgb = raw_rgb * (1 + 2 * hp.rgb_padding) - hp.rgb_padding
     density = torch.nn.functional.softplus(raw_density + hp.density_bias)
     comp_rgb, distance, acc, weights = volumetric_rendering(rgb, density, t_new, rays.directions, hp.white_bkgd)

@@ -456,6 +456,51 @@ def test_unequal_sample_counts_extension(dev, np_, nf):
     close(tn, O.resample_t(t_hat.cpu(), w_hat.cpu(), 0.01, None, nf + 1), atol=8e-6)
 
 
+@pytest.mark.parametrize("M,n,k,act", [(256 * 5, 256, 64, 1), (256 * 9 + 77, 1024, 1024, 1), (300, 96, 128, 2),
+                                        (256 * 40, 768, 256, 0), (1, 64, 64, 2), (256 * 70, 1024, 64, 1)])
+def test_linear_bf16_against_fp64(dev, M, n, k, act):
+    """Opt-in bf16 MLP kernel (persistent LDS-DMA path + generic ragged path): bf16 inputs, fp32 accumulation,
+    bf16 output.  Reference = exact product of the SAME bf16-rounded operands in fp64, then rounded to bf16:
+    the only admissible deviation is the final rounding (1 bf16 ulp = 2^-8 relative) plus fp32 summation noise."""
+    from mipnerf360_amd import ops
+    g = torch.Generator().manual_seed(M + n + k)
+    x = (torch.rand(M, k, generator=g) * 2 - 1).bfloat16()
+    w = ((torch.rand(n, k, generator=g) * 2 - 1) * (6.0 / k) ** 0.5)
+    b = torch.rand(n, generator=g) - 0.5
+    wp, bp = ops.pack_linear_bf16(w.to(dev), b.to(dev), ops.round_up(n, 64), k)
+    assert wp.dtype == torch.bfloat16 and wp.shape == (ops.round_up(n, 64), k)
+    y = ops.linear_bf16(x.to(dev), wp, bp, act)
+    assert y.dtype == torch.bfloat16
+    ref = x.double() @ w.bfloat16().double().T + b.double()
+    ref = {0: ref, 1: ref.clamp_min(0), 2: torch.sigmoid(ref)}[act]
+    got = y[:, :n].float().cpu().double()
+    err = (got - ref).abs()
+    assert float((err - 2 ** -8 * ref.abs()).max()) <= 2e-3, float(err.max())
+    for _ in range(2):  # repeated launches: no race in the persistent tile hand-over / LDS-staged epilogue
+        assert torch.equal(ops.linear_bf16(x.to(dev), wp, bp, act), y)
+
+
+@pytest.mark.parametrize("kind,B,n,hp,hn,wb", [("garden", 96, 128, 256, 1024, False), ("lego", 130, 64, 64, 128, True),
+                                               ("garden", 7, 32, 32, 32, False), ("garden", 1024, 128, 256, 1024, False)])
+def test_forward_bf16_mode(dev, kind, B, n, hp, hn, wb):
+    """mlp_dtype="bf16" (BASELINE configs[4]): against the oracle emulating bf16 storage (tight) and against the
+    fp32 oracle (PSNR / max error of the reduced-precision render, SURVEY.md §8c: no hard gate tighter than 2e-2)."""
+    from mipnerf360_amd.model import mipNeRF360
+    from oracle import ref_path as O
+    sd = synthetic.make_state_dict(hp, hn, seed=5)
+    r = synthetic.make_rays(kind, B, seed=8)
+    m = mipNeRF360(num_samples=n, hidden_proposal=hp, hidden_nerf=hn, white_bkgd=wb, device=dev, mlp_dtype="bf16")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    rgb, dist, acc = m(dev_rays(r, dev))
+    sdt = O.to_torch_state_dict(sd)
+    emu = O.forward(O.rays_from_numpy(r), sdt, O.Hyper(num_samples=n, white_bkgd=wb, mlp_bf16=True))
+    ref = O.forward(O.rays_from_numpy(r), sdt, O.Hyper(num_samples=n, white_bkgd=wb))
+    assert float((rgb.cpu() - emu[0]).abs().max()) <= 6e-3 and float((acc.cpu() - emu[2]).abs().max()) <= 6e-3
+    assert float((rgb.cpu() - ref[0]).abs().max()) <= 2e-2 and float((acc.cpu() - ref[2]).abs().max()) <= 2e-2
+    mse = float(((rgb.cpu() - ref[0]) ** 2).mean())
+    assert -10 * np.log10(max(mse, 1e-20)) > 45.0  # PSNR of the bf16 render against the fp32 render
+
+
 def test_empty_batch(dev):
     m = build_model(synthetic.make_state_dict(32, 32, seed=1), dev, 16, 32, 32, False)
     r = dev_rays(synthetic.make_rays("lego", 0, seed=1), dev)

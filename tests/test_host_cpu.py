@@ -79,7 +79,7 @@ def test_api_surface_matches_reference_signatures():
     assert sig(model.mipNeRF360.__init__)[1:12] == ["randomized", "num_samples", "hidden_proposal", "hidden_nerf",
                                                     "density_bias", "rgb_padding", "resample_padding", "white_bkgd",
                                                     "viewdir_min_deg", "viewdir_max_deg", "device"]
-    assert sig(model.mipNeRF360.__init__)[12:] == ["num_samples_fine"]  # extension, keyword, last, default None
+    assert sig(model.mipNeRF360.__init__)[12:] == ["num_samples_fine", "mlp_dtype"]  # keyword extensions, last
     assert sig(model.mipNeRF360.render_image)[1:] == ["rays", "height", "width", "chunks"]
     assert inspect.signature(model.mipNeRF360.render_image).parameters["chunks"].default == 4096
     assert sig(model.nerf_net.forward)[1:] == ["rays", "t_vals", "coarse_weights"]
