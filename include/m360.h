@@ -192,6 +192,31 @@ int m360_convert_to_ndc(const float *origins /*[n,3]*/, const float *directions 
                         float focal, int w, int h, float near, float *origins_out, float *directions_out,
                         m360_stream_t stream);
 
+/* ------------------------------------------------------------------ visualisation ----- */
+
+size_t m360_visualize_workspace_bytes(void);
+
+/* fake normals of an orthographic depth map: 3x3 blur/edge convolution (scipy convolve2d 'same', zero
+ * fill) -> normals[h,w,3].  Replaces intern/pose.py:112-121 (depth_to_normals). */
+int m360_depth_to_normals(const float *depth /*[h,w]*/, int h, int w, float *normals, m360_stream_t stream);
+
+/* cyclic colormap rgb[n,3] = sin^2(pi (k/6 - h)), k = 3,5,7.  Replaces intern/pose.py:122-125 (sinebow). */
+int m360_sinebow(const float *h, long n, float *rgb, m360_stream_t stream);
+
+/* vis[h,w,3] of the isotropically scaled fake normals, NaN -> 1, blended to white with acc (acc may be
+ * NULL).  Replaces intern/pose.py:127-146 (visualize_normals, scaling=None). */
+int m360_visualize_normals(const float *depth, const float *acc, int h, int w, float *vis,
+                           void *workspace, size_t workspace_bytes, m360_stream_t stream);
+
+/* vis[h,w,3] of a depth map: curve -log(x + eps32), near/far given or taken from the map (near_auto /
+ * far_auto != 0: lowest / highest depth -/+ eps, i.e. the reference's ignore_frac = 0 behaviour),
+ * modulus == 0: matplotlib 'turbo' lookup, modulus > 0: sinebow of mod(value, modulus)/modulus; blended
+ * to white with acc (NULL = ones; NaN depth -> acc 0).  Replaces intern/pose.py:148-212 (visualize_depth
+ * with its default curve_fn / colormap). */
+int m360_visualize_depth(const float *depth, const float *acc, int h, int w, float near, float far,
+                         int near_auto, int far_auto, float modulus, float *vis, void *workspace,
+                         size_t workspace_bytes, m360_stream_t stream);
+
 /* ------------------------------------------------------------------ fused stages ------ */
 
 /* last proposal layer (hidden -> 1) + softplus(raw + density_bias) + density_to_weight +

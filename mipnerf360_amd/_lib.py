@@ -77,6 +77,11 @@ SIGNATURES = {
     "m360_prop_finish_n": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_volumetric_rendering": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "m360_to8b": (_i, [_vp, _l, _vp, _vp]),
+    "m360_visualize_workspace_bytes": (_sz, []),
+    "m360_depth_to_normals": (_i, [_vp, _i, _i, _vp, _vp]),
+    "m360_sinebow": (_i, [_vp, _l, _vp, _vp]),
+    "m360_visualize_normals": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "m360_visualize_depth": (_i, [_vp, _vp, _i, _i, _fl, _fl, _i, _i, _fl, _vp, _vp, _sz, _vp]),
     "m360_generate_rays": (_i, [_vp, _i, _i, _i, _fl, _fl, _fl, _i, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "m360_convert_to_ndc": (_i, [_vp, _vp, _l, _fl, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_prop_finish": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _fl, _vp, _vp, _vp]),

@@ -1,0 +1,229 @@
+// Frame post-processing on the device: the reference's visualize_depth,
+// visualize_normals, depth_to_normals and sinebow (intern/pose.py:112-212), so that test.py / video.py
+// style callers get finished frames without a trip through NumPy / scipy / matplotlib.
+// All kernels are per-pixel and HBM-bound; the image statistics (min / max / variances) are a
+// deterministic two-level fp64 reduction (fixed partition), like the contraction norm.
+#include "m360_common.cuh"
+#include "m360_turbo_lut.h"
+
+namespace m360 {
+
+constexpr int kVisParts = 256;
+constexpr int kVisStats = 10;  // count, sx, sxx, sy, syy, sd, sdd, min, max, n_nan
+
+struct VisScratch {
+    double partial[kVisParts][kVisStats];
+    double stats[kVisStats];
+};
+
+__global__ __launch_bounds__(256) void vis_stats_partial_kernel(const float *__restrict__ depth, int h, int w,
+                                                                VisScratch *__restrict__ ws) {
+    __shared__ double red[4][kVisStats];
+    double s[kVisStats] = {0, 0, 0, 0, 0, 0, 0, 1e300, -1e300, 0};
+    const long n = (long)h * w;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const float d = depth[idx];
+        if (isnan(d)) {
+            s[9] += 1.0;
+            continue;
+        }
+        const double x = (double)(idx % w), y = (double)(idx / w), dd = (double)d;
+        s[0] += 1.0;
+        s[1] += x;
+        s[2] += x * x;
+        s[3] += y;
+        s[4] += y * y;
+        s[5] += dd;
+        s[6] += dd * dd;
+        s[7] = fmin(s[7], dd);
+        s[8] = fmax(s[8], dd);
+    }
+#pragma unroll
+    for (int k = 0; k < kVisStats; ++k) {
+        double v = s[k];
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(v, o, kWave);
+            v = (k == 7) ? fmin(v, other) : (k == 8) ? fmax(v, other) : v + other;
+        }
+        if (lane_id() == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kVisStats) {
+        const int k = threadIdx.x;
+        double v = red[0][k];
+        for (int wv = 1; wv < 4; ++wv) v = (k == 7) ? fmin(v, red[wv][k]) : (k == 8) ? fmax(v, red[wv][k]) : v + red[wv][k];
+        ws->partial[blockIdx.x][k] = v;
+    }
+}
+
+__global__ void vis_stats_final_kernel(VisScratch *__restrict__ ws, int parts) {
+    const int k = threadIdx.x;
+    if (k >= kVisStats) return;
+    double v = ws->partial[0][k];
+    for (int p = 1; p < parts; ++p) v = (k == 7) ? fmin(v, ws->partial[p][k]) : (k == 8) ? fmax(v, ws->partial[p][k]) : v + ws->partial[p][k];
+    ws->stats[k] = v;
+}
+
+// intern/pose.py:112-121 (scipy convolve2d mode='same', zero fill, TRUE convolution => flipped taps)
+__device__ __forceinline__ void normals_at(const float *__restrict__ depth, int h, int w, int y, int x, float scale,
+                                           float n[3]) {
+    auto at = [&](int yy, int xx) -> float {
+        return (yy < 0 || yy >= h || xx < 0 || xx >= w) ? 0.0f : scale * depth[(long)yy * w + xx];
+    };
+    // blurred neighbours: [1 2 1]/4 across, [-1 0 1]/2 along (convolution flips the edge taps)
+    const float up = 0.25f * at(y - 1, x - 1) + 0.5f * at(y - 1, x) + 0.25f * at(y - 1, x + 1);
+    const float dn = 0.25f * at(y + 1, x - 1) + 0.5f * at(y + 1, x) + 0.25f * at(y + 1, x + 1);
+    const float lf = 0.25f * at(y - 1, x - 1) + 0.5f * at(y, x - 1) + 0.25f * at(y + 1, x - 1);
+    const float rt = 0.25f * at(y - 1, x + 1) + 0.5f * at(y, x + 1) + 0.25f * at(y + 1, x + 1);
+    // the zero-weight taps still propagate NaN / inf in the reference (0 * NaN = NaN inside convolve2d): the middle
+    // row of the dy stencil and the middle column of the dx stencil, i.e. additionally the centre pixel itself
+    const float zc = 0.0f * at(y, x);
+    const float dy = 0.5f * (up - dn) + 0.0f * (at(y, x - 1) + at(y, x + 1)) + zc;
+    const float dx = 0.5f * (lf - rt) + 0.0f * (at(y - 1, x) + at(y + 1, x)) + zc;
+    const float inv = 1.0f / sqrtf(1.0f + dx * dx + dy * dy);
+    n[0] = dx * inv;
+    n[1] = dy * inv;
+    n[2] = inv;
+}
+
+__global__ void depth_to_normals_kernel(const float *__restrict__ depth, int h, int w, float *__restrict__ normals) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)h * w) return;
+    float n[3];
+    normals_at(depth, h, w, (int)(idx / w), (int)(idx % w), 1.0f, n);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) normals[3 * idx + c] = n[c];
+}
+
+// intern/pose.py:127-146
+__global__ void visualize_normals_kernel(const float *__restrict__ depth, const float *__restrict__ acc, int h, int w,
+                                         const VisScratch *__restrict__ ws, float *__restrict__ vis) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)h * w) return;
+    const double *s = ws->stats;
+    const double cnt = s[0];
+    const double var_x = s[2] / cnt - (s[1] / cnt) * (s[1] / cnt), var_y = s[4] / cnt - (s[3] / cnt) * (s[3] / cnt);
+    const double var_z = s[6] / cnt - (s[5] / cnt) * (s[5] / cnt);
+    const float scale = (float)sqrt(0.5 * (var_x + var_y) / var_z);
+    float n[3];
+    normals_at(depth, h, w, (int)(idx / w), (int)(idx % w), scale, n);
+    const float a = acc ? acc[idx] : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = isnan(n[c]) ? 1.0f : (n[c] + 1.0f) / 2.0f;  // isnan(n) + nan_to_num((n + 1) / 2, 0)
+        vis[3 * idx + c] = acc ? v * a + (1.0f - a) : v;
+    }
+}
+
+__device__ __forceinline__ float sinebow_f(float x) {
+    const float s = sinf(3.14159265358979323846f * x);
+    return s * s;
+}
+
+// intern/pose.py:122-125
+__global__ void sinebow_kernel(const float *__restrict__ hval, long n, float *__restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float hh = hval[idx];
+    out[3 * idx] = sinebow_f(3.0f / 6.0f - hh);
+    out[3 * idx + 1] = sinebow_f(5.0f / 6.0f - hh);
+    out[3 * idx + 2] = sinebow_f(7.0f / 6.0f - hh);
+}
+
+// intern/pose.py:148-212 with the default curve -log(x + eps) and ignore_frac = 0
+__global__ void visualize_depth_kernel(const float *__restrict__ depth, const float *__restrict__ acc, int h, int w,
+                                       float near, float far, int near_auto, int far_auto, float modulus,
+                                       const VisScratch *__restrict__ ws, float *__restrict__ vis) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)h * w) return;
+    const float eps = 1.1920928955078125e-07f;
+    // automatic planes: lowest / highest value of the depth-sorted map (NaNs sort last => far becomes NaN)
+    if (near_auto) near = (float)ws->stats[7] - eps;
+    if (far_auto) far = (ws->stats[9] > 0.0 ? NAN : (float)ws->stats[8]) + eps;
+    const float d = depth[idx];
+    float a = acc ? acc[idx] : 1.0f;
+    if (isnan(d)) a = 0.0f;
+    const float cd = -logf(d + eps), cn = -logf(near + eps), cf = -logf(far + eps);
+    float rgb[3];
+    if (modulus > 0.0f) {
+        float m = fmodf(cd, modulus);  // np.mod: result takes the sign of the divisor
+        if (m != 0.0f && ((m < 0.0f) != (modulus < 0.0f))) m += modulus;
+        const float value = m / modulus;
+        rgb[0] = sinebow_f(3.0f / 6.0f - value);
+        rgb[1] = sinebow_f(5.0f / 6.0f - value);
+        rgb[2] = sinebow_f(7.0f / 6.0f - value);
+    } else {
+        float value = (cd - fminf(cn, cf)) / fabsf(cf - cn);
+        value = nan_to_numf_(fminf(fmaxf(value, 0.0f), 1.0f));
+        if (isnan(cd) || isnan(cn) || isnan(cf)) value = 0.0f;  // np.clip propagates NaN, nan_to_num zeroes it
+        int li = (int)(value * 256.0f);                          // matplotlib ListedColormap lookup (N = 256)
+        li = li > 255 ? 255 : (li < 0 ? 0 : li);
+        rgb[0] = kTurboLut[li][0];
+        rgb[1] = kTurboLut[li][1];
+        rgb[2] = kTurboLut[li][2];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vis[3 * idx + c] = rgb[c] * a + (1.0f - a);
+}
+
+}  // namespace m360
+
+using namespace m360;
+
+static inline hipStream_t S_(m360_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static int launch_stats(const float *depth, int h, int w, VisScratch *ws, hipStream_t st) {
+    const long n = (long)h * w;
+    long parts = (n + 255) / 256;
+    if (parts > kVisParts) parts = kVisParts;
+    hipLaunchKernelGGL(vis_stats_partial_kernel, dim3((unsigned)parts), dim3(256), 0, st, depth, h, w, ws);
+    hipLaunchKernelGGL(vis_stats_final_kernel, dim3(1), dim3(64), 0, st, ws, (int)parts);
+    return check_launch("vis_stats");
+}
+
+extern "C" {
+
+size_t m360_visualize_workspace_bytes(void) { return sizeof(VisScratch); }
+
+int m360_depth_to_normals(const float *depth, int h, int w, float *normals, m360_stream_t stream) {
+    if (!depth || !normals || h < 1 || w < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_depth_to_normals: bad argument");
+    const long n = (long)h * w;
+    hipLaunchKernelGGL(depth_to_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), depth, h, w, normals);
+    return check_launch("depth_to_normals");
+}
+
+int m360_sinebow(const float *hval, long n, float *rgb, m360_stream_t stream) {
+    if (!hval || !rgb || n < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_sinebow: bad argument");
+    if (n == 0) return M360_OK;
+    hipLaunchKernelGGL(sinebow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), hval, n, rgb);
+    return check_launch("sinebow");
+}
+
+int m360_visualize_normals(const float *depth, const float *acc, int h, int w, float *vis, void *workspace,
+                           size_t workspace_bytes, m360_stream_t stream) {
+    if (!depth || !vis || h < 1 || w < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_visualize_normals: bad argument");
+    if (!workspace || workspace_bytes < sizeof(VisScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_visualize_normals: workspace %zu < %zu", workspace_bytes, sizeof(VisScratch));
+    VisScratch *ws = static_cast<VisScratch *>(workspace);
+    const int rc = launch_stats(depth, h, w, ws, S_(stream));
+    if (rc != M360_OK) return rc;
+    const long n = (long)h * w;
+    hipLaunchKernelGGL(visualize_normals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), depth, acc, h, w, ws, vis);
+    return check_launch("visualize_normals");
+}
+
+int m360_visualize_depth(const float *depth, const float *acc, int h, int w, float near, float far, int near_auto,
+                         int far_auto, float modulus, float *vis, void *workspace, size_t workspace_bytes,
+                         m360_stream_t stream) {
+    if (!depth || !vis || h < 1 || w < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_visualize_depth: bad argument");
+    if (!workspace || workspace_bytes < sizeof(VisScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_visualize_depth: workspace %zu < %zu", workspace_bytes, sizeof(VisScratch));
+    VisScratch *ws = static_cast<VisScratch *>(workspace);
+    if (near_auto || far_auto) {
+        const int rc = launch_stats(depth, h, w, ws, S_(stream));
+        if (rc != M360_OK) return rc;
+    }
+    const long n = (long)h * w;
+    hipLaunchKernelGGL(visualize_depth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), depth, acc, h, w, near, far, near_auto, far_auto, modulus, ws, vis);
+    return check_launch("visualize_depth");
+}
+
+}  // extern "C"

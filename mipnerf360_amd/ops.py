@@ -330,3 +330,45 @@ def convert_to_ndc(origins, directions, focal: float, w: int, h: int, near: floa
     _call("m360_convert_to_ndc", ptr(origins), ptr(directions), origins.numel() // 3, float(focal), int(w), int(h),
           float(near), ptr(oo), ptr(do), stream())
     return oo, do
+
+
+# ----------------------------------------------------------------------------- visualisation
+def _vis_ws(device) -> torch.Tensor:
+    return torch.empty(_lib.lib().m360_visualize_workspace_bytes(), dtype=torch.uint8, device=device)
+
+
+def depth_to_normals(depth) -> torch.Tensor:
+    depth = dev(depth, "depth")
+    h, w = depth.shape
+    out = torch.empty(h, w, 3, device=depth.device)
+    _call("m360_depth_to_normals", ptr(depth), h, w, ptr(out), stream())
+    return out
+
+
+def sinebow(hval) -> torch.Tensor:
+    hval = dev(hval, "h")
+    out = torch.empty(hval.shape + (3,), device=hval.device)
+    _call("m360_sinebow", ptr(hval), hval.numel(), ptr(out), stream())
+    return out
+
+
+def visualize_normals(depth, acc=None) -> torch.Tensor:
+    depth = dev(depth, "depth")
+    acc = None if acc is None else dev(acc, "acc")
+    h, w = depth.shape
+    out = torch.empty(h, w, 3, device=depth.device)
+    ws = _vis_ws(depth.device)
+    _call("m360_visualize_normals", ptr(depth), ptr(acc), h, w, ptr(out), ptr(ws), ws.numel(), stream())
+    return out
+
+
+def visualize_depth(depth, acc=None, near=None, far=None, modulus: float = 0.0) -> torch.Tensor:
+    """near / far falsy (None or 0, as in the reference's `near or ...`) -> taken from the depth map."""
+    depth = dev(depth, "depth")
+    acc = None if acc is None else dev(acc, "acc")
+    h, w = depth.shape
+    out = torch.empty(h, w, 3, device=depth.device)
+    ws = _vis_ws(depth.device)
+    _call("m360_visualize_depth", ptr(depth), ptr(acc), h, w, float(near or 0.0), float(far or 0.0), int(not near),
+          int(not far), float(modulus), ptr(out), ptr(ws), ws.numel(), stream())
+    return out

@@ -408,3 +408,66 @@ def generate_rays(cam_to_world: np.ndarray, h: int, w: int, focal, near, far, nd
     ones = np.ones_like(radii)
     out = dict(origins=origins, directions=dirs, viewdirs=viewdirs, radii=radii, near=ones * near, far=ones * far)
     return {k: np.ascontiguousarray(v, dtype=np.float32).reshape(-1, v.shape[-1]) for k, v in out.items()}
+
+
+# --------------------------------------------------------------------------- visualisation (row f2)
+def _conv3_same(z: np.ndarray, k: np.ndarray) -> np.ndarray:
+    """scipy.signal.convolve2d(z, k, mode='same') for a 3x3 kernel: true convolution, zero fill."""
+    zp = np.pad(z, 1)
+    out = np.zeros_like(z, dtype=np.result_type(z, k))
+    for i in range(3):
+        for j in range(3):
+            out += k[i, j] * zp[2 - i:2 - i + z.shape[0], 2 - j:2 - j + z.shape[1]]
+    return out
+
+
+def depth_to_normals(depth: np.ndarray) -> np.ndarray:
+    """intern/pose.py:112-121."""
+    blur, edge = np.array([1, 2, 1]) / 4, np.array([-1, 0, 1]) / 2
+    dy = _conv3_same(depth, blur[None, :] * edge[:, None])
+    dx = _conv3_same(depth, blur[:, None] * edge[None, :])
+    inv = 1 / np.sqrt(1 + dx ** 2 + dy ** 2)
+    return np.stack([dx * inv, dy * inv, inv], -1)
+
+
+def sinebow(h):
+    """intern/pose.py:122-125."""
+    f = lambda x: np.sin(np.pi * x) ** 2  # noqa: E731
+    return np.stack([f(3 / 6 - h), f(5 / 6 - h), f(7 / 6 - h)], -1)
+
+
+def visualize_normals(depth: np.ndarray, acc: Optional[np.ndarray]) -> np.ndarray:
+    """intern/pose.py:127-146 (scaling=None)."""
+    mask = ~np.isnan(depth)
+    x, y = np.meshgrid(np.arange(depth.shape[1]), np.arange(depth.shape[0]), indexing="xy")
+    scaling = np.sqrt((np.var(x[mask]) + np.var(y[mask])) / 2 / np.var(depth[mask].astype(np.float64)))
+    normals = depth_to_normals(scaling * depth.astype(np.float64))
+    vis = np.isnan(normals) + np.nan_to_num((normals + 1) / 2, nan=0)
+    if acc is not None:
+        vis = vis * acc[:, :, None] + (1 - acc)[:, :, None]
+    return vis
+
+
+def turbo_lut() -> np.ndarray:
+    """The 256 x 3 'turbo' table the reference gets from matplotlib (cm.get_cmap('turbo'), intern/pose.py:197)."""
+    import matplotlib
+    return np.asarray(matplotlib.colormaps["turbo"](np.arange(256))[:, :3])
+
+
+def visualize_depth(depth: np.ndarray, acc=None, near=None, far=None, modulus: float = 0.0) -> np.ndarray:
+    """intern/pose.py:148-212 with the default curve, ignore_frac = 0 and the default colormaps."""
+    eps = np.finfo(np.float32).eps
+    acc = np.ones_like(depth) if acc is None else acc
+    acc = np.where(np.isnan(depth), np.zeros_like(acc), acc)
+    flat = np.sort(depth.reshape(-1))  # NaNs last, like the reference's argsort
+    near = near or flat[0] - eps
+    far = far or flat[-1] + eps
+    curve = lambda v: -np.log(v + eps)  # noqa: E731
+    d, cn, cf = curve(depth), curve(near), curve(far)
+    if modulus > 0:
+        rgb = sinebow(np.mod(d, modulus) / modulus)
+    else:
+        value = np.nan_to_num(np.clip((d - np.minimum(cn, cf)) / np.abs(cf - cn), 0, 1))
+        idx = np.minimum((value * 256).astype(int), 255)
+        rgb = turbo_lut()[idx]
+    return rgb * acc[:, :, None] + (1 - acc)[:, :, None]

@@ -311,9 +311,41 @@ def g10():
     save("g10_ray_generation", **out)
 
 
+def g11():
+    """Visualisation: visualize_depth / visualize_normals / depth_to_normals / sinebow of
+    intern/pose.py:112-212 on a synthetic depth + accumulation map.  The reference calls `cm.get_cmap('turbo')`,
+    removed in matplotlib >= 3.9 (3.10.8 here): patched to the equivalent `matplotlib.colormaps['turbo']`."""
+    import matplotlib
+    import matplotlib.cm as cm
+    if not hasattr(cm, "get_cmap"):
+        cm.get_cmap = lambda name: matplotlib.colormaps[name]
+    from intern import pose as ref_pose
+    g = np.random.Generator(np.random.PCG64(1111))
+    h, w = 23, 31
+    yy, xx = np.meshgrid(np.linspace(-1, 1, h), np.linspace(-1, 1, w), indexing="ij")
+    depth = (3.0 + np.sin(3 * xx) * np.cos(2 * yy) + 0.05 * g.normal(size=(h, w))).astype(np.float32)
+    acc = np.clip(g.uniform(0.2, 1.1, size=(h, w)), 0, 1).astype(np.float32)
+    out = dict(depth=depth, acc=acc)
+    out["normals"] = ref_pose.depth_to_normals(depth)
+    out["vis_normals"] = ref_pose.visualize_normals(depth, acc)
+    out["vis_normals_noacc"] = ref_pose.visualize_normals(depth, None)
+    out["vis_depth_given"] = ref_pose.visualize_depth(depth, acc, 2.0, 6.0)          # blender-style near/far
+    out["vis_depth_auto"] = ref_pose.visualize_depth(depth, acc, 0.0, 1.0)           # near = 0 is falsy -> automatic near
+    out["vis_depth_auto2"] = ref_pose.visualize_depth(depth, None, None, None)
+    out["vis_depth_mod"] = ref_pose.visualize_depth(depth, acc, 2.0, 6.0, modulus=0.25)
+    out["sinebow"] = ref_pose.sinebow(np.linspace(-0.5, 1.5, 41))
+    depth_nan = depth.copy()
+    depth_nan[3, 4] = np.nan
+    depth_nan[h - 1, 0] = np.nan
+    out["depth_nan"] = depth_nan
+    out["vis_depth_nan"] = ref_pose.visualize_depth(depth_nan, acc, 2.0, 6.0)
+    out["vis_normals_nan"] = ref_pose.visualize_normals(depth_nan, acc)
+    save("g11_visualisation", **{k: np.asarray(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
-    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
     for k in which:
         print(k)
         table[k]()

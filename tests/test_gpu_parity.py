@@ -501,6 +501,44 @@ def test_forward_bf16_mode(dev, kind, B, n, hp, hn, wb):
     assert -10 * np.log10(max(mse, 1e-20)) > 45.0  # PSNR of the bf16 render against the fp32 render
 
 
+def test_g11_visualisation(golden, dev):
+    """Row (f2): device versions of intern/pose.py's depth / normal visualisation vs the reference (fixture G11)
+    and vs the oracle on a larger seeded map; NumPy in -> NumPy out like the reference."""
+    from mipnerf360_amd.intern import pose as P
+    from oracle import ref_path as O
+
+    def lut_close(a, b, frac=0.01, step=0.05):
+        d = np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max(-1)
+        assert d.max() <= step and (d > 1e-5).mean() <= frac, (d.max(), (d > 1e-5).mean())
+
+    g = golden("g11_visualisation")
+    depth, acc = g["depth"], g["acc"]
+    close(P.depth_to_normals(depth), g["normals"], atol=2e-6)
+    close(P.visualize_normals(depth, acc), g["vis_normals"], atol=1e-5)
+    close(P.visualize_normals(depth, None), g["vis_normals_noacc"], atol=1e-5)
+    close(P.visualize_normals(g["depth_nan"], acc), g["vis_normals_nan"], atol=1e-5)
+    assert P.visualize_normals(depth, acc, scaling=2.0) is None  # the reference falls through for scaling != None
+    close(P.sinebow(np.linspace(-0.5, 1.5, 41).astype(np.float32)), g["sinebow"], atol=2e-6)
+    lut_close(P.visualize_depth(depth, acc, 2.0, 6.0), g["vis_depth_given"])
+    lut_close(P.visualize_depth(depth, acc, 0.0, 1.0), g["vis_depth_auto"])      # near = 0 is falsy -> automatic
+    lut_close(P.visualize_depth(depth, None, None, None), g["vis_depth_auto2"])
+    lut_close(P.visualize_depth(g["depth_nan"], acc, 2.0, 6.0), g["vis_depth_nan"])
+    close(P.visualize_depth(depth, acc, 2.0, 6.0, modulus=0.25), g["vis_depth_mod"], atol=2e-4)
+    out = P.visualize_depth(D(depth, dev), D(acc, dev), np.float32(2.0), np.array([6.0]))  # tensors in -> tensor out
+    assert isinstance(out, torch.Tensor) and out.shape == depth.shape + (3,)
+    with pytest.raises(NotImplementedError):
+        P.visualize_depth(depth, acc, 2.0, 6.0, ignore_frac=0.1)
+    gen = np.random.Generator(np.random.PCG64(3))
+    big = (2.0 + gen.gamma(2.0, 1.0, size=(301, 517))).astype(np.float32)
+    bacc = gen.uniform(0, 1, size=big.shape).astype(np.float32)
+    close(P.visualize_normals(big, bacc), O.visualize_normals(big, bacc), atol=2e-5)
+    lut_close(P.visualize_depth(big, bacc, None, None), O.visualize_depth(big, bacc, None, None))
+    # end to end: render -> device visualisation -> uint8, as test.py:52-56 does with numpy + to8b
+    from mipnerf360_amd.intern.utils import to8b
+    img = to8b(P.visualize_depth(big, bacc, 1.0, 20.0))
+    assert img.dtype == np.uint8 and img.shape == big.shape + (3,)
+
+
 def test_empty_batch(dev):
     m = build_model(synthetic.make_state_dict(32, 32, seed=1), dev, 16, 32, 32, False)
     r = dev_rays(synthetic.make_rays("lego", 0, seed=1), dev)

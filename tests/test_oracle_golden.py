@@ -139,6 +139,59 @@ def test_g10_ray_generation(golden, name, ndc):
     close(o, g["ndc_out_o"], atol=1e-7), close(d, g["ndc_out_d"], atol=1e-7)
 
 
+def _lut_close(a, b, frac=0.01, step=0.05):
+    """colour images: equal up to rounding, except that a pixel sitting exactly on a colormap-bin edge may land in
+    the neighbouring one of the 256 turbo entries (one LUT step, < 0.05)."""
+    d = np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max(-1)
+    assert d.max() <= step and (d > 2e-6).mean() <= frac, (d.max(), (d > 2e-6).mean())
+
+
+def test_g11_visualisation(golden):
+    """Row (f2): depth_to_normals / visualize_normals / visualize_depth / sinebow of intern/pose.py."""
+    g = golden("g11_visualisation")
+    depth, acc = g["depth"], g["acc"]
+    close(O.depth_to_normals(depth), g["normals"], atol=1e-6)
+    close(O.visualize_normals(depth, acc), g["vis_normals"], atol=2e-6)
+    close(O.visualize_normals(depth, None), g["vis_normals_noacc"], atol=2e-6)
+    close(O.visualize_normals(g["depth_nan"], acc), g["vis_normals_nan"], atol=2e-6)
+    close(O.sinebow(np.linspace(-0.5, 1.5, 41)), g["sinebow"], atol=1e-12)
+    _lut_close(O.visualize_depth(depth, acc, 2.0, 6.0), g["vis_depth_given"])
+    _lut_close(O.visualize_depth(depth, acc, 0.0, 1.0), g["vis_depth_auto"])
+    _lut_close(O.visualize_depth(depth, None, None, None), g["vis_depth_auto2"])
+    _lut_close(O.visualize_depth(g["depth_nan"], acc, 2.0, 6.0), g["vis_depth_nan"])
+    close(O.visualize_depth(depth, acc, 2.0, 6.0, modulus=0.25), g["vis_depth_mod"], atol=2e-5)
+    assert np.all(g["vis_depth_nan"][3, 4] == 1.0)  # NaN depth -> acc 0 -> white
+
+
+def test_png_writer_roundtrip(tmp_path):
+    """cv2-free PNG path: decode our own bytes with zlib and compare pixel for pixel."""
+    import struct
+    import zlib
+    from mipnerf360_amd.png import encode_png, write_png
+    rng = np.random.default_rng(0)
+    for shape in ((5, 7, 3), (4, 9), (3, 3, 4)):
+        img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        data = encode_png(img)
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat, ihdr = 8, b"", None
+        while pos < len(data):
+            n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+            body = data[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xFFFFFFFF
+            if tag == b"IHDR":
+                ihdr = struct.unpack(">IIBBBBB", body)
+            if tag == b"IDAT":
+                idat += body
+            pos += 12 + n
+        h, w = img.shape[:2]
+        assert ihdr[:3] == (w, h, 8)
+        rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, -1)
+        assert np.all(rows[:, 0] == 0) and np.array_equal(rows[:, 1:].reshape(img.shape), img)
+    write_png(str(tmp_path / "x.png"), np.zeros((2, 2, 3), np.uint8))
+    with pytest.raises(ValueError):
+        encode_png(np.zeros((2, 2, 3), np.float32))
+
+
 def test_g9_chunk_dependence_is_real(golden):
     """The reference's global-norm contraction makes results depend on the chunk partition."""
     g = golden("g9_render_image")
