@@ -539,6 +539,29 @@ def test_g11_visualisation(golden, dev):
     assert img.dtype == np.uint8 and img.shape == big.shape + (3,)
 
 
+def test_rccl_path_single_rank_torchrun(dev):
+    """The multi-GPU code path (torch.distributed 'nccl' = RCCL, all_gather_into_tensor of the pixel block) launched
+    exactly like the driver launches bench.py, with one rank (the GPU box has one GPU): tools/dist_check.py compares
+    the sharded render with the single-process render bit for bit, and bench.py must run under torchrun."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+            "127.0.0.1", "--master-port"]
+    res = subprocess.run(base + ["29541", os.path.join(root, "tools", "dist_check.py")], env=env, cwd=root,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0 and "sharded==single: True" in res.stdout, res.stdout[-2000:]
+    res = subprocess.run(base + ["29542", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                                 "--cpu-rays", "0"], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:]
+    import json
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1000 and line["roofline"]["frac"] > 0.5 and line["dtype"] == "f32"
+
+
 def test_empty_batch(dev):
     m = build_model(synthetic.make_state_dict(32, 32, seed=1), dev, 16, 32, 32, False)
     r = dev_rays(synthetic.make_rays("lego", 0, seed=1), dev)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Multi-GPU path check, one process per GPU over RCCL (backend "nccl"):
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port 29533 \
+         tools/dist_check.py
+
+Every rank renders the same small synthetic frame with `render_image_sharded` (chunk-granular ray sharding +
+one all-gather of the [rays,5] pixel block) and compares it bit for bit with its own single-GPU `render_image`.
+Works with N = 1 as well (the all-gather then has a single participant)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from mipnerf360_amd import synthetic  # noqa: E402
+from mipnerf360_amd.distributed import render_image_sharded  # noqa: E402
+from mipnerf360_amd.intern.ray import Rays  # noqa: E402
+from mipnerf360_amd.model import mipNeRF360  # noqa: E402
+
+
+def main():
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("nccl", device_id=dev)
+    h, w, n, chunks = 40, 53, 32, 256
+    sd = synthetic.make_state_dict(64, 128, seed=3)
+    m = mipNeRF360(num_samples=n, hidden_proposal=64, hidden_nerf=128, device=dev)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    r = synthetic.make_rays("garden", h * w, seed=21)
+    rays = Rays(*[torch.from_numpy(r[k]) for k in synthetic.RAY_FIELDS])
+    single = m.render_image(rays, h, w, chunks=chunks)
+    sharded = render_image_sharded(m, rays, h, w, chunks=chunks)
+    ok = all(np.array_equal(a, b) for a, b in zip(single, sharded))
+    flag = torch.tensor([1 if ok else 0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if dist.get_rank() == 0:
+        print(f"dist_check world={dist.get_world_size()} sharded==single: {bool(flag.item())}")
+    dist.destroy_process_group()
+    if not flag.item():
+        raise SystemExit(1)
+
+
+if __name__ == "__main__":
+    main()
