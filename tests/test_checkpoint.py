@@ -1,0 +1,64 @@
+"""Row (f4): checkpoint tooling — the reference's torch.save'd state_dict loads unchanged; architecture is inferred
+from tensor shapes; the packed (padded / bf16) layout for C-ABI consumers round-trips."""
+import numpy as np
+import pytest
+import torch
+
+from mipnerf360_amd import checkpoint, synthetic
+
+
+def _save_reference_style(tmp_path, hp, hn, max_deg=4, seed=0):
+    sd = synthetic.make_state_dict(hp, hn, seed=seed, viewdir_max_deg=max_deg)
+    path = tmp_path / "model_100.pt"  # train.py:99 naming
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, str(path))
+    return sd, str(path)
+
+
+def test_infer_config_and_cpu_roundtrip(tmp_path):
+    sd, path = _save_reference_style(tmp_path, 96, 160, max_deg=3)
+    cfg = checkpoint.infer_config(torch.load(path))
+    assert cfg == dict(hidden_proposal=96, hidden_nerf=160, viewdir_min_deg=0, viewdir_max_deg=3)
+    m = checkpoint.load_reference_checkpoint(path, device=torch.device("cpu"), num_samples=32, white_bkgd=True)
+    assert m.num_samples == 32 and m.white_bkgd is True and not m.training
+    back = checkpoint.to_reference_state_dict(m)
+    assert list(back) == list(sd) and all(np.array_equal(back[k].numpy(), sd[k]) for k in sd)
+    with pytest.raises(KeyError):
+        checkpoint.infer_config({"foo": torch.zeros(1)})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_packed_export_matches_padded_weights(tmp_path, dtype):
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    sd, path = _save_reference_style(tmp_path, 100, 200, seed=3)  # widths that need padding (128 / 256 for bf16: 128, 256)
+    m = checkpoint.load_reference_checkpoint(path, device=dev, num_samples=16, mlp_dtype=dtype)
+    packed = checkpoint.export_packed(m)
+    pad = 64 if dtype == "bf16" else 32
+    in_ch, in_pad, hp_pad, hn_pad, is_bf16 = (int(x) for x in packed["meta"])
+    assert (in_ch, in_pad, is_bf16) == (58, 64, int(dtype == "bf16"))
+    assert hp_pad == -(-100 // pad) * pad and hn_pad == -(-200 // pad) * pad
+    w0 = packed["nerf.w0"]
+    assert w0.shape == (hn_pad, in_pad)
+    ref = np.zeros((hn_pad, in_pad), np.float32)
+    ref[:200, :58] = sd["nerf_net.model.0.weight"]
+    if dtype == "bf16":
+        assert w0.dtype == np.uint16
+        got = torch.from_numpy(w0.view(np.int16).copy()).view(torch.bfloat16).float().numpy()
+        assert np.array_equal(got, torch.from_numpy(ref).bfloat16().float().numpy())
+    else:
+        assert np.array_equal(w0, ref)
+    assert packed["nerf.head_w"].shape == (4, hn_pad) and packed["prop.head_w"].shape == (1, hp_pad)
+    assert np.array_equal(packed["nerf.head_w"][0, :200], sd["nerf_net.final_density.0.weight"][0])
+    assert np.array_equal(packed["nerf.head_w"][1:, :200], sd["nerf_net.final_color.0.weight"])
+    checkpoint.save_packed(m, str(tmp_path / "packed.npz"))
+    again = checkpoint.load_packed(str(tmp_path / "packed.npz"))
+    assert all(np.array_equal(again[k], packed[k]) for k in packed)
+    # the loaded model renders (padding path: 100 -> 128, 200 -> 224/256 columns)
+    from mipnerf360_amd.intern.ray import Rays
+    from oracle import ref_path as O
+    r = synthetic.make_rays("lego", 40, seed=2)
+    rgb, dist, acc = m(Rays(*[torch.from_numpy(r[k]).to(dev) for k in synthetic.RAY_FIELDS]))
+    o = O.forward(O.rays_from_numpy(r), O.to_torch_state_dict(sd), O.Hyper(num_samples=16, mlp_bf16=(dtype == "bf16")))
+    tol = 6e-3 if dtype == "bf16" else 1e-4
+    assert float((rgb.cpu() - o[0]).abs().max()) <= tol and float((acc.cpu() - o[2]).abs().max()) <= tol
