@@ -217,6 +217,34 @@ int m360_visualize_depth(const float *depth, const float *acc, int h, int w, flo
                          int near_auto, int far_auto, float modulus, float *vis, void *workspace,
                          size_t workspace_bytes, m360_stream_t stream);
 
+/* ------------------------------------------------------------------ losses (row f3) --- */
+
+/* workspace for the three loss entry points; N = number of proposal intervals (0 for loss_dist / loss_nerf) */
+size_t m360_loss_workspace_bytes(int B, int N);
+
+/* proposal ("envelope") loss, intern/loss.py:6-21 = distillation.py:4-51.  The reference's bounds() selects
+ * fine_weights[..., mask] with a [B,Nf] mask (distillation.py:29), which flattens over the rays, so
+ *   bounds[b,i] = sum over ALL rays b' and fine intervals j of w[b',j] [not (t0[b',j] > T1[b',i] or t1[b',j] < T0[b',i])]
+ * (the batch total, identical for every b) - reproduced here: per-ray overlap sums, then an fp64 column sum.
+ * loss[0] = sum relu(bounds - w_hat)^2 / (w_hat + 1e-6) / B; optional outputs bounds[B,Np] and
+ * grad_w_hat[B,Np] = d loss / d w_hat (bounds detached, as in the reference).  t == NULL: `w` [B,Np] already
+ * holds the bounds (the reference's two-step bounds() -> loss_prop() use), t_hat is ignored, Nf must equal Np. */
+int m360_loss_prop(const float *t /*[B,Nf+1]*/, const float *w /*[B,Nf]*/, const float *t_hat /*[B,Np+1]*/,
+                   const float *w_hat /*[B,Np]*/, int B, int Nf, int Np, float *bounds, float *loss,
+                   float *grad_w_hat, void *workspace, size_t workspace_bytes, m360_stream_t stream);
+
+/* distortion loss, summed over rays: sum_ij w_i w_j |m_i - m_j| + 1/3 sum_i w_i^2 (s_{i+1} - s_i);
+ * optional gradients grad_w[B,N], grad_s[B,N+1].  Replaces intern/regularization.py:3-19 (O(N^2) Python
+ * double loop) and intern/loss.py:42-54. */
+int m360_loss_dist(const float *s_vals /*[B,N+1]*/, const float *weights /*[B,N]*/, int B, int N, float *loss,
+                   float *grad_w, float *grad_s, void *workspace, size_t workspace_bytes,
+                   m360_stream_t stream);
+
+/* reconstruction loss: mse = sum (input - target)^2 / B; out3 = {10 log10(mse) + 30, psnr, mse}; optional
+ * grad_input[B,C] of out3[0].  Replaces intern/loss.py:23-40,57-59 (Loss_nerf, mse_to_psnr). */
+int m360_loss_nerf(const float *input /*[B,C]*/, const float *target, int B, int C, float *out3,
+                   float *grad_input, void *workspace, size_t workspace_bytes, m360_stream_t stream);
+
 /* ------------------------------------------------------------------ fused stages ------ */
 
 /* last proposal layer (hidden -> 1) + softplus(raw + density_bias) + density_to_weight +

@@ -16,11 +16,14 @@ def install_dropin() -> None:
     """Make `import model` / `from intern.ray import ...` (the reference's module names, as used
     by its train.py / test.py / video.py) resolve to this package."""
     from . import intern, model
-    from .intern import encoding, parameterization, pose, ray, utils
+    from .intern import distillation, encoding, loss, parameterization, pose, ray, regularization, utils
     sys.modules["model"] = model
     sys.modules["intern"] = intern
     sys.modules["intern.ray"] = ray
     sys.modules["intern.parameterization"] = parameterization
     sys.modules["intern.encoding"] = encoding
     sys.modules["intern.utils"] = utils
+    sys.modules["intern.loss"] = loss
+    sys.modules["intern.distillation"] = distillation
+    sys.modules["intern.regularization"] = regularization
     sys.modules["intern.pose"] = pose  # visualisation half only (visualize_depth / visualize_normals)

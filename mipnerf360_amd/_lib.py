@@ -77,6 +77,10 @@ SIGNATURES = {
     "m360_prop_finish_n": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_volumetric_rendering": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "m360_to8b": (_i, [_vp, _l, _vp, _vp]),
+    "m360_loss_workspace_bytes": (_sz, [_i, _i]),
+    "m360_loss_prop": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m360_loss_dist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m360_loss_nerf": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "m360_visualize_workspace_bytes": (_sz, []),
     "m360_depth_to_normals": (_i, [_vp, _i, _i, _vp, _vp]),
     "m360_sinebow": (_i, [_vp, _l, _vp, _vp]),

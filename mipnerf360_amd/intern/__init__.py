@@ -1,3 +1,3 @@
 """Same-named mirrors of the reference's `intern.ray`, `intern.parameterization`,
 `intern.encoding` and `intern.utils` modules, backed by libm360 HIP kernels."""
-from . import encoding, parameterization, pose, ray, utils  # noqa: F401
+from . import distillation, encoding, loss, parameterization, pose, ray, regularization, utils  # noqa: F401

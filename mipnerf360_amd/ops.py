@@ -372,3 +372,58 @@ def visualize_depth(depth, acc=None, near=None, far=None, modulus: float = 0.0) 
     _call("m360_visualize_depth", ptr(depth), ptr(acc), h, w, float(near or 0.0), float(far or 0.0), int(not near),
           int(not far), float(modulus), ptr(out), ptr(ws), ws.numel(), stream())
     return out
+
+
+# ----------------------------------------------------------------------------- losses (row f3)
+def _loss_ws(B: int, device, N: int = 0) -> torch.Tensor:
+    return torch.empty(_lib.lib().m360_loss_workspace_bytes(int(B), int(N)), dtype=torch.uint8, device=device)
+
+
+def loss_prop(t, w, t_hat, w_hat, want_grad: bool = False):
+    """-> (loss[1], bounds[B,Np], grad_w_hat[B,Np] or None)"""
+    t, w, t_hat, w_hat = dev(t, "t"), dev(w, "w"), dev(t_hat, "t_hat"), dev(w_hat, "w_hat")
+    B, Nf = w.shape
+    Np = w_hat.shape[1]
+    d = t.device
+    loss, bounds = torch.empty(1, device=d), torch.empty(B, Np, device=d)
+    grad = torch.empty(B, Np, device=d) if want_grad else None
+    ws = _loss_ws(B, d, Np)
+    _call("m360_loss_prop", ptr(t), ptr(w), ptr(t_hat), ptr(w_hat), B, Nf, Np, ptr(bounds), ptr(loss), ptr(grad), ptr(ws),
+          ws.numel(), stream())
+    return loss, bounds, grad
+
+
+def loss_prop_given_bounds(bounds, w_hat, want_grad: bool = False):
+    """loss_prop with precomputed bounds -> (loss[1], grad_w_hat or None)"""
+    bounds, w_hat = dev(bounds, "bounds"), dev(w_hat, "w_hat")
+    B, Np = w_hat.shape
+    loss = torch.empty(1, device=w_hat.device)
+    grad = torch.empty(B, Np, device=w_hat.device) if want_grad else None
+    ws = _loss_ws(B, w_hat.device, Np)
+    _call("m360_loss_prop", None, ptr(bounds), None, ptr(w_hat), B, Np, Np, None, ptr(loss), ptr(grad), ptr(ws), ws.numel(),
+          stream())
+    return loss, grad
+
+
+def loss_dist(s_vals, weights, want_grad: bool = False):
+    """-> (loss[1], grad_w[B,N] or None, grad_s[B,N+1] or None)"""
+    s_vals, weights = dev(s_vals, "s_vals"), dev(weights, "weights")
+    B, N = weights.shape
+    d = s_vals.device
+    loss = torch.empty(1, device=d)
+    gw = torch.empty(B, N, device=d) if want_grad else None
+    gs = torch.empty(B, N + 1, device=d) if want_grad else None
+    ws = _loss_ws(B, d)
+    _call("m360_loss_dist", ptr(s_vals), ptr(weights), B, N, ptr(loss), ptr(gw), ptr(gs), ptr(ws), ws.numel(), stream())
+    return loss, gw, gs
+
+
+def loss_nerf(inp, target, want_grad: bool = False):
+    """-> (out3 = [10 log10(mse) + 30, psnr, mse], grad_input[B,C] or None)"""
+    inp, target = dev(inp, "input"), dev(target, "target")
+    B, Cc = inp.shape
+    out3 = torch.empty(3, device=inp.device)
+    grad = torch.empty_like(inp) if want_grad else None
+    ws = _loss_ws(B, inp.device)
+    _call("m360_loss_nerf", ptr(inp), ptr(target), B, Cc, ptr(out3), ptr(grad), ptr(ws), ws.numel(), stream())
+    return out3, grad

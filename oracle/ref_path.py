@@ -471,3 +471,65 @@ def visualize_depth(depth: np.ndarray, acc=None, near=None, far=None, modulus: f
         idx = np.minimum((value * 256).astype(int), 255)
         rgb = turbo_lut()[idx]
     return rgb * acc[:, :, None] + (1 - acc)[:, :, None]
+
+
+# ------------------------------------------------------------------------------------------ losses (row f3)
+def prop_bounds(t: torch.Tensor, w: torch.Tensor, t_hat: torch.Tensor) -> torch.Tensor:
+    """intern/distillation.py:4-33.  The mask at :29 is [B, Nf] and indexes `fine_weights[..., mask]`, which flattens
+    over the rays: bounds[:, i] is the overlap sum of the WHOLE BATCH, the same for every ray (no gradient)."""
+    t0, t1, lo, hi = t[..., :-1], t[..., 1:], t_hat[..., :-1], t_hat[..., 1:]
+    overlap = ~((t0[:, None, :] > hi[:, :, None]) | (t1[:, None, :] < lo[:, :, None]))  # [B, Np, Nf]
+    per_ray = (overlap * w[:, None, :].double()).sum(-1)                                   # [B, Np]
+    return per_ray.sum(0, keepdim=True).float().expand(w.shape[0], -1).contiguous().detach()
+
+
+def loss_prop_given(w_hat: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
+    """intern/distillation.py:35-51."""
+    return (torch.relu(bounds - w_hat).square() / (w_hat + 1e-6)).sum() / bounds.shape[0]
+
+
+def loss_prop(t, w, t_hat, w_hat) -> torch.Tensor:
+    """intern/loss.py:6-21."""
+    return loss_prop_given(w_hat, prop_bounds(t, w, t_hat))
+
+
+def loss_prop_grad(w_hat: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
+    """closed form of d loss_prop / d w_hat (what autograd returns for distillation.py:48-49)."""
+    r, den = torch.relu(bounds - w_hat), w_hat + 1e-6
+    return -(2 * r * den + r * r) / (den * den) / bounds.shape[0]
+
+
+def loss_dist(s_vals: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """intern/regularization.py:3-19 (the double Python loop as one outer difference), summed over rays."""
+    m = (s_vals[..., :-1] + s_vals[..., 1:]) / 2
+    pair = (weights[:, :, None] * weights[:, None, :] * (m[:, :, None] - m[:, None, :]).abs()).sum()
+    return pair + (1 / 3) * (weights ** 2 * (s_vals[..., 1:] - s_vals[..., :-1])).sum()
+
+
+def loss_dist_grads(s_vals: torch.Tensor, weights: torch.Tensor):
+    """closed-form gradients of loss_dist -> (grad_s [B, N+1], grad_w [B, N]); sign(0) = 0 like torch.abs'."""
+    m = (s_vals[..., :-1] + s_vals[..., 1:]) / 2
+    d = m[:, :, None] - m[:, None, :]
+    ds = s_vals[..., 1:] - s_vals[..., :-1]
+    grad_w = 2 * (weights[:, None, :] * d.abs()).sum(-1) + (2 / 3) * weights * ds
+    gm = 2 * weights * (weights[:, None, :] * torch.sign(d)).sum(-1)
+    grad_s = torch.zeros_like(s_vals)
+    grad_s[:, :-1] += 0.5 * gm - (1 / 3) * weights ** 2
+    grad_s[:, 1:] += 0.5 * gm + (1 / 3) * weights ** 2
+    return grad_s, grad_w
+
+
+def mse_to_psnr(mse):
+    """intern/loss.py:57-59."""
+    return -10.0 * torch.log10(mse)
+
+
+def loss_nerf(inp: torch.Tensor, target: torch.Tensor):
+    """intern/loss.py:23-40 -> (10 log10(mse) + 30, psnr); mse is the squared error summed over rgb / batch."""
+    mse = ((inp[..., :3] - target[..., :3]) ** 2).sum() / inp.shape[0]
+    return -mse_to_psnr(mse) + 30, mse_to_psnr(mse)
+
+
+def loss_nerf_grad(inp: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    mse = ((inp[..., :3] - target[..., :3]) ** 2).sum() / inp.shape[0]
+    return (10 / np.log(10)) / mse * 2 * (inp[..., :3] - target[..., :3]) / inp.shape[0]

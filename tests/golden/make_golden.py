@@ -343,9 +343,50 @@ def g11():
     save("g11_visualisation", **{k: np.asarray(v) for k, v in out.items()})
 
 
+def g12():
+    """Losses: Loss_prop / Loss_nerf / Loss_dist of intern/loss.py with the autograd
+    gradients w.r.t. their direct inputs, plus the bounds()/loss_prop() pair of intern/distillation.py.
+    Inputs: sorted interval edges (t in [2, 6], s in [0, 1]) and positive weights that sum to < 1 per ray."""
+    from intern import distillation as ref_dis
+    from intern import loss as ref_loss
+    g = np.random.Generator(np.random.PCG64(1212))
+    out = {}
+    for tag, B, n in (("a", 5, 16), ("b", 9, 128), ("c", 1, 1), ("d", 3, 70)):
+        t = np.sort(g.uniform(2.0, 6.0, size=(B, n + 1)), -1).astype(np.float32)
+        t_hat = np.sort(g.uniform(2.0, 6.0, size=(B, n + 1)), -1).astype(np.float32)
+        s = np.sort(g.uniform(0.0, 1.0, size=(B, n + 1)), -1).astype(np.float32)
+        w = g.dirichlet(np.full(n + 1, 0.4), size=B)[:, :n].astype(np.float32)
+        w_hat = g.dirichlet(np.full(n + 1, 0.6), size=B)[:, :n].astype(np.float32)
+        rgb = g.uniform(0, 1, size=(B, 3)).astype(np.float32)
+        pix = g.uniform(0, 1, size=(B, 4)).astype(np.float32)  # the 4th column must be ignored ([..., :3])
+        if tag == "a":
+            t_hat[0] = t[0]            # identical partitions: the <,> comparisons see touching edges
+            w_hat[1, 3] = 0.0          # division by eps alone
+        out.update({f"{tag}.t": t, f"{tag}.t_hat": t_hat, f"{tag}.s": s, f"{tag}.w": w, f"{tag}.w_hat": w_hat,
+                    f"{tag}.rgb": rgb, f"{tag}.pix": pix})
+        wh = T(w_hat).requires_grad_(True)
+        lp = ref_loss.Loss_prop(t=T(t), w=T(w), t_hat=T(t_hat), w_hat=wh)
+        lp.backward()
+        out[f"{tag}.loss_prop"], out[f"{tag}.loss_prop.grad_w_hat"] = N(lp), N(wh.grad)
+        bnd = ref_dis.bounds(t_vals_fine=T(t), fine_weights=T(w), t_vals_coarse=T(t_hat))
+        out[f"{tag}.bounds"] = N(bnd)
+        out[f"{tag}.loss_prop_split"] = N(ref_dis.loss_prop(coarse_weights=T(w_hat), bounds=bnd))
+        sv, wv = T(s).requires_grad_(True), T(w).requires_grad_(True)
+        ld = ref_loss.Loss_dist(s_vals=sv, weights=wv)
+        ld.backward()
+        out[f"{tag}.loss_dist"], out[f"{tag}.loss_dist.grad_s"], out[f"{tag}.loss_dist.grad_w"] = N(ld), N(sv.grad), N(wv.grad)
+        rv = T(rgb).requires_grad_(True)
+        ln, psnr = ref_loss.Loss_nerf(input=rv, target=T(pix))
+        ln.backward()
+        out[f"{tag}.loss_nerf"], out[f"{tag}.psnr"], out[f"{tag}.loss_nerf.grad"] = N(ln), N(psnr), N(rv.grad)
+    out["mse_to_psnr.in"] = np.array([1e-4, 0.02, 0.5, 1.0], np.float32)
+    out["mse_to_psnr.out"] = N(ref_loss.mse_to_psnr(T(out["mse_to_psnr.in"])))
+    save("g12_losses", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
-    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12)
     for k in which:
         print(k)
         table[k]()

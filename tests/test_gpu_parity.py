@@ -581,3 +581,87 @@ def test_repack_after_weight_update(dev):
     o = O.forward(O.rays_from_numpy(r), O.to_torch_state_dict(sd2), O.Hyper(num_samples=16, white_bkgd=True))
     assert not torch.equal(a, b)
     close(b, o[0], atol=RGB_TOL, rtol=0)
+
+
+# ------------------------------------------------------------------ row f3: losses with analytic gradients
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_g12_losses_and_gradients(golden, dev, tag):
+    """HIP loss kernels behind the mirrors of intern/loss.py / distillation.py / regularization.py, forward values
+    and the gradients autograd receives, against the reference's own values + autograd gradients (G12).
+    Tolerance: fp32 sums of up to B*N^2 terms in a different association -> rtol 2e-5."""
+    from mipnerf360_amd.intern import distillation, loss
+    g = golden("g12_losses")
+    t, w, t_hat, s = (D(g[f"{tag}.{k}"], dev) for k in ("t", "w", "t_hat", "s"))
+    w_hat = D(g[f"{tag}.w_hat"], dev).requires_grad_(True)
+    lp = loss.Loss_prop(t=t, w=w, t_hat=t_hat, w_hat=w_hat)
+    lp.backward()
+    close(lp, g[f"{tag}.loss_prop"], rtol=2e-5)
+    gw = g[f"{tag}.loss_prop.grad_w_hat"]
+    close(w_hat.grad, gw, rtol=2e-5, atol=1e-6 * np.abs(gw).max())
+    bnd = distillation.bounds(t_vals_fine=t, fine_weights=w, t_vals_coarse=t_hat)
+    close(bnd, g[f"{tag}.bounds"], rtol=2e-5)
+    assert not bnd.requires_grad and bool((bnd == bnd[:1]).all())      # batch-total quirk of distillation.py:29
+    w_hat2 = D(g[f"{tag}.w_hat"], dev).requires_grad_(True)
+    lp2 = distillation.loss_prop(coarse_weights=w_hat2, bounds=bnd)
+    (3.0 * lp2).backward()                                             # upstream gradient is honoured
+    close(lp2, g[f"{tag}.loss_prop_split"], rtol=2e-5)
+    close(w_hat2.grad, 3.0 * gw, rtol=2e-5, atol=3e-6 * np.abs(gw).max())
+
+    sv, wv = s.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ld = loss.Loss_dist(s_vals=sv, weights=wv)
+    ld.backward()
+    close(ld, g[f"{tag}.loss_dist"], rtol=2e-5)
+    close(sv.grad, g[f"{tag}.loss_dist.grad_s"], rtol=2e-5, atol=2e-7)
+    close(wv.grad, g[f"{tag}.loss_dist.grad_w"], rtol=2e-5, atol=2e-7)
+
+    rgb = D(g[f"{tag}.rgb"], dev).requires_grad_(True)
+    ln, psnr = loss.Loss_nerf(input=rgb, target=D(g[f"{tag}.pix"], dev))   # 4-column target: [..., :3] is used
+    ln.backward()
+    close(ln, g[f"{tag}.loss_nerf"], rtol=2e-5)
+    close(psnr, g[f"{tag}.psnr"], rtol=2e-5)
+    close(rgb.grad, g[f"{tag}.loss_nerf.grad"], rtol=2e-5, atol=1e-7)
+    if tag == "a":
+        close(loss.mse_to_psnr(D(g["mse_to_psnr.in"], dev)), g["mse_to_psnr.out"], rtol=1e-6)
+
+
+def test_losses_training_shape_vs_oracle(dev):
+    """BASELINE training shape (4096 rays x 128 intervals): the three losses and their gradients vs the oracle,
+    combined the way train.py:75-80 does (loss_nerf + 0.01 * loss_dist, one backward through both)."""
+    from mipnerf360_amd.intern import loss
+    from oracle import ref_path as O
+    gen = np.random.Generator(np.random.PCG64(77))
+    B, n = 4096, 128
+    t = np.sort(gen.uniform(2, 6, (B, n + 1)), -1).astype(np.float32)
+    t_hat = np.sort(gen.uniform(2, 6, (B, n + 1)), -1).astype(np.float32)
+    s = np.sort(gen.uniform(0, 1, (B, n + 1)), -1).astype(np.float32)
+    w = gen.dirichlet(np.full(n + 1, 0.4), B)[:, :n].astype(np.float32)
+    w_hat = gen.dirichlet(np.full(n + 1, 0.6), B)[:, :n].astype(np.float32)
+    rgb, pix = gen.uniform(0, 1, (B, 3)).astype(np.float32), gen.uniform(0, 1, (B, 3)).astype(np.float32)
+    C = torch.from_numpy
+
+    wh = D(w_hat, dev).requires_grad_(True)
+    lp = loss.Loss_prop(D(t, dev), D(w, dev), D(t_hat, dev), wh)
+    lp.backward()
+    bnd = O.prop_bounds(C(t), C(w), C(t_hat))
+    close(lp, O.loss_prop_given(C(w_hat), bnd), rtol=5e-5)
+    og = O.loss_prop_grad(C(w_hat), bnd).numpy()
+    close(wh.grad, og, rtol=5e-5, atol=1e-6 * np.abs(og).max())
+
+    sv, wv, rv = D(s, dev).requires_grad_(True), D(w, dev).requires_grad_(True), D(rgb, dev).requires_grad_(True)
+    ln, _ = loss.Loss_nerf(rv, D(pix, dev))
+    ld = loss.Loss_dist(sv, wv)
+    (ln + 0.01 * ld).backward()
+    close(ld, O.loss_dist(C(s).double(), C(w).double()).float(), rtol=5e-5)
+    ogs, ogw = O.loss_dist_grads(C(s).double(), C(w).double())
+    close(sv.grad, 0.01 * ogs.float(), rtol=5e-5, atol=1e-8)
+    close(wv.grad, 0.01 * ogw.float(), rtol=5e-5, atol=1e-8)
+    close(ln, O.loss_nerf(C(rgb), C(pix))[0], rtol=2e-5)
+    close(rv.grad, O.loss_nerf_grad(C(rgb), C(pix)), rtol=2e-5, atol=1e-9)
+
+
+def test_loss_errors_are_loud(dev):
+    from mipnerf360_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.loss_dist(torch.zeros(2, 5), torch.zeros(2, 4))            # CPU tensors
+    with pytest.raises(RuntimeError):
+        ops.loss_dist(torch.zeros(2, 40001, device=dev), torch.zeros(2, 40000, device=dev))  # exceeds LDS

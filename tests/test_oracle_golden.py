@@ -196,3 +196,30 @@ def test_g9_chunk_dependence_is_real(golden):
     """The reference's global-norm contraction makes results depend on the chunk partition."""
     g = golden("g9_render_image")
     assert np.abs(g["c128_acc"] - g["c4096_acc"]).max() > 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_g12_losses(golden, tag):
+    """Row f3: Loss_prop / Loss_dist / Loss_nerf values and autograd gradients of the reference (G12).
+    Tolerance: fp32 sums of up to B*N^2 terms in a different association -> rtol 2e-5."""
+    g = golden("g12_losses")
+    t, w, t_hat, w_hat, s = (torch.from_numpy(g[f"{tag}.{k}"]) for k in ("t", "w", "t_hat", "w_hat", "s"))
+    rgb, pix = torch.from_numpy(g[f"{tag}.rgb"]), torch.from_numpy(g[f"{tag}.pix"])
+    tol = dict(rtol=2e-5, atol=1e-6)
+    bnd = O.prop_bounds(t, w, t_hat)
+    np.testing.assert_allclose(bnd.numpy(), g[f"{tag}.bounds"], **tol)
+    assert (bnd == bnd[:1]).all()  # the reference's batch-total quirk
+    np.testing.assert_allclose(O.loss_prop(t, w, t_hat, w_hat).numpy(), g[f"{tag}.loss_prop"], **tol)
+    np.testing.assert_allclose(O.loss_prop_given(w_hat, bnd).numpy(), g[f"{tag}.loss_prop_split"], **tol)
+    gw = g[f"{tag}.loss_prop.grad_w_hat"]
+    np.testing.assert_allclose(O.loss_prop_grad(w_hat, bnd).numpy(), gw, rtol=2e-5, atol=1e-6 * np.abs(gw).max())
+    np.testing.assert_allclose(O.loss_dist(s, w).numpy(), g[f"{tag}.loss_dist"], **tol)
+    gs, gwd = O.loss_dist_grads(s, w)
+    np.testing.assert_allclose(gs.numpy(), g[f"{tag}.loss_dist.grad_s"], rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(gwd.numpy(), g[f"{tag}.loss_dist.grad_w"], rtol=2e-5, atol=2e-7)
+    ln, psnr = O.loss_nerf(rgb, pix)
+    np.testing.assert_allclose(ln.numpy(), g[f"{tag}.loss_nerf"], **tol)
+    np.testing.assert_allclose(psnr.numpy(), g[f"{tag}.psnr"], **tol)
+    np.testing.assert_allclose(O.loss_nerf_grad(rgb, pix).numpy(), g[f"{tag}.loss_nerf.grad"], rtol=2e-5, atol=1e-7)
+    if tag == "a":
+        np.testing.assert_allclose(O.mse_to_psnr(torch.from_numpy(g["mse_to_psnr.in"])).numpy(), g["mse_to_psnr.out"], rtol=1e-6)
