@@ -39,7 +39,7 @@ enum {
     M360_ERR_NO_DEVICE = -4
 };
 
-enum { M360_ACT_NONE = 0, M360_ACT_RELU = 1, M360_ACT_SIGMOID = 2 };
+enum { M360_ACT_NONE = 0, M360_ACT_RELU = 1, M360_ACT_SIGMOID = 2, M360_ACT_RELU_MASK = 3 /* internal: m360_linear_dgrad */ };
 
 int m360_version(void);
 const char *m360_last_error(void);
@@ -129,6 +129,26 @@ int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_
  * One nn.Linear + activation of model.py:43-53 / :131-148. */
 int m360_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
                 int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t stream);
+
+/* ---- training path (row f3): the two gradient GEMMs autograd runs for every nn.Linear of model.py:43-53 /
+ * :131-158 under train.py:62,80.  All fp32 MFMA, deterministic (no atomics). */
+
+/* wt_packed[k_pad,n_pad] (n contiguous) = zero-padded transpose of a PyTorch [n_out,k_in] weight. */
+int m360_pack_linear_transposed(const float *w, int n_out, int k_in, int n_pad, int k_pad, float *wt_packed,
+                                m360_stream_t stream);
+
+/* input gradient: dx[M,k_pad] = dz[M,n_pad] * W[n_pad,k_pad], optionally masked by ReLU' of the previous layer:
+ * relu_out[M,ldx] is that layer's forward OUTPUT (dx is zeroed where it is <= 0), NULL = no mask. */
+int m360_linear_dgrad(const float *dz, long M, int ldz, const float *wt_packed, int k_pad, int n_pad,
+                      const float *relu_out, float *dx, int ldx, m360_stream_t stream);
+
+/* weight and bias gradient: grad_w[n_pad,k_pad] = dz[M,n_pad]^T * x[M,k_pad] (the packed layout of
+ * m360_pack_linear), grad_b[n_pad] = column sums of dz (NULL to skip).  The M rows are split over the workgroups
+ * and the partial tiles are added in a fixed order. */
+size_t m360_linear_wgrad_workspace_bytes(long M, int n_pad, int k_pad);
+int m360_linear_wgrad(const float *dz, int ldz, const float *x, int ldx, long M, int n_pad, int k_pad,
+                      float *grad_w, float *grad_b, void *workspace, size_t workspace_bytes,
+                      m360_stream_t stream);
 
 /* ---- opt-in bf16 MLP (BASELINE configs[4]): bf16 inputs, fp32 accumulate on v_mfma_f32_32x32x16_bf16.
  * bf16 tensors are passed as raw 16-bit storage (void*).  k_pad multiple of 64, ldx/ldy multiples of 8. */
@@ -346,6 +366,67 @@ int m360_nerf_forward(const m360_rays_t *rays_host, const m360_model_t *model_ho
 int m360_forward(const m360_rays_t *rays_host, const m360_model_t *model_host,
                  const m360_hyper_t *hyper_host, int B, const m360_outputs_t *out_host,
                  void *workspace, size_t workspace_bytes, m360_stream_t stream);
+
+/* ------------------------------------------------------------------ training path (row f3) ---
+ * Backward of the two stages with respect to the network parameters - what `loss.backward()` computes in
+ * train.py:62,80.  As in the reference, the sample positions carry no gradient (resampling runs under
+ * torch.no_grad(), intern/ray.py:136; train.py:70-71 detaches t_hat / w_hat), so the gradient stops at the MLP
+ * inputs.  fp32 only.  Gradients use the packed layouts of the model struct, zero in the padding. */
+
+typedef struct m360_mlp_transposed {
+    const float *w_t[8]; /* layer l >= 1: m360_pack_linear_transposed of that layer's weight; [0] unused */
+} m360_mlp_transposed_t;
+
+typedef struct m360_mlp_grads {
+    float *w[8];    /* [n_pad,k_pad] per layer (4 proposal / 8 NeRF layers) */
+    float *b[8];    /* [n_pad] */
+    float *head_w;  /* proposal [hp_pad]; NeRF [4,hn_pad]: density, r, g, b */
+    float *head_b;  /* [1] / [4] */
+} m360_mlp_grads_t;
+
+/* per-ray backward of the finishers: from the gradients of the stage outputs to dz[B*N,ld] = gradient at the
+ * pre-activation of the last hidden (sigmoid) layer, plus the head gradients.  act = that layer's output.
+ * Replaces autograd through model.py:52,92-93,59-77 (proposal) and model.py:150-158,180-186 +
+ * intern/ray.py:171-191 (NeRF; grad_distance / grad_acc / grad_weights / grad_rgb may each be NULL = zero). */
+size_t m360_finish_backward_workspace_bytes(int B, int heads, int k_pad);
+int m360_prop_finish_backward(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
+                              float density_bias, const float *t_vals, const float *dirs, int B, int N,
+                              const float *grad_weights, float *dz, float *grad_head_w, float *grad_head_b,
+                              void *workspace, size_t workspace_bytes, m360_stream_t stream);
+int m360_nerf_finish_backward(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
+                              float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
+                              int N, int white_bkgd, const float *grad_rgb, const float *grad_distance,
+                              const float *grad_acc, const float *grad_weights, float *dz, float *grad_head_w,
+                              float *grad_head_b, void *workspace, size_t workspace_bytes, m360_stream_t stream);
+
+/* stage = 0 proposal (N = num_samples), 1 NeRF (N = number of fine intervals).  The tape keeps the sample
+ * positions, the encoded features and every layer output of ONE forward for its backward. */
+size_t m360_train_tape_bytes(int B, int N, const m360_model_t *model_host, int stage);
+size_t m360_backward_workspace_bytes(int B, int N, const m360_model_t *model_host, int stage);
+
+/* m360_prop_forward / m360_nerf_forward that also fill the tape (workspace as for the plain forward). */
+int m360_prop_forward_train(const m360_rays_t *rays_host, const m360_model_t *model_host,
+                            const m360_hyper_t *hyper_host, int B, const float *t_rand, float *t_hat,
+                            float *w_hat, void *tape, size_t tape_bytes, void *workspace,
+                            size_t workspace_bytes, m360_stream_t stream);
+int m360_nerf_forward_train(const m360_rays_t *rays_host, const m360_model_t *model_host,
+                            const m360_hyper_t *hyper_host, int B, const float *t_hat, const float *w_hat,
+                            const float *u_rand, const m360_outputs_t *out_host, void *tape, size_t tape_bytes,
+                            void *workspace, size_t workspace_bytes, m360_stream_t stream);
+
+/* d loss / d parameters of prop_net given grad_w_hat[B,N] = d loss / d w_hat (train.py:60-62). */
+int m360_prop_backward(const m360_rays_t *rays_host, const m360_model_t *model_host,
+                       const m360_mlp_transposed_t *wt_host, const m360_hyper_t *hyper_host, int B,
+                       const void *tape, size_t tape_bytes, const float *grad_w_hat,
+                       const m360_mlp_grads_t *grads_host, void *workspace, size_t workspace_bytes,
+                       m360_stream_t stream);
+/* d loss / d parameters of nerf_net given the gradients of comp_rgb[B,3], distance[B], acc[B] and
+ * fine weights[B,N] (train.py:75-80 uses comp_rgb and the weights). */
+int m360_nerf_backward(const m360_rays_t *rays_host, const m360_model_t *model_host,
+                       const m360_mlp_transposed_t *wt_host, const m360_hyper_t *hyper_host, int B,
+                       const void *tape, size_t tape_bytes, const float *grad_rgb, const float *grad_distance,
+                       const float *grad_acc, const float *grad_weights, const m360_mlp_grads_t *grads_host,
+                       void *workspace, size_t workspace_bytes, m360_stream_t stream);
 
 /* ------------------------------------------------------------------ measurement ------ */
 

@@ -42,6 +42,14 @@ class OutputsStruct(C.Structure):  # m360_outputs_t
     _fields_ = [(n, _vp) for n in ("rgb", "distance", "acc", "t_hat", "w_hat", "t_vals", "fine_w", "s_vals")]
 
 
+class MlpTransposedStruct(C.Structure):  # m360_mlp_transposed_t
+    _fields_ = [("w_t", _vp * 8)]
+
+
+class MlpGradsStruct(C.Structure):  # m360_mlp_grads_t
+    _fields_ = [("w", _vp * 8), ("b", _vp * 8), ("head_w", _vp), ("head_b", _vp)]
+
+
 _i, _l, _fl, _sz = C.c_int, C.c_long, C.c_float, C.c_size_t
 _P = C.POINTER
 
@@ -65,6 +73,10 @@ SIGNATURES = {
     "m360_encode_features": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "m360_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "m360_pack_linear_transposed": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "m360_linear_dgrad": (_i, [_vp, _l, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "m360_linear_wgrad_workspace_bytes": (_sz, [_l, _i, _i]),
+    "m360_linear_wgrad": (_i, [_vp, _i, _vp, _i, _l, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "m360_pack_linear_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear_bf16": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_encode_features_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
@@ -101,6 +113,20 @@ SIGNATURES = {
     "m360_prof_reset": (_i, []),
     "m360_prof_read": (_i, [_i, _P(C.c_float), _P(C.c_long), _P(_i), _P(_i)]),
     "m360_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _P(OutputsStruct), _vp, _sz, _vp]),
+    "m360_finish_backward_workspace_bytes": (_sz, [_i, _i, _i]),
+    "m360_prop_finish_backward": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m360_nerf_finish_backward": (_i, [_vp, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp, _sz, _vp]),
+    "m360_train_tape_bytes": (_sz, [_i, _i, _P(ModelStruct), _i]),
+    "m360_backward_workspace_bytes": (_sz, [_i, _i, _P(ModelStruct), _i]),
+    "m360_prop_forward_train": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp, _vp, _sz, _vp, _sz,
+                                     _vp]),
+    "m360_nerf_forward_train": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp, _P(OutputsStruct),
+                                     _vp, _sz, _vp, _sz, _vp]),
+    "m360_prop_backward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(MlpTransposedStruct), _P(HyperStruct), _i, _vp, _sz, _vp,
+                                _P(MlpGradsStruct), _vp, _sz, _vp]),
+    "m360_nerf_backward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(MlpTransposedStruct), _P(HyperStruct), _i, _vp, _sz, _vp,
+                                _vp, _vp, _vp, _P(MlpGradsStruct), _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -106,10 +106,29 @@ static int validate(const m360_rays_t *r, const m360_model_t *m, const m360_hype
         if (rc_ != M360_OK) return rc_; \
     } while (0)
 
+// Training tape of one stage (caller-owned): everything the backward needs from the forward.
+struct TapeLayout {
+    size_t t, feat, act[8], total;
+    int layers;
+};
+static TapeLayout tape_for(int B, int N, const m360_model_t *m, int stage) {
+    TapeLayout T;
+    const size_t S = (size_t)B * N;
+    const int width = stage == 0 ? m->hp_pad : m->hn_pad;
+    T.layers = stage == 0 ? 4 : 8;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    T.t = take((size_t)B * (N + 1) * sizeof(float));
+    T.feat = take(S * m->in_pad * sizeof(float));
+    for (int l = 0; l < 8; ++l) T.act[l] = l < T.layers ? take(S * width * sizeof(float)) : 0;
+    T.total = off;
+    return T;
+}
+
 // sample (or take) t -> features -> 4 proposal layers -> head + weights (+ fused resample)
 static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hyper_t *h, int B,
                       const float *t_rand, float *t_hat, float *w_hat, float *t_new, char *ws,
-                      m360_stream_t st) {
+                      m360_stream_t st, char *tape = nullptr) {
     const int N = h->num_samples;
     const FwdLayout L = layout_for(B, n_max(h), m);
     const int vd_ch = m->in_ch - kIpeCh;
@@ -117,6 +136,22 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     float *feat = reinterpret_cast<float *>(ws + L.feat);
     float *a = reinterpret_cast<float *>(ws + L.act_a), *b = reinterpret_cast<float *>(ws + L.act_b);
     const long S = (long)B * N;
+    if (tape) {  // training: fp32 only, every layer output kept
+        const TapeLayout T = tape_for(B, N, m, 0);
+        const int hp = m->hp_pad;
+        float *tt = reinterpret_cast<float *>(tape + T.t), *tf = reinterpret_cast<float *>(tape + T.feat);
+        float *act[4];
+        for (int l = 0; l < 4; ++l) act[l] = reinterpret_cast<float *>(tape + T.act[l]);
+        M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, tt, st));
+        if (hipMemcpyAsync(t_hat, tt, (size_t)B * (N + 1) * sizeof(float), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(st)) != hipSuccess)
+            return fail(M360_ERR_LAUNCH, "m360_prop_forward_train: copy of t_hat failed");
+        M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
+        M360_TRY(m360_encode_features(tt, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(m360_linear(tf, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, act[0], hp, st));
+        for (int l = 1; l < 4; ++l)
+            M360_TRY(m360_linear(act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, l == 3 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hp, st));
+        return m360_prop_finish_n(act[3], hp, m->prop_head_w, m->prop_head_b, hp, h->density_bias, tt, r->directions, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st);
+    }
     M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, t_hat, st));
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hp = m->hp_pad;
@@ -138,7 +173,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
 
 // resampled t -> features -> 8 NeRF layers -> heads + composite
 static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hyper_t *h, int B,
-                      const float *t1, const m360_outputs_t *out, char *ws, m360_stream_t st) {
+                      const float *t1, const m360_outputs_t *out, char *ws, m360_stream_t st, char *tape = nullptr) {
     const int N = n_fine(h);  // the NeRF stage runs on the resampled intervals
     const FwdLayout L = layout_for(B, n_max(h), m);
     const int vd_ch = m->in_ch - kIpeCh;
@@ -149,7 +184,17 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hn = m->hn_pad;
     float *src = a, *dst = b;
-    if (m->mlp_bf16) {
+    if (tape) {  // training: fp32 only, every layer output kept (t1 already lives in the tape)
+        const TapeLayout T = tape_for(B, N, m, 1);
+        float *tf = reinterpret_cast<float *>(tape + T.feat);
+        float *act[8];
+        for (int l = 0; l < 8; ++l) act[l] = reinterpret_cast<float *>(tape + T.act[l]);
+        M360_TRY(m360_encode_features(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(m360_linear(tf, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, act[0], hn, st));
+        for (int l = 1; l < 8; ++l)
+            M360_TRY(m360_linear(act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, l == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hn, st));
+        M360_TRY(m360_nerf_finish(act[7], hn, m->nerf_head_w, m->nerf_head_b, hn, h->density_bias, h->rgb_padding, t1, r->directions, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
+    } else if (m->mlp_bf16) {
         M360_TRY(m360_encode_features_bf16(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(m360_linear_bf16(feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
         for (int layer = 1; layer < 8; ++layer) {
@@ -275,6 +320,128 @@ int m360_forward(const m360_rays_t *rays, const m360_model_t *model, const m360_
     float *t1 = reinterpret_cast<float *>(ws + L.t1);
     M360_TRY(prop_stage(rays, model, hyper, B, nullptr, t0, what, t1, ws, stream));
     return nerf_stage(rays, model, hyper, B, t1, out, ws, stream);
+}
+
+/* ------------------------------------------------------------------ training path (row f3) */
+
+size_t m360_train_tape_bytes(int B, int N, const m360_model_t *model_host, int stage) {
+    if (!model_host || B < 0 || N < 1 || (stage != 0 && stage != 1)) return 0;
+    return tape_for(B, N, model_host, stage).total;
+}
+
+struct BwdLayout {
+    size_t dz_a, dz_b, gemm, finish, total;
+};
+static BwdLayout bwd_layout_for(int B, int N, const m360_model_t *m, int stage) {
+    BwdLayout L;
+    const size_t S = (size_t)B * N;
+    const int width = stage == 0 ? m->hp_pad : m->hn_pad;
+    const int kmax = width > m->in_pad ? width : m->in_pad;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    L.dz_a = take(S * width * sizeof(float));
+    L.dz_b = take(S * width * sizeof(float));
+    L.gemm = take(m360_linear_wgrad_workspace_bytes((long)S, width, kmax));
+    L.finish = take(m360_finish_backward_workspace_bytes(B, stage == 0 ? 1 : 4, width));
+    L.total = off;
+    return L;
+}
+
+size_t m360_backward_workspace_bytes(int B, int N, const m360_model_t *model_host, int stage) {
+    if (!model_host || B < 0 || N < 1 || (stage != 0 && stage != 1)) return 0;
+    return bwd_layout_for(B, N, model_host, stage).total;
+}
+
+static int validate_train(const m360_model_t *m, const void *tape, size_t tape_bytes, size_t need, const char *who) {
+    if (m->mlp_bf16) return fail(M360_ERR_INVALID_ARGUMENT, "%s: the training path is fp32 only (mlp_bf16 must be 0)", who);
+    if (!tape || tape_bytes < need || ((uintptr_t)tape & 255)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "%s: tape %zu < required %zu bytes (or not 256-byte aligned)", who, tape_bytes, need);
+    return M360_OK;
+}
+
+int m360_prop_forward_train(const m360_rays_t *rays, const m360_model_t *model, const m360_hyper_t *hyper, int B,
+                            const float *t_rand, float *t_hat, float *w_hat, void *tape, size_t tape_bytes,
+                            void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    M360_TRY(validate(rays, model, hyper, B, workspace, workspace_bytes, "m360_prop_forward_train"));
+    if (B == 0) return M360_OK;
+    if (!t_hat || !w_hat) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_forward_train: t_hat and w_hat are required");
+    M360_TRY(validate_train(model, tape, tape_bytes, tape_for(B, hyper->num_samples, model, 0).total, "m360_prop_forward_train"));
+    return prop_stage(rays, model, hyper, B, t_rand, t_hat, w_hat, nullptr, static_cast<char *>(workspace), stream, static_cast<char *>(tape));
+}
+
+int m360_nerf_forward_train(const m360_rays_t *rays, const m360_model_t *model, const m360_hyper_t *hyper, int B,
+                            const float *t_hat, const float *w_hat, const float *u_rand, const m360_outputs_t *out,
+                            void *tape, size_t tape_bytes, void *workspace, size_t workspace_bytes,
+                            m360_stream_t stream) {
+    M360_TRY(validate(rays, model, hyper, B, workspace, workspace_bytes, "m360_nerf_forward_train"));
+    if (B == 0) return M360_OK;
+    if (!t_hat || !w_hat || !out || !out->rgb || !out->distance || !out->acc)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_forward_train: t_hat, w_hat, out.rgb/distance/acc are required");
+    const TapeLayout T = tape_for(B, n_fine(hyper), model, 1);
+    M360_TRY(validate_train(model, tape, tape_bytes, T.total, "m360_nerf_forward_train"));
+    float *t1 = reinterpret_cast<float *>(static_cast<char *>(tape) + T.t);
+    M360_TRY(m360_resample_t_n(t_hat, w_hat, u_rand, B, hyper->num_samples, n_fine(hyper) + 1, hyper->resample_padding, t1, stream));
+    return nerf_stage(rays, model, hyper, B, t1, out, static_cast<char *>(workspace), stream, static_cast<char *>(tape));
+}
+
+// dz (gradient at the pre-activation of the last hidden layer, already in `dz`) -> all weight / bias gradients
+static int mlp_backward(int layers, const float *const *w_t, float *const *grad_w, float *const *grad_b, const float *feat,
+                        int in_pad, float *const *act, int width, long S, float *dz, float *dz_other, void *gemm_ws,
+                        size_t gemm_ws_bytes, m360_stream_t st, const char *who) {
+    for (int l = layers - 1; l >= 0; --l) {
+        const float *x = l == 0 ? feat : act[l - 1];
+        const int k = l == 0 ? in_pad : width;
+        if (!grad_w[l] || !grad_b[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: gradient buffer of layer %d is null", who, l);
+        M360_TRY(m360_linear_wgrad(dz, width, x, k, S, width, k, grad_w[l], grad_b[l], gemm_ws, gemm_ws_bytes, st));
+        if (l > 0) {
+            if (!w_t[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: transposed weight of layer %d is null", who, l);
+            M360_TRY(m360_linear_dgrad(dz, S, width, w_t[l], width, width, act[l - 1], dz_other, width, st));
+            float *tmp = dz; dz = dz_other; dz_other = tmp;
+        }
+    }
+    return M360_OK;
+}
+
+int m360_prop_backward(const m360_rays_t *rays, const m360_model_t *model, const m360_mlp_transposed_t *wt,
+                       const m360_hyper_t *hyper, int B, const void *tape, size_t tape_bytes,
+                       const float *grad_w_hat, const m360_mlp_grads_t *grads, void *workspace,
+                       size_t workspace_bytes, m360_stream_t stream) {
+    if (!rays || !model || !wt || !hyper || !grads || B < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_backward: null descriptor");
+    if (B == 0) return M360_OK;
+    const int N = hyper->num_samples;
+    const TapeLayout T = tape_for(B, N, model, 0);
+    M360_TRY(validate_train(model, tape, tape_bytes, T.total, "m360_prop_backward"));
+    const BwdLayout L = bwd_layout_for(B, N, model, 0);
+    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_prop_backward: workspace %zu < required %zu bytes", workspace_bytes, L.total);
+    if (!grad_w_hat || !rays->directions || !grads->head_w || !grads->head_b) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_backward: grad_w_hat, rays.directions and the head gradient buffers are required");
+    char *tp = const_cast<char *>(static_cast<const char *>(tape)), *ws = static_cast<char *>(workspace);
+    const int hp = model->hp_pad;
+    float *act[4];
+    for (int l = 0; l < 4; ++l) act[l] = reinterpret_cast<float *>(tp + T.act[l]);
+    float *dz = reinterpret_cast<float *>(ws + L.dz_a), *dz2 = reinterpret_cast<float *>(ws + L.dz_b);
+    M360_TRY(m360_prop_finish_backward(act[3], hp, model->prop_head_w, model->prop_head_b, hp, hyper->density_bias, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, grad_w_hat, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, stream));
+    return mlp_backward(4, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hp, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_prop_backward");
+}
+
+int m360_nerf_backward(const m360_rays_t *rays, const m360_model_t *model, const m360_mlp_transposed_t *wt,
+                       const m360_hyper_t *hyper, int B, const void *tape, size_t tape_bytes, const float *grad_rgb,
+                       const float *grad_distance, const float *grad_acc, const float *grad_weights,
+                       const m360_mlp_grads_t *grads, void *workspace, size_t workspace_bytes,
+                       m360_stream_t stream) {
+    if (!rays || !model || !wt || !hyper || !grads || B < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_backward: null descriptor");
+    if (B == 0) return M360_OK;
+    const int N = n_fine(hyper);
+    const TapeLayout T = tape_for(B, N, model, 1);
+    M360_TRY(validate_train(model, tape, tape_bytes, T.total, "m360_nerf_backward"));
+    const BwdLayout L = bwd_layout_for(B, N, model, 1);
+    if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_nerf_backward: workspace %zu < required %zu bytes", workspace_bytes, L.total);
+    if (!rays->directions || !grads->head_w || !grads->head_b) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_backward: rays.directions and the head gradient buffers are required");
+    char *tp = const_cast<char *>(static_cast<const char *>(tape)), *ws = static_cast<char *>(workspace);
+    const int hn = model->hn_pad;
+    float *act[8];
+    for (int l = 0; l < 8; ++l) act[l] = reinterpret_cast<float *>(tp + T.act[l]);
+    float *dz = reinterpret_cast<float *>(ws + L.dz_a), *dz2 = reinterpret_cast<float *>(ws + L.dz_b);
+    M360_TRY(m360_nerf_finish_backward(act[7], hn, model->nerf_head_w, model->nerf_head_b, hn, hyper->density_bias, hyper->rgb_padding, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, hyper->white_bkgd, grad_rgb, grad_distance, grad_acc, grad_weights, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, stream));
+    return mlp_backward(8, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hn, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_nerf_backward");
 }
 
 }  // extern "C"

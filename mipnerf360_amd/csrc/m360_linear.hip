@@ -16,6 +16,7 @@
 #include "m360_common.cuh"
 #include "m360_linear_persist.cuh"
 #include "m360_linear_bf16.cuh"
+#include "m360_linear_tn.cuh"
 
 namespace m360 {
 
@@ -36,7 +37,8 @@ __device__ __forceinline__ float activate(float v) {
 template <int ACT>
 __global__ __launch_bounds__(kThreads, 2) void linear_f32_mfma_kernel(
     const float *__restrict__ X, long M, int ldx, const float *__restrict__ W,
-    const float *__restrict__ bias, int Np, int Kp, float *__restrict__ Y, int ldy, int tiles_n) {
+    const float *__restrict__ bias, int Np, int Kp, float *__restrict__ Y, int ldy, int tiles_n,
+    const float *__restrict__ aux = nullptr) {
     __shared__ float As[2][BM * LDS_LD];
     __shared__ float Bs[2][BN * LDS_LD];
 
@@ -165,6 +167,24 @@ __global__ __launch_bounds__(kThreads, 2) void linear_f32_mfma_kernel(
     // ---- epilogue: bias + activation; lane holds column (n) l31, rows (r&3)+8(r>>2)+4h
     const bool interior = rows_left >= BM && cols_left >= BN;  // wave-uniform
     float *__restrict__ Yt = Y + m0 * ldy + n0;
+    if (ACT == M360_ACT_RELU_MASK) {  // backward of ReLU: no bias, keep where the forward output (aux, same ld) was > 0
+        const float *__restrict__ At = aux + m0 * ldy + n0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rbase = wm * 128 + i * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (col < cols_left && row < rows_left)
+                        Yt[(long)row * ldy + col] = At[(long)row * ldy + col] > 0.0f ? acc[i][j][r] : 0.0f;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = wn * 64 + j * 32 + l31;
@@ -188,6 +208,9 @@ __global__ __launch_bounds__(kThreads, 2) void linear_f32_mfma_kernel(
     }
 }
 
+constexpr int kZeroBias = 8192;
+__device__ float g_zero_bias[kZeroBias];  // zero-initialised
+
 __global__ void pack_linear_kernel(const float *__restrict__ w, const float *__restrict__ b, int n_out,
                                    int k_in, int n_pad, int k_pad, float *__restrict__ wp,
                                    float *__restrict__ bp) {
@@ -197,6 +220,16 @@ __global__ void pack_linear_kernel(const float *__restrict__ w, const float *__r
         wp[idx] = (n < n_out && k < k_in) ? w[(long)n * k_in + k] : 0.0f;
     }
     if (bp != nullptr && idx < n_pad) bp[idx] = (b != nullptr && idx < n_out) ? b[idx] : 0.0f;
+}
+
+int launch_colsum(const float *in, long R, int C, int ld, float *scratch, int slices, float *out, hipStream_t st) {
+    if (slices < 1) slices = 1;
+    long per_slice = (R + slices - 1) / slices;
+    if (per_slice < 1) per_slice = 1;
+    const dim3 block(tn::kColWaves * kWave);
+    hipLaunchKernelGGL(tn::colsum_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)slices), block, 0, st, in, R, C, ld, per_slice, scratch);
+    hipLaunchKernelGGL(tn::colsum_kernel, dim3((unsigned)((C + 63) / 64), 1), block, 0, st, scratch, (long)slices, C, C, (long)slices, out);
+    return check_launch("colsum");
 }
 
 }  // namespace m360
@@ -243,9 +276,10 @@ int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_
     return check_launch("pack_linear");
 }
 
-int m360_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
-                int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t stream) {
-    if (!x || !w_packed || !b_packed || !y || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: null pointer or negative M");
+static int launch_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad,
+                         int k_pad, int act, float *y, int ldy, const float *aux, m360_stream_t stream) {
+    if (!x || !w_packed || (!b_packed && act != M360_ACT_RELU_MASK) || !y || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: null pointer or negative M");
+    if (act == M360_ACT_RELU_MASK && (!aux || ((uintptr_t)aux & 15))) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: the ReLU-mask epilogue needs a 16-byte aligned mask source");
     if (n_pad < 1 || k_pad < BK || k_pad % BK != 0 || ldx < k_pad || ldy < n_pad || ldx % 4 != 0 || ldy % 4 != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad, ldy=%d >= n_pad=%d, both multiples of 4", k_pad, BK, ldx, ldy, n_pad);
     if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: x, w_packed, b_packed and y must be 16-byte aligned");
@@ -255,7 +289,7 @@ int m360_linear(const float *x, long M, int ldx, const float *w_packed, const fl
     const long nwg = tiles_m * tiles_n;
     if (nwg > 0x7fffffffL) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: grid too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: unknown activation %d", act);
+    if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID && act != M360_ACT_RELU_MASK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: unknown activation %d", act);
     const int prof = prof_begin(st, M, n_pad, k_pad);
     // Persistent LDS-DMA kernel on the full 256-row tiles when the width is a multiple of 256; ragged rows
     // (and narrow layers) go to the workgroup-per-tile kernel.  Both produce bit-identical results.
@@ -272,6 +306,7 @@ int m360_linear(const float *x, long M, int ldx, const float *w_packed, const fl
             switch (act) {
                 case M360_ACT_NONE: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
                 case M360_ACT_RELU: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
+                case M360_ACT_RELU_MASK: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU_MASK>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles, aux); break;
                 default: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
             }
         }
@@ -285,11 +320,95 @@ int m360_linear(const float *x, long M, int ldx, const float *w_packed, const fl
         switch (act) {
             case M360_ACT_NONE: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_NONE>, grid, block, 0, st, xt, Mt, ldx, w_packed, b_packed, n_pad, k_pad, yt, ldy, tiles_n); break;
             case M360_ACT_RELU: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_RELU>, grid, block, 0, st, xt, Mt, ldx, w_packed, b_packed, n_pad, k_pad, yt, ldy, tiles_n); break;
+            case M360_ACT_RELU_MASK: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_RELU_MASK>, grid, block, 0, st, xt, Mt, ldx, w_packed, b_packed, n_pad, k_pad, yt, ldy, tiles_n, aux + M_full * ldy); break;
             default: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xt, Mt, ldx, w_packed, b_packed, n_pad, k_pad, yt, ldy, tiles_n); break;
         }
     }
     prof_end(prof, st);
     return check_launch("linear");
+}
+
+int m360_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
+                int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t stream) {
+    if (act == M360_ACT_RELU_MASK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: use m360_linear_dgrad for the masked epilogue");
+    return launch_linear(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, nullptr, stream);
+}
+
+// ---- training path: input gradient, weight gradient, transposed packing
+int m360_linear_dgrad(const float *dz, long M, int ldz, const float *wt_packed, int k_pad, int n_pad,
+                      const float *relu_out, float *dx, int ldx, m360_stream_t stream) {
+    // dX[M, k_pad] = dZ[M, n_pad] * W[n_pad, k_pad]: the forward kernel with the roles of n and k exchanged on the
+    // transposed packing wt[k_pad][n_pad]; relu_out (the forward OUTPUT of the previous layer, leading dimension ldx)
+    // masks the result (ReLU'), NULL = no mask.  Needs n_pad % 32 == 0 (it is the contraction length here).
+    float *zero_bias = nullptr;  // the unmasked epilogue adds a bias: a zero vector that lives in the code object
+    if (!relu_out) {
+        if (k_pad > kZeroBias) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_dgrad: k_pad=%d > %d without a mask", k_pad, kZeroBias);
+        if (hipGetSymbolAddress(reinterpret_cast<void **>(&zero_bias), HIP_SYMBOL(g_zero_bias)) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_linear_dgrad: zero bias symbol not found");
+    }
+    return launch_linear(dz, M, ldz, wt_packed, relu_out ? nullptr : zero_bias, k_pad, n_pad, relu_out ? M360_ACT_RELU_MASK : M360_ACT_NONE, dx, ldx, relu_out, stream);
+}
+
+static void wgrad_plan(long M, int n_pad, int k_pad, int *ntiles, int *nsplit, long *total_steps, long *steps_per_split) {
+    *ntiles = ((n_pad + tn::BT - 1) / tn::BT) * ((k_pad + tn::BT - 1) / tn::BT);
+    *total_steps = M / tn::BKM;
+    long ns = tn::kMaxWorkgroups / *ntiles;
+    if (ns < 1) ns = 1;
+    if (ns > *total_steps) ns = *total_steps;
+    *nsplit = (int)ns;
+    *steps_per_split = ns > 0 ? (*total_steps + ns - 1) / ns : 0;
+}
+static constexpr int kBiasSlices = 64;
+static inline size_t up256_(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t m360_linear_wgrad_workspace_bytes(long M, int n_pad, int k_pad) {
+    if (M < 0 || n_pad < 1 || k_pad < 1) return 0;
+    int ntiles, nsplit;
+    long total, per;
+    wgrad_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
+    return up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)) + up256_((size_t)kBiasSlices * n_pad * sizeof(float));
+}
+
+int m360_linear_wgrad(const float *dz, int ldz, const float *x, int ldx, long M, int n_pad, int k_pad, float *grad_w,
+                      float *grad_b, void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    if (!dz || !x || !grad_w || M < 0 || n_pad < 32 || k_pad < 32 || n_pad % 32 || k_pad % 32 || ldz < n_pad || ldx < k_pad || ldz % 4 || ldx % 4)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_wgrad: bad argument (M=%ld n_pad=%d k_pad=%d ldz=%d ldx=%d)", M, n_pad, k_pad, ldz, ldx);
+    if (((uintptr_t)dz | (uintptr_t)x | (uintptr_t)grad_w) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_wgrad: pointers must be 16-byte aligned");
+    const size_t need = m360_linear_wgrad_workspace_bytes(M, n_pad, k_pad);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_linear_wgrad: workspace %zu < %zu bytes (or not 256-byte aligned)", workspace_bytes, need);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int ntiles, nsplit;
+    long total, per;
+    wgrad_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
+    float *partial = static_cast<float *>(workspace);
+    float *bias_part = reinterpret_cast<float *>(static_cast<char *>(workspace) + up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)));
+    const int prof = prof_begin(st, M, n_pad, k_pad);
+    if (nsplit > 0)
+        hipLaunchKernelGGL(tn::linear_tn_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn::kThreads), 0, st, dz, ldz, x, ldx, n_pad, k_pad, partial, (k_pad + tn::BT - 1) / tn::BT, ntiles, nsplit, total, per);
+    prof_end(prof, st);
+    const long count4 = (long)n_pad * k_pad / 4;
+    hipLaunchKernelGGL(tn::tn_reduce_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, partial, nsplit, n_pad, k_pad, dz, ldz, x, ldx, total * tn::BKM, M, grad_w);
+    if (grad_b) {
+        const int rc = launch_colsum(dz, M, n_pad, ldz, bias_part, kBiasSlices, grad_b, st);
+        if (rc != M360_OK) return rc;
+    }
+    return check_launch("linear_wgrad");
+}
+
+__global__ void pack_linear_t_kernel(const float *__restrict__ w, int n_out, int k_in, int n_pad, int k_pad,
+                                     float *__restrict__ wt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n_pad * k_pad) return;
+    const int k = (int)(idx / n_pad), n = (int)(idx % n_pad);
+    wt[idx] = (n < n_out && k < k_in) ? w[(long)n * k_in + k] : 0.0f;
+}
+
+int m360_pack_linear_transposed(const float *w, int n_out, int k_in, int n_pad, int k_pad, float *wt_packed,
+                                m360_stream_t stream) {
+    if (!w || !wt_packed || n_out < 1 || k_in < 1 || n_pad < n_out || k_pad < k_in)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_pack_linear_transposed: bad argument (n_out=%d k_in=%d n_pad=%d k_pad=%d)", n_out, k_in, n_pad, k_pad);
+    const long n = (long)n_pad * k_pad;
+    hipLaunchKernelGGL(pack_linear_t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, n_out, k_in, n_pad, k_pad, wt_packed);
+    return check_launch("pack_linear_transposed");
 }
 
 // ---- opt-in bf16 MLP (fp32 accumulate): weights and activations as raw 16-bit bf16

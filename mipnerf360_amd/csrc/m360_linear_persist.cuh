@@ -51,7 +51,7 @@ template <int ACT, bool STAMP = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     const float *__restrict__ X, long M, int ldx, const float *__restrict__ W,
     const float *__restrict__ bias, int Np, int Kp, float *__restrict__ Y, int ldy, int tiles_n,
-    int ntiles) {
+    int ntiles, const float *__restrict__ aux = nullptr) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * kBufFloats];  // 128 KiB
 
     const int tid = threadIdx.x;
@@ -269,19 +269,29 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
             const int rrow = lane >> 3, rcol = 4 * (lane & 7);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const float4 b4 = *reinterpret_cast<const float4 *>(bias + n0 + wn * 128 + j * 32 + rcol);
+                float4 b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (ACT != M360_ACT_RELU_MASK) b4 = *reinterpret_cast<const float4 *>(bias + n0 + wn * 128 + j * 32 + rcol);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = acc[i][j][r];
-                    float *__restrict__ Yc = Yt + (long)(wm * 128 + i * 32 + rrow) * ldy_t + wn * 128 + j * 32 + rcol;
+                    const long yoff = (long)(wm * 128 + i * 32 + rrow) * ldy_t + wn * 128 + j * 32 + rcol;
+                    float *__restrict__ Yc = Yt + yoff;
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         float4 v = *reinterpret_cast<const float4 *>(stg + (p * 8 + rrow) * 36 + rcol);
-                        v.x = act_fn<ACT>(v.x + b4.x);
-                        v.y = act_fn<ACT>(v.y + b4.y);
-                        v.z = act_fn<ACT>(v.z + b4.z);
-                        v.w = act_fn<ACT>(v.w + b4.w);
+                        if (ACT == M360_ACT_RELU_MASK) {  // backward of ReLU: keep where the forward output (aux, same ld) was > 0
+                            const float4 a4 = *reinterpret_cast<const float4 *>(aux + m0 * ldy_t + n0 + yoff + (long)(p * 8) * ldy_t);
+                            v.x = a4.x > 0.0f ? v.x : 0.0f;
+                            v.y = a4.y > 0.0f ? v.y : 0.0f;
+                            v.z = a4.z > 0.0f ? v.z : 0.0f;
+                            v.w = a4.w > 0.0f ? v.w : 0.0f;
+                        } else {
+                            v.x = act_fn<ACT>(v.x + b4.x);
+                            v.y = act_fn<ACT>(v.y + b4.y);
+                            v.z = act_fn<ACT>(v.z + b4.z);
+                            v.w = act_fn<ACT>(v.w + b4.w);
+                        }
                         *reinterpret_cast<float4 *>(Yc + (long)(p * 8) * ldy_t) = v;
                     }
                     M360_SB();

@@ -353,12 +353,184 @@ __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
         for (int i = l; i < N; i += kWave) weights[(long)b * N + i] = w[i];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Backward of the stage finishers: what autograd does for model.py:52,92-93 (H = 1) and
+// model.py:150-158,180-186 + intern/ray.py:171-191 (H = 4) under train.py:62,80.  One 256-thread workgroup per ray.
+//   phase 1  re-evaluate the H head dot products of the ray's N samples (head_dots, as in the forward)
+//   phase 2  wave 0: activations, transmittance scan, then the reverse scan
+//              x_i = rho_i delta_i,  w_i = (1 - e^{-x_i}) T_i,  T_i = exp(-sum_{j<i} x_j)
+//              dL/dx_i = g_i T_{i+1} - sum_{k>i} g_k w_k      (g = total gradient reaching w)
+//            and the chain through softplus / sigmoid / rgb padding -> d raw[N][H]
+//   phase 3  dz[s,:] = (sum_h d raw[s,h] head_w[h,:]) * a(1 - a)  (a = sigmoid output of the last hidden layer),
+//            per-ray partial sums of d head_w[h,:] = sum_s d raw[s,h] a[s,:] and d head_b (reduced later, fixed order)
+template <int H>
+__global__ __launch_bounds__(kFinishThreads) void finish_backward_kernel(
+    const float *__restrict__ act, int ld, const float *__restrict__ head_w, const float *__restrict__ head_b,
+    int k_pad, float density_bias, float rgb_padding, const float *__restrict__ t_vals,
+    const float *__restrict__ dirs, int N, int white_bkgd, const float *__restrict__ g_rgb,
+    const float *__restrict__ g_dist, const float *__restrict__ g_acc, const float *__restrict__ g_w,
+    float *__restrict__ dz, float *__restrict__ part_hw /*[B*groups][H*k_pad]*/,
+    float *__restrict__ part_hb /*[B][H]*/, int groups) {
+    extern __shared__ float smem[];
+    const int b = blockIdx.x, l = lane_id();
+    const int nb = N + 1;
+    float *hw = smem, *t = hw + H * k_pad, *raw = t + nb, *w = raw + H * N, *tnext = w + N, *gw = tnext + N,
+          *draw = gw + N;
+    for (int i = threadIdx.x; i < H * k_pad; i += blockDim.x) hw[i] = head_w[i];
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
+    __syncthreads();
+    const float *act_ray = act + (long)b * N * ld;
+    head_dots<H, float>(act_ray, ld, hw, head_b, k_pad, N, raw);
+    __syncthreads();
+    if (threadIdx.x < kWave) {
+        const float dnorm = dir_norm(dirs, b);
+        // pass A: weights, T_{i+1}, accumulated opacity and the distance numerator
+        double carry = 0.0;
+        float sa = 0.0f, sd = 0.0f;
+        for (int base = 0; base < N; base += kWave) {
+            const int i = base + l;
+            float x = 0.0f;
+            if (i < N) {
+                const float rho = H == 1 ? softplusf_(raw[i] + density_bias) : softplusf_(sigmoidf_(raw[H * i]) + density_bias);
+                x = rho * ((t[i + 1] - t[i]) * dnorm);
+            }
+            const double incl = wave_incl_scan_d((double)x);
+            if (i < N) {
+                const float wi = (1.0f - expf(-x)) * expf(-(float)(carry + incl - (double)x));
+                w[i] = wi;
+                tnext[i] = expf(-(float)(carry + incl));
+                sa += wi;
+                sd += wi * (0.5f * (t[i] + t[i + 1]));
+            }
+            carry += __shfl(incl, kWave - 1, kWave);
+        }
+        sa = wave_sum(sa);
+        sd = wave_sum(sd);
+        // pass B: total gradient reaching each weight
+        float gr = 0.0f, gg = 0.0f, gb = 0.0f, ga = 0.0f, gd_scale = 0.0f, dval = 0.0f;
+        if (H == 4) {
+            if (g_rgb) {
+                gr = g_rgb[3 * b];
+                gg = g_rgb[3 * b + 1];
+                gb = g_rgb[3 * b + 2];
+            }
+            if (g_acc) ga = g_acc[b];
+            if (white_bkgd) ga -= gr + gg + gb;  // comp_rgb += 1 - acc
+            if (g_dist) {                        // distance = clamp(nan_to_num(sd / sa), t_0, t_N): gradient only inside
+                dval = sd / sa;
+                if (dval == dval && fabsf(dval) <= 3.4028234e38f && dval >= t[0] && dval <= t[N]) gd_scale = g_dist[b] / sa;
+                else dval = 0.0f;
+            }
+        }
+        wave_sync();
+        double total = 0.0;
+        for (int base = 0; base < N; base += kWave) {
+            const int i = base + l;
+            float g = 0.0f;
+            if (i < N) {
+                if (g_w) g = g_w[(long)b * N + i];
+                if (H == 4) {
+                    const float k = 1.0f + 2.0f * rgb_padding;
+                    g += ga + gr * (sigmoidf_(raw[4 * i + 1]) * k - rgb_padding) + gg * (sigmoidf_(raw[4 * i + 2]) * k - rgb_padding) +
+                         gb * (sigmoidf_(raw[4 * i + 3]) * k - rgb_padding);
+                    g += gd_scale * (0.5f * (t[i] + t[i + 1]) - dval);
+                }
+                gw[i] = g;
+            }
+            total += (double)(i < N ? g * w[i] : 0.0f);
+        }
+        total = wave_sum_d(total);
+        // pass C: reverse scan and the activation chain
+        double pcarry = 0.0;
+        for (int base = 0; base < N; base += kWave) {
+            const int i = base + l;
+            const float gwi = i < N ? gw[i] * w[i] : 0.0f;
+            const double incl = wave_incl_scan_d((double)gwi);
+            if (i < N) {
+                const float suffix = (float)(total - (pcarry + incl));
+                const float dx = gw[i] * tnext[i] - suffix;
+                const float drho = dx * ((t[i + 1] - t[i]) * dnorm);
+                if (H == 1) {
+                    draw[i] = drho * sigmoidf_(raw[i] + density_bias);
+                } else {
+                    const float s0 = sigmoidf_(raw[4 * i]);
+                    draw[4 * i] = drho * sigmoidf_(s0 + density_bias) * s0 * (1.0f - s0);
+                    const float k = (1.0f + 2.0f * rgb_padding) * w[i];
+                    const float s1 = sigmoidf_(raw[4 * i + 1]), s2 = sigmoidf_(raw[4 * i + 2]), s3 = sigmoidf_(raw[4 * i + 3]);
+                    draw[4 * i + 1] = k * gr * s1 * (1.0f - s1);
+                    draw[4 * i + 2] = k * gg * s2 * (1.0f - s2);
+                    draw[4 * i + 3] = k * gb * s3 * (1.0f - s3);
+                }
+            }
+            pcarry += __shfl(incl, kWave - 1, kWave);
+        }
+        wave_sync();
+        // head bias gradient of this ray
+        float hb[H];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) hb[hh] = 0.0f;
+        for (int i = l; i < N; i += kWave)
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh) hb[hh] += draw[H * i + hh];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) {
+            hb[hh] = wave_sum(hb[hh]);
+            if (l == 0) part_hb[(long)b * H + hh] = hb[hh];
+        }
+    }
+    __syncthreads();
+    // phase 3: thread = (sample group, 16-byte column chunk); every group walks its samples n = group, group+groups, ..
+    const int kc = k_pad / 4;
+    const int per = kc < (int)blockDim.x ? kc : (int)blockDim.x;  // threads per group
+    const int group = threadIdx.x / per, tc = threadIdx.x % per;
+    if (group >= groups) return;
+    float *__restrict__ dz_ray = dz + (long)b * N * ld;
+    for (int c = tc; c < kc; c += per) {
+        float4 hwc[H], accw[H];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) {
+            hwc[hh] = *reinterpret_cast<const float4 *>(hw + hh * k_pad + 4 * c);
+            accw[hh] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        for (int n = group; n < N; n += groups) {
+            const float4 a = *reinterpret_cast<const float4 *>(act_ray + (long)n * ld + 4 * c);
+            float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh) {
+                const float dr = draw[H * n + hh];
+                d.x += dr * hwc[hh].x;
+                d.y += dr * hwc[hh].y;
+                d.z += dr * hwc[hh].z;
+                d.w += dr * hwc[hh].w;
+                accw[hh].x += dr * a.x;
+                accw[hh].y += dr * a.y;
+                accw[hh].z += dr * a.z;
+                accw[hh].w += dr * a.w;
+            }
+            d.x *= a.x * (1.0f - a.x);
+            d.y *= a.y * (1.0f - a.y);
+            d.z *= a.z * (1.0f - a.z);
+            d.w *= a.w * (1.0f - a.w);
+            *reinterpret_cast<float4 *>(dz_ray + (long)n * ld + 4 * c) = d;
+        }
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh)
+            *reinterpret_cast<float4 *>(part_hw + ((long)b * groups + group) * (H * k_pad) + hh * k_pad + 4 * c) = accw[hh];
+    }
+}
+
 }  // namespace m360
 
 // =========================================================================================
 using namespace m360;
 
 static inline hipStream_t S_(m360_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+#define M360_RAY_TRY(expr)          \
+    do {                            \
+        const int rc_ = (expr);     \
+        if (rc_ != M360_OK) return rc_; \
+    } while (0)
 static constexpr size_t kMaxDynLds = 64 * 1024;
 
 extern "C" {
@@ -492,6 +664,64 @@ static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_
     if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
     else hipLaunchKernelGGL(nerf_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
     return check_launch("nerf_finish");
+}
+
+// ---- backward of the stage finishers (training path)
+static int finish_groups(int k_pad) {
+    const int kc = k_pad / 4;
+    return kc >= kFinishThreads ? 1 : kFinishThreads / kc;
+}
+static constexpr int kFinishSlices = 64;
+static inline size_t fb_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t m360_finish_backward_workspace_bytes(int B, int heads, int k_pad) {
+    if (B < 0 || heads < 1 || k_pad < 4) return 0;
+    const size_t C = (size_t)heads * k_pad;
+    return fb_up((size_t)B * finish_groups(k_pad) * C * sizeof(float)) + fb_up((size_t)B * heads * sizeof(float)) +
+           fb_up((size_t)kFinishSlices * C * sizeof(float));
+}
+
+extern "C++" {
+template <int H>
+static int finish_backward_any(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
+                               float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
+                               int N, int white_bkgd, const float *g_rgb, const float *g_dist, const float *g_acc,
+                               const float *g_w, float *dz, float *grad_head_w, float *grad_head_b, void *workspace,
+                               size_t workspace_bytes, m360_stream_t stream, const char *who) {
+    if (!act || !head_w || !head_b || !t_vals || !dirs || !dz || !grad_head_w || !grad_head_b || B < 0 || N < 1 || k_pad < 4 || k_pad % 4 || ld < k_pad || ld % 4)
+        return fail(M360_ERR_INVALID_ARGUMENT, "%s: bad argument", who);
+    if (B == 0) return M360_OK;
+    const size_t need = m360_finish_backward_workspace_bytes(B, H, k_pad);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "%s: workspace %zu < %zu bytes (or not 256-byte aligned)", who, workspace_bytes, need);
+    const size_t lds = ((size_t)H * k_pad + (N + 1) + (size_t)(2 * H + 3) * N) * sizeof(float);
+    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "%s: k_pad=%d N=%d too large for LDS", who, k_pad, N);
+    const int groups = finish_groups(k_pad), C = H * k_pad;
+    char *ws = static_cast<char *>(workspace);
+    float *part_hw = reinterpret_cast<float *>(ws);
+    float *part_hb = reinterpret_cast<float *>(ws + fb_up((size_t)B * groups * C * sizeof(float)));
+    float *slices = reinterpret_cast<float *>(reinterpret_cast<char *>(part_hb) + fb_up((size_t)B * H * sizeof(float)));
+    hipLaunchKernelGGL(finish_backward_kernel<H>, dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, g_rgb, g_dist, g_acc, g_w, dz, part_hw, part_hb, groups);
+    const int rc = check_launch(who);
+    if (rc != M360_OK) return rc;
+    M360_RAY_TRY(launch_colsum(part_hw, (long)B * groups, C, C, slices, kFinishSlices, grad_head_w, S_(stream)));
+    return launch_colsum(part_hb, (long)B, H, H, slices, kFinishSlices, grad_head_b, S_(stream));
+}
+}  // extern "C++"
+
+int m360_prop_finish_backward(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
+                              float density_bias, const float *t_vals, const float *dirs, int B, int N,
+                              const float *grad_weights, float *dz, float *grad_head_w, float *grad_head_b,
+                              void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    if (!grad_weights) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish_backward: grad_weights is required");
+    return finish_backward_any<1>(act, ld, head_w, head_b, k_pad, density_bias, 0.0f, t_vals, dirs, B, N, 0, nullptr, nullptr, nullptr, grad_weights, dz, grad_head_w, grad_head_b, workspace, workspace_bytes, stream, "m360_prop_finish_backward");
+}
+
+int m360_nerf_finish_backward(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
+                              float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
+                              int N, int white_bkgd, const float *grad_rgb, const float *grad_distance,
+                              const float *grad_acc, const float *grad_weights, float *dz, float *grad_head_w,
+                              float *grad_head_b, void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    return finish_backward_any<4>(act, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, grad_rgb, grad_distance, grad_acc, grad_weights, dz, grad_head_w, grad_head_b, workspace, workspace_bytes, stream, "m360_nerf_finish_backward");
 }
 
 }  // extern "C"

@@ -6,7 +6,10 @@ hand-written HIP pipeline of libm360 (sampling -> contraction -> IPE -> fp32-MFM
 resampling -> alpha composite) instead of eager PyTorch ops.
 
 Intentional differences:
-  * forward-only: outputs carry no autograd graph (training is out of scope, SURVEY.md §8f);
+  * differentiable with respect to the network PARAMETERS (what train.py:62,80 needs): when autograd is enabled
+    and a parameter requires grad, `prop_net.forward` / `nerf_net.forward` run the tape-keeping forward and their
+    backward is libm360's hand-written backward (m360_prop_backward / m360_nerf_backward).  Sample positions and
+    `coarse_weights` carry no gradient - as in the reference, which resamples under no_grad (intern/ray.py:136);
   * caller tensors are never mutated (the reference's `g()` bumps near/far/t_vals in place);
   * `render_image` is silent unless `self.verbose` and keeps every chunk on the device.
 There is no CPU path: tensors must be on a HIP device and libm360.so must be built.
@@ -122,6 +125,94 @@ def _hyper_struct(num_samples, min_deg, max_deg, white_bkgd=False, density_bias=
                             float(rgb_padding), float(resample_padding))
 
 
+def _wants_grad(module: nn.Module) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+class _TrainCtx:
+    """What one tape-keeping stage forward leaves behind for its backward."""
+
+    def __init__(self, module, stage, rays_keep, rstruct, B, N, hyper, packed, mstruct):
+        self.module, self.stage, self.rays_keep, self.rstruct, self.B, self.N = module, stage, rays_keep, rstruct, B, N
+        self.hyper, self.packed, self.mstruct = hyper, packed, mstruct
+        dev = rays_keep[0].device
+        lib = _lib.lib()
+        self.tape = torch.empty(max(int(lib.m360_train_tape_bytes(B, N, C.byref(mstruct), stage)), 256), dtype=torch.uint8,
+                                device=dev)
+        layers, _ = module._layers()
+        # transposed packings for the input-gradient GEMMs (layer 0 needs none), made from the same parameter
+        # versions as the forward packing
+        self.w_t = [None] + [ops.pack_linear_transposed(lin.weight, packed.h_pad, packed.h_pad) for lin in layers[1:]]
+        self.versions = [p._version for p in module.parameters()]
+
+    def backward(self, grad_args):
+        module, packed, dev = self.module, self.packed, self.tape.device
+        if [p._version for p in module.parameters()] != self.versions:
+            raise RuntimeError("a parameter was modified in place between the forward and its backward")
+        lib = _lib.lib()
+        layers, heads = module._layers()
+        L, H = len(layers), sum(h.out_features for h in heads)
+        gw = [torch.empty_like(w) for w in packed.w]
+        gb = [torch.empty_like(b) for b in packed.b]
+        ghw, ghb = torch.empty(H, packed.h_pad, device=dev), torch.empty(H, device=dev)
+        gstruct, tstruct = _lib.MlpGradsStruct(), _lib.MlpTransposedStruct()
+        for i in range(L):
+            gstruct.w[i], gstruct.b[i] = gw[i].data_ptr(), gb[i].data_ptr()
+            tstruct.w_t[i] = ops.ptr(self.w_t[i])
+        gstruct.head_w, gstruct.head_b = ghw.data_ptr(), ghb.data_ptr()
+        ws = _workspace(max(int(lib.m360_backward_workspace_bytes(self.B, self.N, C.byref(self.mstruct), self.stage)), 256),
+                        dev)
+        grad_args = [None if g is None else ops.dev(g, "gradient") for g in grad_args]
+        if self.stage == 0:
+            (g_w_hat,) = grad_args
+            if g_w_hat is None:
+                g_w_hat = torch.zeros(self.B, self.N, device=dev)
+            _lib.check(lib.m360_prop_backward(C.byref(self.rstruct), C.byref(self.mstruct), C.byref(tstruct),
+                                              C.byref(self.hyper), self.B, self.tape.data_ptr(), self.tape.numel(),
+                                              g_w_hat.data_ptr(), C.byref(gstruct), ws.data_ptr(), ws.numel(),
+                                              ops.stream()), "m360_prop_backward")
+        else:
+            g_rgb, g_dist, g_acc, g_w = grad_args
+            _lib.check(lib.m360_nerf_backward(C.byref(self.rstruct), C.byref(self.mstruct), C.byref(tstruct),
+                                              C.byref(self.hyper), self.B, self.tape.data_ptr(), self.tape.numel(),
+                                              ops.ptr(g_rgb), ops.ptr(g_dist), ops.ptr(g_acc), ops.ptr(g_w),
+                                              C.byref(gstruct), ws.data_ptr(), ws.numel(), ops.stream()),
+                       "m360_nerf_backward")
+        grads = []
+        for i, lin in enumerate(layers):
+            grads += [gw[i][:lin.out_features, :lin.in_features], gb[i][:lin.out_features]]
+        row = 0
+        for h in heads:
+            grads += [ghw[row:row + h.out_features, :h.in_features], ghb[row:row + h.out_features]]
+            row += h.out_features
+        self.tape = None  # one backward per forward, like autograd's freed buffers
+        return [g.contiguous() for g in grads]
+
+
+class _PropTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, rays, *params):
+        t_hat, w_hat, ctx.train = module._forward_impl(rays, train=True)
+        ctx.mark_non_differentiable(t_hat)
+        return t_hat, w_hat
+
+    @staticmethod
+    def backward(ctx, _g_t, g_w):
+        return (None, None, *ctx.train.backward([g_w]))
+
+
+class _NerfTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, rays, t_vals, coarse_weights, *params):
+        outs, ctx.train = module._forward_impl(rays, t_vals, coarse_weights, train=True)
+        ctx.mark_non_differentiable(outs[3], outs[5])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_dist, g_acc, _g_t, g_w, _g_s):
+        return (None, None, None, None, *ctx.train.backward([g_rgb, g_dist, g_acc, g_w]))
+
+
 def _ws_for(B, N, mstruct, device):
     nbytes = _lib.lib().m360_forward_workspace_bytes(B, N, C.byref(mstruct))
     return _workspace(max(int(nbytes), 256), device)
@@ -163,17 +254,36 @@ class prop_net(nn.Module):
         """model.py:59-78."""
         return ops.density_to_weight(t_vals, density, dirs)
 
+    def _layers(self):
+        return [self.model[i] for i in (0, 2, 4, 6)], [self.model[8]]
+
     def forward(self, rays):
-        """model.py:80-94 -> (t_vals[B,N+1], weights[B,N])."""
+        """model.py:80-94 -> (t_vals[B,N+1], weights[B,N]).  With autograd enabled and trainable parameters the
+        weights carry the graph to the parameters (train.py:55-62)."""
+        if _wants_grad(self):
+            if getattr(self, "mlp_bf16", False):
+                raise RuntimeError("training runs the fp32 MLP only: construct the model with mlp_dtype='fp32'")
+            return _PropTrainFn.apply(self, rays, *self.parameters())
+        return self._forward_impl(rays)
+
+    def _forward_impl(self, rays, train=False):
         rstruct, keep, B = _rays_struct(rays)
         dev = keep[0].device
         N = self.num_samples
-        mstruct = _model_struct(self.input_size, self._pack(), None)
+        packed = self._pack()
+        mstruct = _model_struct(self.input_size, packed, None)
         hyper = _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, density_bias=self.density_bias)
         t_hat = torch.empty(B, N + 1, device=dev)
         w_hat = torch.empty(B, N, device=dev)
         t_rand = torch.rand(B, N + 1, device=dev) if self.randomized else None
         ws = _ws_for(B, N, mstruct, dev)
+        if train:
+            tc = _TrainCtx(self, 0, keep, rstruct, B, N, hyper, packed, mstruct)
+            _lib.check(_lib.lib().m360_prop_forward_train(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B,
+                                                          ops.ptr(t_rand), t_hat.data_ptr(), w_hat.data_ptr(),
+                                                          tc.tape.data_ptr(), tc.tape.numel(), ws.data_ptr(), ws.numel(),
+                                                          ops.stream()), "m360_prop_forward_train")
+            return t_hat, w_hat, tc
         _lib.check(_lib.lib().m360_prop_forward(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, ops.ptr(t_rand),
                                                 t_hat.data_ptr(), w_hat.data_ptr(), ws.data_ptr(), ws.numel(),
                                                 ops.stream()), "m360_prop_forward")
@@ -227,9 +337,23 @@ class nerf_net(nn.Module):
         # model.py:192-196: kept on the module for the distillation / regularisation losses
         self.fine_weights, self.t_vals, self.s_vals = outs["fine_w"], outs["t_vals"], outs["s_vals"]
 
+    def _layers(self):
+        return [self.model[i] for i in range(0, 16, 2)], [self.final_density[0], self.final_color[0]]
+
     def forward(self, rays, t_vals, coarse_weights):
         """model.py:163-200 -> (rgb[B,3], distance[B], acc[B], t_vals[B,N+1], fine_weights[B,N], s_vals[B,N+1]).
-        The number of fine samples is t_vals.shape[-1]-1, as in the reference (intern/ray.py:147)."""
+        The number of fine samples is t_vals.shape[-1]-1, as in the reference (intern/ray.py:147).  With autograd
+        enabled and trainable parameters rgb / distance / acc / fine_weights carry the graph to the parameters
+        (train.py:72-80); t_vals and coarse_weights are constants, as under the reference's no_grad resampling."""
+        if _wants_grad(self):
+            if getattr(self, "mlp_bf16", False):
+                raise RuntimeError("training runs the fp32 MLP only: construct the model with mlp_dtype='fp32'")
+            outs = _NerfTrainFn.apply(self, rays, t_vals.detach(), coarse_weights.detach(), *self.parameters())
+            self.fine_weights, self.t_vals, self.s_vals = outs[4], outs[3], outs[5]
+            return outs
+        return self._forward_impl(rays, t_vals, coarse_weights)
+
+    def _forward_impl(self, rays, t_vals, coarse_weights, train=False):
         rstruct, keep, B = _rays_struct(rays)
         dev = keep[0].device
         t_vals, coarse_weights = ops.dev(t_vals, "t_vals"), ops.dev(coarse_weights, "coarse_weights")
@@ -241,6 +365,14 @@ class nerf_net(nn.Module):
         ostruct = _outputs_struct(outs)
         u_rand = torch.rand(B, Nf + 1, device=dev) if self.randomized else None
         ws = _ws_for(B, max(N, Nf), mstruct, dev)
+        if train:
+            tc = _TrainCtx(self, 1, keep, rstruct, B, Nf, hyper, self._packed, mstruct)
+            _lib.check(_lib.lib().m360_nerf_forward_train(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B,
+                                                          t_vals.data_ptr(), coarse_weights.data_ptr(), ops.ptr(u_rand),
+                                                          C.byref(ostruct), tc.tape.data_ptr(), tc.tape.numel(),
+                                                          ws.data_ptr(), ws.numel(), ops.stream()),
+                       "m360_nerf_forward_train")
+            return (outs["rgb"], outs["distance"], outs["acc"], outs["t_vals"], outs["fine_w"], outs["s_vals"]), tc
         _lib.check(_lib.lib().m360_nerf_forward(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, t_vals.data_ptr(),
                                                 coarse_weights.data_ptr(), ops.ptr(u_rand), C.byref(ostruct),
                                                 ws.data_ptr(), ws.numel(), ops.stream()), "m360_nerf_forward")
@@ -331,7 +463,7 @@ class mipNeRF360(nn.Module):
 
     def forward(self, rays):
         """model.py:247-252 -> (rgb[B,3], distance[B], acc[B])."""
-        if not self.prop_net.randomized and not self.nerf_net.randomized:
+        if not self.prop_net.randomized and not self.nerf_net.randomized and not _wants_grad(self):
             return self._forward_fused(rays)
         t_hat, w_hat = self.prop_net.forward(rays)
         rgb, dist, acc, _, _, _ = self.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)

@@ -195,6 +195,46 @@ def linear(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.
     return y
 
 
+def pack_linear_transposed(weight, n_pad: Optional[int] = None, k_pad: Optional[int] = None) -> torch.Tensor:
+    """[n_out,k_in] weight -> zero-padded transpose [k_pad,n_pad] (the operand of linear_dgrad)."""
+    weight = dev(weight.detach(), "weight")
+    n_out, k_in = weight.shape
+    n_pad, k_pad = n_pad or round_up(n_out, 32), k_pad or round_up(k_in, 32)
+    wt = torch.empty(k_pad, n_pad, device=weight.device)
+    _call("m360_pack_linear_transposed", ptr(weight), n_out, k_in, n_pad, k_pad, ptr(wt), stream())
+    return wt
+
+
+def linear_dgrad(dz, wt_packed, relu_out=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx = dz @ W (masked where relu_out <= 0), W given as its packed transpose [k_pad,n_pad]."""
+    dz, wt_packed = dev(dz, "dz"), dev(wt_packed, "wt_packed")
+    M, n_pad = dz.shape
+    k_pad = wt_packed.shape[0]
+    if wt_packed.shape[1] != n_pad:
+        raise RuntimeError(f"linear_dgrad: dz has {n_pad} columns, packed transpose expects {wt_packed.shape[1]}")
+    dx = out if out is not None else torch.empty(M, k_pad, device=dz.device)
+    if relu_out is not None:
+        relu_out = dev(relu_out, "relu_out")
+        if tuple(relu_out.shape) != (M, dx.shape[1]):
+            raise RuntimeError("linear_dgrad: relu_out must have the shape of dx")
+    _call("m360_linear_dgrad", ptr(dz), M, n_pad, ptr(wt_packed), k_pad, n_pad, ptr(relu_out), ptr(dx), dx.shape[1], stream())
+    return dx
+
+
+def linear_wgrad(dz, x, want_bias: bool = True):
+    """-> (grad_w[n_pad,k_pad] = dz^T @ x, grad_b[n_pad] = dz.sum(0) or None)"""
+    dz, x = dev(dz, "dz"), dev(x, "x")
+    M, n_pad = dz.shape
+    if x.shape[0] != M:
+        raise RuntimeError("linear_wgrad: dz and x need the same number of rows")
+    k_pad = x.shape[1]
+    gw = torch.empty(n_pad, k_pad, device=dz.device)
+    gb = torch.empty(n_pad, device=dz.device) if want_bias else None
+    ws = torch.empty(_lib.lib().m360_linear_wgrad_workspace_bytes(M, n_pad, k_pad), dtype=torch.uint8, device=dz.device)
+    _call("m360_linear_wgrad", ptr(dz), n_pad, ptr(x), k_pad, M, n_pad, k_pad, ptr(gw), ptr(gb), ptr(ws), ws.numel(), stream())
+    return gw, gb
+
+
 def dev_bf16(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
     _require_device(t, name)
     if t.dtype != torch.bfloat16:

@@ -533,3 +533,48 @@ def loss_nerf(inp: torch.Tensor, target: torch.Tensor):
 def loss_nerf_grad(inp: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     mse = ((inp[..., :3] - target[..., :3]) ** 2).sum() / inp.shape[0]
     return (10 / np.log(10)) / mse * 2 * (inp[..., :3] - target[..., :3]) / inp.shape[0]
+
+
+# ------------------------------------------------------------------------------- training step (row f3)
+def _trainable(sd):
+    return {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+
+
+def prop_step_gradients(rays: Rays, sd, hp: Hyper):
+    """train.py:55-62: Loss_prop(t, w, t_hat, w_hat).backward() -> (loss, {parameter name: gradient}) by autograd
+    through the restated forward (only prop_net.* receive a gradient: t and w are detached, train.py:57-58)."""
+    p = _trainable(sd)
+    t_hat, w_hat = prop_forward(rays, p, hp)
+    with torch.no_grad():
+        _, _, _, t, w, _ = nerf_forward(rays, t_hat, w_hat, p, hp)
+    loss = loss_prop_given(w_hat, prop_bounds(t, w, t_hat.detach()))
+    loss.backward()
+    return loss.detach(), {k: v.grad for k, v in p.items() if k.startswith("prop_net")}
+
+
+def nerf_step_gradients(rays: Rays, sd, hp: Hyper, pixels: torch.Tensor, dist_weight: float = 0.01):
+    """train.py:69-80: (Loss_nerf + dist_weight * Loss_dist).backward() -> (loss_nerf, loss_dist, gradients of nerf_net.*)."""
+    p = _trainable(sd)
+    with torch.no_grad():
+        t_hat, w_hat = prop_forward(rays, p, hp)
+    rgb, _, _, _, fine_w, s_vals = nerf_forward(rays, t_hat, w_hat, p, hp)
+    ln, _ = loss_nerf(rgb, pixels)
+    ld = loss_dist(s_vals, fine_w)
+    (ln + dist_weight * ld).backward()
+    return ln.detach(), ld.detach(), {k: v.grad for k, v in p.items() if k.startswith("nerf_net")}
+
+
+def nerf_output_gradients(rays: Rays, sd, hp: Hyper, c_dist=None, c_acc=None):
+    """gradients of sum(distance * c_dist) + sum(acc * c_acc) w.r.t. nerf_net.* (the reference can differentiate acc;
+    for distance its in-place g() makes autograd raise, so that half is the mathematical definition only)."""
+    p = _trainable(sd)
+    with torch.no_grad():
+        t_hat, w_hat = prop_forward(rays, p, hp)
+    _, dist, acc, _, _, _ = nerf_forward(rays, t_hat, w_hat, p, hp)
+    loss = 0.0
+    if c_dist is not None:
+        loss = loss + (dist * c_dist).sum()
+    if c_acc is not None:
+        loss = loss + (acc * c_acc).sum()
+    loss.backward()
+    return {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items() if k.startswith("nerf_net")}

@@ -384,9 +384,77 @@ def g12():
     save("g12_losses", **out)
 
 
+def g13():
+    """Training step: the parameter gradients of the reference's own train.py loop body on a
+    reduced-width model (hidden 32 / 64, the G7 weights).
+      prop step (train.py:55-62): Loss_prop(t, w, t_hat, w_hat).backward()        -> gradients of prop_net.*
+      nerf step (train.py:69-80): (Loss_nerf + 0.01 * Loss_dist).backward()       -> gradients of nerf_net.*
+      extra: a loss on acc (sum(acc * b)), not in train.py, to pin that path.  (A loss on `distance` cannot be
+             differentiated in the reference: t_to_s -> g() bumps t_vals in place after the clamp of
+             intern/ray.py:187 saved them, and autograd raises "modified by an inplace operation".)
+    g() mutates rays.near / rays.far in place, so every (prop forward, nerf forward) PAIR shares one fresh clone of the
+    rays - the sequence of mipNeRF360.forward (model.py:247-252) and of G7; the fixture keeps the originals.  (train.py
+    reuses one rays object for all three pairs of an iteration, so there near/far drift by a few 1e-6 more per pair;
+    that drift is not part of the fixture.)"""
+    from intern import loss as ref_loss
+    out = {}
+    hp_, hn_ = 32, 64
+    sd = synthetic.make_state_dict(hp_, hn_, seed=7)
+    for k, v in sd.items():
+        out["sd." + k] = v
+    gen = np.random.Generator(np.random.PCG64(1313))
+    for kind, B, n, wb in (("lego", 12, 16, True), ("garden", 10, 24, False), ("garden70", 3, 70, False)):
+        r = synthetic.make_rays(kind[:6], B, seed=130 + n)
+        pixels = gen.uniform(0, 1, size=(B, 3)).astype(np.float32)
+        ca, cb = gen.normal(size=B).astype(np.float32), gen.normal(size=B).astype(np.float32)
+        m = build_ref_model(sd, n, hp_, hn_, wb)
+        m.train()
+        for k in synthetic.RAY_FIELDS:
+            out[f"{kind}_rays_{k}"] = r[k]
+        out[f"{kind}_cfg"], out[f"{kind}_pixels"], out[f"{kind}_ca"], out[f"{kind}_cb"] = np.array([B, n, int(wb)]), pixels, ca, cb
+
+        # --- prop step
+        m.zero_grad()
+        rays = ref_rays(r)
+        t_hat, w_hat = m.prop_net.forward(rays)
+        _, _, _, t, w, _ = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        loss_prop = ref_loss.Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
+        loss_prop.backward()
+        out[f"{kind}_loss_prop"] = N(loss_prop)
+        for name, p in m.named_parameters():
+            if name.startswith("prop_net"):
+                out[f"{kind}_propstep.{name}"] = N(p.grad)
+            else:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, name   # the NeRF net gets nothing here
+
+        # --- nerf step
+        m.zero_grad()
+        rays = ref_rays(r)
+        t_hat, w_hat = m.prop_net.forward(rays)
+        rgb, _, _, _, fine_w, s_vals = m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+        loss_nerf, psnr = ref_loss.Loss_nerf(input=rgb, target=T(pixels))
+        loss_dist = ref_loss.Loss_dist(s_vals=s_vals, weights=fine_w)
+        (loss_nerf + 0.01 * loss_dist).backward()
+        out[f"{kind}_loss_nerf"], out[f"{kind}_loss_dist"] = N(loss_nerf), N(loss_dist)
+        for name, p in m.named_parameters():
+            if name.startswith("nerf_net"):
+                out[f"{kind}_nerfstep.{name}"] = N(p.grad)
+
+        # --- acc path
+        m.zero_grad()
+        rays = ref_rays(r)
+        t_hat, w_hat = m.prop_net.forward(rays)
+        _, _, acc, _, _, _ = m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+        (acc * T(cb)).sum().backward()
+        for name, p in m.named_parameters():
+            if name.startswith("nerf_net"):
+                out[f"{kind}_acc.{name}"] = N(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), np.float32)  # colour head: no path
+    save("g13_train_gradients", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
-    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12)
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13)
     for k in which:
         print(k)
         table[k]()

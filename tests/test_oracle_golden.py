@@ -223,3 +223,39 @@ def test_g12_losses(golden, tag):
     np.testing.assert_allclose(O.loss_nerf_grad(rgb, pix).numpy(), g[f"{tag}.loss_nerf.grad"], rtol=2e-5, atol=1e-7)
     if tag == "a":
         np.testing.assert_allclose(O.mse_to_psnr(torch.from_numpy(g["mse_to_psnr.in"])).numpy(), g["mse_to_psnr.out"], rtol=1e-6)
+
+
+def _g13_case(g, kind):
+    B, n, wb = (int(v) for v in g[f"{kind}_cfg"])
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g if k.startswith("sd.")}
+    rays = O.Rays(*[torch.from_numpy(g[f"{kind}_rays_{f}"]) for f in synthetic.RAY_FIELDS])
+    return rays, sd, O.Hyper(num_samples=n, white_bkgd=bool(wb))
+
+
+def _grad_close(got, want, name, rel=2e-4):
+    """gradient tensors: max |diff| <= rel * max |want| (fp32 sums in a different order)"""
+    scale = max(float(np.abs(want).max()), 1e-12)
+    err = float(np.abs(np.asarray(got) - want).max())
+    assert err <= rel * scale, f"{name}: max |diff| {err:.3e} > {rel} * {scale:.3e}"
+
+
+@pytest.mark.parametrize("kind", ["lego", "garden", "garden70"])
+def test_g13_training_gradients(golden, kind):
+    """Row f3: parameter gradients of the reference's train.py loop body (autograd in the reference) vs autograd
+    through the oracle's restated forward + losses."""
+    g = golden("g13_train_gradients")
+    rays, sd, hp = _g13_case(g, kind)
+    loss, grads = O.prop_step_gradients(rays, sd, hp)
+    np.testing.assert_allclose(loss.numpy(), g[f"{kind}_loss_prop"], rtol=2e-5)
+    assert len(grads) == 10
+    for name, gr in grads.items():
+        _grad_close(gr.numpy(), g[f"{kind}_propstep.{name}"], name)
+    ln, ld, grads = O.nerf_step_gradients(rays, sd, hp, torch.from_numpy(g[f"{kind}_pixels"]))
+    np.testing.assert_allclose(ln.numpy(), g[f"{kind}_loss_nerf"], rtol=2e-5)
+    np.testing.assert_allclose(ld.numpy(), g[f"{kind}_loss_dist"], rtol=2e-5)
+    assert len(grads) == 20
+    for name, gr in grads.items():
+        _grad_close(gr.numpy(), g[f"{kind}_nerfstep.{name}"], name)
+    grads = O.nerf_output_gradients(rays, sd, hp, c_acc=torch.from_numpy(g[f"{kind}_cb"]))
+    for name, gr in grads.items():
+        _grad_close(gr.numpy(), g[f"{kind}_acc.{name}"], name)
