@@ -89,7 +89,8 @@ def main():
     gathered = torch.empty(world * RAYS_PER_GPU, 5, device=dev) if world > 1 else None
 
     def step():
-        rgb, d, a = model(rays)  # the public forward: (rgb[B,3], distance[B], acc[B])
+        with torch.no_grad():  # rendering, as in render_image (model.py:261); with grad enabled the mirrors keep a training tape
+            rgb, d, a = model(rays)  # the public forward: (rgb[B,3], distance[B], acc[B])
         if world > 1:
             pixels = torch.cat([rgb, d[:, None], a[:, None]], 1)  # 20 B per ray
             dist.all_gather_into_tensor(gathered, pixels)
@@ -172,7 +173,8 @@ def main():
                                 "host_cpus": os.cpu_count()}
         # parity + PSNR of the same sub-batch rendered as its own chunk on the GPU
         sub = Rays(*[f[:n_cpu].contiguous() for f in rays])
-        g_rgb, g_dist, g_acc = model(sub)
+        with torch.no_grad():
+            g_rgb, g_dist, g_acc = model(sub)
         mse = float(((g_rgb.cpu() - o[0]) ** 2).mean())
         line["parity"] = {"max_abs_rgb": float((g_rgb.cpu() - o[0]).abs().max()),
                           "max_abs_acc": float((g_acc.cpu() - o[2]).abs().max()),

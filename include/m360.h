@@ -162,6 +162,16 @@ int m360_encode_features_bf16(const float *t_vals, const float *origins, const f
                               void *feat_bf16, int ld_feat, void *workspace, size_t workspace_bytes,
                               m360_stream_t stream);
 
+/* m360_encode_features[_bf16] with per-chunk contraction norms: rays [g*group_rays, (g+1)*group_rays) form group g
+ * and are contracted with the norm of their own means (what parameterization.py:25 sees when render_image,
+ * model.py:262-264, feeds that chunk alone).  group_rays = 0: one norm for the batch.  group_rays * N <= 131072 and
+ * at most 1024 groups.  A group's norm is reduced by one workgroup in an order that depends only on the group, so
+ * grouped and chunk-by-chunk launches agree bit for bit. */
+int m360_encode_features_grouped(const float *t_vals, const float *origins, const float *directions,
+                                 const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
+                                 int ld_feat, int bf16, int group_rays, void *workspace, size_t workspace_bytes,
+                                 m360_stream_t stream);
+
 /* ------------------------------------------------------------------ per-ray scans ----- */
 
 /* model.py:59-78 (prop_net.density_to_weight); density[B,N]. */
@@ -334,6 +344,10 @@ typedef struct {
     int white_bkgd;
     float density_bias, rgb_padding, resample_padding;
     int num_samples_fine; /* extension: NeRF-stage samples per ray; 0 = num_samples (the reference's behaviour) */
+    int norm_group_rays;  /* extension: > 0 = the batch is a run of render_image chunks (model.py:262-264) of this many
+                             rays, each contracted with ITS OWN global norm (parameterization.py:25): one launch
+                             sequence renders many chunks, bit-identical to launching them one by one; 0 = one norm
+                             for the whole batch (the reference's forward) */
 } m360_hyper_t; /* ctor arguments of model.py:203-215 */
 
 typedef struct {

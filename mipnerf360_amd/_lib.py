@@ -35,7 +35,7 @@ class ModelStruct(C.Structure):  # m360_model_t
 class HyperStruct(C.Structure):  # m360_hyper_t
     _fields_ = [("num_samples", C.c_int), ("viewdir_min_deg", C.c_int), ("viewdir_max_deg", C.c_int),
                 ("white_bkgd", C.c_int), ("density_bias", C.c_float), ("rgb_padding", C.c_float),
-                ("resample_padding", C.c_float), ("num_samples_fine", C.c_int)]
+                ("resample_padding", C.c_float), ("num_samples_fine", C.c_int), ("norm_group_rays", C.c_int)]
 
 
 class OutputsStruct(C.Structure):  # m360_outputs_t
@@ -71,6 +71,7 @@ SIGNATURES = {
     "m360_ipe": (_i, [_vp, _vp, _l, _vp, _vp]),
     "m360_viewdir_enc": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "m360_encode_features": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "m360_encode_features_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "m360_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_pack_linear_transposed": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -85,7 +85,7 @@ static inline int n_max(const m360_hyper_t *h) { return n_fine(h) > h->num_sampl
 static int validate(const m360_rays_t *r, const m360_model_t *m, const m360_hyper_t *h, int B,
                     const void *ws, size_t ws_bytes, const char *who) {
     if (!r || !m || !h) return fail(M360_ERR_INVALID_ARGUMENT, "%s: null descriptor", who);
-    if (B < 0 || h->num_samples < 1 || h->num_samples_fine < 0) return fail(M360_ERR_INVALID_ARGUMENT, "%s: B=%d num_samples=%d num_samples_fine=%d", who, B, h->num_samples, h->num_samples_fine);
+    if (B < 0 || h->num_samples < 1 || h->num_samples_fine < 0 || h->norm_group_rays < 0) return fail(M360_ERR_INVALID_ARGUMENT, "%s: B=%d num_samples=%d num_samples_fine=%d norm_group_rays=%d", who, B, h->num_samples, h->num_samples_fine, h->norm_group_rays);
     if (B == 0) return M360_OK;  // empty batch: nothing is dereferenced
     if (!r->origins || !r->directions || !r->viewdirs || !r->radii || !r->near || !r->far)
         return fail(M360_ERR_INVALID_ARGUMENT, "%s: null ray field", who);
@@ -146,7 +146,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         if (hipMemcpyAsync(t_hat, tt, (size_t)B * (N + 1) * sizeof(float), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(st)) != hipSuccess)
             return fail(M360_ERR_LAUNCH, "m360_prop_forward_train: copy of t_hat failed");
         M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
-        M360_TRY(m360_encode_features(tt, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(m360_encode_features_grouped(tt, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(m360_linear(tf, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, act[0], hp, st));
         for (int l = 1; l < 4; ++l)
             M360_TRY(m360_linear(act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, l == 3 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hp, st));
@@ -156,14 +156,14 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hp = m->hp_pad;
     if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers, half the bytes)
-        M360_TRY(m360_encode_features_bf16(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(m360_encode_features_grouped(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(m360_linear_bf16(feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
         M360_TRY(m360_linear_bf16(a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
         M360_TRY(m360_linear_bf16(b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
         M360_TRY(m360_linear_bf16(a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, hp, st));
         return m360_prop_finish_bf16(b, hp, m->prop_head_w, m->prop_head_b, hp, h->density_bias, t_hat, r->directions, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st);
     }
-    M360_TRY(m360_encode_features(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+    M360_TRY(m360_encode_features_grouped(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(m360_linear(feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
     M360_TRY(m360_linear(a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
     M360_TRY(m360_linear(b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
@@ -189,13 +189,13 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         float *tf = reinterpret_cast<float *>(tape + T.feat);
         float *act[8];
         for (int l = 0; l < 8; ++l) act[l] = reinterpret_cast<float *>(tape + T.act[l]);
-        M360_TRY(m360_encode_features(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(m360_encode_features_grouped(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(m360_linear(tf, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, act[0], hn, st));
         for (int l = 1; l < 8; ++l)
             M360_TRY(m360_linear(act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, l == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hn, st));
         M360_TRY(m360_nerf_finish(act[7], hn, m->nerf_head_w, m->nerf_head_b, hn, h->density_bias, h->rgb_padding, t1, r->directions, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
     } else if (m->mlp_bf16) {
-        M360_TRY(m360_encode_features_bf16(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(m360_encode_features_grouped(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(m360_linear_bf16(feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
         for (int layer = 1; layer < 8; ++layer) {
             M360_TRY(m360_linear_bf16(src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
@@ -203,7 +203,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         }
         M360_TRY(m360_nerf_finish_bf16(src, hn, m->nerf_head_w, m->nerf_head_b, hn, h->density_bias, h->rgb_padding, t1, r->directions, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
     } else {
-    M360_TRY(m360_encode_features(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, ws + L.norm, m360_contract_workspace_bytes(), st));
+    M360_TRY(m360_encode_features_grouped(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(m360_linear(feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
     for (int layer = 1; layer < 8; ++layer) {
         M360_TRY(m360_linear(src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));

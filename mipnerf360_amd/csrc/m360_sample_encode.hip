@@ -6,11 +6,14 @@
 namespace m360 {
 
 constexpr int kNormPartials = 1024;  // fixed partition => deterministic reduction order
+constexpr int kMaxNormGroups = 1024;  // chunks per launch in grouped mode
+constexpr long kSmallGroup = 131072;  // samples: groups up to this size are reduced by ONE workgroup (see norm_group_*)
 
 struct NormScratch {  // layout of the contraction workspace
     double partial[kNormPartials];
-    float gnorm;  // Frobenius norm of the un-contracted means
+    float gnorm;  // Frobenius norm of the un-contracted means (whole batch, = gnorms[0] for a single group)
     float pad[15];
+    float gnorms[kMaxNormGroups];  // grouped mode: one norm per chunk of `group_rays` rays
 };
 
 // ------------------------------------------------------------------------------------------
@@ -141,6 +144,38 @@ __global__ __launch_bounds__(256) void norm_partial_from_t_kernel(
     block_store_partial(acc, ws->partial);
 }
 
+// One workgroup per group of `group_rays` consecutive rays: the summation order depends only on the group's own
+// samples (thread t takes local samples t, t + 256, ...; fp64), so a chunk's norm is bit-identical whether the chunk
+// is launched alone or as one of many groups of a larger launch.  Used for every group of <= kSmallGroup samples.
+__global__ __launch_bounds__(256) void norm_group_from_t_kernel(
+    const float *__restrict__ t_vals, const float *__restrict__ directions,
+    const float *__restrict__ radii, int B, int N, int group_rays, NormScratch *__restrict__ ws) {
+    __shared__ double red[4];
+    const int r0 = blockIdx.x * group_rays;
+    const int rays = (B - r0 < group_rays) ? (B - r0) : group_rays;
+    const long count = (long)rays * N;
+    double acc = 0.0;
+    for (long j = threadIdx.x; j < count; j += blockDim.x) {
+        const int b = r0 + (int)(j / N), n = (int)(j % N);
+        const float t0 = t_vals[(long)b * (N + 1) + n], t1 = t_vals[(long)b * (N + 1) + n + 1];
+        float tm, tv, rv;
+        frustum_moments(t0, t1, radii[b], tm, tv, rv);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float m = directions[3 * b + i] * tm;
+            acc += (double)m * (double)m;
+        }
+    }
+    acc = wave_sum_d(acc);
+    if (lane_id() == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float g = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+        ws->gnorms[blockIdx.x] = g;
+        if (gridDim.x == 1) ws->gnorm = g;
+    }
+}
+
 __global__ __launch_bounds__(256) void norm_partial_from_mean_kernel(const float *__restrict__ mean,
                                                                       long count,
                                                                       NormScratch *__restrict__ ws) {
@@ -268,7 +303,7 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
     const float *__restrict__ t_vals, const float *__restrict__ origins,
     const float *__restrict__ directions, const float *__restrict__ radii,
     const float *__restrict__ vdenc, int vd_ch, int B, int N, const NormScratch *__restrict__ ws,
-    void *__restrict__ feat_out, int ld) {
+    void *__restrict__ feat_out, int ld, int group_rays) {
     extern __shared__ float tile[];  // [kEncThreads][ld + 1]
     const long S = (long)B * N;
     const long s0 = (long)blockIdx.x * kEncThreads;
@@ -278,7 +313,8 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
     if (idx < S) {
         const int b = (int)(idx / N), n = (int)(idx % N);
         float m[3], c[9];
-        sample_gaussian(t_vals, origins, directions, radii, N, b, n, ws->gnorm, m, c);
+        const float gn = group_rays > 0 ? ws->gnorms[b / group_rays] : ws->gnorm;
+        sample_gaussian(t_vals, origins, directions, radii, N, b, n, gn, m, c);
         ipe_sample<true>(m, c, [&](int k, float v) { row[k] = v; });
         for (int k = 0; k < vd_ch; ++k) row[kIpeCh + k] = vdenc[(long)b * vd_ch + k];
         for (int k = kIpeCh + vd_ch; k < ld; ++k) row[k] = 0.0f;
@@ -404,7 +440,12 @@ int m360_gaussian_contract(const float *mean_in, const float *cov_in, long S, fl
 
 // norm pre-pass shared by para_rays / encode_features
 static void launch_norm_from_t(const float *t_vals, const float *directions, const float *radii, int B,
-                               int N, NormScratch *ws, hipStream_t st) {
+                               int N, NormScratch *ws, hipStream_t st, int group_rays = 0) {
+    if (group_rays > 0 || (long)B * N <= kSmallGroup) {  // per-chunk norms, or one small chunk: same kernel, same order
+        const int gr = group_rays > 0 ? group_rays : B;
+        hipLaunchKernelGGL(norm_group_from_t_kernel, dim3((B + gr - 1) / gr), dim3(256), 0, st, t_vals, directions, radii, B, N, gr, ws);
+        return;
+    }
     const int parts = norm_parts((long)B * N);
     hipLaunchKernelGGL(norm_partial_from_t_kernel, dim3(parts), dim3(256), 0, st, t_vals, directions, radii, B, N, ws);
     hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, ws, parts);
@@ -441,7 +482,18 @@ int m360_viewdir_enc(const float *viewdirs, int B, int min_deg, int max_deg, flo
 
 static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
                                const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
-                               int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream);
+                               int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream,
+                               int group_rays = 0);
+
+int m360_encode_features_grouped(const float *t_vals, const float *origins, const float *directions,
+                                 const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
+                                 int ld_feat, int bf16, int group_rays, void *workspace, size_t workspace_bytes,
+                                 m360_stream_t stream) {
+    if (group_rays < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features_grouped: group_rays=%d", group_rays);
+    if (group_rays > 0 && ((long)group_rays * N > kSmallGroup || (B + group_rays - 1) / group_rays > kMaxNormGroups))
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features_grouped: group_rays=%d x N=%d exceeds %ld samples per group, or more than %d groups", group_rays, N, kSmallGroup, kMaxNormGroups);
+    return encode_features_any(t_vals, origins, directions, radii, vdenc, vd_ch, B, N, feat, ld_feat, bf16, workspace, workspace_bytes, stream, group_rays);
+}
 
 int m360_encode_features(const float *t_vals, const float *origins, const float *directions,
                          const float *radii, const float *vdenc, int vd_ch, int B, int N, float *feat,
@@ -457,17 +509,18 @@ int m360_encode_features_bf16(const float *t_vals, const float *origins, const f
 
 static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
                                const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
-                               int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+                               int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream,
+                               int group_rays) {
     if (!t_vals || !origins || !directions || !radii || !feat || B < 0 || N < 1 || vd_ch < 0 || (vd_ch > 0 && !vdenc))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: bad argument");
     if (ld_feat % 32 != 0 || ld_feat < kIpeCh + vd_ch) return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: ld_feat=%d must be a multiple of 32 and >= %d", ld_feat, kIpeCh + vd_ch);
     if (!workspace || workspace_bytes < sizeof(NormScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_encode_features: workspace %zu < %zu", workspace_bytes, sizeof(NormScratch));
     if (B == 0) return M360_OK;
     NormScratch *ws = static_cast<NormScratch *>(workspace);
-    launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream));
+    launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream), group_rays);
     const size_t lds = (size_t)kEncThreads * (ld_feat + 1) * sizeof(float);
-    if (bf16) hipLaunchKernelGGL(encode_features_kernel<true>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat);
-    else hipLaunchKernelGGL(encode_features_kernel<false>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat);
+    if (bf16) hipLaunchKernelGGL(encode_features_kernel<true>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays);
+    else hipLaunchKernelGGL(encode_features_kernel<false>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays);
     return check_launch("encode_features");
 }
 

@@ -126,6 +126,10 @@ def _hyper_struct(num_samples, min_deg, max_deg, white_bkgd=False, density_bias=
 
 
 def _wants_grad(module: nn.Module) -> bool:
+    """Tape-keeping differentiable forward?  Only the fp32 MLP is trainable: a model built with mlp_dtype='bf16' is
+    forward-only (its outputs never carry a graph)."""
+    if getattr(module, "mlp_bf16", False) or getattr(module, "mlp_dtype", "fp32") == "bf16":
+        return False
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
 
@@ -261,8 +265,6 @@ class prop_net(nn.Module):
         """model.py:80-94 -> (t_vals[B,N+1], weights[B,N]).  With autograd enabled and trainable parameters the
         weights carry the graph to the parameters (train.py:55-62)."""
         if _wants_grad(self):
-            if getattr(self, "mlp_bf16", False):
-                raise RuntimeError("training runs the fp32 MLP only: construct the model with mlp_dtype='fp32'")
             return _PropTrainFn.apply(self, rays, *self.parameters())
         return self._forward_impl(rays)
 
@@ -346,8 +348,6 @@ class nerf_net(nn.Module):
         enabled and trainable parameters rgb / distance / acc / fine_weights carry the graph to the parameters
         (train.py:72-80); t_vals and coarse_weights are constants, as under the reference's no_grad resampling."""
         if _wants_grad(self):
-            if getattr(self, "mlp_bf16", False):
-                raise RuntimeError("training runs the fp32 MLP only: construct the model with mlp_dtype='fp32'")
             outs = _NerfTrainFn.apply(self, rays, t_vals.detach(), coarse_weights.detach(), *self.parameters())
             self.fine_weights, self.t_vals, self.s_vals = outs[4], outs[3], outs[5]
             return outs
@@ -423,6 +423,7 @@ class mipNeRF360(nn.Module):
         self.device = device
         self.init_randomized = randomized
         self.verbose = False
+        self.super_batch_rays = 4096  # render_rays launches this many rays at once when `chunks` is smaller
         self.prop_net = prop_net(randomized=self.randomized, num_samples=self.num_samples,
                                  hidden_proposal=self.hidden_proposal, density_bias=self.density_bias,
                                  viewdir_min_deg=self.viewdir_min_deg, viewdir_max_deg=self.viewdir_max_deg,
@@ -440,13 +441,14 @@ class mipNeRF360(nn.Module):
         self.to(device)
 
     # ------------------------------------------------------------------ fused two-stage forward
-    def _forward_fused(self, rays, rgb=None, distance=None, acc=None, stash=True):
+    def _forward_fused(self, rays, rgb=None, distance=None, acc=None, stash=True, norm_group_rays=0):
         rstruct, keep, B = _rays_struct(rays)
         dev = keep[0].device
         N = self.prop_net.num_samples
         Nf = self.nerf_net.num_samples_fine or N
         mstruct = _model_struct(self.prop_net.input_size, self.prop_net._pack(), self.nerf_net._pack())
         hyper = self.nerf_net._hyper(N, Nf)
+        hyper.norm_group_rays = int(norm_group_rays)
         if stash:
             outs = _alloc_outputs(B, Nf, dev, with_prop=False, rgb=rgb, distance=distance, acc=acc)
         else:
@@ -482,11 +484,18 @@ class mipNeRF360(nn.Module):
         dist = torch.empty(length, device=dev)
         acc = torch.empty(length, device=dev)
         fused = not self.prop_net.randomized and not self.nerf_net.randomized
+        # Small chunks (the reference's default is 128 rays, config.py:49) are launched many at a time: the chunk
+        # partition only matters through the per-chunk contraction norm, which the kernels keep per group of `chunks`
+        # rays (m360_hyper_t.norm_group_rays) - bit-identical to one launch per chunk, at large-batch efficiency.
+        n_max = max(self.prop_net.num_samples, self.nerf_net.num_samples_fine or self.prop_net.num_samples)
+        group = chunks if (fused and chunks < self.super_batch_rays and chunks * n_max <= 131072) else 0
+        step = (self.super_batch_rays // chunks) * chunks if group else chunks
         with torch.no_grad():
-            for i in range(0, length, chunks):
-                chunk = namedtuple_map(lambda r: r[i:i + chunks], rays)
+            for i in range(0, length, step):
+                chunk = namedtuple_map(lambda r: r[i:i + step], rays)
                 if fused:
-                    self._forward_fused(chunk, rgb[i:i + chunks], dist[i:i + chunks], acc[i:i + chunks], stash=False)
+                    self._forward_fused(chunk, rgb[i:i + step], dist[i:i + step], acc[i:i + step], stash=False,
+                                        norm_group_rays=group)
                 else:
                     r, d, a = self(chunk)
                     rgb[i:i + chunks], dist[i:i + chunks], acc[i:i + chunks] = r, d, a

@@ -840,7 +840,7 @@ def test_train_step_full_width_vs_oracle(dev):
     assert not torch.allclose(rgb2, rgb.detach())
 
 
-def test_training_rejects_bf16_and_inplace_update(golden, dev):
+def test_training_bf16_is_forward_only_and_inplace_update_is_caught(golden, dev):
     from mipnerf360_amd.model import mipNeRF360
     g = golden("g13_train_gradients")
     model, rays = _g13_model(g, dev, "lego")
@@ -850,5 +850,38 @@ def test_training_rejects_bf16_and_inplace_update(golden, dev):
     with pytest.raises(RuntimeError, match="modified in place"):
         w_hat.sum().backward()
     m16 = mipNeRF360(num_samples=16, hidden_proposal=64, hidden_nerf=64, device=dev, mlp_dtype="bf16").train()
-    with pytest.raises(RuntimeError, match="fp32"):
-        m16.prop_net.forward(rays)
+    t16, w16 = m16.prop_net.forward(rays)      # the bf16 MLP is forward-only: no graph, so backward is an error
+    assert not w16.requires_grad
+    with pytest.raises(RuntimeError):
+        w16.sum().backward()
+
+
+# ------------------------------------------------------------------ many render_image chunks per launch
+@pytest.mark.parametrize("rays,chunks,super_rays", [(1000, 96, 480), (768, 128, 4096), (300, 7, 64)])
+def test_grouped_chunks_bit_identical_to_chunk_loop(dev, rays, chunks, super_rays):
+    """render_rays launches several of the reference's chunks (model.py:262-264) at once, each with its own contraction
+    norm (m360_hyper_t.norm_group_rays).  Must equal the one-launch-per-chunk loop bit for bit, including a ragged last
+    chunk and a ragged last super-batch, and must differ from rendering everything as one chunk (the norm is real)."""
+    sd = synthetic.make_state_dict(64, 128, seed=11)
+    m = build_model(sd, dev, 32, 64, 128, False)
+    r = synthetic.make_rays("garden", rays, seed=12)
+    r["origins"] = r["origins"] * 3.0            # push the means outside the unit ball so the norm matters
+    m.super_batch_rays = super_rays
+    a = [t.clone() for t in m.render_rays(dev_rays(r, dev), chunks)]
+    m.super_batch_rays = 0                       # chunks < 0 is never true: one launch sequence per chunk
+    b = m.render_rays(dev_rays(r, dev), chunks)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    c = m.render_rays(dev_rays(r, dev), rays)
+    assert not torch.equal(a[0], c[0])
+
+
+def test_grouped_encode_limits(dev):
+    from mipnerf360_amd import _lib
+    import ctypes as C
+    z = torch.zeros(4096 * 129, device=dev)
+    ws = torch.zeros(int(_lib.lib().m360_contract_workspace_bytes()), dtype=torch.uint8, device=dev)
+    feat = torch.empty(16, device=dev)
+    rc = _lib.lib().m360_encode_features_grouped(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, 0, 4096, 128,
+                                                 feat.data_ptr(), 64, 0, 2048, ws.data_ptr(), ws.numel(), None)
+    assert rc != 0 and b"131072" in _lib.lib().m360_last_error()
