@@ -442,6 +442,28 @@ int m360_nerf_backward(const m360_rays_t *rays_host, const m360_model_t *model_h
                        const float *grad_acc, const float *grad_weights, const m360_mlp_grads_t *grads_host,
                        void *workspace, size_t workspace_bytes, m360_stream_t stream);
 
+/* ------------------------------------------------------------------ one batch over several devices ---
+ * when ONE logical batch (e.g. BASELINE configs[4], 8192 rays) is split over ranks, the
+ * contraction norm of parameterization.py:25 spans all ranks' rays.  Each rank computes the fp64 sum of squares
+ * of its own un-contracted means (m360_mean_sumsq), the host all-reduces that one double per stage (RCCL) and
+ * hands sqrt(sum) back as a device float.  Everything else is rank-local. */
+int m360_mean_sumsq(const float *t_vals /*[B,N+1]*/, const float *directions, const float *radii, int B, int N,
+                    double *sumsq /*device, 1*/, void *workspace, size_t workspace_bytes, m360_stream_t stream);
+int m360_encode_features_ext_norm(const float *t_vals, const float *origins, const float *directions,
+                                  const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
+                                  int ld_feat, int bf16, const float *norm /*device, 1*/, void *workspace,
+                                  size_t workspace_bytes, m360_stream_t stream);
+/* proposal stage on given sample positions t_hat[B,N+1] (m360_sample_t) -> w_hat[B,N], t_new[B,n_fine+1] (or NULL) */
+int m360_prop_forward_from_t(const m360_rays_t *rays_host, const m360_model_t *model_host,
+                             const m360_hyper_t *hyper_host, int B, const float *t_hat, const float *norm,
+                             float *w_hat, float *t_new, void *workspace, size_t workspace_bytes,
+                             m360_stream_t stream);
+/* NeRF stage on given resampled positions t_new[B,n_fine+1] */
+int m360_nerf_forward_from_t(const m360_rays_t *rays_host, const m360_model_t *model_host,
+                             const m360_hyper_t *hyper_host, int B, const float *t_new, const float *norm,
+                             const m360_outputs_t *out_host, void *workspace, size_t workspace_bytes,
+                             m360_stream_t stream);
+
 /* ------------------------------------------------------------------ measurement ------ */
 
 /* Optional HIP-event timing of every m360_linear launch (the MFMA kernel that bounds the path),

@@ -114,6 +114,11 @@ SIGNATURES = {
     "m360_prof_reset": (_i, []),
     "m360_prof_read": (_i, [_i, _P(C.c_float), _P(C.c_long), _P(_i), _P(_i)]),
     "m360_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _P(OutputsStruct), _vp, _sz, _vp]),
+    "m360_mean_sumsq": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "m360_encode_features_ext_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "m360_prop_forward_from_t": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "m360_nerf_forward_from_t": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _P(OutputsStruct), _vp,
+                                      _sz, _vp]),
     "m360_finish_backward_workspace_bytes": (_sz, [_i, _i, _i]),
     "m360_prop_finish_backward": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m360_nerf_finish_backward": (_i, [_vp, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,

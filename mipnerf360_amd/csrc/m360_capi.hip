@@ -128,7 +128,7 @@ static TapeLayout tape_for(int B, int N, const m360_model_t *m, int stage) {
 // sample (or take) t -> features -> 4 proposal layers -> head + weights (+ fused resample)
 static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hyper_t *h, int B,
                       const float *t_rand, float *t_hat, float *w_hat, float *t_new, char *ws,
-                      m360_stream_t st, char *tape = nullptr) {
+                      m360_stream_t st, char *tape = nullptr, const float *ext_norm = nullptr) {
     const int N = h->num_samples;
     const FwdLayout L = layout_for(B, n_max(h), m);
     const int vd_ch = m->in_ch - kIpeCh;
@@ -152,18 +152,21 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
             M360_TRY(m360_linear(act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, l == 3 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hp, st));
         return m360_prop_finish_n(act[3], hp, m->prop_head_w, m->prop_head_b, hp, h->density_bias, tt, r->directions, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st);
     }
-    M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, t_hat, st));
+    if (!ext_norm) M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, t_hat, st));  // sharded batch: t_hat is given
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hp = m->hp_pad;
+    if (ext_norm) {  // the caller supplies the (all-reduced) contraction norm; the layers below are shared
+        M360_TRY(m360_encode_features_ext_norm(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
+    }
     if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers, half the bytes)
-        M360_TRY(m360_encode_features_grouped(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        if (!ext_norm) M360_TRY(m360_encode_features_grouped(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(m360_linear_bf16(feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
         M360_TRY(m360_linear_bf16(a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
         M360_TRY(m360_linear_bf16(b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
         M360_TRY(m360_linear_bf16(a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, hp, st));
         return m360_prop_finish_bf16(b, hp, m->prop_head_w, m->prop_head_b, hp, h->density_bias, t_hat, r->directions, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st);
     }
-    M360_TRY(m360_encode_features_grouped(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+    if (!ext_norm) M360_TRY(m360_encode_features_grouped(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(m360_linear(feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
     M360_TRY(m360_linear(a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
     M360_TRY(m360_linear(b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
@@ -173,7 +176,8 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
 
 // resampled t -> features -> 8 NeRF layers -> heads + composite
 static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hyper_t *h, int B,
-                      const float *t1, const m360_outputs_t *out, char *ws, m360_stream_t st, char *tape = nullptr) {
+                      const float *t1, const m360_outputs_t *out, char *ws, m360_stream_t st, char *tape = nullptr,
+                      const float *ext_norm = nullptr) {
     const int N = n_fine(h);  // the NeRF stage runs on the resampled intervals
     const FwdLayout L = layout_for(B, n_max(h), m);
     const int vd_ch = m->in_ch - kIpeCh;
@@ -195,7 +199,8 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
             M360_TRY(m360_linear(act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, l == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hn, st));
         M360_TRY(m360_nerf_finish(act[7], hn, m->nerf_head_w, m->nerf_head_b, hn, h->density_bias, h->rgb_padding, t1, r->directions, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
     } else if (m->mlp_bf16) {
-        M360_TRY(m360_encode_features_grouped(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        if (ext_norm) M360_TRY(m360_encode_features_ext_norm(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
+        else M360_TRY(m360_encode_features_grouped(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(m360_linear_bf16(feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
         for (int layer = 1; layer < 8; ++layer) {
             M360_TRY(m360_linear_bf16(src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
@@ -203,7 +208,8 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         }
         M360_TRY(m360_nerf_finish_bf16(src, hn, m->nerf_head_w, m->nerf_head_b, hn, h->density_bias, h->rgb_padding, t1, r->directions, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
     } else {
-    M360_TRY(m360_encode_features_grouped(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+    if (ext_norm) M360_TRY(m360_encode_features_ext_norm(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
+    else M360_TRY(m360_encode_features_grouped(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(m360_linear(feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
     for (int layer = 1; layer < 8; ++layer) {
         M360_TRY(m360_linear(src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
@@ -442,6 +448,26 @@ int m360_nerf_backward(const m360_rays_t *rays, const m360_model_t *model, const
     float *dz = reinterpret_cast<float *>(ws + L.dz_a), *dz2 = reinterpret_cast<float *>(ws + L.dz_b);
     M360_TRY(m360_nerf_finish_backward(act[7], hn, model->nerf_head_w, model->nerf_head_b, hn, hyper->density_bias, hyper->rgb_padding, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, hyper->white_bkgd, grad_rgb, grad_distance, grad_acc, grad_weights, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, stream));
     return mlp_backward(8, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hn, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_nerf_backward");
+}
+
+/* ------------------------------------------------------------------ one batch sharded over devices */
+
+int m360_prop_forward_from_t(const m360_rays_t *rays, const m360_model_t *model, const m360_hyper_t *hyper, int B,
+                             const float *t_hat, const float *norm, float *w_hat, float *t_new, void *workspace,
+                             size_t workspace_bytes, m360_stream_t stream) {
+    M360_TRY(validate(rays, model, hyper, B, workspace, workspace_bytes, "m360_prop_forward_from_t"));
+    if (B == 0) return M360_OK;
+    if (!t_hat || !norm || !w_hat) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_forward_from_t: t_hat, norm and w_hat are required");
+    return prop_stage(rays, model, hyper, B, nullptr, const_cast<float *>(t_hat), w_hat, t_new, static_cast<char *>(workspace), stream, nullptr, norm);
+}
+
+int m360_nerf_forward_from_t(const m360_rays_t *rays, const m360_model_t *model, const m360_hyper_t *hyper, int B,
+                             const float *t_new, const float *norm, const m360_outputs_t *out, void *workspace,
+                             size_t workspace_bytes, m360_stream_t stream) {
+    M360_TRY(validate(rays, model, hyper, B, workspace, workspace_bytes, "m360_nerf_forward_from_t"));
+    if (B == 0) return M360_OK;
+    if (!t_new || !norm || !out || !out->rgb || !out->distance || !out->acc) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_forward_from_t: t_new, norm, out.rgb/distance/acc are required");
+    return nerf_stage(rays, model, hyper, B, t_new, out, static_cast<char *>(workspace), stream, nullptr, norm);
 }
 
 }  // extern "C"

@@ -12,7 +12,9 @@ constexpr long kSmallGroup = 131072;  // samples: groups up to this size are red
 struct NormScratch {  // layout of the contraction workspace
     double partial[kNormPartials];
     float gnorm;  // Frobenius norm of the un-contracted means (whole batch, = gnorms[0] for a single group)
-    float pad[15];
+    float pad0;
+    double sumsq;  // gnorm^2 before the square root (fp64): what ranks exchange when one batch is sharded
+    float pad[12];
     float gnorms[kMaxNormGroups];  // grouped mode: one norm per chunk of `group_rays` rays
 };
 
@@ -170,9 +172,13 @@ __global__ __launch_bounds__(256) void norm_group_from_t_kernel(
     if (lane_id() == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float g = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+        const double ss = red[0] + red[1] + red[2] + red[3];
+        const float g = (float)sqrt(ss);
         ws->gnorms[blockIdx.x] = g;
-        if (gridDim.x == 1) ws->gnorm = g;
+        if (gridDim.x == 1) {
+            ws->gnorm = g;
+            ws->sumsq = ss;
+        }
     }
 }
 
@@ -195,7 +201,10 @@ __global__ __launch_bounds__(256) void norm_final_kernel(NormScratch *__restrict
     v = wave_sum_d(v);
     if (lane_id() == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) ws->gnorm = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        ws->sumsq = red[0] + red[1] + red[2] + red[3];
+        ws->gnorm = (float)sqrt(ws->sumsq);
+    }
 }
 
 // intern/parameterization.py:64-83 on materialised tensors
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
     const float *__restrict__ t_vals, const float *__restrict__ origins,
     const float *__restrict__ directions, const float *__restrict__ radii,
     const float *__restrict__ vdenc, int vd_ch, int B, int N, const NormScratch *__restrict__ ws,
-    void *__restrict__ feat_out, int ld, int group_rays) {
+    void *__restrict__ feat_out, int ld, int group_rays, const float *__restrict__ ext_norm) {
     extern __shared__ float tile[];  // [kEncThreads][ld + 1]
     const long S = (long)B * N;
     const long s0 = (long)blockIdx.x * kEncThreads;
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
     if (idx < S) {
         const int b = (int)(idx / N), n = (int)(idx % N);
         float m[3], c[9];
-        const float gn = group_rays > 0 ? ws->gnorms[b / group_rays] : ws->gnorm;
+        const float gn = ext_norm ? *ext_norm : (group_rays > 0 ? ws->gnorms[b / group_rays] : ws->gnorm);
         sample_gaussian(t_vals, origins, directions, radii, N, b, n, gn, m, c);
         ipe_sample<true>(m, c, [&](int k, float v) { row[k] = v; });
         for (int k = 0; k < vd_ch; ++k) row[kIpeCh + k] = vdenc[(long)b * vd_ch + k];
@@ -483,7 +492,32 @@ int m360_viewdir_enc(const float *viewdirs, int B, int min_deg, int max_deg, flo
 static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
                                const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
                                int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream,
-                               int group_rays = 0);
+                               int group_rays = 0, const float *ext_norm = nullptr);
+
+// one logical batch sharded over several devices: this shard's sum of squares of the un-contracted
+// means, reduced exactly like the norm the encode stage would compute for these rays alone
+int m360_mean_sumsq(const float *t_vals, const float *directions, const float *radii, int B, int N, double *sumsq,
+                    void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    if (!t_vals || !directions || !radii || !sumsq || B < 0 || N < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mean_sumsq: bad argument");
+    if (!workspace || workspace_bytes < sizeof(NormScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_mean_sumsq: workspace %zu < %zu", workspace_bytes, sizeof(NormScratch));
+    NormScratch *ws = static_cast<NormScratch *>(workspace);
+    if (B == 0) {
+        if (hipMemsetAsync(sumsq, 0, sizeof(double), S_(stream)) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_mean_sumsq: memset failed");
+        return M360_OK;
+    }
+    launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream));
+    if (hipMemcpyAsync(sumsq, &ws->sumsq, sizeof(double), hipMemcpyDeviceToDevice, S_(stream)) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_mean_sumsq: copy failed");
+    return check_launch("mean_sumsq");
+}
+
+// m360_encode_features[_bf16] with the contraction norm supplied by the caller (device float)
+int m360_encode_features_ext_norm(const float *t_vals, const float *origins, const float *directions,
+                                  const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
+                                  int ld_feat, int bf16, const float *norm, void *workspace, size_t workspace_bytes,
+                                  m360_stream_t stream) {
+    if (!norm) return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features_ext_norm: norm is required");
+    return encode_features_any(t_vals, origins, directions, radii, vdenc, vd_ch, B, N, feat, ld_feat, bf16, workspace, workspace_bytes, stream, 0, norm);
+}
 
 int m360_encode_features_grouped(const float *t_vals, const float *origins, const float *directions,
                                  const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
@@ -510,17 +544,17 @@ int m360_encode_features_bf16(const float *t_vals, const float *origins, const f
 static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
                                const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
                                int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream,
-                               int group_rays) {
+                               int group_rays, const float *ext_norm) {
     if (!t_vals || !origins || !directions || !radii || !feat || B < 0 || N < 1 || vd_ch < 0 || (vd_ch > 0 && !vdenc))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: bad argument");
     if (ld_feat % 32 != 0 || ld_feat < kIpeCh + vd_ch) return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: ld_feat=%d must be a multiple of 32 and >= %d", ld_feat, kIpeCh + vd_ch);
     if (!workspace || workspace_bytes < sizeof(NormScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_encode_features: workspace %zu < %zu", workspace_bytes, sizeof(NormScratch));
     if (B == 0) return M360_OK;
     NormScratch *ws = static_cast<NormScratch *>(workspace);
-    launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream), group_rays);
+    if (!ext_norm) launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream), group_rays);
     const size_t lds = (size_t)kEncThreads * (ld_feat + 1) * sizeof(float);
-    if (bf16) hipLaunchKernelGGL(encode_features_kernel<true>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays);
-    else hipLaunchKernelGGL(encode_features_kernel<false>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays);
+    if (bf16) hipLaunchKernelGGL(encode_features_kernel<true>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
+    else hipLaunchKernelGGL(encode_features_kernel<false>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
     return check_launch("encode_features");
 }
 

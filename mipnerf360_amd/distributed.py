@@ -63,6 +63,25 @@ def render_rays_sharded(model, rays, chunks: int = 4096, group=None):
     return full[:, :3].contiguous(), full[:, 3].contiguous(), full[:, 4].contiguous()
 
 
+def forward_sharded(model, rays, group=None):
+    """ONE logical batch split over the ranks (BASELINE configs[4]: 8192 rays over 8 GPUs): every rank
+    passes ITS slice of the rays and gets its slice of (rgb, distance, acc).  The contraction norm of
+    intern/parameterization.py:25 spans the whole batch, so each stage exchanges one fp64 sum of squares
+    (all-reduce, 8 bytes) - the path's only data-path collective; results equal the single-device forward of the
+    concatenated batch up to the summation order of that one scalar.
+
+    `model` provides the four rank-local pieces: sharded_sample(rays) -> t, sharded_sumsq(rays, t) -> float64[1],
+    sharded_prop(rays, t, norm) -> (w, t_new), sharded_nerf(rays, t_new, norm) -> (rgb, distance, acc)
+    (mipNeRF360 implements them on the HIP path)."""
+    t_hat = model.sharded_sample(rays)
+    ss = model.sharded_sumsq(rays, t_hat)
+    dist.all_reduce(ss, op=dist.ReduceOp.SUM, group=group)
+    _, t_new = model.sharded_prop(rays, t_hat, ss.sqrt().float())
+    ss = model.sharded_sumsq(rays, t_new)
+    dist.all_reduce(ss, op=dist.ReduceOp.SUM, group=group)
+    return model.sharded_nerf(rays, t_new, ss.sqrt().float())
+
+
 def render_image_sharded(model, rays, height: int, width: int, chunks: int = 4096, group=None):
     """Multi-GPU counterpart of mipNeRF360.render_image (model.py:254-274): same outputs."""
     from . import ops

@@ -471,6 +471,48 @@ class mipNeRF360(nn.Module):
         rgb, dist, acc, _, _, _ = self.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
         return rgb, dist, acc
 
+    # ------------------------------------------------------------------ one batch sharded over ranks
+    def _sharded_common(self, rays):
+        rstruct, keep, B = _rays_struct(rays)
+        N = self.prop_net.num_samples
+        Nf = self.nerf_net.num_samples_fine or N
+        mstruct = _model_struct(self.prop_net.input_size, self.prop_net._pack(), self.nerf_net._pack())
+        hyper = self.nerf_net._hyper(N, Nf)
+        return rstruct, keep, B, N, Nf, mstruct, hyper, _ws_for(B, max(N, Nf), mstruct, keep[0].device)
+
+    def sharded_sample(self, rays):
+        """this rank's proposal sample positions t_hat[B,N+1] (deterministic sampling; intern/ray.py:99-110)"""
+        return ops.sample_t(rays.near, rays.far, self.prop_net.num_samples)
+
+    def sharded_sumsq(self, rays, t_vals):
+        return ops.mean_sumsq(t_vals, rays.directions, rays.radii)
+
+    def sharded_prop(self, rays, t_hat, norm):
+        """proposal stage with the batch-global contraction norm `norm` (device float[1]) -> (w_hat, t_new)"""
+        rstruct, keep, B, N, Nf, mstruct, hyper, ws = self._sharded_common(rays)
+        t_hat, norm = ops.dev(t_hat, "t_hat"), ops.dev(norm, "norm")
+        w_hat, t_new = torch.empty(B, N, device=t_hat.device), torch.empty(B, Nf + 1, device=t_hat.device)
+        with torch.no_grad():
+            _lib.check(_lib.lib().m360_prop_forward_from_t(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B,
+                                                           t_hat.data_ptr(), norm.data_ptr(), w_hat.data_ptr(),
+                                                           t_new.data_ptr(), ws.data_ptr(), ws.numel(), ops.stream()),
+                       "m360_prop_forward_from_t")
+        return w_hat, t_new
+
+    def sharded_nerf(self, rays, t_new, norm):
+        """NeRF stage with the batch-global contraction norm -> (rgb[B,3], distance[B], acc[B])"""
+        rstruct, keep, B, N, Nf, mstruct, hyper, ws = self._sharded_common(rays)
+        t_new, norm = ops.dev(t_new, "t_new"), ops.dev(norm, "norm")
+        dev = t_new.device
+        outs = dict(rgb=torch.empty(B, 3, device=dev), distance=torch.empty(B, device=dev), acc=torch.empty(B, device=dev))
+        ostruct = _outputs_struct(outs)
+        with torch.no_grad():
+            _lib.check(_lib.lib().m360_nerf_forward_from_t(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B,
+                                                           t_new.data_ptr(), norm.data_ptr(), C.byref(ostruct),
+                                                           ws.data_ptr(), ws.numel(), ops.stream()),
+                       "m360_nerf_forward_from_t")
+        return outs["rgb"], outs["distance"], outs["acc"]
+
     # ------------------------------------------------------------------ chunked frame rendering
     def render_rays(self, rays, chunks=4096):
         """Chunk loop of model.py:261-269 with everything resident on the device: one H2D copy of the

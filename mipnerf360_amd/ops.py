@@ -195,6 +195,16 @@ def linear(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.
     return y
 
 
+def mean_sumsq(t_vals, directions, radii) -> torch.Tensor:
+    """float64[1]: sum of squares of the un-contracted sample means of these rays (a shard of a larger batch)."""
+    t_vals, directions, radii = dev(t_vals, "t_vals"), dev(directions, "directions"), dev(radii, "radii")
+    B, N = t_vals.shape[0], t_vals.shape[1] - 1
+    out = torch.empty(1, dtype=torch.float64, device=t_vals.device)
+    ws = torch.empty(int(_lib.lib().m360_contract_workspace_bytes()), dtype=torch.uint8, device=t_vals.device)
+    _call("m360_mean_sumsq", ptr(t_vals), ptr(directions), ptr(radii), B, N, ptr(out), ptr(ws), ws.numel(), stream())
+    return out
+
+
 def pack_linear_transposed(weight, n_pad: Optional[int] = None, k_pad: Optional[int] = None) -> torch.Tensor:
     """[n_out,k_in] weight -> zero-padded transpose [k_pad,n_pad] (the operand of linear_dgrad)."""
     weight = dev(weight.detach(), "weight")

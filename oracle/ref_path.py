@@ -114,9 +114,10 @@ def lift_to_xyz(d, t_mean, t_var, r_var):
     return mean, cov
 
 
-def contract_global(x: torch.Tensor) -> torch.Tensor:
-    """intern/parameterization.py:23-29 — norm over the whole tensor."""
-    n = torch.linalg.vector_norm(x)
+def contract_global(x: torch.Tensor, norm=None) -> torch.Tensor:
+    """intern/parameterization.py:23-29 — norm over the whole tensor (`norm`: the value to use instead, for a batch
+    that is only a shard of the tensor the reference would see)."""
+    n = torch.linalg.vector_norm(x) if norm is None else norm
     if n <= 1:
         return x
     return (2 - 1 / n) * (x / n)
@@ -134,21 +135,28 @@ def contract_jacobian(y: torch.Tensor) -> torch.Tensor:
     return torch.where(r > 1, J, eye)
 
 
-def gaussian_contract(mean, cov):
+def gaussian_contract(mean, cov, norm=None):
     """intern/parameterization.py:64-83."""
-    mean_c = contract_global(mean)
+    mean_c = contract_global(mean, norm)
     J = contract_jacobian(mean_c)
     cov_c = torch.matmul(torch.matmul(J, cov), J.transpose(-1, -2))
     return mean_c, cov_c
 
 
-def para_rays(t_vals, origins, directions, radii):
+def para_rays(t_vals, origins, directions, radii, norm=None):
     """intern/parameterization.py:119-135 (origins added AFTER contraction)."""
     t0, t1 = t_vals[..., :-1], t_vals[..., 1:]
     t_mean, t_var, r_var = frustum_moments(t0, t1, radii)
     mean, cov = lift_to_xyz(directions, t_mean, t_var, r_var)
-    mean, cov = gaussian_contract(mean, cov)
+    mean, cov = gaussian_contract(mean, cov, norm)
     return mean + origins[..., None, :], cov
+
+
+def mean_sumsq(t_vals, directions, radii) -> torch.Tensor:
+    """fp64 sum of squares of the un-contracted means of a shard: what ranks all-reduce to rebuild the global norm."""
+    t_mean, t_var, r_var = frustum_moments(t_vals[..., :-1], t_vals[..., 1:], radii)
+    mean, _ = lift_to_xyz(directions, t_mean, t_var, r_var)
+    return mean.double().square().sum().reshape(1)
 
 
 # --------------------------------------------------------------------------- encodings
@@ -339,6 +347,26 @@ def nerf_forward(rays: Rays, t_vals, coarse_weights, sd, hp: Hyper, u_rand=None)
     comp_rgb, distance, acc, weights = volumetric_rendering(rgb, density, t_new, rays.directions, hp.white_bkgd)
     s_vals = t_to_s(t_new, rays.near, rays.far)
     return comp_rgb, distance, acc, t_new + EPS_G, weights, s_vals
+
+
+def prop_forward_from_t(rays: Rays, sd, hp: Hyper, t_vals, norm):
+    """proposal stage of a shard: given sample positions and the global norm -> (weights, resampled t)."""
+    mean, cov = para_rays(t_vals, rays.origins, rays.directions, rays.radii, norm)
+    x = encode_inputs(mean, cov, rays.viewdirs, hp.viewdir_min_deg, hp.viewdir_max_deg)
+    density = torch.nn.functional.softplus(prop_mlp(x, sd, hp.mlp_bf16) + hp.density_bias)
+    w = density_to_weight(t_vals, density, rays.directions)
+    return w, resample_t(t_vals, w, hp.resample_padding, None, (hp.num_samples_fine + 1) if hp.num_samples_fine else None)
+
+
+def nerf_forward_from_t(rays: Rays, sd, hp: Hyper, t_new, norm):
+    """NeRF stage of a shard on given resampled positions -> (rgb, distance, acc)."""
+    mean, cov = para_rays(t_new, rays.origins, rays.directions, rays.radii, norm)
+    x = encode_inputs(mean, cov, rays.viewdirs, hp.viewdir_min_deg, hp.viewdir_max_deg)
+    raw_density, raw_rgb = nerf_mlp(x, sd, hp.mlp_bf16)
+    rgb = raw_rgb * (1 + 2 * hp.rgb_padding) - hp.rgb_padding
+    density = torch.nn.functional.softplus(raw_density + hp.density_bias)
+    comp_rgb, distance, acc, _ = volumetric_rendering(rgb, density, t_new, rays.directions, hp.white_bkgd)
+    return comp_rgb, distance, acc
 
 
 def forward(rays: Rays, sd, hp: Hyper):

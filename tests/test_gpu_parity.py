@@ -553,6 +553,7 @@ def test_rccl_path_single_rank_torchrun(dev):
     res = subprocess.run(base + ["29541", os.path.join(root, "tools", "dist_check.py")], env=env, cwd=root,
                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert res.returncode == 0 and "sharded==single: True" in res.stdout, res.stdout[-2000:]
+    assert "forward_sharded max |diff| vs whole-batch forward: 0.00e+00" in res.stdout, res.stdout[-2000:]
     res = subprocess.run(base + ["29542", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                                  "--cpu-rays", "0"], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=600)
@@ -885,3 +886,34 @@ def test_grouped_encode_limits(dev):
     rc = _lib.lib().m360_encode_features_grouped(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, 0, 4096, 128,
                                                  feat.data_ptr(), 64, 0, 2048, ws.data_ptr(), ws.numel(), None)
     assert rc != 0 and b"131072" in _lib.lib().m360_last_error()
+
+
+def test_sharded_batch_global_norm_in_process(dev):
+    """SURVEY.md §8e opt-in: one batch split into shards that share the contraction norm through a sum of per-shard sums
+    of squares (what the all-reduce of distributed.forward_sharded carries).  Emulated in one process: two shards, sums
+    added on the device; result vs the whole-batch forward (1e-6: only the summation order of one scalar differs), and
+    the sharded result must differ from rendering the shards independently (the norm is real)."""
+    sd = synthetic.make_state_dict(64, 128, seed=21)
+    m = build_model(sd, dev, 32, 64, 128, True)
+    r = synthetic.make_rays("garden", 200, seed=22)
+    r["origins"] = r["origins"] * 3.0
+    whole = dev_rays(r, dev)
+    with torch.no_grad():
+        ref = m(whole)
+        indep = [m(type(whole)(*[f[a:b] for f in whole])) for a, b in ((0, 120), (120, 200))]
+    shards = [type(whole)(*[f[a:b] for f in whole]) for a, b in ((0, 120), (120, 200))]
+    t_hat = [m.sharded_sample(s) for s in shards]
+    norm = (m.sharded_sumsq(shards[0], t_hat[0]) + m.sharded_sumsq(shards[1], t_hat[1])).sqrt().float()
+    t_new = [m.sharded_prop(s, t, norm)[1] for s, t in zip(shards, t_hat)]
+    norm2 = (m.sharded_sumsq(shards[0], t_new[0]) + m.sharded_sumsq(shards[1], t_new[1])).sqrt().float()
+    outs = [m.sharded_nerf(s, t, norm2) for s, t in zip(shards, t_new)]
+    for j in range(3):
+        got = torch.cat([o[j] for o in outs], 0)
+        close(got, ref[j], atol=2e-6, rtol=2e-6)
+    assert float((torch.cat([o[0] for o in indep], 0) - ref[0]).abs().max()) > 1e-4
+    # single shard == plain forward, bit for bit (same reduction kernel, same order)
+    ss = m.sharded_sumsq(whole, m.sharded_sample(whole))
+    w1, t1 = m.sharded_prop(whole, m.sharded_sample(whole), ss.sqrt().float())
+    one = m.sharded_nerf(whole, t1, m.sharded_sumsq(whole, t1).sqrt().float())
+    for a, b in zip(one, ref):
+        assert torch.equal(a, b)

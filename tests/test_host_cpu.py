@@ -241,3 +241,55 @@ def test_sharded_render_world2_gloo(tmp_path, n, chunks):
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
     assert res.stdout.count("OK") == 2
+
+
+GLOO_SHARDED_BATCH_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mipnerf360_amd.distributed import forward_sharded
+from mipnerf360_amd import synthetic
+from oracle import ref_path as O   # checker only (tests/): stands in for the HIP stages, which need a GPU
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+per = int(sys.argv[2])
+sd = O.to_torch_state_dict(synthetic.make_state_dict(32, 32, seed=1))
+hp = O.Hyper(num_samples=8)
+
+class OracleStages:
+    def sharded_sample(self, rays):
+        return O.sample_t(rays.near, rays.far, hp.num_samples).expand(rays.origins.shape[0], -1).contiguous()
+    def sharded_sumsq(self, rays, t):
+        return O.mean_sumsq(t, rays.directions, rays.radii)
+    def sharded_prop(self, rays, t, norm):
+        return O.prop_forward_from_t(rays, sd, hp, t, norm)
+    def sharded_nerf(self, rays, t_new, norm):
+        return O.nerf_forward_from_t(rays, sd, hp, t_new, norm)
+
+r = synthetic.make_rays("garden", per * world, seed=2)
+r["origins"] = r["origins"] * 3.0
+whole = O.rays_from_numpy(r)
+mine = O.Rays(*[f[rank * per:(rank + 1) * per] for f in whole])
+with torch.no_grad():
+    got = forward_sharded(OracleStages(), mine)
+    ref = O.forward(whole, sd, hp)
+    alone = O.forward(mine, sd, hp)
+for g, w in zip(got, ref):
+    assert torch.allclose(g, w[rank * per:(rank + 1) * per], atol=2e-6, rtol=2e-6), "sharded batch != whole batch"
+assert float((alone[0] - ref[0][rank * per:(rank + 1) * per]).abs().max()) > 1e-4, "the global norm must matter in this test"
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_sharded_batch_global_norm_world2_gloo(tmp_path):
+    """one batch over two ranks, contraction norm rebuilt from an all-reduce of per-rank sums of squares."""
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_SHARDED_BATCH_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", str(script), ROOT, "24"]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert res.stdout.count("OK") == 2

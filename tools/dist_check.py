@@ -40,6 +40,21 @@ def main():
     single = m.render_image(rays, h, w, chunks=chunks)
     sharded = render_image_sharded(m, rays, h, w, chunks=chunks)
     ok = all(np.array_equal(a, b) for a, b in zip(single, sharded))
+    # one logical batch split over the ranks, global contraction norm rebuilt with an all-reduce
+    from mipnerf360_amd.distributed import forward_sharded
+    world, rank = dist.get_world_size(), dist.get_rank()
+    B = 96 * world
+    rb = synthetic.make_rays("garden", B, seed=33)
+    rb["origins"] = rb["origins"] * 3.0      # means outside the unit ball: the norm matters
+    whole = Rays(*[torch.from_numpy(rb[k]).to(dev) for k in synthetic.RAY_FIELDS])
+    mine = Rays(*[f[rank * 96:(rank + 1) * 96] for f in whole])
+    with torch.no_grad():
+        ref = m(whole)
+    got = forward_sharded(m, mine)
+    err = max(float((g - r[rank * 96:(rank + 1) * 96]).abs().max()) for g, r in zip(got, ref))
+    ok = ok and err <= (0.0 if world == 1 else 2e-6)
+    if rank == 0:
+        print(f"dist_check forward_sharded max |diff| vs whole-batch forward: {err:.2e}")
     flag = torch.tensor([1 if ok else 0], device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if dist.get_rank() == 0:
