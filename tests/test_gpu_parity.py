@@ -917,3 +917,16 @@ def test_sharded_batch_global_norm_in_process(dev):
     one = m.sharded_nerf(whole, t1, m.sharded_sumsq(whole, t1).sqrt().float())
     for a, b in zip(one, ref):
         assert torch.equal(a, b)
+
+
+def test_training_descends_end_to_end(dev):
+    """tools/train_demo.py: the reference's loop body on the mirrors fits a student to a teacher's pixels; the
+    reconstruction PSNR must rise substantially within a few dozen AdamW steps (forward, losses, backward, update all on
+    the HIP path)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import train_demo
+    out = train_demo.run(steps=40, rays_n=512, samples=16, hp=32, hn=64, lr=3e-3, log_every=39)
+    first, last = out["trajectory"][0]["psnr"], out["trajectory"][-1]["psnr"]
+    assert np.isfinite(last) and last > first + 3.0, out
