@@ -365,7 +365,7 @@ size_t m360_linear_wgrad_workspace_bytes(long M, int n_pad, int k_pad) {
     int ntiles, nsplit;
     long total, per;
     wgrad_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
-    return up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)) + up256_((size_t)kBiasSlices * n_pad * sizeof(float));
+    return up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)) + up256_((size_t)tn::kMaxWorkgroups * n_pad * sizeof(float));
 }
 
 int m360_linear_wgrad(const float *dz, int ldz, const float *x, int ldx, long M, int n_pad, int k_pad, float *grad_w,
@@ -383,14 +383,11 @@ int m360_linear_wgrad(const float *dz, int ldz, const float *x, int ldx, long M,
     float *bias_part = reinterpret_cast<float *>(static_cast<char *>(workspace) + up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)));
     const int prof = prof_begin(st, M, n_pad, k_pad);
     if (nsplit > 0)
-        hipLaunchKernelGGL(tn::linear_tn_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn::kThreads), 0, st, dz, ldz, x, ldx, n_pad, k_pad, partial, (k_pad + tn::BT - 1) / tn::BT, ntiles, nsplit, total, per);
+        hipLaunchKernelGGL(tn::linear_tn_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn::kThreads), 0, st, dz, ldz, x, ldx, n_pad, k_pad, partial, (k_pad + tn::BT - 1) / tn::BT, ntiles, nsplit, total, per, grad_b ? bias_part : nullptr);
     prof_end(prof, st);
     const long count4 = (long)n_pad * k_pad / 4;
     hipLaunchKernelGGL(tn::tn_reduce_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, partial, nsplit, n_pad, k_pad, dz, ldz, x, ldx, total * tn::BKM, M, grad_w);
-    if (grad_b) {
-        const int rc = launch_colsum(dz, M, n_pad, ldz, bias_part, kBiasSlices, grad_b, st);
-        if (rc != M360_OK) return rc;
-    }
+    if (grad_b) hipLaunchKernelGGL(tn::tn_bias_reduce_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, bias_part, nsplit, n_pad, dz, ldz, total * tn::BKM, M, grad_b);
     return check_launch("linear_wgrad");
 }
 

@@ -36,7 +36,7 @@ constexpr int kMaxWorkgroups = 256;        // tiles x splits target (one per CU)
 __global__ __launch_bounds__(kThreads, 1) void linear_tn_kernel(
     const float *__restrict__ dZ, int ldz, const float *__restrict__ X, int ldx, int Np, int Kp,
     float *__restrict__ partial /*[nsplit][Np][Kp]*/, int tiles_k, int ntiles, int nsplit, long total_steps,
-    long steps_per_split) {
+    long steps_per_split, float *__restrict__ bias_partial /*[nsplit][Np] or nullptr*/) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * kBufFloats];  // 128 KiB
 
     const int tid = threadIdx.x;
@@ -55,6 +55,11 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_kernel(
     const long s_begin = (long)split * steps_per_split;
     long s_end = s_begin + steps_per_split;
     if (s_end > total_steps) s_end = total_steps;
+
+    // bias gradient (column sums of dZ) for free: the workgroups of the first tile column (k0 == 0) also add up the
+    // dZ tile they stage in LDS anyway, thread t = column n0 + t, two rows per MFMA pair (ds_read_b32 in the MFMA shadow)
+    const bool do_bias = bias_partial != nullptr && k0 == 0;
+    float bsum = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
 
     f32x16 acc[4][4];
 #pragma unroll
@@ -84,9 +89,11 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_kernel(
         const unsigned b_base = lds0 + 4u * (kTileFloats + h * BT + wn * 128 + 4 * l31);
 
         f32x4 a0, b0, a1, b1;  // fragment double buffer: (a0, b0) even pairs, (a1, b1) odd pairs
+        const unsigned c_base = lds0 + 4u * tid;
 
 #define TN_DS128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
-#define TN_WAIT(FA, FB) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA), "+v"(FB)::"memory")
+#define TN_DS32(dst, addr, imm) asm volatile("ds_read_b32 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#define TN_WAIT(FA, FB, CX, CY) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA), "+v"(FB), "+v"(CX), "+v"(CY)::"memory")
 #define TN_SB() __builtin_amdgcn_sched_barrier(0)
 #define TN_MFMA16(FA, FB)                                                                         \
     do {                                                                                          \
@@ -94,15 +101,20 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_kernel(
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i], FB[j], acc[i][j], 0, 0, 0);   \
     } while (0)
 // pair p of the K-step: wait for its fragment, issue the reads of pair p+1 (byte offset imm = (p+1) * 2048), optionally
-// one DMA row pair of the next K-step, then 16 MFMAs that cover the latency of both
-#define TN_PAIR(FA, FB, NA, NB, imm, DMAQ)               \
+// one DMA row pair of the next K-step, then 16 MFMAs that cover the latency of both.  Every thread also loads rows
+// 2p, 2p+1 of ITS column of the dZ tile (LX, LY; byte offsets r0, r1) and consumes the two values (CX, CY) loaded by the
+// previous pair: the bias gradient, unconditionally (no branch in the MFMA stream; only k0 == 0 workgroups store it).
+#define TN_PAIR(FA, FB, NA, NB, imm, DMAQ, CX, CY, LX, LY, r0, r1) \
     do {                                                 \
-        TN_WAIT(FA, FB);                                 \
+        TN_WAIT(FA, FB, CX, CY);                         \
         TN_SB();                                         \
         TN_DS128(NA, a_cur, imm);                        \
         TN_DS128(NB, b_cur, imm);                        \
-        if (DMAQ >= 0 && has_next) issue_dma(buf ^ 1, DMAQ); \
+        TN_DS32(LX, c_cur, r0);                          \
+        TN_DS32(LY, c_cur, r1);                          \
+        if (DMAQ >= 0) issue_dma(buf ^ 1, DMAQ);         \
         TN_SB();                                         \
+        bsum += CX + CY;                                 \
         TN_MFMA16(FA, FB);                               \
         TN_SB();                                         \
     } while (0)
@@ -118,48 +130,60 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_kernel(
         TN_SB();
 
         for (long s = s_begin; s < s_end; ++s) {
-            const bool has_next = s + 1 < s_end;
-            ga += (long)BKM * ldz;  // the DMA issued during this step loads step s + 1
-            gb += (long)BKM * ldx;
+            // the DMA issued during this step loads step s + 1; after the last step it harmlessly re-loads the last rows
+            // (nobody reads them): no branch inside the MFMA stream
+            const long adv = (s + 1 < s_end) ? BKM : 0;
+            ga += adv * ldz;
+            gb += adv * ldx;
             const unsigned a_cur = a_base + (buf ? 4u * kBufFloats : 0u), b_cur = b_base + (buf ? 4u * kBufFloats : 0u);
             const unsigned a_nxt = a_base + (buf ? 0u : 4u * kBufFloats), b_nxt = b_base + (buf ? 0u : 4u * kBufFloats);
+            const unsigned c_cur = c_base + (buf ? 4u * kBufFloats : 0u);
             TN_SB();
-            TN_PAIR(a0, b0, a1, b1, 2048, 0);
-            TN_PAIR(a1, b1, a0, b0, 4096, 1);
-            TN_PAIR(a0, b0, a1, b1, 6144, 2);
-            TN_PAIR(a1, b1, a0, b0, 8192, 3);
-            TN_PAIR(a0, b0, a1, b1, 10240, 4);
-            TN_PAIR(a1, b1, a0, b0, 12288, 5);
-            TN_PAIR(a0, b0, a1, b1, 14336, 6);
-            TN_PAIR(a1, b1, a0, b0, 16384, 7);
-            TN_PAIR(a0, b0, a1, b1, 18432, -1);
-            TN_PAIR(a1, b1, a0, b0, 20480, -1);
-            TN_PAIR(a0, b0, a1, b1, 22528, -1);
-            TN_PAIR(a1, b1, a0, b0, 24576, -1);
-            TN_PAIR(a0, b0, a1, b1, 26624, -1);
-            TN_PAIR(a1, b1, a0, b0, 28672, -1);
-            TN_PAIR(a0, b0, a1, b1, 30720, -1);
+            TN_PAIR(a0, b0, a1, b1, 2048, 0, c2, c3, c0, c1, 0, 1024);
+            TN_PAIR(a1, b1, a0, b0, 4096, 1, c0, c1, c2, c3, 2048, 3072);
+            TN_PAIR(a0, b0, a1, b1, 6144, 2, c2, c3, c0, c1, 4096, 5120);
+            TN_PAIR(a1, b1, a0, b0, 8192, 3, c0, c1, c2, c3, 6144, 7168);
+            TN_PAIR(a0, b0, a1, b1, 10240, 4, c2, c3, c0, c1, 8192, 9216);
+            TN_PAIR(a1, b1, a0, b0, 12288, 5, c0, c1, c2, c3, 10240, 11264);
+            TN_PAIR(a0, b0, a1, b1, 14336, 6, c2, c3, c0, c1, 12288, 13312);
+            TN_PAIR(a1, b1, a0, b0, 16384, 7, c0, c1, c2, c3, 14336, 15360);
+            TN_PAIR(a0, b0, a1, b1, 18432, -1, c2, c3, c0, c1, 16384, 17408);
+            TN_PAIR(a1, b1, a0, b0, 20480, -1, c0, c1, c2, c3, 18432, 19456);
+            TN_PAIR(a0, b0, a1, b1, 22528, -1, c2, c3, c0, c1, 20480, 21504);
+            TN_PAIR(a1, b1, a0, b0, 24576, -1, c0, c1, c2, c3, 22528, 23552);
+            TN_PAIR(a0, b0, a1, b1, 26624, -1, c2, c3, c0, c1, 24576, 25600);
+            TN_PAIR(a1, b1, a0, b0, 28672, -1, c0, c1, c2, c3, 26624, 27648);
+            TN_PAIR(a0, b0, a1, b1, 30720, -1, c2, c3, c0, c1, 28672, 29696);
             // pair 15: every read of `buf` by this wave has landed and its DMA of the next step too -> barrier, then
-            // the first reads of the next step go out before the last 16 MFMAs
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(a1), "+v"(b1)::"memory");
+            // the first reads of the next step go out before the last 16 MFMAs (bias: rows 30, 31 are read BEFORE the
+            // barrier, they belong to the buffer that the next step's DMA overwrites)
+            TN_DS32(c2, c_cur, 30720);
+            TN_DS32(c3, c_cur, 31744);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(a1), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)::"memory");
             TN_SB();
             TN_DS128(a0, a_nxt, 0);
             TN_DS128(b0, b_nxt, 0);
             TN_SB();
+            bsum += c0 + c1;
+            c0 = 0.0f;
+            c1 = 0.0f;
             TN_MFMA16(a1, b1);
             TN_SB();
             buf ^= 1;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(b0)::"memory");  // drain the speculative last reads
+        bsum += c2 + c3;  // rows 30, 31 of the last step
 #undef TN_PAIR
 #undef TN_MFMA16
 #undef TN_SB
 #undef TN_WAIT
+#undef TN_DS32
 #undef TN_DS128
     }
 
     // ---- epilogue: block (q, q2) register r of lane (l31, h) is output row n0 + wm*128 + 4*i + q with
     // i = (r&3) + 8(r>>2) + 4h, column k0 + wn*128 + 4*l31 + q2: the four q2 blocks form one 16-byte store
+    if (do_bias && n0 + tid < Np) bias_partial[(long)split * Np + n0 + tid] = bsum;
     float *__restrict__ P = partial + (long)split * Np * Kp;
     const int col = k0 + wn * 128 + 4 * l31;
     if (col < Kp) {
@@ -207,6 +231,18 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float *__restrict_
         s.w += g * x.w;
     }
     *reinterpret_cast<float4 *>(grad_w + idx4 * 4) = s;
+}
+
+// grad_b[n] = sum_s bias_partial[s][n] (s ascending) + the tail rows
+__global__ __launch_bounds__(256) void tn_bias_reduce_kernel(const float *__restrict__ bias_partial, int nsplit, int Np,
+                                                             const float *__restrict__ dZ, int ldz, long m_begin, long M,
+                                                             float *__restrict__ grad_b) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Np) return;
+    float s = 0.0f;
+    for (int p = 0; p < nsplit; ++p) s += bias_partial[(long)p * Np + n];
+    for (long m = m_begin; m < M; ++m) s += dZ[m * ldz + n];
+    grad_b[n] = s;
 }
 
 // Deterministic column sums of a row-major [R, C] matrix (bias gradients, head-weight gradients): grid (ceil(C/64),

@@ -53,6 +53,8 @@ def main():
     flops = 2.0 * M * 1024 * 1024
     ms = timed(lambda: ops.linear_wgrad(dz, x), a.iters)
     out["wgrad_ms"], out["wgrad_tflops"] = round(ms, 3), round(flops / ms / 1e9, 1)
+    ms = timed(lambda: ops.linear_wgrad(dz, x, want_bias=False), a.iters)
+    out["wgrad_nobias_ms"] = round(ms, 3)
     ms = timed(lambda: ops.linear_dgrad(dz, wt, x, out=dx), a.iters)
     out["dgrad_ms"], out["dgrad_tflops"] = round(ms, 3), round(flops / ms / 1e9, 1)
     del dz, x, dx
