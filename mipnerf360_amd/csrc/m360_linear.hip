@@ -16,6 +16,7 @@
 #include "m360_common.cuh"
 #include "m360_linear_persist.cuh"
 #include "m360_linear_bf16.cuh"
+#include "m360_linear_bf16_pp.cuh"
 #include "m360_linear_tn.cuh"
 
 namespace m360 {
@@ -237,6 +238,7 @@ int launch_colsum(const float *in, long R, int C, int ld, float *scratch, int sl
 using namespace m360;
 
 static int g_linear_variant = 2;  // 1 = one workgroup per tile (register staging), 2 = persistent + LDS-DMA
+static int g_bf16_variant = 2;    // bf16: 1 = persistent, one wave per SIMD; 2 = 8-wave ping-pong (m360_linear_bf16_pp.cuh)
 
 static int cu_count() {
     static int cached = -1;
@@ -254,6 +256,10 @@ static int cu_count() {
 extern "C" {
 
 int m360_debug_set_linear_variant(int variant) {
+    if (variant >= 11 && variant <= 13) {  // 13 = 12 with cycle stamps (ReLU only)  // 11 / 12: select the bf16 kernel (A/B switch, see the header)
+        g_bf16_variant = variant - 10;
+        return M360_OK;
+    }
     if (variant < 1 || variant > 3) return fail(M360_ERR_INVALID_ARGUMENT, "m360_debug_set_linear_variant: %d", variant);
     g_linear_variant = variant;
     return M360_OK;
@@ -435,11 +441,24 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
         const int cus = cu_count();
         if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear_bf16: no HIP device");
         const long nt = (M_full / pbf16::BM) * (n_pad / pbf16::BN);
+        const bool pp_ok = k_pad >= 2 * pp16::BK && n_pad <= pp16::kMaxBias;  // else the one-wave-per-SIMD kernel
+        if (g_bf16_variant == 3 && pp_ok) {  // diagnostic: ping-pong kernel with s_memtime stamps
+            dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
+            hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt);
+        } else if (g_bf16_variant == 2 && pp_ok) {  // 8-wave ping-pong kernel, persistent
+            dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
+            switch (act) {
+                case M360_ACT_NONE: hipLaunchKernelGGL(pp16::linear_bf16_pp_kernel<M360_ACT_NONE>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+                case M360_ACT_RELU: hipLaunchKernelGGL(pp16::linear_bf16_pp_kernel<M360_ACT_RELU>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+                default: hipLaunchKernelGGL(pp16::linear_bf16_pp_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+            }
+        } else {
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pbf16::kThreads);
         switch (act) {
             case M360_ACT_NONE: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
             case M360_ACT_RELU: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
             default: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
+        }
         }
     }
     if (M > M_full) {

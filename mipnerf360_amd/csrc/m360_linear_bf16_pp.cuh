@@ -1,0 +1,337 @@
+// Second bf16 linear kernel (opt-in reduced-precision MLP, BASELINE configs[4]): 8 waves = two per SIMD in "ping-pong".
+//
+// Why a second structure: with ONE wave per SIMD (m360_linear_bf16.cuh) every LDS-DMA issue (~100-185 cycles while the
+// phase also carries ds_reads) is exposed against only 2048 MFMA cycles per K-step, and the kernel stops at ~36 % of the
+// bf16 peak.  Here the 256 x 256 tile is shared by 8 waves (2 along M x 4 along N, wave tile 128 x 64 = 8 x 4 blocks of
+// v_mfma_f32_16x16x32_bf16 -> 128 accumulator registers).  A K-step (64 bf16) is 4 phases; every phase is
+//       [ds_read the operand sub-tile | stage one 16 KiB unit of the NEXT K-step by LDS-DMA | s_waitcnt vmcnt(4)]
+//       s_barrier   [s_waitcnt lgkmcnt(0) | 16 MFMAs = one 64 x 32 quadrant over the whole K-step]   s_barrier
+// and the waves of the second M half run ONE barrier behind the first, so on every SIMD one wave computes while its
+// partner loads.  vmcnt is counted (never 0): a unit (= what one phase reads) is staged >= 3 phases before its first read, retired by the
+// wait one phase before that read, and re-staged >= 4 phases after its last read.
+// Operands are swapped (A := weight rows, B := activation rows), so a lane's 4 accumulator registers are 4 consecutive
+// output columns of one row; in addition MFMA row i = 4a + b of N-block jb is weight row 16a + 4jb + b of the wave's 64,
+// so the four N-blocks of a lane are 16 CONSECUTIVE columns: bias + activation + bf16 pack + two 16-byte stores per
+// row, whole 128-byte lines per store instruction, no LDS transposition in the epilogue.
+// Persistent: workgroups walk tiles with stride gridDim.x; the last K-step of a tile stages the first K-step of the next.
+// LDS rows are 128 B with a source-side XOR swizzle (chunk c of row r in slot c ^ f(r)); f = (r>>1)&7 for activation
+// rows and f = 2((r>>4)&3) + ((r>>1)&1) for weight rows (their 16-lane read groups touch rows 16a + b): either way a
+// 16-lane ds_read_b128 group covers 16 distinct 16-byte slots.
+#pragma once
+#include "m360_common.cuh"
+#include "m360_linear_persist.cuh"  // diagnostic stamp buffer
+
+namespace m360 {
+namespace pp16 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int kThreads = 512;
+constexpr int kHalfBytes = 128 * 128;       // half-tile: 128 rows x 128 B
+constexpr int kTileBytes = 4 * kHalfBytes;  // A0 A1 B0 B1 of one K-step
+constexpr int kMaxBias = 4096;              // widest layer this kernel takes (bias is served from LDS)
+
+template <int ACT>
+__device__ __forceinline__ float act_fn(float v) {
+    if (ACT == M360_ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == M360_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    return v;
+}
+
+template <int ACT, bool STAMP = false>
+__global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
+    const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias,
+    int Np, int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * kTileBytes + kMaxBias * 4];  // 128 KiB + the bias vector
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int ksteps = Kp / BK;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+#define PP_STAMP(var)                                                                           \
+    do {                                                                                        \
+        if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");  \
+    } while (0)
+    PP_STAMP(ts0);
+
+    // XCD-aware tile id (speed only): ids sharing id % 8 take a contiguous range, N-tiles of one M-tile adjacent
+    auto tile_coords = [&](int id, long &tm0, int &tn0) __attribute__((always_inline)) {
+        const int full = (ntiles / 8) * 8;
+        int lin = id;
+        if (id < full) lin = (id % 8) * (full / 8) + id / 8;
+        tm0 = (long)(lin / tiles_n) * BM;
+        tn0 = (lin % tiles_n) * BN;
+    };
+    int tile_id = blockIdx.x;
+    if (tile_id >= ntiles) return;
+    const int G = gridDim.x;
+    long m0;
+    int n0;
+    tile_coords(tile_id, m0, n0);
+
+    // ---- staging units = what one phase reads (all waves together), 128 rows x 128 B = 16 KiB each:
+    //   unit 0 "XA": activation rows {0..63, 128..191}    (first 64 rows of each M half, read in phase 0)
+    //   unit 1 "WA": weight rows with (row & 8) == 0       (N blocks 0, 1 of every wave,  read in phase 0)
+    //   unit 2 "WB": weight rows with (row & 8) != 0       (N blocks 2, 3,                read in phase 1)
+    //   unit 3 "XB": activation rows {64..127, 192..255}   (last 64 rows of each M half,  read in phase 2)
+    // wave w stages unit-rows [16w, 16w+16) as two instructions of 8 rows x 128 B; rows keep their natural place in LDS
+    // per-lane byte offsets inside a tile (the same for every tile) + two wave-uniform tile base pointers
+    unsigned src_off[4][2];
+    int dst_off[4][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int ub = 16 * wave + 8 * q;  // first unit-row of this instruction (wave-uniform, multiple of 8)
+        const int row0[4] = {ub < 64 ? ub : ub + 64, (ub >> 3) * 16, (ub >> 3) * 16 + 8, ub < 64 ? ub + 64 : ub + 128};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = row0[u] + (lane >> 3);
+            const bool is_x = (u == 0 || u == 3);
+            const int f = is_x ? ((r >> 1) & 7) : (2 * ((r >> 4) & 3) + ((r >> 1) & 1));
+            const int chunk = (lane & 7) ^ f;
+            src_off[u][q] = (unsigned)(r * (is_x ? ldx : Kp) + 8 * chunk) * 2u;
+            dst_off[u][q] = (is_x ? 0 : 2 * kHalfBytes) + row0[u] * 128;
+        }
+    }
+    const char *xbase = reinterpret_cast<const char *>(X + m0 * ldx);
+    const char *wbase = reinterpret_cast<const char *>(W + (long)n0 * Kp);
+    auto stage = [&](int buf, int unit, int k0) __attribute__((always_inline)) {
+        char *base = smem + buf * kTileBytes;
+        const char *g = ((unit == 0 || unit == 3) ? xbase : wbase) + 2 * k0;
+        __builtin_amdgcn_global_load_lds(g + src_off[unit][0], (lds_ptr_t)(base + dst_off[unit][0]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(g + src_off[unit][1], (lds_ptr_t)(base + dst_off[unit][1]), 16, 0, 0);
+    };
+
+    // ---- fragment addresses: lane (row l15 of a 16-row block, k-chunk g4), K-substep s: chunk 4s + g4
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    unsigned x_addr[2], w_addr[2];  // buffer 0; + kTileBytes for buffer 1
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        x_addr[s] = lds0 + wm * kHalfBytes + l15 * 128 + (((4 * s + g4) ^ (l15 >> 1)) * 16);  // + ib * 2048
+        // weight row of MFMA row l15 = 4a + b in N-block jb: 16a + 4jb + b;  f = 2a + (b >> 1) does not depend on jb
+        const int wr = 16 * (l15 >> 2) + (l15 & 3);
+        const int fw_ = 2 * (l15 >> 2) + ((l15 >> 1) & 1);
+        w_addr[s] = lds0 + 2 * kHalfBytes + wn * 64 * 128 + wr * 128 + (((4 * s + g4) ^ fw_) * 16);  // + jb * 512
+    }
+
+    f32x4 acc[8][4];
+    bf16x8 fx[4][2];   // activation rows of the current M quadrant half (4 blocks x 2 K-substeps)
+    bf16x8 fw[4][2];   // weight rows: blocks 0,1 = N half 0, blocks 2,3 = N half 1
+
+#define PP_DS128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#define PP_BAR() asm volatile("s_barrier" ::: "memory")
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+#define PP_READ_X(boff, IMM0, IMM1, IMM2, IMM3)            \
+    do {                                                   \
+        const unsigned x0_ = x_addr[0] + (boff), x1_ = x_addr[1] + (boff); \
+        PP_DS128(fx[0][0], x0_, IMM0);                     \
+        PP_DS128(fx[0][1], x1_, IMM0);                     \
+        PP_DS128(fx[1][0], x0_, IMM1);                     \
+        PP_DS128(fx[1][1], x1_, IMM1);                     \
+        PP_DS128(fx[2][0], x0_, IMM2);                     \
+        PP_DS128(fx[2][1], x1_, IMM2);                     \
+        PP_DS128(fx[3][0], x0_, IMM3);                     \
+        PP_DS128(fx[3][1], x1_, IMM3);                     \
+    } while (0)
+#define PP_READ_W(J0, boff, IMM0, IMM1)                    \
+    do {                                                   \
+        const unsigned w0_ = w_addr[0] + (boff), w1_ = w_addr[1] + (boff); \
+        PP_DS128(fw[J0][0], w0_, IMM0);                    \
+        PP_DS128(fw[J0][1], w1_, IMM0);                    \
+        PP_DS128(fw[(J0) + 1][0], w0_, IMM1);              \
+        PP_DS128(fw[(J0) + 1][1], w1_, IMM1);              \
+    } while (0)
+// the fragments a phase has just loaded are in/out operands of its wait, so no use can be scheduled above it (and
+// only those: naming dead fragments would keep them alive and push the accumulators out of the register file)
+#define PP_WAIT_X()                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                            \
+                 : "+v"(fx[0][0]), "+v"(fx[0][1]), "+v"(fx[1][0]), "+v"(fx[1][1]), "+v"(fx[2][0]), "+v"(fx[2][1]), \
+                   "+v"(fx[3][0]), "+v"(fx[3][1])::"memory")
+#define PP_WAIT_W(J0)                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fw[J0][0]), "+v"(fw[J0][1]), "+v"(fw[(J0) + 1][0]), "+v"(fw[(J0) + 1][1])::"memory")
+// one quadrant: M blocks I0..I0+3 (fragments fx[0..3]) x N blocks J0, J0+1 (fragments fw[J0], fw[J0+1]) x 2 K-substeps
+#define PP_MFMA16(I0, J0)                                                                                        \
+    do {                                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                           \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)              \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+                acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[(J0) + j][s], fx[i][s],     \
+                                                                                  acc[(I0) + i][(J0) + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                           \
+    } while (0)
+#define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// Deferred epilogue of the PREVIOUS tile, one quadrant: bias + activation + bf16 pack, one 16-byte store per row (the
+// N-blocks J0, J0+1 of a lane are 8 consecutive columns), then the accumulators restart from zero.  Runs in the load
+// half of a phase, i.e. while the partner wave on this SIMD is in its MFMA half.
+#define PP_STORE_Q(I0, J0)                                                                              \
+    do {                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
+            const f32x4 v_ = acc[(I0) + i][(J0)], w_ = acc[(I0) + i][(J0) + 1];                         \
+            bf16x8 o_;                                                                                  \
+            o_[0] = (__bf16)act_fn<ACT>(v_[0] + bq[(J0)][0]);                                           \
+            o_[1] = (__bf16)act_fn<ACT>(v_[1] + bq[(J0)][1]);                                           \
+            o_[2] = (__bf16)act_fn<ACT>(v_[2] + bq[(J0)][2]);                                           \
+            o_[3] = (__bf16)act_fn<ACT>(v_[3] + bq[(J0)][3]);                                           \
+            o_[4] = (__bf16)act_fn<ACT>(w_[0] + bq[(J0) + 1][0]);                                       \
+            o_[5] = (__bf16)act_fn<ACT>(w_[1] + bq[(J0) + 1][1]);                                       \
+            o_[6] = (__bf16)act_fn<ACT>(w_[2] + bq[(J0) + 1][2]);                                       \
+            o_[7] = (__bf16)act_fn<ACT>(w_[3] + bq[(J0) + 1][3]);                                       \
+            *reinterpret_cast<bf16x8 *>(Yp + (long)(((I0) + i) * 16) * ldy_t + ((J0) ? 8 : 0)) = o_;    \
+            acc[(I0) + i][(J0)] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                                      \
+            acc[(I0) + i][(J0) + 1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                                  \
+        }                                                                                               \
+        asm volatile("" ::: "memory");                                                                  \
+        PP_SB();                                                                                        \
+    } while (0)
+// One K-step = 4 phases.  ST: also store the previous tile (4 stores per phase, issued BEFORE the phase's reads - while
+// the fragment registers they fill are still free - and before its 2 LDS-DMA instructions).  V0..V3: the counted vmcnt of each phase = number of vector-memory operations issued after the DMA pair
+// of two phases ago, which must have landed before the next phase reads it.
+#define PP_KSTEP(ST)                                        \
+    do {                                                    \
+        PP_SB();                                            \
+        if (ST) PP_STORE_Q(0, 0);                           \
+        PP_READ_W(0, boff, 0, 512);                         \
+        PP_READ_X(boff, 0, 2048, 4096, 6144);               \
+        stage(nbuf, 0, k_next);                             \
+        if (ST) PP_VMCNT(8); else PP_VMCNT(4);              \
+        PP_BAR();                                           \
+        PP_WAIT_W(0);                                       \
+        PP_WAIT_X();                                        \
+        PP_SB();                                            \
+        PP_MFMA16(0, 0);                                    \
+        PP_SB();                                            \
+        PP_BAR();                                           \
+        if (ST) PP_STORE_Q(0, 2);                           \
+        PP_READ_W(2, boff, 1024, 1536);                     \
+        stage(nbuf, 1, k_next);                             \
+        if (ST) PP_VMCNT(12); else PP_VMCNT(4);             \
+        PP_BAR();                                           \
+        PP_WAIT_W(2);                                       \
+        PP_SB();                                            \
+        PP_MFMA16(0, 2);                                    \
+        PP_SB();                                            \
+        PP_BAR();                                           \
+        if (ST) PP_STORE_Q(4, 2);                           \
+        PP_READ_X(boff, 8192, 10240, 12288, 14336);         \
+        stage(nbuf, 2, k_next);                             \
+        if (ST) PP_VMCNT(12); else PP_VMCNT(4);             \
+        PP_BAR();                                           \
+        PP_WAIT_X();                                        \
+        PP_SB();                                            \
+        PP_MFMA16(4, 2);                                    \
+        PP_SB();                                            \
+        PP_BAR();                                           \
+        if (ST) PP_STORE_Q(4, 0);                           \
+        stage(nbuf, 3, k_next);                             \
+        if (ST) PP_VMCNT(12); else PP_VMCNT(4);             \
+        PP_BAR();                                           \
+        PP_SB();                                            \
+        PP_MFMA16(4, 0);                                    \
+        PP_SB();                                            \
+        PP_BAR();                                           \
+    } while (0)
+
+    // ---- bias -> LDS once (before any LDS-DMA is in flight)
+    float *const bias_lds = reinterpret_cast<float *>(smem + 2 * kTileBytes);
+    for (int i = tid; i < Np; i += kThreads) bias_lds[i] = bias[i];
+    __syncthreads();
+    const unsigned bias_addr = lds0 + 2 * kTileBytes + 4u * (wn * 64 + 16 * g4);  // + 4 * n0 of the tile, + 16 * jb
+
+    // ---- prologue: the four units of K-step 0 in the order they are first read
+    stage(0, 0, 0);
+    stage(0, 1, 0);
+    stage(0, 2, 0);
+    stage(0, 3, 0);
+    PP_VMCNT(4);  // XA and WA of this wave's rows have landed
+    PP_BAR();
+    if (wm == 1) PP_BAR();  // the second M half runs one barrier behind the first
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 bq[4];            // bias of the 16 columns this lane stores, for the tile being written
+    __bf16 *Yp = Y;         // this lane's first output element of that tile
+    int ldy_t = ldy;
+    int buf = 0;
+    PP_STAMP(ts1);
+    bool have_prev = false;
+    for (; tile_id < ntiles; tile_id += G) {
+        tile_coords(tile_id, m0, n0);
+        for (int kt = 0; kt < ksteps; ++kt) {
+            // what this K-step stages: the next K-step of this tile, else K-step 0 of this workgroup's next tile, else
+            // (harmlessly) K-step 0 of the current tile again - nobody reads it
+            int k_next = (kt + 1) * BK;
+            if (kt + 1 == ksteps) {
+                k_next = 0;
+                if (tile_id + G < ntiles) {
+                    long nm0;
+                    int nn0;
+                    tile_coords(tile_id + G, nm0, nn0);
+                    xbase = reinterpret_cast<const char *>(X + nm0 * ldx);
+                    wbase = reinterpret_cast<const char *>(W + (long)nn0 * Kp);
+                }
+            }
+            const unsigned boff = buf ? (unsigned)kTileBytes : 0u;
+            const int nbuf = buf ^ 1;
+            // K-step 0 of every tile but the first also carries the stores of the tile just finished (wave-uniform
+            // branches in the load halves only).  The K-step after it could allow 8 outstanding operations in its
+            // phase 0; 4 merely also waits for the last four stores, issued a whole phase earlier.
+            const bool st = have_prev && kt == 0;
+            PP_KSTEP(st);
+            buf ^= 1;
+        }
+        PP_STAMP(ts2);
+        // the finished tile is written during the first K-step of the next one (or below, if it is the last): its bias
+        {
+            const unsigned ba = bias_addr + 4u * n0;
+            PP_DS128(bq[0], ba, 0);
+            PP_DS128(bq[1], ba, 16);
+            PP_DS128(bq[2], ba, 32);
+            PP_DS128(bq[3], ba, 48);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3])::"memory");
+            Yp = Y + (m0 + wm * 128 + l15) * ldy_t + n0 + wn * 64 + 16 * g4;
+            asm volatile("" : "+s"(ldy_t));
+            have_prev = true;
+        }
+    }
+    // ---- the last tile of this workgroup: plain epilogue (no barrier: the groups keep their one-barrier stagger)
+    PP_STORE_Q(0, 0);
+    PP_STORE_Q(0, 2);
+    PP_STORE_Q(4, 2);
+    PP_STORE_Q(4, 0);
+    if (wm == 0) PP_BAR();  // equalise the barrier count of the two groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STAMP) {  // diagnostic build only: [0] prologue, [1] main loop, [2] epilogue (cycles, wave 0 of the first 256 workgroups)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_STAMP(ts3);
+        if (tid == 0 && blockIdx.x < 256) {
+            persist::g_stamps[blockIdx.x * 8 + 0] = ts1 - ts0;
+            persist::g_stamps[blockIdx.x * 8 + 1] = ts2 - ts1;
+            persist::g_stamps[blockIdx.x * 8 + 2] = ts3 - ts2;
+            persist::g_stamps[blockIdx.x * 8 + 3] = ts0;
+            persist::g_stamps[blockIdx.x * 8 + 4] = ts3;
+        }
+    }
+#undef PP_STAMP
+#undef PP_DS128
+#undef PP_BAR
+#undef PP_SB
+#undef PP_READ_X
+#undef PP_READ_W
+#undef PP_WAIT_X
+#undef PP_WAIT_W
+#undef PP_MFMA16
+#undef PP_VMCNT
+#undef PP_STORE_Q
+#undef PP_KSTEP
+}
+
+}  // namespace pp16
+}  // namespace m360

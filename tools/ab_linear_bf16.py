@@ -20,8 +20,11 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--act", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=1, help="1 = persistent one-wave-per-SIMD kernel, 2 = 8-wave ping-pong")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    from mipnerf360_amd import _lib
+    _lib.check(_lib.lib().m360_debug_set_linear_variant(10 + args.variant), "variant")
     g = torch.Generator(device=dev).manual_seed(0)
     x = (torch.rand(args.m, args.k, device=dev, generator=g) * 2 - 1).bfloat16()
     w = (torch.rand(args.n, args.k, device=dev, generator=g) * 2 - 1) * (6.0 / args.k) ** 0.5
@@ -46,6 +49,15 @@ def main():
         times.append(e0.elapsed_time(e1) / args.iters)
     t = sorted(times)
     med = t[len(t) // 2]
+    if args.variant == 3:
+        import ctypes
+        import numpy as np
+        buf = (ctypes.c_ulonglong * (256 * 8))()
+        _lib.check(_lib.lib().m360_debug_read_stamps(buf, 256 * 8), "stamps")
+        st = np.array(buf[:], dtype=np.float64).reshape(256, 8)
+        print("stamps (median cycles over the first 256 workgroups): prologue %.0f, main loop %.0f (%.0f per K-step), epilogue %.0f; "
+              "workgroup lifetime %.0f" % (np.median(st[:, 0]), np.median(st[:, 1]), np.median(st[:, 1]) / (args.k / 64),
+                                           np.median(st[:, 2]), np.median(st[:, 4] - st[:, 3])))
     print(f"bf16 linear {args.m}x{args.n}x{args.k}: median {med:.3f} ms = {flops / med / 1e9:.1f} TFLOP/s "
           f"({100 * flops / med / 1e9 / 2500:.1f}% of 2.5 PF), best {t[0]:.3f} ms")
 
