@@ -58,7 +58,8 @@ def test_packed_export_matches_padded_weights(tmp_path, dtype):
     from mipnerf360_amd.intern.ray import Rays
     from oracle import ref_path as O
     r = synthetic.make_rays("lego", 40, seed=2)
-    rgb, dist, acc = m(Rays(*[torch.from_numpy(r[k]).to(dev) for k in synthetic.RAY_FIELDS]))
+    with torch.no_grad():
+        rgb, dist, acc = m(Rays(*[torch.from_numpy(r[k]).to(dev) for k in synthetic.RAY_FIELDS]))
     o = O.forward(O.rays_from_numpy(r), O.to_torch_state_dict(sd), O.Hyper(num_samples=16, mlp_bf16=(dtype == "bf16")))
     tol = 6e-3 if dtype == "bf16" else 1e-4
     assert float((rgb.cpu() - o[0]).abs().max()) <= tol and float((acc.cpu() - o[2]).abs().max()) <= tol
