@@ -312,13 +312,17 @@ def test_to8b_matches_numpy(dev):
 
 
 @pytest.mark.parametrize("kind,B,n,hp,hn,wb", [("garden", 96, 128, 256, 1024, False), ("lego", 130, 64, 64, 96, True),
-                                               ("garden", 1, 32, 32, 32, False), ("lego", 1024, 128, 256, 1024, True)])
+                                               ("garden", 1, 32, 32, 32, False), ("lego", 1024, 128, 256, 1024, True),
+                                               ("garden", 40, 256, 64, 128, False),   # BASELINE configs[4]: 256 samples
+                                               ("lego", 9, 1, 32, 32, True), ("garden", 5, 3, 32, 64, False),
+                                               ("lego", 3, 1000, 32, 32, False)])     # one sample; odd; very long rays
 def test_forward_vs_oracle(dev, kind, B, n, hp, hn, wb):
     from oracle import ref_path as O
     sd = synthetic.make_state_dict(hp, hn, seed=5)
     r = synthetic.make_rays(kind, B, seed=8)
     m = build_model(sd, dev, n, hp, hn, wb)
-    rgb, dist, acc = m(dev_rays(r, dev))
+    with torch.no_grad():
+        rgb, dist, acc = m(dev_rays(r, dev))
     o = O.forward(O.rays_from_numpy(r), O.to_torch_state_dict(sd), O.Hyper(num_samples=n, white_bkgd=wb))
     close_render(rgb, dist, acc, *o)
 
@@ -930,3 +934,13 @@ def test_training_descends_end_to_end(dev):
     out = train_demo.run(steps=40, rays_n=512, samples=16, hp=32, hn=64, lr=3e-3, log_every=39)
     first, last = out["trajectory"][0]["psnr"], out["trajectory"][-1]["psnr"]
     assert np.isfinite(last) and last > first + 3.0, out
+
+
+def test_sample_count_beyond_lds_is_a_loud_error(dev):
+    """The per-ray kernels keep one ray's samples in LDS (64 KiB): a sample count that does not fit is refused with an
+    error that says so, never truncated."""
+    sd = synthetic.make_state_dict(32, 32, seed=5)
+    m = build_model(sd, dev, 20000, 32, 32, False)
+    with pytest.raises(RuntimeError, match="LDS"):
+        with torch.no_grad():
+            m(dev_rays(synthetic.make_rays("garden", 2, seed=8), dev))
