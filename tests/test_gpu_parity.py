@@ -944,3 +944,50 @@ def test_sample_count_beyond_lds_is_a_loud_error(dev):
     with pytest.raises(RuntimeError, match="LDS"):
         with torch.no_grad():
             m(dev_rays(synthetic.make_rays("garden", 2, seed=8), dev))
+
+
+def test_c_abi_without_python(dev, tmp_path):
+    """examples/forward_c_abi.cpp: a plain C++ program (HIP runtime + include/m360.h, no Python / torch) packs weights and
+    runs m360_forward; its dump must match the Python mirror fed the same weights and rays, bit for bit (same library,
+    same kernels, same launch sequence)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe, dump = str(tmp_path / "forward_c_abi"), str(tmp_path / "dump.bin")
+    libdir = os.path.join(root, "mipnerf360_amd")
+    res = subprocess.run([hipcc, "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "forward_c_abi.cpp"),
+                          "-L", libdir, "-lm360", f"-Wl,-rpath,{libdir}", "-o", exe], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    res = subprocess.run([exe, dump, "200", "32", "64", "128"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         timeout=300)
+    assert res.returncode == 0 and "forward_c_abi:" in res.stdout, res.stdout[-3000:]
+    raw = np.fromfile(dump, dtype=np.uint8)
+    pos = 0
+
+    def take(count, dtype=np.float32):
+        nonlocal pos
+        a = raw[pos:pos + 4 * count].view(dtype).copy()
+        pos += 4 * count
+        return a
+
+    B, N, hp, hn, nl = (int(v) for v in take(5, np.int32))
+    names = [f"prop_net.model.{i}" for i in (0, 2, 4, 6, 8)] + [f"nerf_net.model.{i}" for i in range(0, 16, 2)] + \
+            ["nerf_net.final_density.0", "nerf_net.final_color.0"]
+    assert nl == len(names)
+    sd = {}
+    for name in names:
+        n_out, k_in = (int(v) for v in take(2, np.int32))
+        sd[name + ".weight"] = take(n_out * k_in).reshape(n_out, k_in)
+        sd[name + ".bias"] = take(n_out)
+    rays = {"origins": take(3 * B).reshape(B, 3), "directions": take(3 * B).reshape(B, 3), "viewdirs": take(3 * B).reshape(B, 3),
+            "radii": take(B).reshape(B, 1), "near": take(B).reshape(B, 1), "far": take(B).reshape(B, 1)}
+    c_rgb, c_dist, c_acc = take(3 * B).reshape(B, 3), take(B), take(B)
+    assert pos == raw.size
+    m = build_model(sd, dev, N, hp, hn, False)
+    with torch.no_grad():
+        rgb, dist, acc = m(dev_rays(rays, dev))
+    assert np.array_equal(H(rgb), c_rgb) and np.array_equal(H(dist), c_dist) and np.array_equal(H(acc), c_acc)
+    assert np.isfinite(c_rgb).all() and c_rgb.std() > 1e-3
