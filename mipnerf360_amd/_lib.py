@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libm360.so")
+LIB_PATH = os.environ.get("M360_LIB") or os.path.join(_HERE, "libm360.so")  # M360_LIB: A/B a diagnostic build
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 M360_OK = 0

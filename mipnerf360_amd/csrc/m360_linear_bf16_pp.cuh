@@ -101,7 +101,11 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     }
     const char *xbase = reinterpret_cast<const char *>(X + m0 * ldx);
     const char *wbase = reinterpret_cast<const char *>(W + (long)n0 * Kp);
+#ifndef PP_ABLATE
+#define PP_ABLATE 0  // diagnostics only (timing experiments, results are wrong when != 0): 1 = no LDS-DMA, 2 = no ds_reads
+#endif
     auto stage = [&](int buf, int unit, int k0) __attribute__((always_inline)) {
+        if (PP_ABLATE & 1) return;
         char *base = smem + buf * kTileBytes;
         const char *g = ((unit == 0 || unit == 3) ? xbase : wbase) + 2 * k0;
         __builtin_amdgcn_global_load_lds(g + src_off[unit][0], (lds_ptr_t)(base + dst_off[unit][0]), 16, 0, 0);
@@ -124,7 +128,11 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     bf16x8 fx[4][2];   // activation rows of the current M quadrant half (4 blocks x 2 K-substeps)
     bf16x8 fw[4][2];   // weight rows: blocks 0,1 = N half 0, blocks 2,3 = N half 1
 
+#if PP_ABLATE & 2
+#define PP_DS128(dst, addr, imm) asm volatile("; no read %0 %1" : "=v"(dst) : "v"(addr))
+#else
 #define PP_DS128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#endif
 #define PP_BAR() asm volatile("s_barrier" ::: "memory")
 #define PP_SB() __builtin_amdgcn_sched_barrier(0)
 #define PP_READ_X(boff, IMM0, IMM1, IMM2, IMM3)            \
