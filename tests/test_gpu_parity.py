@@ -461,7 +461,9 @@ def test_unequal_sample_counts_extension(dev, np_, nf):
 
 
 @pytest.mark.parametrize("M,n,k,act", [(256 * 5, 256, 64, 1), (256 * 9 + 77, 1024, 1024, 1), (300, 96, 128, 2),
-                                        (256 * 40, 768, 256, 0), (1, 64, 64, 2), (256 * 70, 1024, 64, 1)])
+                                        (256 * 40, 768, 256, 0), (1, 64, 64, 2), (256 * 70, 1024, 64, 1),
+                                        (256 * 301, 256, 128, 1),      # ping-pong kernel: 2 K-steps, 301 tiles on 256 CUs
+                                        (256 * 130, 512, 192, 2)])     # odd K-step count: buffer parity across tiles
 def test_linear_bf16_against_fp64(dev, M, n, k, act):
     """Opt-in bf16 MLP kernel (persistent LDS-DMA path + generic ragged path): bf16 inputs, fp32 accumulation,
     bf16 output.  Reference = exact product of the SAME bf16-rounded operands in fp64, then rounded to bf16:
