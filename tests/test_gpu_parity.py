@@ -993,3 +993,29 @@ def test_c_abi_without_python(dev, tmp_path):
         rgb, dist, acc = m(dev_rays(rays, dev))
     assert np.array_equal(H(rgb), c_rgb) and np.array_equal(H(dist), c_dist) and np.array_equal(H(acc), c_acc)
     assert np.isfinite(c_rgb).all() and c_rgb.std() > 1e-3
+
+
+def test_bf16_pingpong_kernel_race_screen(dev):
+    """The ping-pong bf16 kernel orders LDS-DMA, reads and re-staging by counted vmcnt + barriers only; a misplaced read
+    would show as rare wrong tiles.  Screen: 60 back-to-back launches at the BASELINE layer shape (and a small odd one)
+    must all be bit-identical, and agree with the one-wave-per-SIMD kernel to bf16 rounding."""
+    from mipnerf360_amd import _lib, ops
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for M, n, k in ((4096 * 128, 1024, 1024), (256 * 37, 768, 192)):
+        x = (torch.rand(M, k, generator=gen) * 2 - 1).bfloat16().to(dev)
+        w = ((torch.rand(n, k, generator=gen) * 2 - 1) * (6.0 / k) ** 0.5).to(dev)
+        b = (torch.rand(n, generator=gen) - 0.5).to(dev)
+        wp, bp = ops.pack_linear_bf16(w, b, n, k)
+        try:
+            _lib.check(_lib.lib().m360_debug_set_linear_variant(11), "variant")
+            ref = ops.linear_bf16(x, wp, bp, _lib.ACT_RELU)
+            _lib.check(_lib.lib().m360_debug_set_linear_variant(12), "variant")
+            first = ops.linear_bf16(x, wp, bp, _lib.ACT_RELU)
+            out = torch.empty_like(first)
+            for _ in range(60):
+                ops.linear_bf16(x, wp, bp, _lib.ACT_RELU, out=out)
+                assert torch.equal(out, first)
+        finally:
+            _lib.check(_lib.lib().m360_debug_set_linear_variant(12), "variant")
+        diff = (first.float() - ref.float()).abs()
+        assert float(diff.max()) <= 2.0 ** -6 * float(ref.float().abs().max())   # a couple of bf16 ulps (accumulation order differs)
