@@ -936,6 +936,10 @@ def test_training_descends_end_to_end(dev):
     out = train_demo.run(steps=40, rays_n=512, samples=16, hp=32, hn=64, lr=3e-3, log_every=39)
     first, last = out["trajectory"][0]["psnr"], out["trajectory"][-1]["psnr"]
     assert np.isfinite(last) and last > first + 3.0, out
+    # train.py's default: randomized sampling in both stages (uniforms drawn on the device, consumed by the kernels)
+    out = train_demo.run(steps=40, rays_n=512, samples=16, hp=32, hn=64, lr=3e-3, log_every=39, randomized=True)
+    first, last = out["trajectory"][0]["psnr"], out["trajectory"][-1]["psnr"]
+    assert np.isfinite(last) and last > first + 3.0, out
 
 
 def test_sample_count_beyond_lds_is_a_loud_error(dev):
@@ -1019,3 +1023,33 @@ def test_bf16_pingpong_kernel_race_screen(dev):
             _lib.check(_lib.lib().m360_debug_set_linear_variant(12), "variant")
         diff = (first.float() - ref.float()).abs()
         assert float(diff.max()) <= 2.0 ** -6 * float(ref.float().abs().max())   # a couple of bf16 ulps (accumulation order differs)
+
+
+def test_train_gradients_with_unequal_sample_counts(dev):
+    """The num_samples_fine extension ("64+128" style) through the training path: tape and backward are sized by the
+    NeRF stage's own sample count; gradients vs autograd through the oracle's same extension."""
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf
+    from mipnerf360_amd.model import mipNeRF360
+    from oracle import ref_path as O
+    B, n, nf = 21, 12, 20
+    sd_np = synthetic.make_state_dict(32, 64, seed=31)
+    r = synthetic.make_rays("lego", B, seed=32)
+    pixels = np.random.Generator(np.random.PCG64(33)).uniform(0, 1, (B, 3)).astype(np.float32)
+    m = mipNeRF360(randomized=False, num_samples=n, hidden_proposal=32, hidden_nerf=64, white_bkgd=True, device=dev,
+                   num_samples_fine=nf)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    m.train()
+    rays = dev_rays(r, dev)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+    rgb, _, _, _, fw, sv = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    assert fw.shape == (B, nf) and sv.shape == (B, nf + 1)
+    ln, _ = Loss_nerf(rgb, D(pixels, dev))
+    (ln + 0.01 * Loss_dist(sv, fw)).backward()
+    hp = O.Hyper(num_samples=n, white_bkgd=True, num_samples_fine=nf)
+    cpu_rays = O.Rays(*[torch.from_numpy(r[f]) for f in synthetic.RAY_FIELDS])
+    o_ln, _, o_grads = O.nerf_step_gradients(cpu_rays, {k: torch.from_numpy(v) for k, v in sd_np.items()}, hp, torch.from_numpy(pixels))
+    close(ln, o_ln, rtol=5e-5)
+    for name, p in m.named_parameters():
+        if name.startswith("nerf_net"):
+            _grad_close(p.grad, o_grads[name], name)

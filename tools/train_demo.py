@@ -24,11 +24,13 @@ from mipnerf360_amd.intern.ray import Rays  # noqa: E402
 from mipnerf360_amd.model import mipNeRF360  # noqa: E402
 
 
-def run(steps=150, rays_n=1024, samples=32, hp=64, hn=128, lr=2e-3, dist_weight=0.01, seed=0, device="cuda:0", log_every=25):
+def run(steps=150, rays_n=1024, samples=32, hp=64, hn=128, lr=2e-3, dist_weight=0.01, seed=0, device="cuda:0", log_every=25,
+        randomized=False):
     dev = torch.device(device)
     torch.manual_seed(seed)
     kw = dict(randomized=False, num_samples=samples, hidden_proposal=hp, hidden_nerf=hn, white_bkgd=False, device=dev)
-    teacher, student = mipNeRF360(**kw), mipNeRF360(**kw)
+    teacher = mipNeRF360(**kw)
+    student = mipNeRF360(**dict(kw, randomized=randomized))   # train.py's default is randomized=True (config.py:14)
     teacher.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(hp, hn, seed=100 + seed).items()})
     student.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(hp, hn, seed=200 + seed).items()})
     r = synthetic.make_rays("garden", rays_n, seed=300 + seed)
@@ -57,8 +59,8 @@ def run(steps=150, rays_n=1024, samples=32, hp=64, hn=128, lr=2e-3, dist_weight=
         loss_all.backward()
         opt.step()
         if step % log_every == 0 or step == steps - 1:
-            traj.append({"step": step, "psnr": round(float(psnr), 3), "loss_prop": round(float(loss_prop), 4),
-                         "loss_dist": round(float(loss_dist), 5)})
+            traj.append({"step": step, "psnr": round(float(psnr), 3), "loss_prop": round(float(loss_prop.detach()), 4),
+                         "loss_dist": round(float(loss_dist.detach()), 5)})
     torch.cuda.synchronize()
     return {"steps": steps, "rays": rays_n, "samples": samples, "hidden": [hp, hn], "seconds": round(time.perf_counter() - t0, 2),
             "trajectory": traj}
@@ -71,8 +73,9 @@ def main():
     ap.add_argument("--samples", type=int, default=32)
     ap.add_argument("--hidden", type=int, nargs=2, default=[64, 128])
     ap.add_argument("--lr", type=float, default=2e-3)
+    ap.add_argument("--randomized", action="store_true", help="stratified jitter in both stages, as train.py does by default")
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.rays, a.samples, a.hidden[0], a.hidden[1], a.lr)))
+    print(json.dumps(run(a.steps, a.rays, a.samples, a.hidden[0], a.hidden[1], a.lr, randomized=a.randomized)))
 
 
 if __name__ == "__main__":
