@@ -477,7 +477,9 @@ int m360_prof_reset(void);
 int m360_prof_read(int i, float *ms, long *M, int *n_pad, int *k_pad);
 /* A/B switch between the two m360_linear kernels (1 = workgroup per tile, register staging;
  * 2 = persistent workgroups + LDS-DMA staging, the default;
- * 3 = variant 2 instrumented with s_memtime stamps, diagnostics only).  Results are bit-identical.
+ * 3 = variant 2 instrumented with s_memtime stamps, diagnostics only;
+ * 4 = 8-wave ping-pong kernel, an experiment that measured 4 % SLOWER than variant 2).
+ * Results are bit-identical across 1, 2 and 4.
  * 11 / 12 / 13 select the bf16 kernel instead: 11 = one wave per SIMD (m360_linear_bf16.cuh), 12 = 8-wave ping-pong
  * (m360_linear_bf16_pp.cuh, the default), 13 = 12 with cycle stamps. */
 int m360_debug_set_linear_variant(int variant);

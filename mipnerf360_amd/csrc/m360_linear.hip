@@ -15,6 +15,7 @@
 //   Workgroup ids are remapped so the 4 N-tiles of one M-tile run on the same XCD (shared L2).
 #include "m360_common.cuh"
 #include "m360_linear_persist.cuh"
+#include "m360_linear_pp.cuh"
 #include "m360_linear_bf16.cuh"
 #include "m360_linear_bf16_pp.cuh"
 #include "m360_linear_tn.cuh"
@@ -260,7 +261,7 @@ int m360_debug_set_linear_variant(int variant) {
         g_bf16_variant = variant - 10;
         return M360_OK;
     }
-    if (variant < 1 || variant > 3) return fail(M360_ERR_INVALID_ARGUMENT, "m360_debug_set_linear_variant: %d", variant);
+    if (variant < 1 || variant > 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_debug_set_linear_variant: %d", variant);
     g_linear_variant = variant;
     return M360_OK;
 }
@@ -306,7 +307,14 @@ static int launch_linear(const float *x, long M, int ldx, const float *w_packed,
         const long nt = (M_full / persist::BM) * (n_pad / persist::BN);
         const int ntiles = (int)nt;
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(persist::kThreads);
-        if (g_linear_variant == 3) {  // diagnostic build with cycle stamps (ReLU only)
+        if (g_linear_variant == 4 && act != M360_ACT_RELU_MASK && n_pad <= pp32::kMaxBias) {  // 8-wave ping-pong kernel
+            dim3 grid8((unsigned)(nt < cus ? nt : cus)), block8(pp32::kThreads);
+            switch (act) {
+                case M360_ACT_NONE: hipLaunchKernelGGL(pp32::linear_f32_pp_kernel<M360_ACT_NONE>, grid8, block8, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / pp32::BN, ntiles); break;
+                case M360_ACT_RELU: hipLaunchKernelGGL(pp32::linear_f32_pp_kernel<M360_ACT_RELU>, grid8, block8, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / pp32::BN, ntiles); break;
+                default: hipLaunchKernelGGL(pp32::linear_f32_pp_kernel<M360_ACT_SIGMOID>, grid8, block8, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / pp32::BN, ntiles); break;
+            }
+        } else if (g_linear_variant == 3) {  // diagnostic build with cycle stamps (ReLU only)
             hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU, true>), grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles);
         } else {
             switch (act) {

@@ -226,6 +226,10 @@ def test_linear_kernel_variants_bit_identical(dev, M, n, k, act):
         for _ in range(3):  # repeated launches: a race would not reproduce identically
             y2 = ops.linear(x, w, b, act)
             assert torch.equal(y1, y2)
+        _lib.check(lib.m360_debug_set_linear_variant(4), "variant")   # 8-wave ping-pong experiment: same k-order
+        for _ in range(6):
+            y4 = ops.linear(x, w, b, act)
+            assert torch.equal(y1, y4)
     finally:
         lib.m360_debug_set_linear_variant(2)
 
