@@ -12,11 +12,24 @@ import sys
 __version__ = "0.1.0"
 
 
-def install_dropin() -> None:
+def install_dropin(reference_root=None) -> None:
     """Make `import model` / `from intern.ray import ...` (the reference's module names, as used
-    by its train.py / test.py / video.py) resolve to this package."""
+    by its train.py / test.py / video.py) resolve to this package.
+
+    `reference_root`: the reference checkout.  Its scripts also import host-side helpers that are outside the hot path
+    (`intern.scheduler.lr_decay`, the camera paths of `intern.pose`, `intern.utils.normalize / to_float`); given the root,
+    those keep resolving to the reference's own files: `intern.__path__` is extended by `<root>/intern` (modules this
+    package has no mirror for) and names missing from a mirror fall through lazily (mipnerf360_amd/intern/_fallback.py)."""
+    import os
     from . import intern, model
-    from .intern import distillation, encoding, loss, parameterization, pose, ray, regularization, utils
+    from .intern import _fallback, distillation, encoding, loss, parameterization, pose, ray, regularization, utils
+    if reference_root is not None:
+        ref_intern = os.path.join(os.path.abspath(reference_root), "intern")
+        if not os.path.isdir(ref_intern):
+            raise FileNotFoundError(f"{ref_intern} is not a directory")
+        _fallback.set_reference_root(reference_root)
+        if ref_intern not in intern.__path__:
+            intern.__path__.append(ref_intern)
     sys.modules["model"] = model
     sys.modules["intern"] = intern
     sys.modules["intern.ray"] = ray

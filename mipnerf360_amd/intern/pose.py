@@ -51,3 +51,10 @@ def visualize_depth(depth, acc=None, near=None, far=None, ignore_frac=0, curve_f
     near = None if near is None else float(np.asarray(near).reshape(-1)[0])
     far = None if far is None else float(np.asarray(far).reshape(-1)[0])
     return _wrap(ops.visualize_depth, depth, acc, near=near, far=far, modulus=float(modulus))
+
+
+# everything else of the reference's intern/pose.py (host-side helpers outside the hot path) falls through to the
+# reference's own file when install_dropin(reference_root=...) was given one
+from . import _fallback  # noqa: E402
+
+__getattr__ = _fallback.make_getattr("pose", __name__)

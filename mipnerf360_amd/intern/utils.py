@@ -16,3 +16,10 @@ def to8b(img):
         t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).cuda()
         return ops.to8b(t).cpu().numpy()
     return ops.to8b(img)
+
+
+# everything else of the reference's intern/utils.py (host-side helpers outside the hot path) falls through to the
+# reference's own file when install_dropin(reference_root=...) was given one
+from . import _fallback  # noqa: E402
+
+__getattr__ = _fallback.make_getattr("utils", __name__)

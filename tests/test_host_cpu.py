@@ -293,3 +293,38 @@ def test_sharded_batch_global_norm_world2_gloo(tmp_path):
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
     assert res.stdout.count("OK") == 2
+
+
+def test_dropin_falls_through_to_reference_helpers(tmp_path):
+    """install_dropin(reference_root=...): modules without a mirror (intern.scheduler) and names missing from a mirror
+    (camera paths of intern.pose, intern.utils.normalize) resolve to the reference's own files; mirrored names win.
+    Uses a stand-in tree (the real reference is not available where the GPU tests run)."""
+    ref = tmp_path / "ref"
+    (ref / "intern").mkdir(parents=True)
+    (ref / "intern" / "__init__.py").write_text("")
+    (ref / "intern" / "scheduler.py").write_text("def lr_decay(*a, **k):\n    return 'reference lr_decay'\n")
+    (ref / "intern" / "pose.py").write_text("def generate_spiral_cam_to_world(*a):\n    return 'reference spiral'\n"
+                                            "def visualize_depth(*a):\n    return 'reference visualize_depth'\n")
+    (ref / "intern" / "utils.py").write_text("def normalize(x):\n    return 'reference normalize'\n")
+    code = f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import mipnerf360_amd
+mipnerf360_amd.install_dropin(reference_root={str(ref)!r})
+from intern.scheduler import lr_decay
+from intern.pose import generate_spiral_cam_to_world, visualize_depth
+from intern.utils import normalize, to8b
+from intern.ray import Rays, convert_to_ndc, namedtuple_map
+from intern.loss import Loss_prop, Loss_nerf, Loss_dist, mse_to_psnr
+from model import mipNeRF360
+assert lr_decay() == 'reference lr_decay' and generate_spiral_cam_to_world() == 'reference spiral'
+assert normalize(1) == 'reference normalize'
+assert visualize_depth.__module__.startswith('mipnerf360_amd') and to8b.__module__.startswith('mipnerf360_amd')
+assert mipNeRF360.__module__ == 'mipnerf360_amd.model'
+try:
+    from intern.pose import no_such_name
+except ImportError:
+    print('OK')
+"""
+    res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-3000:]
