@@ -150,6 +150,9 @@ class _TrainCtx:
         self.versions = [p._version for p in module.parameters()]
 
     def backward(self, grad_args):
+        if self.tape is None:
+            raise RuntimeError("trying to backward through a mipnerf360_amd stage a second time: its tape (saved activations) "
+                               "was freed by the first backward")
         module, packed, dev = self.module, self.packed, self.tape.device
         if [p._version for p in module.parameters()] != self.versions:
             raise RuntimeError("a parameter was modified in place between the forward and its backward")

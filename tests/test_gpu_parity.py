@@ -860,6 +860,10 @@ def test_training_bf16_is_forward_only_and_inplace_update_is_caught(golden, dev)
         model.prop_net.model[0].weight.add_(1.0)
     with pytest.raises(RuntimeError, match="modified in place"):
         w_hat.sum().backward()
+    t2, w2 = model.prop_net.forward(rays)
+    w2.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        w2.sum().backward()
     m16 = mipNeRF360(num_samples=16, hidden_proposal=64, hidden_nerf=64, device=dev, mlp_dtype="bf16").train()
     t16, w16 = m16.prop_net.forward(rays)      # the bf16 MLP is forward-only: no graph, so backward is an error
     assert not w16.requires_grad
