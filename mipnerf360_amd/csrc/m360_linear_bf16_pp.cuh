@@ -99,17 +99,22 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
             dst_off[u][q] = (is_x ? 0 : 2 * kHalfBytes) + row0[u] * 128;
         }
     }
-    const char *xbase = reinterpret_cast<const char *>(X + m0 * ldx);
-    const char *wbase = reinterpret_cast<const char *>(W + (long)n0 * Kp);
+    // tile bases live in two buffer descriptors (SGPRs); the K offset is the instruction's scalar offset
+    __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(X + m0 * ldx), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)n0 * Kp), 0, 0x7fffffff, 0x00020000);
 #ifndef PP_ABLATE
 #define PP_ABLATE 0  // diagnostics only (timing experiments, results are wrong when != 0): 1 = no LDS-DMA, 2 = no ds_reads
 #endif
     auto stage = [&](int buf, int unit, int k0) __attribute__((always_inline)) {
         if (PP_ABLATE & 1) return;
         char *base = smem + buf * kTileBytes;
-        const char *g = ((unit == 0 || unit == 3) ? xbase : wbase) + 2 * k0;
-        __builtin_amdgcn_global_load_lds(g + src_off[unit][0], (lds_ptr_t)(base + dst_off[unit][0]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(g + src_off[unit][1], (lds_ptr_t)(base + dst_off[unit][1]), 16, 0, 0);
+        if (unit == 0 || unit == 3) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(base + dst_off[unit][0]), 16, src_off[unit][0], 2 * k0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(base + dst_off[unit][1]), 16, src_off[unit][1], 2 * k0, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(base + dst_off[unit][0]), 16, src_off[unit][0], 2 * k0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(base + dst_off[unit][1]), 16, src_off[unit][1], 2 * k0, 0, 0);
+        }
     };
 
     // ---- fragment addresses: lane (row l15 of a 16-row block, k-chunk g4), K-substep s: chunk 4s + g4
@@ -282,8 +287,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
                     long nm0;
                     int nn0;
                     tile_coords(tile_id + G, nm0, nn0);
-                    xbase = reinterpret_cast<const char *>(X + nm0 * ldx);
-                    wbase = reinterpret_cast<const char *>(W + (long)nn0 * Kp);
+                    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(X + nm0 * ldx), 0, 0x7fffffff, 0x00020000);
+                    rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)nn0 * Kp), 0, 0x7fffffff, 0x00020000);
                 }
             }
             const unsigned boff = buf ? (unsigned)kTileBytes : 0u;

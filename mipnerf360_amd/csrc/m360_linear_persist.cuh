@@ -77,6 +77,33 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     // The kernel only ever sees FULL 256 x 256 tiles (M and Np multiples of 256): the host sends ragged
     // rows / columns to the first-generation kernel, which is bit-identical.
     const int st_r = wave * 64 + (lane >> 3);  // row of DMA instruction q = st_r + 8 q
+#ifndef M360_PERSIST_BUFFER_DMA
+#define M360_PERSIST_BUFFER_DMA 1  // 1: buffer_load ... lds (descriptor + 32-bit lane offset + scalar K offset); 0: global_load_lds
+#endif
+#if M360_PERSIST_BUFFER_DMA
+    // per-lane byte offsets inside a tile (tile-independent); the tile base lives in two buffer descriptors (SGPRs) and
+    // the K offset is the instruction's scalar offset: no vector address arithmetic per K-step or per tile
+    unsigned a_voff[kDma], b_voff[kDma];
+#pragma unroll
+    for (int q = 0; q < kDma; ++q) {
+        const int r = st_r + 8 * q;
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        a_voff[q] = (unsigned)(r * ldx + 4 * chunk) * 4u;
+        b_voff[q] = (unsigned)(r * Kp + 4 * chunk) * 4u;
+    }
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+    auto set_load_tile = [&](long m0, int n0) M360_INL {  // full tiles only: no row clamping needed
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + m0 * ldx), 0, 0x7fffffff, 0x00020000);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W + (long)n0 * Kp), 0, 0x7fffffff, 0x00020000);
+    };
+    float *const dma_dst = smem + st_r * 0 + wave * 64 * BK;  // + buf * kBufFloats + q * 8 * BK
+    // which: 1 = A rows, 2 = B rows, 3 = both (row-block q of this wave's 64-row slice)
+    auto issue_dma = [&](int buf, int k0, int q, int which) M360_INL {
+        float *dstA = dma_dst + buf * kBufFloats + q * 8 * BK;
+        if (which & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)dstA, 16, a_voff[q], 4 * k0, 0, 0);
+        if (which & 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(dstA + kTileFloats), 16, b_voff[q], 4 * k0, 0, 0);
+    };
+#else
     const float *ga[kDma];
     const float *gb[kDma];
     auto set_load_tile = [&](long m0, int n0) M360_INL {  // full tiles only: no row clamping needed
@@ -95,6 +122,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         if (which & 1) __builtin_amdgcn_global_load_lds(ga[q] + k0, (lds_ptr_t)dstA, 16, 0, 0);
         if (which & 2) __builtin_amdgcn_global_load_lds(gb[q] + k0, (lds_ptr_t)(dstA + kTileFloats), 16, 0, 0);
     };
+#endif
 
     // ---- operand reads: lane (l31, h), K-group g reads chunk (2g+h) of its rows = slot (2g+h)^f.
     // The reads are inline asm with hand-counted lgkmcnt waits: with LDS-DMA in flight hipcc would

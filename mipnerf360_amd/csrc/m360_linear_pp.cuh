@@ -67,18 +67,18 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_pp_kernel(
         a_off[q] = (unsigned)(r * ldx + 4 * chunk) * 4u;
         b_off[q] = (unsigned)(r * Kp + 4 * chunk) * 4u;
     }
-    const char *xbase = reinterpret_cast<const char *>(X + m0 * ldx);
-    const char *wbase = reinterpret_cast<const char *>(W + (long)n0 * Kp);
+    __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + m0 * ldx), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W + (long)n0 * Kp), 0, 0x7fffffff, 0x00020000);
     char *const dma_dst = smem + wave * 32 * 128;
     auto stage_a = [&](int buf, int k0) __attribute__((always_inline)) {
         char *dst = dma_dst + buf * kBufBytes;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds(xbase + 4 * k0 + a_off[q], (lds_ptr_t)(dst + q * 1024), 16, 0, 0);
+        for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(dst + q * 1024), 16, a_off[q], 4 * k0, 0, 0);
     };
     auto stage_b = [&](int buf, int k0) __attribute__((always_inline)) {
         char *dst = dma_dst + buf * kBufBytes + kTileBytes;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) __builtin_amdgcn_global_load_lds(wbase + 4 * k0 + b_off[q], (lds_ptr_t)(dst + q * 1024), 16, 0, 0);
+        for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(dst + q * 1024), 16, b_off[q], 4 * k0, 0, 0);
     };
 
     // ---- operand reads: lane (l31, h), K-group g reads chunk 2g + h of its row = slot (2g + h) ^ ((row >> 1) & 7)
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_pp_kernel(
                     long nm0;
                     int nn0;
                     tile_coords(tile_id + G, nm0, nn0);
-                    xbase = reinterpret_cast<const char *>(X + nm0 * ldx);
-                    wbase = reinterpret_cast<const char *>(W + (long)nn0 * Kp);
+                    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + nm0 * ldx), 0, 0x7fffffff, 0x00020000);
+                    rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W + (long)nn0 * Kp), 0, 0x7fffffff, 0x00020000);
                 }
             }
             const unsigned boff = buf ? (unsigned)kBufBytes : 0u;

@@ -75,13 +75,17 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_kernel(
         // only reach accumulators which are never stored).
         const int ca = (n0 + 4 * lane < Np) ? n0 + 4 * lane : 0;
         const int cb = (k0 + 4 * lane < Kp) ? k0 + 4 * lane : 0;
-        const float *ga = dZ + (s_begin * BKM + wave * 8) * ldz + ca;
-        const float *gb = X + (s_begin * BKM + wave * 8) * ldx + cb;
+        // buffer descriptors based at this workgroup's first row (SGPRs), one 32-bit lane offset per operand, the row
+        // advance in the instruction's scalar offset: no vector address arithmetic in the loop
+        __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dZ + (s_begin * BKM + wave * 8) * ldz), 0, 0x7fffffff, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + (s_begin * BKM + wave * 8) * ldx), 0, 0x7fffffff, 0x00020000);
+        const unsigned va = 4u * ca, vb = 4u * cb;
+        unsigned soff_a = 0, soff_b = 0;  // bytes: row offset of the K-step being staged
         float *const dma_dst = smem + wave * 8 * BT;
         auto issue_dma = [&](int buf, int q) __attribute__((always_inline)) {
             float *dst = dma_dst + buf * kBufFloats + q * BT;
-            __builtin_amdgcn_global_load_lds(ga + (long)q * ldz, (lds_ptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(gb + (long)q * ldx, (lds_ptr_t)(dst + kTileFloats), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)dst, 16, va, soff_a + 4u * q * ldz, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(dst + kTileFloats), 16, vb, soff_b + 4u * q * ldx, 0, 0);
         };
 
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
@@ -132,9 +136,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_kernel(
         for (long s = s_begin; s < s_end; ++s) {
             // the DMA issued during this step loads step s + 1; after the last step it harmlessly re-loads the last rows
             // (nobody reads them): no branch inside the MFMA stream
-            const long adv = (s + 1 < s_end) ? BKM : 0;
-            ga += adv * ldz;
-            gb += adv * ldx;
+            const unsigned adv = (s + 1 < s_end) ? 4u * BKM : 0u;
+            soff_a += adv * ldz;
+            soff_b += adv * ldx;
             const unsigned a_cur = a_base + (buf ? 4u * kBufFloats : 0u), b_cur = b_base + (buf ? 4u * kBufFloats : 0u);
             const unsigned a_nxt = a_base + (buf ? 0u : 4u * kBufFloats), b_nxt = b_base + (buf ? 0u : 4u * kBufFloats);
             const unsigned c_cur = c_base + (buf ? 4u * kBufFloats : 0u);
