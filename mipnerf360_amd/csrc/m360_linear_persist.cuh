@@ -171,12 +171,28 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         _Pragma("unroll") for (int s = 0; s < 4; ++s) M360_SLICE(FA, FB, s);                           \
     } while (0)
 #define M360_SB() __builtin_amdgcn_sched_barrier(0)
-// 8 MFMAs: rows i0, i0+1 of the wave tile x 4 columns, k-pair s of the current K-group
+#ifndef M360_PERSIST_DIRECT_EPILOGUE
+#define M360_PERSIST_DIRECT_EPILOGUE 0  // 1: operands swapped (A := weight rows), 16-byte stores straight from the accumulators.
+                                        // Measured A/B (same process, bit-identical): 145.4 TF against 148.0 TF for the
+                                        // LDS-transposed epilogue - 32 contiguous bytes per row and store lose to whole
+                                        // 128-byte lines - so the experiment stays off.
+#endif
+// 8 MFMAs: rows i0, i0+1 of the wave tile x 4 columns, k-pair s of the current K-group.  With the operands swapped
+// (A := weight rows, B := activation rows) the same products are summed in the same order - bit-identical - but a
+// lane's registers 4t..4t+3 become 4 consecutive output COLUMNS of one row: no LDS transposition in the epilogue.
+#if M360_PERSIST_DIRECT_EPILOGUE
+#define M360_MFMA8(FA, FB, s, i0)                                                                      \
+    do {                                                                                               \
+        _Pragma("unroll") for (int i = (i0); i < (i0) + 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FB[j][s], FA[i][s], acc[i][j], 0, 0, 0);  \
+    } while (0)
+#else
 #define M360_MFMA8(FA, FB, s, i0)                                                                      \
     do {                                                                                               \
         _Pragma("unroll") for (int i = (i0); i < (i0) + 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i][s], FB[j][s], acc[i][j], 0, 0, 0);  \
     } while (0)
+#endif
 // One K-group = 8 units of 8 MFMAs on fragment (FA, FB).  After each unit ONE ds_read_b128 of the NEXT
 // K-group (into the other fragment NA/NB, byte addresses na/nb) and, when DMA is 1, the two LDS-DMA
 // instruction(s) of row-block q = unit of the next K-step are issued (DMA: 1 = A half, 2 = B half,
@@ -282,6 +298,55 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         }
         M360_STAMP(c0);
 
+#if M360_PERSIST_DIRECT_EPILOGUE
+        // ---- epilogue: bias + activation.  Swapped operands: lane (l31, h) holds row m = block*32 + l31 and, in registers
+        // 4t..4t+3 of a block, the 4 consecutive columns 8t + 4h + 0..3: one 16-byte store each, the two lane halves
+        // together 32 contiguous bytes per row, the four t a whole 128-byte line.
+        {
+            int ldy_t = ldy;
+            asm volatile("" : "+s"(ldy_t));  // keep the address math inside the tile loop (LICM would spill it)
+            float *__restrict__ Yt = Y + (m0 + wm * 128 + l31) * ldy_t + n0 + wn * 128 + 4 * h;
+            // the last MFMAs were issued a few cycles ago: give the first accumulators read below time to retire
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float4 b4[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    b4[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (ACT != M360_ACT_RELU_MASK) b4[t] = *reinterpret_cast<const float4 *>(bias + n0 + wn * 128 + j * 32 + 8 * t + 4 * h);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const long yoff = (long)(i * 32) * ldy_t + j * 32;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        // explicit AGPR -> VGPR moves, four at a time: left to the compiler, all 256 accumulator reads are
+                        // clustered and the loop-invariant DMA offsets get spilled into the K-loop
+                        float4 v;
+                        asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\t"
+                                     "v_accvgpr_read_b32 %3, %7\n\ts_nop 1"
+                                     : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)
+                                     : "a"(acc[i][j][4 * t]), "a"(acc[i][j][4 * t + 1]), "a"(acc[i][j][4 * t + 2]), "a"(acc[i][j][4 * t + 3]));
+                        if (ACT == M360_ACT_RELU_MASK) {  // backward of ReLU: keep where the forward output (aux, same ld) was > 0
+                            const float4 a4 = *reinterpret_cast<const float4 *>(aux + (Yt - Y) + yoff + 8 * t);
+                            v.x = a4.x > 0.0f ? v.x : 0.0f;
+                            v.y = a4.y > 0.0f ? v.y : 0.0f;
+                            v.z = a4.z > 0.0f ? v.z : 0.0f;
+                            v.w = a4.w > 0.0f ? v.w : 0.0f;
+                        } else {
+                            v.x = act_fn<ACT>(v.x + b4[t].x);
+                            v.y = act_fn<ACT>(v.y + b4[t].y);
+                            v.z = act_fn<ACT>(v.z + b4[t].z);
+                            v.w = act_fn<ACT>(v.w + b4[t].w);
+                        }
+                        *reinterpret_cast<float4 *>(Yt + yoff + 8 * t) = v;
+                        M360_SB();  // one quad at a time: keeps the accumulator reads from being hoisted into spills
+                    }
+                }
+            }
+        }
+#else
         // ---- epilogue: bias + activation.  The accumulator layout (lane = column l31, 16 registers =
         // rows (r&3)+8(r>>2)+4h) would store 4 B per lane; interior tiles are instead transposed
         // through the idle LDS buffer (wave-private 32 x 36 floats) so that every lane stores 16 B and one
@@ -326,6 +391,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
                 }
             }
         }
+#endif
         M360_STAMP(c1);
         if (STAMP) st[7] += c1 - c0;
     }
