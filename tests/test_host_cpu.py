@@ -328,3 +328,18 @@ except ImportError:
 """
     res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-3000:]
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/m360.h is the boundary a C caller binds: it must compile as C99 on its own (no torch / HIP / C++ types)."""
+    import shutil
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "c.c"
+    src.write_text('#include "m360.h"\nint main(void) { m360_hyper_t h = {128, 0, 4, 0, -1.0f, 0.001f, 0.01f, 0, 0};\n'
+                   '  m360_rays_t r = {0}; m360_model_t m = {0}; m360_outputs_t o = {0};\n'
+                   '  return (int)(h.num_samples_fine + h.norm_group_rays + (r.origins != 0) + m.in_ch + (o.rgb != 0)) + M360_OK; }\n')
+    res = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o",
+                          str(tmp_path / "c.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
