@@ -1088,3 +1088,17 @@ def test_psnr_within_tenth_db_of_reference(golden, dev, kind, n, mlp_dtype, limi
         psnr = lambda a: -10.0 * np.log10(np.mean((np.clip(a, 0, 1) - target) ** 2))  # noqa: E731
         worst = max(worst, abs(psnr(H(rgb).astype(np.float64)) - psnr(ref_rgb)))
     assert worst <= limit_db, f"PSNR differs from the reference's by {worst:.4f} dB"
+
+
+def test_full_size_forward_soak_is_deterministic(dev):
+    """Race screen at the BASELINE shape (4096 x 128, full width): 40 back-to-back forwards must be bit-identical
+    (LDS-DMA double buffering, tile hand-over, deferred stores: any ordering bug shows up as sporadic mismatches)."""
+    sd = synthetic.make_state_dict(256, 1024, seed=0)
+    m = build_model(sd, dev, 128, 256, 1024, False)
+    rays = dev_rays(synthetic.make_rays("garden", 4096, seed=1), dev)
+    with torch.no_grad():
+        first = [t.clone() for t in m(rays)]
+        for _ in range(40):
+            out = m(rays)
+            assert all(torch.equal(a, b) for a, b in zip(out, first))
+    assert bool(torch.isfinite(first[0]).all())
