@@ -209,7 +209,8 @@ def test_linear_mfma_against_fp64(dev):
 
 @pytest.mark.parametrize("M,n,k,act", [(256 * 37 + 5, 1024, 64, 1), (256 * 530, 256, 64, 0), (256 * 9, 256, 256, 1),
                                         (256 * 64, 1024, 1024, 1), (256, 768, 32, 1), (256 * 3, 512, 96, 0),
-                                        (256 * 21 + 255, 768, 64, 1), (256 * 300 + 1, 256, 32, 0)])
+                                        (256 * 21 + 255, 768, 64, 1), (256 * 300 + 1, 256, 32, 0),
+                                        (256 * 11 + 3, 256, 256, 2), (256 * 40, 1024, 1024, 2)])   # sigmoid layers
 def test_linear_kernel_variants_bit_identical(dev, M, n, k, act):
     """The persistent LDS-DMA kernel (many tiles per workgroup: exercises the tile hand-over, the LDS-staged
     epilogue and the ragged-row split) must reproduce the workgroup-per-tile kernel bit for bit, every element."""
