@@ -342,7 +342,8 @@ def test_randomized_mode_is_statistically_sane(dev):
     rnd = mipNeRF360(randomized=True, num_samples=64, hidden_proposal=64, hidden_nerf=128, white_bkgd=True, device=dev)
     rnd.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     rnd.eval()  # reference quirk: sub-nets keep randomized=True after eval() (model.py:281-283)
-    a, b, c = det(r)[0], rnd(r)[0], rnd(r)[0]
+    with torch.no_grad():
+        a, b, c = det(r)[0], rnd(r)[0], rnd(r)[0]
     assert not torch.equal(b, c)
     assert float((a - b).abs().mean()) < 0.05
     assert torch.isfinite(b).all()
