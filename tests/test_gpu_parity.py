@@ -1104,3 +1104,25 @@ def test_full_size_forward_soak_is_deterministic(dev):
             out = m(rays)
             assert all(torch.equal(a, b) for a, b in zip(out, first))
     assert bool(torch.isfinite(first[0]).all())
+
+
+def test_fused_two_stage_and_tape_forwards_are_bit_identical(dev):
+    """Three ways through the same kernels must agree bit for bit: the fused driver (m360_forward), the two stage entry
+    points called one after the other (prop_net.forward -> nerf_net.forward, what train.py does) and the tape-keeping
+    training forward; including a batch with ragged GEMM rows (B * N not a multiple of 256) and full-width layers."""
+    for hp, hn, B, n in ((64, 128, 37, 24), (256, 1024, 70, 40)):
+        sd = synthetic.make_state_dict(hp, hn, seed=41)
+        m = build_model(sd, dev, n, hp, hn, True)
+        rays = dev_rays(synthetic.make_rays("lego", B, seed=42), dev)
+        with torch.no_grad():
+            fused = m(rays)                                             # m360_forward
+            t_hat, w_hat = m.prop_net.forward(rays)                     # m360_prop_forward
+            staged = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)   # m360_nerf_forward
+        t2, w2 = m.prop_net.forward(rays)                               # grad enabled: m360_prop_forward_train
+        taped = m.nerf_net.forward(rays, t_vals=t2, coarse_weights=w2)  # m360_nerf_forward_train
+        assert w2.requires_grad and taped[0].requires_grad
+        assert torch.equal(t_hat, t2) and torch.equal(w_hat, w2.detach())
+        for k in range(3):
+            assert torch.equal(fused[k], staged[k]) and torch.equal(fused[k], taped[k].detach())
+        for k in (3, 4, 5):
+            assert torch.equal(staged[k], taped[k].detach())
