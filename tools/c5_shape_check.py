@@ -10,6 +10,7 @@ rays = Rays(*[torch.from_numpy(r[k]).to(dev) for k in synthetic.RAY_FIELDS])
 for dt in ('bf16', 'fp32'):
     m = mipNeRF360(num_samples=256, hidden_proposal=256, hidden_nerf=1024, device=dev, mlp_dtype=dt)
     m.load_state_dict(sd)
+    torch.set_grad_enabled(False)  # rendering (with grad enabled the mirrors keep a training tape)
     for _ in range(2): out = m(rays)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 5 if dt == 'bf16' else 2
