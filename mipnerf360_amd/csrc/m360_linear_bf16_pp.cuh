@@ -205,6 +205,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
 // One K-step = 4 phases.  ST: also store the previous tile (4 stores per phase, issued BEFORE the phase's reads - while
 // the fragment registers they fill are still free - and before its 2 LDS-DMA instructions).  V0..V3: the counted vmcnt of each phase = number of vector-memory operations issued after the DMA pair
 // of two phases ago, which must have landed before the next phase reads it.
+#ifndef PP_PHASES
+#define PP_PHASES 4  // phases per K-step: 4 (16 MFMAs each) or 2 (32 MFMAs each, half the barrier hand-offs): measured equal (1110 TF)
+#endif
+#if PP_PHASES == 4
 #define PP_KSTEP(ST)                                        \
     do {                                                    \
         PP_SB();                                            \
@@ -249,6 +253,52 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         PP_SB();                                            \
         PP_BAR();                                           \
     } while (0)
+#define PP_PROLOGUE_VMCNT() PP_VMCNT(4)
+#else
+// Two phases per K-step (M half 0, then M half 1), 32 MFMAs each.  Phase 0 stages the three units the next K-step's
+// phase 0 reads (XA, WA, WB: 6 instructions), phase 1 the one its phase 1 reads (XB: 2).  Counted waits, placed after
+// the phase's own DMA issue: phase 0 retires XB of THIS K-step (6 younger operations, + 8 stores in a store K-step),
+// phase 1 retires XA / WA / WB of the next one (2 younger, + 8 stores) - each one phase before the first read.
+#define PP_KSTEP(ST)                                        \
+    do {                                                    \
+        PP_SB();                                            \
+        if (ST) {                                           \
+            PP_STORE_Q(0, 0);                               \
+            PP_STORE_Q(0, 2);                               \
+        }                                                   \
+        PP_READ_W(0, boff, 0, 512);                         \
+        PP_READ_W(2, boff, 1024, 1536);                     \
+        PP_READ_X(boff, 0, 2048, 4096, 6144);               \
+        stage(nbuf, 0, k_next);                             \
+        stage(nbuf, 1, k_next);                             \
+        stage(nbuf, 2, k_next);                             \
+        if (ST) PP_VMCNT(14); else PP_VMCNT(6);             \
+        PP_BAR();                                           \
+        PP_WAIT_W(0);                                       \
+        PP_WAIT_W(2);                                       \
+        PP_WAIT_X();                                        \
+        PP_SB();                                            \
+        PP_MFMA16(0, 0);                                    \
+        PP_MFMA16(0, 2);                                    \
+        PP_SB();                                            \
+        PP_BAR();                                           \
+        if (ST) {                                           \
+            PP_STORE_Q(4, 2);                               \
+            PP_STORE_Q(4, 0);                               \
+        }                                                   \
+        PP_READ_X(boff, 8192, 10240, 12288, 14336);         \
+        stage(nbuf, 3, k_next);                             \
+        if (ST) PP_VMCNT(10); else PP_VMCNT(2);             \
+        PP_BAR();                                           \
+        PP_WAIT_X();                                        \
+        PP_SB();                                            \
+        PP_MFMA16(4, 2);                                    \
+        PP_MFMA16(4, 0);                                    \
+        PP_SB();                                            \
+        PP_BAR();                                           \
+    } while (0)
+#define PP_PROLOGUE_VMCNT() PP_VMCNT(2)
+#endif
 
     // ---- bias -> LDS once (before any LDS-DMA is in flight)
     float *const bias_lds = reinterpret_cast<float *>(smem + 2 * kTileBytes);
@@ -261,7 +311,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     stage(0, 1, 0);
     stage(0, 2, 0);
     stage(0, 3, 0);
-    PP_VMCNT(4);  // XA and WA of this wave's rows have landed
+    PP_PROLOGUE_VMCNT();  // what phase 0 of the first K-step reads has landed (this wave's rows)
     PP_BAR();
     if (wm == 1) PP_BAR();  // the second M half runs one barrier behind the first
 
@@ -344,6 +394,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
 #undef PP_VMCNT
 #undef PP_STORE_Q
 #undef PP_KSTEP
+#undef PP_PROLOGUE_VMCNT
 }
 
 }  // namespace pp16
