@@ -1,5 +1,7 @@
 """Row (f4): checkpoint tooling — the reference's torch.save'd state_dict loads unchanged; architecture is inferred
 from tensor shapes; the packed (padded / bf16) layout for C-ABI consumers round-trips."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -63,3 +65,26 @@ def test_packed_export_matches_padded_weights(tmp_path, dtype):
     o = O.forward(O.rays_from_numpy(r), O.to_torch_state_dict(sd), O.Hyper(num_samples=16, mlp_bf16=(dtype == "bf16")))
     tol = 6e-3 if dtype == "bf16" else 1e-4
     assert float((rgb.cpu() - o[0]).abs().max()) <= tol and float((acc.cpu() - o[2]).abs().max()) <= tol
+
+
+@pytest.mark.gpu
+def test_render_checkpoint_tool_writes_frames(tmp_path):
+    """tools/render_checkpoint.py: the flow of the reference's test.py (checkpoint -> frames + depth / normal maps as PNG)
+    on the mirrors, from a state_dict saved the way train.py saves it."""
+    import subprocess
+    import sys
+    dev = torch.device("cuda:0")
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(64, 96, seed=9).items()}
+    ck = tmp_path / "model_0.pt"
+    torch.save(sd, str(ck))
+    out = tmp_path / "frames"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "render_checkpoint.py"), str(ck), str(out), "--width", "40",
+                          "--height", "30", "--views", "2", "--num-samples", "16", "--chunks", "128", "--ndc"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:]
+    names = sorted(os.listdir(out))
+    assert names == ["dist_0000.png", "dist_0001.png", "norm_0000.png", "norm_0001.png", "rgb_0000.png", "rgb_0001.png"]
+    for n in names:
+        raw = open(out / n, "rb").read()
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n" and b"IHDR" in raw[:32] and len(raw) > 100
