@@ -348,6 +348,7 @@ typedef struct {
                              rays, each contracted with ITS OWN global norm (parameterization.py:25): one launch
                              sequence renders many chunks, bit-identical to launching them one by one; 0 = one norm
                              for the whole batch (the reference's forward) */
+    void *prof;           /* optional m360_prof_t* (see "measurement" below); NULL = no timing */
 } m360_hyper_t; /* ctor arguments of model.py:203-215 */
 
 typedef struct {
@@ -466,25 +467,27 @@ int m360_nerf_forward_from_t(const m360_rays_t *rays_host, const m360_model_t *m
 
 /* ------------------------------------------------------------------ measurement ------ */
 
-/* Optional HIP-event timing of every m360_linear launch (the MFMA kernel that bounds the path),
- * recorded on the launch stream itself.  Not part of the reference; used by bench.py's roofline.
- * m360_prof_enable(capacity > 0) starts recording up to `capacity` launches (0 disables and frees
- * the events); m360_prof_read() synchronises on record i's stop event (the only call in this
- * library that blocks) and returns its duration and GEMM shape.  Single-threaded use only. */
-int m360_prof_enable(int capacity);
-int m360_prof_count(void);
-int m360_prof_reset(void);
-int m360_prof_read(int i, float *ms, long *M, int *n_pad, int *k_pad);
-/* A/B switch between the two m360_linear kernels (1 = workgroup per tile, register staging;
- * 2 = persistent workgroups + LDS-DMA staging, the default;
- * 3 = variant 2 instrumented with s_memtime stamps, diagnostics only;
- * 4 = 8-wave ping-pong kernel, an experiment that measured 4 % SLOWER than variant 2).
- * Results are bit-identical across 1, 2 and 4.
- * 11 / 12 / 13 select the bf16 kernel instead: 11 = one wave per SIMD (m360_linear_bf16.cuh), 12 = 8-wave ping-pong
- * (m360_linear_bf16_pp.cuh, the default), 13 = 12 with cycle stamps. */
-int m360_debug_set_linear_variant(int variant);
-/* diagnostic only: per-workgroup cycle stamps of the last variant-3 launch (8 x uint64 per workgroup) */
-int m360_debug_read_stamps(unsigned long long *out_host, int n);
+/* Optional HIP-event timing of the kernels of a stage driver (m360_forward, m360_prop_forward, m360_nerf_forward,
+ * their *_train / *_from_t forms and the two backward drivers), recorded on the launch stream itself.  Not part of
+ * the reference; used by bench.py's roofline.  The recorder is a CALLER-OWNED host object (no state lives in the
+ * library): create one with `capacity` record slots, put it into m360_hyper_t.prof for the calls to be timed (NULL =
+ * no timing), read the records afterwards.  m360_prof_read() synchronises on record i's stop event - the only call
+ * in this library that blocks.  One recorder must not be used by two threads at once. */
+typedef struct m360_prof m360_prof_t;
+enum {
+    M360_K_LINEAR = 0,      /* one fp32 layer   (M rows, n_pad, k_pad) */
+    M360_K_LINEAR_BF16 = 1, /* one bf16 layer   */
+    M360_K_ENCODE = 2,      /* sample -> contract -> IPE -> feature rows (M = B*N samples, n_pad = ld_feat, k_pad = bf16?) */
+    M360_K_PROP_FINISH = 3, /* proposal head + weights + resample (M = B*N, n_pad = width, k_pad = bf16?) */
+    M360_K_NERF_FINISH = 4, /* NeRF heads + composite             (M = B*N, n_pad = width, k_pad = bf16?) */
+    M360_K_WGRAD = 5,
+    M360_K_DGRAD = 6
+};
+m360_prof_t *m360_prof_create(int capacity); /* NULL on failure */
+void m360_prof_destroy(m360_prof_t *prof);
+int m360_prof_count(const m360_prof_t *prof);
+int m360_prof_reset(m360_prof_t *prof);
+int m360_prof_read(m360_prof_t *prof, int i, float *ms, int *kind, long *M, int *n_pad, int *k_pad);
 
 #ifdef __cplusplus
 }

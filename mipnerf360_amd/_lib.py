@@ -16,6 +16,8 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 M360_OK = 0
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+# record kinds of the event recorder (include/m360.h, "measurement")
+K_LINEAR, K_LINEAR_BF16, K_ENCODE, K_PROP_FINISH, K_NERF_FINISH, K_WGRAD, K_DGRAD = range(7)
 
 _f = C.POINTER(C.c_float)
 _vp = C.c_void_p
@@ -35,7 +37,8 @@ class ModelStruct(C.Structure):  # m360_model_t
 class HyperStruct(C.Structure):  # m360_hyper_t
     _fields_ = [("num_samples", C.c_int), ("viewdir_min_deg", C.c_int), ("viewdir_max_deg", C.c_int),
                 ("white_bkgd", C.c_int), ("density_bias", C.c_float), ("rgb_padding", C.c_float),
-                ("resample_padding", C.c_float), ("num_samples_fine", C.c_int), ("norm_group_rays", C.c_int)]
+                ("resample_padding", C.c_float), ("num_samples_fine", C.c_int), ("norm_group_rays", C.c_int),
+                ("prof", C.c_void_p)]
 
 
 class OutputsStruct(C.Structure):  # m360_outputs_t
@@ -107,12 +110,11 @@ SIGNATURES = {
     "m360_prop_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m360_nerf_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp,
                                _P(OutputsStruct), _vp, _sz, _vp]),
-    "m360_debug_set_linear_variant": (_i, [_i]),
-    "m360_debug_read_stamps": (_i, [_P(C.c_ulonglong), _i]),
-    "m360_prof_enable": (_i, [_i]),
-    "m360_prof_count": (_i, []),
-    "m360_prof_reset": (_i, []),
-    "m360_prof_read": (_i, [_i, _P(C.c_float), _P(C.c_long), _P(_i), _P(_i)]),
+    "m360_prof_create": (_vp, [_i]),
+    "m360_prof_destroy": (None, [_vp]),
+    "m360_prof_count": (_i, [_vp]),
+    "m360_prof_reset": (_i, [_vp]),
+    "m360_prof_read": (_i, [_vp, _i, _P(C.c_float), _P(_i), _P(C.c_long), _P(_i), _P(_i)]),
     "m360_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _P(OutputsStruct), _vp, _sz, _vp]),
     "m360_mean_sumsq": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "m360_encode_features_ext_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _sz, _vp]),
@@ -167,6 +169,40 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+class Prof:
+    """Caller-owned HIP-event recorder (m360_prof_t): attach to a model with `model.prof = Prof(n)`; the stage drivers
+    then time every kernel they launch on the launch stream.  `records()` blocks until the recorded work is done."""
+
+    def __init__(self, capacity: int):
+        self.handle = lib().m360_prof_create(int(capacity))
+        if not self.handle:
+            raise RuntimeError(f"m360_prof_create({capacity}) failed: {last_error()}")
+
+    def reset(self) -> None:
+        lib().m360_prof_reset(self.handle)
+
+    def records(self):
+        """-> list of dicts {kind, ms, M, n_pad, k_pad}"""
+        out = []
+        ms, kind, M_, n_, k_ = C.c_float(), C.c_int(), C.c_long(), C.c_int(), C.c_int()
+        for i in range(lib().m360_prof_count(self.handle)):
+            check(lib().m360_prof_read(self.handle, i, C.byref(ms), C.byref(kind), C.byref(M_), C.byref(n_), C.byref(k_)),
+                  "m360_prof_read")
+            out.append(dict(kind=kind.value, ms=ms.value, M=M_.value, n_pad=n_.value, k_pad=k_.value))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            lib().m360_prof_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def last_error() -> str:

@@ -6,7 +6,7 @@
 
 #include <vector>
 
-#include "m360_common.cuh"
+#include "m360_common.hip.h"
 
 namespace m360 {
 
@@ -26,28 +26,49 @@ int check_launch(const char *what) {
     return fail(M360_ERR_LAUNCH, "%s: kernel launch failed: %s", what, hipGetErrorString(e));
 }
 
-struct ProfRec {
-    hipEvent_t start, stop;
-    long M;
-    int n_pad, k_pad;
+}  // namespace m360
+
+// Caller-owned event recorder (include/m360.h "measurement"): no state lives in the library.
+struct m360_prof {
+    struct Rec {
+        hipEvent_t start, stop;
+        int kind;
+        long M;
+        int n_pad, k_pad;
+    };
+    std::vector<Rec> recs;
+    size_t used = 0;
 };
-static std::vector<ProfRec> g_prof;
-static size_t g_prof_used = 0;
-static bool g_prof_on = false;
 
-int prof_begin(hipStream_t st, long M, int n_pad, int k_pad) {
-    if (!g_prof_on || g_prof_used >= g_prof.size()) return -1;
-    ProfRec &r = g_prof[g_prof_used];
-    r.M = M;
-    r.n_pad = n_pad;
-    r.k_pad = k_pad;
-    if (hipEventRecord(r.start, st) != hipSuccess) return -1;
-    return (int)g_prof_used++;
-}
+namespace m360 {
 
-void prof_end(int idx, hipStream_t st) {
-    if (idx >= 0) (void)hipEventRecord(g_prof[idx].stop, st);
-}
+// brackets the launches of ONE public entry point with two HIP events on the launch stream
+struct ProfScope {
+    m360_prof *p;
+    hipStream_t st;
+    int idx = -1;
+    ProfScope(const m360_hyper_t *h, m360_stream_t stream, int kind, long M, int n_pad, int k_pad)
+        : p(h ? static_cast<m360_prof *>(h->prof) : nullptr), st(reinterpret_cast<hipStream_t>(stream)) {
+        if (!p || p->used >= p->recs.size()) return;
+        m360_prof::Rec &r = p->recs[p->used];
+        r.kind = kind;
+        r.M = M;
+        r.n_pad = n_pad;
+        r.k_pad = k_pad;
+        if (hipEventRecord(r.start, st) == hipSuccess) idx = (int)p->used++;
+    }
+    int done(int rc) {
+        if (idx >= 0) (void)hipEventRecord(p->recs[idx].stop, st);
+        idx = -1;
+        return rc;
+    }
+};
+#define M360_PROF(h, st, kind, M, n, k, expr)                \
+    do {                                                     \
+        ProfScope ps_((h), (st), (kind), (M), (n), (k));     \
+        const int rc_ = ps_.done(expr);                      \
+        if (rc_ != M360_OK) return rc_;                      \
+    } while (0)
 
 __global__ void add_eps_kernel(const float *__restrict__ x, long n, float *__restrict__ y) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,6 +127,34 @@ static int validate(const m360_rays_t *r, const m360_model_t *m, const m360_hype
         if (rc_ != M360_OK) return rc_; \
     } while (0)
 
+// the entry points the stage drivers chain, each bracketed by the caller's event recorder (hyper->prof, may be NULL)
+static int p_linear(const m360_hyper_t *h, const float *x, long M, int ldx, const float *w, const float *b, int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_LINEAR, M, n_pad, k_pad);
+    return ps.done(m360_linear(x, M, ldx, w, b, n_pad, k_pad, act, y, ldy, st));
+}
+static int p_linear_bf16(const m360_hyper_t *h, const void *x, long M, int ldx, const void *w, const float *b, int n_pad, int k_pad, int act, void *y, int ldy, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, k_pad);
+    return ps.done(m360_linear_bf16(x, M, ldx, w, b, n_pad, k_pad, act, y, ldy, st));
+}
+static int p_encode_grouped(const m360_hyper_t *h, const float *t, const float *o, const float *d, const float *rad, const float *vdenc, int vd_ch, int B, int N, void *feat, int ld, int bf16, int group, void *ws, size_t wsb, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_ENCODE, (long)B * N, ld, bf16);
+    return ps.done(m360_encode_features_grouped(t, o, d, rad, vdenc, vd_ch, B, N, feat, ld, bf16, group, ws, wsb, st));
+}
+static int p_encode_ext_norm(const m360_hyper_t *h, const float *t, const float *o, const float *d, const float *rad, const float *vdenc, int vd_ch, int B, int N, void *feat, int ld, int bf16, const float *norm, void *ws, size_t wsb, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_ENCODE, (long)B * N, ld, bf16);
+    return ps.done(m360_encode_features_ext_norm(t, o, d, rad, vdenc, vd_ch, B, N, feat, ld, bf16, norm, ws, wsb, st));
+}
+static int p_prop_finish(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, float *w_hat, float *t_new, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_PROP_FINISH, (long)B * N, k_pad, bf16);
+    if (bf16) return ps.done(m360_prop_finish_bf16(act, ld, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st));
+    return ps.done(m360_prop_finish_n(static_cast<const float *>(act), ld, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st));
+}
+static int p_nerf_finish(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, const m360_outputs_t *out, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_NERF_FINISH, (long)B * N, k_pad, bf16);
+    if (bf16) return ps.done(m360_nerf_finish_bf16(act, ld, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, dirs, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
+    return ps.done(m360_nerf_finish(static_cast<const float *>(act), ld, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, dirs, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
+}
+
 // Training tape of one stage (caller-owned): everything the backward needs from the forward.
 struct TapeLayout {
     size_t t, feat, act[8], total;
@@ -146,32 +195,32 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         if (hipMemcpyAsync(t_hat, tt, (size_t)B * (N + 1) * sizeof(float), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(st)) != hipSuccess)
             return fail(M360_ERR_LAUNCH, "m360_prop_forward_train: copy of t_hat failed");
         M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
-        M360_TRY(m360_encode_features_grouped(tt, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(m360_linear(tf, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, act[0], hp, st));
+        M360_TRY(p_encode_grouped(h, tt, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_linear(h, tf, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, act[0], hp, st));
         for (int l = 1; l < 4; ++l)
-            M360_TRY(m360_linear(act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, l == 3 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hp, st));
-        return m360_prop_finish_n(act[3], hp, m->prop_head_w, m->prop_head_b, hp, h->density_bias, tt, r->directions, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st);
+            M360_TRY(p_linear(h, act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, l == 3 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hp, st));
+        return p_prop_finish(h, act[3], 0, hp, m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st);
     }
     if (!ext_norm) M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, t_hat, st));  // sharded batch: t_hat is given
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hp = m->hp_pad;
     if (ext_norm) {  // the caller supplies the (all-reduced) contraction norm; the layers below are shared
-        M360_TRY(m360_encode_features_ext_norm(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_encode_ext_norm(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
     }
     if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers, half the bytes)
-        if (!ext_norm) M360_TRY(m360_encode_features_grouped(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(m360_linear_bf16(feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
-        M360_TRY(m360_linear_bf16(a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
-        M360_TRY(m360_linear_bf16(b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
-        M360_TRY(m360_linear_bf16(a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, hp, st));
-        return m360_prop_finish_bf16(b, hp, m->prop_head_w, m->prop_head_b, hp, h->density_bias, t_hat, r->directions, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st);
+        if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_linear_bf16(h, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
+        M360_TRY(p_linear_bf16(h, a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
+        M360_TRY(p_linear_bf16(h, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
+        M360_TRY(p_linear_bf16(h, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, hp, st));
+        return p_prop_finish(h, b, 1, hp, m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
     }
-    if (!ext_norm) M360_TRY(m360_encode_features_grouped(t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-    M360_TRY(m360_linear(feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
-    M360_TRY(m360_linear(a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
-    M360_TRY(m360_linear(b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
-    M360_TRY(m360_linear(a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, hp, st));
-    return m360_prop_finish_n(b, hp, m->prop_head_w, m->prop_head_b, hp, h->density_bias, t_hat, r->directions, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st);
+    if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+    M360_TRY(p_linear(h, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
+    M360_TRY(p_linear(h, a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
+    M360_TRY(p_linear(h, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
+    M360_TRY(p_linear(h, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, hp, st));
+    return p_prop_finish(h, b, 0, hp, m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
 }
 
 // resampled t -> features -> 8 NeRF layers -> heads + composite
@@ -193,29 +242,29 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         float *tf = reinterpret_cast<float *>(tape + T.feat);
         float *act[8];
         for (int l = 0; l < 8; ++l) act[l] = reinterpret_cast<float *>(tape + T.act[l]);
-        M360_TRY(m360_encode_features_grouped(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(m360_linear(tf, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, act[0], hn, st));
+        M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_linear(h, tf, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, act[0], hn, st));
         for (int l = 1; l < 8; ++l)
-            M360_TRY(m360_linear(act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, l == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hn, st));
-        M360_TRY(m360_nerf_finish(act[7], hn, m->nerf_head_w, m->nerf_head_b, hn, h->density_bias, h->rgb_padding, t1, r->directions, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
+            M360_TRY(p_linear(h, act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, l == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hn, st));
+        M360_TRY(p_nerf_finish(h, act[7], 0, hn, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     } else if (m->mlp_bf16) {
-        if (ext_norm) M360_TRY(m360_encode_features_ext_norm(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
-        else M360_TRY(m360_encode_features_grouped(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(m360_linear_bf16(feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
+        if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
+        else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_linear_bf16(h, feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
         for (int layer = 1; layer < 8; ++layer) {
-            M360_TRY(m360_linear_bf16(src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
+            M360_TRY(p_linear_bf16(h, src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
             float *tmp = src; src = dst; dst = tmp;
         }
-        M360_TRY(m360_nerf_finish_bf16(src, hn, m->nerf_head_w, m->nerf_head_b, hn, h->density_bias, h->rgb_padding, t1, r->directions, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
+        M360_TRY(p_nerf_finish(h, src, 1, hn, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     } else {
-    if (ext_norm) M360_TRY(m360_encode_features_ext_norm(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
-    else M360_TRY(m360_encode_features_grouped(t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-    M360_TRY(m360_linear(feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
+    if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
+    else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+    M360_TRY(p_linear(h, feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
     for (int layer = 1; layer < 8; ++layer) {
-        M360_TRY(m360_linear(src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
+        M360_TRY(p_linear(h, src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
         float *tmp = src; src = dst; dst = tmp;
     }
-    M360_TRY(m360_nerf_finish(src, hn, m->nerf_head_w, m->nerf_head_b, hn, h->density_bias, h->rgb_padding, t1, r->directions, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
+    M360_TRY(p_nerf_finish(h, src, 0, hn, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     }
     if (out->t_vals) {  // model.py:194,196: g() inside t_to_s bumps the stored t_vals by 1e-6
         const long n = (long)B * (N + 1);
@@ -244,38 +293,44 @@ int m360_device_count(void) {
     return n;
 }
 
-int m360_prof_enable(int capacity) {
-    for (ProfRec &r : g_prof) {
+m360_prof_t *m360_prof_create(int capacity) {
+    if (capacity <= 0) return nullptr;
+    m360_prof *p = new m360_prof();
+    p->recs.resize((size_t)capacity);
+    for (size_t i = 0; i < p->recs.size(); ++i) {
+        if (hipEventCreate(&p->recs[i].start) != hipSuccess || hipEventCreate(&p->recs[i].stop) != hipSuccess) {
+            (void)hipGetLastError();
+            p->recs.resize(i);  // events [0, i) exist (a half-made pair leaks one event at worst)
+            m360_prof_destroy(p);
+            fail(M360_ERR_LAUNCH, "m360_prof_create: hipEventCreate failed");
+            return nullptr;
+        }
+    }
+    return p;
+}
+
+void m360_prof_destroy(m360_prof_t *p) {
+    if (!p) return;
+    for (m360_prof::Rec &r : p->recs) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
     }
-    g_prof.clear();
-    g_prof_used = 0;
-    g_prof_on = false;
-    if (capacity <= 0) return M360_OK;
-    g_prof.resize((size_t)capacity);
-    for (ProfRec &r : g_prof) {
-        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) {
-            g_prof.clear();
-            return fail(M360_ERR_LAUNCH, "m360_prof_enable: hipEventCreate failed");
-        }
-    }
-    g_prof_on = true;
+    delete p;
+}
+
+int m360_prof_count(const m360_prof_t *p) { return p ? (int)p->used : 0; }
+
+int m360_prof_reset(m360_prof_t *p) {
+    if (p) p->used = 0;
     return M360_OK;
 }
 
-int m360_prof_count(void) { return (int)g_prof_used; }
-
-int m360_prof_reset(void) {
-    g_prof_used = 0;
-    return M360_OK;
-}
-
-int m360_prof_read(int i, float *ms, long *M, int *n_pad, int *k_pad) {
-    if (i < 0 || (size_t)i >= g_prof_used || !ms) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prof_read: bad index %d", i);
-    ProfRec &r = g_prof[i];
+int m360_prof_read(m360_prof_t *p, int i, float *ms, int *kind, long *M, int *n_pad, int *k_pad) {
+    if (!p || i < 0 || (size_t)i >= p->used || !ms) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prof_read: bad index %d", i);
+    m360_prof::Rec &r = p->recs[i];
     if (hipEventSynchronize(r.stop) != hipSuccess || hipEventElapsedTime(ms, r.start, r.stop) != hipSuccess)
         return fail(M360_ERR_LAUNCH, "m360_prof_read: event query failed");
+    if (kind) *kind = r.kind;
     if (M) *M = r.M;
     if (n_pad) *n_pad = r.n_pad;
     if (k_pad) *k_pad = r.k_pad;
@@ -390,17 +445,17 @@ int m360_nerf_forward_train(const m360_rays_t *rays, const m360_model_t *model, 
 }
 
 // dz (gradient at the pre-activation of the last hidden layer, already in `dz`) -> all weight / bias gradients
-static int mlp_backward(int layers, const float *const *w_t, float *const *grad_w, float *const *grad_b, const float *feat,
+static int mlp_backward(const m360_hyper_t *h, int layers, const float *const *w_t, float *const *grad_w, float *const *grad_b, const float *feat,
                         int in_pad, float *const *act, int width, long S, float *dz, float *dz_other, void *gemm_ws,
                         size_t gemm_ws_bytes, m360_stream_t st, const char *who) {
     for (int l = layers - 1; l >= 0; --l) {
         const float *x = l == 0 ? feat : act[l - 1];
         const int k = l == 0 ? in_pad : width;
         if (!grad_w[l] || !grad_b[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: gradient buffer of layer %d is null", who, l);
-        M360_TRY(m360_linear_wgrad(dz, width, x, k, S, width, k, grad_w[l], grad_b[l], gemm_ws, gemm_ws_bytes, st));
+        M360_PROF(h, st, M360_K_WGRAD, S, width, k, m360_linear_wgrad(dz, width, x, k, S, width, k, grad_w[l], grad_b[l], gemm_ws, gemm_ws_bytes, st));
         if (l > 0) {
             if (!w_t[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: transposed weight of layer %d is null", who, l);
-            M360_TRY(m360_linear_dgrad(dz, S, width, w_t[l], width, width, act[l - 1], dz_other, width, st));
+            M360_PROF(h, st, M360_K_DGRAD, S, width, width, m360_linear_dgrad(dz, S, width, w_t[l], width, width, act[l - 1], dz_other, width, st));
             float *tmp = dz; dz = dz_other; dz_other = tmp;
         }
     }
@@ -425,7 +480,7 @@ int m360_prop_backward(const m360_rays_t *rays, const m360_model_t *model, const
     for (int l = 0; l < 4; ++l) act[l] = reinterpret_cast<float *>(tp + T.act[l]);
     float *dz = reinterpret_cast<float *>(ws + L.dz_a), *dz2 = reinterpret_cast<float *>(ws + L.dz_b);
     M360_TRY(m360_prop_finish_backward(act[3], hp, model->prop_head_w, model->prop_head_b, hp, hyper->density_bias, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, grad_w_hat, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, stream));
-    return mlp_backward(4, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hp, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_prop_backward");
+    return mlp_backward(hyper, 4, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hp, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_prop_backward");
 }
 
 int m360_nerf_backward(const m360_rays_t *rays, const m360_model_t *model, const m360_mlp_transposed_t *wt,
@@ -447,7 +502,7 @@ int m360_nerf_backward(const m360_rays_t *rays, const m360_model_t *model, const
     for (int l = 0; l < 8; ++l) act[l] = reinterpret_cast<float *>(tp + T.act[l]);
     float *dz = reinterpret_cast<float *>(ws + L.dz_a), *dz2 = reinterpret_cast<float *>(ws + L.dz_b);
     M360_TRY(m360_nerf_finish_backward(act[7], hn, model->nerf_head_w, model->nerf_head_b, hn, hyper->density_bias, hyper->rgb_padding, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, hyper->white_bkgd, grad_rgb, grad_distance, grad_acc, grad_weights, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, stream));
-    return mlp_backward(8, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hn, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_nerf_backward");
+    return mlp_backward(hyper, 8, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hn, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_nerf_backward");
 }
 
 /* ------------------------------------------------------------------ one batch sharded over devices */

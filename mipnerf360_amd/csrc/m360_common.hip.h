@@ -17,9 +17,6 @@ constexpr int kIpeCh = 2 * kIpeDirs; // 42
 // host-side error plumbing (m360_capi.hip)
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
-// optional event timing of m360_linear launches (m360_capi.hip)
-int prof_begin(hipStream_t st, long M, int n_pad, int k_pad);
-void prof_end(int idx, hipStream_t st);
 // deterministic column sums of a row-major [R, C] matrix (m360_linear.hip): scratch holds slices * C floats
 int launch_colsum(const float *in, long R, int C, int ld, float *scratch, int slices, float *out, hipStream_t st);
 

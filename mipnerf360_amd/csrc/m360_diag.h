@@ -1,0 +1,16 @@
+/* Private to the diagnostics build (make diag -> libm360_diag.so); NOT part of the C-ABI in include/m360.h. */
+#pragma once
+#include "../../include/m360.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Diagnostics build only (make -C mipnerf360_amd/csrc diag -> libm360_diag.so; never shipped, never loaded by the
+ * package): kernels instrumented with s_memtime / s_memrealtime stamps, see tools/. */
+int m360_diag_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
+                     float *y, int ldy, m360_stream_t stream);
+int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
+                          int k_pad, void *y, int ldy, m360_stream_t stream);
+int m360_diag_read_stamps(unsigned long long *out_host, int n);
+#ifdef __cplusplus
+}
+#endif

@@ -13,12 +13,14 @@
 //   The K index inside each group of 8 is permuted (lane half h takes k = 8g+4h+s for MFMA
 //   step s) so one ds_read_b128 feeds four consecutive MFMAs for A and for B alike.
 //   Workgroup ids are remapped so the 4 N-tiles of one M-tile run on the same XCD (shared L2).
-#include "m360_common.cuh"
-#include "m360_linear_persist.cuh"
-#include "m360_linear_pp.cuh"
-#include "m360_linear_bf16.cuh"
-#include "m360_linear_bf16_pp.cuh"
-#include "m360_linear_tn.cuh"
+#include "m360_common.hip.h"
+#include "m360_linear_persist.hip.h"
+#include "m360_linear_bf16.hip.h"
+#include "m360_linear_bf16_pp.hip.h"
+#include "m360_linear_tn.hip.h"
+#ifdef M360_DIAG
+#include "m360_diag.h"
+#endif
 
 namespace m360 {
 
@@ -238,41 +240,24 @@ int launch_colsum(const float *in, long R, int C, int ld, float *scratch, int sl
 
 using namespace m360;
 
-static int g_linear_variant = 2;  // 1 = one workgroup per tile (register staging), 2 = persistent + LDS-DMA
-static int g_bf16_variant = 2;    // bf16: 1 = persistent, one wave per SIMD; 2 = 8-wave ping-pong (m360_linear_bf16_pp.cuh)
-
+// CU count of the CURRENT device (the persistent kernels launch one workgroup per CU); cached per device
 static int cu_count() {
-    static int cached = -1;
-    if (cached < 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            return 0;
-        }
-        cached = n;
+    static int cached[64];  // zero-initialised; a benign race at worst queries twice
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
     }
-    return cached;
+    if (dev >= 0 && dev < 64 && cached[dev] > 0) return cached[dev];
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (dev >= 0 && dev < 64) cached[dev] = n;
+    return n;
 }
 
 extern "C" {
-
-int m360_debug_set_linear_variant(int variant) {
-    if (variant >= 11 && variant <= 13) {  // 13 = 12 with cycle stamps (ReLU only)  // 11 / 12: select the bf16 kernel (A/B switch, see the header)
-        g_bf16_variant = variant - 10;
-        return M360_OK;
-    }
-    if (variant < 1 || variant > 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_debug_set_linear_variant: %d", variant);
-    g_linear_variant = variant;
-    return M360_OK;
-}
-
-// diagnostic: copy the cycle stamps of the last variant-3 (stamped) launch to the host
-int m360_debug_read_stamps(unsigned long long *out_host, int n) {
-    if (!out_host || n < 0 || n > 256 * 8) return fail(M360_ERR_INVALID_ARGUMENT, "m360_debug_read_stamps: bad argument");
-    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(persist::g_stamps), sizeof(unsigned long long) * n) != hipSuccess)
-        return fail(M360_ERR_LAUNCH, "m360_debug_read_stamps: copy failed");
-    return M360_OK;
-}
 
 int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                      float *w_packed, float *b_packed, m360_stream_t stream) {
@@ -297,32 +282,20 @@ static int launch_linear(const float *x, long M, int ldx, const float *w_packed,
     if (nwg > 0x7fffffffL) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: grid too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID && act != M360_ACT_RELU_MASK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: unknown activation %d", act);
-    const int prof = prof_begin(st, M, n_pad, k_pad);
     // Persistent LDS-DMA kernel on the full 256-row tiles when the width is a multiple of 256; ragged rows
     // (and narrow layers) go to the workgroup-per-tile kernel.  Both produce bit-identical results.
-    const long M_full = (g_linear_variant != 1 && n_pad % persist::BN == 0) ? (M / persist::BM) * persist::BM : 0;
+    const long M_full = (n_pad % persist::BN == 0) ? (M / persist::BM) * persist::BM : 0;
     if (M_full > 0) {
         const int cus = cu_count();
         if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear: no HIP device");
         const long nt = (M_full / persist::BM) * (n_pad / persist::BN);
         const int ntiles = (int)nt;
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(persist::kThreads);
-        if (g_linear_variant == 4 && act != M360_ACT_RELU_MASK && n_pad <= pp32::kMaxBias) {  // 8-wave ping-pong kernel
-            dim3 grid8((unsigned)(nt < cus ? nt : cus)), block8(pp32::kThreads);
-            switch (act) {
-                case M360_ACT_NONE: hipLaunchKernelGGL(pp32::linear_f32_pp_kernel<M360_ACT_NONE>, grid8, block8, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / pp32::BN, ntiles); break;
-                case M360_ACT_RELU: hipLaunchKernelGGL(pp32::linear_f32_pp_kernel<M360_ACT_RELU>, grid8, block8, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / pp32::BN, ntiles); break;
-                default: hipLaunchKernelGGL(pp32::linear_f32_pp_kernel<M360_ACT_SIGMOID>, grid8, block8, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / pp32::BN, ntiles); break;
-            }
-        } else if (g_linear_variant == 3) {  // diagnostic build with cycle stamps (ReLU only)
-            hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU, true>), grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles);
-        } else {
-            switch (act) {
-                case M360_ACT_NONE: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
-                case M360_ACT_RELU: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
-                case M360_ACT_RELU_MASK: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU_MASK>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles, aux); break;
-                default: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
-            }
+        switch (act) {
+            case M360_ACT_NONE: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
+            case M360_ACT_RELU: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
+            case M360_ACT_RELU_MASK: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU_MASK>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles, aux); break;
+            default: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
         }
     }
     if (M > M_full) {
@@ -338,7 +311,6 @@ static int launch_linear(const float *x, long M, int ldx, const float *w_packed,
             default: hipLaunchKernelGGL(linear_f32_mfma_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xt, Mt, ldx, w_packed, b_packed, n_pad, k_pad, yt, ldy, tiles_n); break;
         }
     }
-    prof_end(prof, st);
     return check_launch("linear");
 }
 
@@ -371,7 +343,6 @@ static void wgrad_plan(long M, int n_pad, int k_pad, int *ntiles, int *nsplit, l
     *nsplit = (int)ns;
     *steps_per_split = ns > 0 ? (*total_steps + ns - 1) / ns : 0;
 }
-static constexpr int kBiasSlices = 64;
 static inline size_t up256_(size_t v) { return (v + 255) & ~(size_t)255; }
 
 size_t m360_linear_wgrad_workspace_bytes(long M, int n_pad, int k_pad) {
@@ -395,10 +366,8 @@ int m360_linear_wgrad(const float *dz, int ldz, const float *x, int ldx, long M,
     wgrad_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
     float *partial = static_cast<float *>(workspace);
     float *bias_part = reinterpret_cast<float *>(static_cast<char *>(workspace) + up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)));
-    const int prof = prof_begin(st, M, n_pad, k_pad);
     if (nsplit > 0)
         hipLaunchKernelGGL(tn::linear_tn_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn::kThreads), 0, st, dz, ldz, x, ldx, n_pad, k_pad, partial, (k_pad + tn::BT - 1) / tn::BT, ntiles, nsplit, total, per, grad_b ? bias_part : nullptr);
-    prof_end(prof, st);
     const long count4 = (long)n_pad * k_pad / 4;
     hipLaunchKernelGGL(tn::tn_reduce_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, partial, nsplit, n_pad, k_pad, dz, ldz, x, ldx, total * tn::BKM, M, grad_w);
     if (grad_b) hipLaunchKernelGGL(tn::tn_bias_reduce_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, bias_part, nsplit, n_pad, dz, ldz, total * tn::BKM, M, grad_b);
@@ -443,17 +412,13 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *xb = static_cast<const __bf16 *>(x), *wb = static_cast<const __bf16 *>(w_packed);
     __bf16 *yb = static_cast<__bf16 *>(y);
-    const int prof = prof_begin(st, M, n_pad, -k_pad);  // negative k marks bf16 launches in the event records
     const long M_full = (n_pad % pbf16::BN == 0) ? (M / pbf16::BM) * pbf16::BM : 0;
     if (M_full > 0) {
         const int cus = cu_count();
         if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear_bf16: no HIP device");
         const long nt = (M_full / pbf16::BM) * (n_pad / pbf16::BN);
-        const bool pp_ok = k_pad >= 2 * pp16::BK && n_pad <= pp16::kMaxBias;  // else the one-wave-per-SIMD kernel
-        if (g_bf16_variant == 3 && pp_ok) {  // diagnostic: ping-pong kernel with s_memtime stamps
-            dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
-            hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt);
-        } else if (g_bf16_variant == 2 && pp_ok) {  // 8-wave ping-pong kernel, persistent
+        const bool pp_ok = k_pad >= 2 * pp16::BK && n_pad <= pp16::kMaxBias;  // else (the K = 64 first layer) the one-wave-per-SIMD kernel
+        if (pp_ok) {  // 8-wave ping-pong kernel, persistent
             dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
             switch (act) {
                 case M360_ACT_NONE: hipLaunchKernelGGL(pp16::linear_bf16_pp_kernel<M360_ACT_NONE>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
@@ -461,12 +426,12 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
                 default: hipLaunchKernelGGL(pp16::linear_bf16_pp_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
             }
         } else {
-        dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pbf16::kThreads);
-        switch (act) {
-            case M360_ACT_NONE: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
-            case M360_ACT_RELU: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
-            default: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
-        }
+            dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pbf16::kThreads);
+            switch (act) {
+                case M360_ACT_NONE: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
+                case M360_ACT_RELU: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
+                default: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pbf16::BN, (int)nt); break;
+            }
         }
     }
     if (M > M_full) {
@@ -480,8 +445,37 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
             default: hipLaunchKernelGGL(pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k_pad, yt, ldy); break;
         }
     }
-    prof_end(prof, st);
     return check_launch("linear_bf16");
 }
+
+#ifdef M360_DIAG
+// ---- diagnostics build only (libm360_diag.so): the two hot kernels instrumented with cycle stamps (ReLU epilogue)
+int m360_diag_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
+                     float *y, int ldy, m360_stream_t stream) {
+    if (!x || !w_packed || !b_packed || !y || M < persist::BM || M % persist::BM || n_pad % persist::BN || k_pad % BK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear: full 256 x 256 tiles only");
+    const int cus = cu_count();
+    const long nt = (M / persist::BM) * (n_pad / persist::BN);
+    dim3 grid((unsigned)(nt < cus ? nt : cus)), block(persist::kThreads);
+    hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU, true>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, (int)nt);
+    return check_launch("diag_linear");
+}
+
+int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
+                          int k_pad, void *y, int ldy, m360_stream_t stream) {
+    if (!x || !w_packed || !b_packed || !y || M < pp16::BM || M % pp16::BM || n_pad % pp16::BN || k_pad % pp16::BK || k_pad < 2 * pp16::BK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: full 256 x 256 tiles, k_pad >= 128 only");
+    const int cus = cu_count();
+    const long nt = (M / pp16::BM) * (n_pad / pp16::BN);
+    dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
+    hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, true>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), static_cast<const __bf16 *>(x), M, ldx, static_cast<const __bf16 *>(w_packed), b_packed, n_pad, k_pad, static_cast<__bf16 *>(y), ldy, n_pad / pp16::BN, (int)nt);
+    return check_launch("diag_linear_bf16");
+}
+
+int m360_diag_read_stamps(unsigned long long *out_host, int n) {
+    if (!out_host || n < 0 || n > 256 * 8) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_read_stamps: bad argument");
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(persist::g_stamps), sizeof(unsigned long long) * n) != hipSuccess)
+        return fail(M360_ERR_LAUNCH, "m360_diag_read_stamps: copy failed");
+    return M360_OK;
+}
+#endif
 
 }  // extern "C"

@@ -1,14 +1,14 @@
 // bf16-input / fp32-accumulate linear kernel (opt-in reduced-precision MLP, BASELINE configs[4]):
 // y[M,Np] (bf16) = act(x[M,Kp] (bf16) * W^T (bf16) + b (fp32)) on v_mfma_f32_32x32x16_bf16.
 //
-// Same skeleton as the fp32 kernel (m360_linear_persist.cuh): persistent workgroups of 4 waves (one per
+// Same skeleton as the fp32 kernel (m360_linear_persist.hip.h): persistent workgroups of 4 waves (one per
 // SIMD, 512 registers each), 256 x 256 tiles, 128-byte LDS rows filled by global_load_lds_dwordx4 with the
 // source-side XOR swizzle, inline-asm ds_read_b128 with waits tied to the fragment registers, LDS-transposed
 // wide-store epilogue.  Differences: a K-step is 64 bf16 (the same 128 bytes per row), one 16-byte chunk per
 // lane IS one MFMA operand (lane (r,h) holds k = 8h..8h+7 of row r), so a K-group is 16 MFMAs of 32 cycles,
 // and everything that is not an MFMA is 8x more expensive relative to the matrix work than in fp32.
 #pragma once
-#include "m360_common.cuh"
+#include "m360_common.hip.h"
 
 namespace m360 {
 namespace pbf16 {

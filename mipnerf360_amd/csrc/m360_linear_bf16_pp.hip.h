@@ -1,6 +1,6 @@
 // Second bf16 linear kernel (opt-in reduced-precision MLP, BASELINE configs[4]): 8 waves = two per SIMD in "ping-pong".
 //
-// Why a second structure: with ONE wave per SIMD (m360_linear_bf16.cuh) every LDS-DMA issue (~100-185 cycles while the
+// Why a second structure: with ONE wave per SIMD (m360_linear_bf16.hip.h) every LDS-DMA issue (~100-185 cycles while the
 // phase also carries ds_reads) is exposed against only 2048 MFMA cycles per K-step, and the kernel stops at ~36 % of the
 // bf16 peak.  Here the 256 x 256 tile is shared by 8 waves (2 along M x 4 along N, wave tile 128 x 64 = 8 x 4 blocks of
 // v_mfma_f32_16x16x32_bf16 -> 128 accumulator registers).  A K-step (64 bf16) is 4 phases; every phase is
@@ -18,8 +18,8 @@
 // rows and f = 2((r>>4)&3) + ((r>>1)&1) for weight rows (their 16-lane read groups touch rows 16a + b): either way a
 // 16-lane ds_read_b128 group covers 16 distinct 16-byte slots.
 #pragma once
-#include "m360_common.cuh"
-#include "m360_linear_persist.cuh"  // diagnostic stamp buffer
+#include "m360_common.hip.h"
+#include "m360_linear_persist.hip.h"  // diagnostic stamp buffer
 
 namespace m360 {
 namespace pp16 {
@@ -375,11 +375,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PP_STAMP(ts3);
         if (tid == 0 && blockIdx.x < 256) {
-            persist::g_stamps[blockIdx.x * 8 + 0] = ts1 - ts0;
-            persist::g_stamps[blockIdx.x * 8 + 1] = ts2 - ts1;
-            persist::g_stamps[blockIdx.x * 8 + 2] = ts3 - ts2;
-            persist::g_stamps[blockIdx.x * 8 + 3] = ts0;
-            persist::g_stamps[blockIdx.x * 8 + 4] = ts3;
+            using namespace persist;
+            M360_STAMP_STORE(0, ts1 - ts0);
+            M360_STAMP_STORE(1, ts2 - ts1);
+            M360_STAMP_STORE(2, ts3 - ts2);
+            M360_STAMP_STORE(3, ts0);
+            M360_STAMP_STORE(4, ts3);
         }
     }
 #undef PP_STAMP

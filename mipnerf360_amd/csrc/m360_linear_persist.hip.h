@@ -5,7 +5,8 @@
 //     XCD-aware (the 32 workgroups of one XCD sweep 8 M-tiles x 4 N-tiles that share activation
 //     rows in that XCD's L2).  Wave tile 128 x 128 = 4 x 4 MFMA tiles -> 256 accumulator registers.
 //   * A/B K-step tiles (256 rows x 32 floats each) go global -> LDS directly with
-//     global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass), double-buffered.  LDS rows are
+//     buffer_load_dwordx4 ... lds (LDS-DMA: no staging VGPRs, no ds_write pass; tile base in a buffer descriptor,
+//     one tile-independent 32-bit lane offset per instruction, K offset = scalar offset), double-buffered.  LDS rows are
 //     unpadded 128 B; bank conflicts are removed by an XOR swizzle applied on the per-lane SOURCE
 //     address (16-B chunk c of row r lands in slot c ^ ((r>>1)&7)) and mirrored on the
 //     ds_read_b128 side.
@@ -15,7 +16,7 @@
 //     behind matrix work.  The DMA of the next K-step is issued in between MFMA slices.
 //   * the first K-step of the NEXT tile is already in flight while a tile's epilogue runs.
 #pragma once
-#include "m360_common.cuh"
+#include "m360_common.hip.h"
 
 namespace m360 {
 namespace persist {
@@ -45,7 +46,12 @@ __device__ __forceinline__ float act_fn(float v) {
 // diagnostic cycle stamps (STAMP builds only; never used by the product path): per workgroup, summed
 // over all K-steps: [0] group0+DMA issue, [1] group1, [2] group2, [3] DMA-wait+barrier, [4] group3,
 // [5] whole K-step, [6] K-steps, [7] epilogue
+#ifdef M360_DIAG
 __device__ unsigned long long g_stamps[256 * 8];
+#define M360_STAMP_STORE(i, v) g_stamps[blockIdx.x * 8 + (i)] = (v)
+#else
+#define M360_STAMP_STORE(i, v) ((void)(v))
+#endif
 
 template <int ACT, bool STAMP = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
@@ -77,10 +83,6 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     // The kernel only ever sees FULL 256 x 256 tiles (M and Np multiples of 256): the host sends ragged
     // rows / columns to the first-generation kernel, which is bit-identical.
     const int st_r = wave * 64 + (lane >> 3);  // row of DMA instruction q = st_r + 8 q
-#ifndef M360_PERSIST_BUFFER_DMA
-#define M360_PERSIST_BUFFER_DMA 1  // 1: buffer_load ... lds (descriptor + 32-bit lane offset + scalar K offset); 0: global_load_lds
-#endif
-#if M360_PERSIST_BUFFER_DMA
     // per-lane byte offsets inside a tile (tile-independent); the tile base lives in two buffer descriptors (SGPRs) and
     // the K offset is the instruction's scalar offset: no vector address arithmetic per K-step or per tile
     unsigned a_voff[kDma], b_voff[kDma];
@@ -103,26 +105,6 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         if (which & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)dstA, 16, a_voff[q], 4 * k0, 0, 0);
         if (which & 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(dstA + kTileFloats), 16, b_voff[q], 4 * k0, 0, 0);
     };
-#else
-    const float *ga[kDma];
-    const float *gb[kDma];
-    auto set_load_tile = [&](long m0, int n0) M360_INL {  // full tiles only: no row clamping needed
-#pragma unroll
-        for (int q = 0; q < kDma; ++q) {
-            const int r = st_r + 8 * q;
-            const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-            ga[q] = X + (m0 + r) * ldx + 4 * chunk;
-            gb[q] = W + (long)(n0 + r) * Kp + 4 * chunk;
-        }
-    };
-    float *const dma_dst = smem + st_r * 0 + wave * 64 * BK;  // + buf * kBufFloats + q * 8 * BK
-    // which: 1 = A rows, 2 = B rows, 3 = both (row-block q of this wave's 64-row slice)
-    auto issue_dma = [&](int buf, int k0, int q, int which) M360_INL {
-        float *dstA = dma_dst + buf * kBufFloats + q * 8 * BK;
-        if (which & 1) __builtin_amdgcn_global_load_lds(ga[q] + k0, (lds_ptr_t)dstA, 16, 0, 0);
-        if (which & 2) __builtin_amdgcn_global_load_lds(gb[q] + k0, (lds_ptr_t)(dstA + kTileFloats), 16, 0, 0);
-    };
-#endif
 
     // ---- operand reads: lane (l31, h), K-group g reads chunk (2g+h) of its rows = slot (2g+h)^f.
     // The reads are inline asm with hand-counted lgkmcnt waits: with LDS-DMA in flight hipcc would
@@ -159,40 +141,13 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                        \
                  : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FB[0]), "+v"(FB[1]),    \
                    "+v"(FB[2]), "+v"(FB[3])::"memory")
-#define M360_COMP(v, s) ((v)[s])
-#define M360_SLICE(FA, FB, s)                                                                          \
-    do {                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(M360_COMP(FA[i], s), M360_COMP(FB[j], s), \
-                                                             acc[i][j], 0, 0, 0);                      \
-    } while (0)
-#define M360_GROUP(FA, FB)                                                                             \
-    do {                                                                                               \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s) M360_SLICE(FA, FB, s);                           \
-    } while (0)
 #define M360_SB() __builtin_amdgcn_sched_barrier(0)
-#ifndef M360_PERSIST_DIRECT_EPILOGUE
-#define M360_PERSIST_DIRECT_EPILOGUE 0  // 1: operands swapped (A := weight rows), 16-byte stores straight from the accumulators.
-                                        // Measured A/B (same process, bit-identical): 145.4 TF against 148.0 TF for the
-                                        // LDS-transposed epilogue - 32 contiguous bytes per row and store lose to whole
-                                        // 128-byte lines - so the experiment stays off.
-#endif
-// 8 MFMAs: rows i0, i0+1 of the wave tile x 4 columns, k-pair s of the current K-group.  With the operands swapped
-// (A := weight rows, B := activation rows) the same products are summed in the same order - bit-identical - but a
-// lane's registers 4t..4t+3 become 4 consecutive output COLUMNS of one row: no LDS transposition in the epilogue.
-#if M360_PERSIST_DIRECT_EPILOGUE
-#define M360_MFMA8(FA, FB, s, i0)                                                                      \
-    do {                                                                                               \
-        _Pragma("unroll") for (int i = (i0); i < (i0) + 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FB[j][s], FA[i][s], acc[i][j], 0, 0, 0);  \
-    } while (0)
-#else
+// 8 MFMAs: rows i0, i0+1 of the wave tile x 4 columns, k-pair s of the current K-group
 #define M360_MFMA8(FA, FB, s, i0)                                                                      \
     do {                                                                                               \
         _Pragma("unroll") for (int i = (i0); i < (i0) + 2; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i][s], FB[j][s], acc[i][j], 0, 0, 0);  \
     } while (0)
-#endif
 // One K-group = 8 units of 8 MFMAs on fragment (FA, FB).  After each unit ONE ds_read_b128 of the NEXT
 // K-group (into the other fragment NA/NB, byte addresses na/nb) and, when DMA is 1, the two LDS-DMA
 // instruction(s) of row-block q = unit of the next K-step are issued (DMA: 1 = A half, 2 = B half,
@@ -298,55 +253,6 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         }
         M360_STAMP(c0);
 
-#if M360_PERSIST_DIRECT_EPILOGUE
-        // ---- epilogue: bias + activation.  Swapped operands: lane (l31, h) holds row m = block*32 + l31 and, in registers
-        // 4t..4t+3 of a block, the 4 consecutive columns 8t + 4h + 0..3: one 16-byte store each, the two lane halves
-        // together 32 contiguous bytes per row, the four t a whole 128-byte line.
-        {
-            int ldy_t = ldy;
-            asm volatile("" : "+s"(ldy_t));  // keep the address math inside the tile loop (LICM would spill it)
-            float *__restrict__ Yt = Y + (m0 + wm * 128 + l31) * ldy_t + n0 + wn * 128 + 4 * h;
-            // the last MFMAs were issued a few cycles ago: give the first accumulators read below time to retire
-            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float4 b4[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    b4[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (ACT != M360_ACT_RELU_MASK) b4[t] = *reinterpret_cast<const float4 *>(bias + n0 + wn * 128 + j * 32 + 8 * t + 4 * h);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const long yoff = (long)(i * 32) * ldy_t + j * 32;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        // explicit AGPR -> VGPR moves, four at a time: left to the compiler, all 256 accumulator reads are
-                        // clustered and the loop-invariant DMA offsets get spilled into the K-loop
-                        float4 v;
-                        asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\t"
-                                     "v_accvgpr_read_b32 %3, %7\n\ts_nop 1"
-                                     : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w)
-                                     : "a"(acc[i][j][4 * t]), "a"(acc[i][j][4 * t + 1]), "a"(acc[i][j][4 * t + 2]), "a"(acc[i][j][4 * t + 3]));
-                        if (ACT == M360_ACT_RELU_MASK) {  // backward of ReLU: keep where the forward output (aux, same ld) was > 0
-                            const float4 a4 = *reinterpret_cast<const float4 *>(aux + (Yt - Y) + yoff + 8 * t);
-                            v.x = a4.x > 0.0f ? v.x : 0.0f;
-                            v.y = a4.y > 0.0f ? v.y : 0.0f;
-                            v.z = a4.z > 0.0f ? v.z : 0.0f;
-                            v.w = a4.w > 0.0f ? v.w : 0.0f;
-                        } else {
-                            v.x = act_fn<ACT>(v.x + b4[t].x);
-                            v.y = act_fn<ACT>(v.y + b4[t].y);
-                            v.z = act_fn<ACT>(v.z + b4[t].z);
-                            v.w = act_fn<ACT>(v.w + b4[t].w);
-                        }
-                        *reinterpret_cast<float4 *>(Yt + yoff + 8 * t) = v;
-                        M360_SB();  // one quad at a time: keeps the accumulator reads from being hoisted into spills
-                    }
-                }
-            }
-        }
-#else
         // ---- epilogue: bias + activation.  The accumulator layout (lane = column l31, 16 registers =
         // rows (r&3)+8(r>>2)+4h) would store 4 B per lane; interior tiles are instead transposed
         // through the idle LDS buffer (wave-private 32 x 36 floats) so that every lane stores 16 B and one
@@ -391,21 +297,17 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
                 }
             }
         }
-#endif
         M360_STAMP(c1);
         if (STAMP) st[7] += c1 - c0;
     }
     if (STAMP && threadIdx.x == 0 && blockIdx.x < 256) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) g_stamps[blockIdx.x * 8 + i] = st[i];
+        for (int i = 0; i < 8; ++i) M360_STAMP_STORE(i, st[i]);
     }
 #undef M360_STAMP
 #undef M360_READ
 #undef M360_DS128
 #undef M360_WAIT_FRAG
-#undef M360_COMP
-#undef M360_SLICE
-#undef M360_GROUP
 #undef M360_SB
 }
 

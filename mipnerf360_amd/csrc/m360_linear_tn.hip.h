@@ -16,8 +16,8 @@
 //     store).  Reads are conflict-free (16 lanes cover 256 contiguous bytes).
 //   * ids are XCD-aware: the workgroups of one split (same rows, all tiles) are neighbours on one XCD's L2.
 #pragma once
-#include "m360_common.cuh"
-#include "m360_linear_persist.cuh"
+#include "m360_common.hip.h"
+#include "m360_linear_persist.hip.h"
 
 namespace m360 {
 namespace tn {

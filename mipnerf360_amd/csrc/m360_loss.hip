@@ -4,7 +4,7 @@
 //   * proposal / envelope loss:   intern/distillation.py:4-51, intern/loss.py:6-21
 //   * distortion loss:            intern/regularization.py:3-19, intern/loss.py:42-54 (the O(N^2) Python loop)
 //   * reconstruction (log-MSE):   intern/loss.py:23-40,57-59
-#include "m360_common.cuh"
+#include "m360_common.hip.h"
 
 namespace m360 {
 

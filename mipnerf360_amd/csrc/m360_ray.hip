@@ -6,7 +6,7 @@
 // in that wave's private LDS slice; prefix sums are wave-level Hillis-Steele scans in fp64
 // (torch's CPU cumsum accumulates fp32 in double; this also keeps the CDF monotone) with a
 // carry across 64-sample chunks, so any N works.  All of these kernels are HBM-bound.
-#include "m360_common.cuh"
+#include "m360_common.hip.h"
 
 namespace m360 {
 

@@ -3,7 +3,7 @@
 // (dataset.py:364-387, intern/ray.py:59-79).  Removes the 48 B/ray host->device stream for frame /
 // video rendering: only the 48-byte pose per camera crosses PCIe.  One thread per pixel, everything
 // recomputed from the pose (neighbour pixels included), 48 B/ray of coalesced SoA stores: HBM-bound.
-#include "m360_common.cuh"
+#include "m360_common.hip.h"
 
 namespace m360 {
 

@@ -1,7 +1,7 @@
 // Sampling, conical-frustum gaussians, the reference's whole-tensor "contraction" and the
 // encodings.  All kernels here are HBM/VALU-bound elementwise or
 // reduction kernels: one thread per sample, coalesced SoA ray loads, LDS-staged feature rows.
-#include "m360_common.cuh"
+#include "m360_common.hip.h"
 
 namespace m360 {
 

@@ -3,7 +3,7 @@
 // style callers get finished frames without a trip through NumPy / scipy / matplotlib.
 // All kernels are per-pixel and HBM-bound; the image statistics (min / max / variances) are a
 // deterministic two-level fp64 reduction (fixed partition), like the contraction norm.
-#include "m360_common.cuh"
+#include "m360_common.hip.h"
 #include "m360_turbo_lut.h"
 
 namespace m360 {

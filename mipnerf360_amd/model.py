@@ -26,7 +26,7 @@ from . import _lib, ops
 from .intern.encoding import PositionalEncoding, ViewdirectionEncoding
 from .intern.ray import Rays, namedtuple_map
 
-_WORKSPACES: Dict[torch.device, torch.Tensor] = {}
+_WORKSPACES: Dict[tuple, torch.Tensor] = {}
 
 
 def _kaiming_init(model):
@@ -37,14 +37,21 @@ def _kaiming_init(model):
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-device scratch buffer (single-stream use, like the reference)."""
+    """Grow-only scratch buffer per (device, stream): work queued on different streams (a second model rendering on a
+    side stream, eval overlapped with training) never shares scratch, and everything launched on one stream is
+    ordered by that stream.  A buffer that is outgrown goes back to torch's caching allocator, which is stream-aware
+    for the stream it was allocated on - the one it was used on."""
     device = torch.device(device)
-    ws = _WORKSPACES.get(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < nbytes:
-        _WORKSPACES.pop(device, None)
+        _WORKSPACES.pop(key, None)
         ws = None
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _WORKSPACES[device] = ws
+        with torch.cuda.device(device):
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
     return ws
 
 
@@ -66,10 +73,17 @@ class _PackedMLP:
     def _key(params):
         return tuple((p.data_ptr(), p._version, p.device) for p in params)
 
-    def refresh(self, hidden_layers, heads, bf16: bool = False) -> "_PackedMLP":
+    def invalidate(self) -> None:
+        self.key = None
+
+    def refresh(self, hidden_layers, heads, bf16: bool = False, always: bool = False) -> "_PackedMLP":
+        """`always`: re-pack even when the (data_ptr, version) key is unchanged.  Writes through `.data`
+        (`p.data.mul_()`, EMA swaps, weight clamping) do not bump a tensor's version counter, so in training mode
+        - where parameters are expected to change between forwards - the packing is rebuilt on every forward
+        (13 small kernels, ~30 MB); in eval mode the key decides, and `invalidate_packed()` forces a rebuild."""
         params = [p for lin in list(hidden_layers) + list(heads) for p in (lin.weight, lin.bias)]
         key = self._key(params) + (bool(bf16),)
-        if key == self.key:
+        if key == self.key and not always:
             return self
         first = hidden_layers[0]
         ops._require_device(first.weight, "model parameters")
@@ -96,12 +110,16 @@ def _rays_struct(rays):
     for f, t in zip(Rays._fields, keep):
         if t.shape[0] != B:
             raise RuntimeError(f"rays.{f} has {t.shape[0]} rows, expected {B}")
+        if t.device != keep[0].device:
+            raise RuntimeError(f"rays.{f} is on {t.device}, rays.{Rays._fields[0]} on {keep[0].device}")
     return _lib.RaysStruct(*[t.data_ptr() for t in keep]), keep, B
 
 
-def _model_struct(in_ch, prop: Optional[_PackedMLP], nerf: Optional[_PackedMLP]):
+def _model_struct(in_ch, prop: Optional[_PackedMLP], nerf: Optional[_PackedMLP], device=None):
     m = _lib.ModelStruct()
     ref = prop or nerf
+    if device is not None and ref.head_w.device != device:
+        raise RuntimeError(f"model parameters are on {ref.head_w.device}, rays on {device}")
     m.in_ch, m.in_pad = in_ch, ref.in_pad
     m.hp_pad = (prop or nerf).h_pad
     m.hn_pad = (nerf or prop).h_pad
@@ -120,9 +138,11 @@ def _model_struct(in_ch, prop: Optional[_PackedMLP], nerf: Optional[_PackedMLP])
 
 
 def _hyper_struct(num_samples, min_deg, max_deg, white_bkgd=False, density_bias=-1.0, rgb_padding=0.001,
-                  resample_padding=0.01):
-    return _lib.HyperStruct(int(num_samples), int(min_deg), int(max_deg), int(bool(white_bkgd)), float(density_bias),
-                            float(rgb_padding), float(resample_padding))
+                  resample_padding=0.01, prof=None):
+    h = _lib.HyperStruct(int(num_samples), int(min_deg), int(max_deg), int(bool(white_bkgd)), float(density_bias),
+                         float(rgb_padding), float(resample_padding))
+    h.prof = prof.handle if prof is not None else None  # optional _lib.Prof event recorder (bench.py, tools/)
+    return h
 
 
 def _wants_grad(module: nn.Module) -> bool:
@@ -139,6 +159,10 @@ class _TrainCtx:
     def __init__(self, module, stage, rays_keep, rstruct, B, N, hyper, packed, mstruct):
         self.module, self.stage, self.rays_keep, self.rstruct, self.B, self.N = module, stage, rays_keep, rstruct, B, N
         self.hyper, self.packed, self.mstruct = hyper, packed, mstruct
+        # mstruct holds raw pointers into THIS packing: keep its tensors alive until the backward even if a later
+        # forward of the same module re-packs (training mode re-packs on every forward)
+        self.packed_keep = (list(packed.w), list(packed.b), packed.head_w, packed.head_b)
+        self.h_pad = packed.h_pad
         dev = rays_keep[0].device
         lib = _lib.lib()
         self.tape = torch.empty(max(int(lib.m360_train_tape_bytes(B, N, C.byref(mstruct), stage)), 256), dtype=torch.uint8,
@@ -159,9 +183,9 @@ class _TrainCtx:
         lib = _lib.lib()
         layers, heads = module._layers()
         L, H = len(layers), sum(h.out_features for h in heads)
-        gw = [torch.empty_like(w) for w in packed.w]
-        gb = [torch.empty_like(b) for b in packed.b]
-        ghw, ghb = torch.empty(H, packed.h_pad, device=dev), torch.empty(H, device=dev)
+        gw = [torch.empty_like(w) for w in self.packed_keep[0]]
+        gb = [torch.empty_like(b) for b in self.packed_keep[1]]
+        ghw, ghb = torch.empty(H, self.h_pad, device=dev), torch.empty(H, device=dev)
         gstruct, tstruct = _lib.MlpGradsStruct(), _lib.MlpTransposedStruct()
         for i in range(L):
             gstruct.w[i], gstruct.b[i] = gw[i].data_ptr(), gb[i].data_ptr()
@@ -174,17 +198,14 @@ class _TrainCtx:
             (g_w_hat,) = grad_args
             if g_w_hat is None:
                 g_w_hat = torch.zeros(self.B, self.N, device=dev)
-            _lib.check(lib.m360_prop_backward(C.byref(self.rstruct), C.byref(self.mstruct), C.byref(tstruct),
-                                              C.byref(self.hyper), self.B, self.tape.data_ptr(), self.tape.numel(),
-                                              g_w_hat.data_ptr(), C.byref(gstruct), ws.data_ptr(), ws.numel(),
-                                              ops.stream()), "m360_prop_backward")
+            ops.call("m360_prop_backward", C.byref(self.rstruct), C.byref(self.mstruct), C.byref(tstruct),
+                     C.byref(self.hyper), self.B, self.tape, self.tape.numel(), g_w_hat, C.byref(gstruct), ws,
+                     ws.numel(), ops.STREAM, device=dev)
         else:
             g_rgb, g_dist, g_acc, g_w = grad_args
-            _lib.check(lib.m360_nerf_backward(C.byref(self.rstruct), C.byref(self.mstruct), C.byref(tstruct),
-                                              C.byref(self.hyper), self.B, self.tape.data_ptr(), self.tape.numel(),
-                                              ops.ptr(g_rgb), ops.ptr(g_dist), ops.ptr(g_acc), ops.ptr(g_w),
-                                              C.byref(gstruct), ws.data_ptr(), ws.numel(), ops.stream()),
-                       "m360_nerf_backward")
+            ops.call("m360_nerf_backward", C.byref(self.rstruct), C.byref(self.mstruct), C.byref(tstruct),
+                     C.byref(self.hyper), self.B, self.tape, self.tape.numel(), g_rgb, g_dist, g_acc, g_w,
+                     C.byref(gstruct), ws, ws.numel(), ops.STREAM, device=dev)
         grads = []
         for i, lin in enumerate(layers):
             grads += [gw[i][:lin.out_features, :lin.in_features], gb[i][:lin.out_features]]
@@ -192,7 +213,7 @@ class _TrainCtx:
         for h in heads:
             grads += [ghw[row:row + h.out_features, :h.in_features], ghb[row:row + h.out_features]]
             row += h.out_features
-        self.tape = None  # one backward per forward, like autograd's freed buffers
+        self.tape = self.packed_keep = None  # one backward per forward, like autograd's freed buffers
         return [g.contiguous() for g in grads]
 
 
@@ -255,7 +276,11 @@ class prop_net(nn.Module):
 
     def _pack(self) -> _PackedMLP:
         return self._packed.refresh([self.model[i] for i in (0, 2, 4, 6)], [self.model[8]],
-                                    getattr(self, "mlp_bf16", False))
+                                    getattr(self, "mlp_bf16", False), always=self.training)
+
+    def invalidate_packed(self) -> None:
+        """Forget the packed copy of the weights: call after changing parameters through `.data` in eval mode."""
+        self._packed.invalidate()
 
     def density_to_weight(self, t_vals, density, dirs):
         """model.py:59-78."""
@@ -276,22 +301,20 @@ class prop_net(nn.Module):
         dev = keep[0].device
         N = self.num_samples
         packed = self._pack()
-        mstruct = _model_struct(self.input_size, packed, None)
-        hyper = _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, density_bias=self.density_bias)
+        mstruct = _model_struct(self.input_size, packed, None, dev)
+        hyper = _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, density_bias=self.density_bias,
+                              prof=getattr(self, "prof", None))
         t_hat = torch.empty(B, N + 1, device=dev)
         w_hat = torch.empty(B, N, device=dev)
         t_rand = torch.rand(B, N + 1, device=dev) if self.randomized else None
         ws = _ws_for(B, N, mstruct, dev)
         if train:
             tc = _TrainCtx(self, 0, keep, rstruct, B, N, hyper, packed, mstruct)
-            _lib.check(_lib.lib().m360_prop_forward_train(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B,
-                                                          ops.ptr(t_rand), t_hat.data_ptr(), w_hat.data_ptr(),
-                                                          tc.tape.data_ptr(), tc.tape.numel(), ws.data_ptr(), ws.numel(),
-                                                          ops.stream()), "m360_prop_forward_train")
+            ops.call("m360_prop_forward_train", C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, t_rand, t_hat,
+                     w_hat, tc.tape, tc.tape.numel(), ws, ws.numel(), ops.STREAM, device=dev)
             return t_hat, w_hat, tc
-        _lib.check(_lib.lib().m360_prop_forward(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, ops.ptr(t_rand),
-                                                t_hat.data_ptr(), w_hat.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                ops.stream()), "m360_prop_forward")
+        ops.call("m360_prop_forward", C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, t_rand, t_hat, w_hat, ws,
+                 ws.numel(), ops.STREAM, device=dev)
         return t_hat, w_hat
 
 
@@ -330,11 +353,16 @@ class nerf_net(nn.Module):
 
     def _pack(self) -> _PackedMLP:
         return self._packed.refresh([self.model[i] for i in range(0, 16, 2)],
-                                    [self.final_density[0], self.final_color[0]], getattr(self, "mlp_bf16", False))
+                                    [self.final_density[0], self.final_color[0]], getattr(self, "mlp_bf16", False),
+                                    always=self.training)
+
+    def invalidate_packed(self) -> None:
+        """Forget the packed copy of the weights: call after changing parameters through `.data` in eval mode."""
+        self._packed.invalidate()
 
     def _hyper(self, N, n_fine=0):
         h = _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, self.white_bkgd, self.density_bias,
-                          self.rgb_padding, self.resample_padding)
+                          self.rgb_padding, self.resample_padding, prof=getattr(self, "prof", None))
         h.num_samples_fine = int(n_fine or 0)
         return h
 
@@ -362,7 +390,7 @@ class nerf_net(nn.Module):
         t_vals, coarse_weights = ops.dev(t_vals, "t_vals"), ops.dev(coarse_weights, "coarse_weights")
         N = t_vals.shape[-1] - 1
         Nf = getattr(self, "num_samples_fine", None) or N  # extension; None = the reference's behaviour
-        mstruct = _model_struct(self.input_size, None, self._pack())
+        mstruct = _model_struct(self.input_size, None, self._pack(), dev)
         hyper = self._hyper(N, Nf)
         outs = _alloc_outputs(B, Nf, dev, with_prop=False)
         ostruct = _outputs_struct(outs)
@@ -370,15 +398,12 @@ class nerf_net(nn.Module):
         ws = _ws_for(B, max(N, Nf), mstruct, dev)
         if train:
             tc = _TrainCtx(self, 1, keep, rstruct, B, Nf, hyper, self._packed, mstruct)
-            _lib.check(_lib.lib().m360_nerf_forward_train(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B,
-                                                          t_vals.data_ptr(), coarse_weights.data_ptr(), ops.ptr(u_rand),
-                                                          C.byref(ostruct), tc.tape.data_ptr(), tc.tape.numel(),
-                                                          ws.data_ptr(), ws.numel(), ops.stream()),
-                       "m360_nerf_forward_train")
+            ops.call("m360_nerf_forward_train", C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, t_vals,
+                     coarse_weights, u_rand, C.byref(ostruct), tc.tape, tc.tape.numel(), ws, ws.numel(), ops.STREAM,
+                     device=dev)
             return (outs["rgb"], outs["distance"], outs["acc"], outs["t_vals"], outs["fine_w"], outs["s_vals"]), tc
-        _lib.check(_lib.lib().m360_nerf_forward(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, t_vals.data_ptr(),
-                                                coarse_weights.data_ptr(), ops.ptr(u_rand), C.byref(ostruct),
-                                                ws.data_ptr(), ws.numel(), ops.stream()), "m360_nerf_forward")
+        ops.call("m360_nerf_forward", C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, t_vals, coarse_weights,
+                 u_rand, C.byref(ostruct), ws, ws.numel(), ops.STREAM, device=dev)
         self._stash(outs)
         return outs["rgb"], outs["distance"], outs["acc"], self.t_vals, self.fine_weights, self.s_vals
 
@@ -426,6 +451,7 @@ class mipNeRF360(nn.Module):
         self.device = device
         self.init_randomized = randomized
         self.verbose = False
+        self.prof = None  # optional _lib.Prof event recorder: set through `set_prof()`
         self.super_batch_rays = 4096  # render_rays launches this many rays at once when `chunks` is smaller
         self.prop_net = prop_net(randomized=self.randomized, num_samples=self.num_samples,
                                  hidden_proposal=self.hidden_proposal, density_bias=self.density_bias,
@@ -443,13 +469,24 @@ class mipNeRF360(nn.Module):
         self.prop_net.mlp_bf16 = self.nerf_net.mlp_bf16 = self.mlp_dtype == "bf16"
         self.to(device)
 
+    def set_prof(self, prof) -> None:
+        """Attach (or with None detach) a `_lib.Prof` event recorder: the stage drivers then record one HIP-event pair
+        per kernel on the launch stream (measurement only; bench.py's roofline)."""
+        self.prof = self.prop_net.prof = self.nerf_net.prof = prof
+
+    def invalidate_packed(self) -> None:
+        """Forget the packed copies of the weights.  Needed only after changing parameters through `.data` (no version
+        bump) while in eval mode; in training mode every forward re-packs."""
+        self.prop_net.invalidate_packed()
+        self.nerf_net.invalidate_packed()
+
     # ------------------------------------------------------------------ fused two-stage forward
     def _forward_fused(self, rays, rgb=None, distance=None, acc=None, stash=True, norm_group_rays=0):
         rstruct, keep, B = _rays_struct(rays)
         dev = keep[0].device
         N = self.prop_net.num_samples
         Nf = self.nerf_net.num_samples_fine or N
-        mstruct = _model_struct(self.prop_net.input_size, self.prop_net._pack(), self.nerf_net._pack())
+        mstruct = _model_struct(self.prop_net.input_size, self.prop_net._pack(), self.nerf_net._pack(), dev)
         hyper = self.nerf_net._hyper(N, Nf)
         hyper.norm_group_rays = int(norm_group_rays)
         if stash:
@@ -460,8 +497,8 @@ class mipNeRF360(nn.Module):
                         acc=acc if acc is not None else torch.empty(B, device=dev))
         ostruct = _outputs_struct(outs)
         ws = _ws_for(B, max(N, Nf), mstruct, dev)
-        _lib.check(_lib.lib().m360_forward(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, C.byref(ostruct),
-                                           ws.data_ptr(), ws.numel(), ops.stream()), "m360_forward")
+        ops.call("m360_forward", C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, C.byref(ostruct), ws,
+                 ws.numel(), ops.STREAM, device=dev)
         if stash:
             self.nerf_net._stash(outs)
         return outs["rgb"], outs["distance"], outs["acc"]
@@ -479,7 +516,7 @@ class mipNeRF360(nn.Module):
         rstruct, keep, B = _rays_struct(rays)
         N = self.prop_net.num_samples
         Nf = self.nerf_net.num_samples_fine or N
-        mstruct = _model_struct(self.prop_net.input_size, self.prop_net._pack(), self.nerf_net._pack())
+        mstruct = _model_struct(self.prop_net.input_size, self.prop_net._pack(), self.nerf_net._pack(), keep[0].device)
         hyper = self.nerf_net._hyper(N, Nf)
         return rstruct, keep, B, N, Nf, mstruct, hyper, _ws_for(B, max(N, Nf), mstruct, keep[0].device)
 
@@ -494,26 +531,23 @@ class mipNeRF360(nn.Module):
         """proposal stage with the batch-global contraction norm `norm` (device float[1]) -> (w_hat, t_new)"""
         rstruct, keep, B, N, Nf, mstruct, hyper, ws = self._sharded_common(rays)
         t_hat, norm = ops.dev(t_hat, "t_hat"), ops.dev(norm, "norm")
-        w_hat, t_new = torch.empty(B, N, device=t_hat.device), torch.empty(B, Nf + 1, device=t_hat.device)
+        dev = keep[0].device
+        w_hat, t_new = torch.empty(B, N, device=dev), torch.empty(B, Nf + 1, device=dev)
         with torch.no_grad():
-            _lib.check(_lib.lib().m360_prop_forward_from_t(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B,
-                                                           t_hat.data_ptr(), norm.data_ptr(), w_hat.data_ptr(),
-                                                           t_new.data_ptr(), ws.data_ptr(), ws.numel(), ops.stream()),
-                       "m360_prop_forward_from_t")
+            ops.call("m360_prop_forward_from_t", C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, t_hat, norm,
+                     w_hat, t_new, ws, ws.numel(), ops.STREAM, device=dev)
         return w_hat, t_new
 
     def sharded_nerf(self, rays, t_new, norm):
         """NeRF stage with the batch-global contraction norm -> (rgb[B,3], distance[B], acc[B])"""
         rstruct, keep, B, N, Nf, mstruct, hyper, ws = self._sharded_common(rays)
         t_new, norm = ops.dev(t_new, "t_new"), ops.dev(norm, "norm")
-        dev = t_new.device
+        dev = keep[0].device
         outs = dict(rgb=torch.empty(B, 3, device=dev), distance=torch.empty(B, device=dev), acc=torch.empty(B, device=dev))
         ostruct = _outputs_struct(outs)
         with torch.no_grad():
-            _lib.check(_lib.lib().m360_nerf_forward_from_t(C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B,
-                                                           t_new.data_ptr(), norm.data_ptr(), C.byref(ostruct),
-                                                           ws.data_ptr(), ws.numel(), ops.stream()),
-                       "m360_nerf_forward_from_t")
+            ops.call("m360_nerf_forward_from_t", C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, t_new, norm,
+                     C.byref(ostruct), ws, ws.numel(), ops.STREAM, device=dev)
         return outs["rgb"], outs["distance"], outs["acc"]
 
     # ------------------------------------------------------------------ chunked frame rendering
@@ -534,7 +568,8 @@ class mipNeRF360(nn.Module):
         # rays (m360_hyper_t.norm_group_rays) - bit-identical to one launch per chunk, at large-batch efficiency.
         n_max = max(self.prop_net.num_samples, self.nerf_net.num_samples_fine or self.prop_net.num_samples)
         group = chunks if (fused and chunks < self.super_batch_rays and chunks * n_max <= 131072) else 0
-        step = (self.super_batch_rays // chunks) * chunks if group else chunks
+        # at most 1024 contraction-norm groups per launch (kMaxNormGroups of the encode kernel)
+        step = min(self.super_batch_rays // chunks, 1024) * chunks if group else chunks
         with torch.no_grad():
             for i in range(0, length, step):
                 chunk = namedtuple_map(lambda r: r[i:i + step], rays)

@@ -38,17 +38,57 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+class _Stream:
+    """Placeholder for the `m360_stream_t` argument: `call` replaces it by the current HIP stream of the device the
+    tensor arguments live on."""
+
+    def __repr__(self):
+        return "STREAM"
+
+
+STREAM = _Stream()
+
+
+def stream(device=None) -> int:
+    """Raw handle of torch's current HIP stream on `device` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def round_up(v: int, m: int = 32) -> int:
     return (v + m - 1) // m * m
 
 
-def _call(name, *args):
+def call(name: str, *args, device=None):
+    """One C-ABI call.  Tensor arguments are passed as raw device pointers; all of them (and `device`, when given:
+    descriptor structs carry pointers ctypes cannot see) must live on ONE HIP device.  The call runs with that device
+    current (libm360 launches on the current device: hipGetDevice / the stream's device) and `STREAM` becomes torch's
+    current stream of THAT device - so `mipNeRF360(device='cuda:1')` works without a prior torch.cuda.set_device(1),
+    like the reference with `device=config.device` alone."""
+    device = None if device is None else torch.device(device)
+    conv = []
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            if not a.is_cuda:
+                raise RuntimeError(f"{name}: tensor argument on {a.device}; mipnerf360_amd has no CPU path")
+            if device is None:
+                device = a.device
+            elif a.device != device:
+                raise RuntimeError(f"{name}: tensor arguments on different devices ({device} and {a.device})")
+            conv.append(a.data_ptr())
+        else:
+            conv.append(a)
     fn = getattr(_lib.lib(), name)
-    _lib.check(fn(*args), name)
+    if device is None:  # no tensor at all (size queries)
+        _lib.check(fn(*[None if a is STREAM else a for a in conv]), name)
+        return
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    with torch.cuda.device(device):
+        s = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(fn(*[s if a is STREAM else a for a in conv]), name)
+
+
+_call = call
 
 
 def _ws(device) -> torch.Tensor:
@@ -63,14 +103,14 @@ def sample_t(near, far, num_samples: int, t_rand=None) -> torch.Tensor:
     t = torch.empty(B, num_samples + 1, device=near.device)
     if t_rand is not None:
         t_rand = dev(t_rand, "t_rand")
-    _call("m360_sample_t", ptr(near), ptr(far), ptr(t_rand), B, num_samples, ptr(t), stream())
+    _call("m360_sample_t", near, far, t_rand, B, num_samples, t, STREAM)
     return t
 
 
 def g(x) -> torch.Tensor:
     x = dev(x, "x")
     y = torch.empty_like(x)
-    _call("m360_g", ptr(x), x.numel(), ptr(y), stream())
+    _call("m360_g", x, x.numel(), y, STREAM)
     return y
 
 
@@ -80,7 +120,7 @@ def s_to_t(s_vals, near, far) -> torch.Tensor:
     s_vals = dev(s_vals, "s_vals")
     s2 = s_vals.expand(B, s_vals.shape[-1]).contiguous() if s_vals.dim() == 1 or s_vals.shape[0] != B else s_vals
     t = torch.empty_like(s2)
-    _call("m360_s_to_t", ptr(s2), ptr(near), ptr(far), B, s2.shape[-1], ptr(t), stream())
+    _call("m360_s_to_t", s2, near, far, B, s2.shape[-1], t, STREAM)
     return t
 
 
@@ -88,7 +128,7 @@ def contract(x) -> torch.Tensor:
     x = dev(x, "x")
     y = torch.empty_like(x)
     ws = _ws(x.device)
-    _call("m360_contract", ptr(x), x.numel(), ptr(y), ptr(ws), ws.numel(), stream())
+    _call("m360_contract", x, x.numel(), y, ws, ws.numel(), STREAM)
     return y
 
 
@@ -96,7 +136,7 @@ def t_to_s(t_vals, near, far, near_calls: int = 1, far_calls: int = 1) -> torch.
     t_vals, near, far = dev(t_vals, "t_vals"), dev(near, "near"), dev(far, "far")
     B, M = t_vals.shape
     s = torch.empty_like(t_vals)
-    _call("m360_t_to_s", ptr(t_vals), ptr(near), ptr(far), B, M, near_calls, far_calls, ptr(s), stream())
+    _call("m360_t_to_s", t_vals, near, far, B, M, near_calls, far_calls, s, STREAM)
     return s
 
 
@@ -105,7 +145,7 @@ def frustum_moments(t0, t1, radii):
     t0, t1, radii = dev(t0, "t0"), dev(t1, "t1"), dev(radii, "radii")
     B, N = t0.shape
     outs = [torch.empty_like(t0) for _ in range(3)]
-    _call("m360_frustum_moments", ptr(t0), ptr(t1), ptr(radii), B, N, *[ptr(o) for o in outs], stream())
+    _call("m360_frustum_moments", t0, t1, radii, B, N, *[o for o in outs], STREAM)
     return tuple(outs)
 
 
@@ -114,7 +154,7 @@ def gaussian_to_xyz(d, t_mean, t_var, r_var):
     B, N = t_mean.shape
     mean = torch.empty(B, N, 3, device=d.device)
     cov = torch.empty(B, N, 3, 3, device=d.device)
-    _call("m360_gaussian_to_xyz", ptr(d), ptr(t_mean), ptr(t_var), ptr(r_var), B, N, ptr(mean), ptr(cov), stream())
+    _call("m360_gaussian_to_xyz", d, t_mean, t_var, r_var, B, N, mean, cov, STREAM)
     return mean, cov
 
 
@@ -123,7 +163,7 @@ def gaussian_contract(mean, cov):
     S = mean.numel() // 3
     mo, co = torch.empty_like(mean), torch.empty_like(cov)
     ws = _ws(mean.device)
-    _call("m360_gaussian_contract", ptr(mean), ptr(cov), S, ptr(mo), ptr(co), ptr(ws), ws.numel(), stream())
+    _call("m360_gaussian_contract", mean, cov, S, mo, co, ws, ws.numel(), STREAM)
     return mo, co
 
 
@@ -135,8 +175,8 @@ def para_rays(t_vals, origins, directions, radii):
     means = torch.empty(B, N, 3, device=t_vals.device)
     covs = torch.empty(B, N, 3, 3, device=t_vals.device)
     ws = _ws(t_vals.device)
-    _call("m360_para_rays", ptr(t_vals), ptr(origins), ptr(directions), ptr(radii), B, N, ptr(means), ptr(covs),
-          ptr(ws), ws.numel(), stream())
+    _call("m360_para_rays", t_vals, origins, directions, radii, B, N, means, covs,
+          ws, ws.numel(), STREAM)
     return means, covs
 
 
@@ -146,7 +186,7 @@ def ipe(mean, cov=None) -> torch.Tensor:
     cov = None if cov is None else dev(cov, "cov")
     S = mean.numel() // 3
     enc = torch.empty(mean.shape[:-1] + (IPE_CH,), device=mean.device)
-    _call("m360_ipe", ptr(mean), ptr(cov), S, ptr(enc), stream())
+    _call("m360_ipe", mean, cov, S, enc, STREAM)
     return enc
 
 
@@ -154,7 +194,7 @@ def viewdir_enc(viewdirs, min_deg: int, max_deg: int) -> torch.Tensor:
     viewdirs = dev(viewdirs, "viewdirs")
     B = viewdirs.numel() // 3
     enc = torch.empty(viewdirs.shape[:-1] + (4 * (max_deg - min_deg),), device=viewdirs.device)
-    _call("m360_viewdir_enc", ptr(viewdirs), B, min_deg, max_deg, ptr(enc), stream())
+    _call("m360_viewdir_enc", viewdirs, B, min_deg, max_deg, enc, STREAM)
     return enc
 
 
@@ -167,8 +207,8 @@ def encode_features(t_vals, origins, directions, radii, vdenc, ld_feat: Optional
     ld = ld_feat or round_up(IPE_CH + vd_ch)
     feat = torch.empty(B * N, ld, device=t_vals.device)
     ws = _ws(t_vals.device)
-    _call("m360_encode_features", ptr(t_vals), ptr(origins), ptr(directions), ptr(radii), ptr(vdenc), vd_ch, B, N,
-          ptr(feat), ld, ptr(ws), ws.numel(), stream())
+    _call("m360_encode_features", t_vals, origins, directions, radii, vdenc, vd_ch, B, N,
+          feat, ld, ws, ws.numel(), STREAM)
     return feat
 
 
@@ -180,7 +220,7 @@ def pack_linear(weight, bias=None, n_pad: Optional[int] = None, k_pad: Optional[
     wp = torch.empty(n_pad, k_pad, device=weight.device)
     bp = torch.empty(n_pad, device=weight.device)
     b = None if bias is None else dev(bias.detach(), "bias")
-    _call("m360_pack_linear", ptr(weight), ptr(b), n_out, k_in, n_pad, k_pad, ptr(wp), ptr(bp), stream())
+    _call("m360_pack_linear", weight, b, n_out, k_in, n_pad, k_pad, wp, bp, STREAM)
     return wp, bp
 
 
@@ -191,7 +231,7 @@ def linear(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.
     if ldx != k_pad:
         raise RuntimeError(f"linear: x has {ldx} columns, packed weight expects {k_pad}")
     y = out if out is not None else torch.empty(M, n_pad, device=x.device)
-    _call("m360_linear", ptr(x), M, ldx, ptr(w_packed), ptr(b_packed), n_pad, k_pad, act, ptr(y), y.shape[1], stream())
+    _call("m360_linear", x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, y.shape[1], STREAM)
     return y
 
 
@@ -201,7 +241,7 @@ def mean_sumsq(t_vals, directions, radii) -> torch.Tensor:
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
     out = torch.empty(1, dtype=torch.float64, device=t_vals.device)
     ws = torch.empty(int(_lib.lib().m360_contract_workspace_bytes()), dtype=torch.uint8, device=t_vals.device)
-    _call("m360_mean_sumsq", ptr(t_vals), ptr(directions), ptr(radii), B, N, ptr(out), ptr(ws), ws.numel(), stream())
+    _call("m360_mean_sumsq", t_vals, directions, radii, B, N, out, ws, ws.numel(), STREAM)
     return out
 
 
@@ -211,7 +251,7 @@ def pack_linear_transposed(weight, n_pad: Optional[int] = None, k_pad: Optional[
     n_out, k_in = weight.shape
     n_pad, k_pad = n_pad or round_up(n_out, 32), k_pad or round_up(k_in, 32)
     wt = torch.empty(k_pad, n_pad, device=weight.device)
-    _call("m360_pack_linear_transposed", ptr(weight), n_out, k_in, n_pad, k_pad, ptr(wt), stream())
+    _call("m360_pack_linear_transposed", weight, n_out, k_in, n_pad, k_pad, wt, STREAM)
     return wt
 
 
@@ -227,7 +267,7 @@ def linear_dgrad(dz, wt_packed, relu_out=None, out: Optional[torch.Tensor] = Non
         relu_out = dev(relu_out, "relu_out")
         if tuple(relu_out.shape) != (M, dx.shape[1]):
             raise RuntimeError("linear_dgrad: relu_out must have the shape of dx")
-    _call("m360_linear_dgrad", ptr(dz), M, n_pad, ptr(wt_packed), k_pad, n_pad, ptr(relu_out), ptr(dx), dx.shape[1], stream())
+    _call("m360_linear_dgrad", dz, M, n_pad, wt_packed, k_pad, n_pad, relu_out, dx, dx.shape[1], STREAM)
     return dx
 
 
@@ -241,7 +281,7 @@ def linear_wgrad(dz, x, want_bias: bool = True):
     gw = torch.empty(n_pad, k_pad, device=dz.device)
     gb = torch.empty(n_pad, device=dz.device) if want_bias else None
     ws = torch.empty(_lib.lib().m360_linear_wgrad_workspace_bytes(M, n_pad, k_pad), dtype=torch.uint8, device=dz.device)
-    _call("m360_linear_wgrad", ptr(dz), n_pad, ptr(x), k_pad, M, n_pad, k_pad, ptr(gw), ptr(gb), ptr(ws), ws.numel(), stream())
+    _call("m360_linear_wgrad", dz, n_pad, x, k_pad, M, n_pad, k_pad, gw, gb, ws, ws.numel(), STREAM)
     return gw, gb
 
 
@@ -260,7 +300,7 @@ def pack_linear_bf16(weight, bias=None, n_pad: Optional[int] = None, k_pad: Opti
     wp = torch.empty(n_pad, k_pad, device=weight.device, dtype=torch.bfloat16)
     bp = torch.empty(n_pad, device=weight.device)
     b = None if bias is None else dev(bias.detach(), "bias")
-    _call("m360_pack_linear_bf16", ptr(weight), ptr(b), n_out, k_in, n_pad, k_pad, ptr(wp), ptr(bp), stream())
+    _call("m360_pack_linear_bf16", weight, b, n_out, k_in, n_pad, k_pad, wp, bp, STREAM)
     return wp, bp
 
 
@@ -272,7 +312,7 @@ def linear_bf16(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[t
     if ldx != k_pad:
         raise RuntimeError(f"linear_bf16: x has {ldx} columns, packed weight expects {k_pad}")
     y = out if out is not None else torch.empty(M, n_pad, device=x.device, dtype=torch.bfloat16)
-    _call("m360_linear_bf16", ptr(x), M, ldx, ptr(w_packed), ptr(b_packed), n_pad, k_pad, act, ptr(y), y.shape[1], stream())
+    _call("m360_linear_bf16", x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, y.shape[1], STREAM)
     return y
 
 
@@ -285,7 +325,7 @@ def density_to_weight(t_vals, density, dirs) -> torch.Tensor:
     t_vals, density, dirs = dev(t_vals, "t_vals"), dev(_density2d(density), "density"), dev(dirs, "dirs")
     B, N = density.shape
     w = torch.empty(B, N, device=t_vals.device)
-    _call("m360_density_to_weight", ptr(t_vals), ptr(density), ptr(dirs), B, N, ptr(w), stream())
+    _call("m360_density_to_weight", t_vals, density, dirs, B, N, w, STREAM)
     return w
 
 
@@ -296,7 +336,7 @@ def sorted_pdf(bins, weights, num_samples: int, u_rand=None) -> torch.Tensor:
         raise RuntimeError(f"sorted_pdf: weights must have {nb - 1} entries per ray, got {weights.shape[-1]}")
     out = torch.empty(B, num_samples, device=bins.device)
     u = None if u_rand is None else dev(u_rand, "u_rand")
-    _call("m360_sorted_pdf", ptr(bins), ptr(weights), ptr(u), B, nb, num_samples, ptr(out), stream())
+    _call("m360_sorted_pdf", bins, weights, u, B, nb, num_samples, out, STREAM)
     return out
 
 
@@ -307,8 +347,8 @@ def resample_t(t_vals, weights, resample_padding: float, u_rand=None, num_out: O
     n_out = M if num_out is None else int(num_out)
     out = torch.empty(B, n_out, device=t_vals.device)
     u = None if u_rand is None else dev(u_rand, "u_rand")
-    _call("m360_resample_t_n", ptr(t_vals), ptr(weights), ptr(u), B, M - 1, n_out, float(resample_padding), ptr(out),
-          stream())
+    _call("m360_resample_t_n", t_vals, weights, u, B, M - 1, n_out, float(resample_padding), out,
+          STREAM)
     return out
 
 
@@ -318,15 +358,15 @@ def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd: bool):
     B, N = density.shape
     d = t_vals.device
     comp, dist, acc, w = torch.empty(B, 3, device=d), torch.empty(B, device=d), torch.empty(B, device=d), torch.empty(B, N, device=d)
-    _call("m360_volumetric_rendering", ptr(rgb), ptr(density), ptr(t_vals), ptr(dirs), B, N, int(bool(white_bkgd)),
-          ptr(comp), ptr(dist), ptr(acc), ptr(w), stream())
+    _call("m360_volumetric_rendering", rgb, density, t_vals, dirs, B, N, int(bool(white_bkgd)),
+          comp, dist, acc, w, STREAM)
     return comp, dist, acc, w
 
 
 def to8b(x: torch.Tensor) -> torch.Tensor:
     x = dev(x, "image")
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-    _call("m360_to8b", ptr(x), x.numel(), ptr(out), stream())
+    _call("m360_to8b", x, x.numel(), out, STREAM)
     return out
 
 
@@ -338,8 +378,8 @@ def prop_finish(act, head_w, head_b, density_bias, t_vals, dirs, resample_paddin
     w = torch.empty(B, N, device=act.device)
     t_new = torch.empty_like(t_vals) if want_t_new else None
     u = None if u_rand is None else dev(u_rand, "u_rand")
-    _call("m360_prop_finish", ptr(act), act.shape[1], ptr(head_w), ptr(head_b), head_w.numel(), float(density_bias),
-          ptr(t_vals), ptr(dirs), ptr(u), B, N, float(resample_padding), ptr(w), ptr(t_new), stream())
+    _call("m360_prop_finish", act, act.shape[1], head_w, head_b, head_w.numel(), float(density_bias),
+          t_vals, dirs, u, B, N, float(resample_padding), w, t_new, STREAM)
     return w, t_new
 
 
@@ -350,9 +390,9 @@ def nerf_finish(act, head_w, head_b, density_bias, rgb_padding, t_vals, dirs, wh
     N = M - 1
     d = act.device
     comp, dist, acc, w = torch.empty(B, 3, device=d), torch.empty(B, device=d), torch.empty(B, device=d), torch.empty(B, N, device=d)
-    _call("m360_nerf_finish", ptr(act), act.shape[1], ptr(head_w), ptr(head_b), head_w.shape[1], float(density_bias),
-          float(rgb_padding), ptr(t_vals), ptr(dirs), B, N, int(bool(white_bkgd)), ptr(comp), ptr(dist), ptr(acc), ptr(w),
-          stream())
+    _call("m360_nerf_finish", act, act.shape[1], head_w, head_b, head_w.shape[1], float(density_bias),
+          float(rgb_padding), t_vals, dirs, B, N, int(bool(white_bkgd)), comp, dist, acc, w,
+          STREAM)
     return comp, dist, acc, w
 
 
@@ -369,16 +409,16 @@ def generate_rays(cam_to_world, h: int, w: int, focal: float, near: float, far: 
     d = c2w.device
     o, di, v = (torch.empty(total, 3, device=d) for _ in range(3))
     r, ne, fa = (torch.empty(total, 1, device=d) for _ in range(3))
-    _call("m360_generate_rays", ptr(c2w), n, int(h), int(w), float(focal), float(near), float(far), int(bool(ndc)),
-          float(ndc_near), ptr(o), ptr(di), ptr(v), ptr(r), ptr(ne), ptr(fa), stream())
+    _call("m360_generate_rays", c2w, n, int(h), int(w), float(focal), float(near), float(far), int(bool(ndc)),
+          float(ndc_near), o, di, v, r, ne, fa, STREAM)
     return o, di, v, r, ne, fa
 
 
 def convert_to_ndc(origins, directions, focal: float, w: int, h: int, near: float = 1.0):
     origins, directions = dev(origins, "origins"), dev(directions, "directions")
     oo, do = torch.empty_like(origins), torch.empty_like(directions)
-    _call("m360_convert_to_ndc", ptr(origins), ptr(directions), origins.numel() // 3, float(focal), int(w), int(h),
-          float(near), ptr(oo), ptr(do), stream())
+    _call("m360_convert_to_ndc", origins, directions, origins.numel() // 3, float(focal), int(w), int(h),
+          float(near), oo, do, STREAM)
     return oo, do
 
 
@@ -391,14 +431,14 @@ def depth_to_normals(depth) -> torch.Tensor:
     depth = dev(depth, "depth")
     h, w = depth.shape
     out = torch.empty(h, w, 3, device=depth.device)
-    _call("m360_depth_to_normals", ptr(depth), h, w, ptr(out), stream())
+    _call("m360_depth_to_normals", depth, h, w, out, STREAM)
     return out
 
 
 def sinebow(hval) -> torch.Tensor:
     hval = dev(hval, "h")
     out = torch.empty(hval.shape + (3,), device=hval.device)
-    _call("m360_sinebow", ptr(hval), hval.numel(), ptr(out), stream())
+    _call("m360_sinebow", hval, hval.numel(), out, STREAM)
     return out
 
 
@@ -408,7 +448,7 @@ def visualize_normals(depth, acc=None) -> torch.Tensor:
     h, w = depth.shape
     out = torch.empty(h, w, 3, device=depth.device)
     ws = _vis_ws(depth.device)
-    _call("m360_visualize_normals", ptr(depth), ptr(acc), h, w, ptr(out), ptr(ws), ws.numel(), stream())
+    _call("m360_visualize_normals", depth, acc, h, w, out, ws, ws.numel(), STREAM)
     return out
 
 
@@ -419,8 +459,8 @@ def visualize_depth(depth, acc=None, near=None, far=None, modulus: float = 0.0) 
     h, w = depth.shape
     out = torch.empty(h, w, 3, device=depth.device)
     ws = _vis_ws(depth.device)
-    _call("m360_visualize_depth", ptr(depth), ptr(acc), h, w, float(near or 0.0), float(far or 0.0), int(not near),
-          int(not far), float(modulus), ptr(out), ptr(ws), ws.numel(), stream())
+    _call("m360_visualize_depth", depth, acc, h, w, float(near or 0.0), float(far or 0.0), int(not near),
+          int(not far), float(modulus), out, ws, ws.numel(), STREAM)
     return out
 
 
@@ -438,8 +478,8 @@ def loss_prop(t, w, t_hat, w_hat, want_grad: bool = False):
     loss, bounds = torch.empty(1, device=d), torch.empty(B, Np, device=d)
     grad = torch.empty(B, Np, device=d) if want_grad else None
     ws = _loss_ws(B, d, Np)
-    _call("m360_loss_prop", ptr(t), ptr(w), ptr(t_hat), ptr(w_hat), B, Nf, Np, ptr(bounds), ptr(loss), ptr(grad), ptr(ws),
-          ws.numel(), stream())
+    _call("m360_loss_prop", t, w, t_hat, w_hat, B, Nf, Np, bounds, loss, grad, ws,
+          ws.numel(), STREAM)
     return loss, bounds, grad
 
 
@@ -450,8 +490,8 @@ def loss_prop_given_bounds(bounds, w_hat, want_grad: bool = False):
     loss = torch.empty(1, device=w_hat.device)
     grad = torch.empty(B, Np, device=w_hat.device) if want_grad else None
     ws = _loss_ws(B, w_hat.device, Np)
-    _call("m360_loss_prop", None, ptr(bounds), None, ptr(w_hat), B, Np, Np, None, ptr(loss), ptr(grad), ptr(ws), ws.numel(),
-          stream())
+    _call("m360_loss_prop", None, bounds, None, w_hat, B, Np, Np, None, loss, grad, ws, ws.numel(),
+          STREAM)
     return loss, grad
 
 
@@ -464,7 +504,7 @@ def loss_dist(s_vals, weights, want_grad: bool = False):
     gw = torch.empty(B, N, device=d) if want_grad else None
     gs = torch.empty(B, N + 1, device=d) if want_grad else None
     ws = _loss_ws(B, d)
-    _call("m360_loss_dist", ptr(s_vals), ptr(weights), B, N, ptr(loss), ptr(gw), ptr(gs), ptr(ws), ws.numel(), stream())
+    _call("m360_loss_dist", s_vals, weights, B, N, loss, gw, gs, ws, ws.numel(), STREAM)
     return loss, gw, gs
 
 
@@ -475,5 +515,5 @@ def loss_nerf(inp, target, want_grad: bool = False):
     out3 = torch.empty(3, device=inp.device)
     grad = torch.empty_like(inp) if want_grad else None
     ws = _loss_ws(B, inp.device)
-    _call("m360_loss_nerf", ptr(inp), ptr(target), B, Cc, ptr(out3), ptr(grad), ptr(ws), ws.numel(), stream())
+    _call("m360_loss_nerf", inp, target, B, Cc, out3, grad, ws, ws.numel(), STREAM)
     return out3, grad

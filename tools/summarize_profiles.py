@@ -18,6 +18,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_sha  # noqa: E402  (sha256 over the dominant kernel's source files)
 M_BENCH, N_BENCH = 4096 * 128, 1024
 
 
@@ -111,7 +113,9 @@ def main():
                       "--cpu-rays 0`, mean over the ReLU 1024x1024 launches; bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024 "
                       "(gfx950 corrections of MI355X_MICROARCH.md, HBM section); clock = GRBM_GUI_ACTIVE/8/duration; "
                       "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE/8)",
-            "sq_counters_mean": {k: v[0] for k, v in s.items()}}
+            "sq_counters_mean": {k: v[0] for k, v in s.items()},
+            # bench.py trusts this file only while the kernel sources it was measured on are unchanged
+            "kernel_source_sha256": kernel_source_sha()}
     json.dump(info, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps({k: info[k] for k in list(info)[:9]}, indent=1))
 
