@@ -349,6 +349,12 @@ typedef struct {
                              sequence renders many chunks, bit-identical to launching them one by one; 0 = one norm
                              for the whole batch (the reference's forward) */
     void *prof;           /* optional m360_prof_t* (see "measurement" below); NULL = no timing */
+    int rays_mutated;     /* 0 (default): rays.near / rays.far are the caller's ORIGINAL values and the +1e-6 offsets the
+                             reference's in-place g() accumulates inside one (prop, nerf) forward pair are applied
+                             numerically.  1: the caller mutates near / far physically like the reference does
+                             (intern/parameterization.py:15-21: +1e-6 each after the proposal stage, so the NeRF stage's
+                             t_to_s starts from the values it is handed); used by the mirrors'
+                             mutate_like_reference mode to reproduce train.py's drift over its three pairs */
 } m360_hyper_t; /* ctor arguments of model.py:203-215 */
 
 typedef struct {

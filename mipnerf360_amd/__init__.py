@@ -12,14 +12,20 @@ import sys
 __version__ = "0.1.0"
 
 
-def install_dropin(reference_root=None) -> None:
+def install_dropin(reference_root=None, mutate_like_reference: bool = False) -> None:
     """Make `import model` / `from intern.ray import ...` (the reference's module names, as used
     by its train.py / test.py / video.py) resolve to this package.
 
     `reference_root`: the reference checkout.  Its scripts also import host-side helpers that are outside the hot path
     (`intern.scheduler.lr_decay`, the camera paths of `intern.pose`, `intern.utils.normalize / to_float`); given the root,
     those keep resolving to the reference's own files: `intern.__path__` is extended by `<root>/intern` (modules this
-    package has no mirror for) and names missing from a mirror fall through lazily (mipnerf360_amd/intern/_fallback.py)."""
+    package has no mirror for) and names on the allowlist of out-of-scope host helpers fall through lazily
+    (mipnerf360_amd/intern/_fallback.py).
+
+    `mutate_like_reference`: models built afterwards also reproduce the reference's in-place `g()` side effect on
+    `rays.near` / `rays.far` (+3e-6 / +2e-6 per forward pair, intern/parameterization.py:15-21), so train.py's three
+    pairs per iteration drift exactly like the reference's (fixture G14).  Default off: caller tensors are never
+    mutated and every forward behaves like the reference's FIRST forward on fresh rays."""
     import os
     from . import intern, model
     from .intern import _fallback, distillation, encoding, loss, parameterization, pose, ray, regularization, utils
@@ -30,6 +36,7 @@ def install_dropin(reference_root=None) -> None:
         _fallback.set_reference_root(reference_root)
         if ref_intern not in intern.__path__:
             intern.__path__.append(ref_intern)
+    model.MUTATE_LIKE_REFERENCE = bool(mutate_like_reference)
     sys.modules["model"] = model
     sys.modules["intern"] = intern
     sys.modules["intern.ray"] = ray

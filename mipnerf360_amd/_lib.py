@@ -38,7 +38,7 @@ class HyperStruct(C.Structure):  # m360_hyper_t
     _fields_ = [("num_samples", C.c_int), ("viewdir_min_deg", C.c_int), ("viewdir_max_deg", C.c_int),
                 ("white_bkgd", C.c_int), ("density_bias", C.c_float), ("rgb_padding", C.c_float),
                 ("resample_padding", C.c_float), ("num_samples_fine", C.c_int), ("norm_group_rays", C.c_int),
-                ("prof", C.c_void_p)]
+                ("prof", C.c_void_p), ("rays_mutated", C.c_int)]
 
 
 class OutputsStruct(C.Structure):  # m360_outputs_t

@@ -271,7 +271,10 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         hipLaunchKernelGGL(add_eps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(st), t1, n, out->t_vals);
         M360_TRY(check_launch("add_eps"));
     }
-    if (out->s_vals) M360_TRY(m360_t_to_s(t1, r->near, r->far, B, N + 1, 1, 1, out->s_vals, st));
+    if (out->s_vals) {  // near / far went through g() once in sample_along_rays (numerically, or physically when rays_mutated)
+        const int done = h->rays_mutated ? 0 : 1;
+        M360_TRY(m360_t_to_s(t1, r->near, r->far, B, N + 1, done, done, out->s_vals, st));
+    }
     return M360_OK;
 }
 

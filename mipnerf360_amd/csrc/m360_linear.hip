@@ -471,7 +471,7 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
 }
 
 int m360_diag_read_stamps(unsigned long long *out_host, int n) {
-    if (!out_host || n < 0 || n > 256 * 8) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_read_stamps: bad argument");
+    if (!out_host || n < 0 || n > 256 * 16) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_read_stamps: bad argument");
     if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(persist::g_stamps), sizeof(unsigned long long) * n) != hipSuccess)
         return fail(M360_ERR_LAUNCH, "m360_diag_read_stamps: copy failed");
     return M360_OK;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     const int wm = wave >> 2, wn = wave & 3;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int ksteps = Kp / BK;
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, rt1 = 0, rt2 = 0;  // rt*: s_memrealtime (100 MHz) around the main loop
 #define PP_STAMP(var)                                                                           \
     do {                                                                                        \
         if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");  \
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     int ldy_t = ldy;
     int buf = 0;
     PP_STAMP(ts1);
+    if (STAMP) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
     bool have_prev = false;
     for (; tile_id < ntiles; tile_id += G) {
         tile_coords(tile_id, m0, n0);
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
             have_prev = true;
         }
     }
+    if (STAMP) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt2)::"memory");
     // ---- the last tile of this workgroup: plain epilogue (no barrier: the groups keep their one-barrier stagger)
     PP_STORE_Q(0, 0);
     PP_STORE_Q(0, 2);
@@ -381,6 +383,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
             M360_STAMP_STORE(2, ts3 - ts2);
             M360_STAMP_STORE(3, ts0);
             M360_STAMP_STORE(4, ts3);
+            M360_STAMP_STORE(5, rt2 - rt1);  // in-kernel clock = [1] / [5] x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
         }
     }
 #undef PP_STAMP

@@ -47,8 +47,8 @@ __device__ __forceinline__ float act_fn(float v) {
 // over all K-steps: [0] group0+DMA issue, [1] group1, [2] group2, [3] DMA-wait+barrier, [4] group3,
 // [5] whole K-step, [6] K-steps, [7] epilogue
 #ifdef M360_DIAG
-__device__ unsigned long long g_stamps[256 * 8];
-#define M360_STAMP_STORE(i, v) g_stamps[blockIdx.x * 8 + (i)] = (v)
+__device__ unsigned long long g_stamps[256 * 16];
+#define M360_STAMP_STORE(i, v) g_stamps[blockIdx.x * 16 + (i)] = (v)
 #else
 #define M360_STAMP_STORE(i, v) ((void)(v))
 #endif
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
 
+    unsigned long long mt0 = 0, mt1 = 0, rt0 = 0, rt1 = 0;  // whole tile loop: s_memtime (shader clock) / s_memrealtime (100 MHz)
     int lin_id = blockIdx.x;
     if (lin_id >= ntiles) return;
     long m0;
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     M360_READ(fa_a, fa_b, 0u, 0);  // loop invariant from here on: group 0 of the current step in flight
     M360_SB();
 
+    if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt0), "=s"(rt0)::"memory");
     for (; lin_id < ntiles; lin_id += G) {
         tile_coords(lin_id, m0, n0);
 #pragma unroll
@@ -300,9 +302,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         M360_STAMP(c1);
         if (STAMP) st[7] += c1 - c0;
     }
+    if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt1), "=s"(rt1)::"memory");
     if (STAMP && threadIdx.x == 0 && blockIdx.x < 256) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) M360_STAMP_STORE(i, st[i]);
+        M360_STAMP_STORE(8, mt1 - mt0);  // in-kernel clock = [8] / [9] x 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
+        M360_STAMP_STORE(9, rt1 - rt0);
     }
 #undef M360_STAMP
 #undef M360_READ

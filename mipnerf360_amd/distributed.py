@@ -30,6 +30,30 @@ def chunk_partition(num_rays: int, chunks: int, world_size: int) -> List[Tuple[i
     return out
 
 
+def _host_staged(group) -> bool:
+    """gloo cannot all-gather device tensors: stage them through the host (used by the tests that run several ranks of
+    the HIP renderer on ONE GPU; with RCCL - the production backend - device tensors go over xGMI directly)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(recv: torch.Tensor, send: torch.Tensor, group=None) -> None:
+    if send.is_cuda and _host_staged(group):
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_gather_into_tensor(r, send.cpu(), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+
+
+def _all_reduce_sum(t: torch.Tensor, group=None) -> None:
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 def gather_pixels(local: torch.Tensor, spans: List[Tuple[int, int]], group=None) -> torch.Tensor:
     """All-gather the per-rank pixel blocks local[n_r, C] (n_r = spans[rank] length) into [sum n_r, C]
     on every rank.  Blocks are padded to the longest span so a single fixed-size all-gather suffices."""
@@ -43,7 +67,7 @@ def gather_pixels(local: torch.Tensor, spans: List[Tuple[int, int]], group=None)
     send = torch.zeros(longest, width, dtype=local.dtype, device=local.device)
     send[:counts[rank]] = local
     recv = torch.empty(world * longest, width, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
+    _all_gather_into(recv, send, group)
     recv = recv.view(world, longest, width)
     return torch.cat([recv[r, :counts[r]] for r in range(world)], 0)
 
@@ -75,10 +99,10 @@ def forward_sharded(model, rays, group=None):
     (mipNeRF360 implements them on the HIP path)."""
     t_hat = model.sharded_sample(rays)
     ss = model.sharded_sumsq(rays, t_hat)
-    dist.all_reduce(ss, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(ss, group)
     _, t_new = model.sharded_prop(rays, t_hat, ss.sqrt().float())
     ss = model.sharded_sumsq(rays, t_new)
-    dist.all_reduce(ss, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(ss, group)
     return model.sharded_nerf(rays, t_new, ss.sqrt().float())
 
 

@@ -28,6 +28,11 @@ from .intern.ray import Rays, namedtuple_map
 
 _WORKSPACES: Dict[tuple, torch.Tensor] = {}
 
+# Default of the `mutate_like_reference` attribute of newly built models (install_dropin(..., mutate_like_reference=True)
+# sets it): reproduce the reference's in-place g() side effect on rays.near / rays.far (intern/parameterization.py:15-21).
+MUTATE_LIKE_REFERENCE = False
+EPS_G = 1e-6
+
 
 def _kaiming_init(model):
     """model.py:8-12."""
@@ -84,6 +89,8 @@ class _PackedMLP:
         params = [p for lin in list(hidden_layers) + list(heads) for p in (lin.weight, lin.bias)]
         key = self._key(params) + (bool(bf16),)
         if key == self.key and not always:
+            if torch.cuda.current_stream(self.head_w.device) != self.pack_stream:
+                torch.cuda.current_stream(self.head_w.device).wait_event(self.ready)  # packed on another stream
             return self
         first = hidden_layers[0]
         ops._require_device(first.weight, "model parameters")
@@ -101,6 +108,10 @@ class _PackedMLP:
         self.head_w, _ = ops.pack_linear(hw, None, hw.shape[0], self.h_pad)
         self.head_b = hb
         self.key = key
+        # a forward on a different stream must not read the packing before the kernels that write it have run
+        self.pack_stream = torch.cuda.current_stream(hw.device)
+        self.ready = torch.cuda.Event()
+        self.ready.record(self.pack_stream)
         return self
 
 
@@ -143,6 +154,15 @@ def _hyper_struct(num_samples, min_deg, max_deg, white_bkgd=False, density_bias=
                          float(rgb_padding), float(resample_padding))
     h.prof = prof.handle if prof is not None else None  # optional _lib.Prof event recorder (bench.py, tools/)
     return h
+
+
+def _mutable_field(rays, name):
+    """The caller's own tensor of a ray field, for the in-place bumps of mutate_like_reference mode."""
+    t = getattr(rays, name)
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f"mutate_like_reference: rays.{name} must be a contiguous float32 device tensor (it is mutated "
+                           f"in place, like the reference's g() does)")
+    return t
 
 
 def _wants_grad(module: nn.Module) -> bool:
@@ -273,6 +293,7 @@ class prop_net(nn.Module):
         _kaiming_init(self)
         self.to(device)
         self._packed = _PackedMLP()
+        self.mutate_like_reference = MUTATE_LIKE_REFERENCE
 
     def _pack(self) -> _PackedMLP:
         return self._packed.refresh([self.model[i] for i in (0, 2, 4, 6)], [self.model[8]],
@@ -292,9 +313,14 @@ class prop_net(nn.Module):
     def forward(self, rays):
         """model.py:80-94 -> (t_vals[B,N+1], weights[B,N]).  With autograd enabled and trainable parameters the
         weights carry the graph to the parameters (train.py:55-62)."""
-        if _wants_grad(self):
-            return _PropTrainFn.apply(self, rays, *self.parameters())
-        return self._forward_impl(rays)
+        if self.mutate_like_reference:
+            near, far = _mutable_field(rays, "near"), _mutable_field(rays, "far")
+        out = _PropTrainFn.apply(self, rays, *self.parameters()) if _wants_grad(self) else self._forward_impl(rays)
+        if self.mutate_like_reference:  # sample_along_rays: g(far), g(near) (intern/ray.py:100) bump the caller's tensors
+            with torch.no_grad():
+                far.add_(EPS_G)
+                near.add_(EPS_G)
+        return out
 
     def _forward_impl(self, rays, train=False):
         rstruct, keep, B = _rays_struct(rays)
@@ -350,6 +376,7 @@ class nerf_net(nn.Module):
         _kaiming_init(self)
         self.to(device)
         self._packed = _PackedMLP()
+        self.mutate_like_reference = MUTATE_LIKE_REFERENCE
 
     def _pack(self) -> _PackedMLP:
         return self._packed.refresh([self.model[i] for i in range(0, 16, 2)],
@@ -364,6 +391,7 @@ class nerf_net(nn.Module):
         h = _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, self.white_bkgd, self.density_bias,
                           self.rgb_padding, self.resample_padding, prof=getattr(self, "prof", None))
         h.num_samples_fine = int(n_fine or 0)
+        h.rays_mutated = int(bool(self.mutate_like_reference))
         return h
 
     def _stash(self, outs):
@@ -378,11 +406,19 @@ class nerf_net(nn.Module):
         The number of fine samples is t_vals.shape[-1]-1, as in the reference (intern/ray.py:147).  With autograd
         enabled and trainable parameters rgb / distance / acc / fine_weights carry the graph to the parameters
         (train.py:72-80); t_vals and coarse_weights are constants, as under the reference's no_grad resampling."""
+        if self.mutate_like_reference:
+            near, far = _mutable_field(rays, "near"), _mutable_field(rays, "far")
         if _wants_grad(self):
             outs = _NerfTrainFn.apply(self, rays, t_vals.detach(), coarse_weights.detach(), *self.parameters())
             self.fine_weights, self.t_vals, self.s_vals = outs[4], outs[3], outs[5]
-            return outs
-        return self._forward_impl(rays, t_vals, coarse_weights)
+        else:
+            outs = self._forward_impl(rays, t_vals, coarse_weights)
+        if self.mutate_like_reference:  # t_to_s (model.py:196): g(near), g(far), g(near) on the caller's tensors
+            with torch.no_grad():
+                near.add_(EPS_G)
+                far.add_(EPS_G)
+                near.add_(EPS_G)
+        return outs
 
     def _forward_impl(self, rays, t_vals, coarse_weights, train=False):
         rstruct, keep, B = _rays_struct(rays)
@@ -452,6 +488,7 @@ class mipNeRF360(nn.Module):
         self.init_randomized = randomized
         self.verbose = False
         self.prof = None  # optional _lib.Prof event recorder: set through `set_prof()`
+        self.mutate_like_reference = MUTATE_LIKE_REFERENCE
         self.super_batch_rays = 4096  # render_rays launches this many rays at once when `chunks` is smaller
         self.prop_net = prop_net(randomized=self.randomized, num_samples=self.num_samples,
                                  hidden_proposal=self.hidden_proposal, density_bias=self.density_bias,
@@ -473,6 +510,12 @@ class mipNeRF360(nn.Module):
         """Attach (or with None detach) a `_lib.Prof` event recorder: the stage drivers then record one HIP-event pair
         per kernel on the launch stream (measurement only; bench.py's roofline)."""
         self.prof = self.prop_net.prof = self.nerf_net.prof = prof
+
+    def set_mutate_like_reference(self, on: bool = True) -> None:
+        """Opt in to the reference's side effect: every prop_net.forward adds 1e-6 to the caller's rays.near / rays.far in
+        place and every nerf_net.forward 2e-6 / 1e-6 more (g() of intern/parameterization.py:15-21), so the three forward
+        pairs of one train.py iteration (train.py:51-71) see the same drifting near / far as in the reference."""
+        self.mutate_like_reference = self.prop_net.mutate_like_reference = self.nerf_net.mutate_like_reference = bool(on)
 
     def invalidate_packed(self) -> None:
         """Forget the packed copies of the weights.  Needed only after changing parameters through `.data` (no version
@@ -505,7 +548,8 @@ class mipNeRF360(nn.Module):
 
     def forward(self, rays):
         """model.py:247-252 -> (rgb[B,3], distance[B], acc[B])."""
-        if not self.prop_net.randomized and not self.nerf_net.randomized and not _wants_grad(self):
+        staged = self.prop_net.mutate_like_reference or self.nerf_net.mutate_like_reference
+        if not self.prop_net.randomized and not self.nerf_net.randomized and not _wants_grad(self) and not staged:
             return self._forward_fused(rays)
         t_hat, w_hat = self.prop_net.forward(rays)
         rgb, dist, acc, _, _, _ = self.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
@@ -562,7 +606,7 @@ class mipNeRF360(nn.Module):
         rgb = torch.empty(length, 3, device=dev)
         dist = torch.empty(length, device=dev)
         acc = torch.empty(length, device=dev)
-        fused = not self.prop_net.randomized and not self.nerf_net.randomized
+        fused = not self.prop_net.randomized and not self.nerf_net.randomized and not self.mutate_like_reference
         # Small chunks (the reference's default is 128 rays, config.py:49) are launched many at a time: the chunk
         # partition only matters through the per-chunk contraction norm, which the kernels keep per group of `chunks`
         # rays (m360_hyper_t.norm_group_rays) - bit-identical to one launch per chunk, at large-batch efficiency.

@@ -70,9 +70,10 @@ def g1_g2():
                 T(r["origins"]), T(r["directions"]), T(r["radii"]), n, T(r["near"]), T(r["far"]), False)
             key = f"{kind}_{n}"
             out[key + "_t"] = N(t_vals)
-            if n == 8:  # full contracted gaussians only for the small case (python jacobian loop)
-                out[key + "_means"] = N(means)
-                out[key + "_covs"] = N(covs)
+            # the reference's own conical_frustum_to_gaussian + gaussian_contract + origin shift (para_rays) for EVERY
+            # sample count, so the near = 0 / N = 128 near-denormal t_var / r_var are pinned directly (768 Jacobian calls)
+            out[key + "_means"] = N(means)
+            out[key + "_covs"] = N(covs)
             # pre-contraction lift (G2)
             # the frustum moments are only INPUTS of the reference's gaussian_to_xyz here; they
             # are pinned end-to-end by the contracted means/covs of sample_along_rays above
@@ -452,9 +453,83 @@ def g13():
     save("g13_train_gradients", **out)
 
 
+def g14():
+    """Reference-mutation fidelity (train.py:51-71): the reference's g() adds 1e-6 IN PLACE, so
+    within one training iteration - three (prop forward, nerf forward) pairs on ONE rays object - rays.near gains
+    3e-6 and rays.far 2e-6 per pair.  For nerf_360 (near = 0) the 2nd and 3rd pair therefore sample from
+    near ~ 3e-6 / 6e-6 instead of 1e-6.  This fixture runs the loop body of train.py:53-80 (without optimizer steps:
+    weights stay fixed) on ONE rays object and stores what every pair produced, the gradients of the steps and the
+    final near / far.  Mirrors reproduce it with mutate_like_reference=True."""
+    from intern import loss as ref_loss
+    out = {}
+    hp_, hn_ = 32, 64
+    sd = synthetic.make_state_dict(hp_, hn_, seed=7)
+    for k, v in sd.items():
+        out["sd." + k] = v
+    gen = np.random.Generator(np.random.PCG64(1414))
+    for kind, B, n, wb in (("garden", 10, 24, False), ("lego", 6, 16, True)):
+        r = synthetic.make_rays(kind, B, seed=140 + n)
+        pixels = gen.uniform(0, 1, size=(B, 3)).astype(np.float32)
+        m = build_ref_model(sd, n, hp_, hn_, wb)
+        m.train()
+        for k in synthetic.RAY_FIELDS:
+            out[f"{kind}_rays_{k}"] = r[k]
+        out[f"{kind}_cfg"], out[f"{kind}_pixels"] = np.array([B, n, int(wb)]), pixels
+        rays = ref_rays(r)  # ONE object for the three pairs, as in train.py:52
+        for pair in range(2):  # train.py:53-65
+            m.zero_grad()
+            t_hat, w_hat = m.prop_net.forward(rays)
+            _, _, _, t, w, s = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+            loss_prop = ref_loss.Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
+            loss_prop.backward()
+            out[f"{kind}_p{pair}_t_hat"], out[f"{kind}_p{pair}_w_hat"] = N(t_hat), N(w_hat)
+            out[f"{kind}_p{pair}_t"], out[f"{kind}_p{pair}_w"], out[f"{kind}_p{pair}_s"] = N(t), N(w), N(s)
+            out[f"{kind}_p{pair}_loss_prop"] = N(loss_prop)
+            out[f"{kind}_p{pair}_near"], out[f"{kind}_p{pair}_far"] = N(rays.near), N(rays.far)
+            for name, p in m.named_parameters():
+                if name.startswith("prop_net"):
+                    out[f"{kind}_p{pair}_grad.{name}"] = N(p.grad)
+        m.zero_grad()  # train.py:68-80
+        t_hat, w_hat = m.prop_net.forward(rays)
+        rgb, dist, acc, t, fine_w, s_vals = m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+        loss_nerf, psnr = ref_loss.Loss_nerf(input=rgb, target=T(pixels))
+        loss_dist = ref_loss.Loss_dist(s_vals=s_vals, weights=fine_w)
+        (loss_nerf + 0.01 * loss_dist).backward()
+        out[f"{kind}_p2_t_hat"], out[f"{kind}_p2_w_hat"] = N(t_hat), N(w_hat)
+        out[f"{kind}_p2_t"], out[f"{kind}_p2_w"], out[f"{kind}_p2_s"] = N(t), N(fine_w), N(s_vals)
+        out[f"{kind}_p2_rgb"], out[f"{kind}_p2_dist"], out[f"{kind}_p2_acc"] = N(rgb), N(dist), N(acc)
+        out[f"{kind}_p2_loss_nerf"], out[f"{kind}_p2_loss_dist"] = N(loss_nerf), N(loss_dist)
+        out[f"{kind}_p2_near"], out[f"{kind}_p2_far"] = N(rays.near), N(rays.far)
+        for name, p in m.named_parameters():
+            if name.startswith("nerf_net"):
+                out[f"{kind}_p2_grad.{name}"] = N(p.grad)
+    save("g14_mutation", **out)
+
+
+def g15():
+    """Row f4: a checkpoint written by the REFERENCE's own class exactly as train.py:98-103 writes it
+    (`torch.save(model.state_dict(), path)`; tiny widths, the reference's own kaiming init under a fixed torch seed),
+    plus what that reference model renders on a small seeded batch - `load_reference_checkpoint` must load the file
+    and reproduce the render."""
+    torch.manual_seed(1515)
+    n = 16
+    m = ref_model.mipNeRF360(randomized=False, num_samples=n, hidden_proposal=16, hidden_nerf=24, white_bkgd=True, device=CPU)
+    path = os.path.join(HERE, "g15_reference_checkpoint.pt")
+    torch.save(m.state_dict(), path)
+    print(f"  wrote g15_reference_checkpoint.pt  ({os.path.getsize(path) / 1024:.1f} KiB)")
+    r = synthetic.make_rays("lego", 12, seed=150)
+    m.eval()
+    with torch.no_grad():
+        rgb, dist, acc = m(ref_rays(r))
+    out = {f"rays_{k}": r[k] for k in synthetic.RAY_FIELDS}
+    out.update(rgb=N(rgb), dist=N(dist), acc=N(acc), cfg=np.array([n, 16, 24, 1]))
+    save("g15_reference_render", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
-    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13)
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14,
+                 g15=g15)
     for k in which:
         print(k)
         table[k]()

@@ -75,9 +75,9 @@ def test_g1_g2_sampling_and_lift(golden, dev, kind, n):
     mean, cov = P.gaussian_to_xyz(d, tm, tv, rv)
     close(mean, g[f"{kind}_{n}_xyzmean"], atol=1e-7)
     close(cov, g[f"{kind}_{n}_xyzcov"], atol=1e-9, rtol=1e-5)
-    if n == 8:
-        close(means, g[f"{kind}_{n}_means"])
-        close(covs, g[f"{kind}_{n}_covs"], atol=1e-9, rtol=2e-4)
+    # the reference's own contracted Gaussians at every sample count (near = 0 / N = 128: near-denormal variances)
+    close(means, g[f"{kind}_{n}_means"])
+    close(covs, g[f"{kind}_{n}_covs"], atol=1e-9 if n == 8 else 1e-12, rtol=2e-4)
 
 
 @pytest.mark.parametrize("case", ["big", "tiny", "inside"])
@@ -1147,3 +1147,74 @@ def test_gradients_are_bitwise_reproducible(dev):
     assert torch.equal(l1, l2)
     assert all(torch.equal(a, b) for a, b in zip(g1, g2))
     assert all(bool(torch.isfinite(a).all()) for a in g1) and any(float(a.abs().max()) > 0 for a in g1)
+
+
+@pytest.mark.parametrize("kind", ["garden", "lego"])
+def test_g14_mutate_like_reference_three_pairs(golden, dev, kind):
+    """G14: the loop body of train.py:51-80 on ONE rays object with mutate_like_reference=True - the mirrors bump the
+    caller's rays.near / rays.far in place exactly like the reference's g(), so pairs 2 and 3 sample from the drifted
+    near / far: every pair's outputs, the gradients of the three steps and the final near / far (bitwise)."""
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
+    g = golden("g14_mutation")
+    B, n, wb = (int(v) for v in g[f"{kind}_cfg"])
+    sd = {k[3:]: g[k] for k in g if k.startswith("sd.")}
+    model = build_model(sd, dev, n, 32, 64, bool(wb))
+    model.train()
+    model.set_mutate_like_reference(True)
+    rays = dev_rays({f: g[f"{kind}_rays_{f}"] for f in synthetic.RAY_FIELDS}, dev)  # ONE object for the three pairs
+    for pair in range(2):
+        t_hat, w_hat = model.prop_net.forward(rays)
+        _, _, _, t, w, s = model.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        loss_prop = Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
+        model.zero_grad()
+        loss_prop.backward()
+        close(t_hat, g[f"{kind}_p{pair}_t_hat"], atol=0, rtol=3e-6)
+        close(w_hat, g[f"{kind}_p{pair}_w_hat"], atol=3e-6)
+        close(t, g[f"{kind}_p{pair}_t"], atol=2e-6, rtol=1e-5)
+        close(w, g[f"{kind}_p{pair}_w"], atol=3e-6)
+        close(s, g[f"{kind}_p{pair}_s"], atol=3e-6)
+        assert np.array_equal(H(rays.near), g[f"{kind}_p{pair}_near"]) and np.array_equal(H(rays.far), g[f"{kind}_p{pair}_far"])
+        close(loss_prop, g[f"{kind}_p{pair}_loss_prop"], rtol=5e-4)
+        for name, p in model.named_parameters():
+            if name.startswith("prop_net"):
+                _grad_close(p.grad, g[f"{kind}_p{pair}_grad.{name}"], name, rel=5e-4)
+    t_hat, w_hat = model.prop_net.forward(rays)
+    rgb, dist, acc, t, fine_w, s_vals = model.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+    loss_nerf, _ = Loss_nerf(input=rgb, target=D(g[f"{kind}_pixels"], dev))
+    loss_dist = Loss_dist(s_vals=s_vals, weights=fine_w)
+    model.zero_grad()
+    (loss_nerf + 0.01 * loss_dist).backward()
+    close(t_hat, g[f"{kind}_p2_t_hat"], atol=0, rtol=3e-6)
+    close(rgb, g[f"{kind}_p2_rgb"], atol=RGB_TOL), close(acc, g[f"{kind}_p2_acc"], atol=RGB_TOL)
+    close(s_vals, g[f"{kind}_p2_s"], atol=3e-6)
+    close(loss_nerf, g[f"{kind}_p2_loss_nerf"], rtol=5e-5), close(loss_dist, g[f"{kind}_p2_loss_dist"], rtol=5e-5)
+    assert np.array_equal(H(rays.near), g[f"{kind}_p2_near"]) and np.array_equal(H(rays.far), g[f"{kind}_p2_far"])
+    for name, p in model.named_parameters():
+        if name.startswith("nerf_net"):
+            _grad_close(p.grad, g[f"{kind}_p2_grad.{name}"], name)
+    # default mode: caller tensors untouched, every pair behaves like the reference's first
+    plain = build_model(sd, dev, n, 32, 64, bool(wb))
+    fresh = dev_rays({f: g[f"{kind}_rays_{f}"] for f in synthetic.RAY_FIELDS}, dev)
+    with torch.no_grad():
+        for _ in range(2):
+            t0, _ = plain.prop_net.forward(fresh)
+            close(t0, g[f"{kind}_p0_t_hat"], atol=0, rtol=3e-6)
+    assert np.array_equal(H(fresh.near), g[f"{kind}_rays_near"])
+
+
+def test_g15_reference_written_checkpoint_loads_and_renders(golden, dev):
+    """Row f4: the file the reference's own class wrote with torch.save(model.state_dict()) loads through
+    load_reference_checkpoint and renders what the reference rendered (fixture G15)."""
+    import os
+    from conftest import GOLDEN_DIR
+    from mipnerf360_amd import checkpoint
+    g = golden("g15_reference_render")
+    m = checkpoint.load_reference_checkpoint(os.path.join(GOLDEN_DIR, "g15_reference_checkpoint.pt"), device=dev,
+                                             num_samples=int(g["cfg"][0]), white_bkgd=True)
+    assert m.hidden_proposal == 16 and m.hidden_nerf == 24 and not m.training
+    with torch.no_grad():
+        rgb, dist, acc = m(dev_rays({f: g[f"rays_{f}"] for f in synthetic.RAY_FIELDS}, dev))
+    close_render(rgb, dist, acc, g["rgb"], g["dist"], g["acc"])
+    back = checkpoint.to_reference_state_dict(m)
+    ref = torch.load(os.path.join(GOLDEN_DIR, "g15_reference_checkpoint.pt"), map_location="cpu")
+    assert list(back) == list(ref) and all(torch.equal(back[k], ref[k]) for k in ref)

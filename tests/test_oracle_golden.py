@@ -29,10 +29,11 @@ def test_g1_t_sampling_and_g2_lift(golden, kind, n):
     mean, cov = O.lift_to_xyz(d, T(g[f"{kind}_{n}_tmean"]), T(g[f"{kind}_{n}_tvar"]), T(g[f"{kind}_{n}_rvar"]))
     close(mean, g[f"{kind}_{n}_xyzmean"], atol=1e-7)
     close(cov, g[f"{kind}_{n}_xyzcov"], atol=1e-9, rtol=1e-5)
-    if n == 8:
-        m, c = O.para_rays(t, T(g[f"{kind}_origins"]), d, radii)
-        close(m, g[f"{kind}_{n}_means"])
-        close(c, g[f"{kind}_{n}_covs"], atol=1e-9, rtol=2e-4)
+    # the reference's own conical_frustum_to_gaussian -> gaussian_contract -> + origins at EVERY sample count: pins the
+    # near = 0 / N = 128 near-denormal t_var / r_var directly (not only through the rendered colours of G8)
+    m, c = O.para_rays(t, T(g[f"{kind}_origins"]), d, radii)
+    close(m, g[f"{kind}_{n}_means"])
+    close(c, g[f"{kind}_{n}_covs"], atol=1e-9 if n == 8 else 1e-12, rtol=2e-4)
 
 
 @pytest.mark.parametrize("case", ["big", "tiny", "inside"])
@@ -259,3 +260,66 @@ def test_g13_training_gradients(golden, kind):
     grads = O.nerf_output_gradients(rays, sd, hp, c_acc=torch.from_numpy(g[f"{kind}_cb"]))
     for name, gr in grads.items():
         _grad_close(gr.numpy(), g[f"{kind}_acc.{name}"], name)
+
+
+def _bump(x, times):
+    """what the reference's in-place `x += 1e-6` leaves after `times` calls of g() on the same tensor (fp32 adds)"""
+    y = x.clone()
+    for _ in range(times):
+        y = y + O.EPS_G
+    return y
+
+
+@pytest.mark.parametrize("kind", ["garden", "lego"])
+def test_g14_reference_mutation_over_three_pairs(golden, kind):
+    """G14: train.py:51-71 runs three (prop, nerf) forward pairs on ONE rays object and the reference's g() keeps
+    bumping rays.near (+3e-6 per pair) and rays.far (+2e-6 per pair) in place.  The oracle fed the near / far the k-th
+    pair starts from reproduces every pair's outputs, the final near / far bitwise, and the step gradients."""
+    g = golden("g14_mutation")
+    B, n, wb = (int(v) for v in g[f"{kind}_cfg"])
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g if k.startswith("sd.")}
+    hp = O.Hyper(num_samples=n, white_bkgd=bool(wb))
+    base = {f: torch.from_numpy(g[f"{kind}_rays_{f}"]) for f in synthetic.RAY_FIELDS}
+    for pair in range(3):
+        fields = dict(base, near=_bump(base["near"], 3 * pair), far=_bump(base["far"], 2 * pair))
+        rays = O.Rays(*[fields[f] for f in synthetic.RAY_FIELDS])
+        assert np.array_equal(_bump(base["near"], 3 * pair + 3).numpy(), g[f"{kind}_p{pair}_near"])
+        assert np.array_equal(_bump(base["far"], 2 * pair + 2).numpy(), g[f"{kind}_p{pair}_far"])
+        with torch.no_grad():
+            t_hat, w_hat = O.prop_forward(rays, sd, hp)
+            out = O.nerf_forward(rays, t_hat, w_hat, sd, hp)
+        close(t_hat, g[f"{kind}_p{pair}_t_hat"], atol=0, rtol=3e-6)
+        close(w_hat, g[f"{kind}_p{pair}_w_hat"], atol=2e-6)
+        close(out[3], g[f"{kind}_p{pair}_t"], atol=2e-6, rtol=1e-5)
+        close(out[4], g[f"{kind}_p{pair}_w"], atol=2e-6)
+        close(out[5], g[f"{kind}_p{pair}_s"], atol=2e-6)
+        if pair < 2:
+            loss, grads = O.prop_step_gradients(rays, sd, hp)
+            np.testing.assert_allclose(loss.numpy(), g[f"{kind}_p{pair}_loss_prop"], rtol=5e-5)
+            for name, gr in grads.items():
+                _grad_close(gr.numpy(), g[f"{kind}_p{pair}_grad.{name}"], name)
+        else:
+            close(out[0], g[f"{kind}_p2_rgb"], atol=2e-6), close(out[2], g[f"{kind}_p2_acc"], atol=2e-6)
+            ln, ld, grads = O.nerf_step_gradients(rays, sd, hp, torch.from_numpy(g[f"{kind}_pixels"]))
+            np.testing.assert_allclose(ln.numpy(), g[f"{kind}_p2_loss_nerf"], rtol=2e-5)
+            np.testing.assert_allclose(ld.numpy(), g[f"{kind}_p2_loss_dist"], rtol=2e-5)
+            for name, gr in grads.items():
+                _grad_close(gr.numpy(), g[f"{kind}_p2_grad.{name}"], name)
+    # the drift is real: pair 2 samples from a different near than pair 0 (near = 0: 7e-6 vs 1e-6 for the first t)
+    if kind == "garden":
+        assert g["garden_p2_t_hat"][0, 0] > 5 * g["garden_p0_t_hat"][0, 0]
+
+
+def test_g15_reference_written_checkpoint(golden):
+    """Row f4: a file written by the reference's own class with torch.save(model.state_dict()) (train.py:98-103):
+    the layout the tooling expects (30 tensors, reference key order) and, through the oracle, the reference's render."""
+    import os
+    from conftest import GOLDEN_DIR
+    from mipnerf360_amd import checkpoint
+    sd = torch.load(os.path.join(GOLDEN_DIR, "g15_reference_checkpoint.pt"), map_location="cpu")
+    assert len(sd) == 30 and list(sd)[0] == "prop_net.model.0.weight" and list(sd)[-1] == "nerf_net.final_color.0.bias"
+    assert checkpoint.infer_config(sd) == dict(hidden_proposal=16, hidden_nerf=24, viewdir_min_deg=0, viewdir_max_deg=4)
+    g = golden("g15_reference_render")
+    rays = O.Rays(*[torch.from_numpy(g[f"rays_{f}"]) for f in synthetic.RAY_FIELDS])
+    rgb, dist, acc = O.forward(rays, {k: v.float() for k, v in sd.items()}, O.Hyper(num_samples=int(g["cfg"][0]), white_bkgd=True))
+    close(rgb, g["rgb"], atol=2e-6), close(acc, g["acc"], atol=2e-6), close(dist, g["dist"], atol=2e-6, rtol=1e-5)

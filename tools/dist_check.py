@@ -6,7 +6,10 @@
 
 Every rank renders the same small synthetic frame with `render_image_sharded` (chunk-granular ray sharding +
 one all-gather of the [rays,5] pixel block) and compares it bit for bit with its own single-GPU `render_image`.
-Works with N = 1 as well (the all-gather then has a single participant)."""
+Works with N = 1 as well (the all-gather then has a single participant).
+
+  ... tools/dist_check.py --backend gloo --same-gpu     (tests/: N ranks of the HIP renderer on ONE GPU; RCCL refuses
+  two ranks on one device, so the collectives go through gloo with host staging - the compute path is unchanged)"""
 import os
 import sys
 
@@ -23,17 +26,27 @@ from mipnerf360_amd.model import mipNeRF360  # noqa: E402
 
 
 def main():
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl")
+    ap.add_argument("--same-gpu", action="store_true", help="every rank uses cuda:0")
+    ap.add_argument("--full-width", action="store_true", help="256 / 1024 hidden units instead of 64 / 128")
+    args = ap.parse_args()
+    local_rank = 0 if args.same_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
-    dist.init_process_group("nccl", device_id=dev)
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
     h, w, n, chunks = 40, 53, 32, 256
-    sd = synthetic.make_state_dict(64, 128, seed=3)
-    m = mipNeRF360(num_samples=n, hidden_proposal=64, hidden_nerf=128, device=dev)
+    hp, hn = (256, 1024) if args.full_width else (64, 128)
+    sd = synthetic.make_state_dict(hp, hn, seed=3)
+    m = mipNeRF360(num_samples=n, hidden_proposal=hp, hidden_nerf=hn, device=dev)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     r = synthetic.make_rays("garden", h * w, seed=21)
     rays = Rays(*[torch.from_numpy(r[k]) for k in synthetic.RAY_FIELDS])
@@ -55,7 +68,7 @@ def main():
     ok = ok and err <= (0.0 if world == 1 else 2e-6)
     if rank == 0:
         print(f"dist_check forward_sharded max |diff| vs whole-batch forward: {err:.2e}")
-    flag = torch.tensor([1 if ok else 0], device=dev)
+    flag = torch.tensor([1 if ok else 0], device=dev if args.backend == "nccl" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if dist.get_rank() == 0:
         print(f"dist_check world={dist.get_world_size()} sharded==single: {bool(flag.item())}")
