@@ -309,6 +309,40 @@ int m360_nerf_finish(const float *act, int ld, const float *head_w, const float 
                      const float *dirs, int B, int N, int white_bkgd, float *comp_rgb,
                      float *distance, float *acc, float *weights /*or NULL*/, m360_stream_t stream);
 
+/* ------------------------------------------------------------------ fused last layer + heads ----- */
+
+/* The LAST hidden layer of a stage (sigmoid, model.py:50 / :146) fused with the stage's output heads (model.py:52:
+ * hidden -> 1; model.py:150-158: hidden -> 1 + 3): while a 256 x 256 output tile is still in registers its activated
+ * values are multiplied with the `heads` (1 or 4) head rows head_w[heads,n_pad] (fp32, the m360_model_t layout) and
+ * per-row PARTIAL sums go to head_part[fused_rows][slots][heads] (slots = m360_linear_heads_slots(n_pad), one per
+ * 128-column wave tile; no bias).  store_y = 0: the fused rows of y are NOT written (rendering: the 2.15 GB activation
+ * of the last NeRF layer never reaches HBM); store_y = 1: also written (training tape).  Rows beyond
+ * fused_rows = m360_linear_heads_fused_rows(M, n_pad) (ragged tail; every row when n_pad % 256 != 0 or n_pad > 1024)
+ * are computed as by m360_linear into y, and the *_finish_fused entry points take their head products from there.
+ * Replaces the last nn.Linear + nn.Sigmoid of model.py:43-53 / :131-148 plus the matrix product of the heads. */
+long m360_linear_heads_fused_rows(long M, int n_pad);
+int m360_linear_heads_slots(int n_pad);
+int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad,
+                      int k_pad, int act /* M360_ACT_SIGMOID */, float *y, int ldy, int store_y, const float *head_w,
+                      int heads, float *head_part, m360_stream_t stream);
+/* bf16 counterpart (x, w_packed, y: bf16 as for m360_linear_bf16; head_w, head_part: fp32; the head product uses the
+ * bf16-ROUNDED activations, i.e. exactly what m360_nerf_finish_bf16 would read back) */
+int m360_linear_heads_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
+                           int k_pad, int act, void *y, int ldy, int store_y, const float *head_w, int heads,
+                           float *head_part, m360_stream_t stream);
+
+/* m360_prop_finish_n / m360_nerf_finish whose head products of the samples [0, fused_rows) come from
+ * head_part[fused_rows][slots][heads] (summed slot 0, 1, ... + bias) and of the remaining samples from the activation
+ * rows `act` (fp32, or bf16 when act_bf16 != 0) as before.  fused_rows = 0 is exactly the unfused finisher. */
+int m360_prop_finish_fused(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots,
+                           const float *head_w, const float *head_b, int k_pad, float density_bias,
+                           const float *t_vals, const float *dirs, const float *u_rand, int B, int N, int num_out,
+                           float resample_padding, float *weights, float *t_new, m360_stream_t stream);
+int m360_nerf_finish_fused(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots,
+                           const float *head_w, const float *head_b, int k_pad, float density_bias, float rgb_padding,
+                           const float *t_vals, const float *dirs, int B, int N, int white_bkgd, float *comp_rgb,
+                           float *distance, float *acc, float *weights, m360_stream_t stream);
+
 /* ------------------------------------------------------------------ whole forward ----- */
 
 typedef struct {

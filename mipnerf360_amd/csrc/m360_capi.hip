@@ -78,7 +78,7 @@ __global__ void add_eps_kernel(const float *__restrict__ x, long n, float *__res
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FwdLayout {
-    size_t norm, vdenc, t1, t0, what, feat, act_a, act_b, total;
+    size_t norm, vdenc, t1, t0, what, feat, act_a, act_b, hpart, total;
 };
 
 static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
@@ -96,6 +96,10 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     L.feat = take(S * m->in_pad * sizeof(float));
     L.act_a = take(S * wmax * sizeof(float));
     L.act_b = take(S * wmax * sizeof(float));
+    // partial head sums of the fused last layer: [S][slots][heads] fp32 (67 MB at 4096 x 128, width 1024)
+    const size_t hp_slots = (size_t)m360_linear_heads_slots(m->hp_pad), hn_slots = (size_t)m360_linear_heads_slots(m->hn_pad);
+    const size_t hp_b = S * hp_slots * 1 * sizeof(float), hn_b = S * hn_slots * 4 * sizeof(float);
+    L.hpart = take(hp_b > hn_b ? hp_b : hn_b);
     L.total = off;
     return L;
 }
@@ -143,6 +147,20 @@ static int p_encode_grouped(const m360_hyper_t *h, const float *t, const float *
 static int p_encode_ext_norm(const m360_hyper_t *h, const float *t, const float *o, const float *d, const float *rad, const float *vdenc, int vd_ch, int B, int N, void *feat, int ld, int bf16, const float *norm, void *ws, size_t wsb, m360_stream_t st) {
     ProfScope ps(h, st, M360_K_ENCODE, (long)B * N, ld, bf16);
     return ps.done(m360_encode_features_ext_norm(t, o, d, rad, vdenc, vd_ch, B, N, feat, ld, bf16, norm, ws, wsb, st));
+}
+// last hidden layer + heads fused (fp32 or bf16): partial head sums to `part`, y written only when store_y
+static int p_linear_heads(const m360_hyper_t *h, int bf16, const void *x, long M, int ldx, const void *w, const float *b, int n_pad, int k_pad, void *y, int ldy, int store_y, const float *head_w, int heads, float *part, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_LINEAR_HEADS, M, n_pad, bf16 ? -k_pad : k_pad);
+    if (bf16) return ps.done(m360_linear_heads_bf16(x, M, ldx, w, b, n_pad, k_pad, M360_ACT_SIGMOID, y, ldy, store_y, head_w, heads, part, st));
+    return ps.done(m360_linear_heads(static_cast<const float *>(x), M, ldx, static_cast<const float *>(w), b, n_pad, k_pad, M360_ACT_SIGMOID, static_cast<float *>(y), ldy, store_y, head_w, heads, part, st));
+}
+static int p_prop_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, float *w_hat, float *t_new, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_PROP_FINISH, (long)B * N, k_pad, bf16);
+    return ps.done(m360_prop_finish_fused(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st));
+}
+static int p_nerf_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, const m360_outputs_t *out, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_NERF_FINISH, (long)B * N, k_pad, bf16);
+    return ps.done(m360_nerf_finish_fused(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, dirs, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
 }
 static int p_prop_finish(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, float *w_hat, float *t_new, m360_stream_t st) {
     ProfScope ps(h, st, M360_K_PROP_FINISH, (long)B * N, k_pad, bf16);

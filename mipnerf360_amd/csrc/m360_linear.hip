@@ -320,6 +320,47 @@ int m360_linear(const float *x, long M, int ldx, const float *w_packed, const fl
     return launch_linear(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, nullptr, stream);
 }
 
+// ---- last hidden layer of a stage fused with its heads
+long m360_linear_heads_fused_rows(long M, int n_pad) {
+    if (M < 0 || n_pad < persist::BN || n_pad % persist::BN != 0 || n_pad > persist::kHeadMaxN) return 0;
+    return (M / persist::BM) * persist::BM;
+}
+
+int m360_linear_heads_slots(int n_pad) { return n_pad >= persist::BN ? 2 * (n_pad / persist::BN) : 0; }
+
+int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
+                      int act, float *y, int ldy, int store_y, const float *head_w, int heads, float *head_part,
+                      m360_stream_t stream) {
+    if (heads != 1 && heads != 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads: heads=%d (1 or 4)", heads);
+    if (act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads: the last hidden layer is a sigmoid layer (model.py:50,146), act=%d", act);
+    if (!x || !w_packed || !b_packed || !y || !head_w || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads: null pointer or negative M");
+    const long M_fused = m360_linear_heads_fused_rows(M, n_pad);
+    if (M_fused > 0) {
+        if (!head_part || ((uintptr_t)head_part & 15) || ((uintptr_t)head_w & 15)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads: head_part / head_w must be 16-byte aligned device pointers");
+        if (k_pad < BK || k_pad % BK != 0 || ldx < k_pad || ldy < n_pad || ldx % 4 != 0 || ldy % 4 != 0)
+            return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad, ldy=%d >= n_pad=%d, both multiples of 4", k_pad, BK, ldx, ldy, n_pad);
+        if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads: x, w_packed, b_packed and y must be 16-byte aligned");
+        const int cus = cu_count();
+        if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear_heads: no HIP device");
+        const long nt = (M_fused / persist::BM) * (n_pad / persist::BN);
+        dim3 grid((unsigned)(nt < cus ? nt : cus)), block(persist::kThreads);
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        const int tn = n_pad / persist::BN;
+#define M360_LAUNCH_HEADS(H, SY) hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID, false, H, SY>), grid, block, 0, st, x, M_fused, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tn, (int)nt, nullptr, head_w, head_part)
+        if (heads == 1) {
+            if (store_y) M360_LAUNCH_HEADS(1, true); else M360_LAUNCH_HEADS(1, false);
+        } else {
+            if (store_y) M360_LAUNCH_HEADS(4, true); else M360_LAUNCH_HEADS(4, false);
+        }
+#undef M360_LAUNCH_HEADS
+        const int rc = check_launch("linear_heads");
+        if (rc != M360_OK) return rc;
+    }
+    if (M > M_fused)  // ragged tail rows / widths the fused epilogue does not take: the plain layer; the finisher reads y there
+        return launch_linear(x + M_fused * ldx, M - M_fused, ldx, w_packed, b_packed, n_pad, k_pad, act, y + M_fused * ldy, ldy, nullptr, stream);
+    return M360_OK;
+}
+
 // ---- training path: input gradient, weight gradient, transposed packing
 int m360_linear_dgrad(const float *dz, long M, int ldz, const float *wt_packed, int k_pad, int n_pad,
                       const float *relu_out, float *dx, int ldx, m360_stream_t stream) {

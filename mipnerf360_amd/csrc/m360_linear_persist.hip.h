@@ -53,12 +53,29 @@ __device__ unsigned long long g_stamps[256 * 16];
 #define M360_STAMP_STORE(i, v) ((void)(v))
 #endif
 
-template <int ACT, bool STAMP = false>
+constexpr int kHeadMaxN = 1024;  // widest layer whose heads can be fused (bias + head rows live in LDS: (1 + HEADS) x 4 KiB)
+
+// xor-butterfly over the 8 consecutive lanes that share an output row in the epilogue (DPP: no LDS traffic)
+__device__ __forceinline__ float row8_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));  // row_half_mirror: lane i <-> 7 - i
+    return x;
+}
+
+// HEADS > 0 (the LAST hidden layer of a stage): the epilogue also multiplies the activated outputs with the HEADS head
+// rows (model.py:52 / :150-158: hidden -> 1 density, hidden -> 1 + 3 density / colour) while they are in registers and
+// writes per-row PARTIAL head sums head_part[M][2 * tiles_n][HEADS] (one slot per 128-column wave tile; the finisher
+// adds the slots in a fixed order).  With STORE_Y = false the layer output itself never goes to HBM (rendering);
+// the training tape keeps it (STORE_Y = true) - both produce the same partial sums bit for bit.
+template <int ACT, bool STAMP = false, int HEADS = 0, bool STORE_Y = true>
 __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     const float *__restrict__ X, long M, int ldx, const float *__restrict__ W,
     const float *__restrict__ bias, int Np, int Kp, float *__restrict__ Y, int ldy, int tiles_n,
-    int ntiles, const float *__restrict__ aux = nullptr) {
+    int ntiles, const float *__restrict__ aux = nullptr, const float *__restrict__ head_w = nullptr,
+    float *__restrict__ head_part = nullptr) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * kBufFloats];  // 128 KiB
+    __shared__ __attribute__((aligned(16))) float s_hw[HEADS > 0 ? (1 + HEADS) * kHeadMaxN : 4];  // bias, then the head rows
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -182,6 +199,13 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     unsigned long long mt0 = 0, mt1 = 0, rt0 = 0, rt1 = 0;  // whole tile loop: s_memtime (shader clock) / s_memrealtime (100 MHz)
     int lin_id = blockIdx.x;
     if (lin_id >= ntiles) return;
+    if (HEADS > 0) {  // before any LDS-DMA is in flight; made visible by the __syncthreads() below
+        for (int c = tid; c < Np; c += kThreads) {
+            s_hw[c] = bias[c];
+#pragma unroll
+            for (int hh = 0; hh < HEADS; ++hh) s_hw[(1 + hh) * kHeadMaxN + c] = head_w[(long)hh * Np + c];
+        }
+    }
     long m0;
     int n0;
     tile_coords(lin_id, m0, n0);
@@ -268,34 +292,82 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
             // idle buffer can therefore never overwrite another wave's staging rows, and program order protects ours
             float *stg = dma_dst + (buf ^ 1) * kBufFloats;
             const int rrow = lane >> 3, rcol = 4 * (lane & 7);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float4 b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (ACT != M360_ACT_RELU_MASK) b4 = *reinterpret_cast<const float4 *>(bias + n0 + wn * 128 + j * 32 + rcol);
+            if constexpr (HEADS > 0) {
+                // row-major walk (all 4 column blocks of a 32-row block before the next rows): a lane carries the head
+                // sums of its 4 rows (p) across the 128 columns of the wave tile, then the 8 lanes of a row are reduced
+                const int slots = 2 * tiles_n, slot = 2 * (n0 / BN) + wn;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
+                    float hacc[4][HEADS];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = acc[i][j][r];
-                    const long yoff = (long)(wm * 128 + i * 32 + rrow) * ldy_t + wn * 128 + j * 32 + rcol;
-                    float *__restrict__ Yc = Yt + yoff;
+                    for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        float4 v = *reinterpret_cast<const float4 *>(stg + (p * 8 + rrow) * 36 + rcol);
-                        if (ACT == M360_ACT_RELU_MASK) {  // backward of ReLU: keep where the forward output (aux, same ld) was > 0
-                            const float4 a4 = *reinterpret_cast<const float4 *>(aux + m0 * ldy_t + n0 + yoff + (long)(p * 8) * ldy_t);
-                            v.x = a4.x > 0.0f ? v.x : 0.0f;
-                            v.y = a4.y > 0.0f ? v.y : 0.0f;
-                            v.z = a4.z > 0.0f ? v.z : 0.0f;
-                            v.w = a4.w > 0.0f ? v.w : 0.0f;
-                        } else {
+                        for (int hh = 0; hh < HEADS; ++hh) hacc[p][hh] = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = n0 + wn * 128 + j * 32 + rcol;
+                        const float4 b4 = *reinterpret_cast<const float4 *>(s_hw + col);
+                        float4 hw4[HEADS];
+#pragma unroll
+                        for (int hh = 0; hh < HEADS; ++hh) hw4[hh] = *reinterpret_cast<const float4 *>(s_hw + (1 + hh) * kHeadMaxN + col);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = acc[i][j][r];
+                        const long yoff = (long)(wm * 128 + i * 32 + rrow) * ldy_t + wn * 128 + j * 32 + rcol;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            float4 v = *reinterpret_cast<const float4 *>(stg + (p * 8 + rrow) * 36 + rcol);
                             v.x = act_fn<ACT>(v.x + b4.x);
                             v.y = act_fn<ACT>(v.y + b4.y);
                             v.z = act_fn<ACT>(v.z + b4.z);
                             v.w = act_fn<ACT>(v.w + b4.w);
+                            if (STORE_Y) *reinterpret_cast<float4 *>(Yt + yoff + (long)(p * 8) * ldy_t) = v;
+#pragma unroll
+                            for (int hh = 0; hh < HEADS; ++hh)
+                                hacc[p][hh] = fmaf(v.w, hw4[hh].w, fmaf(v.z, hw4[hh].z, fmaf(v.y, hw4[hh].y, fmaf(v.x, hw4[hh].x, hacc[p][hh]))));
                         }
-                        *reinterpret_cast<float4 *>(Yc + (long)(p * 8) * ldy_t) = v;
+                        M360_SB();
                     }
-                    M360_SB();
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                        for (int hh = 0; hh < HEADS; ++hh) hacc[p][hh] = row8_sum(hacc[p][hh]);
+                        if ((lane & 7) == 0) {
+                            float *dst = head_part + ((m0 + wm * 128 + i * 32 + p * 8 + rrow) * slots + slot) * HEADS;
+#pragma unroll
+                            for (int hh = 0; hh < HEADS; ++hh) dst[hh] = hacc[p][hh];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float4 b4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (ACT != M360_ACT_RELU_MASK) b4 = *reinterpret_cast<const float4 *>(bias + n0 + wn * 128 + j * 32 + rcol);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = acc[i][j][r];
+                        const long yoff = (long)(wm * 128 + i * 32 + rrow) * ldy_t + wn * 128 + j * 32 + rcol;
+                        float *__restrict__ Yc = Yt + yoff;
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            float4 v = *reinterpret_cast<const float4 *>(stg + (p * 8 + rrow) * 36 + rcol);
+                            if (ACT == M360_ACT_RELU_MASK) {  // backward of ReLU: keep where the forward output (aux, same ld) was > 0
+                                const float4 a4 = *reinterpret_cast<const float4 *>(aux + m0 * ldy_t + n0 + yoff + (long)(p * 8) * ldy_t);
+                                v.x = a4.x > 0.0f ? v.x : 0.0f;
+                                v.y = a4.y > 0.0f ? v.y : 0.0f;
+                                v.z = a4.z > 0.0f ? v.z : 0.0f;
+                                v.w = a4.w > 0.0f ? v.w : 0.0f;
+                            } else {
+                                v.x = act_fn<ACT>(v.x + b4.x);
+                                v.y = act_fn<ACT>(v.y + b4.y);
+                                v.z = act_fn<ACT>(v.z + b4.z);
+                                v.w = act_fn<ACT>(v.w + b4.w);
+                            }
+                            *reinterpret_cast<float4 *>(Yc + (long)(p * 8) * ldy_t) = v;
+                        }
+                        M360_SB();
+                    }
                 }
             }
         }

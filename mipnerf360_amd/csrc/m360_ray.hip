@@ -286,22 +286,44 @@ __device__ __forceinline__ void head_dots(const T *__restrict__ act_ray, int ld,
     }
 }
 
+// Head products of one ray's N samples -> raw[N][H] (LDS).  Samples whose global row (b N + n) lies below `fused_rows`
+// take them from the partial sums the fused last layer left (m360_linear_heads: head_part[row][slots][H], added slot
+// 0, 1, ... then the bias); the others are computed from the activation rows as in the unfused path.
+template <int H, typename T>
+__device__ __forceinline__ void ray_heads(const T *__restrict__ act, int ld, const float *__restrict__ head_part,
+                                          long fused_rows, int slots, const float *__restrict__ head_w,
+                                          const float *__restrict__ head_b, int k_pad, int b, int N, float *hw /*LDS [H][k_pad]*/,
+                                          float *raw /*LDS [N][H]*/) {
+    const long s0 = (long)b * N;
+    long nfl = fused_rows - s0;
+    const int nf = nfl <= 0 ? 0 : (nfl >= N ? N : (int)nfl);  // block-uniform
+    if (nf < N)
+        for (int i = threadIdx.x; i < H * k_pad; i += blockDim.x) hw[i] = head_w[i];
+    for (int idx = threadIdx.x; idx < nf * H; idx += blockDim.x) {
+        const int n = idx / H, hh = idx % H;
+        const float *p = head_part + ((s0 + n) * slots) * H + hh;
+        float a = 0.0f;
+        for (int q = 0; q < slots; ++q) a += p[q * H];
+        raw[idx] = a + head_b[hh];
+    }
+    __syncthreads();
+    if (nf < N) head_dots<H, T>(act + (s0 + nf) * ld, ld, hw, head_b, k_pad, N - nf, raw + nf * H);
+    __syncthreads();
+}
+
 // model.py:52,92-93 + intern/ray.py:136-149
 template <typename T>
 __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
-    const T *__restrict__ act, int ld, const float *__restrict__ head_w,
-    const float *__restrict__ head_b, int k_pad, float density_bias, const float *__restrict__ t_vals,
-    const float *__restrict__ dirs, const float *__restrict__ u_rand, int N, int ns, float padding,
-    float *__restrict__ weights, float *__restrict__ t_new) {
+    const T *__restrict__ act, int ld, const float *__restrict__ head_part, long fused_rows, int slots,
+    const float *__restrict__ head_w, const float *__restrict__ head_b, int k_pad, float density_bias,
+    const float *__restrict__ t_vals, const float *__restrict__ dirs, const float *__restrict__ u_rand, int N, int ns,
+    float padding, float *__restrict__ weights, float *__restrict__ t_new) {
     extern __shared__ float smem[];
     const int b = blockIdx.x, l = lane_id();
     const int nb = N + 1;
     float *hw = smem, *t = hw + k_pad, *rho = t + nb, *w = rho + nb, *w2 = w + nb, *cdf = w2 + nb;
-    for (int i = threadIdx.x; i < k_pad; i += blockDim.x) hw[i] = head_w[i];
     for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
-    __syncthreads();
-    head_dots<1, T>(act + (long)b * N * ld, ld, hw, head_b, k_pad, N, rho);
-    __syncthreads();
+    ray_heads<1, T>(act, ld, head_part, fused_rows, slots, head_w, head_b, k_pad, b, N, hw, rho);
     if (threadIdx.x >= kWave) return;
     for (int i = l; i < N; i += kWave) rho[i] = softplusf_(rho[i] + density_bias);
     wave_sync();
@@ -317,20 +339,17 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
 // model.py:150-158,180-186 + intern/ray.py:155-191
 template <typename T>
 __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
-    const T *__restrict__ act, int ld, const float *__restrict__ head_w,
-    const float *__restrict__ head_b, int k_pad, float density_bias, float rgb_padding,
-    const float *__restrict__ t_vals, const float *__restrict__ dirs, int N, int white_bkgd,
+    const T *__restrict__ act, int ld, const float *__restrict__ head_part, long fused_rows, int slots,
+    const float *__restrict__ head_w, const float *__restrict__ head_b, int k_pad, float density_bias,
+    float rgb_padding, const float *__restrict__ t_vals, const float *__restrict__ dirs, int N, int white_bkgd,
     float *__restrict__ comp_rgb, float *__restrict__ distance, float *__restrict__ acc,
     float *__restrict__ weights) {
     extern __shared__ float smem[];
     const int b = blockIdx.x, l = lane_id();
     const int nb = N + 1;
     float *hw = smem, *t = hw + 4 * k_pad, *raw = t + nb, *w = raw + 4 * N;
-    for (int i = threadIdx.x; i < 4 * k_pad; i += blockDim.x) hw[i] = head_w[i];
     for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
-    __syncthreads();
-    head_dots<4, T>(act + (long)b * N * ld, ld, hw, head_b, k_pad, N, raw);
-    __syncthreads();
+    ray_heads<4, T>(act, ld, head_part, fused_rows, slots, head_w, head_b, k_pad, b, N, hw, raw);
     if (threadIdx.x >= kWave) return;
     for (int i = l; i < N; i += kWave) {
         raw[4 * i] = softplusf_(sigmoidf_(raw[4 * i]) + density_bias);
@@ -600,7 +619,7 @@ int m360_prop_finish(const float *act, int ld, const float *head_w, const float 
 static int prop_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                            int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
-                           m360_stream_t stream);
+                           m360_stream_t stream, const float *head_part = nullptr, long fused_rows = 0, int slots = 0);
 
 int m360_prop_finish_n(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
                        float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
@@ -616,10 +635,18 @@ int m360_prop_finish_bf16(const void *act_bf16, int ld, const float *head_w, con
     return prop_finish_any(act_bf16, 1, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, stream);
 }
 
+int m360_prop_finish_fused(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots,
+                           const float *head_w, const float *head_b, int k_pad, float density_bias,
+                           const float *t_vals, const float *dirs, const float *u_rand, int B, int N, int num_out,
+                           float resample_padding, float *weights, float *t_new, m360_stream_t stream) {
+    if (fused_rows < 0 || (fused_rows > 0 && (!head_part || slots < 1))) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish_fused: fused_rows=%ld slots=%d head_part=%p", fused_rows, slots, (const void *)head_part);
+    return prop_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, stream, head_part, fused_rows, slots);
+}
+
 static int prop_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                            int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
-                           m360_stream_t stream) {
+                           m360_stream_t stream, const float *head_part, long fused_rows, int slots) {
     if (num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: num_out=%d", num_out);
     const int align = bf16 ? 8 : 4;
     if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < k_pad || ld % align != 0)
@@ -627,15 +654,15 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
     if (B == 0) return M360_OK;
     const size_t lds = ((size_t)k_pad + 5 * (N + 1)) * sizeof(float);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
-    else hipLaunchKernelGGL(prop_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
+    if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
+    else hipLaunchKernelGGL(prop_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
     return check_launch("prop_finish");
 }
 
 static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
                            int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
-                           m360_stream_t stream);
+                           m360_stream_t stream, const float *head_part = nullptr, long fused_rows = 0, int slots = 0);
 
 int m360_nerf_finish(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
                      float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
@@ -651,18 +678,26 @@ int m360_nerf_finish_bf16(const void *act_bf16, int ld, const float *head_w, con
     return nerf_finish_any(act_bf16, 1, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, stream);
 }
 
+int m360_nerf_finish_fused(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots,
+                           const float *head_w, const float *head_b, int k_pad, float density_bias, float rgb_padding,
+                           const float *t_vals, const float *dirs, int B, int N, int white_bkgd, float *comp_rgb,
+                           float *distance, float *acc, float *weights, m360_stream_t stream) {
+    if (fused_rows < 0 || (fused_rows > 0 && (!head_part || slots < 1))) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish_fused: fused_rows=%ld slots=%d head_part=%p", fused_rows, slots, (const void *)head_part);
+    return nerf_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, stream, head_part, fused_rows, slots);
+}
+
 static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
                            int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
-                           m360_stream_t stream) {
+                           m360_stream_t stream, const float *head_part, long fused_rows, int slots) {
     const int align = bf16 ? 8 : 4;
     if (!act || !head_w || !head_b || !t_vals || !dirs || !comp_rgb || !distance || !acc || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < k_pad || ld % align != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: bad argument");
     if (B == 0) return M360_OK;
     const size_t lds = ((size_t)4 * k_pad + (N + 1) + 5 * N) * sizeof(float);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
-    else hipLaunchKernelGGL(nerf_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
+    if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
+    else hipLaunchKernelGGL(nerf_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
     return check_launch("nerf_finish");
 }
 
