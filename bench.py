@@ -196,14 +196,26 @@ def main():
                     "median_launch_ms": round(statistics.median(durs), 4), "flops_per_launch": flops}
         if traffic_note:
             roofline["traffic_note"] = traffic_note
-    # HBM-bound kernels of the path: algorithmic bytes / mean launch duration
+    # HBM-bound kernels of the path: algorithmic bytes / mean launch duration.  The finishers read the
+    # last layer's partial head sums [S, slots, heads] fp32 for the rows the fused epilogue covered, activation rows else.
     el = 2 if bf16 else 4
     in_pad = 64
+    lib = _lib.lib()
+
+    def finish_in_bytes(width, heads):
+        fused = int(lib.m360_linear_heads_fused_rows(S, width, int(bf16)))
+        return fused * int(lib.m360_linear_heads_slots(width)) * heads * 4 + (S - fused) * width * el
+
     hbm_kernels = {}
+    fused_last = [r["ms"] for r in recs if r["kind"] == _lib.K_LINEAR_HEADS and r["n_pad"] == HN]
+    if fused_last:
+        ms = sum(fused_last) / len(fused_last)
+        hbm_kernels["nerf_last_layer_fused_heads"] = {"avg_launch_ms": round(ms, 4), "tflops": round(2.0 * S * HN * HN / ms / 1e9, 1),
+                                                      "launches": len(fused_last), "note": "MFMA-bound; listed for completeness"}
     for kind, name, nbytes in (
             (_lib.K_ENCODE, "encode_features", S * in_pad * el + n_rays * (48 + 4 * (samples + 1))),
-            (_lib.K_PROP_FINISH, "prop_finish", S * HP * el + n_rays * (4 * (samples + 1) + 12 + 4 * samples + 4 * (samples + 1))),
-            (_lib.K_NERF_FINISH, "nerf_finish", S * HN * el + n_rays * (4 * (samples + 1) + 12 + 20))):
+            (_lib.K_PROP_FINISH, "prop_finish", finish_in_bytes(HP, 1) + n_rays * (4 * (samples + 1) + 12 + 4 * samples + 4 * (samples + 1))),
+            (_lib.K_NERF_FINISH, "nerf_finish", finish_in_bytes(HN, 4) + n_rays * (4 * (samples + 1) + 12 + 20))):
         d = [r["ms"] for r in recs if r["kind"] == kind]
         if d:
             ms = sum(d) / len(d)

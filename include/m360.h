@@ -317,10 +317,10 @@ int m360_nerf_finish(const float *act, int ld, const float *head_w, const float 
  * per-row PARTIAL sums go to head_part[fused_rows][slots][heads] (slots = m360_linear_heads_slots(n_pad), one per
  * 128-column wave tile; no bias).  store_y = 0: the fused rows of y are NOT written (rendering: the 2.15 GB activation
  * of the last NeRF layer never reaches HBM); store_y = 1: also written (training tape).  Rows beyond
- * fused_rows = m360_linear_heads_fused_rows(M, n_pad) (ragged tail; every row when n_pad % 256 != 0 or n_pad > 1024)
+ * fused_rows = m360_linear_heads_fused_rows(M, n_pad, bf16) (ragged tail; every row when n_pad % 256 != 0 or n_pad > 1024)
  * are computed as by m360_linear into y, and the *_finish_fused entry points take their head products from there.
  * Replaces the last nn.Linear + nn.Sigmoid of model.py:43-53 / :131-148 plus the matrix product of the heads. */
-long m360_linear_heads_fused_rows(long M, int n_pad);
+long m360_linear_heads_fused_rows(long M, int n_pad, int bf16);
 int m360_linear_heads_slots(int n_pad);
 int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad,
                       int k_pad, int act /* M360_ACT_SIGMOID */, float *y, int ldy, int store_y, const float *head_w,
@@ -521,7 +521,8 @@ enum {
     M360_K_PROP_FINISH = 3, /* proposal head + weights + resample (M = B*N, n_pad = width, k_pad = bf16?) */
     M360_K_NERF_FINISH = 4, /* NeRF heads + composite             (M = B*N, n_pad = width, k_pad = bf16?) */
     M360_K_WGRAD = 5,
-    M360_K_DGRAD = 6
+    M360_K_DGRAD = 6,
+    M360_K_LINEAR_HEADS = 7 /* last hidden layer fused with the heads (k_pad < 0: bf16) */
 };
 m360_prof_t *m360_prof_create(int capacity); /* NULL on failure */
 void m360_prof_destroy(m360_prof_t *prof);

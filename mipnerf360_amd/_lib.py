@@ -17,7 +17,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 M360_OK = 0
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 # record kinds of the event recorder (include/m360.h, "measurement")
-K_LINEAR, K_LINEAR_BF16, K_ENCODE, K_PROP_FINISH, K_NERF_FINISH, K_WGRAD, K_DGRAD = range(7)
+K_LINEAR, K_LINEAR_BF16, K_ENCODE, K_PROP_FINISH, K_NERF_FINISH, K_WGRAD, K_DGRAD, K_LINEAR_HEADS = range(8)
 
 _f = C.POINTER(C.c_float)
 _vp = C.c_void_p
@@ -106,6 +106,13 @@ SIGNATURES = {
     "m360_convert_to_ndc": (_i, [_vp, _vp, _l, _fl, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_prop_finish": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_nerf_finish": (_i, [_vp, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "m360_linear_heads_fused_rows": (_l, [_l, _i, _i]),
+    "m360_linear_heads_slots": (_i, [_i]),
+    "m360_linear_heads": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "m360_linear_heads_bf16": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "m360_prop_finish_fused": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _vp, _vp]),
+    "m360_nerf_finish_fused": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
+                                    _vp]),
     "m360_forward_workspace_bytes": (_sz, [_i, _i, _P(ModelStruct)]),
     "m360_prop_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m360_nerf_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp,

@@ -97,7 +97,7 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     L.act_a = take(S * wmax * sizeof(float));
     L.act_b = take(S * wmax * sizeof(float));
     // partial head sums of the fused last layer: [S][slots][heads] fp32 (67 MB at 4096 x 128, width 1024)
-    const size_t hp_slots = (size_t)m360_linear_heads_slots(m->hp_pad), hn_slots = (size_t)m360_linear_heads_slots(m->hn_pad);
+    const size_t hp_slots = (size_t)m360_linear_heads_slots(m->hp_pad), hn_slots = (size_t)m360_linear_heads_slots(m->hn_pad);  // (an upper bound: sized whether or not the widths allow fusion)
     const size_t hp_b = S * hp_slots * 1 * sizeof(float), hn_b = S * hn_slots * 4 * sizeof(float);
     L.hpart = take(hp_b > hn_b ? hp_b : hn_b);
     L.total = off;
@@ -162,16 +162,6 @@ static int p_nerf_finish_fused(const m360_hyper_t *h, const void *act, int bf16,
     ProfScope ps(h, st, M360_K_NERF_FINISH, (long)B * N, k_pad, bf16);
     return ps.done(m360_nerf_finish_fused(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, dirs, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
 }
-static int p_prop_finish(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, float *w_hat, float *t_new, m360_stream_t st) {
-    ProfScope ps(h, st, M360_K_PROP_FINISH, (long)B * N, k_pad, bf16);
-    if (bf16) return ps.done(m360_prop_finish_bf16(act, ld, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st));
-    return ps.done(m360_prop_finish_n(static_cast<const float *>(act), ld, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st));
-}
-static int p_nerf_finish(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, const m360_outputs_t *out, m360_stream_t st) {
-    ProfScope ps(h, st, M360_K_NERF_FINISH, (long)B * N, k_pad, bf16);
-    if (bf16) return ps.done(m360_nerf_finish_bf16(act, ld, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, dirs, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
-    return ps.done(m360_nerf_finish(static_cast<const float *>(act), ld, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, dirs, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
-}
 
 // Training tape of one stage (caller-owned): everything the backward needs from the forward.
 struct TapeLayout {
@@ -202,6 +192,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     float *vdenc = reinterpret_cast<float *>(ws + L.vdenc);
     float *feat = reinterpret_cast<float *>(ws + L.feat);
     float *a = reinterpret_cast<float *>(ws + L.act_a), *b = reinterpret_cast<float *>(ws + L.act_b);
+    float *hpart = reinterpret_cast<float *>(ws + L.hpart);
     const long S = (long)B * N;
     if (tape) {  // training: fp32 only, every layer output kept
         const TapeLayout T = tape_for(B, N, m, 0);
@@ -215,9 +206,11 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
         M360_TRY(p_encode_grouped(h, tt, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(p_linear(h, tf, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, act[0], hp, st));
-        for (int l = 1; l < 4; ++l)
-            M360_TRY(p_linear(h, act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, l == 3 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hp, st));
-        return p_prop_finish(h, act[3], 0, hp, m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st);
+        for (int l = 1; l < 3; ++l)
+            M360_TRY(p_linear(h, act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, M360_ACT_RELU, act[l], hp, st));
+        // last hidden layer + head fused; the tape keeps the layer output (store_y = 1), same partial sums as when rendering
+        M360_TRY(p_linear_heads(h, 0, act[2], S, hp, m->prop_w[3], m->prop_b[3], hp, hp, act[3], hp, 1, m->prop_head_w, 1, hpart, st));
+        return p_prop_finish_fused(h, act[3], 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st);
     }
     if (!ext_norm) M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, t_hat, st));  // sharded batch: t_hat is given
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
@@ -230,15 +223,16 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         M360_TRY(p_linear_bf16(h, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
         M360_TRY(p_linear_bf16(h, a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
         M360_TRY(p_linear_bf16(h, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
-        M360_TRY(p_linear_bf16(h, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, hp, st));
-        return p_prop_finish(h, b, 1, hp, m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
+        M360_TRY(p_linear_heads(h, 1, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, b, hp, 0, m->prop_head_w, 1, hpart, st));
+        return p_prop_finish_fused(h, b, 1, hp, hpart, m360_linear_heads_fused_rows(S, hp, 1), m360_linear_heads_slots(hp), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
     }
     if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(p_linear(h, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
     M360_TRY(p_linear(h, a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
     M360_TRY(p_linear(h, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
-    M360_TRY(p_linear(h, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, hp, st));
-    return p_prop_finish(h, b, 0, hp, m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
+    // last hidden layer + head fused: its 537 MB output never goes to HBM (store_y = 0; ragged tail rows excepted)
+    M360_TRY(p_linear_heads(h, 0, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, b, hp, 0, m->prop_head_w, 1, hpart, st));
+    return p_prop_finish_fused(h, b, 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
 }
 
 // resampled t -> features -> 8 NeRF layers -> heads + composite
@@ -251,9 +245,11 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     float *vdenc = reinterpret_cast<float *>(ws + L.vdenc);
     float *feat = reinterpret_cast<float *>(ws + L.feat);
     float *a = reinterpret_cast<float *>(ws + L.act_a), *b = reinterpret_cast<float *>(ws + L.act_b);
+    float *hpart = reinterpret_cast<float *>(ws + L.hpart);
     const long S = (long)B * N;
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hn = m->hn_pad;
+    const int slots = m360_linear_heads_slots(hn);
     float *src = a, *dst = b;
     if (tape) {  // training: fp32 only, every layer output kept (t1 already lives in the tape)
         const TapeLayout T = tape_for(B, N, m, 1);
@@ -262,27 +258,31 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         for (int l = 0; l < 8; ++l) act[l] = reinterpret_cast<float *>(tape + T.act[l]);
         M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(p_linear(h, tf, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, act[0], hn, st));
-        for (int l = 1; l < 8; ++l)
-            M360_TRY(p_linear(h, act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, l == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, act[l], hn, st));
-        M360_TRY(p_nerf_finish(h, act[7], 0, hn, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
+        for (int l = 1; l < 7; ++l)
+            M360_TRY(p_linear(h, act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, M360_ACT_RELU, act[l], hn, st));
+        M360_TRY(p_linear_heads(h, 0, act[6], S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, act[7], hn, 1, m->nerf_head_w, 4, hpart, st));
+        M360_TRY(p_nerf_finish_fused(h, act[7], 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     } else if (m->mlp_bf16) {
         if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
         else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(p_linear_bf16(h, feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
-        for (int layer = 1; layer < 8; ++layer) {
-            M360_TRY(p_linear_bf16(h, src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
+        for (int layer = 1; layer < 7; ++layer) {
+            M360_TRY(p_linear_bf16(h, src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, hn, st));
             float *tmp = src; src = dst; dst = tmp;
         }
-        M360_TRY(p_nerf_finish(h, src, 1, hn, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
+        M360_TRY(p_linear_heads(h, 1, src, S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, hn, 0, m->nerf_head_w, 4, hpart, st));
+        M360_TRY(p_nerf_finish_fused(h, dst, 1, hn, hpart, m360_linear_heads_fused_rows(S, hn, 1), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     } else {
     if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
     else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(p_linear(h, feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
-    for (int layer = 1; layer < 8; ++layer) {
-        M360_TRY(p_linear(h, src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, layer == 7 ? M360_ACT_SIGMOID : M360_ACT_RELU, dst, hn, st));
+    for (int layer = 1; layer < 7; ++layer) {
+        M360_TRY(p_linear(h, src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, hn, st));
         float *tmp = src; src = dst; dst = tmp;
     }
-    M360_TRY(p_nerf_finish(h, src, 0, hn, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
+    // last hidden layer + the 4 heads fused: its 2.15 GB output never goes to HBM (store_y = 0; ragged tail rows excepted)
+    M360_TRY(p_linear_heads(h, 0, src, S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, hn, 0, m->nerf_head_w, 4, hpart, st));
+    M360_TRY(p_nerf_finish_fused(h, dst, 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     }
     if (out->t_vals) {  // model.py:194,196: g() inside t_to_s bumps the stored t_vals by 1e-6
         const long n = (long)B * (N + 1);

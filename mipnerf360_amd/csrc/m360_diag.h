@@ -8,8 +8,9 @@ extern "C" {
  * package): kernels instrumented with s_memtime / s_memrealtime stamps, see tools/. */
 int m360_diag_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
                      float *y, int ldy, m360_stream_t stream);
+/* variant: 0 = ping-pong kernel with stamps, 1 = software-pipelined kernel with stamps, 2 / 3 = the same two without */
 int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
-                          int k_pad, void *y, int ldy, m360_stream_t stream);
+                          int k_pad, void *y, int ldy, int variant, m360_stream_t stream);
 /* 16 x uint64 per workgroup, the first 256 workgroups (slot meaning: see the STAMP blocks of the two kernels) */
 int m360_diag_read_stamps(unsigned long long *out_host, int n);
 #ifdef __cplusplus

@@ -17,6 +17,7 @@
 #include "m360_linear_persist.hip.h"
 #include "m360_linear_bf16.hip.h"
 #include "m360_linear_bf16_pp.hip.h"
+#include "m360_linear_bf16_sp.hip.h"
 #include "m360_linear_tn.hip.h"
 #ifdef M360_DIAG
 #include "m360_diag.h"
@@ -321,7 +322,8 @@ int m360_linear(const float *x, long M, int ldx, const float *w_packed, const fl
 }
 
 // ---- last hidden layer of a stage fused with its heads
-long m360_linear_heads_fused_rows(long M, int n_pad) {
+long m360_linear_heads_fused_rows(long M, int n_pad, int bf16) {
+    if (bf16) return 0;  // bf16 kernel: not fused (yet) - every row goes through y
     if (M < 0 || n_pad < persist::BN || n_pad % persist::BN != 0 || n_pad > persist::kHeadMaxN) return 0;
     return (M / persist::BM) * persist::BM;
 }
@@ -334,7 +336,7 @@ int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, co
     if (heads != 1 && heads != 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads: heads=%d (1 or 4)", heads);
     if (act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads: the last hidden layer is a sigmoid layer (model.py:50,146), act=%d", act);
     if (!x || !w_packed || !b_packed || !y || !head_w || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads: null pointer or negative M");
-    const long M_fused = m360_linear_heads_fused_rows(M, n_pad);
+    const long M_fused = m360_linear_heads_fused_rows(M, n_pad, 0);
     if (M_fused > 0) {
         if (!head_part || ((uintptr_t)head_part & 15) || ((uintptr_t)head_w & 15)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads: head_part / head_w must be 16-byte aligned device pointers");
         if (k_pad < BK || k_pad % BK != 0 || ldx < k_pad || ldy < n_pad || ldx % 4 != 0 || ldy % 4 != 0)
@@ -359,6 +361,15 @@ int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, co
     if (M > M_fused)  // ragged tail rows / widths the fused epilogue does not take: the plain layer; the finisher reads y there
         return launch_linear(x + M_fused * ldx, M - M_fused, ldx, w_packed, b_packed, n_pad, k_pad, act, y + M_fused * ldy, ldy, nullptr, stream);
     return M360_OK;
+}
+
+int m360_linear_heads_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
+                           int k_pad, int act, void *y, int ldy, int store_y, const float *head_w, int heads,
+                           float *head_part, m360_stream_t stream) {
+    if (heads != 1 && heads != 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads_bf16: heads=%d (1 or 4)", heads);
+    if (act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads_bf16: the last hidden layer is a sigmoid layer, act=%d", act);
+    (void)store_y; (void)head_w; (void)head_part;  // fused_rows == 0 for bf16: the plain layer, heads taken from y by the finisher
+    return m360_linear_bf16(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, stream);
 }
 
 // ---- training path: input gradient, weight gradient, transposed packing
@@ -502,12 +513,25 @@ int m360_diag_linear(const float *x, long M, int ldx, const float *w_packed, con
 }
 
 int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
-                          int k_pad, void *y, int ldy, m360_stream_t stream) {
+                          int k_pad, void *y, int ldy, int variant, m360_stream_t stream) {
     if (!x || !w_packed || !b_packed || !y || M < pp16::BM || M % pp16::BM || n_pad % pp16::BN || k_pad % pp16::BK || k_pad < 2 * pp16::BK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: full 256 x 256 tiles, k_pad >= 128 only");
     const int cus = cu_count();
     const long nt = (M / pp16::BM) * (n_pad / pp16::BN);
     dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
-    hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, true>), grid, block, 0, reinterpret_cast<hipStream_t>(stream), static_cast<const __bf16 *>(x), M, ldx, static_cast<const __bf16 *>(w_packed), b_packed, n_pad, k_pad, static_cast<__bf16 *>(y), ldy, n_pad / pp16::BN, (int)nt);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const __bf16 *xb = static_cast<const __bf16 *>(x), *wb = static_cast<const __bf16 *>(w_packed);
+    __bf16 *yb = static_cast<__bf16 *>(y);
+    switch (variant) {  // ReLU epilogue throughout
+        case 0: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+        case 1: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
+        case 2: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
+        case 4: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 1>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
+        case 5: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 2>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
+        case 6: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 4>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
+        case 7: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 6>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
+        case 3: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, false>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+        default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);
+    }
     return check_launch("diag_linear_bf16");
 }
 

@@ -396,6 +396,48 @@ def nerf_finish(act, head_w, head_b, density_bias, rgb_padding, t_vals, dirs, wh
     return comp, dist, acc, w
 
 
+def linear_heads(x, w_packed, b_packed, head_w, store_y: bool = True):
+    """Last hidden (sigmoid) layer fused with the `heads` = head_w.shape[0] (1 or 4) output heads (m360_linear_heads):
+    -> (y[M,n_pad] (fused rows only written when store_y), head_part[fused_rows, slots, heads], fused_rows)."""
+    x, w_packed, b_packed, head_w = dev(x, "x"), dev(w_packed, "w_packed"), dev(b_packed, "b_packed"), dev(head_w, "head_w")
+    M, ldx = x.shape
+    n_pad, k_pad = w_packed.shape
+    heads = head_w.shape[0]
+    if head_w.shape[1] != n_pad or ldx != k_pad:
+        raise RuntimeError("linear_heads: shapes of x / w_packed / head_w do not match")
+    lib = _lib.lib()
+    fused, slots = int(lib.m360_linear_heads_fused_rows(M, n_pad, 0)), int(lib.m360_linear_heads_slots(n_pad))
+    y = torch.zeros(M, n_pad, device=x.device)
+    part = torch.zeros(max(fused, 1), max(slots, 1), heads, device=x.device)
+    _call("m360_linear_heads", x, M, ldx, w_packed, b_packed, n_pad, k_pad, _lib.ACT_SIGMOID, y, n_pad, int(bool(store_y)),
+          head_w, heads, part, STREAM)
+    return y, part, fused
+
+
+def nerf_finish_fused(act, head_part, fused_rows, head_w, head_b, density_bias, rgb_padding, t_vals, dirs, white_bkgd):
+    act, head_part, head_w, head_b = dev(act, "act"), dev(head_part, "head_part"), dev(head_w, "head_w"), dev(head_b, "head_b")
+    t_vals, dirs = dev(t_vals, "t_vals"), dev(dirs, "dirs")
+    B, M = t_vals.shape
+    N = M - 1
+    d = act.device
+    comp, dist, acc, w = torch.empty(B, 3, device=d), torch.empty(B, device=d), torch.empty(B, device=d), torch.empty(B, N, device=d)
+    _call("m360_nerf_finish_fused", act, 0, act.shape[1], head_part, int(fused_rows), head_part.shape[1], head_w, head_b,
+          head_w.shape[1], float(density_bias), float(rgb_padding), t_vals, dirs, B, N, int(bool(white_bkgd)), comp, dist, acc, w,
+          STREAM)
+    return comp, dist, acc, w
+
+
+def prop_finish_fused(act, head_part, fused_rows, head_w, head_b, density_bias, t_vals, dirs, resample_padding):
+    act, head_part, head_w, head_b = dev(act, "act"), dev(head_part, "head_part"), dev(head_w, "head_w"), dev(head_b, "head_b")
+    t_vals, dirs = dev(t_vals, "t_vals"), dev(dirs, "dirs")
+    B, M = t_vals.shape
+    N = M - 1
+    w, t_new = torch.empty(B, N, device=act.device), torch.empty_like(t_vals)
+    _call("m360_prop_finish_fused", act, 0, act.shape[1], head_part, int(fused_rows), head_part.shape[1], head_w, head_b,
+          head_w.numel(), float(density_bias), t_vals, dirs, None, B, N, M, float(resample_padding), w, t_new, STREAM)
+    return w, t_new
+
+
 # ----------------------------------------------------------------------------- ray generation
 def generate_rays(cam_to_world, h: int, w: int, focal: float, near: float, far: float, ndc: bool = False,
                   ndc_near: float = 1.0):

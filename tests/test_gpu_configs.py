@@ -234,3 +234,49 @@ def test_data_writes_are_seen_after_invalidate_or_in_training_mode(dev):
         m.nerf_net.final_color[0].weight.data.mul_(2.0)
         again = m(rays)[0].clone()
     assert float((again - base).abs().max()) <= 1e-6
+
+
+# ------------------------------------------------------------------------------- fused last layer + heads
+@pytest.mark.parametrize("B,N,width,heads", [(8, 128, 1024, 4), (6, 100, 1024, 4), (16, 64, 256, 1), (5, 77, 256, 1),
+                                              (3, 50, 128, 4), (4, 64, 512, 4)])
+def test_fused_last_layer_heads_match_the_unfused_path(dev, B, N, width, heads):
+    """the last hidden layer's epilogue forms the head products (m360_linear_heads) and the finisher
+    only adds the per-wave-tile partial sums (m360_*_finish_fused).  Against the unfused pair m360_linear +
+    m360_*_finish on the same inputs: layer output bit-identical where it is stored, rendered values within 1e-6 (the
+    head dot product is summed in a different order); ragged row counts (tail rows take the unfused route), widths
+    that cannot fuse (128: fused_rows = 0) and store_y = 0 (the activation is never written) included."""
+    from mipnerf360_amd import _lib, ops
+    g = torch.Generator(device=dev).manual_seed(B * N + width)
+    S = B * N
+    x = torch.rand(S, width, device=dev, generator=g)
+    w = (torch.rand(width, width, device=dev, generator=g) * 2 - 1) * (6.0 / width) ** 0.5
+    b = torch.rand(width, device=dev, generator=g) - 0.5
+    hw = (torch.rand(heads, width, device=dev, generator=g) * 2 - 1) * (6.0 / width) ** 0.5
+    hb = torch.rand(heads, device=dev, generator=g) - 0.5
+    t = torch.sort(torch.rand(B, N + 1, device=dev, generator=g), dim=1).values
+    dirs = torch.rand(B, 3, device=dev, generator=g) + 0.5
+    wp, bp = ops.pack_linear(w, b)
+    y_ref = ops.linear(x, wp, bp, _lib.ACT_SIGMOID)
+    y1, part1, fused = ops.linear_heads(x, wp, bp, hw, store_y=True)
+    y0, part0, fused0 = ops.linear_heads(x, wp, bp, hw, store_y=False)
+    expect = (S // 256) * 256 if width % 256 == 0 else 0
+    assert fused == fused0 == expect
+    assert torch.equal(y1, y_ref)                               # stored: bit-identical to the plain layer
+    assert torch.equal(y0[fused:], y_ref[fused:])               # tail rows always go through y
+    assert fused == 0 or float(y0[:fused].abs().max()) == 0.0   # fused rows never written when store_y = 0
+    assert torch.equal(part0, part1)                            # same partial sums with and without the store
+    if fused:
+        raw = part1[:fused].sum(1) + hb
+        want = y_ref[:fused].double() @ hw.double().T + hb.double()
+        assert float((raw.double() - want).abs().max()) <= 2e-5
+    for y, part in ((y1, part1), (y0, part0)):
+        if heads == 4:
+            a = ops.nerf_finish_fused(y, part, fused, hw, hb, -1.0, 0.001, t, dirs, False)
+            r = ops.nerf_finish(y_ref, hw, hb, -1.0, 0.001, t, dirs, False)
+        else:
+            a = ops.prop_finish_fused(y, part, fused, hw, hb, -1.0, t, dirs, 0.01)
+            r = ops.prop_finish(y_ref, hw, hb, -1.0, t, dirs, 0.01)
+        for u, v in zip(a, r):
+            assert float((u - v).abs().max()) <= 1e-6, float((u - v).abs().max())
+    for _ in range(3):  # deterministic: fixed summation order, no atomics
+        assert torch.equal(ops.linear_heads(x, wp, bp, hw, store_y=False)[1], part0)

@@ -14,6 +14,10 @@ for s in $steps; do
     ceiling) timeout 300 tools/mfma_ceiling.bin > $out/mfma_ceiling.jsonl 2>&1; cat $out/mfma_ceiling.jsonl ;;
     clock)   timeout 600 python tools/linear_bench.py --dtype fp32 --clock --json $out/linear_clock.jsonl > $out/linear_fp32.log 2>&1; tail -3 $out/linear_fp32.log
              timeout 600 python tools/linear_bench.py --dtype bf16 --clock --json $out/linear_clock.jsonl > $out/linear_bf16.log 2>&1; tail -3 $out/linear_bf16.log ;;
+    sp16)    for v in 3 2; do timeout 600 python tools/linear_bench.py --dtype bf16 --variant $v --clock --json $out/linear_bf16_variants.jsonl > $out/linear_bf16_v$v.log 2>&1; tail -4 $out/linear_bf16_v$v.log; done
+             timeout 300 python tools/linear_bench.py --dtype bf16 --variant 2 --m 65536 --n 256 --k 256 > $out/linear_bf16_v2_small.log 2>&1; tail -2 $out/linear_bf16_v2_small.log
+             timeout 300 python tools/linear_bench.py --dtype bf16 --variant 2 --m 77056 --n 768 --k 192 > $out/linear_bf16_v2_odd.log 2>&1; tail -2 $out/linear_bf16_v2_odd.log ;;
+    ablate)  for v in 4 5 6 7; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/linear_bf16_ablate.jsonl > $out/linear_bf16_abl$v.log 2>&1; tail -1 $out/linear_bf16_abl$v.log; done ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac

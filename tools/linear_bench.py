@@ -34,6 +34,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--clock", action="store_true", help="in-kernel clock + cycle stamps from libm360_diag.so")
+    ap.add_argument("--variant", type=int, default=-1,
+                    help="bf16 only: time a kernel of the diagnostics library instead of the product one (2 = software-pipelined, "
+                         "3 = ping-pong); its stamped twin (variant - 2) serves --clock; the output is checked against fp64")
+    ap.add_argument("--no-check", action="store_true", help="timing-only ablation variants produce wrong results by design")
     ap.add_argument("--soak-s", type=float, default=2.5)
     ap.add_argument("--json", type=str, default=None, help="append the result as one JSON line to this file")
     args = ap.parse_args()
@@ -43,11 +47,27 @@ def main():
     x = torch.rand(args.m, args.k, device=dev, generator=g) * 2 - 1
     w = (torch.rand(args.n, args.k, device=dev, generator=g) * 2 - 1) * (6.0 / args.k) ** 0.5
     b = torch.rand(args.n, device=dev, generator=g) - 0.5
+    diag = None
+    if args.clock or args.variant >= 0:
+        path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libm360_diag.so")
+        if not os.path.exists(path):
+            raise SystemExit(f"{path} missing: make -C mipnerf360_amd/csrc diag")
+        diag = ctypes.CDLL(path)
+        vp = ctypes.c_void_p
+        diag.m360_diag_linear_bf16.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp]
+        diag.m360_diag_linear.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]
+        diag.m360_diag_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     if bf16:
         x = x.bfloat16()
         wp, bp = ops.pack_linear_bf16(w, b, args.n, args.k)
         y = torch.empty(args.m, args.n, device=dev, dtype=torch.bfloat16)
-        run = lambda: ops.linear_bf16(x, wp, bp, args.act, out=y)  # noqa: E731
+        if args.variant >= 0:
+            def run():
+                rc = diag.m360_diag_linear_bf16(x.data_ptr(), args.m, args.k, wp.data_ptr(), bp.data_ptr(), args.n, args.k,
+                                                y.data_ptr(), args.n, args.variant, torch.cuda.current_stream().cuda_stream)
+                assert rc == 0, rc
+        else:
+            run = lambda: ops.linear_bf16(x, wp, bp, args.act, out=y)  # noqa: E731
         peak, cyc_per_flop = 2500.0, 1.0 / (256 * 4 * 2 * 16 * 16 * 32 / 16.0)  # 16x16x32: 16 cycles per MFMA per SIMD
     else:
         wp, bp = ops.pack_linear(w, b, args.n, args.k)
@@ -56,6 +76,18 @@ def main():
         peak, cyc_per_flop = 157.3, 1.0 / (256 * 4 * 2 * 32 * 32 * 2 / 64.0)   # 32x32x2 f32: 64 cycles per MFMA per SIMD
     run()
     torch.cuda.synchronize()
+    if bf16 and not args.no_check:  # against the exact product of the same bf16 operands (a strided row sample), ReLU
+        sub = slice(None, None, max(1, args.m // 4096))
+        ref = (x[sub].double() @ wp.double().T + bp.double()).clamp_min(0)
+        err = (y[sub].double() - ref).abs()
+        bad = float((err - 2.0 ** -8 * ref.abs()).max())
+        print(f"max |err| vs fp64 on a row sample: {float(err.max()):.3e}; worst excess over one bf16 ulp: {bad:.3e}")
+        assert bad <= 2e-3, "wrong results"
+        y2 = y.clone()
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2), "non-deterministic results (race)"
     flops = 2.0 * args.m * args.n * args.k
     times = []
     for _ in range(args.rounds):
@@ -68,15 +100,11 @@ def main():
         times.append(e0.elapsed_time(e1) / args.iters)
     med = float(np.median(times))
     tf = flops / med / 1e9
-    res = {"dtype": args.dtype, "M": args.m, "N": args.n, "K": args.k, "median_ms": round(med, 4), "best_ms": round(min(times), 4),
+    res = {"dtype": args.dtype, "variant": args.variant, "M": args.m, "N": args.n, "K": args.k, "median_ms": round(med, 4), "best_ms": round(min(times), 4),
            "tflops": round(tf, 1), "frac_of_spec_peak": round(tf / peak, 4), "spec_peak_tflops": peak}
     print(f"{args.dtype} linear {args.m}x{args.n}x{args.k}: median {med:.3f} ms = {tf:.1f} TFLOP/s ({100 * tf / peak:.1f}% of "
           f"{peak} TF), best {min(times):.3f} ms")
     if args.clock:
-        path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libm360_diag.so")
-        if not os.path.exists(path):
-            raise SystemExit(f"{path} missing: make -C mipnerf360_amd/csrc diag")
-        diag = ctypes.CDLL(path)
         t_end = time.time() + args.soak_s
         while time.time() < t_end:  # back-to-back product launches: the chip settles at its loaded clock
             for _ in range(20):
@@ -84,18 +112,15 @@ def main():
             torch.cuda.synchronize()
         for _ in range(40):
             run()
-        vp = ctypes.c_void_p
         st = torch.cuda.current_stream().cuda_stream
         if bf16:
-            diag.m360_diag_linear_bf16.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]
-            rc = diag.m360_diag_linear_bf16(x.data_ptr(), args.m, args.k, wp.data_ptr(), bp.data_ptr(), args.n, args.k, y.data_ptr(), args.n, st)
+            stamped = args.variant - 2 if args.variant >= 2 else 0
+            rc = diag.m360_diag_linear_bf16(x.data_ptr(), args.m, args.k, wp.data_ptr(), bp.data_ptr(), args.n, args.k, y.data_ptr(), args.n, stamped, st)
         else:
-            diag.m360_diag_linear.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]
             rc = diag.m360_diag_linear(x.data_ptr(), args.m, args.k, wp.data_ptr(), bp.data_ptr(), args.n, args.k, y.data_ptr(), args.n, st)
         assert rc == 0, rc
         torch.cuda.synchronize()
         buf = (ctypes.c_ulonglong * (256 * 16))()
-        diag.m360_diag_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
         assert diag.m360_diag_read_stamps(buf, 256 * 16) == 0
         s = np.array(buf[:], dtype=np.float64).reshape(256, 16)
         if bf16:
