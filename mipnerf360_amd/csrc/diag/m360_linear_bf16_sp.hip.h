@@ -20,8 +20,8 @@
 // next K-step have landed (vmcnt(0)); after it u3 runs from registers while the fragments of the next K-step's u0 are
 // read from the other buffer and the K-step after next is staged into the buffer just freed.
 #pragma once
-#include "m360_common.hip.h"
-#include "m360_linear_persist.hip.h"  // diagnostic stamp buffer
+#include "../m360_common.hip.h"
+#include "../m360_linear_persist.hip.h"  // diagnostic stamp buffer
 
 namespace m360 {
 namespace sp16 {
@@ -48,7 +48,7 @@ __device__ __forceinline__ float act_fn(float v) {
 template <int ACT, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_sp_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias,
-    int Np, int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
+    int Np, int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, int ldw) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kTileBytes + kMaxBias * 4];  // 128 KiB + the bias vector
 
     const int tid = threadIdx.x;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_sp_kernel(
             const int r = row0 + (lane >> 3);
             const int f = is_x ? ((r >> 1) & 7) : (2 * ((r >> 4) & 3) + ((r >> 1) & 1));
             const int chunk = (lane & 7) ^ f;
-            src_off[u][q] = (unsigned)(r * (is_x ? ldx : Kp) + 8 * chunk) * 2u;
+            src_off[u][q] = (unsigned)(r * (is_x ? ldx : ldw) + 8 * chunk) * 2u;
             dst_off[u][q] = (is_x ? 0 : 2 * kHalfBytes) + row0 * 128;
         }
     }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_sp_kernel(
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(X + tm0 * ldx), 0, 0x7fffffff, 0x00020000);
     };
     auto make_w = [&](int tn0) __attribute__((always_inline)) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)tn0 * Kp), 0, 0x7fffffff, 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)tn0 * ldw), 0, 0x7fffffff, 0x00020000);
     };
     // one staging unit (2 instructions) of the K-step at element offset k0 of the tile behind (rx, rw) into LDS buffer `buf`
     auto stage = [&](int buf, int unit, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rw, int k0) __attribute__((always_inline)) {

@@ -17,10 +17,11 @@
 #include "m360_linear_persist.hip.h"
 #include "m360_linear_bf16.hip.h"
 #include "m360_linear_bf16_pp.hip.h"
-#include "m360_linear_bf16_sp.hip.h"
 #include "m360_linear_tn.hip.h"
-#ifdef M360_DIAG
-#include "m360_diag.h"
+#ifdef M360_DIAG  // diagnostics build only: stamped twins of the product kernels + the two bf16 structures that lost the A/B
+#include "diag/m360_diag.h"
+#include "diag/m360_linear_bf16_sp.hip.h"
+#include "diag/m360_linear_bf16_rg.hip.h"
 #endif
 
 namespace m360 {
@@ -513,7 +514,7 @@ int m360_diag_linear(const float *x, long M, int ldx, const float *w_packed, con
 }
 
 int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
-                          int k_pad, void *y, int ldy, int variant, m360_stream_t stream) {
+                          int k_pad, void *y, int ldy, int variant, int ldw, m360_stream_t stream) {
     if (!x || !w_packed || !b_packed || !y || M < pp16::BM || M % pp16::BM || n_pad % pp16::BN || k_pad % pp16::BK || k_pad < 2 * pp16::BK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: full 256 x 256 tiles, k_pad >= 128 only");
     const int cus = cu_count();
     const long nt = (M / pp16::BM) * (n_pad / pp16::BN);
@@ -523,12 +524,20 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
     __bf16 *yb = static_cast<__bf16 *>(y);
     switch (variant) {  // ReLU epilogue throughout
         case 0: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
-        case 1: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
-        case 2: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
-        case 4: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 1>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
-        case 5: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 2>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
-        case 6: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 4>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
-        case 7: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 6>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt); break;
+        case 1: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt, ldw); break;
+        case 2: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt, ldw); break;
+        case 4: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 1>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt, ldw); break;
+        case 5: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 2>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt, ldw); break;
+        case 6: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 4>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt, ldw); break;
+        case 7: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, false, 6>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt, ldw); break;
+#define M360_RG(ST, AB) hipLaunchKernelGGL((rg16::linear_bf16_rg_kernel<M360_ACT_RELU, ST, AB>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / rg16::BN, (int)nt, ldw)
+        case 8: M360_RG(true, 0); break;
+        case 9: M360_RG(false, 0); break;
+        case 10: M360_RG(false, 1); break;
+        case 11: M360_RG(false, 2); break;
+        case 12: M360_RG(false, 4); break;
+        case 13: M360_RG(false, 6); break;
+#undef M360_RG
         case 3: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, false>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
         default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);
     }

@@ -18,6 +18,11 @@ for s in $steps; do
              timeout 300 python tools/linear_bench.py --dtype bf16 --variant 2 --m 65536 --n 256 --k 256 > $out/linear_bf16_v2_small.log 2>&1; tail -2 $out/linear_bf16_v2_small.log
              timeout 300 python tools/linear_bench.py --dtype bf16 --variant 2 --m 77056 --n 768 --k 192 > $out/linear_bf16_v2_odd.log 2>&1; tail -2 $out/linear_bf16_v2_odd.log ;;
     ablate)  for v in 4 5 6 7; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/linear_bf16_ablate.jsonl > $out/linear_bf16_abl$v.log 2>&1; tail -1 $out/linear_bf16_abl$v.log; done ;;
+    ldpad)   for pad in 0 32 64 128; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant 2 --ld-pad $pad --rounds 5 --json $out/linear_bf16_ldpad.jsonl > $out/linear_bf16_pad$pad.log 2>&1; tail -1 $out/linear_bf16_pad$pad.log; done ;;
+    rg16)    timeout 600 python tools/linear_bench.py --dtype bf16 --variant 9 --clock --json $out/linear_bf16_rg.jsonl > $out/linear_bf16_v9.log 2>&1; tail -4 $out/linear_bf16_v9.log
+             for v in 10 11 12 13; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/linear_bf16_rg.jsonl > $out/linear_bf16_v$v.log 2>&1; tail -1 $out/linear_bf16_v$v.log; done
+             timeout 300 python tools/linear_bench.py --dtype bf16 --variant 9 --m 77056 --n 768 --k 192 > $out/linear_bf16_v9_odd.log 2>&1; tail -2 $out/linear_bf16_v9_odd.log
+             timeout 300 python tools/linear_bench.py --dtype bf16 --variant 9 --m 65536 --n 256 --k 128 > $out/linear_bf16_v9_k128.log 2>&1; tail -2 $out/linear_bf16_v9_k128.log ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--variant", type=int, default=-1,
                     help="bf16 only: time a kernel of the diagnostics library instead of the product one (2 = software-pipelined, "
                          "3 = ping-pong); its stamped twin (variant - 2) serves --clock; the output is checked against fp64")
+    ap.add_argument("--ld-pad", type=int, default=0, help="bf16 diag variants: pad the row stride of x / y / w by this many elements")
     ap.add_argument("--no-check", action="store_true", help="timing-only ablation variants produce wrong results by design")
     ap.add_argument("--soak-s", type=float, default=2.5)
     ap.add_argument("--json", type=str, default=None, help="append the result as one JSON line to this file")
@@ -54,7 +55,7 @@ def main():
             raise SystemExit(f"{path} missing: make -C mipnerf360_amd/csrc diag")
         diag = ctypes.CDLL(path)
         vp = ctypes.c_void_p
-        diag.m360_diag_linear_bf16.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp]
+        diag.m360_diag_linear_bf16.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
         diag.m360_diag_linear.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]
         diag.m360_diag_read_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
     if bf16:
@@ -62,9 +63,18 @@ def main():
         wp, bp = ops.pack_linear_bf16(w, b, args.n, args.k)
         y = torch.empty(args.m, args.n, device=dev, dtype=torch.bfloat16)
         if args.variant >= 0:
+            pad = args.ld_pad
+            xs, ys, ws = (torch.zeros(args.m, args.k + pad, device=dev, dtype=torch.bfloat16),
+                          torch.zeros(args.m, args.n + pad, device=dev, dtype=torch.bfloat16),
+                          torch.zeros(args.n, args.k + pad, device=dev, dtype=torch.bfloat16))
+            xs[:, :args.k] = x
+            ws[:, :args.k] = wp
+            x, wp, y = xs[:, :args.k], ws[:, :args.k], ys[:, :args.n]  # strided views: rows (k + pad) / (n + pad) elements apart
+
             def run():
-                rc = diag.m360_diag_linear_bf16(x.data_ptr(), args.m, args.k, wp.data_ptr(), bp.data_ptr(), args.n, args.k,
-                                                y.data_ptr(), args.n, args.variant, torch.cuda.current_stream().cuda_stream)
+                rc = diag.m360_diag_linear_bf16(x.data_ptr(), args.m, args.k + pad, wp.data_ptr(), bp.data_ptr(), args.n, args.k,
+                                                y.data_ptr(), args.n + pad, args.variant, args.k + pad,
+                                                torch.cuda.current_stream().cuda_stream)
                 assert rc == 0, rc
         else:
             run = lambda: ops.linear_bf16(x, wp, bp, args.act, out=y)  # noqa: E731
@@ -100,7 +110,7 @@ def main():
         times.append(e0.elapsed_time(e1) / args.iters)
     med = float(np.median(times))
     tf = flops / med / 1e9
-    res = {"dtype": args.dtype, "variant": args.variant, "M": args.m, "N": args.n, "K": args.k, "median_ms": round(med, 4), "best_ms": round(min(times), 4),
+    res = {"dtype": args.dtype, "variant": args.variant, "ld_pad": args.ld_pad, "M": args.m, "N": args.n, "K": args.k, "median_ms": round(med, 4), "best_ms": round(min(times), 4),
            "tflops": round(tf, 1), "frac_of_spec_peak": round(tf / peak, 4), "spec_peak_tflops": peak}
     print(f"{args.dtype} linear {args.m}x{args.n}x{args.k}: median {med:.3f} ms = {tf:.1f} TFLOP/s ({100 * tf / peak:.1f}% of "
           f"{peak} TF), best {min(times):.3f} ms")
@@ -114,8 +124,8 @@ def main():
             run()
         st = torch.cuda.current_stream().cuda_stream
         if bf16:
-            stamped = args.variant - 2 if args.variant >= 2 else 0
-            rc = diag.m360_diag_linear_bf16(x.data_ptr(), args.m, args.k, wp.data_ptr(), bp.data_ptr(), args.n, args.k, y.data_ptr(), args.n, stamped, st)
+            stamped = {2: 1, 3: 0, 9: 8}.get(args.variant, 0)
+            rc = diag.m360_diag_linear_bf16(x.data_ptr(), args.m, x.stride(0), wp.data_ptr(), bp.data_ptr(), args.n, args.k, y.data_ptr(), y.stride(0), stamped, wp.stride(0), st)
         else:
             rc = diag.m360_diag_linear(x.data_ptr(), args.m, args.k, wp.data_ptr(), bp.data_ptr(), args.n, args.k, y.data_ptr(), args.n, st)
         assert rc == 0, rc
