@@ -204,7 +204,7 @@ def main():
 
     def finish_in_bytes(width, heads):
         fused = int(lib.m360_linear_heads_fused_rows(S, width, int(bf16)))
-        return fused * int(lib.m360_linear_heads_slots(width)) * heads * 4 + (S - fused) * width * el
+        return fused * int(lib.m360_linear_heads_slots(width, int(bf16))) * heads * 4 + (S - fused) * width * el
 
     hbm_kernels = {}
     fused_last = [r["ms"] for r in recs if r["kind"] == _lib.K_LINEAR_HEADS and r["n_pad"] == HN]

@@ -314,14 +314,14 @@ int m360_nerf_finish(const float *act, int ld, const float *head_w, const float 
 /* The LAST hidden layer of a stage (sigmoid, model.py:50 / :146) fused with the stage's output heads (model.py:52:
  * hidden -> 1; model.py:150-158: hidden -> 1 + 3): while a 256 x 256 output tile is still in registers its activated
  * values are multiplied with the `heads` (1 or 4) head rows head_w[heads,n_pad] (fp32, the m360_model_t layout) and
- * per-row PARTIAL sums go to head_part[fused_rows][slots][heads] (slots = m360_linear_heads_slots(n_pad), one per
- * 128-column wave tile; no bias).  store_y = 0: the fused rows of y are NOT written (rendering: the 2.15 GB activation
+ * per-row PARTIAL sums go to head_part[fused_rows][slots][heads] (slots = m360_linear_heads_slots(n_pad, bf16), one per
+ * wave tile of 128 (fp32) or 64 (bf16) columns; no bias).  store_y = 0: the fused rows of y are NOT written (rendering: the 2.15 GB activation
  * of the last NeRF layer never reaches HBM); store_y = 1: also written (training tape).  Rows beyond
  * fused_rows = m360_linear_heads_fused_rows(M, n_pad, bf16) (ragged tail; every row when n_pad % 256 != 0 or n_pad > 1024)
  * are computed as by m360_linear into y, and the *_finish_fused entry points take their head products from there.
  * Replaces the last nn.Linear + nn.Sigmoid of model.py:43-53 / :131-148 plus the matrix product of the heads. */
 long m360_linear_heads_fused_rows(long M, int n_pad, int bf16);
-int m360_linear_heads_slots(int n_pad);
+int m360_linear_heads_slots(int n_pad, int bf16);
 int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad,
                       int k_pad, int act /* M360_ACT_SIGMOID */, float *y, int ldy, int store_y, const float *head_w,
                       int heads, float *head_part, m360_stream_t stream);

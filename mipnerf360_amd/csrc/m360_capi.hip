@@ -97,7 +97,7 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     L.act_a = take(S * wmax * sizeof(float));
     L.act_b = take(S * wmax * sizeof(float));
     // partial head sums of the fused last layer: [S][slots][heads] fp32 (67 MB at 4096 x 128, width 1024)
-    const size_t hp_slots = (size_t)m360_linear_heads_slots(m->hp_pad), hn_slots = (size_t)m360_linear_heads_slots(m->hn_pad);  // (an upper bound: sized whether or not the widths allow fusion)
+    const size_t hp_slots = (size_t)m360_linear_heads_slots(m->hp_pad, m->mlp_bf16), hn_slots = (size_t)m360_linear_heads_slots(m->hn_pad, m->mlp_bf16);  // (an upper bound: sized whether or not the widths allow fusion)
     const size_t hp_b = S * hp_slots * 1 * sizeof(float), hn_b = S * hn_slots * 4 * sizeof(float);
     L.hpart = take(hp_b > hn_b ? hp_b : hn_b);
     L.total = off;
@@ -210,7 +210,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
             M360_TRY(p_linear(h, act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, M360_ACT_RELU, act[l], hp, st));
         // last hidden layer + head fused; the tape keeps the layer output (store_y = 1), same partial sums as when rendering
         M360_TRY(p_linear_heads(h, 0, act[2], S, hp, m->prop_w[3], m->prop_b[3], hp, hp, act[3], hp, 1, m->prop_head_w, 1, hpart, st));
-        return p_prop_finish_fused(h, act[3], 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st);
+        return p_prop_finish_fused(h, act[3], 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp, 0), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st);
     }
     if (!ext_norm) M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, t_hat, st));  // sharded batch: t_hat is given
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
@@ -224,7 +224,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         M360_TRY(p_linear_bf16(h, a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
         M360_TRY(p_linear_bf16(h, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
         M360_TRY(p_linear_heads(h, 1, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, b, hp, 0, m->prop_head_w, 1, hpart, st));
-        return p_prop_finish_fused(h, b, 1, hp, hpart, m360_linear_heads_fused_rows(S, hp, 1), m360_linear_heads_slots(hp), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
+        return p_prop_finish_fused(h, b, 1, hp, hpart, m360_linear_heads_fused_rows(S, hp, 1), m360_linear_heads_slots(hp, 1), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
     }
     if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(p_linear(h, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
@@ -232,7 +232,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     M360_TRY(p_linear(h, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
     // last hidden layer + head fused: its 537 MB output never goes to HBM (store_y = 0; ragged tail rows excepted)
     M360_TRY(p_linear_heads(h, 0, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, b, hp, 0, m->prop_head_w, 1, hpart, st));
-    return p_prop_finish_fused(h, b, 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
+    return p_prop_finish_fused(h, b, 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp, 0), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
 }
 
 // resampled t -> features -> 8 NeRF layers -> heads + composite
@@ -249,7 +249,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     const long S = (long)B * N;
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hn = m->hn_pad;
-    const int slots = m360_linear_heads_slots(hn);
+    const int slots = m360_linear_heads_slots(hn, m->mlp_bf16);
     float *src = a, *dst = b;
     if (tape) {  // training: fp32 only, every layer output kept (t1 already lives in the tape)
         const TapeLayout T = tape_for(B, N, m, 1);

@@ -324,12 +324,14 @@ int m360_linear(const float *x, long M, int ldx, const float *w_packed, const fl
 
 // ---- last hidden layer of a stage fused with its heads
 long m360_linear_heads_fused_rows(long M, int n_pad, int bf16) {
-    if (bf16) return 0;  // bf16 kernel: not fused (yet) - every row goes through y
+    if (bf16) return 0;  // see m360_linear_heads_bf16
     if (M < 0 || n_pad < persist::BN || n_pad % persist::BN != 0 || n_pad > persist::kHeadMaxN) return 0;
-    return (M / persist::BM) * persist::BM;
+    return (M / persist::BM) * persist::BM;  // full 256-row tiles of a 256-multiple width <= 1024
 }
 
-int m360_linear_heads_slots(int n_pad) { return n_pad >= persist::BN ? 2 * (n_pad / persist::BN) : 0; }
+int m360_linear_heads_slots(int n_pad, int bf16) {  // partial sums per row: one per wave tile (fp32 128 columns, bf16 64)
+    return n_pad >= persist::BN ? (bf16 ? 4 : 2) * (n_pad / persist::BN) : 0;
+}
 
 int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
                       int act, float *y, int ldy, int store_y, const float *head_w, int heads, float *head_part,
@@ -369,7 +371,10 @@ int m360_linear_heads_bf16(const void *x, long M, int ldx, const void *w_packed,
                            float *head_part, m360_stream_t stream) {
     if (heads != 1 && heads != 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads_bf16: heads=%d (1 or 4)", heads);
     if (act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads_bf16: the last hidden layer is a sigmoid layer, act=%d", act);
-    (void)store_y; (void)head_w; (void)head_part;  // fused_rows == 0 for bf16: the plain layer, heads taken from y by the finisher
+    // m360_linear_heads_fused_rows(.., bf16 = 1) is 0: the bf16 kernel's deferred epilogue has no registers left for the head
+    // sums (an attempt spilled into the K loop: 4.0 ms instead of 0.97 ms per layer, profiles/r02), so every row goes through
+    // y and the finisher forms the head products from there - the same contract as the tail rows of the fp32 entry point
+    (void)store_y; (void)head_w; (void)head_part;
     return m360_linear_bf16(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, stream);
 }
 

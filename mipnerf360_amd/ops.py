@@ -406,7 +406,7 @@ def linear_heads(x, w_packed, b_packed, head_w, store_y: bool = True):
     if head_w.shape[1] != n_pad or ldx != k_pad:
         raise RuntimeError("linear_heads: shapes of x / w_packed / head_w do not match")
     lib = _lib.lib()
-    fused, slots = int(lib.m360_linear_heads_fused_rows(M, n_pad, 0)), int(lib.m360_linear_heads_slots(n_pad))
+    fused, slots = int(lib.m360_linear_heads_fused_rows(M, n_pad, 0)), int(lib.m360_linear_heads_slots(n_pad, 0))
     y = torch.zeros(M, n_pad, device=x.device)
     part = torch.zeros(max(fused, 1), max(slots, 1), heads, device=x.device)
     _call("m360_linear_heads", x, M, ldx, w_packed, b_packed, n_pad, k_pad, _lib.ACT_SIGMOID, y, n_pad, int(bool(store_y)),
