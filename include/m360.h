@@ -74,6 +74,15 @@ int m360_frustum_moments(const float *t0 /*[B,N]*/, const float *t1 /*[B,N]*/,
                          const float *radii /*[B]*/, int B, int N, float *t_mean, float *t_var,
                          float *r_var, m360_stream_t stream);
 
+/* the reference's other two public branches (never taken by its own hot path, kept for API completeness):
+ * direct ("unstable") frustum moments, intern/parameterization.py:108-113 (stable=False), and the diagonal lift,
+ * intern/parameterization.py:48-54 (diag=True): cov_diag[B,N,3]. */
+int m360_frustum_moments_unstable(const float *t0, const float *t1, const float *radii, int B, int N,
+                                  float *t_mean, float *t_var, float *r_var, m360_stream_t stream);
+int m360_gaussian_to_xyz_diag(const float *d /*[B,3]*/, const float *t_mean /*[B,N]*/, const float *t_var,
+                              const float *r_var, int B, int N, float *mean /*[B,N,3]*/,
+                              float *cov_diag /*[B,N,3]*/, m360_stream_t stream);
+
 /* lift to xyz, full covariance.  Replaces intern/parameterization.py:31-62 (diag=False). */
 int m360_gaussian_to_xyz(const float *d /*[B,3]*/, const float *t_mean /*[B,N]*/,
                          const float *t_var, const float *r_var, int B, int N,

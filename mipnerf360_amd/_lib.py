@@ -68,6 +68,8 @@ SIGNATURES = {
     "m360_t_to_s": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "m360_frustum_moments": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "m360_gaussian_to_xyz": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "m360_frustum_moments_unstable": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "m360_gaussian_to_xyz_diag": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "m360_contract_workspace_bytes": (_sz, []),
     "m360_gaussian_contract": (_i, [_vp, _vp, _l, _vp, _vp, _vp, _sz, _vp]),
     "m360_para_rays": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),

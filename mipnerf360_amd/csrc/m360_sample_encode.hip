@@ -95,6 +95,44 @@ __global__ void frustum_moments_kernel(const float *__restrict__ t0, const float
     r_var[idx] = rv;
 }
 
+// intern/parameterization.py:108-113 (stable=False): the direct moment formulas (catastrophic cancellation for thin
+// frusta - the reference's own docstring warns - but a public branch all the same)
+__global__ void frustum_moments_unstable_kernel(const float *__restrict__ t0, const float *__restrict__ t1,
+                                                const float *__restrict__ radii, int B, int N,
+                                                float *__restrict__ t_mean, float *__restrict__ t_var,
+                                                float *__restrict__ r_var) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * N) return;
+    const int b = (int)(idx / N);
+    const float a = t0[idx], c = t1[idx], r = radii[b];
+    const float a2 = a * a, c2 = c * c;
+    const float a3 = a2 * a, c3 = c2 * c, a4 = a2 * a2, c4 = c2 * c2, a5 = a4 * a, c5 = c4 * c;
+    const float d3 = c3 - a3, d5 = c5 - a5;
+    const float tm = (3.0f * (c4 - a4)) / (4.0f * d3);
+    const float rv = (r * r) * ((3.0f / 20.0f) * d5 / d3);
+    const float mosq = (3.0f / 5.0f) * d5 / d3;
+    t_mean[idx] = tm;
+    r_var[idx] = rv;
+    t_var[idx] = mosq - tm * tm;
+}
+
+// intern/parameterization.py:48-54 (diag=True): mean = d t_mean, diagonal of the covariance only
+__global__ void gaussian_to_xyz_diag_kernel(const float *__restrict__ d, const float *__restrict__ t_mean,
+                                            const float *__restrict__ t_var, const float *__restrict__ r_var,
+                                            int B, int N, float *__restrict__ mean, float *__restrict__ cov_diag) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * N) return;
+    const int b = (int)(idx / N);
+    const float dd[3] = {d[3 * b], d[3 * b + 1], d[3 * b + 2]};
+    const float mag = fmaxf(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2], 1e-10f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float outer = dd[i] * dd[i];
+        mean[3 * idx + i] = dd[i] * t_mean[idx];
+        cov_diag[3 * idx + i] = t_var[idx] * outer + r_var[idx] * (1.0f - outer / mag);
+    }
+}
+
 __global__ void gaussian_to_xyz_kernel(const float *__restrict__ d, const float *__restrict__ t_mean,
                                        const float *__restrict__ t_var,
                                        const float *__restrict__ r_var, int B, int N,
@@ -402,6 +440,24 @@ int m360_frustum_moments(const float *t0, const float *t1, const float *radii, i
     if (B == 0) return M360_OK;
     hipLaunchKernelGGL(frustum_moments_kernel, dim3(blocks_for((long)B * N, 256)), dim3(256), 0, S_(stream), t0, t1, radii, B, N, t_mean, t_var, r_var);
     return check_launch("frustum_moments");
+}
+
+int m360_frustum_moments_unstable(const float *t0, const float *t1, const float *radii, int B, int N,
+                                  float *t_mean, float *t_var, float *r_var, m360_stream_t stream) {
+    if (!t0 || !t1 || !radii || !t_mean || !t_var || !r_var || B < 0 || N < 1)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_frustum_moments_unstable: bad argument");
+    if (B == 0) return M360_OK;
+    hipLaunchKernelGGL(frustum_moments_unstable_kernel, dim3(blocks_for((long)B * N, 256)), dim3(256), 0, S_(stream), t0, t1, radii, B, N, t_mean, t_var, r_var);
+    return check_launch("frustum_moments_unstable");
+}
+
+int m360_gaussian_to_xyz_diag(const float *d, const float *t_mean, const float *t_var, const float *r_var,
+                              int B, int N, float *mean, float *cov_diag, m360_stream_t stream) {
+    if (!d || !t_mean || !t_var || !r_var || !mean || !cov_diag || B < 0 || N < 1)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_gaussian_to_xyz_diag: bad argument");
+    if (B == 0) return M360_OK;
+    hipLaunchKernelGGL(gaussian_to_xyz_diag_kernel, dim3(blocks_for((long)B * N, 256)), dim3(256), 0, S_(stream), d, t_mean, t_var, r_var, B, N, mean, cov_diag);
+    return check_launch("gaussian_to_xyz_diag");
 }
 
 int m360_gaussian_to_xyz(const float *d, const float *t_mean, const float *t_var, const float *r_var,

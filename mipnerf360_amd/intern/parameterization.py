@@ -33,9 +33,10 @@ def contract(x):
 
 
 def gaussian_to_xyz(d, t_mean, t_var, r_var, diag=False):
-    """intern/parameterization.py:31-62; only the full-covariance branch is on the hot path."""
+    """intern/parameterization.py:31-62 -> (mean[B,N,3], cov[B,N,3,3]), or with diag=True the diagonal cov[B,N,3]
+    (a branch the reference's own hot path never takes)."""
     if diag:
-        raise NotImplementedError("diag=True is a dead branch of the reference's hot path (never taken)")
+        return ops.gaussian_to_xyz_diag(d, t_mean, t_var, r_var)
     return ops.gaussian_to_xyz(d, t_mean, t_var, r_var)
 
 
@@ -45,10 +46,12 @@ def gaussian_contract(mean, cov):
 
 
 def conical_frustum_to_gaussian(d, t0, t1, base_radius, diag, stable=True):
-    """intern/parameterization.py:85-117 (stable branch)."""
-    if diag or not stable:
-        raise NotImplementedError("only diag=False, stable=True is reachable from the reference's hot path")
-    t_mean, t_var, r_var = ops.frustum_moments(t0, t1, base_radius)
+    """intern/parameterization.py:85-117; stable=False takes the direct moment formulas (:108-113).  diag=True raises
+    like the reference does there (its gaussian_contract needs the full 3 x 3 covariance, :76-81)."""
+    if diag:
+        raise RuntimeError("conical_frustum_to_gaussian(diag=True): gaussian_contract needs a full covariance (the reference "
+                           "raises at this point as well)")
+    t_mean, t_var, r_var = ops.frustum_moments(t0, t1, base_radius, stable=bool(stable))
     mean, cov = ops.gaussian_to_xyz(d, t_mean, t_var, r_var)
     return ops.gaussian_contract(mean, cov)
 
@@ -56,5 +59,5 @@ def conical_frustum_to_gaussian(d, t0, t1, base_radius, diag, stable=True):
 def para_rays(t_vals, origins, directions, radii, diag=False):
     """intern/parameterization.py:119-135 (origins are added after the contraction)."""
     if diag:
-        raise NotImplementedError("diag=True is a dead branch of the reference's hot path (never taken)")
+        raise RuntimeError("para_rays(diag=True): gaussian_contract needs a full covariance (the reference raises here as well)")
     return ops.para_rays(t_vals, origins, directions, radii)

@@ -141,12 +141,21 @@ def t_to_s(t_vals, near, far, near_calls: int = 1, far_calls: int = 1) -> torch.
 
 
 # ----------------------------------------------------------------------------- gaussians
-def frustum_moments(t0, t1, radii):
+def frustum_moments(t0, t1, radii, stable: bool = True):
     t0, t1, radii = dev(t0, "t0"), dev(t1, "t1"), dev(radii, "radii")
     B, N = t0.shape
     outs = [torch.empty_like(t0) for _ in range(3)]
-    _call("m360_frustum_moments", t0, t1, radii, B, N, *[o for o in outs], STREAM)
+    _call("m360_frustum_moments" if stable else "m360_frustum_moments_unstable", t0, t1, radii, B, N, *outs, STREAM)
     return tuple(outs)
+
+
+def gaussian_to_xyz_diag(d, t_mean, t_var, r_var):
+    d, t_mean, t_var, r_var = dev(d, "d"), dev(t_mean, "t_mean"), dev(t_var, "t_var"), dev(r_var, "r_var")
+    B, N = t_mean.shape
+    mean = torch.empty(B, N, 3, device=d.device)
+    cov = torch.empty(B, N, 3, device=d.device)
+    _call("m360_gaussian_to_xyz_diag", d, t_mean, t_var, r_var, B, N, mean, cov, STREAM)
+    return mean, cov
 
 
 def gaussian_to_xyz(d, t_mean, t_var, r_var):

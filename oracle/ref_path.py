@@ -103,6 +103,23 @@ def frustum_moments(t0, t1, radii):
     return t_mean, t_var, r_var
 
 
+def frustum_moments_unstable(t0, t1, radii):
+    """Direct moment formulas, intern/parameterization.py:108-113 (stable=False)."""
+    t_mean = (3 * (t1 ** 4 - t0 ** 4)) / (4 * (t1 ** 3 - t0 ** 3))
+    r_var = radii ** 2 * (3 / 20 * (t1 ** 5 - t0 ** 5) / (t1 ** 3 - t0 ** 3))
+    t_mosq = 3 / 5 * (t1 ** 5 - t0 ** 5) / (t1 ** 3 - t0 ** 3)
+    return t_mean, t_mosq - t_mean ** 2, r_var
+
+
+def lift_to_xyz_diag(d, t_mean, t_var, r_var):
+    """Diagonal lift, intern/parameterization.py:44-54 (diag=True) -> (mean[B,N,3], cov_diag[B,N,3])."""
+    mean = d[..., None, :] * t_mean[..., None]
+    d_mag_sq = torch.clamp_min(torch.sum(d ** 2, dim=-1, keepdim=True), 1e-10)
+    d_outer_diag = d ** 2
+    null_outer_diag = 1 - d_outer_diag / d_mag_sq
+    return mean, t_var[..., None] * d_outer_diag[..., None, :] + r_var[..., None] * null_outer_diag[..., None, :]
+
+
 def lift_to_xyz(d, t_mean, t_var, r_var):
     """Full-covariance lift, intern/parameterization.py:44-46,55-62 (diag=False)."""
     mean = d[..., None, :] * t_mean[..., None]

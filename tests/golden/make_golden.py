@@ -526,10 +526,26 @@ def g15():
     save("g15_reference_render", **out)
 
 
+def g16():
+    """The reference's two public branches its own hot path never takes: gaussian_to_xyz(diag=True)
+    (intern/parameterization.py:48-54) and conical_frustum_to_gaussian(stable=False) (:108-113)."""
+    g = np.random.Generator(np.random.PCG64(1616))
+    B, n = 5, 7
+    d = g.normal(size=(B, 3)).astype(np.float32)
+    t0 = (2.0 + np.sort(g.uniform(0, 4, size=(B, n + 1)), axis=1)).astype(np.float32)
+    radii = g.uniform(1e-3, 5e-2, size=(B, 1)).astype(np.float32)
+    tm, tv, rv = (g.uniform(0.5, 3, size=(B, n)).astype(np.float32), g.uniform(1e-4, 1e-2, size=(B, n)).astype(np.float32),
+                  g.uniform(1e-5, 1e-3, size=(B, n)).astype(np.float32))
+    mean, cov = ref_par.gaussian_to_xyz(T(d), T(tm), T(tv), T(rv), diag=True)
+    m2, c2 = ref_par.conical_frustum_to_gaussian(T(d), T(t0[:, :-1]), T(t0[:, 1:]), T(radii), diag=False, stable=False)
+    save("g16_dead_branches", d=d, t=t0, radii=radii, tm=tm, tv=tv, rv=rv, diag_mean=N(mean), diag_cov=N(cov),
+         unstable_mean=N(m2), unstable_cov=N(c2))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14,
-                 g15=g15)
+                 g15=g15, g16=g16)
     for k in which:
         print(k)
         table[k]()

@@ -1220,3 +1220,19 @@ def test_g15_reference_written_checkpoint_loads_and_renders(golden, dev):
     back = checkpoint.to_reference_state_dict(m)
     ref = torch.load(os.path.join(GOLDEN_DIR, "g15_reference_checkpoint.pt"), map_location="cpu")
     assert list(back) == list(ref) and all(torch.equal(back[k], ref[k]) for k in ref)
+
+
+def test_g16_diag_lift_and_unstable_moments(golden, dev):
+    """gaussian_to_xyz(diag=True) and conical_frustum_to_gaussian(stable=False): public branches of the reference that its
+    hot path never takes (fixture G16); diag=True through the contraction raises, as in the reference."""
+    from mipnerf360_amd.intern import parameterization as P
+    g = golden("g16_dead_branches")
+    d, t, radii = D(g["d"], dev), D(g["t"], dev), D(g["radii"], dev)
+    mean, cov = P.gaussian_to_xyz(d, D(g["tm"], dev), D(g["tv"], dev), D(g["rv"], dev), diag=True)
+    assert cov.shape == g["diag_cov"].shape
+    close(mean, g["diag_mean"], atol=1e-7), close(cov, g["diag_cov"], atol=1e-9, rtol=1e-5)
+    m, c = P.conical_frustum_to_gaussian(d, t[:, :-1].contiguous(), t[:, 1:].contiguous(), radii, diag=False, stable=False)
+    close(m, g["unstable_mean"], atol=1e-6, rtol=1e-5)
+    close(c, g["unstable_cov"], atol=2e-3 * float(np.abs(g["unstable_cov"]).max()), rtol=0)
+    with pytest.raises(RuntimeError):
+        P.conical_frustum_to_gaussian(d, t[:, :-1].contiguous(), t[:, 1:].contiguous(), radii, diag=True)

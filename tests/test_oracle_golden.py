@@ -323,3 +323,15 @@ def test_g15_reference_written_checkpoint(golden):
     rays = O.Rays(*[torch.from_numpy(g[f"rays_{f}"]) for f in synthetic.RAY_FIELDS])
     rgb, dist, acc = O.forward(rays, {k: v.float() for k, v in sd.items()}, O.Hyper(num_samples=int(g["cfg"][0]), white_bkgd=True))
     close(rgb, g["rgb"], atol=2e-6), close(acc, g["acc"], atol=2e-6), close(dist, g["dist"], atol=2e-6, rtol=1e-5)
+
+
+def test_g16_diag_lift_and_unstable_moments(golden):
+    """The reference's two public branches its hot path never takes (fixture G16)."""
+    g = golden("g16_dead_branches")
+    d, t, radii = T(g["d"]), T(g["t"]), T(g["radii"])
+    mean, cov = O.lift_to_xyz_diag(d, T(g["tm"]), T(g["tv"]), T(g["rv"]))
+    close(mean, g["diag_mean"], atol=1e-7), close(cov, g["diag_cov"], atol=1e-9, rtol=1e-5)
+    tm, tv, rv = O.frustum_moments_unstable(t[:, :-1], t[:, 1:], radii)
+    m, c = O.gaussian_contract(*O.lift_to_xyz(d, tm, tv, rv))
+    close(m, g["unstable_mean"], atol=1e-6, rtol=1e-5)
+    close(c, g["unstable_cov"], atol=2e-3 * float(np.abs(g["unstable_cov"]).max()), rtol=0)   # t_var = E[t^2] - E[t]^2 cancels ~5 digits: fp32 noise is amplified

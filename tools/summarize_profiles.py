@@ -32,14 +32,14 @@ def one(pattern):
 
 def durations(d):
     return {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in
-            csv.DictReader(open(one(f"{d}/runc/*_kernel_trace.csv")))}
+            csv.DictReader(open(one(f"{d}/*/*_kernel_trace.csv")))}
 
 
 def dominant_counters(d):
     """mean counter value over the dominant launches (ReLU 1024x1024 layers on M=524288: persistent kernel, > 6 ms)."""
     dur = durations(d)
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(one(f"{d}/runc/*_counter_collection.csv"))):
+    for r in csv.DictReader(open(one(f"{d}/*/*_counter_collection.csv"))):
         if "persist_kernel<1" in r["Kernel_Name"] and dur[r["Dispatch_Id"]] > 6e6:
             agg[r["Counter_Name"]].append((float(r["Counter_Value"]), dur[r["Dispatch_Id"]]))
     return {k: (sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v), len(v)) for k, v in agg.items()}
@@ -47,7 +47,7 @@ def dominant_counters(d):
 
 def counter_summary(d, out):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(one(f"{d}/runc/*_counter_collection.csv"))):
+    for r in csv.DictReader(open(one(f"{d}/*/*_counter_collection.csv"))):
         k = (r["Kernel_Name"].split("(")[0][-70:], r["Counter_Name"])
         agg[k][0] += 1
         agg[k][1] += float(r["Counter_Value"])
@@ -59,7 +59,7 @@ def counter_summary(d, out):
 
 def step_trace(d, out):
     """per-launch durations of the LAST bench step (kernel order as launched)."""
-    rows = sorted(csv.DictReader(open(one(f"{d}/runc/*_kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
+    rows = sorted(csv.DictReader(open(one(f"{d}/*/*_kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
     starts = [i for i, n in enumerate(names) if "sample_t_kernel" in n]
     ends = [min(j for j, n in enumerate(names) if "t_to_s_kernel" in n and j > i) for i in starts]
@@ -83,7 +83,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
-    shutil.copy(one(f"{src}/stats/runc/*_kernel_stats.csv"), f"{dst}/rocprofv3_kernel_stats_bench.csv")
+    shutil.copy(one(f"{src}/stats/*/*_kernel_stats.csv"), f"{dst}/rocprofv3_kernel_stats_bench.csv")
     for extra in ("bench.json", "bench_under_rocprof.log"):
         if os.path.exists(f"{src}/{extra}"):
             shutil.copy(f"{src}/{extra}", f"{dst}/{extra}")
@@ -92,7 +92,7 @@ def main():
     print(step_trace(f"{src}/stats", f"{dst}/last_step_kernel_trace.csv"))
     # the dominant launches alone (ReLU 1024x1024 layers on M = 524288): what bench.py's roofline.avg_launch_ms must agree with
     dur = [v for k, v in durations(f"{src}/stats").items()]
-    rows = [r for r in csv.DictReader(open(one(f"{src}/stats/runc/*_kernel_trace.csv"))) if "persist_kernel<1" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(one(f"{src}/stats/*/*_kernel_trace.csv"))) if "persist_kernel<1" in r["Kernel_Name"]]
     big = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
     big = [d for d in big if d > 6e6]
     with open(f"{dst}/dominant_kernel_launches.csv", "w") as f:
