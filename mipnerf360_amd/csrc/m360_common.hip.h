@@ -67,6 +67,16 @@ __device__ __forceinline__ double wave_incl_scan_d(double v) {
     return v;
 }
 
+// xor-butterfly over 8 consecutive lanes (DPP: no LDS traffic); every lane of the group gets the sum.  Shared by the fused
+// epilogue of the last hidden layer (m360_linear_persist.hip.h) and the finishers' tail-row path (m360_ray.hip), which
+// must add in the same order.
+__device__ __forceinline__ float row8_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));  // row_half_mirror: lane i <-> 7 - i
+    return x;
+}
+
 // ---- frustum -> gaussian ------------------------------------------------------------------
 // intern/parameterization.py:99-107
 __device__ __forceinline__ void frustum_moments(float t0, float t1, float radius, float &t_mean,
@@ -161,14 +171,15 @@ __device__ __forceinline__ void sincos_small(float x, float *s, float *c) {
 }
 
 // intern/encoding.py:43-56 for one sample: out[k] = exp(-sigma_k/2) sin(gamma_k), out[21+k] = ... cos
-template <bool HAS_COV, typename Store>
+// STATIC_K: the caller's store() needs compile-time channel indices (values kept in registers): the rare path is then
+// unrolled as well (dead weight in the code object, never fetched by the contracted path)
+template <bool HAS_COV, bool STATIC_K = false, typename Store>
 __device__ __forceinline__ void ipe_sample(const float mean[3], const float cov[9], Store &&store) {
     // |gamma_k| <= |mean| (unit directions): ONE range test per sample picks the short sin / cos for all 21 directions;
     // far-away / non-finite means (never produced by the contracted path) take the library routines in a rolled loop
     const float m2 = mean[0] * mean[0] + mean[1] * mean[1] + mean[2] * mean[2];
     if (!(m2 <= 6.0e7f)) {
-#pragma unroll 1
-        for (int k = 0; k < kIpeDirs; ++k) {
+        auto slow = [&](int k) __attribute__((always_inline)) {
             const float p0 = kIpeBasis[k][0], p1 = kIpeBasis[k][1], p2 = kIpeBasis[k][2];
             const float gamma = p0 * mean[0] + p1 * mean[1] + p2 * mean[2];
             float sn, cs;
@@ -183,6 +194,13 @@ __device__ __forceinline__ void ipe_sample(const float mean[3], const float cov[
             }
             store(k, sn);
             store(kIpeDirs + k, cs);
+        };
+        if (STATIC_K) {
+#pragma unroll
+            for (int k = 0; k < kIpeDirs; ++k) slow(k);
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < kIpeDirs; ++k) slow(k);
         }
         return;
     }

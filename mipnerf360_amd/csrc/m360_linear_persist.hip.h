@@ -55,14 +55,6 @@ __device__ unsigned long long g_stamps[256 * 16];
 
 constexpr int kHeadMaxN = 1024;  // widest layer whose heads can be fused (bias + head rows live in LDS: (1 + HEADS) x 4 KiB)
 
-// xor-butterfly over the 8 consecutive lanes that share an output row in the epilogue (DPP: no LDS traffic)
-__device__ __forceinline__ float row8_sum(float x) {
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));  // row_half_mirror: lane i <-> 7 - i
-    return x;
-}
-
 // HEADS > 0 (the LAST hidden layer of a stage): the epilogue also multiplies the activated outputs with the HEADS head
 // rows (model.py:52 / :150-158: hidden -> 1 density, hidden -> 1 + 3 density / colour) while they are in registers and
 // writes per-row PARTIAL head sums head_part[M][2 * tiles_n][HEADS] (one slot per 128-column wave tile; the finisher

@@ -286,6 +286,43 @@ __device__ __forceinline__ void head_dots(const T *__restrict__ act_ray, int ld,
     }
 }
 
+// Head products of activation rows in EXACTLY the order of the fused epilogue (m360_linear_persist.hip.h, HEADS > 0): per
+// 128-column wave tile ("slot") the 8 lanes of a row each chain 4 column blocks x 4 columns of fused multiply-adds, the
+// lanes are reduced by the same DPP butterfly, the slots are added 0, 1, ...  Used for the rows the fused layer did not
+// cover (ragged tail of the batch), so a row's result does not depend on which side of `fused_rows` it fell - a chunk
+// rendered alone and the same chunk inside a larger launch stay bit-identical.  One wave per sample, 8 lanes per slot.
+template <int H>
+__device__ __forceinline__ void head_dots_fused_order(const float *__restrict__ act_rows, int ld, const float *hw /*LDS [H][k_pad]*/,
+                                                      const float *__restrict__ hb, int k_pad, int slots, int count,
+                                                      float *raw /*LDS [count][H]*/) {
+    const int wave = threadIdx.x >> 6, l = lane_id(), nwaves = blockDim.x >> 6;
+    const int q = l >> 3, lane8 = l & 7;
+    for (int n = wave; n < count; n += nwaves) {
+        float accq[H];
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) accq[hh] = 0.0f;
+        if (q < slots) {
+            const float *x = act_rows + (long)n * ld + q * 128 + 4 * lane8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v = *reinterpret_cast<const float4 *>(x + 32 * j);
+#pragma unroll
+                for (int hh = 0; hh < H; ++hh) {
+                    const float4 w4 = *reinterpret_cast<const float4 *>(hw + hh * k_pad + q * 128 + 32 * j + 4 * lane8);
+                    accq[hh] = fmaf(v.w, w4.w, fmaf(v.z, w4.z, fmaf(v.y, w4.y, fmaf(v.x, w4.x, accq[hh]))));
+                }
+            }
+        }
+#pragma unroll
+        for (int hh = 0; hh < H; ++hh) {
+            accq[hh] = row8_sum(accq[hh]);
+            float a = 0.0f;
+            for (int s = 0; s < slots; ++s) a += __shfl(accq[hh], 8 * s, kWave);
+            if (l == 0) raw[n * H + hh] = a + hb[hh];
+        }
+    }
+}
+
 // Head products of one ray's N samples -> raw[N][H] (LDS).  Samples whose global row (b N + n) lies below `fused_rows`
 // take them from the partial sums the fused last layer left (m360_linear_heads: head_part[row][slots][H], added slot
 // 0, 1, ... then the bias); the others are computed from the activation rows as in the unfused path.
@@ -307,7 +344,14 @@ __device__ __forceinline__ void ray_heads(const T *__restrict__ act, int ld, con
         raw[idx] = a + head_b[hh];
     }
     __syncthreads();
-    if (nf < N) head_dots<H, T>(act + (s0 + nf) * ld, ld, hw, head_b, k_pad, N - nf, raw + nf * H);
+    if (nf < N) {
+        if constexpr (sizeof(T) == 4) {  // fp32: widths the fused layer takes (slots > 0) keep ITS summation order in the tail rows
+            if (slots > 0 && slots <= 8 && k_pad == 128 * slots) head_dots_fused_order<H>(reinterpret_cast<const float *>(act) + (s0 + nf) * ld, ld, hw, head_b, k_pad, slots, N - nf, raw + nf * H);
+            else head_dots<H, T>(act + (s0 + nf) * ld, ld, hw, head_b, k_pad, N - nf, raw + nf * H);
+        } else {
+            head_dots<H, T>(act + (s0 + nf) * ld, ld, hw, head_b, k_pad, N - nf, raw + nf * H);
+        }
+    }
     __syncthreads();
 }
 

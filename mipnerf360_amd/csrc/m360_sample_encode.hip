@@ -343,6 +343,13 @@ __global__ void viewdir_enc_kernel(const float *__restrict__ viewdirs, int B, in
 // conflict-free per-row writes) and streams it out as whole 16-byte-per-lane coalesced stores.
 constexpr int kEncThreads = 128;
 
+// intra-wave LDS ordering (wave-private tiles): a wave-scope fence suffices
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 template <bool BF16>  // BF16: feature rows are written as bf16 (opt-in reduced-precision MLP), else fp32
@@ -387,6 +394,79 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)src[e];
             out[q] = o;
         }
+    }
+}
+
+
+// Wave-tiled form of the kernel above for ld = 64 / 96 (every model of the path): one sample per lane, the 42 IPE values
+// stay in registers and go out in 32-channel passes through a wave-private [64][36]-float LDS tile (9 KiB per wave instead
+// of 33 KiB per 128 samples, no workgroup barrier): 4 x the resident waves per CU of the kernel above, whose 2.6 TB/s were
+// occupancy-bound once the short sin / cos had removed the ALU bound.  Each pass writes whole 128-byte (fp32) or 64-byte
+// (bf16) row segments with 16-byte lanes.  Same values as the kernel above, bit for bit.
+constexpr int kEncWaves = 4;
+constexpr int kEncTileLd = 36;
+
+template <bool BF16, int NPASS>
+__global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kernel(
+    const float *__restrict__ t_vals, const float *__restrict__ origins,
+    const float *__restrict__ directions, const float *__restrict__ radii,
+    const float *__restrict__ vdenc, int vd_ch, int B, int N, const NormScratch *__restrict__ ws,
+    void *__restrict__ feat_out, int group_rays, const float *__restrict__ ext_norm) {
+    __shared__ __attribute__((aligned(16))) float tiles[kEncWaves][kWave * kEncTileLd];
+    constexpr int ld = 32 * NPASS;
+    const long S = (long)B * N;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const long s0 = ((long)blockIdx.x * kEncWaves + wave) * kWave;  // first sample of this wave
+    if (s0 >= S) return;
+    const long idx = s0 + lane;
+    const bool live = idx < S;
+    float *tile = tiles[wave];
+    float v[kIpeCh];
+    int b = 0;
+    if (live) {
+        b = (int)(idx / N);
+        const int n = (int)(idx % N);
+        float m[3], c[9];
+        const float gn = ext_norm ? *ext_norm : (group_rays > 0 ? ws->gnorms[b / group_rays] : ws->gnorm);
+        sample_gaussian(t_vals, origins, directions, radii, N, b, n, gn, m, c);
+        ipe_sample<true, true>(m, c, [&](int k, float val) { v[k] = val; });
+    } else {
+#pragma unroll
+        for (int k = 0; k < kIpeCh; ++k) v[k] = 0.0f;
+    }
+    const long rows = (S - s0 < kWave) ? (S - s0) : kWave;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+#pragma unroll
+        for (int cc = 0; cc < 32; ++cc) {
+            const int ch = 32 * p + cc;  // compile-time
+            float val;
+            if (ch < kIpeCh) val = v[ch];
+            else val = (live && ch - kIpeCh < vd_ch) ? vdenc[(long)b * vd_ch + (ch - kIpeCh)] : 0.0f;
+            tile[lane * kEncTileLd + cc] = val;
+        }
+        wave_sync_lds();
+        if (!BF16) {  // 8 lanes x 16 B = one 128-byte row segment; 8 rows per instruction
+            float *out = static_cast<float *>(feat_out) + s0 * ld + 32 * p;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 8 * i + (lane >> 3), col = 4 * (lane & 7);
+                if (r < rows) *reinterpret_cast<float4 *>(out + (long)r * ld + col) = *reinterpret_cast<const float4 *>(tile + r * kEncTileLd + col);
+            }
+        } else {      // 4 lanes x 16 B (8 bf16) = one 64-byte row segment; 16 rows per instruction
+            __bf16 *out = static_cast<__bf16 *>(feat_out) + s0 * ld + 32 * p;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * i + (lane >> 2), col = 8 * (lane & 3);
+                const float4 lo = *reinterpret_cast<const float4 *>(tile + r * kEncTileLd + col);
+                const float4 hi = *reinterpret_cast<const float4 *>(tile + r * kEncTileLd + col + 4);
+                bf16x8_t o;
+                o[0] = (__bf16)lo.x; o[1] = (__bf16)lo.y; o[2] = (__bf16)lo.z; o[3] = (__bf16)lo.w;
+                o[4] = (__bf16)hi.x; o[5] = (__bf16)hi.y; o[6] = (__bf16)hi.z; o[7] = (__bf16)hi.w;
+                if (r < rows) *reinterpret_cast<bf16x8_t *>(out + (long)r * ld + col) = o;
+            }
+        }
+        wave_sync_lds();  // the tile is rewritten by the next pass
     }
 }
 
@@ -608,6 +688,14 @@ static int encode_features_any(const float *t_vals, const float *origins, const 
     if (B == 0) return M360_OK;
     NormScratch *ws = static_cast<NormScratch *>(workspace);
     if (!ext_norm) launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream), group_rays);
+    if (ld_feat == 64 || ld_feat == 96) {  // every model of the path: wave-tiled kernel
+        const dim3 grid(blocks_for((long)B * N, kEncWaves * kWave)), block(kEncWaves * kWave);
+#define M360_ENC(BF, NP) hipLaunchKernelGGL((encode_features_wave_kernel<BF, NP>), grid, block, 0, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, group_rays, ext_norm)
+        if (ld_feat == 64) { if (bf16) M360_ENC(true, 2); else M360_ENC(false, 2); }
+        else { if (bf16) M360_ENC(true, 3); else M360_ENC(false, 3); }
+#undef M360_ENC
+        return check_launch("encode_features");
+    }
     const size_t lds = (size_t)kEncThreads * (ld_feat + 1) * sizeof(float);
     if (bf16) hipLaunchKernelGGL(encode_features_kernel<true>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
     else hipLaunchKernelGGL(encode_features_kernel<false>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);

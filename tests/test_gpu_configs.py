@@ -280,3 +280,32 @@ def test_fused_last_layer_heads_match_the_unfused_path(dev, B, N, width, heads):
             assert float((u - v).abs().max()) <= 1e-6, float((u - v).abs().max())
     for _ in range(3):  # deterministic: fixed summation order, no atomics
         assert torch.equal(ops.linear_heads(x, wp, bp, hw, store_y=False)[1], part0)
+    # rows the fused layer does not cover are summed by the finisher in the SAME order as the fused epilogue: a row's result
+    # does not depend on which side of `fused_rows` it fell (chunk alone == chunk inside a larger launch, bit for bit)
+    if width % 256 == 0 and width <= 1024:
+        if heads == 4:
+            fused_out = ops.nerf_finish_fused(y1, part1, fused, hw, hb, -1.0, 0.001, t, dirs, True)
+            tail_out = ops.nerf_finish_fused(y_ref, part1, 0, hw, hb, -1.0, 0.001, t, dirs, True)
+        else:
+            fused_out = ops.prop_finish_fused(y1, part1, fused, hw, hb, -1.0, t, dirs, 0.01)
+            tail_out = ops.prop_finish_fused(y_ref, part1, 0, hw, hb, -1.0, t, dirs, 0.01)
+        for u, v in zip(fused_out, tail_out):
+            assert torch.equal(u, v)
+
+
+def test_grouped_chunks_bit_identical_at_fusable_widths(dev):
+    """Full-width MLPs (the last hidden layer of each stage is fused with its heads for whole 256-row tiles) with a sample
+    count and chunk size whose products are NOT multiples of 256: a chunk rendered by its own launch has a ragged tail of
+    unfused rows in other places than the same chunk inside a many-chunk launch.  The finisher adds those rows' head
+    products in the fused epilogue's order, so both renders are still bit-identical."""
+    m, _ = make_model(dev, 33, seed=12)
+    r = synthetic.make_rays("garden", 700, seed=38)
+    r["origins"] = r["origins"] * 3.0
+    rays = dev_rays(r, dev)
+    m.super_batch_rays = 512
+    a = [t.clone() for t in m.render_rays(rays, 100)]      # 5 chunks per launch (500 rays x 33 samples), then 200 rays
+    m.super_batch_rays = 0
+    b = m.render_rays(rays, 100)                           # one launch sequence per chunk (3300 rows: 12 tiles + 228 tail rows)
+    m.super_batch_rays = 4096
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
