@@ -318,6 +318,24 @@ int m360_nerf_finish(const float *act, int ld, const float *head_w, const float 
                      const float *dirs, int B, int N, int white_bkgd, float *comp_rgb,
                      float *distance, float *acc, float *weights /*or NULL*/, m360_stream_t stream);
 
+/* visualize_depth with the reference's remaining options (intern/pose.py:148-212):
+ *   ignore_frac > 0: the automatic near / far planes are the first / last depth of the depth-SORTED map whose running sum
+ *     of acc lies inside [ignore_frac, 1 - ignore_frac] of the total (device radix sort + numpy's sequential float32 cumsum);
+ *   curved != 0: `depth`, `near`, `far` already went through the caller's own curve_fn (a host callable in the reference's
+ *     API) - the default -log(x + eps) is then skipped; automatic planes cannot be combined with it;
+ *   value_out != NULL: write the normalised value [h,w] (the argument of the colormap) instead of colours, for a
+ *     caller-supplied colormap callable, whose colours m360_visualize_composite then blends with acc;
+ *   planes_out != NULL (device float[2]): the automatic near / far planes (with their -/+ eps), e.g. to curve them on the host.
+ * vis and value_out may both be NULL (planes only). */
+size_t m360_visualize_depth_ex_workspace_bytes(int h, int w);
+int m360_visualize_depth_ex(const float *depth, const float *acc, int h, int w, float near, float far, int near_auto,
+                            int far_auto, float ignore_frac, int curved, float modulus, float *vis /*[h,w,3]*/,
+                            float *value_out /*[h,w]*/, float *planes_out /*[2]*/, void *workspace,
+                            size_t workspace_bytes, m360_stream_t stream);
+/* vis[h,w,3] = colors[h,w,3] * acc + (1 - acc), acc := 0 where depth is NaN (depth may be NULL).  intern/pose.py:207-210. */
+int m360_visualize_composite(const float *colors, const float *acc, const float *depth, int h, int w, float *vis,
+                             m360_stream_t stream);
+
 /* ------------------------------------------------------------------ fused last layer + heads ----- */
 
 /* The LAST hidden layer of a stage (sigmoid, model.py:50 / :146) fused with the stage's output heads (model.py:52:

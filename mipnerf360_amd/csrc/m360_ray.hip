@@ -286,6 +286,45 @@ __device__ __forceinline__ void head_dots(const T *__restrict__ act_ray, int ld,
     }
 }
 
+// bf16 activation rows: 8 lanes per row, 8 rows per wave.  A lane walks every 8th 16-byte chunk of its row (consecutive
+// lanes read consecutive chunks: whole 128-byte lines per row), the head rows come from LDS (the 8 rows of a wave read the
+// same addresses: broadcast), and the 8 lanes of a row are reduced by three DPP steps - no ds_bpermute chains.  The
+// 64-lanes-per-row form above spends most of its time in its six-step shuffle reductions once a row is only 2 KB
+// (profiles/r02: 3.3 TB/s on the bf16 path).
+template <int H>
+__device__ __forceinline__ void head_dots_rows8_bf16(const __bf16 *__restrict__ act_ray, int ld, const float *hw /*LDS [H][k_pad]*/,
+                                                     const float *__restrict__ hb, int k_pad, int N, float *raw /*LDS [N][H]*/) {
+    const int wave = threadIdx.x >> 6, l = lane_id(), nwaves = blockDim.x >> 6;
+    const int lane8 = l & 7, rsub = l >> 3;
+    const int kc = k_pad / 8;
+    float bias[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) bias[h] = hb[h];
+    for (int n0 = wave * 8; n0 < N; n0 += nwaves * 8) {
+        const int n = n0 + rsub;
+        const bool valid = n < N;
+        const __bf16 *x = act_ray + (long)(valid ? n : N - 1) * ld;
+        float a[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) a[h] = 0.0f;
+        for (int c = lane8; c < kc; c += 8) {
+            float v[8];
+            ActChunk<__bf16>::load(x, c, v);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float4 w0 = *reinterpret_cast<const float4 *>(hw + h * k_pad + c * 8);
+                const float4 w1 = *reinterpret_cast<const float4 *>(hw + h * k_pad + c * 8 + 4);
+                a[h] += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w + v[4] * w1.x + v[5] * w1.y + v[6] * w1.z + v[7] * w1.w;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            a[h] = row8_sum(a[h]);
+            if (lane8 == 0 && valid) raw[n * H + h] = a[h] + bias[h];
+        }
+    }
+}
+
 // Head products of activation rows in EXACTLY the order of the fused epilogue (m360_linear_persist.hip.h, HEADS > 0): per
 // 128-column wave tile ("slot") the 8 lanes of a row each chain 4 column blocks x 4 columns of fused multiply-adds, the
 // lanes are reduced by the same DPP butterfly, the slots are added 0, 1, ...  Used for the rows the fused layer did not
@@ -349,7 +388,7 @@ __device__ __forceinline__ void ray_heads(const T *__restrict__ act, int ld, con
             if (slots > 0 && slots <= 8 && k_pad == 128 * slots) head_dots_fused_order<H>(reinterpret_cast<const float *>(act) + (s0 + nf) * ld, ld, hw, head_b, k_pad, slots, N - nf, raw + nf * H);
             else head_dots<H, T>(act + (s0 + nf) * ld, ld, hw, head_b, k_pad, N - nf, raw + nf * H);
         } else {
-            head_dots<H, T>(act + (s0 + nf) * ld, ld, hw, head_b, k_pad, N - nf, raw + nf * H);
+            head_dots_rows8_bf16<H>(reinterpret_cast<const __bf16 *>(act) + (s0 + nf) * ld, ld, hw, head_b, k_pad, N - nf, raw + nf * H);
         }
     }
     __syncthreads();

@@ -3,6 +3,10 @@
 // style callers get finished frames without a trip through NumPy / scipy / matplotlib.
 // All kernels are per-pixel and HBM-bound; the image statistics (min / max / variances) are a
 // deterministic two-level fp64 reduction (fixed partition), like the contraction norm.
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "m360_common.hip.h"
 #include "m360_turbo_lut.h"
 
@@ -131,24 +135,33 @@ __global__ void sinebow_kernel(const float *__restrict__ hval, long n, float *__
 }
 
 // intern/pose.py:148-212 with the default curve -log(x + eps) and ignore_frac = 0
+// `curved`: depth / near / far already went through the caller's own curve_fn (a host callable in the reference's API);
+// `value_out`: write the normalised value [h,w] (the argument of the colormap) instead of colours - for a caller-supplied
+// colormap callable; `planes` (device float[2], may be NULL): the automatic planes of m360_visualize_depth_ex's
+// ignore_frac > 0 selection, else ws->stats.
 __global__ void visualize_depth_kernel(const float *__restrict__ depth, const float *__restrict__ acc, int h, int w,
                                        float near, float far, int near_auto, int far_auto, float modulus,
-                                       const VisScratch *__restrict__ ws, float *__restrict__ vis) {
+                                       const VisScratch *__restrict__ ws, float *__restrict__ vis, int curved = 0,
+                                       float *__restrict__ value_out = nullptr, const float *__restrict__ planes = nullptr) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)h * w) return;
     const float eps = 1.1920928955078125e-07f;
     // automatic planes: lowest / highest value of the depth-sorted map (NaNs sort last => far becomes NaN)
-    if (near_auto) near = (float)ws->stats[7] - eps;
-    if (far_auto) far = (ws->stats[9] > 0.0 ? NAN : (float)ws->stats[8]) + eps;
+    if (near_auto) near = planes ? planes[0] : (float)ws->stats[7] - eps;
+    if (far_auto) far = planes ? planes[1] : (ws->stats[9] > 0.0 ? NAN : (float)ws->stats[8]) + eps;
     const float d = depth[idx];
     float a = acc ? acc[idx] : 1.0f;
     if (isnan(d)) a = 0.0f;
-    const float cd = -logf(d + eps), cn = -logf(near + eps), cf = -logf(far + eps);
+    const float cd = curved ? d : -logf(d + eps), cn = curved ? near : -logf(near + eps), cf = curved ? far : -logf(far + eps);
     float rgb[3];
     if (modulus > 0.0f) {
         float m = fmodf(cd, modulus);  // np.mod: result takes the sign of the divisor
         if (m != 0.0f && ((m < 0.0f) != (modulus < 0.0f))) m += modulus;
         const float value = m / modulus;
+        if (value_out) {
+            value_out[idx] = value;
+            return;
+        }
         rgb[0] = sinebow_f(3.0f / 6.0f - value);
         rgb[1] = sinebow_f(5.0f / 6.0f - value);
         rgb[2] = sinebow_f(7.0f / 6.0f - value);
@@ -156,6 +169,10 @@ __global__ void visualize_depth_kernel(const float *__restrict__ depth, const fl
         float value = (cd - fminf(cn, cf)) / fabsf(cf - cn);
         value = nan_to_numf_(fminf(fmaxf(value, 0.0f), 1.0f));
         if (isnan(cd) || isnan(cn) || isnan(cf)) value = 0.0f;  // np.clip propagates NaN, nan_to_num zeroes it
+        if (value_out) {
+            value_out[idx] = value;
+            return;
+        }
         int li = (int)(value * 256.0f);                          // matplotlib ListedColormap lookup (N = 256)
         li = li > 255 ? 255 : (li < 0 ? 0 : li);
         rgb[0] = kTurboLut[li][0];
@@ -165,6 +182,70 @@ __global__ void visualize_depth_kernel(const float *__restrict__ depth, const fl
 #pragma unroll
     for (int c = 0; c < 3; ++c) vis[3 * idx + c] = rgb[c] * a + (1.0f - a);
 }
+
+// ---- ignore_frac > 0 (intern/pose.py:177-192): the planes are the first / last depth of the depth-sorted map whose
+// running sum of acc lies inside [f, 1 - f] of the total.  The running sum is numpy's float32 cumsum: SEQUENTIAL fp32
+// adds - reproduced by one lane walking the sorted array (a few ms for a megapixel frame; exactness over speed in a
+// visualisation helper).
+__global__ void vis_prepare_sort_kernel(const float *__restrict__ depth, const float *__restrict__ acc, long n,
+                                        float *__restrict__ keys, float *__restrict__ vals) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float d = depth[idx];
+    keys[idx] = d;
+    vals[idx] = isnan(d) ? 0.0f : (acc ? acc[idx] : 1.0f);
+}
+
+__global__ void vis_cumsum_seq_kernel(const float *__restrict__ vals, long n, float *__restrict__ cum, int *__restrict__ range) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float run = 0.0f;
+    for (long i = 0; i < n; ++i) {
+        run += vals[i];
+        cum[i] = run;
+    }
+    range[0] = 0x7fffffff;  // first / last index inside the kept band
+    range[1] = -1;
+}
+
+__global__ void vis_band_kernel(const float *__restrict__ cum, long n, float frac, int *__restrict__ range) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float total = cum[n - 1];
+    const float lo = total * frac, hi = total * (float)(1.0 - (double)frac);  // np.float32 * python float (NEP 50)
+    const float c = cum[idx];
+    if (c >= lo && c <= hi) {
+        atomicMin(&range[0], (int)idx);
+        atomicMax(&range[1], (int)idx);
+    }
+}
+
+__global__ void vis_planes_kernel(const float *__restrict__ keys_sorted, const int *__restrict__ range, float *__restrict__ planes) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float eps = 1.1920928955078125e-07f;
+    // an empty band raises IndexError in the reference; here both planes become NaN (an all-white frame)
+    planes[0] = range[1] >= 0 ? keys_sorted[range[0]] - eps : NAN;
+    planes[1] = range[1] >= 0 ? keys_sorted[range[1]] + eps : NAN;
+}
+
+__global__ void vis_planes_from_stats_kernel(const VisScratch *__restrict__ ws, float *__restrict__ planes) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float eps = 1.1920928955078125e-07f;
+    planes[0] = (float)ws->stats[7] - eps;
+    planes[1] = (ws->stats[9] > 0.0 ? NAN : (float)ws->stats[8]) + eps;
+}
+
+// intern/pose.py:207-210: vis = colormap(value)[..., :3] * acc + (1 - acc), acc zeroed where depth is NaN
+__global__ void vis_composite_kernel(const float *__restrict__ colors, const float *__restrict__ acc,
+                                     const float *__restrict__ depth, long n, float *__restrict__ vis) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float a = acc ? acc[idx] : 1.0f;
+    if (depth && isnan(depth[idx])) a = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vis[3 * idx + c] = colors[3 * idx + c] * a + (1.0f - a);
+}
+
+static inline size_t vis_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace m360
 
@@ -224,6 +305,73 @@ int m360_visualize_depth(const float *depth, const float *acc, int h, int w, flo
     const long n = (long)h * w;
     hipLaunchKernelGGL(visualize_depth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), depth, acc, h, w, near, far, near_auto, far_auto, modulus, ws, vis);
     return check_launch("visualize_depth");
+}
+
+static size_t sort_temp_bytes(long n) {
+    size_t bytes = 0;
+    float *nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, (size_t)n, 0, 32, (hipStream_t)0);
+    return bytes;
+}
+
+size_t m360_visualize_depth_ex_workspace_bytes(int h, int w) {
+    if (h < 1 || w < 1) return 0;
+    const long n = (long)h * w;
+    // VisScratch | planes[2] + range[2] | keys, vals, keys sorted, vals sorted, cum | rocPRIM temporary storage
+    return vis_up(sizeof(VisScratch)) + 256 + 5 * vis_up((size_t)n * sizeof(float)) + vis_up(sort_temp_bytes(n));
+}
+
+int m360_visualize_depth_ex(const float *depth, const float *acc, int h, int w, float near, float far, int near_auto,
+                            int far_auto, float ignore_frac, int curved, float modulus, float *vis, float *value_out,
+                            float *planes_out, void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    if (!depth || h < 1 || w < 1 || !(ignore_frac >= 0.0f) || ignore_frac > 0.5f)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_visualize_depth_ex: bad argument (ignore_frac=%g)", (double)ignore_frac);
+    if (curved && (near_auto || far_auto) && (vis || value_out))
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_visualize_depth_ex: a pre-curved depth map needs explicit (curved) near / far");
+    const size_t need = m360_visualize_depth_ex_workspace_bytes(h, w);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_visualize_depth_ex: workspace %zu < %zu (or not 256-byte aligned)", workspace_bytes, need);
+    const long n = (long)h * w;
+    hipStream_t st = S_(stream);
+    char *base = static_cast<char *>(workspace);
+    VisScratch *ws = reinterpret_cast<VisScratch *>(base);
+    float *planes = reinterpret_cast<float *>(base + vis_up(sizeof(VisScratch)));
+    int *range = reinterpret_cast<int *>(planes + 2);
+    const size_t arr = vis_up((size_t)n * sizeof(float));
+    float *keys = reinterpret_cast<float *>(base + vis_up(sizeof(VisScratch)) + 256);
+    float *vals = reinterpret_cast<float *>(reinterpret_cast<char *>(keys) + arr);
+    float *keys_s = reinterpret_cast<float *>(reinterpret_cast<char *>(keys) + 2 * arr);
+    float *vals_s = reinterpret_cast<float *>(reinterpret_cast<char *>(keys) + 3 * arr);
+    float *cum = reinterpret_cast<float *>(reinterpret_cast<char *>(keys) + 4 * arr);
+    void *temp = reinterpret_cast<char *>(keys) + 5 * arr;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (near_auto || far_auto) {
+        if (ignore_frac > 0.0f) {
+            hipLaunchKernelGGL(vis_prepare_sort_kernel, dim3(blocks), dim3(256), 0, st, depth, acc, n, keys, vals);
+            size_t temp_bytes = sort_temp_bytes(n);
+            if (rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_s, vals, vals_s, (size_t)n, 0, 32, st) != hipSuccess)
+                return fail(M360_ERR_LAUNCH, "m360_visualize_depth_ex: radix sort failed");
+            hipLaunchKernelGGL(vis_cumsum_seq_kernel, dim3(1), dim3(64), 0, st, vals_s, n, cum, range);
+            hipLaunchKernelGGL(vis_band_kernel, dim3(blocks), dim3(256), 0, st, cum, n, ignore_frac, range);
+            hipLaunchKernelGGL(vis_planes_kernel, dim3(1), dim3(64), 0, st, keys_s, range, planes);
+        } else {
+            const int rc = launch_stats(depth, h, w, ws, st);
+            if (rc != M360_OK) return rc;
+            hipLaunchKernelGGL(vis_planes_from_stats_kernel, dim3(1), dim3(64), 0, st, ws, planes);
+        }
+        if (planes_out && hipMemcpyAsync(planes_out, planes, 2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(M360_ERR_LAUNCH, "m360_visualize_depth_ex: copy of the planes failed");
+    }
+    if (vis || value_out)
+        hipLaunchKernelGGL(visualize_depth_kernel, dim3(blocks), dim3(256), 0, st, depth, acc, h, w, near, far, near_auto, far_auto, modulus, ws, vis, curved, value_out, (near_auto || far_auto) ? planes : nullptr);
+    return check_launch("visualize_depth_ex");
+}
+
+int m360_visualize_composite(const float *colors, const float *acc, const float *depth, int h, int w, float *vis,
+                             m360_stream_t stream) {
+    if (!colors || !vis || h < 1 || w < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_visualize_composite: bad argument");
+    const long n = (long)h * w;
+    hipLaunchKernelGGL(vis_composite_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S_(stream), colors, acc, depth, n, vis);
+    return check_launch("visualize_composite");
 }
 
 }  // extern "C"

@@ -41,16 +41,42 @@ def visualize_normals(depth, acc, scaling=None):
 
 
 def visualize_depth(depth, acc=None, near=None, far=None, ignore_frac=0, curve_fn=None, modulus=0, colormap=None):
-    """intern/pose.py:148-212 with the reference's default curve (-log(x + eps)) and colormaps (matplotlib
-    'turbo' for modulus == 0, sinebow otherwise).  Custom curve_fn / colormap callables and ignore_frac > 0
-    (a global weighted quantile: a device-wide sort) are not implemented on the device path."""
-    if curve_fn is not None or colormap is not None:
-        raise NotImplementedError("visualize_depth: only the reference's default curve_fn / colormap are implemented")
-    if ignore_frac:
-        raise NotImplementedError("visualize_depth: ignore_frac > 0 is not implemented (callers in the reference never pass it)")
+    """intern/pose.py:148-212.  Defaults (curve -log(x + eps), matplotlib 'turbo' / sinebow) run entirely on the device,
+    `ignore_frac > 0` included (device sort + numpy's sequential float32 cumsum).  `curve_fn` / `colormap` are Python
+    callables in the reference's API, i.e. the caller's own host code: they are applied where the reference applies them
+    (to the depth map and the two planes / to the normalised value map) on host copies, everything around them - plane
+    selection, normalisation, modulus, blending with acc - stays on the device."""
+    np_in = isinstance(depth, np.ndarray)
+    d = _to_dev(depth) if np_in else depth
+    a = None if acc is None else (_to_dev(acc) if isinstance(acc, np.ndarray) else acc)
     near = None if near is None else float(np.asarray(near).reshape(-1)[0])
     far = None if far is None else float(np.asarray(far).reshape(-1)[0])
-    return _wrap(ops.visualize_depth, depth, acc, near=near, far=far, modulus=float(modulus))
+
+    def back(t):
+        return t.cpu().numpy() if np_in else t
+
+    if curve_fn is None and colormap is None:
+        if not ignore_frac:
+            return back(ops.visualize_depth(d, a, near=near, far=far, modulus=float(modulus)))
+        return back(ops.visualize_depth_ex(d, a, near, far, ignore_frac=float(ignore_frac), modulus=float(modulus)))
+    curved = curve_fn is not None
+    if curved:
+        if not near or not far:  # the automatic planes are chosen on the UNcurved map, then curved like it
+            planes = ops.visualize_depth_ex(d, a, near, far, ignore_frac=float(ignore_frac), want="planes").cpu().numpy()
+            near, far = near or float(planes[0]), far or float(planes[1])
+        host = d.cpu().numpy()
+        dc = _to_dev(np.asarray(curve_fn(host), dtype=np.float32))
+        near, far = float(curve_fn(np.float32(near))), float(curve_fn(np.float32(far)))
+        if near == 0.0 or far == 0.0:
+            raise ValueError("visualize_depth: a curve_fn that maps a plane to exactly 0 cannot be told from 'automatic plane'")
+    else:
+        dc = d
+    if colormap is None:
+        return back(ops.visualize_depth_ex(dc, a, near, far, ignore_frac=float(ignore_frac), curved=curved, modulus=float(modulus)))
+    value = ops.visualize_depth_ex(dc, a, near, far, ignore_frac=float(ignore_frac), curved=curved, modulus=float(modulus),
+                                   want="value").cpu().numpy()
+    colors = np.asarray(colormap(value), dtype=np.float32)[:, :, :3]
+    return back(ops.visualize_composite(_to_dev(colors), a, d))
 
 
 # everything else of the reference's intern/pose.py (host-side helpers outside the hot path) falls through to the

@@ -515,6 +515,33 @@ def visualize_depth(depth, acc=None, near=None, far=None, modulus: float = 0.0) 
     return out
 
 
+def visualize_depth_ex(depth, acc=None, near=None, far=None, ignore_frac: float = 0.0, curved: bool = False,
+                       modulus: float = 0.0, want: str = "vis"):
+    """m360_visualize_depth_ex.  want = "vis" -> colours [h,w,3]; "value" -> the colormap argument [h,w];
+    "planes" -> the automatic (near, far) planes as a device float[2] (nothing rendered)."""
+    depth = dev(depth, "depth")
+    acc = None if acc is None else dev(acc, "acc")
+    h, w = depth.shape
+    d = depth.device
+    ws = torch.empty(_lib.lib().m360_visualize_depth_ex_workspace_bytes(h, w), dtype=torch.uint8, device=d)
+    vis = torch.empty(h, w, 3, device=d) if want == "vis" else None
+    value = torch.empty(h, w, device=d) if want == "value" else None
+    planes = torch.empty(2, device=d) if want == "planes" else None
+    _call("m360_visualize_depth_ex", depth, acc, h, w, float(near or 0.0), float(far or 0.0), int(not near), int(not far),
+          float(ignore_frac), int(bool(curved)), float(modulus), vis, value, planes, ws, ws.numel(), STREAM)
+    return vis if want == "vis" else (value if want == "value" else planes)
+
+
+def visualize_composite(colors, acc=None, depth=None) -> torch.Tensor:
+    colors = dev(colors, "colors")
+    h, w = colors.shape[:2]
+    acc = None if acc is None else dev(acc, "acc")
+    depth = None if depth is None else dev(depth, "depth")
+    out = torch.empty(h, w, 3, device=colors.device)
+    _call("m360_visualize_composite", colors, acc, depth, h, w, out, STREAM)
+    return out
+
+
 # ----------------------------------------------------------------------------- losses (row f3)
 def _loss_ws(B: int, device, N: int = 0) -> torch.Tensor:
     return torch.empty(_lib.lib().m360_loss_workspace_bytes(int(B), int(N)), dtype=torch.uint8, device=device)

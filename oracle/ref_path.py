@@ -499,22 +499,30 @@ def turbo_lut() -> np.ndarray:
     return np.asarray(matplotlib.colormaps["turbo"](np.arange(256))[:, :3])
 
 
-def visualize_depth(depth: np.ndarray, acc=None, near=None, far=None, modulus: float = 0.0) -> np.ndarray:
-    """intern/pose.py:148-212 with the default curve, ignore_frac = 0 and the default colormaps."""
+def visualize_depth(depth: np.ndarray, acc=None, near=None, far=None, modulus: float = 0.0, ignore_frac: float = 0.0,
+                    curve_fn=None, colormap=None) -> np.ndarray:
+    """intern/pose.py:148-212 (default curve -log(x + eps), default colormaps turbo / sinebow unless given)."""
     eps = np.finfo(np.float32).eps
     acc = np.ones_like(depth) if acc is None else acc
     acc = np.where(np.isnan(depth), np.zeros_like(acc), acc)
-    flat = np.sort(depth.reshape(-1))  # NaNs last, like the reference's argsort
-    near = near or flat[0] - eps
-    far = far or flat[-1] + eps
-    curve = lambda v: -np.log(v + eps)  # noqa: E731
+    order = np.argsort(depth.reshape(-1), kind="stable")  # NaNs last, like the reference's argsort
+    flat = depth.reshape(-1)[order]
+    cum = np.cumsum(acc.reshape(-1)[order])
+    keep = flat[(cum >= cum[-1] * ignore_frac) & (cum <= cum[-1] * (1 - ignore_frac))]
+    near = near or keep[0] - eps
+    far = far or keep[-1] + eps
+    curve = curve_fn or (lambda v: -np.log(v + eps))  # noqa: E731
     d, cn, cf = curve(depth), curve(near), curve(far)
     if modulus > 0:
-        rgb = sinebow(np.mod(d, modulus) / modulus)
+        value = np.mod(d, modulus) / modulus
+        rgb = colormap(value)[:, :, :3] if colormap else sinebow(value)
     else:
         value = np.nan_to_num(np.clip((d - np.minimum(cn, cf)) / np.abs(cf - cn), 0, 1))
-        idx = np.minimum((value * 256).astype(int), 255)
-        rgb = turbo_lut()[idx]
+        if colormap:
+            rgb = colormap(value)[:, :, :3]
+        else:
+            idx = np.minimum((value * 256).astype(int), 255)
+            rgb = turbo_lut()[idx]
     return rgb * acc[:, :, None] + (1 - acc)[:, :, None]
 
 

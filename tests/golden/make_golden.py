@@ -542,10 +542,46 @@ def g16():
          unstable_mean=N(m2), unstable_cov=N(c2))
 
 
+# build-owned callables for G17 (the tests pass the same two to the mirrors)
+def g17_curve(x):
+    return 1.0 / (x + np.finfo(np.float32).eps)
+
+
+def g17_colormap(v):
+    return np.stack([v, 1.0 - v, v * v, np.ones_like(v)], -1)
+
+
+def g17():
+    """visualize_depth's remaining options (intern/pose.py:148-212): ignore_frac > 0 (weighted-quantile planes), a custom
+    curve_fn and a custom colormap callable."""
+    import matplotlib
+    import matplotlib.cm as cm
+    if not hasattr(cm, "get_cmap"):
+        cm.get_cmap = lambda name: matplotlib.colormaps[name]
+    from intern import pose as ref_pose
+    g = np.random.Generator(np.random.PCG64(1717))
+    h, w = 37, 41
+    yy, xx = np.meshgrid(np.linspace(-1, 1, h), np.linspace(-1, 1, w), indexing="ij")
+    depth = (3.0 + np.sin(3 * xx) * np.cos(2 * yy) + 0.3 * g.normal(size=(h, w))).astype(np.float32)
+    acc = np.clip(g.uniform(0.1, 1.2, size=(h, w)), 0, 1).astype(np.float32)
+    depth_nan = depth.copy()
+    depth_nan[5, 6] = np.nan
+    out = dict(depth=depth, acc=acc, depth_nan=depth_nan)
+    out["ignore"] = ref_pose.visualize_depth(depth, acc, ignore_frac=0.1)
+    out["ignore_nan"] = ref_pose.visualize_depth(depth_nan, acc, ignore_frac=0.05)
+    out["ignore_noacc_far"] = ref_pose.visualize_depth(depth, None, None, 5.0, ignore_frac=0.2)
+    out["curve"] = ref_pose.visualize_depth(depth, acc, 2.0, 6.0, curve_fn=g17_curve)
+    out["curve_auto"] = ref_pose.visualize_depth(depth, acc, curve_fn=g17_curve, ignore_frac=0.1)
+    out["colormap"] = ref_pose.visualize_depth(depth, acc, 2.0, 6.0, colormap=g17_colormap)
+    out["colormap_mod"] = ref_pose.visualize_depth(depth, acc, 2.0, 6.0, modulus=0.3, colormap=g17_colormap)
+    out["both"] = ref_pose.visualize_depth(depth, acc, curve_fn=g17_curve, colormap=g17_colormap, ignore_frac=0.05)
+    save("g17_visualize_depth_options", **{k: np.asarray(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14,
-                 g15=g15, g16=g16)
+                 g15=g15, g16=g16, g17=g17)
     for k in which:
         print(k)
         table[k]()

@@ -1236,3 +1236,41 @@ def test_g16_diag_lift_and_unstable_moments(golden, dev):
     close(c, g["unstable_cov"], atol=2e-3 * float(np.abs(g["unstable_cov"]).max()), rtol=0)
     with pytest.raises(RuntimeError):
         P.conical_frustum_to_gaussian(d, t[:, :-1].contiguous(), t[:, 1:].contiguous(), radii, diag=True)
+
+
+def _g17_curve(x):
+    return 1.0 / (x + np.finfo(np.float32).eps)
+
+
+def _g17_colormap(v):
+    return np.stack([v, 1.0 - v, v * v, np.ones_like(v)], -1)
+
+
+_G17_CASES = {
+    "ignore": dict(depth="depth", acc=True, kw=dict(ignore_frac=0.1)),
+    "ignore_nan": dict(depth="depth_nan", acc=True, kw=dict(ignore_frac=0.05)),
+    "ignore_noacc_far": dict(depth="depth", acc=False, kw=dict(near=None, far=5.0, ignore_frac=0.2)),
+    "curve": dict(depth="depth", acc=True, kw=dict(near=2.0, far=6.0, curve_fn=_g17_curve)),
+    "curve_auto": dict(depth="depth", acc=True, kw=dict(curve_fn=_g17_curve, ignore_frac=0.1)),
+    "colormap": dict(depth="depth", acc=True, kw=dict(near=2.0, far=6.0, colormap=_g17_colormap)),
+    "colormap_mod": dict(depth="depth", acc=True, kw=dict(near=2.0, far=6.0, modulus=0.3, colormap=_g17_colormap)),
+    "both": dict(depth="depth", acc=True, kw=dict(curve_fn=_g17_curve, colormap=_g17_colormap, ignore_frac=0.05)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(_G17_CASES))
+def test_g17_visualize_depth_options(golden, dev, case):
+    """Row f2: visualize_depth with ignore_frac > 0 (device sort + sequential float32 cumsum), a custom curve_fn and a custom
+    colormap callable (the caller's host code, applied where the reference applies it) - fixture G17; NumPy in -> NumPy out
+    and device tensors in -> device tensor out."""
+    from mipnerf360_amd.intern import pose as P
+    g = golden("g17_visualize_depth_options")
+    c = _G17_CASES[case]
+    acc = g["acc"] if c["acc"] else None
+    got = P.visualize_depth(g[c["depth"]], acc, **c["kw"])
+    assert isinstance(got, np.ndarray) and got.shape == g[case].shape
+    # the turbo lookup quantises: a value within 1e-6 of a bin edge may pick the neighbouring entry (<= 1 of 256 steps)
+    bad = np.abs(got - g[case]) > 2e-6
+    assert bad.mean() < 0.002 and np.abs(got - g[case]).max() < 0.03, (bad.mean(), np.abs(got - g[case]).max())
+    dev_out = P.visualize_depth(D(g[c["depth"]], dev), None if acc is None else D(acc, dev), **c["kw"])
+    assert isinstance(dev_out, torch.Tensor) and np.array_equal(H(dev_out), got)

@@ -335,3 +335,32 @@ def test_g16_diag_lift_and_unstable_moments(golden):
     m, c = O.gaussian_contract(*O.lift_to_xyz(d, tm, tv, rv))
     close(m, g["unstable_mean"], atol=1e-6, rtol=1e-5)
     close(c, g["unstable_cov"], atol=2e-3 * float(np.abs(g["unstable_cov"]).max()), rtol=0)   # t_var = E[t^2] - E[t]^2 cancels ~5 digits: fp32 noise is amplified
+
+
+def _g17_curve(x):
+    return 1.0 / (x + np.finfo(np.float32).eps)
+
+
+def _g17_colormap(v):
+    return np.stack([v, 1.0 - v, v * v, np.ones_like(v)], -1)
+
+
+_G17_CASES = {
+    "ignore": dict(depth="depth", acc=True, kw=dict(ignore_frac=0.1)),
+    "ignore_nan": dict(depth="depth_nan", acc=True, kw=dict(ignore_frac=0.05)),
+    "ignore_noacc_far": dict(depth="depth", acc=False, kw=dict(near=None, far=5.0, ignore_frac=0.2)),
+    "curve": dict(depth="depth", acc=True, kw=dict(near=2.0, far=6.0, curve_fn=_g17_curve)),
+    "curve_auto": dict(depth="depth", acc=True, kw=dict(curve_fn=_g17_curve, ignore_frac=0.1)),
+    "colormap": dict(depth="depth", acc=True, kw=dict(near=2.0, far=6.0, colormap=_g17_colormap)),
+    "colormap_mod": dict(depth="depth", acc=True, kw=dict(near=2.0, far=6.0, modulus=0.3, colormap=_g17_colormap)),
+    "both": dict(depth="depth", acc=True, kw=dict(curve_fn=_g17_curve, colormap=_g17_colormap, ignore_frac=0.05)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(_G17_CASES))
+def test_g17_visualize_depth_options(golden, case):
+    """Row f2: ignore_frac > 0, custom curve_fn, custom colormap of visualize_depth (intern/pose.py:148-212), fixture G17."""
+    g = golden("g17_visualize_depth_options")
+    c = _G17_CASES[case]
+    got = O.visualize_depth(g[c["depth"]], g["acc"] if c["acc"] else None, **c["kw"])
+    np.testing.assert_allclose(got, g[case], atol=2e-6, rtol=0)
