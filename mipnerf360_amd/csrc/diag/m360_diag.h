@@ -11,6 +11,9 @@ int m360_diag_linear(const float *x, long M, int ldx, const float *w_packed, con
 /* variant: 0 = ping-pong kernel with stamps, 1 = software-pipelined kernel with stamps, 2 / 3 = the same two without */
 int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
                           int k_pad, void *y, int ldy, int variant, int ldw /* row stride of w_packed, elements */, m360_stream_t stream);
+/* the half-tile / double-accumulator fp32 kernel (m360_linear_hd.hip.h) while it is evaluated against the product kernel */
+int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
+                        int act, float *y, int ldy, m360_stream_t stream);
 /* 16 x uint64 per workgroup, the first 256 workgroups (slot meaning: see the STAMP blocks of the two kernels) */
 int m360_diag_read_stamps(unsigned long long *out_host, int n);
 #ifdef __cplusplus

@@ -22,6 +22,7 @@
 #include "diag/m360_diag.h"
 #include "diag/m360_linear_bf16_sp.hip.h"
 #include "diag/m360_linear_bf16_rg.hip.h"
+#include "m360_linear_hd.hip.h"
 #endif
 
 namespace m360 {
@@ -547,6 +548,19 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
         default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);
     }
     return check_launch("diag_linear_bf16");
+}
+
+int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
+                        int act, float *y, int ldy, m360_stream_t stream) {
+    if (!x || !w_packed || !b_packed || !y || M < hd::BM || M % hd::BM || n_pad % hd::BN || k_pad % hd::BK || k_pad < 2 * hd::BK || n_pad > hd::kMaxBias || (act != M360_ACT_NONE && act != M360_ACT_RELU))
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_hd: full 128 x 256 tiles, k_pad >= 64, act none / ReLU only");
+    const int cus = cu_count();
+    const long nt = (M / hd::BM) * (n_pad / hd::BN);
+    dim3 grid((unsigned)(nt < cus ? nt : cus)), block(hd::kThreads);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (act == M360_ACT_RELU) hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt);
+    else hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt);
+    return check_launch("diag_linear_hd");
 }
 
 int m360_diag_read_stamps(unsigned long long *out_host, int n) {

@@ -1,0 +1,245 @@
+// Third-generation fp32-MFMA linear kernel: HALF tile (128 x 256), DOUBLE accumulator set, epilogue in MFMA shadows.
+//
+// The persistent kernel (m360_linear_persist.hip.h) spends its whole accumulator file (256 registers per lane) on ONE
+// 256 x 256 tile, so a tile's epilogue (LDS transposition + bias + activation + stores: 10.3 k cycles) cannot overlap
+// matrix work: 1.9 % of a 1024-deep tile, 7 % of a 256-deep one (proposal layers: 0.81-0.84 of the roofline) and 24 % of a
+// 64-deep one (first layers: 0.64).  Here a workgroup's tile is 128 x 256 (wave tile 64 x 128 = 2 x 4 MFMA blocks = 128
+// accumulators) and the file holds TWO sets: while tile t accumulates into one set, the 8 blocks of tile t-1 in the
+// other set are staged through a wave-private LDS area, activated and stored - one block per K-group during the first
+// two K-steps of tile t, every instruction in its own MFMA gap (the schedule is GENERATED: tools/gen_hd_kstep.py ->
+// m360_linear_hd_gen.inc).  Everything else follows the persistent kernel: one wave per SIMD, persistent workgroups
+// with XCD-aware tile order, K-step 32 staged by LDS-DMA (buffer descriptors, scalar K offset, source-side XOR swizzle,
+// double-buffered), operand fragments by ds_read_b128 feeding four MFMAs each, hand-counted waits tied to the fragment
+// registers, one barrier per K-step placed before the last K-group.  The k order of every output element is the
+// persistent kernel's, so results are bit-identical to the other two fp32 kernels.
+// Bias + {none, ReLU} epilogues only (the sigmoid / fused-heads / ReLU-mask layers stay with the persistent kernel).
+#pragma once
+#include "m360_common.hip.h"
+
+namespace m360 {
+namespace hd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+constexpr int BM = 128, BN = 256, BK = 32;
+constexpr int kThreads = 256;
+constexpr int kAFloats = BM * BK;                    // 16 KiB
+constexpr int kBFloats = BN * BK;                    // 32 KiB
+constexpr int kStageFloats = kAFloats + kBFloats;    // one K-step: 48 KiB
+constexpr int kStgFloats = 32 * 36;                  // per-wave epilogue staging (32 x 32 block, rows padded to 36)
+constexpr int kMaxBias = 4096;                       // widest layer (bias is served from LDS)
+
+template <int ACT>
+__global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
+    const float *__restrict__ X, long M, int ldx, const float *__restrict__ W, const float *__restrict__ bias, int Np,
+    int Kp, float *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * kStageFloats + 4 * kStgFloats + kMaxBias];  // 130 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int G = gridDim.x;
+    const int ksteps = Kp / BK;  // >= 2
+
+    auto tile_coords = [&](int lin_id, long &m0, int &n0) __attribute__((always_inline)) {
+        const int full = (ntiles / 8) * 8;  // XCD-aware (speed only): ids sharing id % 8 cover a contiguous range of tiles
+        int lin = lin_id;
+        if (lin_id < full) lin = (lin_id % 8) * (full / 8) + lin_id / 8;
+        m0 = (long)(lin / tiles_n) * BM;
+        n0 = (lin % tiles_n) * BN;
+    };
+
+    // ---- LDS-DMA staging: wave w fills A rows [32w, 32w+32) (4 pieces) and B rows [64w, 64w+64) (8 pieces) of a K-step
+    unsigned a_voff[4], b_voff[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 32 * wave + 8 * q + (lane >> 3);
+        a_voff[q] = (unsigned)(r * ldx + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * 4u;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = 64 * wave + 8 * q + (lane >> 3);
+        b_voff[q] = (unsigned)(r * Kp + 4 * ((lane & 7) ^ ((r >> 1) & 7))) * 4u;
+    }
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+    auto set_load_tile = [&](long m0, int n0) __attribute__((always_inline)) {
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X + m0 * ldx), 0, 0x7fffffff, 0x00020000);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(W + (long)n0 * Kp), 0, 0x7fffffff, 0x00020000);
+    };
+    float *const dma_a = smem + wave * 32 * BK;             // + buf * kStageFloats + q * 8 * BK
+    float *const dma_b = smem + kAFloats + wave * 64 * BK;
+
+    // ---- operand reads: lane (l31, h), K-group g reads chunk (2g + h) of its rows = slot (2g + h) ^ f
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    const int fsw = (l31 >> 1) & 7;
+    unsigned a_addr[4], b_addr[4];  // byte addresses in buffer 0
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int slot = ((2 * g + h) ^ fsw) * 4;
+        a_addr[g] = lds0 + 4u * ((wm * 64 + l31) * BK + slot);
+        b_addr[g] = lds0 + 4u * (kAFloats + (wn * 128 + l31) * BK + slot);
+    }
+    // ---- epilogue staging (wave-private) and bias
+    const unsigned stg0 = lds0 + 4u * (2 * kStageFloats + wave * kStgFloats);
+    const unsigned stw = stg0 + 4u * (4 * h * 36 + l31);                       // + ((r&3) + 8(r>>2)) * 144 per register r
+    const int rrow = lane >> 3, rcol = 4 * (lane & 7);
+    const unsigned str = stg0 + 4u * (rrow * 36 + rcol);                       // + p * 8 * 144
+    float *const bias_lds = smem + 2 * kStageFloats + 4 * kStgFloats;
+    for (int c = tid; c < Np; c += kThreads) bias_lds[c] = bias[c];
+    const unsigned bias_addr = lds0 + 4u * (2 * kStageFloats + 4 * kStgFloats + wn * 128 + rcol);  // + 4 * n0 + 128 * j
+
+    f32x16 acc[2][2][4];
+    f32x4 fa0[2], fb0[4], fa1[2], fb1[4];
+    f32x4 ev[4];   // one staged 32 x 32 block as this lane reads it back: 4 row groups x 4 consecutive columns
+    f32x4 bq[4];   // bias of this lane's 4 columns in each of the 4 column blocks, tile being stored
+    float *Ye = Y; // this lane's first output element of the tile being stored
+    int ldy_e = ldy;
+    const f32x16 kZero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+#define HD_DS128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#define HD_SB() __builtin_amdgcn_sched_barrier(0)
+#define HD_WAIT_FRAG(FA, FB) \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]), "+v"(FB[2]), "+v"(FB[3])::"memory")
+#define HD_BARRIER(VM, FA, FB)                                                                                        \
+    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier"                                                    \
+                 : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]), "+v"(FB[2]), "+v"(FB[3])::"memory")
+#define HD_DMA_A(Q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(dma_a + nbuf * kStageFloats + (Q) * 8 * BK), 16, a_voff[Q], 4 * next_k0, 0, 0)
+#define HD_DMA_B(Q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(dma_b + nbuf * kStageFloats + (Q) * 8 * BK), 16, b_voff[Q], 4 * next_k0, 0, 0)
+// epilogue pieces: register r of block (I, J) of accumulator set P -> staging row (r&3) + 8(r>>2) + 4h, column l31
+#define HD_EW(P, I, J, R) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(stw), "a"(acc[P][I][J][R]), "n"((((R) & 3) + 8 * ((R) >> 2)) * 144) : "memory")
+#define HD_ER(PP) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ev[PP]) : "v"(str), "n"((PP) * 8 * 144) : "memory")
+#define HD_EWAIT() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3])::"memory")
+#define HD_ES(I, J, PP)                                                                                     \
+    do {                                                                                                    \
+        f32x4 v_ = ev[PP] + bq[J];                                                                          \
+        if (ACT == M360_ACT_RELU) {                                                                         \
+            v_[0] = fmaxf(v_[0], 0.0f); v_[1] = fmaxf(v_[1], 0.0f); v_[2] = fmaxf(v_[2], 0.0f); v_[3] = fmaxf(v_[3], 0.0f); \
+        }                                                                                                   \
+        *reinterpret_cast<f32x4 *>(Ye + (long)((I) * 32 + (PP) * 8) * ldy_e + (J) * 32) = v_;               \
+    } while (0)
+#include "m360_linear_hd_gen.inc"
+
+    int lin_id = blockIdx.x;
+    if (lin_id >= ntiles) return;
+    long m0;
+    int n0;
+    tile_coords(lin_id, m0, n0);
+    set_load_tile(m0, n0);
+    {
+        const int nbuf = 0, next_k0 = 0;
+        HD_DMA_A(0); HD_DMA_A(1); HD_DMA_A(2); HD_DMA_A(3);
+        HD_DMA_B(0); HD_DMA_B(1); HD_DMA_B(2); HD_DMA_B(3); HD_DMA_B(4); HD_DMA_B(5); HD_DMA_B(6); HD_DMA_B(7);
+    }
+    int buf = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first K-step of the first tile has landed; bias_lds written
+    __syncthreads();
+    HD_SB();
+    HD_DS128(fa0[0], a_addr[0], 0); HD_DS128(fa0[1], a_addr[0], 4096);
+    HD_DS128(fb0[0], b_addr[0], 0); HD_DS128(fb0[1], b_addr[0], 4096); HD_DS128(fb0[2], b_addr[0], 8192); HD_DS128(fb0[3], b_addr[0], 12288);
+    HD_SB();
+
+    bool have_prev = false;
+    // one tile into accumulator set S while (have_prev) the previous tile's set P is stored
+#define HD_KSETUP(KT)                                                                                              \
+    int next_k0 = ((KT) + 1) * BK;                                                                                \
+    if ((KT) + 1 == ksteps) { /* stage K-step 0 of this workgroup's next tile (else, harmlessly, of this one) */   \
+        next_k0 = 0;                                                                                              \
+        if (lin_id + G < ntiles) {                                                                                \
+            long nm0;                                                                                             \
+            int nn0;                                                                                              \
+            tile_coords(lin_id + G, nm0, nn0);                                                                    \
+            set_load_tile(nm0, nn0);                                                                              \
+        }                                                                                                         \
+    }                                                                                                             \
+    const int nbuf = buf ^ 1;                                                                                     \
+    const unsigned boff = buf ? 4u * kStageFloats : 0u, noff = buf ? 0u : 4u * kStageFloats;                      \
+    const unsigned a1 = a_addr[1] + boff, b1 = b_addr[1] + boff, a2 = a_addr[2] + boff, b2 = b_addr[2] + boff;    \
+    const unsigned a3 = a_addr[3] + boff, b3 = b_addr[3] + boff, a0n = a_addr[0] + noff, b0n = b_addr[0] + noff;  \
+    HD_SB()
+#define HD_TILE(S, P)                                                                                             \
+    do {                                                                                                          \
+        {                                                                                                         \
+            HD_KSETUP(0);                                                                                         \
+            HD_KSTEP_F(S, P);                                                                                     \
+            buf ^= 1;                                                                                             \
+        }                                                                                                         \
+        {                                                                                                         \
+            HD_KSETUP(1);                                                                                         \
+            HD_KSTEP_S(S, P);                                                                                     \
+            buf ^= 1;                                                                                             \
+        }                                                                                                         \
+        for (int kt = 2; kt < ksteps; ++kt) {                                                                     \
+            HD_KSETUP(kt);                                                                                        \
+            HD_KSTEP_P(S, P);                                                                                     \
+            buf ^= 1;                                                                                             \
+        }                                                                                                         \
+    } while (0)
+    // what the epilogue of the tile just finished needs: its bias slices and this lane's first output element
+#define HD_SET_EPILOGUE()                                                                                         \
+    do {                                                                                                          \
+        const unsigned ba_ = bias_addr + 4u * n0;                                                                 \
+        HD_DS128(bq[0], ba_, 0); HD_DS128(bq[1], ba_, 128); HD_DS128(bq[2], ba_, 256); HD_DS128(bq[3], ba_, 384); \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3])::"memory");      \
+        asm volatile("" : "+s"(ldy_e));                                                                           \
+        Ye = Y + (m0 + wm * 64 + rrow) * ldy_e + n0 + wn * 128 + rcol;                                            \
+        have_prev = true;                                                                                         \
+    } while (0)
+    // the last tile of this workgroup: its set is stored without matrix work to hide behind
+#define HD_EBLOCK(P, I, J)                                                                                        \
+    do {                                                                                                          \
+        HD_EW(P, I, J, 0); HD_EW(P, I, J, 1); HD_EW(P, I, J, 2); HD_EW(P, I, J, 3); HD_EW(P, I, J, 4); HD_EW(P, I, J, 5);   \
+        HD_EW(P, I, J, 6); HD_EW(P, I, J, 7); HD_EW(P, I, J, 8); HD_EW(P, I, J, 9); HD_EW(P, I, J, 10); HD_EW(P, I, J, 11); \
+        HD_EW(P, I, J, 12); HD_EW(P, I, J, 13); HD_EW(P, I, J, 14); HD_EW(P, I, J, 15);                            \
+        HD_ER(0); HD_ER(1); HD_ER(2); HD_ER(3);                                                                   \
+        HD_EWAIT();                                                                                               \
+        HD_ES(I, J, 0); HD_ES(I, J, 1); HD_ES(I, J, 2); HD_ES(I, J, 3);                                           \
+        HD_SB();                                                                                                  \
+    } while (0)
+#define HD_FINAL_EPILOGUE(P)                                                                                      \
+    do {                                                                                                          \
+        HD_EBLOCK(P, 0, 0); HD_EBLOCK(P, 0, 1); HD_EBLOCK(P, 0, 2); HD_EBLOCK(P, 0, 3);                           \
+        HD_EBLOCK(P, 1, 0); HD_EBLOCK(P, 1, 1); HD_EBLOCK(P, 1, 2); HD_EBLOCK(P, 1, 3);                           \
+    } while (0)
+
+    for (;;) {
+        tile_coords(lin_id, m0, n0);
+        HD_TILE(0, 1);
+        HD_SET_EPILOGUE();
+        lin_id += G;
+        if (lin_id >= ntiles) {
+            HD_FINAL_EPILOGUE(0);
+            break;
+        }
+        tile_coords(lin_id, m0, n0);
+        HD_TILE(1, 0);
+        HD_SET_EPILOGUE();
+        lin_id += G;
+        if (lin_id >= ntiles) {
+            HD_FINAL_EPILOGUE(1);
+            break;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of this wave may land after the workgroup is gone
+#undef HD_DS128
+#undef HD_SB
+#undef HD_WAIT_FRAG
+#undef HD_BARRIER
+#undef HD_DMA_A
+#undef HD_DMA_B
+#undef HD_EW
+#undef HD_ER
+#undef HD_EWAIT
+#undef HD_ES
+#undef HD_TILE
+#undef HD_KSETUP
+#undef HD_SET_EPILOGUE
+#undef HD_FINAL_EPILOGUE
+#undef HD_EBLOCK
+}
+
+}  // namespace hd
+}  // namespace m360
