@@ -46,8 +46,8 @@ CONFIGS = {
 }
 
 # source files that define the dominant kernel: profiles/traffic.json is only trusted while they are unchanged
-TRAFFIC_SOURCES = ("mipnerf360_amd/csrc/m360_linear_persist.hip.h", "mipnerf360_amd/csrc/m360_linear.hip",
-                   "mipnerf360_amd/csrc/m360_common.hip.h")
+TRAFFIC_SOURCES = ("mipnerf360_amd/csrc/m360_linear_hd.hip.h", "mipnerf360_amd/csrc/m360_linear_hd_gen.inc",
+                   "mipnerf360_amd/csrc/m360_linear.hip", "mipnerf360_amd/csrc/m360_common.hip.h")
 
 
 def kernel_source_sha():
@@ -189,7 +189,7 @@ def main():
             else:
                 traffic_note = "profiles/traffic.json was measured on different kernel sources (stale): not reported"
         peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        kname = "linear_bf16_pp_kernel" if bf16 else "linear_f32_mfma_persist_kernel"
+        kname = "linear_bf16_pp_kernel" if bf16 else "linear_f32_hd_kernel"
         roofline = {"bound": "mfma", "kernel": f"{kname} (1024x1024 layer, M={S})", "achieved": round(achieved, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": traffic, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),

@@ -13,6 +13,7 @@
 //   The K index inside each group of 8 is permuted (lane half h takes k = 8g+4h+s for MFMA
 //   step s) so one ds_read_b128 feeds four consecutive MFMAs for A and for B alike.
 //   Workgroup ids are remapped so the 4 N-tiles of one M-tile run on the same XCD (shared L2).
+#include <stdlib.h>
 #include "m360_common.hip.h"
 #include "m360_linear_persist.hip.h"
 #include "m360_linear_bf16.hip.h"
@@ -22,8 +23,8 @@
 #include "diag/m360_diag.h"
 #include "diag/m360_linear_bf16_sp.hip.h"
 #include "diag/m360_linear_bf16_rg.hip.h"
-#include "m360_linear_hd.hip.h"
 #endif
+#include "m360_linear_hd.hip.h"
 
 namespace m360 {
 
@@ -271,6 +272,35 @@ int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_
     return check_launch("pack_linear");
 }
 
+// Half-tile kernel (m360_linear_hd.hip.h) on M rows (a multiple of 128) of a 256-multiple width, bias + {none, ReLU}.
+static int launch_linear_hd(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
+                            int act, float *y, int ldy, hipStream_t st) {
+    const int cus = cu_count();
+    if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear: no HIP device");
+    const long nt = (M / hd::BM) * (n_pad / hd::BN);
+    if (nt > 0x7fffffffL) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: grid too large");
+    dim3 grid((unsigned)(nt < cus ? nt : cus)), block(hd::kThreads);
+    if (act == M360_ACT_RELU) hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt);
+    else hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt);
+    return check_launch("linear_hd");
+}
+
+// Which of the two persistent kernels takes the full tiles of a layer (both give the same bits).  The half-tile kernel hides
+// the epilogue of a tile behind the next tile's matrix work, balances the last round of tiles better and leaves at most 127
+// ragged rows: it takes every layer it can express (bias + {none, ReLU}, width a multiple of 256, contraction >= 64).
+// Whole forward at BASELINE configs[1]: 54.42 ms against 54.61 ms with the 256 x 256 kernel (profiles/r02/bench_kernel_ab.txt).
+#ifdef M360_DIAG
+// diagnostics build only (A/B of the two kernels): 0 = the rule, 1 = 256 x 256, 2 = half tiles; M360_DIAG_FORCE_KERNEL presets it
+static int g_diag_force_kernel = [] { const char *e = getenv("M360_DIAG_FORCE_KERNEL"); return e ? atoi(e) : 0; }();
+#endif
+static bool prefer_half_tiles(long M, int n_pad, int k_pad, int act) {
+    if ((act != M360_ACT_NONE && act != M360_ACT_RELU) || n_pad % hd::BN != 0 || n_pad > hd::kMaxBias || k_pad < 2 * hd::BK || M < hd::BM) return false;
+#ifdef M360_DIAG
+    if (g_diag_force_kernel == 1) return false;
+#endif
+    return true;
+}
+
 static int launch_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad,
                          int k_pad, int act, float *y, int ldy, const float *aux, m360_stream_t stream) {
     if (!x || !w_packed || (!b_packed && act != M360_ACT_RELU_MASK) || !y || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: null pointer or negative M");
@@ -285,12 +315,17 @@ static int launch_linear(const float *x, long M, int ldx, const float *w_packed,
     if (nwg > 0x7fffffffL) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: grid too large");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID && act != M360_ACT_RELU_MASK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: unknown activation %d", act);
-    // Persistent LDS-DMA kernel on the full 256-row tiles when the width is a multiple of 256; ragged rows
-    // (and narrow layers) go to the workgroup-per-tile kernel.  Both produce bit-identical results.
-    const long M_full = (n_pad % persist::BN == 0) ? (M / persist::BM) * persist::BM : 0;
-    if (M_full > 0) {
-        const int cus = cu_count();
-        if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear: no HIP device");
+    // Full tiles go to one of the two persistent LDS-DMA kernels when the width is a multiple of 256; ragged rows (and
+    // narrow layers) go to the workgroup-per-tile kernel.  All three produce bit-identical results.
+    const int cus = cu_count();
+    if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear: no HIP device");
+    long M_full = 0;
+    if (prefer_half_tiles(M, n_pad, k_pad, act)) {
+        M_full = (M / hd::BM) * hd::BM;
+        const int rc = launch_linear_hd(x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, st);
+        if (rc != M360_OK) return rc;
+    } else if (n_pad % persist::BN == 0 && M >= persist::BM) {
+        M_full = (M / persist::BM) * persist::BM;
         const long nt = (M_full / persist::BM) * (n_pad / persist::BN);
         const int ntiles = (int)nt;
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(persist::kThreads);
@@ -551,16 +586,34 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
 }
 
 int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
-                        int act, float *y, int ldy, m360_stream_t stream) {
+                        int act, float *y, int ldy, int ablate, m360_stream_t stream) {
     if (!x || !w_packed || !b_packed || !y || M < hd::BM || M % hd::BM || n_pad % hd::BN || k_pad % hd::BK || k_pad < 2 * hd::BK || n_pad > hd::kMaxBias || (act != M360_ACT_NONE && act != M360_ACT_RELU))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_hd: full 128 x 256 tiles, k_pad >= 64, act none / ReLU only");
     const int cus = cu_count();
     const long nt = (M / hd::BM) * (n_pad / hd::BN);
     dim3 grid((unsigned)(nt < cus ? nt : cus)), block(hd::kThreads);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (act == M360_ACT_RELU) hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt);
-    else hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt);
-    return check_launch("diag_linear_hd");
+#define M360_HD_ABL(A) hipLaunchKernelGGL((hd::linear_f32_hd_kernel<M360_ACT_RELU, A>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt)
+    if (ablate) {  // timing-only ablations of the ReLU kernel: 1 no barrier, 2 no LDS-DMA, 4 no operand reads (sums allowed)
+        switch (ablate) {
+            case 1: M360_HD_ABL(1); break;
+            case 2: M360_HD_ABL(2); break;
+            case 3: M360_HD_ABL(3); break;
+            case 4: M360_HD_ABL(4); break;
+            case 6: M360_HD_ABL(6); break;
+            case 7: M360_HD_ABL(7); break;
+            default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_hd: ablate=%d", ablate);
+        }
+        return check_launch("diag_linear_hd");
+    }
+#undef M360_HD_ABL
+    return launch_linear_hd(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, st);
+}
+
+int m360_diag_force_linear_kernel(int which) {
+    if (which < 0 || which > 2) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_force_linear_kernel: 0 rule, 1 full tiles, 2 half tiles");
+    g_diag_force_kernel = which;
+    return M360_OK;
 }
 
 int m360_diag_read_stamps(unsigned long long *out_host, int n) {

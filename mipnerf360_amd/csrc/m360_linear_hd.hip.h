@@ -31,7 +31,8 @@ constexpr int kStageFloats = kAFloats + kBFloats;    // one K-step: 48 KiB
 constexpr int kStgFloats = 32 * 36;                  // per-wave epilogue staging (32 x 32 block, rows padded to 36)
 constexpr int kMaxBias = 4096;                       // widest layer (bias is served from LDS)
 
-template <int ACT>
+// ABL (diagnostic builds only; results are wrong unless 0): 1 = no workgroup barrier, 2 = no LDS-DMA, 4 = no operand reads
+template <int ACT, int ABL = 0>
 __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     const float *__restrict__ X, long M, int ldx, const float *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, float *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
@@ -100,15 +101,25 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     int ldy_e = ldy;
     const f32x16 kZero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-#define HD_DS128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr))
+#define HD_DS128(dst, addr, imm)                                                            \
+    do {                                                                                    \
+        if (!(ABL & 4)) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr)); \
+        else asm volatile("" : "=v"(dst) : "v"(addr));                                      \
+    } while (0)
 #define HD_SB() __builtin_amdgcn_sched_barrier(0)
 #define HD_WAIT_FRAG(FA, FB) \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]), "+v"(FB[2]), "+v"(FB[3])::"memory")
 #define HD_BARRIER(VM, FA, FB)                                                                                        \
-    asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier"                                                    \
-                 : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]), "+v"(FB[2]), "+v"(FB[3])::"memory")
-#define HD_DMA_A(Q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(dma_a + nbuf * kStageFloats + (Q) * 8 * BK), 16, a_voff[Q], 4 * next_k0, 0, 0)
-#define HD_DMA_B(Q) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(dma_b + nbuf * kStageFloats + (Q) * 8 * BK), 16, b_voff[Q], 4 * next_k0, 0, 0)
+    do {                                                                                                              \
+        if (!(ABL & 1))                                                                                               \
+            asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier"                                            \
+                         : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]), "+v"(FB[2]), "+v"(FB[3])::"memory");   \
+        else                                                                                                          \
+            asm volatile("s_waitcnt vmcnt(" #VM ") lgkmcnt(0)"                                                        \
+                         : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]), "+v"(FB[2]), "+v"(FB[3])::"memory");   \
+    } while (0)
+#define HD_DMA_A(Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(dma_a + nbuf * kStageFloats + (Q) * 8 * BK), 16, a_voff[Q], 4 * next_k0, 0, 0)
+#define HD_DMA_B(Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(dma_b + nbuf * kStageFloats + (Q) * 8 * BK), 16, b_voff[Q], 4 * next_k0, 0, 0)
 // epilogue pieces: register r of block (I, J) of accumulator set P -> staging row (r&3) + 8(r>>2) + 4h, column l31
 #define HD_EW(P, I, J, R) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(stw), "a"(acc[P][I][J][R]), "n"((((R) & 3) + 8 * ((R) >> 2)) * 144) : "memory")
 #define HD_ER(PP) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ev[PP]) : "v"(str), "n"((PP) * 8 * 144) : "memory")

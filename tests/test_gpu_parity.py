@@ -210,12 +210,16 @@ def test_linear_mfma_against_fp64(dev):
 @pytest.mark.parametrize("M,n,k,act", [(256 * 37 + 5, 1024, 64, 1), (256 * 530, 256, 64, 0), (256 * 9, 256, 256, 1),
                                         (256 * 64, 1024, 1024, 1), (256, 768, 32, 1), (256 * 3, 512, 96, 0),
                                         (256 * 21 + 255, 768, 64, 1), (256 * 300 + 1, 256, 32, 0),
-                                        (256 * 11 + 3, 256, 256, 2), (256 * 40, 1024, 1024, 2)])   # sigmoid layers
+                                        (256 * 11 + 3, 256, 256, 2), (256 * 40, 1024, 1024, 2),   # sigmoid layers
+                                        (128 * 601, 1024, 96, 1), (128 * 3, 256, 64, 0), (128 * 515 + 77, 512, 160, 1),
+                                        (128 * 257, 256, 1024, 1), (128, 4096, 64, 1), (128 * 19, 4352, 64, 1)])
 def test_linear_kernel_variants_bit_identical(dev, M, n, k, act):
-    """The persistent LDS-DMA kernel (many tiles per workgroup: exercises the tile hand-over, the LDS-staged
-    epilogue and the ragged-row split) must reproduce the workgroup-per-tile kernel bit for bit, every element.
-    The library picks the kernel per call from the shape alone (no global switch): blocks of fewer than 256 rows
-    always take the workgroup-per-tile kernel, so the same rows are recomputed in 255-row blocks and compared."""
+    """The three fp32 kernels behind m360_linear must agree bit for bit, every element.  The library picks the kernel per
+    call from the shape alone (no global switch): full tiles of a 256-multiple width go to the half-tile kernel (bias +
+    none / ReLU, contraction >= 64, width <= 4096: 128-row tiles, two accumulator sets, the epilogue of a tile inside the
+    next tile's K loop) or to the 256 x 256 persistent kernel (sigmoid, contraction 32, wider layers), ragged rows to the
+    workgroup-per-tile kernel.  Blocks of fewer than 128 rows always take the last one, so the same rows are recomputed in
+    127-row blocks (and in 255-row blocks: one half tile + 127 ragged rows) and compared."""
     from mipnerf360_amd import ops
     g = torch.Generator(device=dev).manual_seed(M + n + k)
     x = torch.rand(M, k, device=dev, generator=g) * 2 - 1
@@ -227,14 +231,15 @@ def test_linear_kernel_variants_bit_identical(dev, M, n, k, act):
     y_full = ops.linear(xp, wp, bp, act)
     for _ in range(3):  # repeated launches: a race would not reproduce identically
         assert torch.equal(ops.linear(xp, wp, bp, act), y_full)
-    # row blocks spread over the batch (first / middle / last tiles of the persistent walk), each < 256 rows
-    starts = sorted({0, 256, (M // 512) * 256, max(((M // 256) - 1) * 256, 0), max(M - 255, 0)})
+    # row blocks spread over the batch (first / middle / last tiles of the persistent walk)
+    starts = sorted({0, 128, 256, (M // 512) * 256, max(((M // 256) - 1) * 256, 0), max(((M // 128) - 1) * 128, 0), max(M - 255, 0), max(M - 127, 0)})
     for a in starts:
-        rows = min(255, M - a)
-        if rows <= 0:
-            continue
-        y_blk = ops.linear(xp[a:a + rows], wp, bp, act)
-        assert torch.equal(y_blk, y_full[a:a + rows]), f"rows {a}..{a + rows} differ between the two kernels"
+        for blk in (127, 255):
+            rows = min(blk, M - a)
+            if rows <= 0:
+                continue
+            y_blk = ops.linear(xp[a:a + rows], wp, bp, act)
+            assert torch.equal(y_blk, y_full[a:a + rows]), f"rows {a}..{a + rows} differ between the kernels"
 
 
 def test_linear_rejects_bad_arguments(dev):

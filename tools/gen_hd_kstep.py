@@ -3,8 +3,10 @@
 kernel (m360_linear_hd.hip.h) with every non-matrix instruction assigned to ONE MFMA gap.
 
 A K-step = 4 K-groups x 32 MFMAs (v_mfma_f32_32x32x2_f32, 64 cycles each) on a 64 x 128 wave tile (TM = 2, TN = 4).
-Fillers per K-step: 24 ds_read_b128 of the next group's fragments, 12 LDS-DMA pieces of the next K-step (all in group 0,
-so that everything issued later is younger than them and a counted vmcnt can leave the epilogue's stores in flight), one
+Fillers per K-step: 24 ds_read_b128 of the next group's fragments, 12 LDS-DMA pieces of the next K-step (one every
+P_STRIDE gaps - back to back the four waves of a CU would keep the texture addresser 100 % busy and the issue stalls show up
+as MFMA bubbles; in the epilogue K-steps all of them inside group 0, so that everything issued later is younger than
+them and a counted vmcnt can leave the epilogue's stores in flight), one
 barrier between groups 2 and 3 - and, in the first two K-steps of a tile, the EPILOGUE OF THE PREVIOUS TILE: its 8 blocks
 of 32 x 32 accumulators (the other accumulator set) go through a wave-private LDS staging area, one block per K-group
 (16 ds_write_b32 + 4 ds_read_b128 + 4 x [bias, activation, 16-byte store]).
@@ -19,6 +21,10 @@ straight-line MFMA stream per K-step, so the 256 accumulators never meet a contr
 import os
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mipnerf360_amd", "csrc", "m360_linear_hd_gen.inc")
+
+
+P_STRIDE = 4   # MFMA gaps between two LDS-DMA pieces in the K-steps without epilogue (12 pieces: groups 0-1)
+FS_STRIDE = 2  # ... in the two epilogue K-steps (all 12 inside group 0, before the first epilogue stores)
 
 
 def group(lines, g, first, epi_block, dma):
@@ -37,9 +43,11 @@ def group(lines, g, first, epi_block, dma):
                 else:
                     lines.append(f"    acc[S][{i}][{j}] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa{cur}[{i}][{s}], fb{cur}[{j}][{s}], acc[S][{i}][{j}], 0, 0, 0);")
                 fill = []
-                if dma and m < 12:                      # 4 A pieces, then 8 B pieces of the next K-step
-                    fill.append(f"HD_DMA_A({m})" if m < 4 else f"HD_DMA_B({m - 4})")
-                if m in (12, 13, 14, 15, 16, 17) if dma else m in (1, 3, 5, 7, 9, 11):
+                gm = 32 * g + m                          # gap index inside the K-step
+                if dma and gm % dma == 0 and gm // dma < 12:   # 4 A pieces, then 8 B pieces of the next K-step
+                    q = gm // dma
+                    fill.append(f"HD_DMA_A({q})" if q < 4 else f"HD_DMA_B({q - 4})")
+                if m in (1, 3, 5, 7, 9, 11):
                     fill.append(reads.pop(0))
                 for f in fill:
                     lines.append(f"    {f};")
@@ -76,12 +84,21 @@ def kstep(name, first, epi):
             else:
                 lines.append(f"    HD_BARRIER(0, fa{cur}, fb{cur});")
             lines.append("    HD_SB();")
-        group(lines, g, first, blocks[g], dma=(g == 0))
+        stride = FS_STRIDE if epi else P_STRIDE
+        assert 11 * stride < (32 if epi else 64)  # epilogue K-steps: every piece older than the first store; else: landed by group 3
+        group(lines, g, first, blocks[g], dma=stride)
     lines.append("} while (0)")
     return " \\\n".join(lines) + "\n"
 
 
 def main():
+    global P_STRIDE, FS_STRIDE
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--p-stride", type=int, default=P_STRIDE)
+    ap.add_argument("--fs-stride", type=int, default=FS_STRIDE)
+    a = ap.parse_args()
+    P_STRIDE, FS_STRIDE = a.p_stride, a.fs_stride
     out = ["// GENERATED by tools/gen_hd_kstep.py - do not edit.  K-step bodies of m360_linear_hd.hip.h.\n"]
     out.append(kstep("F", True, 1))
     out.append(kstep("S", False, 2))

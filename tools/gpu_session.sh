@@ -17,6 +17,7 @@ for s in $steps; do
     sp16)    for v in 3 2; do timeout 600 python tools/linear_bench.py --dtype bf16 --variant $v --clock --json $out/linear_bf16_variants.jsonl > $out/linear_bf16_v$v.log 2>&1; tail -4 $out/linear_bf16_v$v.log; done
              timeout 300 python tools/linear_bench.py --dtype bf16 --variant 2 --m 65536 --n 256 --k 256 > $out/linear_bf16_v2_small.log 2>&1; tail -2 $out/linear_bf16_v2_small.log
              timeout 300 python tools/linear_bench.py --dtype bf16 --variant 2 --m 77056 --n 768 --k 192 > $out/linear_bf16_v2_odd.log 2>&1; tail -2 $out/linear_bf16_v2_odd.log ;;
+    hd)      timeout 900 python tools/hd_check.py --ablate --out $out/hd_check.jsonl > $out/hd_check.log 2>&1; tail -25 $out/hd_check.log | cut -c1-400 ;;
     ablate)  for v in 4 5 6 7; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/linear_bf16_ablate.jsonl > $out/linear_bf16_abl$v.log 2>&1; tail -1 $out/linear_bf16_abl$v.log; done ;;
     ldpad)   for pad in 0 32 64 128; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant 2 --ld-pad $pad --rounds 5 --json $out/linear_bf16_ldpad.jsonl > $out/linear_bf16_pad$pad.log 2>&1; tail -1 $out/linear_bf16_pad$pad.log; done ;;
     rg16)    timeout 600 python tools/linear_bench.py --dtype bf16 --variant 9 --clock --json $out/linear_bf16_rg.jsonl > $out/linear_bf16_v9.log 2>&1; tail -4 $out/linear_bf16_v9.log

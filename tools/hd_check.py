@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the half-tile / double-accumulator fp32 kernel (libm360_diag.so: m360_diag_linear_hd) against the product
-m360_linear on the layer shapes of the path: bit-identity of every element and median launch time."""
+"""A/B of the two persistent fp32 kernels behind m360_linear - the 256 x 256 tile kernel and the half-tile / double-accumulator
+kernel (m360_linear_hd.hip.h) - through the diagnostics library's kernel switch: bit-identity of every element, median launch
+time over a sweep of layer shapes, and (--ablate) the timing-only ablations of the half-tile kernel."""
+import argparse
 import ctypes
 import json
 import os
@@ -13,13 +15,38 @@ import torch  # noqa: E402
 from mipnerf360_amd import _lib, ops  # noqa: E402
 
 
+def timed(fn, reps=5, inner=10):
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / inner)
+    return float(np.median(ts))
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--ablate", action="store_true")
+    ap.add_argument("--diag-lib", default="libm360_diag.so")
+    ap.add_argument("--quick", action="store_true", help="three shapes only")
+    args = ap.parse_args()
     dev = torch.device("cuda:0")
-    diag = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libm360_diag.so"))
-    vp = ctypes.c_void_p
-    diag.m360_diag_linear_hd.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]
-    shapes = [(4096 * 128, 1024, 1024, 1), (4096 * 128, 1024, 64, 1), (4096 * 128, 256, 256, 1), (4096 * 128, 256, 64, 1),
-              (128 * 37, 768, 96, 0), (128 * 3, 256, 64, 1), (128 * 513, 512, 160, 1)]
+    diag = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), args.diag_lib))
+    vp, ci, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+    diag.m360_diag_linear_hd.argtypes = [vp, cl, ci, vp, vp, ci, ci, ci, vp, ci, ci, vp]
+    diag.m360_linear.argtypes = [vp, cl, ci, vp, vp, ci, ci, ci, vp, ci, vp]
+    diag.m360_diag_force_linear_kernel.argtypes = [ci]
+    big = 4096 * 128
+    shapes = [(big, n, k, 1) for n in (256, 1024) for k in (64, 96, 128, 256, 384, 512, 1024)]
+    shapes += [(128 * 37, 768, 96, 0), (128 * 3 + 5, 256, 64, 1), (128 * 513 + 77, 512, 160, 1), (256 * 96, 1024, 1024, 1),
+               (256 * 64, 1024, 1024, 1), (256 * 100 + 128, 1024, 1024, 0), (8192 * 256, 1024, 1024, 1)]
+    if args.quick:
+        shapes = [(big, 1024, 1024, 1), (big, 256, 256, 1), (big, 1024, 96, 1)]
     out = []
     for M, n, k, act in shapes:
         g = torch.Generator(device=dev).manual_seed(M + n + k)
@@ -27,43 +54,45 @@ def main():
         w = (torch.rand(n, k, device=dev, generator=g) * 2 - 1) * (6.0 / k) ** 0.5
         b = torch.rand(n, device=dev, generator=g) - 0.5
         wp, bp = ops.pack_linear(w, b, n, k)
-        y_ref = ops.linear(x, wp, bp, act)
-        y = torch.full((M, n), float("nan"), device=dev)
+        ys = {}
 
-        def run_hd():
-            rc = diag.m360_diag_linear_hd(x.data_ptr(), M, k, wp.data_ptr(), bp.data_ptr(), n, k, act, y.data_ptr(), n,
-                                          torch.cuda.current_stream().cuda_stream)
+        def run(which, y):
+            assert diag.m360_diag_force_linear_kernel(which) == 0
+            rc = diag.m360_linear(x.data_ptr(), M, k, wp.data_ptr(), bp.data_ptr(), n, k, act, y.data_ptr(), n,
+                                  torch.cuda.current_stream().cuda_stream)
             assert rc == 0, rc
 
-        run_hd()
-        torch.cuda.synchronize()
-        same = bool(torch.equal(y, y_ref))
-        nbad = int((y != y_ref).sum()) if not same else 0
-        for _ in range(4):
-            y.fill_(float("nan"))
-            run_hd()
-            torch.cuda.synchronize()
-            same = same and bool(torch.equal(y, y_ref))
         times = {}
-        for name, fn in (("product", lambda: ops.linear(x, wp, bp, act, out=y)), ("hd", run_hd)):
-            ts = []
-            for _ in range(5):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(10):
-                    fn()
-                e1.record()
-                torch.cuda.synchronize()
-                ts.append(e0.elapsed_time(e1) / 10)
-            times[name] = float(np.median(ts))
+        for name, which in (("full", 1), ("half", 2)):
+            y = torch.full((M, n), float("nan"), device=dev)
+            run(which, y)
+            torch.cuda.synchronize()
+            ys[name] = y.clone()
+            times[name] = timed(lambda: run(which, y))
+            assert torch.equal(y, ys[name])
+        y_rule = ops.linear(x, wp, bp, act)   # the product library with its shape rule
+        t_rule = timed(lambda: ops.linear(x, wp, bp, act, out=y_rule))
+        same = bool(torch.equal(ys["full"], ys["half"])) and bool(torch.equal(ys["full"], y_rule))
         fl = 2.0 * M * n * k
-        rec = {"M": M, "N": n, "K": k, "act": act, "bit_identical": same, "mismatches": nbad,
-               "product_ms": round(times["product"], 4), "hd_ms": round(times["hd"], 4),
-               "product_tflops": round(fl / times["product"] / 1e9, 1), "hd_tflops": round(fl / times["hd"] / 1e9, 1)}
+        rec = {"M": M, "N": n, "K": k, "act": act, "bit_identical": same,
+               "full_ms": round(times["full"], 4), "half_ms": round(times["half"], 4), "rule_ms": round(t_rule, 4),
+               "full_tflops": round(fl / times["full"] / 1e9, 1), "half_tflops": round(fl / times["half"] / 1e9, 1)}
+        if args.ablate and M % 128 == 0 and act == 1 and (n, k) in ((1024, 1024), (256, 256), (1024, 64)):
+            y = torch.empty(M, n, device=dev)
+            for abl in (0, 1, 2, 3, 4, 6, 7):
+                def f():
+                    rc = diag.m360_diag_linear_hd(x.data_ptr(), M, k, wp.data_ptr(), bp.data_ptr(), n, k, act, y.data_ptr(), n, abl,
+                                                  torch.cuda.current_stream().cuda_stream)
+                    assert rc == 0, rc
+                f()
+                torch.cuda.synchronize()
+                rec[f"abl{abl}_ms"] = round(timed(f), 4)
         print(json.dumps(rec), flush=True)
         out.append(rec)
-    if len(sys.argv) > 1:
-        with open(sys.argv[1], "w") as f:
+        del x, y, ys, y_rule
+    diag.m360_diag_force_linear_kernel(0)
+    if args.out:
+        with open(args.out, "w") as f:
             for r in out:
                 f.write(json.dumps(r) + "\n")
 

@@ -36,11 +36,11 @@ def durations(d):
 
 
 def dominant_counters(d):
-    """mean counter value over the dominant launches (ReLU 1024x1024 layers on M=524288: persistent kernel, > 6 ms)."""
+    """mean counter value over the dominant launches (ReLU 1024x1024 layers on M=524288: half-tile kernel, > 6 ms)."""
     dur = durations(d)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(one(f"{d}/*/*_counter_collection.csv"))):
-        if "persist_kernel<1" in r["Kernel_Name"] and dur[r["Dispatch_Id"]] > 6e6:
+        if "linear_f32_hd_kernel<1" in r["Kernel_Name"] and dur[r["Dispatch_Id"]] > 6e6:
             agg[r["Counter_Name"]].append((float(r["Counter_Value"]), dur[r["Dispatch_Id"]]))
     return {k: (sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v), len(v)) for k, v in agg.items()}
 
@@ -92,12 +92,12 @@ def main():
     print(step_trace(f"{src}/stats", f"{dst}/last_step_kernel_trace.csv"))
     # the dominant launches alone (ReLU 1024x1024 layers on M = 524288): what bench.py's roofline.avg_launch_ms must agree with
     dur = [v for k, v in durations(f"{src}/stats").items()]
-    rows = [r for r in csv.DictReader(open(one(f"{src}/stats/*/*_kernel_trace.csv"))) if "persist_kernel<1" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(one(f"{src}/stats/*/*_kernel_trace.csv"))) if "linear_f32_hd_kernel<1" in r["Kernel_Name"]]
     big = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
     big = [d for d in big if d > 6e6]
     with open(f"{dst}/dominant_kernel_launches.csv", "w") as f:
         f.write("kernel,shape,launches,mean_ns,min_ns,max_ns,tflops_at_mean\n")
-        f.write(f"linear_f32_mfma_persist_kernel<ReLU>,M=524288 N=1024 K=1024,{len(big)},{sum(big) / len(big):.0f},{min(big)},{max(big)},"
+        f.write(f"linear_f32_hd_kernel<ReLU>,M=524288 N=1024 K=1024,{len(big)},{sum(big) / len(big):.0f},{min(big)},{max(big)},"
                 f"{2.0 * M_BENCH * N_BENCH * N_BENCH / (sum(big) / len(big)) / 1e3:.1f}\n")
     f, w, s = dominant_counters(f"{src}/pmc_fetch"), dominant_counters(f"{src}/pmc_write"), dominant_counters(f"{src}/pmc_sq")
     fetch_b = f["FETCH_SIZE"][0] * 1024 * 2  # KB -> B; x2: gfx950 tallies the 128-B requests of a wide coalesced stream at 64 B
