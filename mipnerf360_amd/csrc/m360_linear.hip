@@ -593,15 +593,17 @@ int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, 
     const long nt = (M / hd::BM) * (n_pad / hd::BN);
     dim3 grid((unsigned)(nt < cus ? nt : cus)), block(hd::kThreads);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define M360_HD_ABL(A) hipLaunchKernelGGL((hd::linear_f32_hd_kernel<M360_ACT_RELU, A>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt)
-    if (ablate) {  // timing-only ablations of the ReLU kernel: 1 no barrier, 2 no LDS-DMA, 4 no operand reads (sums allowed)
+#define M360_HD_ABL(A) hipLaunchKernelGGL((hd::linear_f32_hd_kernel<M360_ACT_RELU, A, true>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt)
+    if (ablate || act == M360_ACT_RELU) {  // stamped; timing-only ablations: bits as listed in m360_linear_hd.hip.h (the combinations instantiated here)
         switch (ablate) {
+            case 0: M360_HD_ABL(0); break;
             case 1: M360_HD_ABL(1); break;
             case 2: M360_HD_ABL(2); break;
-            case 3: M360_HD_ABL(3); break;
-            case 4: M360_HD_ABL(4); break;
-            case 6: M360_HD_ABL(6); break;
             case 7: M360_HD_ABL(7); break;
+            case 8: M360_HD_ABL(8); break;
+            case 24: M360_HD_ABL(24); break;
+            case 40: M360_HD_ABL(40); break;
+            case 56: M360_HD_ABL(56); break;
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_hd: ablate=%d", ablate);
         }
         return check_launch("diag_linear_hd");
@@ -613,6 +615,13 @@ int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, 
 int m360_diag_force_linear_kernel(int which) {
     if (which < 0 || which > 2) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_force_linear_kernel: 0 rule, 1 full tiles, 2 half tiles");
     g_diag_force_kernel = which;
+    return M360_OK;
+}
+
+int m360_diag_read_hd_stamps(unsigned long long *out_host, int n) {
+    if (!out_host || n < 0 || n > 2 * 256 * 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_read_hd_stamps: bad argument");
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(hd::g_hd_stamps), sizeof(unsigned long long) * n) != hipSuccess)
+        return fail(M360_ERR_LAUNCH, "m360_diag_read_hd_stamps: copy failed");
     return M360_OK;
 }
 

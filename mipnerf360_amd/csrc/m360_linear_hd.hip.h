@@ -31,8 +31,15 @@ constexpr int kStageFloats = kAFloats + kBFloats;    // one K-step: 48 KiB
 constexpr int kStgFloats = 32 * 36;                  // per-wave epilogue staging (32 x 32 block, rows padded to 36)
 constexpr int kMaxBias = 4096;                       // widest layer (bias is served from LDS)
 
-// ABL (diagnostic builds only; results are wrong unless 0): 1 = no workgroup barrier, 2 = no LDS-DMA, 4 = no operand reads
-template <int ACT, int ABL = 0>
+#ifdef M360_DIAG
+// diagnostics build, per workgroup: [0] shader-clock cycles (s_memtime) and [1] 100 MHz ticks (s_memrealtime) of the whole tile
+// loop, [2] K-steps executed (cycles per K-step against the 128 x 64 = 8192 the matrix pipe needs, and the clock held);
+// second half: cycles summed over the first / second / further K-steps of every tile
+__device__ unsigned long long g_hd_stamps[2 * 256 * 4];
+#endif
+// ABL (diagnostic builds only; results are wrong unless 0): 1 = no workgroup barrier, 2 = no LDS-DMA, 4 = no operand reads,
+// 8 = epilogue fillers unguarded, 16 = no epilogue stores, 32 = no epilogue arithmetic
+template <int ACT, int ABL = 0, bool STAMP = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     const float *__restrict__ X, long M, int ldx, const float *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, float *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
@@ -95,10 +102,16 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
 
     f32x16 acc[2][2][4];
     f32x4 fa0[2], fb0[4], fa1[2], fb1[4];
-    f32x4 ev[4];   // one staged 32 x 32 block as this lane reads it back: 4 row groups x 4 consecutive columns
-    f32x4 bq[4];   // bias of this lane's 4 columns in each of the 4 column blocks, tile being stored
-    float *Ye = Y; // this lane's first output element of the tile being stored
-    int ldy_e = ldy;
+    f32x4 ev[4] = {};  // one staged 32 x 32 block as this lane reads it back: 4 row groups x 4 consecutive columns
+    // A VALU instruction is never hidden behind this wave's own MFMAs on gfx950 (both go through the SIMD's vector issue port,
+    // which an MFMA holds for its 64 cycles): n of them in one MFMA gap cost 4 n + 8 cycles of matrix time, one per gap 12
+    // each (tools/mfma32_filler_cost.hip, profiles/r02/mfma32_filler_cost.jsonl).  So the epilogue keeps its arithmetic to
+    // the minimum (bias: 2 packed adds, ReLU: 4 max per 1 KiB) and issues a block's 24 instructions in ONE gap; everything
+    // else is LDS / scalar / VMEM work, which is hidden: ds_write_b32 straight from the accumulator registers, stores with a
+    // scalar row base + one lane-offset register + immediate column offset (no address arithmetic).
+    f32x4 bq[4];            // bias of this lane's 4 columns in each of the 4 column blocks, tile being stored
+    const float *Yt = Y;    // wave-uniform: first element of this wave's 64 x 128 corner of the tile being stored
+    const unsigned y_voff = (unsigned)(rrow * ldy + rcol) * 4u;  // this lane's 16 bytes inside an 8-row slab of that corner
     const f32x16 kZero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 #define HD_DS128(dst, addr, imm)                                                            \
@@ -124,13 +137,40 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
 #define HD_EW(P, I, J, R) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(stw), "a"(acc[P][I][J][R]), "n"((((R) & 3) + 8 * ((R) >> 2)) * 144) : "memory")
 #define HD_ER(PP) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ev[PP]) : "v"(str), "n"((PP) * 8 * 144) : "memory")
 #define HD_EWAIT() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3])::"memory")
-#define HD_ES(I, J, PP)                                                                                     \
-    do {                                                                                                    \
-        f32x4 v_ = ev[PP] + bq[J];                                                                          \
-        if (ACT == M360_ACT_RELU) {                                                                         \
-            v_[0] = fmaxf(v_[0], 0.0f); v_[1] = fmaxf(v_[1], 0.0f); v_[2] = fmaxf(v_[2], 0.0f); v_[3] = fmaxf(v_[3], 0.0f); \
-        }                                                                                                   \
-        *reinterpret_cast<f32x4 *>(Ye + (long)((I) * 32 + (PP) * 8) * ldy_e + (J) * 32) = v_;               \
+// bias + activation of the staged block (column block J) in registers: the block's whole vector arithmetic, one MFMA gap
+#define HD_EV(J, PA, PB)                                                                                     \
+    do {                                                                                                     \
+        if (!(ABL & 32)) {                                                                                   \
+            _Pragma("unroll") for (int pp_ = PA; pp_ < PB; ++pp_) {                                          \
+                ev[pp_] += bq[J];                                                                            \
+                if (ACT == M360_ACT_RELU) {                                                                  \
+                    ev[pp_][0] = fmaxf(ev[pp_][0], 0.0f); ev[pp_][1] = fmaxf(ev[pp_][1], 0.0f);              \
+                    ev[pp_][2] = fmaxf(ev[pp_][2], 0.0f); ev[pp_][3] = fmaxf(ev[pp_][3], 0.0f);              \
+                }                                                                                            \
+            }                                                                                                \
+            /* pins the instructions here (machine sinking would move them next to the stores) */           \
+            asm volatile("" : "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3]));                          \
+        }                                                                                                    \
+    } while (0)
+#define HD_ES(I, J, PP)                                                                                      \
+    do {                                                                                                     \
+        if (!(ABL & 16))                                                                                     \
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(y_voff), "v"(ev[PP]),            \
+                         "s"(Yt + (long)((I) * 32 + (PP) * 8) * ldy), "n"((J) * 128) : "memory");            \
+    } while (0)
+// an epilogue filler of the generated schedule: skipped (wave-uniform branch) while there is no previous tile
+#define HD_G(X)                                   \
+    do {                                          \
+        if (ABL & 8) { X; }                       \
+        else if (have_prev) { X; }                \
+    } while (0)
+// barrier of an epilogue K-step: the 12 stores younger than this K-step's LDS-DMA pieces may stay in flight.  The counted
+// wait is a bare instruction under the branch (no register ties: two tied variants would meet in a join and cost copies)
+#define HD_BARRIER_E(FA, FB)                                                         \
+    do {                                                                             \
+        if ((ABL & 8) || have_prev) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+        HD_BARRIER(63, FA, FB);                                                      \
     } while (0)
 #include "m360_linear_hd_gen.inc"
 
@@ -154,6 +194,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     HD_SB();
 
     bool have_prev = false;
+    unsigned long long mt0 = 0, rt0 = 0, mt1 = 0, rt1 = 0, nk = 0;
+    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, tF = 0, tS = 0, tP = 0;  // cycles in the first / second / further K-steps
+    (void)nk; (void)c0; (void)c1; (void)c2; (void)c3; (void)tF; (void)tS; (void)tP; (void)mt1; (void)rt1;
+    if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt0), "=s"(rt0)::"memory");
     // one tile into accumulator set S while (have_prev) the previous tile's set P is stored
 #define HD_KSETUP(KT)                                                                                              \
     int next_k0 = ((KT) + 1) * BK;                                                                                \
@@ -171,23 +215,32 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     const unsigned a1 = a_addr[1] + boff, b1 = b_addr[1] + boff, a2 = a_addr[2] + boff, b2 = b_addr[2] + boff;    \
     const unsigned a3 = a_addr[3] + boff, b3 = b_addr[3] + boff, a0n = a_addr[0] + noff, b0n = b_addr[0] + noff;  \
     HD_SB()
+#define HD_STAMP(var)                                                                             \
+    do {                                                                                          \
+        if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");    \
+    } while (0)
 #define HD_TILE(S, P)                                                                                             \
     do {                                                                                                          \
+        HD_STAMP(c0);                                                                                             \
         {                                                                                                         \
             HD_KSETUP(0);                                                                                         \
             HD_KSTEP_F(S, P);                                                                                     \
             buf ^= 1;                                                                                             \
         }                                                                                                         \
+        HD_STAMP(c1);                                                                                             \
         {                                                                                                         \
             HD_KSETUP(1);                                                                                         \
             HD_KSTEP_S(S, P);                                                                                     \
             buf ^= 1;                                                                                             \
         }                                                                                                         \
+        HD_STAMP(c2);                                                                                             \
         for (int kt = 2; kt < ksteps; ++kt) {                                                                     \
             HD_KSETUP(kt);                                                                                        \
             HD_KSTEP_P(S, P);                                                                                     \
             buf ^= 1;                                                                                             \
         }                                                                                                         \
+        HD_STAMP(c3);                                                                                             \
+        if (STAMP) { tF += c1 - c0; tS += c2 - c1; tP += c3 - c2; }                                               \
     } while (0)
     // what the epilogue of the tile just finished needs: its bias slices and this lane's first output element
 #define HD_SET_EPILOGUE()                                                                                         \
@@ -195,8 +248,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
         const unsigned ba_ = bias_addr + 4u * n0;                                                                 \
         HD_DS128(bq[0], ba_, 0); HD_DS128(bq[1], ba_, 128); HD_DS128(bq[2], ba_, 256); HD_DS128(bq[3], ba_, 384); \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3])::"memory");      \
-        asm volatile("" : "+s"(ldy_e));                                                                           \
-        Ye = Y + (m0 + wm * 64 + rrow) * ldy_e + n0 + wn * 128 + rcol;                                            \
+        Yt = Y + (m0 + wm * 64) * ldy + n0 + wn * 128;                                                            \
         have_prev = true;                                                                                         \
     } while (0)
     // the last tile of this workgroup: its set is stored without matrix work to hide behind
@@ -207,6 +259,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
         HD_EW(P, I, J, 12); HD_EW(P, I, J, 13); HD_EW(P, I, J, 14); HD_EW(P, I, J, 15);                            \
         HD_ER(0); HD_ER(1); HD_ER(2); HD_ER(3);                                                                   \
         HD_EWAIT();                                                                                               \
+        HD_EV(J, 0, 4);                                                                                           \
         HD_ES(I, J, 0); HD_ES(I, J, 1); HD_ES(I, J, 2); HD_ES(I, J, 3);                                           \
         HD_SB();                                                                                                  \
     } while (0)
@@ -221,7 +274,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
         HD_TILE(0, 1);
         HD_SET_EPILOGUE();
         lin_id += G;
+        nk += ksteps;
         if (lin_id >= ntiles) {
+            if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt1), "=s"(rt1)::"memory");
             HD_FINAL_EPILOGUE(0);
             break;
         }
@@ -229,11 +284,23 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
         HD_TILE(1, 0);
         HD_SET_EPILOGUE();
         lin_id += G;
+        nk += ksteps;
         if (lin_id >= ntiles) {
+            if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt1), "=s"(rt1)::"memory");
             HD_FINAL_EPILOGUE(1);
             break;
         }
     }
+#ifdef M360_DIAG
+    if (STAMP && tid == 0 && blockIdx.x < 256) {
+        g_hd_stamps[blockIdx.x * 4 + 0] = mt1 - mt0;
+        g_hd_stamps[blockIdx.x * 4 + 1] = rt1 - rt0;
+        g_hd_stamps[blockIdx.x * 4 + 2] = nk;
+        g_hd_stamps[1024 + blockIdx.x * 4 + 0] = tF;
+        g_hd_stamps[1024 + blockIdx.x * 4 + 1] = tS;
+        g_hd_stamps[1024 + blockIdx.x * 4 + 2] = tP;
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of this wave may land after the workgroup is gone
 #undef HD_DS128
 #undef HD_SB
@@ -245,7 +312,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
 #undef HD_ER
 #undef HD_EWAIT
 #undef HD_ES
+#undef HD_EV
 #undef HD_TILE
+#undef HD_STAMP
+#undef HD_G
+#undef HD_BARRIER_E
+#undef HD_EB
 #undef HD_KSETUP
 #undef HD_SET_EPILOGUE
 #undef HD_FINAL_EPILOGUE

@@ -9,7 +9,7 @@ as MFMA bubbles; in the epilogue K-steps all of them inside group 0, so that eve
 them and a counted vmcnt can leave the epilogue's stores in flight), one
 barrier between groups 2 and 3 - and, in the first two K-steps of a tile, the EPILOGUE OF THE PREVIOUS TILE: its 8 blocks
 of 32 x 32 accumulators (the other accumulator set) go through a wave-private LDS staging area, one block per K-group
-(16 ds_write_b32 + 4 ds_read_b128 + 4 x [bias, activation, 16-byte store]).
+(16 ds_write_b32 + 4 ds_read_b128 + the 24 vector instructions of bias and activation in ONE gap + 4 16-byte stores).
 
 Macros emitted (S = accumulator set of the running tile, P = set of the previous tile):
   HD_KSTEP_F(S, P)  first K-step of a tile: the accumulators of S start from 0 through the C operand; epilogue blocks 0-3 of P
@@ -23,6 +23,7 @@ import os
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mipnerf360_amd", "csrc", "m360_linear_hd_gen.inc")
 
 
+EV_MODE = "four" # gaps the bias + activation instructions of a block are spread over
 P_STRIDE = 4   # MFMA gaps between two LDS-DMA pieces in the K-steps without epilogue (12 pieces: groups 0-1)
 FS_STRIDE = 2  # ... in the two epilogue K-steps (all 12 inside group 0, before the first epilogue stores)
 
@@ -63,7 +64,14 @@ def group(lines, g, first, epi_block, dma):
                     elif m in (24, 26, 28, 30):
                         g_ = f"HD_ES({e >> 2}, {e & 3}, {(m - 24) // 2})"
                     if g_:
-                        lines.append(f"    if (have_prev) {{ {g_}; }}")
+                        lines.append(f"    HD_G({g_});")
+                    # the block's 24 vector instructions; unguarded: no control-flow join on the staged registers (first tile: harmless)
+                    if EV_MODE == "one" and m == 23:
+                        lines.append(f"    HD_EV({e & 3}, 0, 4);")
+                    if EV_MODE == "two" and m in (23, 25):
+                        lines.append(f"    HD_EV({e & 3}, {m - 23}, {m - 21});")
+                    if EV_MODE == "four" and m in (23, 25, 27, 29):
+                        lines.append(f"    HD_EV({e & 3}, {(m - 23) // 2}, {(m - 23) // 2 + 1});")
                 lines.append("    HD_SB();")
                 m += 1
     assert not reads
@@ -80,7 +88,7 @@ def kstep(name, first, epi):
         else:
             # stores of the blocks of groups 0-2 (12) are younger than the 12 LDS-DMA pieces: they may stay in flight
             if epi:
-                lines.append(f"    if (have_prev) {{ HD_BARRIER(12, fa{cur}, fb{cur}); }} else {{ HD_BARRIER(0, fa{cur}, fb{cur}); }}")
+                lines.append(f"    HD_BARRIER_E(fa{cur}, fb{cur});")
             else:
                 lines.append(f"    HD_BARRIER(0, fa{cur}, fb{cur});")
             lines.append("    HD_SB();")
@@ -92,12 +100,14 @@ def kstep(name, first, epi):
 
 
 def main():
-    global P_STRIDE, FS_STRIDE
+    global P_STRIDE, FS_STRIDE, EV_MODE
     import argparse
     ap = argparse.ArgumentParser()
     ap.add_argument("--p-stride", type=int, default=P_STRIDE)
     ap.add_argument("--fs-stride", type=int, default=FS_STRIDE)
+    ap.add_argument("--ev-mode", default=EV_MODE, choices=["one", "two", "four"])
     a = ap.parse_args()
+    EV_MODE = a.ev_mode
     P_STRIDE, FS_STRIDE = a.p_stride, a.fs_stride
     out = ["// GENERATED by tools/gen_hd_kstep.py - do not edit.  K-step bodies of m360_linear_hd.hip.h.\n"]
     out.append(kstep("F", True, 1))

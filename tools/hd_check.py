@@ -41,6 +41,7 @@ def main():
     diag.m360_diag_linear_hd.argtypes = [vp, cl, ci, vp, vp, ci, ci, ci, vp, ci, ci, vp]
     diag.m360_linear.argtypes = [vp, cl, ci, vp, vp, ci, ci, ci, vp, ci, vp]
     diag.m360_diag_force_linear_kernel.argtypes = [ci]
+    diag.m360_diag_read_hd_stamps.argtypes = [vp, ci]
     big = 4096 * 128
     shapes = [(big, n, k, 1) for n in (256, 1024) for k in (64, 96, 128, 256, 384, 512, 1024)]
     shapes += [(128 * 37, 768, 96, 0), (128 * 3 + 5, 256, 64, 1), (128 * 513 + 77, 512, 160, 1), (256 * 96, 1024, 1024, 1),
@@ -63,30 +64,40 @@ def main():
             assert rc == 0, rc
 
         times = {}
+        stable = True
         for name, which in (("full", 1), ("half", 2)):
             y = torch.full((M, n), float("nan"), device=dev)
             run(which, y)
             torch.cuda.synchronize()
             ys[name] = y.clone()
             times[name] = timed(lambda: run(which, y))
-            assert torch.equal(y, ys[name])
+            stable = stable and bool(torch.equal(y, ys[name]))
         y_rule = ops.linear(x, wp, bp, act)   # the product library with its shape rule
         t_rule = timed(lambda: ops.linear(x, wp, bp, act, out=y_rule))
         same = bool(torch.equal(ys["full"], ys["half"])) and bool(torch.equal(ys["full"], y_rule))
         fl = 2.0 * M * n * k
-        rec = {"M": M, "N": n, "K": k, "act": act, "bit_identical": same,
+        rec = {"M": M, "N": n, "K": k, "act": act, "bit_identical": same, "repeatable": stable,
                "full_ms": round(times["full"], 4), "half_ms": round(times["half"], 4), "rule_ms": round(t_rule, 4),
                "full_tflops": round(fl / times["full"] / 1e9, 1), "half_tflops": round(fl / times["half"] / 1e9, 1)}
         if args.ablate and M % 128 == 0 and act == 1 and (n, k) in ((1024, 1024), (256, 256), (1024, 64)):
             y = torch.empty(M, n, device=dev)
-            for abl in (0, 1, 2, 3, 4, 6, 7):
+            for abl in (0, 1, 2, 7, 8, 24, 40, 56):
                 def f():
                     rc = diag.m360_diag_linear_hd(x.data_ptr(), M, k, wp.data_ptr(), bp.data_ptr(), n, k, act, y.data_ptr(), n, abl,
                                                   torch.cuda.current_stream().cuda_stream)
                     assert rc == 0, rc
                 f()
                 torch.cuda.synchronize()
-                rec[f"abl{abl}_ms"] = round(timed(f), 4)
+                rec[f"abl{abl}_ms"] = round(timed(f, reps=5, inner=max(10, int(150 / max(rec["half_ms"], 0.05)))), 4)  # ~0.75 s soak
+                st = (ctypes.c_ulonglong * 2048)()
+                assert diag.m360_diag_read_hd_stamps(st, 2048) == 0
+                a = np.array(st[:1024], dtype=np.float64).reshape(256, 4)
+                ph = np.array(st[1024:], dtype=np.float64).reshape(256, 4)
+                tiles = np.maximum(a[:, 2] / (k // 32), 1)
+                rec[f"abl{abl}_cycles_F_S_P"] = [round(float(np.median(ph[:, 0] / tiles)), 1), round(float(np.median(ph[:, 1] / tiles)), 1),
+                                                round(float(np.median(ph[:, 2] / tiles / max(k // 32 - 2, 1))), 1)]
+                rec[f"abl{abl}_clock_ghz"] = round(float(np.median(a[:, 0] / np.maximum(a[:, 1], 1)) * 0.1), 3)
+                rec[f"abl{abl}_cycles_per_kstep"] = round(float(np.median(a[:, 0] / np.maximum(a[:, 2], 1))), 1)
         print(json.dumps(rec), flush=True)
         out.append(rec)
         del x, y, ys, y_rule
