@@ -139,6 +139,14 @@ int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_
 int m360_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
                 int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t stream);
 
+/* The same layer with load balancing across the chip's 8 XCDs, whose clocks differ by 1-2 %: the last few percent of the
+ * 128-row tiles are handed out through `tile_queue`, a caller-owned 4-byte device word that is ZERO when the launch starts
+ * (the launch leaves it non-zero: zero it again - or pass a fresh word - before the next launch; the forward entry points
+ * below keep 16 such words in their workspace).  NULL, or a layer the balanced kernel does not take, = m360_linear.
+ * Results are bit-identical to m360_linear. */
+int m360_linear_balanced(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
+                         int n_pad, int k_pad, int act, float *y, int ldy, unsigned *tile_queue, m360_stream_t stream);
+
 /* ---- training path (row f3): the two gradient GEMMs autograd runs for every nn.Linear of model.py:43-53 /
  * :131-158 under train.py:62,80.  All fp32 MFMA, deterministic (no atomics). */
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     "m360_encode_features_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "m360_pack_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "m360_linear_balanced": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "m360_pack_linear_transposed": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "m360_linear_dgrad": (_i, [_vp, _l, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "m360_linear_wgrad_workspace_bytes": (_sz, [_l, _i, _i]),

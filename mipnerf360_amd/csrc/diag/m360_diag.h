@@ -13,7 +13,7 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
                           int k_pad, void *y, int ldy, int variant, int ldw /* row stride of w_packed, elements */, m360_stream_t stream);
 /* the half-tile / double-accumulator fp32 kernel (m360_linear_hd.hip.h) while it is evaluated against the product kernel */
 int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
-                        int act, float *y, int ldy, int ablate /* 0; 1 no barrier, 2 no LDS-DMA, 4 no operand reads: timing only */,
+                        int act, float *y, int ldy, int ablate /* 0, or ABL bits of m360_linear_hd.hip.h: timing only */, unsigned *queue /* zeroed word or NULL */,
                         m360_stream_t stream);
 /* 4 x uint64 per workgroup of the last (ReLU or ablated) m360_diag_linear_hd launch: cycles, 100 MHz ticks, K-steps */
 int m360_diag_read_hd_stamps(unsigned long long *out_host, int n);

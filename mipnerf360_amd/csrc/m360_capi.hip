@@ -78,8 +78,22 @@ __global__ void add_eps_kernel(const float *__restrict__ x, long n, float *__res
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FwdLayout {
-    size_t norm, vdenc, t1, t0, what, feat, act_a, act_b, hpart, total;
+    size_t norm, vdenc, t1, t0, what, feat, act_a, act_b, hpart, queues, total;
 };
+// tile-queue words of the balanced linear launches of one stage (m360_linear_balanced): 16 words, one per 64-byte line
+constexpr int kQueueSlots = 16, kQueueStride = 16;
+struct TileQueues {
+    unsigned *base = nullptr;
+    int next = 0;
+    unsigned *take() { return (base && next < kQueueSlots) ? base + kQueueStride * next++ : nullptr; }
+};
+static int queues_begin(TileQueues *q, char *ws, size_t off, m360_stream_t st) {
+    q->base = reinterpret_cast<unsigned *>(ws + off);
+    q->next = 0;
+    if (hipMemsetAsync(q->base, 0, (size_t)kQueueSlots * kQueueStride * sizeof(unsigned), reinterpret_cast<hipStream_t>(st)) != hipSuccess)
+        return fail(M360_ERR_LAUNCH, "tile queues: memset failed");
+    return M360_OK;
+}
 
 static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     FwdLayout L;
@@ -100,6 +114,7 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     const size_t hp_slots = (size_t)m360_linear_heads_slots(m->hp_pad, m->mlp_bf16), hn_slots = (size_t)m360_linear_heads_slots(m->hn_pad, m->mlp_bf16);  // (an upper bound: sized whether or not the widths allow fusion)
     const size_t hp_b = S * hp_slots * 1 * sizeof(float), hn_b = S * hn_slots * 4 * sizeof(float);
     L.hpart = take(hp_b > hn_b ? hp_b : hn_b);
+    L.queues = take((size_t)kQueueSlots * kQueueStride * sizeof(unsigned));
     L.total = off;
     return L;
 }
@@ -132,9 +147,9 @@ static int validate(const m360_rays_t *r, const m360_model_t *m, const m360_hype
     } while (0)
 
 // the entry points the stage drivers chain, each bracketed by the caller's event recorder (hyper->prof, may be NULL)
-static int p_linear(const m360_hyper_t *h, const float *x, long M, int ldx, const float *w, const float *b, int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t st) {
+static int p_linear(const m360_hyper_t *h, TileQueues *q, const float *x, long M, int ldx, const float *w, const float *b, int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t st) {
     ProfScope ps(h, st, M360_K_LINEAR, M, n_pad, k_pad);
-    return ps.done(m360_linear(x, M, ldx, w, b, n_pad, k_pad, act, y, ldy, st));
+    return ps.done(m360_linear_balanced(x, M, ldx, w, b, n_pad, k_pad, act, y, ldy, q->take(), st));
 }
 static int p_linear_bf16(const m360_hyper_t *h, const void *x, long M, int ldx, const void *w, const float *b, int n_pad, int k_pad, int act, void *y, int ldy, m360_stream_t st) {
     ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, k_pad);
@@ -194,6 +209,8 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     float *a = reinterpret_cast<float *>(ws + L.act_a), *b = reinterpret_cast<float *>(ws + L.act_b);
     float *hpart = reinterpret_cast<float *>(ws + L.hpart);
     const long S = (long)B * N;
+    TileQueues tq;
+    M360_TRY(queues_begin(&tq, ws, L.queues, st));
     if (tape) {  // training: fp32 only, every layer output kept
         const TapeLayout T = tape_for(B, N, m, 0);
         const int hp = m->hp_pad;
@@ -205,9 +222,9 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
             return fail(M360_ERR_LAUNCH, "m360_prop_forward_train: copy of t_hat failed");
         M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
         M360_TRY(p_encode_grouped(h, tt, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(p_linear(h, tf, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, act[0], hp, st));
+        M360_TRY(p_linear(h, &tq, tf, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, act[0], hp, st));
         for (int l = 1; l < 3; ++l)
-            M360_TRY(p_linear(h, act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, M360_ACT_RELU, act[l], hp, st));
+            M360_TRY(p_linear(h, &tq, act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, M360_ACT_RELU, act[l], hp, st));
         // last hidden layer + head fused; the tape keeps the layer output (store_y = 1), same partial sums as when rendering
         M360_TRY(p_linear_heads(h, 0, act[2], S, hp, m->prop_w[3], m->prop_b[3], hp, hp, act[3], hp, 1, m->prop_head_w, 1, hpart, st));
         return p_prop_finish_fused(h, act[3], 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp, 0), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st);
@@ -227,9 +244,9 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         return p_prop_finish_fused(h, b, 1, hp, hpart, m360_linear_heads_fused_rows(S, hp, 1), m360_linear_heads_slots(hp, 1), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
     }
     if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-    M360_TRY(p_linear(h, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
-    M360_TRY(p_linear(h, a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
-    M360_TRY(p_linear(h, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
+    M360_TRY(p_linear(h, &tq, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
+    M360_TRY(p_linear(h, &tq, a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
+    M360_TRY(p_linear(h, &tq, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
     // last hidden layer + head fused: its 537 MB output never goes to HBM (store_y = 0; ragged tail rows excepted)
     M360_TRY(p_linear_heads(h, 0, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, b, hp, 0, m->prop_head_w, 1, hpart, st));
     return p_prop_finish_fused(h, b, 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp, 0), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
@@ -247,6 +264,8 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     float *a = reinterpret_cast<float *>(ws + L.act_a), *b = reinterpret_cast<float *>(ws + L.act_b);
     float *hpart = reinterpret_cast<float *>(ws + L.hpart);
     const long S = (long)B * N;
+    TileQueues tq;
+    M360_TRY(queues_begin(&tq, ws, L.queues, st));
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hn = m->hn_pad;
     const int slots = m360_linear_heads_slots(hn, m->mlp_bf16);
@@ -257,9 +276,9 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         float *act[8];
         for (int l = 0; l < 8; ++l) act[l] = reinterpret_cast<float *>(tape + T.act[l]);
         M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(p_linear(h, tf, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, act[0], hn, st));
+        M360_TRY(p_linear(h, &tq, tf, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, act[0], hn, st));
         for (int l = 1; l < 7; ++l)
-            M360_TRY(p_linear(h, act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, M360_ACT_RELU, act[l], hn, st));
+            M360_TRY(p_linear(h, &tq, act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, M360_ACT_RELU, act[l], hn, st));
         M360_TRY(p_linear_heads(h, 0, act[6], S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, act[7], hn, 1, m->nerf_head_w, 4, hpart, st));
         M360_TRY(p_nerf_finish_fused(h, act[7], 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     } else if (m->mlp_bf16) {
@@ -275,9 +294,9 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     } else {
     if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
     else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-    M360_TRY(p_linear(h, feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
+    M360_TRY(p_linear(h, &tq, feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
     for (int layer = 1; layer < 7; ++layer) {
-        M360_TRY(p_linear(h, src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, hn, st));
+        M360_TRY(p_linear(h, &tq, src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, hn, st));
         float *tmp = src; src = dst; dst = tmp;
     }
     // last hidden layer + the 4 heads fused: its 2.15 GB output never goes to HBM (store_y = 0; ragged tail rows excepted)

@@ -274,14 +274,20 @@ int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_
 
 // Half-tile kernel (m360_linear_hd.hip.h) on M rows (a multiple of 128) of a 256-multiple width, bias + {none, ReLU}.
 static int launch_linear_hd(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
-                            int act, float *y, int ldy, hipStream_t st) {
+                            int act, float *y, int ldy, unsigned *queue, hipStream_t st) {
     const int cus = cu_count();
     if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear: no HIP device");
     const long nt = (M / hd::BM) * (n_pad / hd::BN);
-    if (nt > 0x7fffffffL) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: grid too large");
+    if (nt > 0x7fffffffL - 4L * cus) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: grid too large");
     dim3 grid((unsigned)(nt < cus ? nt : cus)), block(hd::kThreads);
-    if (act == M360_ACT_RELU) hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt);
-    else hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt);
+    // with a queue word: all but the last max(2, 1/16) of a workgroup's share of tiles stay static (XCD-aware order), the
+    // rest is handed out by ticket; launches of fewer than 4 tiles per workgroup have nothing to balance
+    const long share = nt / cus;
+    int n_static = 0;
+    if (queue && share >= 4) n_static = (int)(share - (share / 16 > 2 ? share / 16 : 2));
+    else queue = nullptr;
+    if (act == M360_ACT_RELU) hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt, queue, n_static);
+    else hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt, queue, n_static);
     return check_launch("linear_hd");
 }
 
@@ -302,7 +308,8 @@ static bool prefer_half_tiles(long M, int n_pad, int k_pad, int act) {
 }
 
 static int launch_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad,
-                         int k_pad, int act, float *y, int ldy, const float *aux, m360_stream_t stream) {
+                         int k_pad, int act, float *y, int ldy, const float *aux, m360_stream_t stream, unsigned *queue = nullptr) {
+    if ((uintptr_t)queue & 3) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_balanced: tile_queue must be a 4-byte aligned device pointer");
     if (!x || !w_packed || (!b_packed && act != M360_ACT_RELU_MASK) || !y || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: null pointer or negative M");
     if (act == M360_ACT_RELU_MASK && (!aux || ((uintptr_t)aux & 15))) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: the ReLU-mask epilogue needs a 16-byte aligned mask source");
     if (n_pad < 1 || k_pad < BK || k_pad % BK != 0 || ldx < k_pad || ldy < n_pad || ldx % 4 != 0 || ldy % 4 != 0)
@@ -322,7 +329,7 @@ static int launch_linear(const float *x, long M, int ldx, const float *w_packed,
     long M_full = 0;
     if (prefer_half_tiles(M, n_pad, k_pad, act)) {
         M_full = (M / hd::BM) * hd::BM;
-        const int rc = launch_linear_hd(x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, st);
+        const int rc = launch_linear_hd(x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, queue, st);
         if (rc != M360_OK) return rc;
     } else if (n_pad % persist::BN == 0 && M >= persist::BM) {
         M_full = (M / persist::BM) * persist::BM;
@@ -356,6 +363,12 @@ int m360_linear(const float *x, long M, int ldx, const float *w_packed, const fl
                 int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t stream) {
     if (act == M360_ACT_RELU_MASK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear: use m360_linear_dgrad for the masked epilogue");
     return launch_linear(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, nullptr, stream);
+}
+
+int m360_linear_balanced(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
+                         int n_pad, int k_pad, int act, float *y, int ldy, unsigned *tile_queue, m360_stream_t stream) {
+    if (act == M360_ACT_RELU_MASK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_balanced: use m360_linear_dgrad for the masked epilogue");
+    return launch_linear(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, nullptr, stream, tile_queue);
 }
 
 // ---- last hidden layer of a stage fused with its heads
@@ -586,14 +599,18 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
 }
 
 int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
-                        int act, float *y, int ldy, int ablate, m360_stream_t stream) {
+                        int act, float *y, int ldy, int ablate, unsigned *queue, m360_stream_t stream) {
     if (!x || !w_packed || !b_packed || !y || M < hd::BM || M % hd::BM || n_pad % hd::BN || k_pad % hd::BK || k_pad < 2 * hd::BK || n_pad > hd::kMaxBias || (act != M360_ACT_NONE && act != M360_ACT_RELU))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_hd: full 128 x 256 tiles, k_pad >= 64, act none / ReLU only");
     const int cus = cu_count();
     const long nt = (M / hd::BM) * (n_pad / hd::BN);
     dim3 grid((unsigned)(nt < cus ? nt : cus)), block(hd::kThreads);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-#define M360_HD_ABL(A) hipLaunchKernelGGL((hd::linear_f32_hd_kernel<M360_ACT_RELU, A, true>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt)
+    const long share = nt / (cus > 0 ? cus : 1);  // the split of launch_linear_hd
+    int n_static = 0;
+    if (queue && share >= 4) n_static = (int)(share - (share / 16 > 2 ? share / 16 : 2));
+    else queue = nullptr;
+#define M360_HD_ABL(A) hipLaunchKernelGGL((hd::linear_f32_hd_kernel<M360_ACT_RELU, A, true>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt, queue, n_static)
     if (ablate || act == M360_ACT_RELU) {  // stamped; timing-only ablations: bits as listed in m360_linear_hd.hip.h (the combinations instantiated here)
         switch (ablate) {
             case 0: M360_HD_ABL(0); break;
@@ -603,13 +620,14 @@ int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, 
             case 8: M360_HD_ABL(8); break;
             case 24: M360_HD_ABL(24); break;
             case 40: M360_HD_ABL(40); break;
+            case 64: M360_HD_ABL(64); break;
             case 56: M360_HD_ABL(56); break;
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_hd: ablate=%d", ablate);
         }
         return check_launch("diag_linear_hd");
     }
 #undef M360_HD_ABL
-    return launch_linear_hd(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, st);
+    return launch_linear_hd(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, queue, st);
 }
 
 int m360_diag_force_linear_kernel(int which) {

@@ -38,12 +38,12 @@ constexpr int kMaxBias = 4096;                       // widest layer (bias is se
 __device__ unsigned long long g_hd_stamps[2 * 256 * 4];
 #endif
 // ABL (diagnostic builds only; results are wrong unless 0): 1 = no workgroup barrier, 2 = no LDS-DMA, 4 = no operand reads,
-// 8 = epilogue fillers unguarded, 16 = no epilogue stores, 32 = no epilogue arithmetic
+// 8 = epilogue fillers unguarded, 16 = no epilogue stores, 32 = no epilogue arithmetic, 64 = tiles in natural order (no XCD-aware remap; results stay right)
 template <int ACT, int ABL = 0, bool STAMP = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     const float *__restrict__ X, long M, int ldx, const float *__restrict__ W, const float *__restrict__ bias, int Np,
-    int Kp, float *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
-    __shared__ __attribute__((aligned(1024))) float smem[2 * kStageFloats + 4 * kStgFloats + kMaxBias];  // 130 KiB
+    int Kp, float *__restrict__ Y, int ldy, int tiles_n, int ntiles, unsigned *__restrict__ queue, int n_static) {
+    __shared__ __attribute__((aligned(1024))) float smem[2 * kStageFloats + 4 * kStgFloats + kMaxBias + 64];  // 130 KiB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     auto tile_coords = [&](int lin_id, long &m0, int &n0) __attribute__((always_inline)) {
         const int full = (ntiles / 8) * 8;  // XCD-aware (speed only): ids sharing id % 8 cover a contiguous range of tiles
         int lin = lin_id;
-        if (lin_id < full) lin = (lin_id % 8) * (full / 8) + lin_id / 8;
+        if (lin_id < full && !(ABL & 64)) lin = (lin_id % 8) * (full / 8) + lin_id / 8;
         m0 = (long)(lin / tiles_n) * BM;
         n0 = (lin % tiles_n) * BN;
     };
@@ -174,7 +174,14 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     } while (0)
 #include "m360_linear_hd_gen.inc"
 
-    int lin_id = blockIdx.x;
+    // Tile ids of a workgroup: b, b + G, ... (n_static of them), then - when the caller supplied a zeroed queue word - ids
+    // n_static * G + (ticket from the queue): the XCDs of one chip hold clocks 1-2 % apart (profiles/r02/hd_xcd_spread.jsonl),
+    // with equal shares the launch ends with the slowest one.  The static part keeps the XCD-aware order (worth 0.8 %), the
+    // last ~6 % of the tiles go to whoever is free.  `cur` runs, `nxt` is prefetched by cur's last K-step, the id after that
+    // is fetched (thread 0, returning atomic) at the start of cur and handed to the other waves through LDS.
+    int lin_id = blockIdx.x, nxt_id = blockIdx.x + G, tcount = 0;
+    unsigned ticket = 0;
+    int *const id_slot = reinterpret_cast<int *>(smem + 2 * kStageFloats + 4 * kStgFloats + kMaxBias);
     if (lin_id >= ntiles) return;
     long m0;
     int n0;
@@ -203,10 +210,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     int next_k0 = ((KT) + 1) * BK;                                                                                \
     if ((KT) + 1 == ksteps) { /* stage K-step 0 of this workgroup's next tile (else, harmlessly, of this one) */   \
         next_k0 = 0;                                                                                              \
-        if (lin_id + G < ntiles) {                                                                                \
+        if (nxt_id < ntiles) {                                                                                    \
             long nm0;                                                                                             \
             int nn0;                                                                                              \
-            tile_coords(lin_id + G, nm0, nn0);                                                                    \
+            tile_coords(nxt_id, nm0, nn0);                                                                        \
             set_load_tile(nm0, nn0);                                                                              \
         }                                                                                                         \
     }                                                                                                             \
@@ -221,6 +228,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     } while (0)
 #define HD_TILE(S, P)                                                                                             \
     do {                                                                                                          \
+        const bool dyn = queue != nullptr && tcount + 2 >= n_static;                                              \
+        nn_id = blockIdx.x + (tcount + 2) * G;                                                                    \
+        if (dyn && tid == 0) ticket = atomicAdd(queue, 1u);                                                       \
         HD_STAMP(c0);                                                                                             \
         {                                                                                                         \
             HD_KSETUP(0);                                                                                         \
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
             buf ^= 1;                                                                                             \
         }                                                                                                         \
         HD_STAMP(c1);                                                                                             \
+        if (dyn && tid == 0) id_slot[0] = n_static * G + (int)ticket; /* the wait for the ticket lands here: free */ \
         {                                                                                                         \
             HD_KSETUP(1);                                                                                         \
             HD_KSTEP_S(S, P);                                                                                     \
@@ -241,6 +252,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
         }                                                                                                         \
         HD_STAMP(c3);                                                                                             \
         if (STAMP) { tF += c1 - c0; tS += c2 - c1; tP += c3 - c2; }                                               \
+        if (dyn) nn_id = __builtin_amdgcn_readfirstlane(id_slot[0]); /* written before this tile's last barrier */ \
     } while (0)
     // what the epilogue of the tile just finished needs: its bias slices and this lane's first output element
 #define HD_SET_EPILOGUE()                                                                                         \
@@ -269,11 +281,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
         HD_EBLOCK(P, 1, 0); HD_EBLOCK(P, 1, 1); HD_EBLOCK(P, 1, 2); HD_EBLOCK(P, 1, 3);                           \
     } while (0)
 
+    int nn_id = 0;
     for (;;) {
         tile_coords(lin_id, m0, n0);
         HD_TILE(0, 1);
         HD_SET_EPILOGUE();
-        lin_id += G;
+        lin_id = nxt_id; nxt_id = nn_id; ++tcount;
         nk += ksteps;
         if (lin_id >= ntiles) {
             if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt1), "=s"(rt1)::"memory");
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
         tile_coords(lin_id, m0, n0);
         HD_TILE(1, 0);
         HD_SET_EPILOGUE();
-        lin_id += G;
+        lin_id = nxt_id; nxt_id = nn_id; ++tcount;
         nk += ksteps;
         if (lin_id >= ntiles) {
             if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt1), "=s"(rt1)::"memory");

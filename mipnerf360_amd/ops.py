@@ -233,14 +233,21 @@ def pack_linear(weight, bias=None, n_pad: Optional[int] = None, k_pad: Optional[
     return wp, bp
 
 
-def linear(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.Tensor] = None,
+           balanced: bool = False) -> torch.Tensor:
+    """One packed layer.  balanced=True hands the last tiles out through a (fresh, zeroed) queue word so that the 8 XCDs
+    finish together (m360_linear_balanced); the result is bit-identical either way."""
     x, w_packed, b_packed = dev(x, "x"), dev(w_packed, "w_packed"), dev(b_packed, "b_packed")
     M, ldx = x.shape
     n_pad, k_pad = w_packed.shape
     if ldx != k_pad:
         raise RuntimeError(f"linear: x has {ldx} columns, packed weight expects {k_pad}")
     y = out if out is not None else torch.empty(M, n_pad, device=x.device)
-    _call("m360_linear", x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, y.shape[1], STREAM)
+    if balanced:
+        queue = torch.zeros(1, dtype=torch.int32, device=x.device)
+        _call("m360_linear_balanced", x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, y.shape[1], queue, STREAM)
+    else:
+        _call("m360_linear", x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, y.shape[1], STREAM)
     return y
 
 

@@ -212,7 +212,8 @@ def test_linear_mfma_against_fp64(dev):
                                         (256 * 21 + 255, 768, 64, 1), (256 * 300 + 1, 256, 32, 0),
                                         (256 * 11 + 3, 256, 256, 2), (256 * 40, 1024, 1024, 2),   # sigmoid layers
                                         (128 * 601, 1024, 96, 1), (128 * 3, 256, 64, 0), (128 * 515 + 77, 512, 160, 1),
-                                        (128 * 257, 256, 1024, 1), (128, 4096, 64, 1), (128 * 19, 4352, 64, 1)])
+                                        (128 * 257, 256, 1024, 1), (128, 4096, 64, 1), (128 * 19, 4352, 64, 1),
+                                        (128 * 256 * 5 + 128 * 3, 256, 64, 1), (128 * 256 * 9, 512, 96, 0)])   # >= 4 tiles per workgroup: the ticket pool is live
 def test_linear_kernel_variants_bit_identical(dev, M, n, k, act):
     """The three fp32 kernels behind m360_linear must agree bit for bit, every element.  The library picks the kernel per
     call from the shape alone (no global switch): full tiles of a 256-multiple width go to the half-tile kernel (bias +
@@ -231,6 +232,9 @@ def test_linear_kernel_variants_bit_identical(dev, M, n, k, act):
     y_full = ops.linear(xp, wp, bp, act)
     for _ in range(3):  # repeated launches: a race would not reproduce identically
         assert torch.equal(ops.linear(xp, wp, bp, act), y_full)
+    # the XCD-balanced launch (last tiles handed out by ticket: which workgroup computes a tile varies from run to run)
+    for _ in range(3):
+        assert torch.equal(ops.linear(xp, wp, bp, act, balanced=True), y_full)
     # row blocks spread over the batch (first / middle / last tiles of the persistent walk)
     starts = sorted({0, 128, 256, (M // 512) * 256, max(((M // 256) - 1) * 256, 0), max(((M // 128) - 1) * 128, 0), max(M - 255, 0), max(M - 127, 0)})
     for a in starts:

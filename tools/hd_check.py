@@ -38,7 +38,8 @@ def main():
     dev = torch.device("cuda:0")
     diag = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), args.diag_lib))
     vp, ci, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
-    diag.m360_diag_linear_hd.argtypes = [vp, cl, ci, vp, vp, ci, ci, ci, vp, ci, ci, vp]
+    diag.m360_diag_linear_hd.argtypes = [vp, cl, ci, vp, vp, ci, ci, ci, vp, ci, ci, vp, vp]
+    diag.m360_linear_balanced.argtypes = [vp, cl, ci, vp, vp, ci, ci, ci, vp, ci, vp, vp]
     diag.m360_linear.argtypes = [vp, cl, ci, vp, vp, ci, ci, ci, vp, ci, vp]
     diag.m360_diag_force_linear_kernel.argtypes = [ci]
     diag.m360_diag_read_hd_stamps.argtypes = [vp, ci]
@@ -74,17 +75,34 @@ def main():
             stable = stable and bool(torch.equal(y, ys[name]))
         y_rule = ops.linear(x, wp, bp, act)   # the product library with its shape rule
         t_rule = timed(lambda: ops.linear(x, wp, bp, act, out=y_rule))
-        same = bool(torch.equal(ys["full"], ys["half"])) and bool(torch.equal(ys["full"], y_rule))
+        queue = torch.zeros(16, dtype=torch.int32, device=dev)
+        y_bal = torch.full((M, n), float("nan"), device=dev)
+
+        def run_bal():   # half tiles + the dynamic pool for the last tiles (queue word zeroed before every launch)
+            diag.m360_diag_force_linear_kernel(2)
+            queue.zero_()
+            rc = diag.m360_linear_balanced(x.data_ptr(), M, k, wp.data_ptr(), bp.data_ptr(), n, k, act, y_bal.data_ptr(), n,
+                                           queue.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+
+        run_bal()
+        torch.cuda.synchronize()
+        t_bal = timed(run_bal)
+        same = bool(torch.equal(ys["full"], ys["half"])) and bool(torch.equal(ys["full"], y_rule)) and bool(torch.equal(ys["full"], y_bal))
         fl = 2.0 * M * n * k
         rec = {"M": M, "N": n, "K": k, "act": act, "bit_identical": same, "repeatable": stable,
-               "full_ms": round(times["full"], 4), "half_ms": round(times["half"], 4), "rule_ms": round(t_rule, 4),
+               "full_ms": round(times["full"], 4), "half_ms": round(times["half"], 4), "rule_ms": round(t_rule, 4), "balanced_ms": round(t_bal, 4), "tickets": int(queue[0]),
                "full_tflops": round(fl / times["full"] / 1e9, 1), "half_tflops": round(fl / times["half"] / 1e9, 1)}
         if args.ablate and M % 128 == 0 and act == 1 and (n, k) in ((1024, 1024), (256, 256), (1024, 64)):
             y = torch.empty(M, n, device=dev)
-            for abl in (0, 1, 2, 7, 8, 24, 40, 56):
+            for abl in (0, "q", 64, 1, 2, 7):
                 def f():
-                    rc = diag.m360_diag_linear_hd(x.data_ptr(), M, k, wp.data_ptr(), bp.data_ptr(), n, k, act, y.data_ptr(), n, abl,
-                                                  torch.cuda.current_stream().cuda_stream)
+                    qp = None
+                    if abl == "q":
+                        queue.zero_()
+                        qp = queue.data_ptr()
+                    rc = diag.m360_diag_linear_hd(x.data_ptr(), M, k, wp.data_ptr(), bp.data_ptr(), n, k, act, y.data_ptr(), n,
+                                                  0 if abl == "q" else abl, qp, torch.cuda.current_stream().cuda_stream)
                     assert rc == 0, rc
                 f()
                 torch.cuda.synchronize()
@@ -96,6 +114,12 @@ def main():
                 tiles = np.maximum(a[:, 2] / (k // 32), 1)
                 rec[f"abl{abl}_cycles_F_S_P"] = [round(float(np.median(ph[:, 0] / tiles)), 1), round(float(np.median(ph[:, 1] / tiles)), 1),
                                                 round(float(np.median(ph[:, 2] / tiles / max(k // 32 - 2, 1))), 1)]
+                if abl in (0, "q"):  # spread of the tile-loop duration over the workgroups (100 MHz ticks -> us), and by XCD (workgroup id % 8)
+                    us = a[:, 1] / 100.0
+                    sfx = "" if abl == 0 else "_balanced"
+                    rec["loop_us_min_median_max" + sfx] = [round(float(us.min()), 1), round(float(np.median(us)), 1), round(float(us.max()), 1)]
+                    rec["loop_us_median_by_xcd" + sfx] = [round(float(np.median(us[x::8])), 1) for x in range(8)]
+                    rec["clock_ghz_by_xcd" + sfx] = [round(float(np.median(a[x::8, 0] / np.maximum(a[x::8, 1], 1)) * 0.1), 3) for x in range(8)]
                 rec[f"abl{abl}_clock_ghz"] = round(float(np.median(a[:, 0] / np.maximum(a[:, 1], 1)) * 0.1), 3)
                 rec[f"abl{abl}_cycles_per_kstep"] = round(float(np.median(a[:, 0] / np.maximum(a[:, 2], 1))), 1)
         print(json.dumps(rec), flush=True)
