@@ -15,6 +15,8 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
 int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
                         int act, float *y, int ldy, int ablate /* 0, or ABL bits of m360_linear_hd.hip.h: timing only */, unsigned *queue /* zeroed word or NULL */,
                         m360_stream_t stream);
+/* 4 x uint64 per workgroup of the last m360_diag_linear_bf16 launch with variant 20 + ABL (the w32 kernel): cycles, 100 MHz ticks, slabs, epilogue cycles */
+int m360_diag_read_w32_stamps(unsigned long long *out_host, int n);
 /* 4 x uint64 per workgroup of the last (ReLU or ablated) m360_diag_linear_hd launch: cycles, 100 MHz ticks, K-steps */
 int m360_diag_read_hd_stamps(unsigned long long *out_host, int n);
 /* m360_linear of THIS (diagnostics) library: 0 = the shape rule, 1 = always the 256 x 256 kernel, 2 = half tiles where they apply */

@@ -23,6 +23,7 @@
 #include "diag/m360_diag.h"
 #include "diag/m360_linear_bf16_sp.hip.h"
 #include "diag/m360_linear_bf16_rg.hip.h"
+#include "diag/m360_linear_bf16_w32.hip.h"
 #endif
 #include "m360_linear_hd.hip.h"
 
@@ -576,6 +577,24 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *xb = static_cast<const __bf16 *>(x), *wb = static_cast<const __bf16 *>(w_packed);
     __bf16 *yb = static_cast<__bf16 *>(y);
+    if (variant >= 20 && variant < 100) {  // the one-wave-per-SIMD 32x32x16 ring kernel (m360_linear_bf16_w32.hip.h), stamped; 20 + ABL bits
+        if (k_pad % 128 || n_pad > w32::kMaxBias) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant 20 needs k_pad %% 128 == 0");
+        dim3 g4((unsigned)(nt < cus ? nt : cus)), b4(w32::kThreads);
+#define M360_W32_ABL(A) hipLaunchKernelGGL((w32::linear_bf16_w32_kernel<M360_ACT_RELU, A, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w32::BN, (int)nt)
+        switch (variant - 20) {
+            case 0: M360_W32_ABL(0); break;
+            case 1: M360_W32_ABL(1); break;
+            case 2: M360_W32_ABL(2); break;
+            case 4: M360_W32_ABL(4); break;
+            case 7: M360_W32_ABL(7); break;
+            case 16: M360_W32_ABL(16); break;
+            case 32: M360_W32_ABL(32); break;
+            case 39: M360_W32_ABL(39); break;
+            default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);
+        }
+#undef M360_W32_ABL
+        return check_launch("diag_linear_bf16_w32");
+    }
     switch (variant) {  // ReLU epilogue throughout
         case 0: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
         case 1: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt, ldw); break;
@@ -633,6 +652,13 @@ int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, 
 int m360_diag_force_linear_kernel(int which) {
     if (which < 0 || which > 2) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_force_linear_kernel: 0 rule, 1 full tiles, 2 half tiles");
     g_diag_force_kernel = which;
+    return M360_OK;
+}
+
+int m360_diag_read_w32_stamps(unsigned long long *out_host, int n) {
+    if (!out_host || n < 0 || n > 256 * 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_read_w32_stamps: bad argument");
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(w32::g_w32_stamps), sizeof(unsigned long long) * n) != hipSuccess)
+        return fail(M360_ERR_LAUNCH, "m360_diag_read_w32_stamps: copy failed");
     return M360_OK;
 }
 

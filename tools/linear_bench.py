@@ -114,6 +114,15 @@ def main():
            "tflops": round(tf, 1), "frac_of_spec_peak": round(tf / peak, 4), "spec_peak_tflops": peak}
     print(f"{args.dtype} linear {args.m}x{args.n}x{args.k}: median {med:.3f} ms = {tf:.1f} TFLOP/s ({100 * tf / peak:.1f}% of "
           f"{peak} TF), best {min(times):.3f} ms")
+    if bf16 and 20 <= args.variant < 100:  # in-kernel stamps of the w32 kernel (after the timed launches: a loaded chip)
+        stt = (ctypes.c_ulonglong * 1024)()
+        diag.m360_diag_read_w32_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+        assert diag.m360_diag_read_w32_stamps(stt, 1024) == 0
+        a = np.array(stt[:], dtype=np.float64).reshape(256, 4)
+        res.update(in_kernel_clock_ghz=round(float(np.median(a[:, 0] / np.maximum(a[:, 1], 1)) * 0.1), 3),
+                   cycles_per_slab=round(float(np.median((a[:, 0] - a[:, 3]) / np.maximum(a[:, 2], 1))), 1),
+                   epilogue_cycles_per_tile=round(float(np.median(a[:, 3] / np.maximum(a[:, 2] / (args.k // 32), 1))), 1))
+        print({k: res[k] for k in ("in_kernel_clock_ghz", "cycles_per_slab", "epilogue_cycles_per_tile")})
     if args.clock:
         t_end = time.time() + args.soak_s
         while time.time() < t_end:  # back-to-back product launches: the chip settles at its loaded clock

@@ -10,6 +10,7 @@
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -17,7 +18,7 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 __device__ __forceinline__ unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 __device__ __forceinline__ float rnd(unsigned s) { return (hash32(s) >> 8) * (1.0f / 8388608.0f) - 1.0f; }
 
-template <int KIND, int F>
+template <int KIND, int F, int BIG = 0>
 __global__ __launch_bounds__(512) void loop_kernel(int iters, const float4 *__restrict__ src, float *sink, unsigned long long *cyc) {
     __shared__ __attribute__((aligned(1024))) char smem[64 * 1024];
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -30,6 +31,11 @@ __global__ __launch_bounds__(512) void loop_kernel(int iters, const float4 *__re
     f32x4 acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0, 0, 0, 0};
+    f32x16 accb[8];  // BIG: 8 MFMAs 32x32x16 (32 cycles each) per body instead of 16 MFMAs 16x16x32 (16 cycles each)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accb[i][e] = 0;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(src), 0, 0x7fffffff, 0x00020000);
     const unsigned voff = (unsigned)(lane * 16 + wave * 1024);
     const unsigned lds_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * 4096 + lane * 16;
@@ -44,8 +50,9 @@ __global__ __launch_bounds__(512) void loop_kernel(int iters, const float4 *__re
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[4 * i + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[4 * i + j], 0, 0, 0);
                 const int slot = 4 * i + j;
+                if (!BIG) acc[slot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[slot], 0, 0, 0);
+                else if ((slot & 1) == 0) accb[slot >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], accb[slot >> 1], 0, 0, 0);
                 if (F > 0 && slot % (16 / F) == 0) {
                     const int f = slot / (16 / F);
                     const int off = ((it * F + f) & 31) * 8192;  // 256 KiB footprint per CU: L2-resident
@@ -66,12 +73,14 @@ __global__ __launch_bounds__(512) void loop_kernel(int iters, const float4 *__re
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
 #pragma unroll
+    for (int i = 0; i < 8; ++i) s += accb[i][0] + accb[i][15];
+#pragma unroll
     for (int f = 0; f < (F > 0 ? F : 1); ++f) s += g[f].x + d[f][0];
     if (s == 12345.678f) sink[tid] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = c1 - c0;
 }
 
-template <int KIND, int F>
+template <int KIND, int F, int BIG = 0>
 static double run(int wps) {
     int cus = 0;
     CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
@@ -79,7 +88,7 @@ static double run(int wps) {
     float4 *src; float *sink; unsigned long long *cyc;
     CHECK(hipMalloc(&src, 64 << 20)); CHECK(hipMemset(src, 0x11, 64 << 20));
     CHECK(hipMalloc(&sink, (size_t)cus * threads * 4)); CHECK(hipMalloc(&cyc, cus * 8));
-    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((loop_kernel<KIND, F>), dim3(cus), dim3(threads), 0, 0, iters, src, sink, cyc);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((loop_kernel<KIND, F, BIG>), dim3(cus), dim3(threads), 0, 0, iters, src, sink, cyc);
     CHECK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(cus);
     CHECK(hipMemcpy(h.data(), cyc, cus * 8, hipMemcpyDeviceToHost));
@@ -95,6 +104,12 @@ int main() {
         printf("{\"waves_per_simd\": %d, \"kind\": \"none\", \"cycles_per_16_mfma_per_wave\": %.1f}\n", wps, base);
 #define ROW(K, F) { const double c = run<K, F>(wps); printf("{\"waves_per_simd\": %d, \"kind\": \"%s\", \"fillers_per_16_mfma\": %d, \"cycles_per_16_mfma_per_wave\": %.1f, \"cost_per_filler_cycles\": %.1f}\n", wps, names[K], F, c, (c - base) / F); }
         ROW(1, 1) ROW(1, 2) ROW(1, 4) ROW(2, 1) ROW(2, 2) ROW(2, 4) ROW(3, 2) ROW(3, 4) ROW(3, 8) ROW(4, 2) ROW(4, 4)
+    }
+    for (int wps = 1; wps <= 2; ++wps) {  // the same fillers beside 8 x v_mfma_f32_32x32x16_bf16 (same 256 cycles of matrix work per body)
+        const double base = run<0, 0, 1>(wps);
+        printf("{\"mfma\": \"32x32x16\", \"waves_per_simd\": %d, \"kind\": \"none\", \"cycles_per_body\": %.1f}\n", wps, base);
+#define ROWB(K, F) { const double c = run<K, F, 1>(wps); printf("{\"mfma\": \"32x32x16\", \"waves_per_simd\": %d, \"kind\": \"%s\", \"fillers_per_body\": %d, \"cycles_per_body\": %.1f, \"cost_per_filler_cycles\": %.1f}\n", wps, names[K], F, c, (c - base) / F); }
+        ROWB(1, 1) ROWB(1, 2) ROWB(1, 4) ROWB(2, 2) ROWB(2, 4) ROWB(3, 4) ROWB(3, 8) ROWB(4, 2) ROWB(4, 4)
     }
     return 0;
 }
