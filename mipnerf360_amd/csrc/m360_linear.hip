@@ -287,8 +287,14 @@ static int launch_linear_hd(const float *x, long M, int ldx, const float *w_pack
     int n_static = 0;
     if (queue && share >= 4) n_static = (int)(share - (share / 16 > 2 ? share / 16 : 2));
     else queue = nullptr;
-    if (act == M360_ACT_RELU) hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt, queue, n_static);
-    else hipLaunchKernelGGL(hd::linear_f32_hd_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt, queue, n_static);
+    const bool even = (k_pad / hd::BK) % 2 == 0;  // static LDS stages: no vector address updates in the K loop
+#define M360_HD_LAUNCH(A, E) hipLaunchKernelGGL((hd::linear_f32_hd_kernel<A, E>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt, queue, n_static)
+    if (act == M360_ACT_RELU) {
+        if (even) M360_HD_LAUNCH(M360_ACT_RELU, true); else M360_HD_LAUNCH(M360_ACT_RELU, false);
+    } else {
+        if (even) M360_HD_LAUNCH(M360_ACT_NONE, true); else M360_HD_LAUNCH(M360_ACT_NONE, false);
+    }
+#undef M360_HD_LAUNCH
     return check_launch("linear_hd");
 }
 
@@ -625,22 +631,19 @@ int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, 
     const long nt = (M / hd::BM) * (n_pad / hd::BN);
     dim3 grid((unsigned)(nt < cus ? nt : cus)), block(hd::kThreads);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool even_ = (k_pad / hd::BK) % 2 == 0;
     const long share = nt / (cus > 0 ? cus : 1);  // the split of launch_linear_hd
     int n_static = 0;
     if (queue && share >= 4) n_static = (int)(share - (share / 16 > 2 ? share / 16 : 2));
     else queue = nullptr;
-#define M360_HD_ABL(A) hipLaunchKernelGGL((hd::linear_f32_hd_kernel<M360_ACT_RELU, A, true>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt, queue, n_static)
+#define M360_HD_ABL(A) do { if (even_) hipLaunchKernelGGL((hd::linear_f32_hd_kernel<M360_ACT_RELU, true, A, true>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt, queue, n_static); else hipLaunchKernelGGL((hd::linear_f32_hd_kernel<M360_ACT_RELU, false, A, true>), grid, block, 0, st, x, M, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / hd::BN, (int)nt, queue, n_static); } while (0)
     if (ablate || act == M360_ACT_RELU) {  // stamped; timing-only ablations: bits as listed in m360_linear_hd.hip.h (the combinations instantiated here)
         switch (ablate) {
             case 0: M360_HD_ABL(0); break;
             case 1: M360_HD_ABL(1); break;
             case 2: M360_HD_ABL(2); break;
             case 7: M360_HD_ABL(7); break;
-            case 8: M360_HD_ABL(8); break;
-            case 24: M360_HD_ABL(24); break;
-            case 40: M360_HD_ABL(40); break;
             case 64: M360_HD_ABL(64); break;
-            case 56: M360_HD_ABL(56); break;
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_hd: ablate=%d", ablate);
         }
         return check_launch("diag_linear_hd");

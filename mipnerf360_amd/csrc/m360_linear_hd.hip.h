@@ -39,7 +39,8 @@ __device__ unsigned long long g_hd_stamps[2 * 256 * 4];
 #endif
 // ABL (diagnostic builds only; results are wrong unless 0): 1 = no workgroup barrier, 2 = no LDS-DMA, 4 = no operand reads,
 // 8 = epilogue fillers unguarded, 16 = no epilogue stores, 32 = no epilogue arithmetic, 64 = tiles in natural order (no XCD-aware remap; results stay right)
-template <int ACT, int ABL = 0, bool STAMP = false>
+// EVENK: Kp / 32 is even -> static LDS stages (see the generated K-steps)
+template <int ACT, bool EVENK = false, int ABL = 0, bool STAMP = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     const float *__restrict__ X, long M, int ldx, const float *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, float *__restrict__ Y, int ldy, int tiles_n, int ntiles, unsigned *__restrict__ queue, int n_static) {
@@ -222,6 +223,20 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     const unsigned a1 = a_addr[1] + boff, b1 = b_addr[1] + boff, a2 = a_addr[2] + boff, b2 = b_addr[2] + boff;    \
     const unsigned a3 = a_addr[3] + boff, b3 = b_addr[3] + boff, a0n = a_addr[0] + noff, b0n = b_addr[0] + noff;  \
     HD_SB()
+// static stages: K-step KT works on stage BUF = KT & 1, nothing to compute but the scalar offset of the next K-step
+#define HD_KSETUP_S(KT, BUF)                                                                                      \
+    int next_k0 = ((KT) + 1) * BK;                                                                                \
+    if ((KT) + 1 == ksteps) {                                                                                     \
+        next_k0 = 0;                                                                                              \
+        if (nxt_id < ntiles) {                                                                                    \
+            long nm0;                                                                                             \
+            int nn0;                                                                                              \
+            tile_coords(nxt_id, nm0, nn0);                                                                        \
+            set_load_tile(nm0, nn0);                                                                              \
+        }                                                                                                         \
+    }                                                                                                             \
+    const int nbuf = 1 - (BUF);                                                                                   \
+    HD_SB()
 #define HD_STAMP(var)                                                                             \
     do {                                                                                          \
         if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");    \
@@ -232,23 +247,47 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
         nn_id = blockIdx.x + (tcount + 2) * G;                                                                    \
         if (dyn && tid == 0) ticket = atomicAdd(queue, 1u);                                                       \
         HD_STAMP(c0);                                                                                             \
-        {                                                                                                         \
-            HD_KSETUP(0);                                                                                         \
-            HD_KSTEP_F(S, P);                                                                                     \
-            buf ^= 1;                                                                                             \
-        }                                                                                                         \
-        HD_STAMP(c1);                                                                                             \
-        if (dyn && tid == 0) id_slot[0] = n_static * G + (int)ticket; /* the wait for the ticket lands here: free */ \
-        {                                                                                                         \
-            HD_KSETUP(1);                                                                                         \
-            HD_KSTEP_S(S, P);                                                                                     \
-            buf ^= 1;                                                                                             \
-        }                                                                                                         \
-        HD_STAMP(c2);                                                                                             \
-        for (int kt = 2; kt < ksteps; ++kt) {                                                                     \
-            HD_KSETUP(kt);                                                                                        \
-            HD_KSTEP_P(S, P);                                                                                     \
-            buf ^= 1;                                                                                             \
+        if (EVENK) {                                                                                              \
+            {                                                                                                     \
+                HD_KSETUP_S(0, 0);                                                                                \
+                HD_KSTEP_F0(S, P);                                                                                \
+            }                                                                                                     \
+            HD_STAMP(c1);                                                                                         \
+            if (dyn && tid == 0) id_slot[0] = n_static * G + (int)ticket; /* the wait for the ticket lands here: free */ \
+            {                                                                                                     \
+                HD_KSETUP_S(1, 1);                                                                                \
+                HD_KSTEP_S1(S, P);                                                                                \
+            }                                                                                                     \
+            HD_STAMP(c2);                                                                                         \
+            for (int kt = 2; kt < ksteps; kt += 2) {                                                              \
+                {                                                                                                 \
+                    HD_KSETUP_S(kt, 0);                                                                           \
+                    HD_KSTEP_P0(S, P);                                                                            \
+                }                                                                                                 \
+                {                                                                                                 \
+                    HD_KSETUP_S(kt + 1, 1);                                                                       \
+                    HD_KSTEP_P1(S, P);                                                                            \
+                }                                                                                                 \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            {                                                                                                     \
+                HD_KSETUP(0);                                                                                     \
+                HD_KSTEP_F(S, P);                                                                                 \
+                buf ^= 1;                                                                                         \
+            }                                                                                                     \
+            HD_STAMP(c1);                                                                                         \
+            if (dyn && tid == 0) id_slot[0] = n_static * G + (int)ticket;                                         \
+            {                                                                                                     \
+                HD_KSETUP(1);                                                                                     \
+                HD_KSTEP_S(S, P);                                                                                 \
+                buf ^= 1;                                                                                         \
+            }                                                                                                     \
+            HD_STAMP(c2);                                                                                         \
+            for (int kt = 2; kt < ksteps; ++kt) {                                                                 \
+                HD_KSETUP(kt);                                                                                    \
+                HD_KSTEP_P(S, P);                                                                                 \
+                buf ^= 1;                                                                                         \
+            }                                                                                                     \
         }                                                                                                         \
         HD_STAMP(c3);                                                                                             \
         if (STAMP) { tF += c1 - c0; tS += c2 - c1; tP += c3 - c2; }                                               \
@@ -332,6 +371,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
 #undef HD_BARRIER_E
 #undef HD_EB
 #undef HD_KSETUP
+#undef HD_KSETUP_S
 #undef HD_SET_EPILOGUE
 #undef HD_FINAL_EPILOGUE
 #undef HD_EBLOCK

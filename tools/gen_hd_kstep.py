@@ -15,6 +15,9 @@ Macros emitted (S = accumulator set of the running tile, P = set of the previous
   HD_KSTEP_F(S, P)  first K-step of a tile: the accumulators of S start from 0 through the C operand; epilogue blocks 0-3 of P
   HD_KSTEP_S(S, P)  second K-step: epilogue blocks 4-7 of P
   HD_KSTEP_P(S, P)  every further K-step: no epilogue
+  HD_KSTEP_F0 / S1 / P0 / P1: the same for layers with an even number of K-steps - K-step kt then always works on LDS stage
+  kt & 1, the stage offset moves into the immediates of the ds_read_b128 and the 8 vector address updates per K-step (32-40
+  cycles of matrix time: vector instructions are not hidden behind MFMAs) disappear
 The epilogue fillers are guarded by the wave-uniform `have_prev` (the first tile of a workgroup has nothing to store): ONE
 straight-line MFMA stream per K-step, so the 256 accumulators never meet a control-flow join inside a tile.
 """
@@ -28,13 +31,22 @@ P_STRIDE = 4   # MFMA gaps between two LDS-DMA pieces in the K-steps without epi
 FS_STRIDE = 2  # ... in the two epilogue K-steps (all 12 inside group 0, before the first epilogue stores)
 
 
-def group(lines, g, first, epi_block, dma):
+STAGE_BYTES = 49152  # one LDS stage (A + B tile of a K-step)
+
+
+def group(lines, g, first, epi_block, dma, buf=None):
     cur, nxt = ("0", "1") if g % 2 == 0 else ("1", "0")   # fragment sets: G0 F0, G1 F1, G2 F0, G3 F1
-    # address variables of the reads issued in this group (fragments of the NEXT group)
-    ra, rb = {0: ("a1", "b1"), 1: ("a2", "b2"), 2: ("a3", "b3"), 3: ("a0n", "b0n")}[g]
-    reads = [f"HD_DS128(fa{nxt}[0], {ra}, 0)", f"HD_DS128(fa{nxt}[1], {ra}, 4096)",
-             f"HD_DS128(fb{nxt}[0], {rb}, 0)", f"HD_DS128(fb{nxt}[1], {rb}, 4096)",
-             f"HD_DS128(fb{nxt}[2], {rb}, 8192)", f"HD_DS128(fb{nxt}[3], {rb}, 12288)"]
+    # addresses of the reads issued in this group (fragments of the NEXT group; group 3: group 0 of the next K-step)
+    if buf is None:   # LDS stage known at run time only: per-K-step address registers (8 vector adds per K-step)
+        ra, rb = {0: ("a1", "b1"), 1: ("a2", "b2"), 2: ("a3", "b3"), 3: ("a0n", "b0n")}[g]
+        off = 0
+    else:             # static stage (even number of K-steps): the stage offset is part of the instruction's immediate
+        gi = (g + 1) % 4
+        ra, rb = f"a_addr[{gi}]", f"b_addr[{gi}]"
+        off = (buf if g < 3 else 1 - buf) * STAGE_BYTES
+    reads = [f"HD_DS128(fa{nxt}[0], {ra}, {off})", f"HD_DS128(fa{nxt}[1], {ra}, {off + 4096})",
+             f"HD_DS128(fb{nxt}[0], {rb}, {off})", f"HD_DS128(fb{nxt}[1], {rb}, {off + 4096})",
+             f"HD_DS128(fb{nxt}[2], {rb}, {off + 8192})", f"HD_DS128(fb{nxt}[3], {rb}, {off + 12288})"]
     m = 0
     for s in range(4):
         for i in range(2):
@@ -77,7 +89,7 @@ def group(lines, g, first, epi_block, dma):
     assert not reads
 
 
-def kstep(name, first, epi):
+def kstep(name, first, epi, buf=None):
     lines = [f"#define HD_KSTEP_{name}(S, P) do {{"]
     blocks = {0: [None] * 4, 1: [0, 1, 2, 3], 2: [4, 5, 6, 7]}[epi]
     for g in range(4):
@@ -94,7 +106,7 @@ def kstep(name, first, epi):
             lines.append("    HD_SB();")
         stride = FS_STRIDE if epi else P_STRIDE
         assert 11 * stride < (32 if epi else 64)  # epilogue K-steps: every piece older than the first store; else: landed by group 3
-        group(lines, g, first, blocks[g], dma=stride)
+        group(lines, g, first, blocks[g], dma=stride, buf=buf)
     lines.append("} while (0)")
     return " \\\n".join(lines) + "\n"
 
@@ -113,6 +125,11 @@ def main():
     out.append(kstep("F", True, 1))
     out.append(kstep("S", False, 2))
     out.append(kstep("P", False, 0))
+    # the same with the LDS stage static (K-step kt works on stage kt & 1: layers with an even number of K-steps)
+    out.append(kstep("F0", True, 1, buf=0))
+    out.append(kstep("S1", False, 2, buf=1))
+    out.append(kstep("P0", False, 0, buf=0))
+    out.append(kstep("P1", False, 0, buf=1))
     with open(OUT, "w") as f:
         f.write("\n".join(out))
     print("wrote", OUT, sum(len(o) for o in out), "bytes")
