@@ -342,12 +342,19 @@ static int launch_linear(const float *x, long M, int ldx, const float *w_packed,
         M_full = (M / persist::BM) * persist::BM;
         const long nt = (M_full / persist::BM) * (n_pad / persist::BN);
         const int ntiles = (int)nt;
+        const bool even_k = (k_pad / persist::BK) % 2 == 0;  // static LDS buffers (sigmoid and masked epilogues: the layers this kernel still serves)
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(persist::kThreads);
         switch (act) {
             case M360_ACT_NONE: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_NONE>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
             case M360_ACT_RELU: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
-            case M360_ACT_RELU_MASK: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU_MASK>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles, aux); break;
-            default: hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles); break;
+            case M360_ACT_RELU_MASK:
+                if (even_k) hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU_MASK, false, 0, true, true>), grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles, aux);
+                else hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_RELU_MASK>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles, aux);
+                break;
+            default:
+                if (even_k) hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID, false, 0, true, true>), grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles);
+                else hipLaunchKernelGGL(persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID>, grid, block, 0, st, x, M_full, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, n_pad / persist::BN, ntiles);
+                break;
         }
     }
     if (M > M_full) {
@@ -407,7 +414,11 @@ int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, co
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(persist::kThreads);
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         const int tn = n_pad / persist::BN;
-#define M360_LAUNCH_HEADS(H, SY) hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID, false, H, SY>), grid, block, 0, st, x, M_fused, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tn, (int)nt, nullptr, head_w, head_part)
+#define M360_LAUNCH_HEADS(H, SY)                                                                                              \
+    do {                                                                                                                       \
+        if ((k_pad / persist::BK) % 2 == 0) hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID, false, H, SY, true>), grid, block, 0, st, x, M_fused, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tn, (int)nt, nullptr, head_w, head_part); \
+        else hipLaunchKernelGGL((persist::linear_f32_mfma_persist_kernel<M360_ACT_SIGMOID, false, H, SY, false>), grid, block, 0, st, x, M_fused, ldx, w_packed, b_packed, n_pad, k_pad, y, ldy, tn, (int)nt, nullptr, head_w, head_part); \
+    } while (0)
         if (heads == 1) {
             if (store_y) M360_LAUNCH_HEADS(1, true); else M360_LAUNCH_HEADS(1, false);
         } else {

@@ -60,7 +60,9 @@ constexpr int kHeadMaxN = 1024;  // widest layer whose heads can be fused (bias 
 // writes per-row PARTIAL head sums head_part[M][2 * tiles_n][HEADS] (one slot per 128-column wave tile; the finisher
 // adds the slots in a fixed order).  With STORE_Y = false the layer output itself never goes to HBM (rendering);
 // the training tape keeps it (STORE_Y = true) - both produce the same partial sums bit for bit.
-template <int ACT, bool STAMP = false, int HEADS = 0, bool STORE_Y = true>
+// EVENK: Kp / 32 is even -> K-step kt always works on LDS buffer kt & 1: the fragment addresses of both buffers are kept in
+// registers and the 8 vector address updates per K-step disappear (vector instructions are not hidden behind MFMAs)
+template <int ACT, bool STAMP = false, int HEADS = 0, bool STORE_Y = true, bool EVENK = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
     const float *__restrict__ X, long M, int ldx, const float *__restrict__ W,
     const float *__restrict__ bias, int Np, int Kp, float *__restrict__ Y, int ldy, int tiles_n,
@@ -126,6 +128,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
         const int slot = ((2 * g + h) ^ fsw) * 4;
         a_addr[g] = lds0 + 4u * ((wm * 128 + l31) * BK + slot);
         b_addr[g] = lds0 + 4u * (kTileFloats + (wn * 128 + l31) * BK + slot);
+    }
+    unsigned a_hi[4], b_hi[4];  // the same in buffer 1 (EVENK only: 65536 does not fit the 16-bit offset of ds_read)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        a_hi[g] = a_addr[g] + 4u * kBufFloats;
+        b_hi[g] = b_addr[g] + 4u * kBufFloats;
     }
 
     f32x16 acc[TM][TN];
@@ -221,54 +229,77 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_mfma_persist_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-        for (int kt = 0; kt < ksteps; ++kt) {
-            // the K-step loaded next: kt+1 of this tile, else step 0 of this workgroup's next tile
-            // (else, harmlessly, step 0 of the current tile again: nobody reads it)
-            int next_k0 = (kt + 1) * BK;
-            if (kt + 1 == ksteps) {
-                next_k0 = 0;
-                if (lin_id + G < ntiles) {
-                    long nm0;
-                    int nn0;
-                    tile_coords(lin_id + G, nm0, nn0);
-                    set_load_tile(nm0, nn0);
+        // the K-step loaded next: kt+1 of this tile, else step 0 of this workgroup's next tile
+        // (else, harmlessly, step 0 of the current tile again: nobody reads it)
+#define M360_KSETUP(KT)                                  \
+    int next_k0 = ((KT) + 1) * BK;                       \
+    if ((KT) + 1 == ksteps) {                            \
+        next_k0 = 0;                                     \
+        if (lin_id + G < ntiles) {                       \
+            long nm0;                                    \
+            int nn0;                                     \
+            tile_coords(lin_id + G, nm0, nn0);           \
+            set_load_tile(nm0, nn0);                     \
+        }                                                \
+    }
+        // every group: wait for its own operands (the only LDS reads outstanding), then run its 64 MFMAs with the next
+        // group's 8 reads (and, in group 0, the next K-step's 16 DMA instructions) in between; the barrier comes before
+        // group 3, which hides its skew and whose interleaved reads are group 0 of the NEXT step / tile
+#define M360_KSTEP(A1, B1, A2, B2, A3, B3, A0N, B0N)                                                                     \
+    do {                                                                                                                 \
+        M360_SB();                                                                                                       \
+        M360_STAMP(c0);                                                                                                  \
+        M360_WAIT_FRAG(0, fa_a, fa_b); /* R0 landed */                                                                   \
+        M360_SB();                                                                                                       \
+        M360_GROUP_PIPE(fa_a, fa_b, fb_a, fb_b, A1, B1, 3); /* group 0 (+ reads R1, + the 16 DMA instructions of step t+1) */ \
+        M360_STAMP(c1);                                                                                                  \
+        M360_WAIT_FRAG(0, fb_a, fb_b);                                                                                   \
+        M360_SB();                                                                                                       \
+        M360_GROUP_PIPE(fb_a, fb_b, fa_a, fa_b, A2, B2, 0);                                                              \
+        M360_STAMP(c2);                                                                                                  \
+        M360_WAIT_FRAG(0, fa_a, fa_b);                                                                                   \
+        M360_SB();                                                                                                       \
+        M360_GROUP_PIPE(fa_a, fa_b, fb_a, fb_b, A3, B3, 0);                                                              \
+        M360_STAMP(c3);                                                                                                  \
+        /* R3 landed => every read of `buf` by this wave is done; own DMA of the next step landed */                    \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                        \
+                     : "+v"(fb_a[0]), "+v"(fb_a[1]), "+v"(fb_a[2]), "+v"(fb_a[3]), "+v"(fb_b[0]), "+v"(fb_b[1]),         \
+                       "+v"(fb_b[2]), "+v"(fb_b[3])::"memory");                                                          \
+        M360_SB();                                                                                                       \
+        M360_STAMP(c4);                                                                                                  \
+        M360_GROUP_PIPE(fb_a, fb_b, fa_a, fa_b, A0N, B0N, 0);                                                            \
+        M360_STAMP(c5);                                                                                                  \
+        if (STAMP) {                                                                                                     \
+            st[0] += c1 - c0; st[1] += c2 - c1; st[2] += c3 - c2; st[3] += c4 - c3; st[4] += c5 - c4;                    \
+            st[5] += c5 - c0; st[6] += 1;                                                                                \
+        }                                                                                                                \
+    } while (0)
+        if (EVENK) {  // `buf` stays 0 across tiles; the inner `buf` names the K-step's buffer for the DMA target
+            for (int kt = 0; kt < ksteps; kt += 2) {
+                {
+                    M360_KSETUP(kt);
+                    const int buf = 0;
+                    M360_KSTEP(a_addr[1], b_addr[1], a_addr[2], b_addr[2], a_addr[3], b_addr[3], a_hi[0], b_hi[0]);
+                }
+                {
+                    M360_KSETUP(kt + 1);
+                    const int buf = 1;
+                    M360_KSTEP(a_hi[1], b_hi[1], a_hi[2], b_hi[2], a_hi[3], b_hi[3], a_addr[0], b_addr[0]);
                 }
             }
-            const unsigned boff = buf ? 4u * kBufFloats : 0u;
-            const unsigned noff = buf ? 0u : 4u * kBufFloats;  // the other buffer (next K-step)
-            const unsigned a1 = a_addr[1] + boff, b1 = b_addr[1] + boff, a2 = a_addr[2] + boff, b2 = b_addr[2] + boff;
-            const unsigned a3 = a_addr[3] + boff, b3 = b_addr[3] + boff, a0n = a_addr[0] + noff, b0n = b_addr[0] + noff;
-            M360_SB();
-            M360_STAMP(c0);
-            // every group: wait for its own operands (the only LDS reads outstanding), then run its 64 MFMAs
-            // with the next group's 8 reads (and, in group 0, the next K-step's 16 DMA instructions) in between
-            M360_WAIT_FRAG(0, fa_a, fa_b);  // R0 landed
-            M360_SB();
-            M360_GROUP_PIPE(fa_a, fa_b, fb_a, fb_b, a1, b1, 3);  // group 0  (+ reads R1, + the 16 DMA instructions of step t+1)
-            M360_STAMP(c1);
-            M360_WAIT_FRAG(0, fb_a, fb_b);  // R1 landed
-            M360_SB();
-            M360_GROUP_PIPE(fb_a, fb_b, fa_a, fa_b, a2, b2, 0);  // group 1  (+ reads R2)
-            M360_STAMP(c2);
-            M360_WAIT_FRAG(0, fa_a, fa_b);  // R2 landed
-            M360_SB();
-            M360_GROUP_PIPE(fa_a, fa_b, fb_a, fb_b, a3, b3, 0);  // group 2  (+ reads R3)
-            M360_STAMP(c3);
-            // R3 landed => every read of `buf` by this wave is done; own DMA of the next step landed
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
-                         : "+v"(fb_a[0]), "+v"(fb_a[1]), "+v"(fb_a[2]), "+v"(fb_a[3]), "+v"(fb_b[0]), "+v"(fb_b[1]),
-                           "+v"(fb_b[2]), "+v"(fb_b[3])::"memory");
-            M360_SB();
-            M360_STAMP(c4);
-            // group 3 hides the barrier skew; its interleaved reads are group 0 of the NEXT step / tile
-            M360_GROUP_PIPE(fb_a, fb_b, fa_a, fa_b, a0n, b0n, 0);
-            buf ^= 1;
-            M360_STAMP(c5);
-            if (STAMP) {
-                st[0] += c1 - c0; st[1] += c2 - c1; st[2] += c3 - c2; st[3] += c4 - c3; st[4] += c5 - c4;
-                st[5] += c5 - c0; st[6] += 1;
+        } else {
+            for (int kt = 0; kt < ksteps; ++kt) {
+                M360_KSETUP(kt);
+                const unsigned boff = buf ? 4u * kBufFloats : 0u;
+                const unsigned noff = buf ? 0u : 4u * kBufFloats;  // the other buffer (next K-step)
+                const unsigned a1 = a_addr[1] + boff, b1 = b_addr[1] + boff, a2 = a_addr[2] + boff, b2 = b_addr[2] + boff;
+                const unsigned a3 = a_addr[3] + boff, b3 = b_addr[3] + boff, a0n = a_addr[0] + noff, b0n = b_addr[0] + noff;
+                M360_KSTEP(a1, b1, a2, b2, a3, b3, a0n, b0n);
+                buf ^= 1;
             }
         }
+#undef M360_KSTEP
+#undef M360_KSETUP
         M360_STAMP(c0);
 
         // ---- epilogue: bias + activation.  The accumulator layout (lane = column l31, 16 registers =
