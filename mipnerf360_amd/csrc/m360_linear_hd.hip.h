@@ -21,6 +21,7 @@ namespace hd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 constexpr int BM = 128, BN = 256, BK = 32;
@@ -143,11 +144,20 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     do {                                                                                                     \
         if (!(ABL & 32)) {                                                                                   \
             _Pragma("unroll") for (int pp_ = PA; pp_ < PB; ++pp_) {                                          \
-                ev[pp_] += bq[J];                                                                            \
+                /* bias: two packed adds, ReLU: four v_max - spelled out: left to itself hipcc emits four v_add_f32 in some \
+                   instantiations, and a canonicalising v_max in front of every fmaxf on an asm result */   \
+                f32x2 lo_ = __builtin_shufflevector(ev[pp_], ev[pp_], 0, 1), hi_ = __builtin_shufflevector(ev[pp_], ev[pp_], 2, 3); \
+                const f32x2 blo_ = __builtin_shufflevector(bq[J], bq[J], 0, 1), bhi_ = __builtin_shufflevector(bq[J], bq[J], 2, 3); \
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo_) : "v"(lo_), "v"(blo_));                            \
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi_) : "v"(hi_), "v"(bhi_));                            \
+                float e0_ = lo_[0], e1_ = lo_[1], e2_ = hi_[0], e3_ = hi_[1];                                \
                 if (ACT == M360_ACT_RELU) {                                                                  \
-                    ev[pp_][0] = fmaxf(ev[pp_][0], 0.0f); ev[pp_][1] = fmaxf(ev[pp_][1], 0.0f);              \
-                    ev[pp_][2] = fmaxf(ev[pp_][2], 0.0f); ev[pp_][3] = fmaxf(ev[pp_][3], 0.0f);              \
+                    asm("v_max_f32 %0, 0, %1" : "=v"(e0_) : "v"(e0_));                                       \
+                    asm("v_max_f32 %0, 0, %1" : "=v"(e1_) : "v"(e1_));                                       \
+                    asm("v_max_f32 %0, 0, %1" : "=v"(e2_) : "v"(e2_));                                       \
+                    asm("v_max_f32 %0, 0, %1" : "=v"(e3_) : "v"(e3_));                                       \
                 }                                                                                            \
+                ev[pp_] = (f32x4){e0_, e1_, e2_, e3_};                                                       \
             }                                                                                                \
             /* pins the instructions here (machine sinking would move them next to the stores) */           \
             asm volatile("" : "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3]));                          \
