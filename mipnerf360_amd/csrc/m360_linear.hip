@@ -654,6 +654,7 @@ int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, 
             case 1: M360_HD_ABL(1); break;
             case 2: M360_HD_ABL(2); break;
             case 7: M360_HD_ABL(7); break;
+            case 16: M360_HD_ABL(16); break;
             case 64: M360_HD_ABL(64); break;
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_hd: ablate=%d", ablate);
         }

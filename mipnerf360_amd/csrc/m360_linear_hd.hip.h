@@ -13,6 +13,10 @@
 // registers, one barrier per K-step placed before the last K-group.  The k order of every output element is the
 // persistent kernel's, so results are bit-identical to the other two fp32 kernels.
 // Bias + {none, ReLU} epilogues only (the sigmoid / fused-heads / ReLU-mask layers stay with the persistent kernel).
+// Only the matrix pipe, the LDS and the scalar unit work inside the K loop: with an even number of K-steps (EVENK) the LDS
+// stage of every read is an instruction immediate; the epilogue's arithmetic (6 vector instructions per 16 bytes, which no
+// schedule hides behind the same wave's MFMAs) is all the vector work there is.  With a queue word the last tiles of a launch
+// are handed out by ticket so that XCDs with different clocks finish together (m360_linear_balanced).  DESIGN.md 4.1b.
 #pragma once
 #include "m360_common.hip.h"
 

@@ -403,3 +403,24 @@ def test_header_is_plain_c99(tmp_path):
     res = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o",
                           str(tmp_path / "c.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert res.returncode == 0, res.stdout
+
+
+def test_generated_kernel_schedules_are_current(tmp_path):
+    """The K-step / slab bodies of the two generated kernels are committed next to their sources; they must be exactly what
+    the generators in tools/ emit (a hand edit of the .inc, or a generator change without regenerating, fails here)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tool, rel in (("gen_hd_kstep.py", "mipnerf360_amd/csrc/m360_linear_hd_gen.inc"),
+                      ("gen_w32_slab.py", "mipnerf360_amd/csrc/diag/m360_linear_bf16_w32_gen.inc")):
+        spec = importlib.util.spec_from_file_location(tool[:-3], os.path.join(root, "tools", tool))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        committed = open(os.path.join(root, rel)).read()
+        mod.OUT = str(tmp_path / os.path.basename(rel))
+        argv = sys.argv
+        sys.argv = [tool]
+        try:
+            mod.main()
+        finally:
+            sys.argv = argv
+        assert open(mod.OUT).read() == committed, f"{rel} is stale: run python tools/{tool}"

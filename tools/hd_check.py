@@ -95,7 +95,7 @@ def main():
                "full_tflops": round(fl / times["full"] / 1e9, 1), "half_tflops": round(fl / times["half"] / 1e9, 1)}
         if args.ablate and M % 128 == 0 and act == 1 and (n, k) in ((1024, 1024), (256, 256), (1024, 64)):
             y = torch.empty(M, n, device=dev)
-            for abl in (0, "q", 1, 2, 7):
+            for abl in (0, "q", 1, 2, 7, 16):
                 def f():
                     qp = None
                     if abl == "q":
