@@ -383,7 +383,13 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
 #undef HD_STAMP
 #undef HD_G
 #undef HD_BARRIER_E
-#undef HD_EB
+#undef HD_KSTEP_F
+#undef HD_KSTEP_S
+#undef HD_KSTEP_P
+#undef HD_KSTEP_F0
+#undef HD_KSTEP_S1
+#undef HD_KSTEP_P0
+#undef HD_KSTEP_P1
 #undef HD_KSETUP
 #undef HD_KSETUP_S
 #undef HD_SET_EPILOGUE
