@@ -7,21 +7,36 @@ full-width fp32 proposal (4x256) + NeRF (8x1024) MLPs — BASELINE.json configs[
 weights are resident in HBM before the timed region.
 
   python bench.py --gpus 1 --steps 50 --warmup 5
+  python bench.py --gpus 8                      # starts 8 fresh rank processes itself (torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N ...
+         --master-port P bench.py --gpus N ...  # or launched from outside: RANK / LOCAL_RANK / WORLD_SIZE from the env
 
-For N > 1 every rank renders its own batch (weak scaling; rays shard with no data-path collective) and
-the rendered pixels ([rays,5] fp32 per rank) are all-gathered over RCCL each step, as the path's one
-exchange step.  Rank 0 prints ONE JSON line.
+Launching: with WORLD_SIZE unset and --gpus N > 1 this process touches no GPU; it starts `python -m torch.distributed.run`
+as a CHILD (which starts one fresh process per rank), relays rank 0's single JSON line and exits with the child's code.
+Nothing is ever exec'ed in place (`--dry-launch` prints the child command instead of running it).
 
-Other named workloads (never the default line): `--config c5` = BASELINE configs[4]'s per-GPU shape
-(8192 rays x 256 samples, bf16 MLP), `--mlp-dtype bf16` = configs[1] with the opt-in bf16 MLP.
+Default workload (c2, weak scaling): every rank renders its own 4096-ray batch (rays shard with no data-path
+collective) and the rendered pixels (20 B per ray) are all-gathered over RCCL each step, as the path's one exchange
+step.  Rank 0 prints ONE JSON line; for N > 1 it carries `rccl.ranks`, the world size read back from an all-reduce.
+After the timed region the same processes render ONE 1237 x 822 frame sharded over the N ranks (BASELINE configs[3],
+strong scaling; `strong_scaling_frame` in the line, `--frame-steps 0` to skip).
+
+Other named workloads (never the default line):
+  --config c4          BASELINE configs[3] as the timed workload: frames of 1237 x 822 rays, each rank generates and
+                       renders the rays of its own block of 4096-ray chunks, one pixel all-gather per frame, overlapped
+                       with the next frame's compute on a side stream (the serial numbers are reported beside it);
+  --config c5          BASELINE configs[4]'s per-GPU shape (8192 rays x 256 samples, bf16 MLP);
+  --mlp-dtype bf16     configs[1] with the opt-in bf16 MLP.
+  --backend gloo       (diagnostics) ranks may share a GPU, collectives staged through the host: exercises the launcher
+                       and the sharded code on a 1-GPU box; never a scaling measurement.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -33,12 +48,18 @@ FLOPS_PER_SAMPLE = 2 * (58 * 256 + 3 * 256 * 256 + 256) + 2 * (58 * 1024 + 7 * 1
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz x 256 FLOP/clk
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (never the 2:1-sparsity figure)
 PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable with a float4 copy)
+FRAME_W, FRAME_H, FRAME_CHUNKS = 1237, 822, 4096  # BASELINE configs[2]/[3]: nerf_360/garden at 4x downscale
 
 CONFIGS = {
     # name: (rays per GPU, samples, default MLP dtype, metric, workload description)
     "c2": (4096, 128, "fp32", "rendered rays/sec at 128 samples/ray",
            "nerf_360/garden-like synthetic NDC ray batch (near 0 / far 1), 4096 rays x 128 samples/ray per GPU, "
            "proposal 4x256 + NeRF 8x1024 MLPs in {mlp} on MFMA, random-init Kaiming weights (BASELINE.json configs[1])"),
+    "c4": (FRAME_CHUNKS, 128, "fp32", "rendered rays/sec at 128 samples/ray",
+           "nerf_360/garden-sized 1237x822 frame (1 016 814 rays, synthetic forward-facing NDC pose, near 0 / far 1) in "
+           "249 chunks of 4096 rays x 128 samples/ray, whole chunks sharded over the GPUs, rays generated on each GPU for "
+           "its own chunks, proposal 4x256 + NeRF 8x1024 MLPs in {mlp} on MFMA, random-init Kaiming weights, one pixel "
+           "all-gather per frame (BASELINE.json configs[3]; configs[2] at 1 GPU)"),
     "c5": (8192, 256, "bf16", "rendered rays/sec at 256 samples/ray",
            "nerf_360/bicycle-like synthetic NDC ray batch (near 0 / far 1), 8192 rays x 256 samples/ray per GPU, "
            "proposal 4x256 + NeRF 8x1024 MLPs in {mlp} on MFMA, random-init Kaiming weights (BASELINE.json configs[4] "
@@ -58,16 +79,83 @@ def kernel_source_sha():
     return h.hexdigest()
 
 
-def cpu_baseline(sd_np, rays_np, n_rays, samples, passes=3):
-    """The oracle (CPU restatement of the reference path, kind="port") on the first n_rays of the batch:
-    median of `passes` timed passes after one small warm-up."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50; c4: 3 frames)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 5; c4: 1 frame)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="c2 = the headline workload (BASELINE configs[1]); c4 = one frame sharded over the GPUs "
+                         "(configs[3], strong scaling); c5 = BASELINE configs[4]'s shape (bf16)")
+    ap.add_argument("--cpu-rays", type=int, default=None,
+                    help="rays of the batch timed on the host CPU (default: the whole 4096-ray batch for c2, 0 = skip)")
+    ap.add_argument("--mlp-dtype", choices=("fp32", "bf16"), default=None,
+                    help="override the workload's MLP precision (c2: fp32 = the headline; bf16 = opt-in reduced-precision "
+                         "MLP, reported with dtype bf16 and never comparable to the fp32 line)")
+    ap.add_argument("--frame-steps", type=int, default=None,
+                    help="c2 only: frames of the 1237x822 strong-scaling workload rendered AFTER the timed region and "
+                         "reported as `strong_scaling_frame` (default 1; 0 = skip)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL (the product); gloo = diagnostics only (ranks may share a GPU, host-staged collectives)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE: print the child command as JSON and exit")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------- launcher
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def child_command(args, argv, port):
+    passed = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + passed
+
+
+def launch(args, argv) -> int:
+    """Parent of an N > 1 run started without a launcher.  Imports no torch, touches no GPU: the ranks are fresh child
+    processes of `torch.distributed.run`, itself a child of this process (never an exec in place)."""
+    cmd = child_command(args, argv, free_port())
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd, "ranks": args.gpus}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:  # ranks' stderr goes straight through; stdout is scanned for rank 0's JSON line
+        s = out.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(s, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc != 0:
+        print(f"bench.py: {args.gpus}-rank child run failed with exit code {rc}", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(sd_np, rays_np, n_rays, samples):
+    """The oracle (CPU restatement of the reference path, kind="port") on the first n_rays of the batch as ONE chunk:
+    one timed pass for >= 2048 rays (about 20 s), else the median of 3, after a small warm-up."""
     from oracle import ref_path as O
     sd = O.to_torch_state_dict(sd_np)
     sub = {k: v[:n_rays] for k, v in rays_np.items()}
     hp = O.Hyper(num_samples=samples)
     O.forward(O.rays_from_numpy({k: v[:32] for k, v in rays_np.items()}), sd, hp)  # page in / thread pool warm-up
     times, out = [], None
-    for _ in range(passes):
+    for _ in range(1 if n_rays >= 2048 else 3):
         t0 = time.perf_counter()
         out = O.forward(O.rays_from_numpy(sub), sd, hp)
         times.append(time.perf_counter() - t0)
@@ -75,27 +163,213 @@ def cpu_baseline(sd_np, rays_np, n_rays, samples, passes=3):
     return n_rays / dt, times, out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
-                    help="c2 = the headline workload (BASELINE configs[1]); c5 = BASELINE configs[4]'s shape (bf16)")
-    ap.add_argument("--cpu-rays", type=int, default=None,
-                    help="rays of the batch timed on the host CPU, 3 passes (default 1024 for c2, 0 = skip)")
-    ap.add_argument("--mlp-dtype", choices=("fp32", "bf16"), default=None,
-                    help="override the workload's MLP precision (c2: fp32 = the headline; bf16 = opt-in reduced-precision "
-                         "MLP, reported with dtype bf16 and never comparable to the fp32 line)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------- rank process
+class Comm:
+    """The few collectives bench.py itself needs (barrier, max / gather of timings), on RCCL or - diagnostics - gloo."""
+
+    def __init__(self, world, rank, dev, backend):
+        import torch
+        import torch.distributed as dist
+        self.world, self.rank, self.dev, self.backend, self.dist, self.torch = world, rank, dev, backend, dist, torch
+        self.info = None
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo")
+            ones = torch.ones(1, device=self.cdev)
+            dist.all_reduce(ones)  # the world size as the collective library saw it
+            self.info = {"backend": backend, "ranks": int(ones.item())}
+            if backend == "nccl":
+                self.info["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            else:
+                self.info["note"] = "diagnostics backend: collectives staged through the host, NOT a scaling measurement"
+
+    @property
+    def cdev(self):
+        return self.dev if self.backend == "nccl" else self.torch.device("cpu")
+
+    def barrier(self):
+        if self.world > 1:
+            if self.backend == "nccl":
+                self.dist.barrier(device_ids=[self.dev.index])
+            else:
+                self.dist.barrier()
+
+    def fence(self):
+        self.barrier()
+        self.torch.cuda.synchronize()
+
+    def max(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_floats(self, vals):
+        """-> list over ranks of the list `vals`"""
+        if self.world == 1:
+            return [list(vals)]
+        mine = self.torch.tensor(list(vals), dtype=self.torch.float64, device=self.cdev)
+        allr = [self.torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(allr, mine)
+        return [[float(x) for x in t] for t in allr]
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def roofline_from_records(recs, S, bf16, config_name, _lib):
+    lin_kind = _lib.K_LINEAR_BF16 if bf16 else _lib.K_LINEAR
+    durs = [r["ms"] for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == HN and r["M"] == S]
+    if not durs:
+        return None
+    flops = 2.0 * S * HN * HN
+    avg_ms = sum(durs) / len(durs)
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    traffic, traffic_note = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch counter bytes from separate rocprofv3 --pmc passes
+    if os.path.exists(tpath) and not bf16 and config_name in ("c2", "c4"):
+        tj = json.load(open(tpath))
+        if tj.get("kernel_source_sha256") == kernel_source_sha():
+            traffic = tj.get("linear_f32_mfma_1024x1024_bytes_per_launch")
+            traffic_note = ("fabric-side counter bytes per launch (FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, gfx950 corrections): "
+                            "Infinity-Cache hits included, so W re-streamed per tile counts; algorithmic bytes are 4.30 GB")
+        else:
+            traffic_note = "profiles/traffic.json was measured on different kernel sources (stale): not reported"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    kname = "linear_bf16_pp_kernel" if bf16 else "linear_f32_hd_kernel"
+    roofline = {"bound": "mfma", "kernel": f"{kname} (1024x1024 layer, M={S})", "achieved": round(achieved, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "traffic": traffic, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),
+                "median_launch_ms": round(statistics.median(durs), 4), "flops_per_launch": flops}
+    if traffic_note:
+        roofline["traffic_note"] = traffic_note
+    return roofline
+
+
+def hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib):
+    """HBM-bound kernels of the path: algorithmic bytes / mean launch duration.  The finishers read the
+    last layer's partial head sums [S, slots, heads] fp32 for the rows the fused epilogue covered, activation rows else."""
+    S = n_rays * samples
+    el = 2 if bf16 else 4
+    lib = _lib.lib()
+    enc = [r for r in recs if r["kind"] == _lib.K_ENCODE]
+    in_pad = enc[0]["n_pad"] if enc else 64  # row length of the MLP input the encoder writes (58 channels, zero-padded)
+
+    def finish_in_bytes(width, heads):
+        fused = int(lib.m360_linear_heads_fused_rows(S, width, int(bf16)))
+        return fused * int(lib.m360_linear_heads_slots(width, int(bf16))) * heads * 4 + (S - fused) * width * el
+
+    out = {}
+    fused_last = [r["ms"] for r in recs if r["kind"] == _lib.K_LINEAR_HEADS and r["n_pad"] == HN and r["M"] == S]
+    if fused_last:
+        ms = sum(fused_last) / len(fused_last)
+        out["nerf_last_layer_fused_heads"] = {"avg_launch_ms": round(ms, 4), "tflops": round(2.0 * S * HN * HN / ms / 1e9, 1),
+                                              "launches": len(fused_last), "note": "MFMA-bound; listed for completeness"}
+    for kind, name, nbytes in (
+            (_lib.K_ENCODE, "encode_features", S * in_pad * el + n_rays * (48 + 4 * (samples + 1))),
+            (_lib.K_PROP_FINISH, "prop_finish", finish_in_bytes(HP, 1) + n_rays * (4 * (samples + 1) + 12 + 4 * samples + 4 * (samples + 1))),
+            (_lib.K_NERF_FINISH, "nerf_finish", finish_in_bytes(HN, 4) + n_rays * (4 * (samples + 1) + 12 + 20))):
+        d = [r["ms"] for r in recs if r["kind"] == kind and r["M"] == S]  # full chunks only (a frame ends with a partial one)
+        if d:
+            ms = sum(d) / len(d)
+            out[name] = {"avg_launch_ms": round(ms, 4), "algorithmic_bytes": nbytes,
+                         "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                         "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 3), "launches": len(d)}
+    return out
+
+
+FRAME_POSE = [[1.0, 0.0, 0.0, 0.05], [0.0, 1.0, 0.0, -0.02], [0.0, 0.0, 1.0, 0.1]]
+
+
+def frame_pipeline(model, comm, frames, warmup, overlap, width=FRAME_W, height=FRAME_H, chunks=FRAME_CHUNKS):
+    """`frames` frames of width x height rays rendered by all ranks together: per frame every rank generates the rays of
+    its own block of chunks (m360_generate_rays_span), renders them into the send block of a PixelGather and the
+    pixels are all-gathered.  overlap=True: the all-gather + assembly of frame i run on a side stream under the compute
+    of frame i + 1 (two send / receive slots); overlap=False: everything on one stream.
+    -> dict with wall seconds (max over ranks) and per-rank medians."""
+    import torch
+
+    from mipnerf360_amd.distributed import PixelGather, partition_efficiency, render_local_block
+    from mipnerf360_amd.intern.ray import generate_rays
+    dev, world = comm.dev, comm.world
+    n = width * height
+    pg = PixelGather(n, chunks, dev, slots=2)
+    pose = torch.tensor(FRAME_POSE, dtype=torch.float32, device=dev)
+    focal = 0.9 * width
+    outs = [(torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)) for _ in range(2)]
+    side = torch.cuda.Stream(device=dev) if (overlap and world > 1) else None
+    done = [None, None]
+    total = warmup + frames
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(total)]
+
+    def one_frame(i):
+        s = i % 2
+        cur = torch.cuda.current_stream(dev)
+        if side is not None and done[s] is not None:
+            cur.wait_event(done[s])  # the gather that read send[s] two frames ago must be through
+        ev[i][0].record()
+        local = generate_rays(pose, height, width, focal, 0.0, 1.0, True, span=pg.span)
+        render_local_block(model, None, chunks, pg, slot=s, local_rays=local)
+        ev[i][1].record()
+        if world > 1:
+            if side is not None:
+                side.wait_event(ev[i][1])
+                with torch.cuda.stream(side):
+                    ev[i][2].record()
+                    pg.gather(s)
+                    pg.assemble(s, out=outs[s])
+                    ev[i][3].record()
+                    done[s] = ev[i][3]
+            else:
+                ev[i][2].record()
+                pg.gather(s)
+                pg.assemble(s, out=outs[s])
+                ev[i][3].record()
+        else:
+            pg.recv[s].view(-1).copy_(pg.send[s])
+            pg.assemble(s, out=outs[s])
+
+    for i in range(warmup):
+        one_frame(i)
+    comm.fence()
+    t0 = time.perf_counter()
+    for i in range(warmup, total):
+        one_frame(i)
+    comm.fence()
+    elapsed = comm.max(time.perf_counter() - t0)
+    compute = [e[0].elapsed_time(e[1]) for e in ev[warmup:]]
+    gather = [e[2].elapsed_time(e[3]) for e in ev[warmup:]] if world > 1 else [0.0]
+    per_rank = comm.gather_floats([statistics.median(compute), statistics.median(gather), float(pg.span[1] - pg.span[0])])
+    last = outs[(total - 1) % 2]
+    finite = bool(torch.isfinite(last[0]).all() and torch.isfinite(last[1]).all() and torch.isfinite(last[2]).all())
+    n_chunks = (n + chunks - 1) // chunks
+    return {"frames": frames, "rays_per_frame": n, "seconds": round(elapsed, 4), "seconds_per_frame": round(elapsed / max(frames, 1), 4),
+            "rays_per_s": round(n * frames / elapsed, 1), "n_chunks": n_chunks,
+            "chunks_per_rank": (n_chunks + world - 1) // world,
+            "partition_efficiency_bound": round(partition_efficiency(n, chunks, world), 4),
+            "overlap": bool(side is not None), "finite": finite,
+            "per_rank": [{"rank": r, "rays": int(v[2]), "compute_ms_median": round(v[0], 2),
+                          "all_gather_ms_median": round(v[1], 3)} for r, v in enumerate(per_rank)]}
+
+
+def worker(args):
     n_rays, samples, mlp_default, metric, workload = CONFIGS[args.config]
     mlp_dtype = args.mlp_dtype or mlp_default
+    frame_cfg = args.config == "c4"
+    steps = args.steps if args.steps is not None else (3 if frame_cfg else 50)
+    warmup = args.warmup if args.warmup is not None else (1 if frame_cfg else 5)
     if args.cpu_rays is None:
-        args.cpu_rays = 1024 if args.config == "c2" else 0
+        args.cpu_rays = n_rays if args.config == "c2" else 0
+    if args.frame_steps is None:
+        args.frame_steps = 1 if (args.config == "c2" and mlp_dtype == "fp32") else 0
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
     from mipnerf360_amd import _lib, synthetic
     from mipnerf360_amd.intern.ray import Rays
@@ -105,170 +379,170 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    ndev = torch.cuda.device_count()
+    # one GPU per rank.  With fewer devices than ranks the ranks wrap around: RCCL then refuses the duplicate device
+    # with its own error (the gloo diagnostics backend lets ranks share a GPU).
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
+    comm = Comm(world, rank, dev, args.backend)
 
     sd_np = synthetic.make_state_dict(HP, HN, seed=0)
-    rays_np = synthetic.make_rays("garden", n_rays, seed=1 + rank)
     bf16 = mlp_dtype == "bf16"
     model = mipNeRF360(randomized=False, num_samples=samples, hidden_proposal=HP, hidden_nerf=HN, white_bkgd=False,
                        device=dev, mlp_dtype=mlp_dtype)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
     model.eval()  # rendering: weights are packed once, outside the timed region
-    rays = Rays(*[torch.from_numpy(rays_np[k]).to(dev) for k in synthetic.RAY_FIELDS])
-    gathered = torch.empty(world * n_rays, 5, device=dev) if world > 1 else None
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record()
-        with torch.no_grad():  # rendering, as in render_image (model.py:261); with grad enabled the mirrors keep a training tape
-            rgb, d, a = model(rays)  # the public forward: (rgb[B,3], distance[B], acc[B])
-        if i is not None:
-            ev[i][1].record()
-        if world > 1:
-            pixels = torch.cat([rgb, d[:, None], a[:, None]], 1)  # 20 B per ray
-            dist.all_gather_into_tensor(gathered, pixels)
-        if i is not None:
-            ev[i][2].record()
-        return rgb, d, a
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    prof = _lib.Prof(40 * max(args.steps, 1))  # caller-owned HIP-event recorder: every kernel of the stage drivers
-    model.set_prof(prof)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    model.set_prof(None)
-    compute_ms = [e[0].elapsed_time(e[1]) for e in ev]
-    gather_ms = [e[1].elapsed_time(e[2]) for e in ev]
-    step_ms = [e[0].elapsed_time(e[2]) for e in ev]
-    per_rank = None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        mine = torch.tensor([statistics.median(compute_ms), statistics.median(gather_ms)], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "compute_ms_median": round(float(t[0]), 3), "all_gather_ms_median": round(float(t[1]), 3)}
-                    for r, t in enumerate(allr)]
+        from mipnerf360_amd.distributed import check_replicas
+        check_replicas(model)  # one 32-byte all-reduce at setup: every rank holds the same weights / sample counts
+
+    line = {"metric": metric, "value": None, "unit": "rays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if frame_cfg else "weak",
+            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic"}
+    S = n_rays * samples
+    prof = None
+
+    if frame_cfg:
+        # ---------------------------------------------------------------- c4: frames sharded over the ranks
+        n_frame = FRAME_W * FRAME_H
+        chunks_mine = (n_frame + FRAME_CHUNKS - 1) // FRAME_CHUNKS
+        prof = _lib.Prof(40 * (chunks_mine // world + 2) * (steps + warmup) * 2 + 64)
+        model.set_prof(prof)
+        res = frame_pipeline(model, comm, steps, warmup, overlap=True)
+        model.set_prof(None)
+        recs = prof.records()
+        serial = frame_pipeline(model, comm, steps, warmup, overlap=False) if world > 1 else None
+        elapsed = res["seconds"]
+        line.update(value=res["rays_per_s"], ms_per_step=round(1e3 * elapsed / max(steps, 1), 3))
+        line["config"] = {"workload": workload.format(mlp="bf16 (fp32 accumulate)" if bf16 else "fp32"), "name": "c4",
+                          "rays_per_frame": n_frame, "samples_per_ray": samples, "chunks": FRAME_CHUNKS,
+                          "n_chunks": res["n_chunks"], "chunks_per_rank": res["chunks_per_rank"],
+                          "partition_efficiency_bound": res["partition_efficiency_bound"],
+                          "parallelism": f"whole chunks sharded over {world} GPU(s), replicated weights" +
+                                         (", one RCCL all-gather of the pixel block per frame overlapped with the next "
+                                          "frame's compute" if world > 1 else ""),
+                          "flops_per_ray": FLOPS_PER_SAMPLE * samples,
+                          "whole_path_tflops": round(res["rays_per_s"] * FLOPS_PER_SAMPLE * samples / 1e12, 2)}
+        line["frame"] = {"overlapped": res, "serial": serial}
+    else:
+        # ---------------------------------------------------------------- c2 / c5: one batch per rank and step
+        rays_np = synthetic.make_rays("garden", n_rays, seed=1 + rank)
+        rays = Rays(*[torch.from_numpy(rays_np[k]).to(dev) for k in synthetic.RAY_FIELDS])
+        pg = None
+        if world > 1:
+            from mipnerf360_amd.distributed import PixelGather
+            pg = PixelGather(world * n_rays, n_rays, dev)  # one chunk per rank: preallocated send / receive blocks
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+
+        def step(i=None):
+            if i is not None:
+                ev[i][0].record()
+            with torch.no_grad():  # rendering, as in render_image (model.py:261); with grad enabled the mirrors keep a training tape
+                rgb, d, a = model(rays)  # the public forward: (rgb[B,3], distance[B], acc[B])
+            if i is not None:
+                ev[i][1].record()
+            if pg is not None:  # the path's one exchange step: 20 B per ray
+                for dst, src in zip(pg.local_outputs(), (rgb, d, a)):
+                    dst.copy_(src)
+                pg.gather()
+            if i is not None:
+                ev[i][2].record()
+            return rgb, d, a
+
+        for _ in range(warmup):
+            step()
+        prof = _lib.Prof(40 * max(steps, 1))  # caller-owned HIP-event recorder: every kernel of the stage drivers
+        model.set_prof(prof)
+        comm.fence()
+        t0 = time.perf_counter()
+        out = None
+        for i in range(steps):
+            out = step(i)
+        comm.fence()
+        elapsed = time.perf_counter() - t0
+        model.set_prof(None)
+        compute_ms = [e[0].elapsed_time(e[1]) for e in ev]
+        gather_ms = [e[1].elapsed_time(e[2]) for e in ev]
+        step_ms = [e[0].elapsed_time(e[2]) for e in ev]
+        elapsed = comm.max(elapsed)
+        per_rank = None
+        if world > 1:
+            allr = comm.gather_floats([statistics.median(compute_ms), statistics.median(gather_ms)])
+            per_rank = [{"rank": r, "compute_ms_median": round(t[0], 3), "all_gather_ms_median": round(t[1], 3)}
+                        for r, t in enumerate(allr)]
+        recs = prof.records()
+        value = world * n_rays * steps / elapsed
+        med_ms = statistics.median(step_ms) if step_ms else 0.0
+        line.update(value=round(value, 1), ms_per_step=round(1e3 * elapsed / max(steps, 1), 3),
+                    ms_per_step_median=round(med_ms, 3),
+                    value_at_median_step=round(world * n_rays / (med_ms * 1e-3), 1) if med_ms else None)
+        line["config"] = {"workload": workload.format(mlp="bf16 (fp32 accumulate)" if bf16 else "fp32"),
+                          "name": args.config, "rays_per_gpu": n_rays, "samples_per_ray": samples,
+                          "parallelism": f"rays sharded over {world} GPU(s), replicated weights" +
+                                         (f", RCCL all-gather of the [{n_rays},5] pixel block per step" if world > 1 else ""),
+                          "flops_per_ray": FLOPS_PER_SAMPLE * samples,
+                          "whole_path_tflops": round(value * FLOPS_PER_SAMPLE * samples / 1e12, 2)}
+        if per_rank:
+            line["per_rank"] = per_rank
 
     # ---- per-kernel numbers from the event records (HIP events on the launch stream, inside the timed region)
-    recs = prof.records()
     prof.close()
-    S = n_rays * samples
-    lin_kind = _lib.K_LINEAR_BF16 if bf16 else _lib.K_LINEAR
-    durs = [r["ms"] for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == HN and r["M"] == S]
-    roofline = None
-    if durs:
-        flops = 2.0 * S * HN * HN
-        avg_ms = sum(durs) / len(durs)
-        achieved = flops / (avg_ms * 1e-3) / 1e12
-        traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from separate rocprofv3 --pmc passes
-        if os.path.exists(tpath) and not bf16 and args.config == "c2":
-            tj = json.load(open(tpath))
-            if tj.get("kernel_source_sha256") == kernel_source_sha():
-                traffic = tj.get("linear_f32_mfma_1024x1024_bytes_per_launch")
-            else:
-                traffic_note = "profiles/traffic.json was measured on different kernel sources (stale): not reported"
-        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-        kname = "linear_bf16_pp_kernel" if bf16 else "linear_f32_hd_kernel"
-        roofline = {"bound": "mfma", "kernel": f"{kname} (1024x1024 layer, M={S})", "achieved": round(achieved, 2),
-                    "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": traffic, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),
-                    "median_launch_ms": round(statistics.median(durs), 4), "flops_per_launch": flops}
-        if traffic_note:
-            roofline["traffic_note"] = traffic_note
-    # HBM-bound kernels of the path: algorithmic bytes / mean launch duration.  The finishers read the
-    # last layer's partial head sums [S, slots, heads] fp32 for the rows the fused epilogue covered, activation rows else.
-    el = 2 if bf16 else 4
-    in_pad = 64
-    lib = _lib.lib()
+    line["roofline"] = roofline_from_records(recs, S, bf16, args.config, _lib)
+    line["hbm_kernels"] = hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib)
+    line["rccl"] = comm.info
 
-    def finish_in_bytes(width, heads):
-        fused = int(lib.m360_linear_heads_fused_rows(S, width, int(bf16)))
-        return fused * int(lib.m360_linear_heads_slots(width, int(bf16))) * heads * 4 + (S - fused) * width * el
-
-    hbm_kernels = {}
-    fused_last = [r["ms"] for r in recs if r["kind"] == _lib.K_LINEAR_HEADS and r["n_pad"] == HN]
-    if fused_last:
-        ms = sum(fused_last) / len(fused_last)
-        hbm_kernels["nerf_last_layer_fused_heads"] = {"avg_launch_ms": round(ms, 4), "tflops": round(2.0 * S * HN * HN / ms / 1e9, 1),
-                                                      "launches": len(fused_last), "note": "MFMA-bound; listed for completeness"}
-    for kind, name, nbytes in (
-            (_lib.K_ENCODE, "encode_features", S * in_pad * el + n_rays * (48 + 4 * (samples + 1))),
-            (_lib.K_PROP_FINISH, "prop_finish", finish_in_bytes(HP, 1) + n_rays * (4 * (samples + 1) + 12 + 4 * samples + 4 * (samples + 1))),
-            (_lib.K_NERF_FINISH, "nerf_finish", finish_in_bytes(HN, 4) + n_rays * (4 * (samples + 1) + 12 + 20))):
-        d = [r["ms"] for r in recs if r["kind"] == kind]
-        if d:
-            ms = sum(d) / len(d)
-            hbm_kernels[name] = {"avg_launch_ms": round(ms, 4), "algorithmic_bytes": nbytes,
-                                 "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
-                                 "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 3), "launches": len(d)}
+    if not frame_cfg and args.frame_steps > 0:
+        # BASELINE configs[3] beside the headline: the same processes render one frame together (strong scaling)
+        fr = frame_pipeline(model, comm, args.frame_steps, 0, overlap=False)
+        fr["workload"] = CONFIGS["c4"][4].format(mlp="fp32")
+        line["strong_scaling_frame"] = fr
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        comm.close()
         return
 
-    total_rays = world * n_rays * args.steps
-    value = total_rays / elapsed
-    med_ms = statistics.median(step_ms)
-    line = {
-        "metric": metric,
-        "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-        "ms_per_step_median": round(med_ms, 3), "value_at_median_step": round(world * n_rays / (med_ms * 1e-3), 1),
-        "config": {"workload": workload.format(mlp="bf16 (fp32 accumulate)" if bf16 else "fp32"),
-                   "name": args.config, "rays_per_gpu": n_rays, "samples_per_ray": samples,
-                   "parallelism": f"rays sharded over {world} GPU(s), replicated weights" +
-                                  (f", RCCL all-gather of [{n_rays},5] pixels per step" if world > 1 else ""),
-                   "flops_per_ray": FLOPS_PER_SAMPLE * samples,
-                   "whole_path_tflops": round(value * FLOPS_PER_SAMPLE * samples / 1e12, 2)},
-        "roofline": roofline,
-        "hbm_kernels": hbm_kernels,
-    }
-    if per_rank:
-        line["per_rank"] = per_rank
-    if world == 1 and args.cpu_rays > 0:
+    if not frame_cfg and world == 1 and args.cpu_rays > 0:
         n_cpu = min(args.cpu_rays, n_rays)
         cpu_rps, cpu_times, o = cpu_baseline(sd_np, rays_np, n_cpu, samples)
         line["cpu_baseline"] = {"value": round(cpu_rps, 2), "unit": "rays/s", "cores": torch.get_num_threads(),
                                 "kind": "port",
-                                "sample": f"first {n_cpu} rays of the same {n_rays}x{samples} batch as one chunk, median of "
-                                          f"{len(cpu_times)} passes ({', '.join(f'{t:.1f}' for t in cpu_times)} s) "
+                                "sample": f"{'all' if n_cpu == n_rays else 'first'} {n_cpu} rays of the same {n_rays}x{samples} batch "
+                                          f"as one chunk, {len(cpu_times)} pass(es) ({', '.join(f'{t:.1f}' for t in cpu_times)} s) "
                                           f"(oracle/ref_path.py, vectorised torch-CPU fp32, closed-form Jacobian; the "
                                           f"unmodified reference measured 17.9-19.1 rays/s on 8 cores, BASELINE.md)",
                                 "host_cpus": os.cpu_count()}
-        # parity + PSNR of the same sub-batch rendered as its own chunk on the GPU
-        sub = Rays(*[f[:n_cpu].contiguous() for f in rays])
-        with torch.no_grad():
-            g_rgb, g_dist, g_acc = model(sub)
+        # parity + PSNR: with the whole batch on the CPU the timed forward's own output is compared (same chunk, same
+        # contraction norm); a sub-batch is re-rendered as its own chunk on the GPU
+        if n_cpu == n_rays:
+            g_rgb, g_dist, g_acc = out
+        else:
+            sub = Rays(*[f[:n_cpu].contiguous() for f in rays])
+            with torch.no_grad():
+                g_rgb, g_dist, g_acc = model(sub)
         mse = float(((g_rgb.cpu() - o[0]) ** 2).mean())
         line["parity"] = {"max_abs_rgb": float((g_rgb.cpu() - o[0]).abs().max()),
                           "max_abs_acc": float((g_acc.cpu() - o[2]).abs().max()),
-                          "psnr_vs_cpu_db": round(-10.0 * float(np.log10(max(mse, 1e-20))), 2), "rays": n_cpu}
+                          "max_abs_dist": float((g_dist.cpu() - o[1]).abs().max()),
+                          "psnr_vs_cpu_db": round(-10.0 * float(np.log10(max(mse, 1e-20))), 2), "rays": n_cpu,
+                          "note": "HIP forward of the timed region vs the CPU oracle on the same rays as ONE chunk"}
     print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    comm.close()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch(args, argv))
+    if args.dry_launch:
+        print(json.dumps({"launch": None, "ranks": 1, "note": "single process: nothing to launch"}), flush=True)
+        return
+    worker(args)
 
 
 if __name__ == "__main__":

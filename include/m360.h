@@ -234,6 +234,14 @@ int m360_generate_rays(const float *cam_to_world, int n_cams, int h, int w, floa
                        float *viewdirs, float *radii, float *near_out, float *far_out,
                        m360_stream_t stream);
 
+/* The same rays for the flat pixel span [first, first+count) of the n_cams*h*w pixels only (output row 0 = pixel
+ * `first`): what one rank of a ray-sharded frame render needs (each GPU generates the rays of its own
+ * block of chunks, nothing but the pose is broadcast).  Values are bit-identical to the rows of the full call. */
+int m360_generate_rays_span(const float *cam_to_world, int n_cams, int h, int w, float focal, float near,
+                            float far, int ndc, float ndc_near, long first, long count, float *origins,
+                            float *directions, float *viewdirs, float *radii, float *near_out, float *far_out,
+                            m360_stream_t stream);
+
 /* NDC conversion of n rays.  Replaces intern/ray.py:59-79 (convert_to_ndc). */
 int m360_convert_to_ndc(const float *origins /*[n,3]*/, const float *directions /*[n,3]*/, long n,
                         float focal, int w, int h, float near, float *origins_out, float *directions_out,

@@ -109,6 +109,7 @@ SIGNATURES = {
     "m360_visualize_depth_ex": (_i, [_vp, _vp, _i, _i, _fl, _fl, _i, _i, _fl, _i, _fl, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m360_visualize_composite": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "m360_generate_rays": (_i, [_vp, _i, _i, _i, _fl, _fl, _fl, _i, _fl, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "m360_generate_rays_span": (_i, [_vp, _i, _i, _i, _fl, _fl, _fl, _i, _fl, _l, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "m360_convert_to_ndc": (_i, [_vp, _vp, _l, _fl, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_prop_finish": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_nerf_finish": (_i, [_vp, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

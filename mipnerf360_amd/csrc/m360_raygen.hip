@@ -54,16 +54,18 @@ __device__ __forceinline__ float dist3(const float a[3], const float b[3]) {
 }
 
 template <bool NDC>
-__global__ void generate_rays_kernel(const float *__restrict__ c2w, int n_cams, int h, int w, float focal,
+__global__ void generate_rays_kernel(const float *__restrict__ c2w, long first, long count, int h, int w, float focal,
                                      float sx, float sy, float near, float far, float ndc_near,
                                      float *__restrict__ origins, float *__restrict__ directions,
                                      float *__restrict__ viewdirs, float *__restrict__ radii,
                                      float *__restrict__ near_out, float *__restrict__ far_out) {
+    // idx = row of the OUTPUT arrays; pix = flat pixel index over all cameras (the span starts at `first`)
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long per_cam = (long)h * w;
-    if (idx >= per_cam * n_cams) return;
-    const int c = (int)(idx / per_cam);
-    const int y = (int)((idx % per_cam) / w), x = (int)(idx % w);
+    if (idx >= count) return;
+    const long pix = first + idx;
+    const int c = (int)(pix / per_cam);
+    const int y = (int)((pix % per_cam) / w), x = (int)(pix % w);
     const Cam m = load_cam(c2w, c);
     float d[3];
     pixel_dir(m, x, y, h, w, focal, d);
@@ -136,20 +138,30 @@ using namespace m360;
 
 extern "C" {
 
-int m360_generate_rays(const float *cam_to_world, int n_cams, int h, int w, float focal, float near, float far,
-                       int ndc, float ndc_near, float *origins, float *directions, float *viewdirs, float *radii,
-                       float *near_out, float *far_out, m360_stream_t stream) {
+int m360_generate_rays_span(const float *cam_to_world, int n_cams, int h, int w, float focal, float near, float far,
+                            int ndc, float ndc_near, long first, long count, float *origins, float *directions,
+                            float *viewdirs, float *radii, float *near_out, float *far_out, m360_stream_t stream) {
     if (!cam_to_world || !origins || !directions || !viewdirs || !radii || !near_out || !far_out || n_cams < 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_generate_rays: null pointer or negative camera count");
     if (h < 3 || w < 3 || !(focal > 0.0f)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_generate_rays: h=%d w=%d must be >= 3 (the reference's radii padding reads difference n-3), focal=%g > 0", h, w, (double)focal);
-    if (n_cams == 0) return M360_OK;
     const long n = (long)n_cams * h * w;
+    if (first < 0 || count < 0 || first + count > n)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_generate_rays_span: span [%ld, %ld) outside the %ld pixels of %d camera(s)", first, first + count, n, n_cams);
+    if (count == 0) return M360_OK;
     const float sx = (float)((2.0 * (double)focal) / (double)w), sy = (float)((2.0 * (double)focal) / (double)h);
-    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    dim3 grid((unsigned)((count + 255) / 256)), block(256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (ndc) hipLaunchKernelGGL(generate_rays_kernel<true>, grid, block, 0, st, cam_to_world, n_cams, h, w, focal, sx, sy, near, far, ndc_near, origins, directions, viewdirs, radii, near_out, far_out);
-    else hipLaunchKernelGGL(generate_rays_kernel<false>, grid, block, 0, st, cam_to_world, n_cams, h, w, focal, sx, sy, near, far, ndc_near, origins, directions, viewdirs, radii, near_out, far_out);
+    if (ndc) hipLaunchKernelGGL(generate_rays_kernel<true>, grid, block, 0, st, cam_to_world, first, count, h, w, focal, sx, sy, near, far, ndc_near, origins, directions, viewdirs, radii, near_out, far_out);
+    else hipLaunchKernelGGL(generate_rays_kernel<false>, grid, block, 0, st, cam_to_world, first, count, h, w, focal, sx, sy, near, far, ndc_near, origins, directions, viewdirs, radii, near_out, far_out);
     return check_launch("generate_rays");
+}
+
+int m360_generate_rays(const float *cam_to_world, int n_cams, int h, int w, float focal, float near, float far,
+                       int ndc, float ndc_near, float *origins, float *directions, float *viewdirs, float *radii,
+                       float *near_out, float *far_out, m360_stream_t stream) {
+    return m360_generate_rays_span(cam_to_world, n_cams, h, w, focal, near, far, ndc, ndc_near, 0,
+                                   n_cams < 0 ? 0 : (long)n_cams * h * w, origins, directions, viewdirs, radii, near_out,
+                                   far_out, stream);
 }
 
 int m360_convert_to_ndc(const float *origins, const float *directions, long n, float focal, int w, int h, float near,

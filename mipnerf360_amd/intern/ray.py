@@ -34,10 +34,12 @@ def convert_to_ndc(origins, directions, focal, w, h, near=1.0):
     return ops.convert_to_ndc(origins, directions, focal, w, h, near)
 
 
-def generate_rays(cam_to_world, h, w, focal, near, far, ndc=False):
+def generate_rays(cam_to_world, h, w, focal, near, far, ndc=False, span=None):
     """On-device equivalent of NeRFDataset.generate_rays + flatten_to_pytorch (dataset.py:109-145,147-150)
-    and, with ndc=True, of LLFF.generate_rays (dataset.py:364-387) -> Rays of [n*h*w, .] device tensors."""
-    return Rays(*ops.generate_rays(cam_to_world, h, w, focal, near, far, ndc))
+    and, with ndc=True, of LLFF.generate_rays (dataset.py:364-387) -> Rays of [n*h*w, .] device tensors.
+    `span=(first, end)` (extension): only the rays of that flat pixel range, bit-identical to those rows of the
+    full call - what one rank of a ray-sharded frame render generates for its own block of chunks."""
+    return Rays(*ops.generate_rays(cam_to_world, h, w, focal, near, far, ndc, span=span))
 
 
 def sample_along_rays(origins, directions, radii, num_samples, near, far, randomized):

@@ -595,17 +595,24 @@ class mipNeRF360(nn.Module):
         return outs["rgb"], outs["distance"], outs["acc"]
 
     # ------------------------------------------------------------------ chunked frame rendering
-    def render_rays(self, rays, chunks=4096):
+    def render_rays(self, rays, chunks=4096, out=None):
         """Chunk loop of model.py:261-269 with everything resident on the device: one H2D copy of the
         ray batch, outputs written in place, no per-chunk sync.  The chunk PARTITION is the reference's
         (consecutive blocks of `chunks` rays) because the global contraction norm makes results
-        chunk-dependent.  Returns float device tensors (rgb[n,3], distance[n], acc[n])."""
+        chunk-dependent.  Returns float device tensors (rgb[n,3], distance[n], acc[n]); `out` = three such
+        contiguous tensors to write into (the send block of a multi-GPU pixel gather, distributed.PixelGather)."""
         dev = torch.device(self.device)
         rays = namedtuple_map(lambda r: torch.as_tensor(r).to(device=dev, dtype=torch.float32).contiguous(), rays)
         length = rays[0].shape[0]
-        rgb = torch.empty(length, 3, device=dev)
-        dist = torch.empty(length, device=dev)
-        acc = torch.empty(length, device=dev)
+        if out is not None:
+            rgb, dist, acc = out
+            for t, shape in ((rgb, (length, 3)), (dist, (length,)), (acc, (length,))):
+                if tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous() or t.device != rays[0].device:
+                    raise RuntimeError(f"render_rays: `out` tensors must be contiguous float32 {shape} on {rays[0].device}")
+        else:
+            rgb = torch.empty(length, 3, device=dev)
+            dist = torch.empty(length, device=dev)
+            acc = torch.empty(length, device=dev)
         fused = not self.prop_net.randomized and not self.nerf_net.randomized and not self.mutate_like_reference
         # Small chunks (the reference's default is 128 rays, config.py:49) are launched many at a time: the chunk
         # partition only matters through the per-chunk contraction norm, which the kernels keep per group of `chunks`

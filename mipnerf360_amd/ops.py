@@ -456,19 +456,23 @@ def prop_finish_fused(act, head_part, fused_rows, head_w, head_b, density_bias, 
 
 # ----------------------------------------------------------------------------- ray generation
 def generate_rays(cam_to_world, h: int, w: int, focal: float, near: float, far: float, ndc: bool = False,
-                  ndc_near: float = 1.0):
-    """-> 6 flattened device tensors (origins, directions, viewdirs [n*h*w,3]; radii, near, far [n*h*w,1])."""
+                  ndc_near: float = 1.0, span=None):
+    """-> 6 flattened device tensors (origins, directions, viewdirs [n*h*w,3]; radii, near, far [n*h*w,1]).
+    `span=(first, end)`: only the rays of that flat pixel range (a rank's block of chunks of a sharded render)."""
     c2w = dev(cam_to_world, "cam_to_world")
     if c2w.dim() == 2:
         c2w = c2w[None]
     c2w = c2w[:, :3, :4].contiguous()
     n = c2w.shape[0]
-    total = n * h * w
+    first, end = (0, n * h * w) if span is None else (int(span[0]), int(span[1]))
+    total = end - first
+    if total < 0:
+        raise RuntimeError(f"generate_rays: empty-negative span {span}")
     d = c2w.device
     o, di, v = (torch.empty(total, 3, device=d) for _ in range(3))
     r, ne, fa = (torch.empty(total, 1, device=d) for _ in range(3))
-    _call("m360_generate_rays", c2w, n, int(h), int(w), float(focal), float(near), float(far), int(bool(ndc)),
-          float(ndc_near), o, di, v, r, ne, fa, STREAM)
+    _call("m360_generate_rays_span", c2w, n, int(h), int(w), float(focal), float(near), float(far), int(bool(ndc)),
+          float(ndc_near), first, total, o, di, v, r, ne, fa, STREAM)
     return o, di, v, r, ne, fa
 
 

@@ -295,6 +295,125 @@ def test_sharded_batch_global_norm_world2_gloo(tmp_path):
     assert res.stdout.count("OK") == 2
 
 
+GLOO_FRAME_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mipnerf360_amd.distributed import (PixelGather, check_replicas, chunk_partition, partition_efficiency,
+                                        render_local_block, render_rays_sharded)
+from mipnerf360_amd.intern.ray import Rays
+from mipnerf360_amd import synthetic
+from oracle import ref_path as O   # checker only (tests/): stands in for the HIP renderer, which needs a GPU
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+h, w, chunks = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+n = h * w
+sd = O.to_torch_state_dict(synthetic.make_state_dict(32, 32, seed=1))
+hp = O.Hyper(num_samples=8)
+pose = np.concatenate([np.eye(3), np.array([[0.05], [-0.02], [0.1]])], 1).astype(np.float32)
+full = O.generate_rays(pose[None], h, w, 0.9 * w, 0.0, 1.0, ndc=True)
+full = Rays(*[torch.from_numpy(full[k]) for k in synthetic.RAY_FIELDS])
+
+class OracleRenderer(torch.nn.Module):       # has parameters: check_replicas fingerprints them
+    def __init__(self, scale=1.0):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.full((3,), float(scale)))
+        self.num_samples = 8
+    def render_rays(self, rays, chunks):
+        outs = [O.forward(O.Rays(*[f[i:i + chunks] for f in rays]), sd, hp) for i in range(0, rays[0].shape[0], chunks)]
+        if not outs:
+            return torch.zeros(0, 3), torch.zeros(0), torch.zeros(0)
+        return tuple(torch.cat([o[j] for o in outs], 0) for j in range(3))
+
+m = OracleRenderer()
+single = m.render_rays(full, chunks)
+# the bench's c4 frame loop in miniature: two frames through the two slots of one PixelGather, every rank renders only
+# the rays of its own span ("generated on the device per rank": here sliced from the oracle's frame)
+pg = PixelGather(n, chunks, "cpu", slots=2)
+assert pg.spans == chunk_partition(n, chunks, world)
+outs = [(torch.empty(n, 3), torch.empty(n), torch.empty(n)) for _ in range(2)]
+for frame in range(3):
+    s = frame % 2
+    b, e = pg.span
+    local = Rays(*[f[b:e] for f in full])
+    render_local_block(m, None, chunks, pg, slot=s, local_rays=local)
+    pg.gather(s)
+    got = pg.assemble(s, out=outs[s])
+    assert all(torch.equal(g, x) for g, x in zip(got, single)), "sharded frame != single-process frame"
+fresh = pg.assemble(0)
+assert fresh[0].data_ptr() != outs[0][0].data_ptr() and torch.equal(fresh[0], single[0])
+# the public entry point, and the efficiency bound the bench reports
+got = render_rays_sharded(m, full, chunks)
+assert all(torch.equal(g, x) for g, x in zip(got, single))
+n_chunks = (n + chunks - 1) // chunks
+assert partition_efficiency(n, chunks, world) <= 1.0
+assert abs(partition_efficiency(n, chunks, world) - n / (world * max(e - b for b, e in pg.spans))) < 1e-12
+# replicas with different weights are refused
+bad = OracleRenderer(scale=1.0 + rank)
+try:
+    check_replicas(bad)
+    raise SystemExit("check_replicas accepted different weights")
+except RuntimeError as ex:
+    assert "different weights" in str(ex)
+check_replicas(m)
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+@pytest.mark.parametrize("h,w,chunks", [(11, 13, 16), (9, 7, 64), (8, 8, 16)])
+def test_sharded_frame_pipeline_world2_gloo(tmp_path, h, w, chunks):
+    """bench.py --config c4 / render_view_sharded in miniature (BASELINE configs[3]): ragged last chunk, a frame smaller than
+    one chunk (rank 1 idle), an exact split."""
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_FRAME_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29601 + h), str(script), ROOT, str(h), str(w), str(chunks)]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert res.stdout.count("OK") == 2
+
+
+def test_bench_dry_launch_prints_the_child_command():
+    """bench.py --gpus N without a launcher starts the ranks itself: N fresh processes under torch.distributed.run."""
+    import json
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "7", "--warmup", "2",
+                          "--dry-launch"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads(res.stdout.strip().splitlines()[-1])
+    cmd = d["launch"]
+    assert d["ranks"] == 8 and cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 1024
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "7", "--warmup", "2"]      # the ranks get the same arguments, minus --dry-launch
+    # the parent must not import torch (it must never touch the GPU before the ranks exist)
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '2', '--dry-launch']\n"
+            "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit:\n    pass\n"
+            "assert 'torch' not in sys.modules, 'launcher imported torch'\n" % os.path.join(ROOT, "bench.py"))
+    res = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert res.returncode == 0, res.stderr[-2000:]
+
+
+def test_bench_launcher_starts_ranks_and_reports_their_failure():
+    """Here (no GPU) both ranks stop with 'needs a HIP device': the launcher must really start them (not refuse with its own
+    SystemExit), relay their message and exit non-zero."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert res.returncode == 0 and '"n_gpus": 2' in res.stdout
+        return
+    assert res.returncode != 0
+    assert "launch with torch.distributed.run" not in res.stderr
+    assert "2-rank child run failed" in res.stderr
+    if not torch.cuda.is_available():
+        assert "needs a HIP device" in res.stderr
+
+
 def test_dropin_falls_through_to_reference_helpers(tmp_path):
     """install_dropin(reference_root=...): modules without a mirror (intern.scheduler) and names missing from a mirror
     (camera paths of intern.pose, intern.utils.normalize) resolve to the reference's own files; mirrored names win.
