@@ -34,6 +34,7 @@ import argparse
 import hashlib
 import json
 import os
+import signal
 import socket
 import statistics
 import subprocess
@@ -97,6 +98,9 @@ def parse_args(argv=None):
                          "reported as `strong_scaling_frame` (default 1; 0 = skip)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="nccl = RCCL (the product); gloo = diagnostics only (ranks may share a GPU, host-staged collectives)")
+    ap.add_argument("--frame-size", type=str, default=None, metavar="WxH",
+                    help="(diagnostics) frame size of the c4 workload / strong_scaling_frame instead of 1237x822; the line "
+                         "then says so in config.workload")
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the child command as JSON and exit")
     return ap.parse_args(argv)
@@ -125,7 +129,18 @@ def launch(args, argv) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
     env.setdefault("MASTER_ADDR", "127.0.0.1")
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    # own session: if this process is told to stop (a driver's timeout), the whole rank tree goes with it
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+
+    def stop(signum, _frame):
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        raise SystemExit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, stop)
     line = None
     for out in proc.stdout:  # ranks' stderr goes straight through; stdout is scanned for rank 0's JSON line
         s = out.strip()
@@ -286,6 +301,13 @@ def hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib):
 FRAME_POSE = [[1.0, 0.0, 0.0, 0.05], [0.0, 1.0, 0.0, -0.02], [0.0, 0.0, 1.0, 0.1]]
 
 
+def frame_size(args):
+    if not args.frame_size:
+        return FRAME_W, FRAME_H
+    w, h = (int(v) for v in args.frame_size.lower().split("x"))
+    return w, h
+
+
 def frame_pipeline(model, comm, frames, warmup, overlap, width=FRAME_W, height=FRAME_H, chunks=FRAME_CHUNKS):
     """`frames` frames of width x height rays rendered by all ranks together: per frame every rank generates the rays of
     its own block of chunks (m360_generate_rays_span), renders them into the send block of a PixelGather and the
@@ -407,14 +429,17 @@ def worker(args):
 
     if frame_cfg:
         # ---------------------------------------------------------------- c4: frames sharded over the ranks
-        n_frame = FRAME_W * FRAME_H
+        fw, fh = frame_size(args)
+        n_frame = fw * fh
         chunks_mine = (n_frame + FRAME_CHUNKS - 1) // FRAME_CHUNKS
         prof = _lib.Prof(40 * (chunks_mine // world + 2) * (steps + warmup) * 2 + 64)
         model.set_prof(prof)
-        res = frame_pipeline(model, comm, steps, warmup, overlap=True)
+        res = frame_pipeline(model, comm, steps, warmup, overlap=True, width=fw, height=fh)
         model.set_prof(None)
         recs = prof.records()
-        serial = frame_pipeline(model, comm, steps, warmup, overlap=False) if world > 1 else None
+        serial = frame_pipeline(model, comm, steps, warmup, overlap=False, width=fw, height=fh) if world > 1 else None
+        if args.frame_size:
+            workload = f"DIAGNOSTIC frame size {fw}x{fh} instead of 1237x822; " + workload
         elapsed = res["seconds"]
         line.update(value=res["rays_per_s"], ms_per_step=round(1e3 * elapsed / max(steps, 1), 3))
         line["config"] = {"workload": workload.format(mlp="bf16 (fp32 accumulate)" if bf16 else "fp32"), "name": "c4",
@@ -496,8 +521,10 @@ def worker(args):
 
     if not frame_cfg and args.frame_steps > 0:
         # BASELINE configs[3] beside the headline: the same processes render one frame together (strong scaling)
-        fr = frame_pipeline(model, comm, args.frame_steps, 0, overlap=False)
-        fr["workload"] = CONFIGS["c4"][4].format(mlp="fp32")
+        fw, fh = frame_size(args)
+        fr = frame_pipeline(model, comm, args.frame_steps, 0, overlap=False, width=fw, height=fh)
+        fr["workload"] = (f"DIAGNOSTIC frame size {fw}x{fh} instead of 1237x822; " if args.frame_size else "") + \
+            CONFIGS["c4"][4].format(mlp="fp32")
         line["strong_scaling_frame"] = fr
 
     if rank != 0:

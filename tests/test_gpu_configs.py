@@ -195,6 +195,61 @@ def test_two_ranks_of_the_hip_renderer_on_one_gpu(dev, full_width):
     assert res.returncode == 0 and "dist_check world=2 sharded==single: True" in res.stdout, res.stdout[-3000:]
 
 
+def _run_bench(*argv, timeout=900):
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_its_own_ranks_weak_scaling_line(dev):
+    """`python bench.py --gpus 2` with no launcher around it (how the driver starts it): the parent starts two fresh rank
+    processes, rank 0's single JSON line comes back through the parent.  One GPU here, so the diagnostics backend (gloo,
+    ranks share cuda:0) stands in for RCCL: launcher, per-rank batches, PixelGather, replica check and the
+    strong_scaling_frame leg are the production code."""
+    res, line = _run_bench("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--frame-size", "160x120")
+    assert res.returncode == 0 and line is not None, (res.stdout[-1500:], res.stderr[-3000:])
+    assert len([ln for ln in res.stdout.splitlines() if ln.strip()]) == 1, "exactly ONE line on stdout"
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["dtype"] == "f32"
+    assert line["rccl"]["ranks"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert len(line["per_rank"]) == 2 and all(r["compute_ms_median"] > 0 for r in line["per_rank"])
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0.2     # two ranks share one GPU: no performance claim
+    fr = line["strong_scaling_frame"]
+    assert fr["finite"] and fr["rays_per_frame"] == 160 * 120 and fr["n_chunks"] == 5 and fr["chunks_per_rank"] == 3
+    assert [r["rays"] for r in fr["per_rank"]] == [3 * 4096, 160 * 120 - 3 * 4096]
+    assert abs(fr["partition_efficiency_bound"] - 160 * 120 / (2 * 3 * 4096)) < 1e-4
+    assert "cpu_baseline" not in line  # N = 1 only
+
+
+def test_bench_c4_frames_sharded_over_two_ranks(dev):
+    """bench.py --config c4 (BASELINE configs[3]) through its own launcher: frames sharded by whole chunks, each rank
+    generating the rays of its own span, overlapped and serial pixel gathers."""
+    res, line = _run_bench("--gpus", "2", "--backend", "gloo", "--config", "c4", "--steps", "3", "--warmup", "1",
+                           "--frame-size", "200x123")
+    assert res.returncode == 0 and line is not None, (res.stdout[-1500:], res.stderr[-3000:])
+    n = 200 * 123
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["config"]["name"] == "c4"
+    assert line["config"]["rays_per_frame"] == n and line["config"]["n_chunks"] == 7 and line["config"]["chunks_per_rank"] == 4
+    for mode in ("overlapped", "serial"):
+        fr = line["frame"][mode]
+        assert fr["finite"] and fr["frames"] == 3 and sum(r["rays"] for r in fr["per_rank"]) == n
+        assert fr["rays_per_s"] > 0
+    assert line["frame"]["overlapped"]["overlap"] and not line["frame"]["serial"]["overlap"]
+    assert abs(line["value"] - line["frame"]["overlapped"]["rays_per_s"]) < 1.0
+    assert line["roofline"] is not None and line["rccl"]["ranks"] == 2
+
+
+def test_bench_single_gpu_frame_workload(dev):
+    """--config c4 at N = 1 = BASELINE configs[2] (no collective): the same frame loop, one process."""
+    res, line = _run_bench("--config", "c4", "--steps", "1", "--warmup", "1", "--frame-size", "300x137")
+    assert res.returncode == 0 and line is not None, (res.stdout[-1500:], res.stderr[-3000:])
+    assert line["n_gpus"] == 1 and line["rccl"] is None and line["frame"]["serial"] is None
+    assert line["frame"]["overlapped"]["finite"] and line["frame"]["overlapped"]["per_rank"][0]["rays"] == 300 * 137
+
+
 def test_model_on_explicit_device_without_set_device(dev):
     """mipNeRF360(device='cuda:0') must work whatever torch's current device/stream bookkeeping says: every C-ABI call
     runs under a device guard on the device its tensors live on, on that device's current stream (side stream too)."""

@@ -370,8 +370,10 @@ def test_c2_full_size_properties(dev):
     r = synthetic.make_rays("garden", 4096, seed=1)
     m = build_model(sd, dev, 128, 256, 1024, False)
     rays = dev_rays(r, dev)
-    rgb, dist, acc = m(rays)
-    rgb2, dist2, acc2 = m(rays)
+    with torch.no_grad():  # the fused rendering forward (m360_forward), the one bench.py times
+        rgb, dist, acc = m(rays)
+        rgb2, dist2, acc2 = m(rays)
+    assert not rgb.requires_grad
     assert torch.equal(rgb, rgb2) and torch.equal(dist, dist2) and torch.equal(acc, acc2)
     assert torch.isfinite(rgb).all() and torch.isfinite(dist).all() and torch.isfinite(acc).all()
     assert float(acc.min()) >= 0 and float(acc.max()) <= 1 + 1e-5
@@ -382,8 +384,48 @@ def test_c2_full_size_properties(dev):
     perm = torch.randperm(4096, generator=torch.Generator().manual_seed(0)).to(dev)
     from mipnerf360_amd.intern.ray import Rays
     rp = Rays(*[f[perm].contiguous() for f in rays])
-    rgb_p, dist_p, acc_p = m(rp)
+    with torch.no_grad():
+        rgb_p, dist_p, acc_p = m(rp)
     close(rgb_p, rgb[perm], atol=2e-5), close(acc_p, acc[perm], atol=2e-5), close(dist_p, dist[perm], atol=2e-5)
+
+
+def test_c2_headline_batch_vs_oracle_as_one_chunk(dev):
+    """configs[1] at its OWN chunk size: bench.py's exact batch (seed-0 weights, seed-1 rays, 4096 x 128, full width)
+    through the fused rendering forward (m360_forward under no_grad) against the CPU oracle on all 4096 rays as ONE
+    chunk - the contraction norm of intern/parameterization.py:23-29 (called at :75) spans the whole chunk, so a
+    sub-batch is a different computation (model.py:247-252).  Stated fp32 tolerance: |d rgb|, |d acc| <= 1e-4,
+    |d distance| <= 1e-4 * max(1, |distance|).  Also: the tape-keeping forward (grad enabled) gives the same bits at
+    this size, and so do the two stage entry points called one after the other."""
+    from oracle import ref_path as O
+    sd = synthetic.make_state_dict(256, 1024, seed=0)
+    r = synthetic.make_rays("garden", 4096, seed=1)
+    m = build_model(sd, dev, 128, 256, 1024, False)
+    rays = dev_rays(r, dev)
+    with torch.no_grad():
+        rgb, dist, acc = m(rays)
+        tv, fw, sv = m.nerf_net.t_vals.clone(), m.nerf_net.fine_weights.clone(), m.nerf_net.s_vals.clone()
+        t_hat, w_hat = m.prop_net.forward(rays)
+        staged = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    assert not rgb.requires_grad
+    with torch.no_grad():
+        o_sd = O.to_torch_state_dict(sd)
+        hp = O.Hyper(num_samples=128)
+        o_rays = O.rays_from_numpy(r)
+        o_t, o_w = O.prop_forward(o_rays, o_sd, hp)
+        o_rgb, o_dist, o_acc, o_tv, o_fw, o_sv = O.nerf_forward(o_rays, o_t, o_w, o_sd, hp)
+    close(rgb, o_rgb, atol=1e-4, rtol=0), close(acc, o_acc, atol=1e-4, rtol=0)
+    assert float(((dist.cpu() - o_dist).abs() / o_dist.abs().clamp(min=1.0)).max()) <= 1e-4
+    close(t_hat, o_t, atol=2e-6, rtol=1e-5), close(w_hat, o_w, atol=2e-5, rtol=1e-4)
+    close(tv, o_tv, atol=1e-5, rtol=1e-4), close(fw, o_fw, atol=2e-5, rtol=1e-4), close(sv, o_sv, atol=1e-5, rtol=1e-4)
+    for k, ref in enumerate((rgb, dist, acc)):
+        assert torch.equal(staged[k], ref)
+    del staged, o_rgb, o_tv, o_fw, o_sv
+    t2, w2 = m.prop_net.forward(rays)                               # grad enabled: m360_prop_forward_train
+    taped = m.nerf_net.forward(rays, t_vals=t2, coarse_weights=w2)  # m360_nerf_forward_train (17 GB tape)
+    assert taped[0].requires_grad
+    assert torch.equal(t2, t_hat) and torch.equal(w2.detach(), w_hat)
+    for k, ref in enumerate((rgb, dist, acc, tv, fw, sv)):
+        assert torch.equal(taped[k].detach(), ref), f"tape-keeping forward differs from the fused one in output {k}"
 
 
 @pytest.mark.parametrize("name,ndc", [("pinhole", False), ("llff", True)])
@@ -1097,6 +1139,24 @@ def test_psnr_within_tenth_db_of_reference(golden, dev, kind, n, mlp_dtype, limi
         psnr = lambda a: -10.0 * np.log10(np.mean((np.clip(a, 0, 1) - target) ** 2))  # noqa: E731
         worst = max(worst, abs(psnr(H(rgb).astype(np.float64)) - psnr(ref_rgb)))
     assert worst <= limit_db, f"PSNR differs from the reference's by {worst:.4f} dB"
+
+
+def test_generate_rays_span_bit_identical_to_the_full_frame(dev):
+    """m360_generate_rays_span (what each rank of a sharded frame render calls for its own block of chunks): any flat
+    pixel span equals those rows of the full call bit for bit, pinhole and NDC, spans crossing camera boundaries."""
+    from mipnerf360_amd.intern import ray as R
+    poses = torch.tensor(np.stack([np.concatenate([np.eye(3), np.array([[0.05 * k], [-0.02], [0.1 + k]])], 1) for k in range(3)]),
+                         dtype=torch.float32, device=dev)
+    h, w = 17, 23
+    for ndc in (False, True):
+        near, far = (0.0, 1.0) if ndc else (2.0, 6.0)
+        full = R.generate_rays(poses, h, w, 0.9 * w, near, far, ndc)
+        for b, e in ((0, 3 * h * w), (0, 1), (5, 5), (100, 391), (h * w - 3, 2 * h * w + 7), (3 * h * w - 1, 3 * h * w)):
+            part = R.generate_rays(poses, h, w, 0.9 * w, near, far, ndc, span=(b, e))
+            for name, f, p in zip(full._fields, full, part):
+                assert p.shape[0] == e - b and torch.equal(p, f[b:e]), (name, b, e, ndc)
+    with pytest.raises(RuntimeError):
+        R.generate_rays(poses, h, w, 0.9 * w, 0.0, 1.0, True, span=(0, 3 * h * w + 1))
 
 
 def test_full_size_forward_soak_is_deterministic(dev):

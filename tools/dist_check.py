@@ -53,6 +53,14 @@ def main():
     single = m.render_image(rays, h, w, chunks=chunks)
     sharded = render_image_sharded(m, rays, h, w, chunks=chunks)
     ok = all(np.array_equal(a, b) for a, b in zip(single, sharded))
+    # the same from a pose: every rank generates only the rays of its own block of chunks (m360_generate_rays_span)
+    from mipnerf360_amd import ops
+    from mipnerf360_amd.distributed import render_view_sharded
+    pose = np.concatenate([np.eye(3), np.array([[0.05], [-0.02], [0.1]])], 1).astype(np.float32)
+    view1 = m.render_view(pose, h, w, 0.9 * w, 0.0, 1.0, ndc=True, chunks=chunks)
+    rgb_s, dist_s, acc_s = render_view_sharded(m, pose, h, w, 0.9 * w, 0.0, 1.0, ndc=True, chunks=chunks)
+    ok = ok and np.array_equal(view1[0], ops.to8b(rgb_s).reshape(h, w, 3).cpu().numpy())
+    ok = ok and np.array_equal(view1[1], dist_s.reshape(h, w).cpu().numpy()) and np.array_equal(view1[2], acc_s.reshape(h, w).cpu().numpy())
     # one logical batch split over the ranks, global contraction norm rebuilt with an all-reduce
     from mipnerf360_amd.distributed import forward_sharded
     world, rank = dist.get_world_size(), dist.get_rank()
