@@ -353,7 +353,7 @@ def frame_pipeline(model, comm, frames, warmup, overlap, width=FRAME_W, height=F
                 pg.assemble(s, out=outs[s])
                 ev[i][3].record()
         else:
-            pg.recv[s].view(-1).copy_(pg.send[s])
+            pg.gather(s)  # one rank: a local copy into the receive block
             pg.assemble(s, out=outs[s])
 
     for i in range(warmup):

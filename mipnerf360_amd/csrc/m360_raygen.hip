@@ -141,13 +141,14 @@ extern "C" {
 int m360_generate_rays_span(const float *cam_to_world, int n_cams, int h, int w, float focal, float near, float far,
                             int ndc, float ndc_near, long first, long count, float *origins, float *directions,
                             float *viewdirs, float *radii, float *near_out, float *far_out, m360_stream_t stream) {
-    if (!cam_to_world || !origins || !directions || !viewdirs || !radii || !near_out || !far_out || n_cams < 0)
-        return fail(M360_ERR_INVALID_ARGUMENT, "m360_generate_rays: null pointer or negative camera count");
+    if (n_cams < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_generate_rays: negative camera count");
     if (h < 3 || w < 3 || !(focal > 0.0f)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_generate_rays: h=%d w=%d must be >= 3 (the reference's radii padding reads difference n-3), focal=%g > 0", h, w, (double)focal);
     const long n = (long)n_cams * h * w;
     if (first < 0 || count < 0 || first + count > n)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_generate_rays_span: span [%ld, %ld) outside the %ld pixels of %d camera(s)", first, first + count, n, n_cams);
-    if (count == 0) return M360_OK;
+    if (count == 0) return M360_OK;  // an empty span (no cameras, or a rank without chunks) needs no buffers
+    if (!cam_to_world || !origins || !directions || !viewdirs || !radii || !near_out || !far_out)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_generate_rays: null pointer");
     const float sx = (float)((2.0 * (double)focal) / (double)w), sy = (float)((2.0 * (double)focal) / (double)h);
     dim3 grid((unsigned)((count + 255) / 256)), block(256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -48,6 +48,17 @@ def partition_efficiency(num_rays: int, chunks: int, world_size: int) -> float:
     return 1.0 if longest == 0 else num_rays / (world_size * longest)
 
 
+def _initialized() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def _world_rank(group=None) -> Tuple[int, int]:
+    """(world size, rank); (1, 0) in a process without a process group (single-GPU use of the same code)."""
+    if not _initialized():
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
 def _host_staged(group) -> bool:
     """gloo cannot all-gather device tensors: stage them through the host (used by the tests that run several ranks of
     the HIP renderer on ONE GPU; with RCCL - the production backend - device tensors go over xGMI directly)."""
@@ -55,7 +66,9 @@ def _host_staged(group) -> bool:
 
 
 def _all_gather_into(recv: torch.Tensor, send: torch.Tensor, group=None) -> None:
-    if send.is_cuda and _host_staged(group):
+    if not _initialized():  # one process, no group: the "gather" is the local block
+        recv.view(-1)[:send.numel()].copy_(send.view(-1))
+    elif send.is_cuda and _host_staged(group):
         r = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_gather_into_tensor(r, send.cpu(), group=group)
         recv.copy_(r)
@@ -64,6 +77,8 @@ def _all_gather_into(recv: torch.Tensor, send: torch.Tensor, group=None) -> None
 
 
 def _all_reduce(t: torch.Tensor, op, group=None) -> None:
+    if not _initialized():
+        return
     if t.is_cuda and _host_staged(group):
         h = t.cpu()
         dist.all_reduce(h, op=op, group=group)
@@ -85,8 +100,7 @@ class PixelGather:
 
     def __init__(self, num_rays: int, chunks: int, device, group=None, slots: int = 1, dtype=torch.float32):
         self.group = group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.world, self.rank = _world_rank(group)
         self.num_rays, self.chunks = int(num_rays), int(chunks)
         self.spans = chunk_partition(num_rays, chunks, self.world)
         self.counts = [e - b for b, e in self.spans]
@@ -142,7 +156,7 @@ _MAX_GATHERS = 4
 
 def pixel_gather_for(num_rays: int, chunks: int, device, group=None, slots: int = 1) -> PixelGather:
     """Cached PixelGather per frame shape (at most 4 shapes are kept: a renderer alternates between very few)."""
-    key = (int(num_rays), int(chunks), str(torch.device(device)), id(group), dist.get_world_size(group), int(slots))
+    key = (int(num_rays), int(chunks), str(torch.device(device)), id(group), _world_rank(group), int(slots))
     pg = _GATHERS.get(key)
     if pg is None:
         pg = _GATHERS[key] = PixelGather(num_rays, chunks, device, group, slots)
@@ -156,8 +170,7 @@ def pixel_gather_for(num_rays: int, chunks: int, device, group=None, slots: int 
 def gather_pixels(local: torch.Tensor, spans: List[Tuple[int, int]], group=None) -> torch.Tensor:
     """All-gather per-rank blocks local[n_r, C] (n_r = spans[rank] length) of ARBITRARY spans into [sum n_r, C] on every
     rank (general-purpose helper; the frame renderer uses PixelGather, whose buffers are preallocated)."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    world, rank = _world_rank(group)
     counts = [e - b for b, e in spans]
     if len(spans) != world or local.shape[0] != counts[rank]:
         raise ValueError("gather_pixels: spans do not match the process group / local block")
@@ -195,6 +208,8 @@ def replica_fingerprint(model) -> Optional[torch.Tensor]:
 def check_replicas(model, group=None) -> None:
     """Every rank must render with the same weights and sample counts or the frame is silently inconsistent.  Once per
     (model, parameter versions): one all-reduce (MAX) of 4 int64 = (f, -f) - all ranks agree iff max(f) == -max(-f)."""
+    if _world_rank(group)[0] == 1:
+        return
     fp = replica_fingerprint(model)
     if fp is None:
         return

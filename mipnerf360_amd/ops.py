@@ -471,8 +471,11 @@ def generate_rays(cam_to_world, h: int, w: int, focal: float, near: float, far: 
     d = c2w.device
     o, di, v = (torch.empty(total, 3, device=d) for _ in range(3))
     r, ne, fa = (torch.empty(total, 1, device=d) for _ in range(3))
-    _call("m360_generate_rays_span", c2w, n, int(h), int(w), float(focal), float(near), float(far), int(bool(ndc)),
-          float(ndc_near), first, total, o, di, v, r, ne, fa, STREAM)
+    if first < 0 or end > n * h * w:
+        raise RuntimeError(f"generate_rays: span [{first}, {end}) outside the {n * h * w} pixels of {n} camera(s)")
+    if total:  # an empty span (a rank without chunks) launches nothing
+        _call("m360_generate_rays_span", c2w, n, int(h), int(w), float(focal), float(near), float(far), int(bool(ndc)),
+              float(ndc_near), first, total, o, di, v, r, ne, fa, STREAM)
     return o, di, v, r, ne, fa
 
 

@@ -231,11 +231,12 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, u_rand: Optional[t
     eps = 1e-5
     f32eps = float(torch.finfo(torch.float32).eps)
     wsum = torch.sum(weights, dim=-1, keepdim=True)
-    pad = torch.clamp_min(eps - wsum, 0)
+    pad = torch.maximum(torch.zeros_like(wsum), eps - wsum)  # NaN-propagating, like the reference's torch.maximum
     weights = weights + pad / weights.shape[-1]
     wsum = wsum + pad
     pdf = weights / wsum
-    cdf = torch.clamp_max(torch.cumsum(pdf[..., :-1], dim=-1), 1.0)
+    cdf = torch.cumsum(pdf[..., :-1], dim=-1)
+    cdf = torch.minimum(torch.ones_like(cdf), cdf)
     edge = torch.zeros_like(wsum)  # [...,1] even when there is a single interval (empty cumsum)
     cdf = torch.cat([edge, cdf, edge + 1.0], dim=-1)
     if u_rand is None:
@@ -246,12 +247,28 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, u_rand: Optional[t
         base = (torch.arange(num_samples) * s)[None, :]
         u = base + base + u_rand * (s - f32eps)
         u = torch.clamp_max(u, 1.0 - f32eps)
-    idx = torch.searchsorted(cdf.contiguous(), u, right=True) - 1
+    idx = torch.searchsorted(torch.nan_to_num(cdf, nan=2.0).contiguous(), u, right=True) - 1
     last = cdf.shape[-1] - 1
     i0 = idx.clamp(0, last)
     i1 = (idx + 1).clamp(0, last)
     b0, b1 = torch.gather(bins, -1, i0), torch.gather(bins, -1, i1)
     c0, c1 = torch.gather(cdf, -1, i0), torch.gather(cdf, -1, i1)
+    # Rows whose cdf is not a finite non-decreasing sequence (NaN / Inf / negative weights; fixture G18): the sorted
+    # search does not describe the reference there.  Its bracket is defined through the comparison table
+    # m[i,j] = (u_j >= cdf_i) (intern/ray.py:43-50): x0_j = max over i of (x_i where m, else x_0), x1_j = min over i of
+    # (x_i where not m, else x_last) - with NaN comparing false and torch.max / torch.min propagating NaN.
+    bad = ~(torch.isfinite(cdf).all(-1) & (cdf[..., 1:] >= cdf[..., :-1]).all(-1))
+    if bool(bad.any()):
+        cb, bb, ub = cdf[bad], bins[bad], u[bad]
+        m = ub[:, None, :] >= cb[:, :, None]
+
+        def bracket(x):
+            lo = torch.where(m, x[:, :, None], x[:, :1, None]).max(dim=-2).values
+            hi = torch.where(~m, x[:, :, None], x[:, -1:, None]).min(dim=-2).values
+            return lo, hi
+
+        b0, b1, c0, c1 = b0.clone(), b1.clone(), c0.clone(), c1.clone()
+        (b0[bad], b1[bad]), (c0[bad], c1[bad]) = bracket(bb), bracket(cb)
     tt = torch.clip(torch.nan_to_num((u - c0) / (c1 - c0), 0), 0, 1)
     return b0 + tt * (b1 - b0)
 

@@ -578,10 +578,129 @@ def g17():
     save("g17_visualize_depth_options", **{k: np.asarray(v) for k, v in out.items()})
 
 
+def g18():
+    """NaN / Inf / degenerate inputs on the hot path, as the REFERENCE treats them: where it produces NaN, where
+    nan_to_num / clamp swallow it, where a degenerate value stays finite.
+      vd        ViewdirectionEncoding with |z| = 1 + 2^-23 (acos -> NaN), NaN / Inf / zero components, x + 1e-6 == 0
+                (intern/encoding.py:69-90)
+      sample    sample_along_rays with far == near, near = far = 0, far < near, directions = 0, radii = 0
+                (intern/ray.py:81-116, intern/parameterization.py:46 clamp 1e-10)
+      lift      gaussian_to_xyz with d = 0 rows (parameterization.py:31-62)
+      resample  sorted_piecewise_constant_pdf / resample_along_rays with a NaN weight, an all-NaN row, +Inf, a negative
+                weight, weights whose sum overflows (intern/ray.py:12-57,118-153)
+      render    density_to_weight / volumetric_rendering with NaN, +Inf, 1e38 and -1e4 densities (exp overflow), a NaN
+                colour, a zero direction (model.py:59-78, intern/ray.py:155-191)
+      e2e       both stage forwards of a small model on a batch holding such rays (NaN stays local to its ray), and on
+                a batch with one NaN origin (local: origins are added after the contraction) and one NaN direction (the
+                whole-chunk contraction norm turns every ray of the chunk NaN)"""
+    out = {}
+    nan, inf = np.float32(np.nan), np.float32(np.inf)
+    one_up = np.float32(1.0) + np.float32(2.0 ** -23)
+    # ---- vd
+    v = np.array([[0.0, 0.0, one_up], [0.0, 0.0, -one_up], [0.6, 0.0, 0.8], [nan, 0.5, 0.5], [inf, 0.0, 0.5],
+                  [0.0, 0.0, 0.0], [-1e-6, 0.0, 0.5], [-1e-6, 0.3, 0.5], [0.3, nan, 0.5], [0.3, 0.4, inf]], dtype=np.float32)
+    out["vd_in"] = v
+    for lo, hi in ((0, 4), (1, 3)):
+        out[f"vd_{lo}_{hi}"] = N(ref_enc.ViewdirectionEncoding(lo, hi)(T(v)))
+    # ---- sample
+    r = synthetic.make_rays("lego", 7, seed=181)
+    r["near"][:, 0] = [1.0, 0.0, 3.0, 2.0, 2.0, 2.0, 0.0]
+    r["far"][:, 0] = [1.0, 0.0, 2.0, 6.0, 6.0, 6.0, 1.0]
+    r["directions"][4] = 0.0
+    r["radii"][5] = 0.0
+    n = 4
+    t_vals, (means, covs) = ref_ray.sample_along_rays(T(r["origins"]), T(r["directions"]), T(r["radii"]), n, T(r["near"]),
+                                                      T(r["far"]), False)
+    for k in synthetic.RAY_FIELDS:
+        out["sample_rays_" + k] = r[k]
+    out["sample_t"], out["sample_means"], out["sample_covs"] = N(t_vals), N(means), N(covs)
+    # ---- lift
+    g = np.random.Generator(np.random.PCG64(1818))
+    d = g.normal(size=(4, 3)).astype(np.float32)
+    d[1] = 0.0
+    d[2] = [1e-6, 0.0, 0.0]          # |d|^2 = 1e-12 < the 1e-10 clamp
+    tm, tv, rv = (g.uniform(0.5, 3, size=(4, 5)).astype(np.float32), g.uniform(1e-4, 1e-2, size=(4, 5)).astype(np.float32),
+                  g.uniform(1e-5, 1e-3, size=(4, 5)).astype(np.float32))
+    m_, c_ = ref_par.gaussian_to_xyz(T(d), T(tm), T(tv), T(rv), diag=False)
+    out.update(lift_d=d, lift_tm=tm, lift_tv=tv, lift_rv=rv, lift_mean=N(m_), lift_cov=N(c_))
+    # ---- resample
+    B, n = 8, 8
+    t = np.sort(g.uniform(2, 6, size=(B, n + 1)), axis=1).astype(np.float32)
+    w = g.uniform(0.05, 1, size=(B, n)).astype(np.float32)
+    w[0, 3] = nan
+    w[1, :] = nan
+    w[2, 5] = inf
+    w[3, 2] = -1.0
+    w[4, :] = 3e38                   # the sum overflows to +Inf
+    w[5, 0] = nan                    # NaN in the first / last interval (the replicate padding of the blur)
+    w[6, n - 1] = nan
+    out["resample_t"], out["resample_w"] = t, w
+    out["pdf_samples"] = N(ref_ray.sorted_piecewise_constant_pdf(T(t), T(w), n + 1, randomized=False))
+    out["pdf_samples_5"] = N(ref_ray.sorted_piecewise_constant_pdf(T(t), T(w), 5, randomized=False))
+    rr = synthetic.make_rays("lego", B, seed=182)
+    new_t, (means, covs) = ref_ray.resample_along_rays(T(rr["origins"]), T(rr["directions"]), T(rr["radii"]), T(t), T(w),
+                                                       False, 0.01)
+    for k in synthetic.RAY_FIELDS:
+        out["resample_rays_" + k] = rr[k]
+    out["resample_new_t"], out["resample_means"], out["resample_covs"] = N(new_t), N(means), N(covs)
+    # ---- render
+    B, n = 8, 8
+    t = np.sort(g.uniform(2, 6, size=(B, n + 1)), axis=1).astype(np.float32)
+    dens = g.gamma(0.6, 4.0, size=(B, n, 1)).astype(np.float32)
+    dens[0, 3] = nan
+    dens[1, 2] = inf
+    dens[2, :] = 1e38                # density * delta overflows
+    dens[3, 4] = -1e4                # exp(+big) = Inf -> alpha = -Inf
+    dens[4, 0] = nan                 # first sample: every transmittance after it is NaN
+    dens[5, n - 1] = nan             # last sample: only its own weight
+    rgb = g.uniform(0, 1, size=(B, n, 3)).astype(np.float32)
+    rgb[6, 2, 1] = nan
+    dirs = g.normal(size=(B, 3)).astype(np.float32)
+    dirs[7] = 0.0
+    dens[7, 1] = inf                 # Inf * 0 = NaN
+    out.update(render_t=t, render_density=dens, render_rgb=rgb, render_dirs=dirs)
+    pn = ref_model.prop_net(num_samples=n, hidden_proposal=8, device=CPU)
+    out["render_w_prop"] = N(pn.density_to_weight(T(t), T(dens), T(dirs)))
+    for wb in (False, True):
+        c, dd, a, ww = ref_ray.volumetric_rendering(T(rgb), T(dens), T(t), T(dirs), wb)
+        tag = f"render_wb{int(wb)}"
+        out[tag + "_rgb"], out[tag + "_dist"], out[tag + "_acc"], out[tag + "_w"] = N(c), N(dd), N(a), N(ww)
+    # ---- e2e
+    hp_, hn_, n = 32, 64, 8
+    sd = synthetic.make_state_dict(hp_, hn_, seed=18)
+    for k, v_ in sd.items():
+        out["sd." + k] = v_
+    out["e2e_cfg"] = np.array([n, hp_, hn_])
+    for tag in ("local", "nan_origin", "nan_direction"):
+        r = synthetic.make_rays("garden", 8, seed=183)
+        r["viewdirs"][0] = [0.0, 0.0, one_up]
+        r["far"][1] = r["near"][1]
+        r["directions"][2] = 0.0
+        r["radii"][3] = 0.0
+        r["viewdirs"][4] = [0.0, 0.0, -one_up]
+        if tag == "nan_origin":      # origins are added AFTER the contraction (parameterization.py:135): stays local
+            r["origins"][5, 1] = nan
+        if tag == "nan_direction":   # enters the whole-chunk norm of contract(): every ray of the chunk turns NaN
+            r["directions"][5, 1] = nan
+        m = build_ref_model(sd, n, hp_, hn_, False)
+        with torch.no_grad():
+            rays = ref_rays(r)
+            t_hat, w_hat = m.prop_net.forward(rays)
+            t_hat_np, w_hat_np = N(t_hat), N(w_hat)
+            o = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        for k in synthetic.RAY_FIELDS:
+            out[f"e2e_{tag}_rays_{k}"] = r[k]
+        out[f"e2e_{tag}_t_hat"], out[f"e2e_{tag}_w_hat"] = t_hat_np, w_hat_np
+        for nm, v_ in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), o):
+            out[f"e2e_{tag}_{nm}"] = N(v_)
+        print(f"  G18 e2e {tag}: NaN rays in rgb = {np.isnan(N(o[0])).any(1).nonzero()[0].tolist()}")
+    save("g18_degenerate", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14,
-                 g15=g15, g16=g16, g17=g17)
+                 g15=g15, g16=g16, g17=g17, g18=g18)
     for k in which:
         print(k)
         table[k]()

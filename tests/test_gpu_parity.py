@@ -132,6 +132,102 @@ def test_g6_resampling(golden, dev):
     assert torch.equal(w, w_before)
 
 
+# =============================================================================== G18: NaN / Inf / degenerate inputs
+def same_nans_and_close(got, want, atol=4e-6, rtol=1e-5, what=""):
+    """NaN exactly where the reference has NaN, Inf exactly where it has Inf (same sign), close elsewhere."""
+    got = H(got) if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), \
+        f"{what}: NaN pattern differs at {np.argwhere(np.isnan(got) != np.isnan(want))[:8].tolist()}"
+    inf = np.isinf(want)
+    assert np.array_equal(np.isinf(got), inf) and np.array_equal(got[inf], want[inf]), f"{what}: Inf pattern differs"
+    ok = ~np.isnan(want) & ~inf
+    np.testing.assert_allclose(got[ok], want[ok], atol=atol, rtol=rtol, err_msg=what)
+
+
+def test_g18_viewdir_encoding_degenerate(golden, dev):
+    """intern/encoding.py:69-90: acos of |z| = 1 + 2^-23 is NaN in the theta channels only; NaN / Inf / zero components;
+    x + 1e-6 == 0 (0/0 and y/0)."""
+    from mipnerf360_amd.intern.encoding import ViewdirectionEncoding
+    g = golden("g18_degenerate")
+    for lo, hi in ((0, 4), (1, 3)):
+        same_nans_and_close(ViewdirectionEncoding(lo, hi)(D(g["vd_in"], dev)), g[f"vd_{lo}_{hi}"], what=f"vd_{lo}_{hi}")
+
+
+def test_g18_sampling_and_lift_degenerate(golden, dev):
+    """intern/ray.py:81-116 with far == near, near = far = 0, far < near, directions = 0, radii = 0;
+    intern/parameterization.py:46 (the 1e-10 clamp of |d|^2)."""
+    from mipnerf360_amd.intern import parameterization as P, ray as R
+    g = golden("g18_degenerate")
+    r = {k: D(g["sample_rays_" + k], dev) for k in synthetic.RAY_FIELDS}
+    t, (m, c) = R.sample_along_rays(r["origins"], r["directions"], r["radii"], 4, r["near"], r["far"], False)
+    same_nans_and_close(t, g["sample_t"], atol=0, rtol=2e-6, what="t")
+    same_nans_and_close(m, g["sample_means"], what="means")
+    same_nans_and_close(c, g["sample_covs"], atol=1e-9, rtol=2e-3, what="covs")
+    mean, cov = P.gaussian_to_xyz(D(g["lift_d"], dev), D(g["lift_tm"], dev), D(g["lift_tv"], dev), D(g["lift_rv"], dev))
+    same_nans_and_close(mean, g["lift_mean"], atol=1e-7, what="lift mean")
+    same_nans_and_close(cov, g["lift_cov"], atol=1e-9, what="lift cov")
+
+
+def test_g18_resampling_degenerate(golden, dev):
+    """intern/ray.py:12-57,118-153 with a NaN weight (the row collapses onto the first bin edge: no NaN comes out), an
+    all-NaN row, +Inf, a negative weight (non-monotone cdf), a sum that overflows."""
+    from mipnerf360_amd.intern import ray as R
+    g = golden("g18_degenerate")
+    t, w = D(g["resample_t"], dev), D(g["resample_w"], dev)
+    same_nans_and_close(R.sorted_piecewise_constant_pdf(t, w.clone(), 9, randomized=False), g["pdf_samples"], what="pdf 9")
+    same_nans_and_close(R.sorted_piecewise_constant_pdf(t, w.clone(), 5, randomized=False), g["pdf_samples_5"], what="pdf 5")
+    o, d, r = (D(g["resample_rays_" + k], dev) for k in ("origins", "directions", "radii"))
+    new_t, (m, c) = R.resample_along_rays(o, d, r, t, w, False, 0.01)
+    same_nans_and_close(new_t, g["resample_new_t"], what="resample t")
+    same_nans_and_close(m, g["resample_means"], what="means")
+    same_nans_and_close(c, g["resample_covs"], atol=1e-7, rtol=2e-3, what="covs")
+
+
+def test_g18_weights_and_composite_degenerate(golden, dev):
+    """model.py:59-78, intern/ray.py:155-191 with NaN / +Inf / 1e38 / -1e4 densities, a NaN colour, a zero direction:
+    NaN weights exactly where the reference has them, the distance never NaN (nan_to_num + clamp, ray.py:187)."""
+    from mipnerf360_amd.intern import ray as R
+    from mipnerf360_amd.model import prop_net
+    g = golden("g18_degenerate")
+    t, dens, rgb, dirs = (D(g["render_" + k], dev) for k in ("t", "density", "rgb", "dirs"))
+    pn = prop_net(num_samples=dens.shape[1], hidden_proposal=32, device=dev)
+    same_nans_and_close(pn.density_to_weight(t, dens, dirs), g["render_w_prop"], what="prop weights")
+    for wb in (0, 1):
+        c, d, a, w = R.volumetric_rendering(rgb, dens, t, dirs, bool(wb))
+        tag = f"render_wb{wb}"
+        same_nans_and_close(c, g[tag + "_rgb"], what="rgb"), same_nans_and_close(a, g[tag + "_acc"], what="acc")
+        same_nans_and_close(d, g[tag + "_dist"], what="dist"), same_nans_and_close(w, g[tag + "_w"], what="w")
+
+
+@pytest.mark.parametrize("tag", ["local", "nan_origin", "nan_direction"])
+def test_g18_stage_forwards_degenerate(golden, dev, tag):
+    """Both stage forwards and the fused forward on a batch that holds degenerate rays: viewdir |z| > 1 (NaN features ->
+    the ray is NaN through both MLPs, its resampled t collapses to t[0]), far == near, directions = 0, radii = 0; a NaN
+    origin stays local (origins are added after the contraction), a NaN direction enters the whole-chunk norm and turns
+    every ray NaN - exactly as in the reference."""
+    g = golden("g18_degenerate")
+    n, hp, hn = (int(x) for x in g["e2e_cfg"])
+    m = build_model(_sd(g), dev, n, hp, hn, False)
+    rays = dev_rays({k: g[f"e2e_{tag}_rays_{k}"] for k in synthetic.RAY_FIELDS}, dev)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+        out = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        fused = m(rays)
+    same_nans_and_close(t_hat, g[f"e2e_{tag}_t_hat"], atol=0, rtol=2e-6, what="t_hat")
+    same_nans_and_close(w_hat, g[f"e2e_{tag}_w_hat"], atol=5e-6, what="w_hat")
+    for nm, v in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), out):
+        same_nans_and_close(v, g[f"e2e_{tag}_{nm}"], atol=2e-5, rtol=1e-4, what=nm)
+    for nm, v in zip(("rgb", "dist", "acc"), fused):
+        same_nans_and_close(v, g[f"e2e_{tag}_{nm}"], atol=2e-5, rtol=1e-4, what="fused " + nm)
+    # the tape-keeping forward (training) treats them the same way
+    t2, w2 = m.prop_net.forward(rays)
+    taped = m.nerf_net.forward(rays, t_vals=t2, coarse_weights=w2)
+    for nm, v in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), taped):
+        same_nans_and_close(v.detach(), g[f"e2e_{tag}_{nm}"], atol=2e-5, rtol=1e-4, what="taped " + nm)
+
+
 def _sd(g):
     return {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
 

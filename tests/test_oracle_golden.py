@@ -364,3 +364,82 @@ def test_g17_visualize_depth_options(golden, case):
     c = _G17_CASES[case]
     got = O.visualize_depth(g[c["depth"]], g["acc"] if c["acc"] else None, **c["kw"])
     np.testing.assert_allclose(got, g[case], atol=2e-6, rtol=0)
+
+
+# ------------------------------------------------------------------------------- G18: NaN / Inf / degenerate inputs
+def same_nans_and_close(got, want, atol=2e-6, rtol=1e-5, what=""):
+    """NaN exactly where the reference has NaN, Inf exactly where it has Inf (same sign), close elsewhere."""
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), \
+        f"{what}: NaN pattern differs at {np.argwhere(np.isnan(got) != np.isnan(want))[:8].tolist()}"
+    inf = np.isinf(want)
+    assert np.array_equal(np.isinf(got), inf) and np.array_equal(got[inf], want[inf]), f"{what}: Inf pattern differs"
+    ok = ~np.isnan(want) & ~inf
+    np.testing.assert_allclose(got[ok], want[ok], atol=atol, rtol=rtol, err_msg=what)
+
+
+def test_g18_viewdir_encoding_degenerate(golden):
+    g = golden("g18_degenerate")
+    assert np.isnan(g["vd_0_4"][0, :8]).all() and not np.isnan(g["vd_0_4"][0, 8:]).any()  # acos(1 + 2^-23): theta only
+    for lo, hi in ((0, 4), (1, 3)):
+        same_nans_and_close(O.viewdir_enc(T(g["vd_in"]), lo, hi), g[f"vd_{lo}_{hi}"], what=f"vd_{lo}_{hi}")
+
+
+def test_g18_sampling_and_lift_degenerate(golden):
+    g = golden("g18_degenerate")
+    r = {k: T(g["sample_rays_" + k]) for k in synthetic.RAY_FIELDS}
+    t = O.sample_t(r["near"], r["far"], 4)
+    same_nans_and_close(t, g["sample_t"], atol=0, rtol=2e-6, what="t")
+    m, c = O.para_rays(t, r["origins"], r["directions"], r["radii"])
+    same_nans_and_close(m, g["sample_means"], what="means")
+    same_nans_and_close(c, g["sample_covs"], atol=1e-9, rtol=2e-4, what="covs")
+    mean, cov = O.lift_to_xyz(T(g["lift_d"]), T(g["lift_tm"]), T(g["lift_tv"]), T(g["lift_rv"]))
+    same_nans_and_close(mean, g["lift_mean"], atol=1e-7, what="lift mean")
+    same_nans_and_close(cov, g["lift_cov"], atol=1e-9, what="lift cov")
+
+
+def test_g18_resampling_degenerate(golden):
+    g = golden("g18_degenerate")
+    t, w = T(g["resample_t"]), T(g["resample_w"])
+    same_nans_and_close(O.sorted_piecewise_constant_pdf(t, w.clone(), 9), g["pdf_samples"], what="pdf 9")
+    same_nans_and_close(O.sorted_piecewise_constant_pdf(t, w.clone(), 5), g["pdf_samples_5"], what="pdf 5")
+    new_t = O.resample_t(t, w, 0.01)
+    same_nans_and_close(new_t, g["resample_new_t"], what="resample t")
+    r = {k: T(g["resample_rays_" + k]) for k in synthetic.RAY_FIELDS}
+    m, c = O.para_rays(new_t, r["origins"], r["directions"], r["radii"])
+    same_nans_and_close(m, g["resample_means"], what="means")
+    same_nans_and_close(c, g["resample_covs"], atol=1e-7, rtol=2e-4, what="covs")
+    # what the reference does with a NaN weight: the whole row collapses onto the first bin edge - no NaN comes out
+    assert not np.isnan(g["resample_new_t"][0]).any() and np.all(g["resample_new_t"][0] == g["resample_t"][0, 0])
+
+
+def test_g18_weights_and_composite_degenerate(golden):
+    g = golden("g18_degenerate")
+    t, dens, rgb, dirs = (T(g["render_" + k]) for k in ("t", "density", "rgb", "dirs"))
+    same_nans_and_close(O.density_to_weight(t, dens, dirs), g["render_w_prop"], what="prop weights")
+    for wb in (False, True):
+        c, d, a, w = O.volumetric_rendering(rgb, dens, t, dirs, wb)
+        tag = f"render_wb{int(wb)}"
+        same_nans_and_close(c, g[tag + "_rgb"], what="rgb"), same_nans_and_close(a, g[tag + "_acc"], what="acc")
+        same_nans_and_close(d, g[tag + "_dist"], atol=2e-6, what="dist"), same_nans_and_close(w, g[tag + "_w"], what="w")
+    assert not np.isnan(g["render_wb0_dist"]).any()     # nan_to_num + clamp: the distance is never NaN
+
+
+@pytest.mark.parametrize("tag", ["local", "nan_origin", "nan_direction"])
+def test_g18_stage_forwards_degenerate(golden, tag):
+    g = golden("g18_degenerate")
+    n = int(g["e2e_cfg"][0])
+    sd = O.to_torch_state_dict({k[3:]: g[k] for k in g if k.startswith("sd.")})
+    rays = O.rays_from_numpy({k: g[f"e2e_{tag}_rays_{k}"] for k in synthetic.RAY_FIELDS})
+    hp = O.Hyper(num_samples=n)
+    with torch.no_grad():
+        t_hat, w_hat = O.prop_forward(rays, sd, hp)
+        outs = O.nerf_forward(rays, t_hat, w_hat, sd, hp)
+    same_nans_and_close(t_hat, g[f"e2e_{tag}_t_hat"], what="t_hat")
+    same_nans_and_close(w_hat, g[f"e2e_{tag}_w_hat"], atol=5e-6, what="w_hat")
+    for nm, v in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), outs):
+        same_nans_and_close(v, g[f"e2e_{tag}_{nm}"], atol=5e-6, rtol=1e-4, what=nm)
+    nan_rays = np.isnan(g[f"e2e_{tag}_rgb"]).any(1).nonzero()[0].tolist()
+    assert nan_rays == {"local": [0, 4], "nan_origin": [0, 4, 5], "nan_direction": list(range(8))}[tag]
