@@ -32,6 +32,17 @@ __device__ __forceinline__ float nan_to_numf_(float x) {
     if (isinf(x)) return x > 0 ? FLT_MAX : -FLT_MAX;
     return x;
 }
+// torch.maximum / torch.minimum: NaN if either operand is NaN (fmaxf / fminf return the other operand)
+__device__ __forceinline__ float nan_maxf_(float a, float b) { return (a != a || b != b) ? a + b : fmaxf(a, b); }
+__device__ __forceinline__ float nan_minf_(float a, float b) { return (a != a || b != b) ? a + b : fminf(a, b); }
+// ReLU that lets NaN through, as torch.relu does (v_max_f32 returns the non-NaN operand: relu(NaN) would be 0 and a ray
+// with NaN features would come out of the MLP finite).  Signed-integer max on the bit pattern: everything with the sign
+// bit set becomes +0, everything else - +NaN included, the only NaN the matrix pipes and the fp32 adders produce - stays.
+// One v_max_i32, the same cost as v_max_f32.  (Fixture G18.)
+__device__ __forceinline__ float relu_nanf_(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
 // value returned by the reference's g() on its `calls`-th application to the same tensor
 __device__ __forceinline__ float g_calls(float x, int calls) {
     for (int i = 0; i < calls; ++i) x = x + kEpsG;
@@ -118,7 +129,7 @@ __device__ __forceinline__ void contract_mean(float mean[3], float gnorm) {
 // what intern/parameterization.py:76-81 obtains from autograd per sample.
 __device__ __forceinline__ void contract_cov(const float y[3], float cov[9]) {
     const float r = sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
-    if (!(r > 1.0f)) return;  // J = I
+    if (r <= 1.0f) return;  // J = I.  A NaN norm takes the other branch, as `if x_norm <= 1` does in contract(): NaN Jacobian
     const float r2 = r * r;
     const float a = 2.0f / r - 1.0f / r2;
     const float b = 2.0f / (r2 * r2) - 2.0f / (r2 * r);

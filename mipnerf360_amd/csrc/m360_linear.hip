@@ -38,7 +38,7 @@ constexpr int TM = 4, TN = 2;   // 32x32 MFMA tiles per wave (M, N)
 
 template <int ACT>
 __device__ __forceinline__ float activate(float v) {
-    if (ACT == M360_ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == M360_ACT_RELU) return relu_nanf_(v);
     if (ACT == M360_ACT_SIGMOID) return persist::act_fn<M360_ACT_SIGMOID>(v);  // the same hardware exp / rcp form as the persistent kernel: rows of one layer never differ by kernel
     return v;
 }

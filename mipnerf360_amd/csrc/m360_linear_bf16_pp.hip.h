@@ -37,7 +37,7 @@ constexpr int kMaxBias = 4096;              // widest layer this kernel takes (b
 
 template <int ACT>
 __device__ __forceinline__ float act_fn(float v) {
-    if (ACT == M360_ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == M360_ACT_RELU) return relu_nanf_(v);
     if (ACT == M360_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     return v;
 }

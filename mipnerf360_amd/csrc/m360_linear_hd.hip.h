@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     do {                                                                                                     \
         if (!(ABL & 32)) {                                                                                   \
             _Pragma("unroll") for (int pp_ = PA; pp_ < PB; ++pp_) {                                          \
-                /* bias: two packed adds, ReLU: four v_max - spelled out: left to itself hipcc emits four v_add_f32 in some \
+                /* bias: two packed adds, ReLU: four v_max_i32 (NaN-preserving ReLU, relu_nanf_ of m360_common) - spelled out: left to itself hipcc emits four v_add_f32 in some \
                    instantiations, and a canonicalising v_max in front of every fmaxf on an asm result */   \
                 f32x2 lo_ = __builtin_shufflevector(ev[pp_], ev[pp_], 0, 1), hi_ = __builtin_shufflevector(ev[pp_], ev[pp_], 2, 3); \
                 const f32x2 blo_ = __builtin_shufflevector(bq[J], bq[J], 0, 1), bhi_ = __builtin_shufflevector(bq[J], bq[J], 2, 3); \
@@ -156,10 +156,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
                 asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi_) : "v"(hi_), "v"(bhi_));                            \
                 float e0_ = lo_[0], e1_ = lo_[1], e2_ = hi_[0], e3_ = hi_[1];                                \
                 if (ACT == M360_ACT_RELU) {                                                                  \
-                    asm("v_max_f32 %0, 0, %1" : "=v"(e0_) : "v"(e0_));                                       \
-                    asm("v_max_f32 %0, 0, %1" : "=v"(e1_) : "v"(e1_));                                       \
-                    asm("v_max_f32 %0, 0, %1" : "=v"(e2_) : "v"(e2_));                                       \
-                    asm("v_max_f32 %0, 0, %1" : "=v"(e3_) : "v"(e3_));                                       \
+                    asm("v_max_i32 %0, 0, %1" : "=v"(e0_) : "v"(e0_));                                       \
+                    asm("v_max_i32 %0, 0, %1" : "=v"(e1_) : "v"(e1_));                                       \
+                    asm("v_max_i32 %0, 0, %1" : "=v"(e2_) : "v"(e2_));                                       \
+                    asm("v_max_i32 %0, 0, %1" : "=v"(e3_) : "v"(e3_));                                       \
                 }                                                                                            \
                 ev[pp_] = (f32x4){e0_, e1_, e2_, e3_};                                                       \
             }                                                                                                \

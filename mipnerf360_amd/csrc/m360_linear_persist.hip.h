@@ -36,7 +36,7 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 template <int ACT>
 __device__ __forceinline__ float act_fn(float v) {
-    if (ACT == M360_ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == M360_ACT_RELU) return relu_nanf_(v);
     // hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each): |error| of the sigmoid <= ~2e-7 absolute,
     // against the 1e-4 render tolerance; the IEEE divide + full expf cost 8 % of a 1024x1024 layer
     if (ACT == M360_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.0f + __expf(-v));

@@ -32,7 +32,11 @@ __device__ __forceinline__ void wave_weights(const float *t, const float *rho, i
         float x = 0.0f;
         if (i < N) x = rho[i * rho_stride] * ((t[i + 1] - t[i]) * dnorm);
         const double incl = wave_incl_scan_d((double)x);
-        const float excl = (float)(carry + incl - (double)x);
+        // exclusive prefix = the previous lane's inclusive one (not incl - x: an infinite or NaN x_i must not reach its
+        // own transmittance; the reference's cumsum runs over x[:-1])
+        double prev = __shfl_up(incl, 1, kWave);
+        if (l == 0) prev = 0.0;
+        const float excl = (float)(carry + prev);
         if (i < N) w[i] = (1.0f - expf(-x)) * expf(-excl);
         carry += __shfl(incl, kWave - 1, kWave);
     }
@@ -42,8 +46,8 @@ __device__ __forceinline__ void wave_weights(const float *t, const float *rho, i
 __device__ __forceinline__ void wave_blur(const float *w, int N, float padding, float *out) {
     for (int i = lane_id(); i < N; i += kWave) {
         const float c = w[i];
-        const float lo = fmaxf(w[i > 0 ? i - 1 : 0], c);
-        const float hi = fmaxf(c, w[i < N - 1 ? i + 1 : N - 1]);
+        const float lo = nan_maxf_(w[i > 0 ? i - 1 : 0], c);  // torch.maximum: NaN-propagating
+        const float hi = nan_maxf_(c, w[i < N - 1 ? i + 1 : N - 1]);
         out[i] = 0.5f * (lo + hi) + padding;
     }
 }
@@ -57,7 +61,7 @@ __device__ __forceinline__ void wave_sorted_pdf(const float *bins, float *w, flo
     float part = 0.0f;
     for (int i = l; i < nw; i += kWave) part += w[i];
     float wsum = wave_sum(part);
-    const float pad = fmaxf(0.0f, 1e-5f - wsum);
+    const float pad = nan_maxf_(0.0f, 1e-5f - wsum);
     const float padw = pad / (float)nw;
     wsum = wsum + pad;
     // cdf[0] = 0, cdf[i+1] = min(1, cumsum(pdf)[i]) for i < nw-1, cdf[nw] = 1
@@ -67,7 +71,7 @@ __device__ __forceinline__ void wave_sorted_pdf(const float *bins, float *w, flo
         float pdf = 0.0f;
         if (i < nw - 1) pdf = (w[i] + padw) / wsum;
         const double incl = wave_incl_scan_d((double)pdf);
-        if (i < nw - 1) cdf[i + 1] = fminf(1.0f, (float)(carry + incl));
+        if (i < nw - 1) cdf[i + 1] = nan_minf_(1.0f, (float)(carry + incl));
         carry += __shfl(incl, kWave - 1, kWave);
     }
     if (l == 0) {
@@ -75,6 +79,15 @@ __device__ __forceinline__ void wave_sorted_pdf(const float *bins, float *w, flo
         cdf[nw] = 1.0f;
     }
     wave_sync();
+    // A cdf that is not a finite non-decreasing sequence (NaN / Inf / negative weights: never from the path's own
+    // weights, fixture G18) has no "sorted" bracket; the reference's comparison table (intern/ray.py:43-50) still defines
+    // one, evaluated literally below.
+    int bad = 0;
+    for (int i = l; i < nw; i += kWave) {
+        const float a = cdf[i], c = cdf[i + 1];
+        bad |= !(c >= a) || !(fabsf(c) <= FLT_MAX);
+    }
+    bad = __any(bad);
     const float f32eps = 1.1920928955078125e-07f;
     const float umax = 1.0f - f32eps;
     for (int j = l; j < ns; j += kWave) {
@@ -86,15 +99,28 @@ __device__ __forceinline__ void wave_sorted_pdf(const float *bins, float *w, flo
             const float base = (float)j * s;
             u = fminf(base + base + u_rand_row[j] * (s - f32eps), umax);
         }
-        // last index i with cdf[i] <= u  (cdf[0] = 0 <= u always)
-        int lo = 0, hi = nb;  // invariant: cdf[lo] <= u, (hi == nb or cdf[hi] > u)
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= u) lo = mid; else hi = mid;
+        float c0, c1, b0, b1;
+        if (!bad) {
+            // last index i with cdf[i] <= u  (cdf[0] = 0 <= u always)
+            int lo = 0, hi = nb;  // invariant: cdf[lo] <= u, (hi == nb or cdf[hi] > u)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] <= u) lo = mid; else hi = mid;
+            }
+            const int i0 = lo, i1 = lo + 1 < nb ? lo + 1 : nb - 1;
+            c0 = cdf[i0], c1 = cdf[i1];
+            b0 = bins[i0], b1 = bins[i1];
+        } else {
+            // x0 = max_i (u >= cdf_i ? x_i : x_0), x1 = min_i (u >= cdf_i ? x_last : x_i), NaN-propagating like torch.max / min
+            c0 = cdf[0], b0 = bins[0], c1 = cdf[nb - 1], b1 = bins[nb - 1];
+            for (int i = 0; i < nb; ++i) {
+                const bool m = u >= cdf[i];
+                c0 = nan_maxf_(c0, m ? cdf[i] : cdf[0]);
+                b0 = nan_maxf_(b0, m ? bins[i] : bins[0]);
+                c1 = nan_minf_(c1, m ? cdf[nb - 1] : cdf[i]);
+                b1 = nan_minf_(b1, m ? bins[nb - 1] : bins[i]);
+            }
         }
-        const int i0 = lo, i1 = lo + 1 < nb ? lo + 1 : nb - 1;
-        const float c0 = cdf[i0], c1 = cdf[i1];
-        const float b0 = bins[i0], b1 = bins[i1];
         float tt = nan_to_numf_((u - c0) / (c1 - c0));
         tt = fminf(fmaxf(tt, 0.0f), 1.0f);
         out_row[j] = b0 + tt * (b1 - b0);

@@ -342,6 +342,36 @@ def test_linear_kernel_variants_bit_identical(dev, M, n, k, act):
             assert torch.equal(y_blk, y_full[a:a + rows]), f"rows {a}..{a + rows} differ between the kernels"
 
 
+@pytest.mark.parametrize("M,n,k", [(1024, 256, 64), (1024, 256, 256), (700, 256, 64), (90, 96, 64), (1024, 512, 32)])
+def test_linear_relu_lets_nan_rows_through(dev, M, n, k):
+    """torch.relu(NaN) is NaN (model.py:43-53,131-148 are nn.ReLU): a sample whose features hold a NaN - of either sign -
+    must come out of every ReLU / sigmoid layer as NaN in EVERY unit, in every kernel behind m360_linear (half-tile,
+    256 x 256 persistent, ragged), and must not disturb any other row.  +Inf inputs follow IEEE through the MFMA."""
+    from mipnerf360_amd import _lib, ops
+    g = torch.Generator(device=dev).manual_seed(M + n + k)
+    x = torch.rand(M, k, device=dev, generator=g) * 2 - 1
+    w = (torch.rand(n, k, device=dev, generator=g) * 2 - 1) * (6.0 / k) ** 0.5
+    b = torch.rand(n, device=dev, generator=g) - 0.5
+    wp, bp = ops.pack_linear(w, b)
+    bad = x.clone()
+    pos_nan = torch.tensor([0x7FC00000], dtype=torch.int32).view(torch.float32).item()
+    rows = [5, M // 2 + 3, M - 1]
+    bad[rows[0], 3] = pos_nan
+    bad.view(torch.int32)[rows[1], 7] = -4194304         # 0xFFC00000: the negative quiet NaN x86 produces
+    bad[rows[2], k - 1] = float("nan")
+    for act in (_lib.ACT_RELU, _lib.ACT_SIGMOID, _lib.ACT_NONE):
+        clean = ops.linear(x, wp, bp, act)
+        y = ops.linear(bad, wp, bp, act)
+        assert torch.isnan(y[rows]).all(), f"act {act}: a NaN input row came out with finite units"
+        keep = torch.ones(M, dtype=torch.bool, device=dev)
+        keep[rows] = False
+        assert torch.equal(y[keep], clean[keep])
+        if act == _lib.ACT_RELU:  # what the next layer's ReLU sees: NaN * w + b in every unit -> NaN again
+            y2 = ops.linear(torch.nn.functional.pad(y, (0, 0))[:, :k].contiguous(), wp, bp, act) if n >= k else None
+            if y2 is not None:
+                assert torch.isnan(y2[rows]).all()
+
+
 def test_linear_rejects_bad_arguments(dev):
     from mipnerf360_amd import ops
     x = torch.zeros(4, 48, device=dev)
