@@ -45,6 +45,23 @@ def T(x):
     return torch.from_numpy(np.ascontiguousarray(x)).float().clone()
 
 
+def T64(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).double().clone()
+
+
+class reference_in_fp64:
+    """Run the reference in double precision: its fp32-ness comes from torch's default dtype alone (`Jf = torch.zeros(..)`
+    in gaussian_contract, `torch.linspace`, `torch.eye`: intern/parameterization.py:75,57, intern/ray.py:99), so with the
+    default switched and fp64 inputs the SAME code evaluates the same formulas in fp64.  Used to measure how far the
+    reference's own fp32 covariances are from their exact values (the t_var cancellation, parameterization.py:102-105)."""
+
+    def __enter__(self):
+        torch.set_default_dtype(torch.float64)
+
+    def __exit__(self, *a):
+        torch.set_default_dtype(torch.float32)
+
+
 def N(x):
     return x.detach().cpu().numpy().copy()
 
@@ -74,6 +91,11 @@ def g1_g2():
             # sample count, so the near = 0 / N = 128 near-denormal t_var / r_var are pinned directly (768 Jacobian calls)
             out[key + "_means"] = N(means)
             out[key + "_covs"] = N(covs)
+            with reference_in_fp64():  # the same call in double precision, from the same fp32 ray values
+                _, (means64, covs64) = ref_ray.sample_along_rays(
+                    T64(r["origins"]), T64(r["directions"]), T64(r["radii"]), n, T64(r["near"]), T64(r["far"]), False)
+            assert means64.dtype == torch.float64 and covs64.dtype == torch.float64
+            out[key + "_means64"], out[key + "_covs64"] = N(means64), N(covs64)
             # pre-contraction lift (G2)
             # the frustum moments are only INPUTS of the reference's gaussian_to_xyz here; they
             # are pinned end-to-end by the contracted means/covs of sample_along_rays above
@@ -192,6 +214,10 @@ def g6():
         out[f"resample_t_pad{pad}"] = N(new_t)
         if pad == 0.01:
             out["resample_means"], out["resample_covs"] = N(means), N(covs)
+            with reference_in_fp64():
+                t64, (means64, covs64) = ref_ray.resample_along_rays(T64(r["origins"]), T64(r["directions"]), T64(r["radii"]),
+                                                                     T64(t), T64(w), False, pad)
+            out["resample_t64"], out["resample_means64"], out["resample_covs64"] = N(t64), N(means64), N(covs64)
     for k in synthetic.RAY_FIELDS:
         out["rays_" + k] = r[k]
     save("g6_resample", **out)

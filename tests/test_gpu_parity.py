@@ -9,6 +9,7 @@ per-op kernels are held much tighter (1e-6 .. 1e-5).
 import numpy as np
 import pytest
 import torch
+from conftest import assert_cov_within_reference_error
 
 from mipnerf360_amd import synthetic
 
@@ -77,7 +78,10 @@ def test_g1_g2_sampling_and_lift(golden, dev, kind, n):
     close(cov, g[f"{kind}_{n}_xyzcov"], atol=1e-9, rtol=1e-5)
     # the reference's own contracted Gaussians at every sample count (near = 0 / N = 128: near-denormal variances)
     close(means, g[f"{kind}_{n}_means"])
-    close(covs, g[f"{kind}_{n}_covs"], atol=1e-9 if n == 8 else 1e-12, rtol=2e-4)
+    # covariances: the tolerance is the reference's own fp32 error against its fp64 evaluation (2.4e-6 ... 5e-5 of the
+    # matrix scale on these inputs), not a guessed rtol
+    assert_cov_within_reference_error(H(covs), g[f"{kind}_{n}_covs"], g[f"{kind}_{n}_covs64"], what=f"{kind} N={n}")
+    close(means, g[f"{kind}_{n}_means64"], atol=2e-6, rtol=1e-6)
 
 
 @pytest.mark.parametrize("case", ["big", "tiny", "inside"])
@@ -128,7 +132,7 @@ def test_g6_resampling(golden, dev):
         close(new_t, g[f"resample_t_pad{pad}"], atol=4e-6)
         if pad == 0.01:
             close(means, g["resample_means"], atol=4e-6)
-            close(covs, g["resample_covs"], atol=1e-9, rtol=2e-3)
+            assert_cov_within_reference_error(H(covs), g["resample_covs"], g["resample_covs64"], what="resampled covs")
     assert torch.equal(w, w_before)
 
 
@@ -397,7 +401,13 @@ def test_sample_encode_vs_oracle(dev, kind, B, n):
     t = ops.sample_t(rd.near, rd.far, n)
     close(t, t_o, atol=0, rtol=2e-6)
     m, c = ops.para_rays(t, rd.origins, rd.directions, rd.radii)
-    close(m, m_o, atol=2e-6), close(c, c_o, atol=1e-9, rtol=1e-3)
+    close(m, m_o, atol=2e-6)
+    # covariances against the oracle's formulas evaluated in fp64 on the same fp32 rays: no further than 3 x the fp32
+    # oracle's own distance from them
+    r64 = O.Rays(*[f.double() for f in ro])
+    _, c_64 = O.para_rays(O.sample_t(r64.near, r64.far, n).expand(B, -1).contiguous(), r64.origins, r64.directions, r64.radii)
+    assert c_64.dtype == torch.float64
+    assert_cov_within_reference_error(H(c), c_o.numpy(), c_64.numpy(), what=f"{kind} B={B} N={n}")
     vd = ops.viewdir_enc(rd.viewdirs, 0, 4)
     close(vd, O.viewdir_enc(ro.viewdirs), atol=4e-6)
     feat = ops.encode_features(t, rd.origins, rd.directions, rd.radii, vd)

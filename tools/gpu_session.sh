@@ -32,7 +32,7 @@ for s in $steps; do
                timeout 600 rocprofv3 $PMC --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1 )
              # raw traces are large: keep the csv files the summariser needs, drop the rest
              find $O -name "*.db" -delete 2>/dev/null; du -sh $O; tail -2 $O/bench_under_rocprof.log | cut -c1-300 ;;
-    r3new)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "span or one_chunk or bench_ or two_ranks or c2_full or rccl" > $out/pytest_r3new.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r3new.log; tail -25 $out/pytest_r3new.log ;;
+    r3new)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "span or one_chunk or bench_ or two_ranks or c2_full or rccl or g18 or nan_rows" > $out/pytest_r3new.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r3new.log; tail -25 $out/pytest_r3new.log ;;
     nccl2)   # two RCCL ranks on a 1-GPU box: must fail with RCCL's own error (not a SystemExit of bench.py), and must not hang
              timeout 300 python bench.py --gpus 2 --steps 2 --warmup 1 --frame-steps 0 > $out/nccl2.out 2> $out/nccl2.err; echo "rc=$?" >> $out/nccl2.out; tail -3 $out/nccl2.out; grep -i "nccl\|rccl\|duplicate\|error" $out/nccl2.err | head -12 ;;
     c4)      timeout 900 python bench.py --config c4 --steps 2 --warmup 1 > $out/bench_c4.json 2> $out/bench_c4.err; tail -c 2500 $out/bench_c4.json ;;
