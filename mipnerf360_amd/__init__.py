@@ -12,7 +12,7 @@ import sys
 __version__ = "0.1.0"
 
 
-def install_dropin(reference_root=None, mutate_like_reference: bool = False) -> None:
+def install_dropin(reference_root=None, mutate_like_reference: bool = True) -> None:
     """Make `import model` / `from intern.ray import ...` (the reference's module names, as used
     by its train.py / test.py / video.py) resolve to this package.
 
@@ -22,10 +22,11 @@ def install_dropin(reference_root=None, mutate_like_reference: bool = False) -> 
     package has no mirror for) and names on the allowlist of out-of-scope host helpers fall through lazily
     (mipnerf360_amd/intern/_fallback.py).
 
-    `mutate_like_reference`: models built afterwards also reproduce the reference's in-place `g()` side effect on
-    `rays.near` / `rays.far` (+3e-6 / +2e-6 per forward pair, intern/parameterization.py:15-21), so train.py's three
-    pairs per iteration drift exactly like the reference's (fixture G14).  Default off: caller tensors are never
-    mutated and every forward behaves like the reference's FIRST forward on fresh rays."""
+    `mutate_like_reference` (default True HERE, because the drop-in exists to run the reference's own scripts): models
+    built afterwards also reproduce the reference's in-place `g()` side effect on `rays.near` / `rays.far` (+3e-6 / +2e-6
+    per forward pair, intern/parameterization.py:15-21), so train.py's three pairs per iteration drift exactly like the
+    reference's (fixture G14) and training curves are comparable.  False: caller tensors are never mutated and every
+    forward behaves like the reference's FIRST forward on fresh rays - the default of `mipnerf360_amd.model` used directly."""
     import os
     from . import intern, model
     from .intern import _fallback, distillation, encoding, loss, parameterization, pose, ray, regularization, utils

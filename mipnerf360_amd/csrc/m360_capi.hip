@@ -111,8 +111,10 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     L.act_a = take(S * wmax * sizeof(float));
     L.act_b = take(S * wmax * sizeof(float));
     // partial head sums of the fused last layer: [S][slots][heads] fp32 (67 MB at 4096 x 128, width 1024)
-    const size_t hp_slots = (size_t)m360_linear_heads_slots(m->hp_pad, m->mlp_bf16), hn_slots = (size_t)m360_linear_heads_slots(m->hn_pad, m->mlp_bf16);  // (an upper bound: sized whether or not the widths allow fusion)
-    const size_t hp_b = S * hp_slots * 1 * sizeof(float), hn_b = S * hn_slots * 4 * sizeof(float);
+    // sized by the rows the fused epilogue really covers: none in bf16 mode or at widths it does not take
+    const size_t hp_slots = (size_t)m360_linear_heads_slots(m->hp_pad, m->mlp_bf16), hn_slots = (size_t)m360_linear_heads_slots(m->hn_pad, m->mlp_bf16);
+    const size_t hp_rows = (size_t)m360_linear_heads_fused_rows((long)S, m->hp_pad, m->mlp_bf16), hn_rows = (size_t)m360_linear_heads_fused_rows((long)S, m->hn_pad, m->mlp_bf16);
+    const size_t hp_b = hp_rows * hp_slots * 1 * sizeof(float), hn_b = hn_rows * hn_slots * 4 * sizeof(float);
     L.hpart = take(hp_b > hn_b ? hp_b : hn_b);
     L.queues = take((size_t)kQueueSlots * kQueueStride * sizeof(unsigned));
     L.total = off;

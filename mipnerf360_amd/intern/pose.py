@@ -60,6 +60,7 @@ def visualize_depth(depth, acc=None, near=None, far=None, ignore_frac=0, curve_f
             return back(ops.visualize_depth(d, a, near=near, far=far, modulus=float(modulus)))
         return back(ops.visualize_depth_ex(d, a, near, far, ignore_frac=float(ignore_frac), modulus=float(modulus)))
     curved = curve_fn is not None
+    auto = {}
     if curved:
         if not near or not far:  # the automatic planes are chosen on the UNcurved map, then curved like it
             planes = ops.visualize_depth_ex(d, a, near, far, ignore_frac=float(ignore_frac), want="planes").cpu().numpy()
@@ -67,14 +68,14 @@ def visualize_depth(depth, acc=None, near=None, far=None, ignore_frac=0, curve_f
         host = d.cpu().numpy()
         dc = _to_dev(np.asarray(curve_fn(host), dtype=np.float32))
         near, far = float(curve_fn(np.float32(near))), float(curve_fn(np.float32(far)))
-        if near == 0.0 or far == 0.0:
-            raise ValueError("visualize_depth: a curve_fn that maps a plane to exactly 0 cannot be told from 'automatic plane'")
+        auto = dict(near_auto=False, far_auto=False)  # both planes are known now; a curved value of exactly 0.0 is legal
     else:
         dc = d
     if colormap is None:
-        return back(ops.visualize_depth_ex(dc, a, near, far, ignore_frac=float(ignore_frac), curved=curved, modulus=float(modulus)))
+        return back(ops.visualize_depth_ex(dc, a, near, far, ignore_frac=float(ignore_frac), curved=curved, modulus=float(modulus),
+                                           **auto))
     value = ops.visualize_depth_ex(dc, a, near, far, ignore_frac=float(ignore_frac), curved=curved, modulus=float(modulus),
-                                   want="value").cpu().numpy()
+                                   want="value", **auto).cpu().numpy()
     colors = np.asarray(colormap(value), dtype=np.float32)[:, :, :3]
     return back(ops.visualize_composite(_to_dev(colors), a, d))
 

@@ -17,7 +17,8 @@ There is no CPU path: tensors must be on a HIP device and libm360.so must be bui
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional
+from collections import OrderedDict
+from typing import Optional
 
 import torch
 import torch.nn as nn
@@ -26,7 +27,8 @@ from . import _lib, ops
 from .intern.encoding import PositionalEncoding, ViewdirectionEncoding
 from .intern.ray import Rays, namedtuple_map
 
-_WORKSPACES: Dict[tuple, torch.Tensor] = {}
+_WORKSPACES: "OrderedDict[tuple, torch.Tensor]" = OrderedDict()
+_MAX_WORKSPACES_PER_DEVICE = 3  # streams per device whose scratch is kept (one entry is 4.5 GB at 4096 x 128, full width)
 
 # Default of the `mutate_like_reference` attribute of newly built models (install_dropin(..., mutate_like_reference=True)
 # sets it): reproduce the reference's in-place g() side effect on rays.near / rays.far (intern/parameterization.py:15-21).
@@ -45,7 +47,9 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per (device, stream): work queued on different streams (a second model rendering on a
     side stream, eval overlapped with training) never shares scratch, and everything launched on one stream is
     ordered by that stream.  A buffer that is outgrown goes back to torch's caching allocator, which is stream-aware
-    for the stream it was allocated on - the one it was used on."""
+    for the stream it was allocated on - the one it was used on.  At most 3 streams per device keep their buffer (least
+    recently used first out): short-lived side streams do not pile up multi-GB entries, and a recycled stream handle
+    finds at worst a buffer that was used on a stream with the same handle, i.e. itself."""
     device = torch.device(device)
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
@@ -57,10 +61,18 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
         with torch.cuda.device(device):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _WORKSPACES[key] = ws
+        mine = [k for k in _WORKSPACES if k[0] == device]
+        for k in mine[:max(0, len(mine) - _MAX_WORKSPACES_PER_DEVICE)]:
+            # safe while kernels queued on ITS stream still use it: the caching allocator keeps a freed block in the pool of
+            # the stream it was allocated on (= the only stream it was used on) and reuses it in that stream's order
+            del _WORKSPACES[k]
+    else:
+        _WORKSPACES.move_to_end(key)
     return ws
 
 
 def release_workspaces() -> None:
+    """Drop every cached scratch buffer (after all queued work is done: synchronise first)."""
     _WORKSPACES.clear()
 
 
@@ -198,6 +210,9 @@ class _TrainCtx:
             raise RuntimeError("trying to backward through a mipnerf360_amd stage a second time: its tape (saved activations) "
                                "was freed by the first backward")
         module, packed, dev = self.module, self.packed, self.tape.device
+        # the event recorder of the FORWARD may have been detached / closed since: use what is attached now, or none
+        prof = getattr(module, "prof", None)
+        self.hyper.prof = prof.handle if (prof is not None and getattr(prof, "handle", None)) else None
         if [p._version for p in module.parameters()] != self.versions:
             raise RuntimeError("a parameter was modified in place between the forward and its backward")
         lib = _lib.lib()

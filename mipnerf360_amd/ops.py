@@ -530,9 +530,13 @@ def visualize_depth(depth, acc=None, near=None, far=None, modulus: float = 0.0) 
 
 
 def visualize_depth_ex(depth, acc=None, near=None, far=None, ignore_frac: float = 0.0, curved: bool = False,
-                       modulus: float = 0.0, want: str = "vis"):
+                       modulus: float = 0.0, want: str = "vis", near_auto: Optional[bool] = None,
+                       far_auto: Optional[bool] = None):
     """m360_visualize_depth_ex.  want = "vis" -> colours [h,w,3]; "value" -> the colormap argument [h,w];
-    "planes" -> the automatic (near, far) planes as a device float[2] (nothing rendered)."""
+    "planes" -> the automatic (near, far) planes as a device float[2] (nothing rendered).
+    near_auto / far_auto: choose that plane from the map.  Default None = the reference's `near or ...` rule (a falsy
+    plane is automatic, intern/pose.py:176-177); pass False to use the given value even when it is 0.0 (a plane that a
+    curve_fn mapped to exactly 0)."""
     depth = dev(depth, "depth")
     acc = None if acc is None else dev(acc, "acc")
     h, w = depth.shape
@@ -541,7 +545,9 @@ def visualize_depth_ex(depth, acc=None, near=None, far=None, ignore_frac: float 
     vis = torch.empty(h, w, 3, device=d) if want == "vis" else None
     value = torch.empty(h, w, device=d) if want == "value" else None
     planes = torch.empty(2, device=d) if want == "planes" else None
-    _call("m360_visualize_depth_ex", depth, acc, h, w, float(near or 0.0), float(far or 0.0), int(not near), int(not far),
+    near_auto = (not near) if near_auto is None else bool(near_auto)
+    far_auto = (not far) if far_auto is None else bool(far_auto)
+    _call("m360_visualize_depth_ex", depth, acc, h, w, float(near or 0.0), float(far or 0.0), int(near_auto), int(far_auto),
           float(ignore_frac), int(bool(curved)), float(modulus), vis, value, planes, ws, ws.numel(), STREAM)
     return vis if want == "vis" else (value if want == "value" else planes)
 

@@ -164,7 +164,12 @@ def test_dropin_aliases():
         from intern.parameterization import t_to_s  # noqa: F401
         from intern.utils import to8b  # noqa: F401
         assert ref_named_model.mipNeRF360 is mipnerf360_amd.model.mipNeRF360
+        # the drop-in runs the reference's own scripts: its models reproduce the in-place g() drift by default (G14) ...
+        assert mipnerf360_amd.model.MUTATE_LIKE_REFERENCE is True
+        mipnerf360_amd.install_dropin(mutate_like_reference=False)
+        assert mipnerf360_amd.model.MUTATE_LIKE_REFERENCE is False  # ... direct use of mipnerf360_amd.model never mutates
     finally:
+        mipnerf360_amd.model.MUTATE_LIKE_REFERENCE = False
         for k, v in saved.items():
             if v is None:
                 sys.modules.pop(k, None)
