@@ -121,6 +121,7 @@ int m360_viewdir_enc(const float *viewdirs /*[B,3]*/, int B, int min_deg, int ma
 
 /* fused: t_vals + rays (+ per-ray view-direction encoding vdenc[B,vd_ch]) -> MLP input rows
  * feat[B*N, ld_feat] = [ipe(42) | vdenc(vd_ch) | zero pad].  No means/covs are materialised.
+ * A NaN feature (NaN rays, |viewdir z| > 1) is written as the positive quiet NaN 0x7FC00000 whatever its source's sign.
  * Replaces model.py:82-88 / :167-176 minus the t sampling (fused para_rays + IPE + repeat + cat). */
 int m360_encode_features(const float *t_vals /*[B,N+1]*/, const float *origins,
                          const float *directions, const float *radii, const float *vdenc, int vd_ch,
@@ -135,7 +136,12 @@ int m360_pack_linear(const float *w, const float *b, int n_out, int k_in, int n_
                      float *w_packed, float *b_packed, m360_stream_t stream);
 
 /* y[M,n_pad] = act(x[M,k_pad] * w_packed^T + b_packed) on fp32 MFMA (v_mfma_f32_32x32x2_f32).
- * One nn.Linear + activation of model.py:43-53 / :131-148. */
+ * One nn.Linear + activation of model.py:43-53 / :131-148.
+ * NaN: like torch.relu, the ReLU epilogue lets NaN through - a row of x that holds a NaN comes out NaN in every unit
+ * (fixture G18).  It is a signed-integer max on the bit pattern, so this holds for NaNs with a CLEAR sign bit
+ * (0x7FC00000, what numpy / torch write for float('nan') and what m360_encode_features writes for every NaN feature);
+ * the matrix pipe hands a NaN operand on with its sign, and a NaN with the sign bit set (x86's default result of 0/0)
+ * is treated as a negative number by the ReLU.  Sigmoid / none epilogues keep either. */
 int m360_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed,
                 int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t stream);
 

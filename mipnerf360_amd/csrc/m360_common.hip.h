@@ -43,6 +43,10 @@ __device__ __forceinline__ float relu_nanf_(float v) {
     const int b = __builtin_bit_cast(int, v);
     return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
+// NaN -> the positive quiet NaN 0x7FC00000, everything else unchanged.  The fp32 MFMA and the fp32 adders hand a NaN
+// operand on with its sign and payload (measured: tools/diag/nan_bits.py), so a feature row that enters the MLP with its
+// NaNs canonicalised stays +NaN through every layer - which is what relu_nanf_ relies on.
+__device__ __forceinline__ float canon_nanf_(float v) { return v != v ? __builtin_bit_cast(float, 0x7FC00000) : v; }
 // value returned by the reference's g() on its `calls`-th application to the same tensor
 __device__ __forceinline__ float g_calls(float x, int calls) {
     for (int i = 0; i < calls; ++i) x = x + kEpsG;

@@ -369,8 +369,9 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
         float m[3], c[9];
         const float gn = ext_norm ? *ext_norm : (group_rays > 0 ? ws->gnorms[b / group_rays] : ws->gnorm);
         sample_gaussian(t_vals, origins, directions, radii, N, b, n, gn, m, c);
-        ipe_sample<true>(m, c, [&](int k, float v) { row[k] = v; });
-        for (int k = 0; k < vd_ch; ++k) row[kIpeCh + k] = vdenc[(long)b * vd_ch + k];
+        // NaN features are written as +NaN (canon_nanf_): the MLP's ReLU keeps exactly those
+        ipe_sample<true>(m, c, [&](int k, float v) { row[k] = canon_nanf_(v); });
+        for (int k = 0; k < vd_ch; ++k) row[kIpeCh + k] = canon_nanf_(vdenc[(long)b * vd_ch + k]);
         for (int k = kIpeCh + vd_ch; k < ld; ++k) row[k] = 0.0f;
     }
     __syncthreads();
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kern
             float val;
             if (ch < kIpeCh) val = v[ch];
             else val = (live && ch - kIpeCh < vd_ch) ? vdenc[(long)b * vd_ch + (ch - kIpeCh)] : 0.0f;
-            tile[lane * kEncTileLd + cc] = val;
+            tile[lane * kEncTileLd + cc] = canon_nanf_(val);  // NaN features go out as +NaN: the MLP's ReLU keeps exactly those
         }
         wave_sync_lds();
         if (!BF16) {  // 8 lanes x 16 B = one 128-byte row segment; 8 rows per instruction

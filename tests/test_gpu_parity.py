@@ -348,9 +348,11 @@ def test_linear_kernel_variants_bit_identical(dev, M, n, k, act):
 
 @pytest.mark.parametrize("M,n,k", [(1024, 256, 64), (1024, 256, 256), (700, 256, 64), (90, 96, 64), (1024, 512, 32)])
 def test_linear_relu_lets_nan_rows_through(dev, M, n, k):
-    """torch.relu(NaN) is NaN (model.py:43-53,131-148 are nn.ReLU): a sample whose features hold a NaN - of either sign -
-    must come out of every ReLU / sigmoid layer as NaN in EVERY unit, in every kernel behind m360_linear (half-tile,
-    256 x 256 persistent, ragged), and must not disturb any other row.  +Inf inputs follow IEEE through the MFMA."""
+    """torch.relu(NaN) is NaN (model.py:43-53,131-148 are nn.ReLU): a sample whose features hold a NaN must come out of
+    every ReLU / sigmoid layer as NaN in EVERY unit, in every kernel behind m360_linear (half-tile, 256 x 256 persistent,
+    ragged), and must not disturb any other row.  The ReLU is a signed-integer max (include/m360.h): it keeps NaNs with a
+    clear sign bit - what the path's encoder writes for every NaN feature (next test) - and the matrix pipe hands a NaN
+    operand on with its sign and payload, so such a row stays +NaN through a whole stack of layers."""
     from mipnerf360_amd import _lib, ops
     g = torch.Generator(device=dev).manual_seed(M + n + k)
     x = torch.rand(M, k, device=dev, generator=g) * 2 - 1
@@ -358,22 +360,52 @@ def test_linear_relu_lets_nan_rows_through(dev, M, n, k):
     b = torch.rand(n, device=dev, generator=g) - 0.5
     wp, bp = ops.pack_linear(w, b)
     bad = x.clone()
-    pos_nan = torch.tensor([0x7FC00000], dtype=torch.int32).view(torch.float32).item()
     rows = [5, M // 2 + 3, M - 1]
-    bad[rows[0], 3] = pos_nan
-    bad.view(torch.int32)[rows[1], 7] = -4194304         # 0xFFC00000: the negative quiet NaN x86 produces
+    bad[rows[0], 3] = float("nan")                        # 0x7FC00000
+    bad.view(torch.int32)[rows[1], 7] = 0x7FC12345         # a payload
     bad[rows[2], k - 1] = float("nan")
     for act in (_lib.ACT_RELU, _lib.ACT_SIGMOID, _lib.ACT_NONE):
         clean = ops.linear(x, wp, bp, act)
         y = ops.linear(bad, wp, bp, act)
         assert torch.isnan(y[rows]).all(), f"act {act}: a NaN input row came out with finite units"
+        assert (y[rows].view(torch.int32) > 0).all()      # and still with a clear sign bit: the next layer's ReLU keeps it too
         keep = torch.ones(M, dtype=torch.bool, device=dev)
         keep[rows] = False
         assert torch.equal(y[keep], clean[keep])
-        if act == _lib.ACT_RELU:  # what the next layer's ReLU sees: NaN * w + b in every unit -> NaN again
-            y2 = ops.linear(torch.nn.functional.pad(y, (0, 0))[:, :k].contiguous(), wp, bp, act) if n >= k else None
-            if y2 is not None:
-                assert torch.isnan(y2[rows]).all()
+    # the sign-bit convention, pinned: sigmoid / none keep a negative NaN, the integer-max ReLU reads it as negative
+    neg = x.clone()
+    neg.view(torch.int32)[5, 3] = -4194304                # 0xFFC00000
+    assert torch.isnan(ops.linear(neg, wp, bp, _lib.ACT_NONE)[5]).all()
+    assert not torch.isnan(ops.linear(neg, wp, bp, _lib.ACT_RELU)[5]).any()
+
+
+def test_encoder_writes_every_nan_feature_with_a_clear_sign_bit(dev):
+    """The convention the ReLU relies on: whatever the sign of the NaN in the rays (x86 arithmetic produces 0xFFC00000),
+    m360_encode_features writes 0x7FC00000 - checked on the features of the fused path's encoder, fp32 and bf16."""
+    from mipnerf360_amd import _lib, ops
+    r = synthetic.make_rays("garden", 70, seed=5)
+    rays = dev_rays(r, dev)
+    neg_nan = torch.tensor([-4194304], dtype=torch.int32, device=dev).view(torch.float32)
+    rays.origins[3, 1] = neg_nan[0]          # NaN mean (added after the contraction): IPE sin / cos NaN
+    rays.radii[9, 0] = neg_nan[0]            # NaN covariance only: the damping factor is NaN
+    rays.viewdirs[20] = torch.tensor([0.0, 0.0, -(1.0 + 2.0 ** -23)], device=dev)
+    rays.viewdirs[21, 0] = neg_nan[0]
+    n = 24
+    t = ops.sample_t(rays.near, rays.far, n)
+    vd = ops.viewdir_enc(rays.viewdirs, 0, 4)
+    feats = [ops.encode_features(t, rays.origins, rays.directions, rays.radii, vd, 64)]
+    fb = torch.empty(70 * n, 64, device=dev, dtype=torch.bfloat16)
+    ws = torch.empty(_lib.lib().m360_contract_workspace_bytes(), dtype=torch.uint8, device=dev)
+    ops.call("m360_encode_features_bf16", t, rays.origins, rays.directions, rays.radii, vd, 16, 70, n, fb, 64, ws, ws.numel(),
+             ops.STREAM)
+    feats.append(fb)
+    for feat in feats:
+        f32 = feat.float().view(70, n, 64)
+        nan = torch.isnan(f32)
+        assert nan[3, :, :42].all() and nan[9, :, :42].all() and nan[20, :, 42:50].all() and nan[21, :, 42:58].any()
+        assert not nan[[0, 1, 2, 4, 5]].any()
+        bits = f32.contiguous().view(torch.int32)
+        assert (bits[nan] > 0).all(), "a NaN feature left the encoder with its sign bit set"
 
 
 def test_linear_rejects_bad_arguments(dev):
