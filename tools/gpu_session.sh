@@ -36,6 +36,7 @@ for s in $steps; do
     nccl2)   # two RCCL ranks on a 1-GPU box: must fail with RCCL's own error (not a SystemExit of bench.py), and must not hang
              timeout 300 python bench.py --gpus 2 --steps 2 --warmup 1 --frame-steps 0 > $out/nccl2.out 2> $out/nccl2.err; echo "rc=$?" >> $out/nccl2.out; tail -3 $out/nccl2.out; grep -i "nccl\|rccl\|duplicate\|error" $out/nccl2.err | head -12 ;;
     c4)      timeout 900 python bench.py --config c4 --steps 2 --warmup 1 > $out/bench_c4.json 2> $out/bench_c4.err; tail -c 2500 $out/bench_c4.json ;;
+    lintests) timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "linear or soak or bit_identical or one_chunk or g8 or g7 or fused" > $out/pytest_linear.log 2>&1; echo "pytest rc=$?" >> $out/pytest_linear.log; tail -6 $out/pytest_linear.log ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
