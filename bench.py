@@ -90,9 +90,10 @@ def parse_args(argv=None):
                          "(configs[3], strong scaling); c5 = BASELINE configs[4]'s shape (bf16)")
     ap.add_argument("--cpu-rays", type=int, default=None,
                     help="rays of the batch timed on the host CPU (default: the whole 4096-ray batch for c2, 0 = skip)")
-    ap.add_argument("--mlp-dtype", choices=("fp32", "bf16"), default=None,
+    ap.add_argument("--mlp-dtype", choices=("fp32", "bf16", "bf16x3"), default=None,
                     help="override the workload's MLP precision (c2: fp32 = the headline; bf16 = opt-in reduced-precision "
-                         "MLP, reported with dtype bf16 and never comparable to the fp32 line)")
+                         "MLP, reported with dtype bf16 and never comparable to the fp32 line; bf16x3 = two bf16 terms per "
+                         "value, three MFMA passes per product: inside the fp32 render tolerance, reported with dtype bf16x3)")
     ap.add_argument("--frame-steps", type=int, default=None,
                     help="c2 only: frames of the 1237x822 strong-scaling workload rendered AFTER the timed region and "
                          "reported as `strong_scaling_frame` (default 1; 0 = skip)")
@@ -237,12 +238,13 @@ class Comm:
             self.dist.destroy_process_group()
 
 
-def roofline_from_records(recs, S, bf16, config_name, _lib):
+def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
     lin_kind = _lib.K_LINEAR_BF16 if bf16 else _lib.K_LINEAR
-    durs = [r["ms"] for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == HN and r["M"] == S]
+    kk = 3 * HN if x3 else HN  # bf16x3: one contraction of length 3K (xh wh + xl wh + xh wl)
+    durs = [r["ms"] for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == kk and r["M"] == S]
     if not durs:
         return None
-    flops = 2.0 * S * HN * HN
+    flops = 2.0 * S * HN * kk  # what the matrix pipe executes (bf16x3: three times the layer's algorithmic FLOPs)
     avg_ms = sum(durs) / len(durs)
     achieved = flops / (avg_ms * 1e-3) / 1e12
     traffic, traffic_note = None, None
@@ -256,27 +258,29 @@ def roofline_from_records(recs, S, bf16, config_name, _lib):
         else:
             traffic_note = "profiles/traffic.json was measured on different kernel sources (stale): not reported"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    kname = "linear_bf16_pp_kernel" if bf16 else "linear_f32_hd_kernel"
+    kname = ("linear_bf16_pp_kernel<X3> (bf16x3: 3 MFMA passes per product)" if x3 else "linear_bf16_pp_kernel") if bf16 else "linear_f32_hd_kernel"
     roofline = {"bound": "mfma", "kernel": f"{kname} (1024x1024 layer, M={S})", "achieved": round(achieved, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),
                 "median_launch_ms": round(statistics.median(durs), 4), "flops_per_launch": flops}
     if traffic_note:
         roofline["traffic_note"] = traffic_note
+    if x3:
+        roofline["layer_algorithmic_tflops"] = round(achieved / 3.0, 2)  # 2 M N K of the fp32 layer / launch time
     return roofline
 
 
-def hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib):
+def hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib, x3=False):
     """HBM-bound kernels of the path: algorithmic bytes / mean launch duration.  The finishers read the
     last layer's partial head sums [S, slots, heads] fp32 for the rows the fused epilogue covered, activation rows else."""
     S = n_rays * samples
-    el = 2 if bf16 else 4
+    el = 2 if (bf16 and not x3) else 4  # bf16x3 rows are [hi | lo] pairs: 4 bytes per value, like fp32
     lib = _lib.lib()
     enc = [r for r in recs if r["kind"] == _lib.K_ENCODE]
     in_pad = enc[0]["n_pad"] if enc else 64  # row length of the MLP input the encoder writes (58 channels, zero-padded)
 
     def finish_in_bytes(width, heads):
-        fused = int(lib.m360_linear_heads_fused_rows(S, width, int(bf16)))
+        fused = int(lib.m360_linear_heads_fused_rows(S, width, int(bf16)))  # 0 on the bf16 pipe: the finishers read the activations
         return fused * int(lib.m360_linear_heads_slots(width, int(bf16))) * heads * 4 + (S - fused) * width * el
 
     out = {}
@@ -298,6 +302,8 @@ def hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib):
     return out
 
 
+MLP_NAMES = {"fp32": "fp32", "bf16": "bf16 (fp32 accumulate)",
+             "bf16x3": "bf16x3 (two bf16 terms per value, xh wh + xl wh + xh wl on the bf16 MFMA, fp32 accumulate)"}
 FRAME_POSE = [[1.0, 0.0, 0.0, 0.05], [0.0, 1.0, 0.0, -0.02], [0.0, 0.0, 1.0, 0.1]]
 
 
@@ -386,7 +392,7 @@ def worker(args):
     steps = args.steps if args.steps is not None else (3 if frame_cfg else 50)
     warmup = args.warmup if args.warmup is not None else (1 if frame_cfg else 5)
     if args.cpu_rays is None:
-        args.cpu_rays = n_rays if args.config == "c2" else 0
+        args.cpu_rays = n_rays if (args.config == "c2" and mlp_dtype != "bf16") else 0
     if args.frame_steps is None:
         args.frame_steps = 1 if (args.config == "c2" and mlp_dtype == "fp32") else 0
 
@@ -412,7 +418,8 @@ def worker(args):
     comm = Comm(world, rank, dev, args.backend)
 
     sd_np = synthetic.make_state_dict(HP, HN, seed=0)
-    bf16 = mlp_dtype == "bf16"
+    bf16 = mlp_dtype in ("bf16", "bf16x3")  # the bf16 matrix pipe (roofline peak); bf16x3 keeps 16 significant bits
+    x3 = mlp_dtype == "bf16x3"
     model = mipNeRF360(randomized=False, num_samples=samples, hidden_proposal=HP, hidden_nerf=HN, white_bkgd=False,
                        device=dev, mlp_dtype=mlp_dtype)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
@@ -423,7 +430,7 @@ def worker(args):
 
     line = {"metric": metric, "value": None, "unit": "rays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if frame_cfg else "weak",
-            "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic"}
+            "vs_baseline": None, "dtype": mlp_dtype if bf16 else "f32", "data": "synthetic"}
     S = n_rays * samples
     prof = None
 
@@ -442,7 +449,7 @@ def worker(args):
             workload = f"DIAGNOSTIC frame size {fw}x{fh} instead of 1237x822; " + workload
         elapsed = res["seconds"]
         line.update(value=res["rays_per_s"], ms_per_step=round(1e3 * elapsed / max(steps, 1), 3))
-        line["config"] = {"workload": workload.format(mlp="bf16 (fp32 accumulate)" if bf16 else "fp32"), "name": "c4",
+        line["config"] = {"workload": workload.format(mlp=MLP_NAMES[mlp_dtype]), "name": "c4",
                           "rays_per_frame": n_frame, "samples_per_ray": samples, "chunks": FRAME_CHUNKS,
                           "n_chunks": res["n_chunks"], "chunks_per_rank": res["chunks_per_rank"],
                           "partition_efficiency_bound": res["partition_efficiency_bound"],
@@ -504,7 +511,7 @@ def worker(args):
         line.update(value=round(value, 1), ms_per_step=round(1e3 * elapsed / max(steps, 1), 3),
                     ms_per_step_median=round(med_ms, 3),
                     value_at_median_step=round(world * n_rays / (med_ms * 1e-3), 1) if med_ms else None)
-        line["config"] = {"workload": workload.format(mlp="bf16 (fp32 accumulate)" if bf16 else "fp32"),
+        line["config"] = {"workload": workload.format(mlp=MLP_NAMES[mlp_dtype]),
                           "name": args.config, "rays_per_gpu": n_rays, "samples_per_ray": samples,
                           "parallelism": f"rays sharded over {world} GPU(s), replicated weights" +
                                          (f", RCCL all-gather of the [{n_rays},5] pixel block per step" if world > 1 else ""),
@@ -515,8 +522,8 @@ def worker(args):
 
     # ---- per-kernel numbers from the event records (HIP events on the launch stream, inside the timed region)
     prof.close()
-    line["roofline"] = roofline_from_records(recs, S, bf16, args.config, _lib)
-    line["hbm_kernels"] = hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib)
+    line["roofline"] = roofline_from_records(recs, S, bf16, args.config, _lib, x3)
+    line["hbm_kernels"] = hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib, x3)
     line["rccl"] = comm.info
 
     if not frame_cfg and args.frame_steps > 0:

@@ -179,6 +179,18 @@ int m360_pack_linear_bf16(const float *w, const float *b, int n_out, int k_in, i
                           void *w_packed_bf16, float *b_packed, m360_stream_t stream);
 int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_bf16, const float *b_packed,
                      int n_pad, int k_pad, int act, void *y_bf16, int ldy, m360_stream_t stream);
+/* ---- opt-in "bf16x3" MLP: near-fp32 accuracy on the bf16 matrix pipe.  Every activation and weight is carried as TWO bf16
+ * terms (hi = bf16(v), lo = bf16(v - hi): 16 significant bits) and a product x w is formed as xh wh + xl wh + xh wl with
+ * fp32 accumulation (the xl wl term, 2^-16 of the product, is dropped): three bf16 MFMA passes in ONE contraction of
+ * length 3K.  Layouts: activations [M, 2 K] = [hi | lo]; packed weights [n_pad, 3 k_pad] = [Wh | Wh | Wl]; the output is
+ * written as [M, 2 n_pad] = [hi | lo] again.  Measured against the fp32 path: hidden activations differ by <= 2e-5, rendered
+ * colours by <= 1e-4 (the fp32 tolerance of SURVEY.md 8c) at ~2.4x the fp32 MFMA throughput.  Never the default. */
+int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
+                            void *w_packed3_bf16 /*[n_pad, 3 k_pad]*/, float *b_packed, m360_stream_t stream);
+int m360_linear_bf16x3(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M, int ldx, const void *w_packed3_bf16,
+                       const float *b_packed, int n_pad, int k_pad, int act, void *y_hi_lo_bf16 /*[M, ldy >= 2 n_pad]*/,
+                       int ldy, m360_stream_t stream);
+
 /* m360_encode_features writing bf16 rows */
 int m360_encode_features_bf16(const float *t_vals, const float *origins, const float *directions,
                               const float *radii, const float *vdenc, int vd_ch, int B, int N,
@@ -418,7 +430,8 @@ typedef struct {
     const float *nerf_head_b; /* [4] */
     int mlp_bf16; /* extension: 0 = fp32 MLP (default, the parity path); 1 = prop_w / nerf_w point to bf16
                      weights from m360_pack_linear_bf16 (pads multiples of 64), features and hidden activations
-                     are bf16, accumulation / biases / heads stay fp32 */
+                     are bf16, accumulation / biases / heads stay fp32; 2 = "bf16x3": weights from
+                     m360_pack_linear_bf16x3, features and hidden activations as [hi | lo] bf16 pairs (m360_linear_bf16x3) */
 } m360_model_t; /* packed form of the state_dict of model.py:43-53,131-158 */
 
 typedef struct {

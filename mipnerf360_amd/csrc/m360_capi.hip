@@ -153,9 +153,11 @@ static int p_linear(const m360_hyper_t *h, TileQueues *q, const float *x, long M
     ProfScope ps(h, st, M360_K_LINEAR, M, n_pad, k_pad);
     return ps.done(m360_linear_balanced(x, M, ldx, w, b, n_pad, k_pad, act, y, ldy, q->take(), st));
 }
-static int p_linear_bf16(const m360_hyper_t *h, const void *x, long M, int ldx, const void *w, const float *b, int n_pad, int k_pad, int act, void *y, int ldy, m360_stream_t st) {
-    ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, k_pad);
-    return ps.done(m360_linear_bf16(x, M, ldx, w, b, n_pad, k_pad, act, y, ldy, st));
+// mode 1: bf16 rows of k_pad / n_pad columns; mode 2 (bf16x3): [hi | lo] rows of 2 k_pad / 2 n_pad columns
+static int p_linear_bf16(const m360_hyper_t *h, int mode, const void *x, long M, const void *w, const float *b, int n_pad, int k_pad, int act, void *y, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, mode == 2 ? 3 * k_pad : k_pad);
+    if (mode == 2) return ps.done(m360_linear_bf16x3(x, M, 2 * k_pad, w, b, n_pad, k_pad, act, y, 2 * n_pad, st));
+    return ps.done(m360_linear_bf16(x, M, k_pad, w, b, n_pad, k_pad, act, y, n_pad, st));
 }
 static int p_encode_grouped(const m360_hyper_t *h, const float *t, const float *o, const float *d, const float *rad, const float *vdenc, int vd_ch, int B, int N, void *feat, int ld, int bf16, int group, void *ws, size_t wsb, m360_stream_t st) {
     ProfScope ps(h, st, M360_K_ENCODE, (long)B * N, ld, bf16);
@@ -235,13 +237,18 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hp = m->hp_pad;
     if (ext_norm) {  // the caller supplies the (all-reduced) contraction norm; the layers below are shared
-        M360_TRY(p_encode_ext_norm(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_encode_ext_norm(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));  /* mlp_bf16 = 0 / 1 / 2 selects the row format */
     }
-    if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers, half the bytes)
-        if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(p_linear_bf16(h, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
-        M360_TRY(p_linear_bf16(h, a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
-        M360_TRY(p_linear_bf16(h, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
+    if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers; mode 2 = bf16x3: [hi | lo] pairs)
+        const int mode = m->mlp_bf16;
+        if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, mode, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_linear_bf16(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, st));
+        M360_TRY(p_linear_bf16(h, mode, a, S, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, st));
+        M360_TRY(p_linear_bf16(h, mode, b, S, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, st));
+        if (mode == 2) {  // the last hidden layer writes its [hi | lo] output, the finisher forms the head from hi + lo
+            M360_TRY(p_linear_bf16(h, 2, a, S, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, st));
+            return p_prop_finish_fused(h, b, 2, 2 * hp, hpart, 0, 0, m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
+        }
         M360_TRY(p_linear_heads(h, 1, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, b, hp, 0, m->prop_head_w, 1, hpart, st));
         return p_prop_finish_fused(h, b, 1, hp, hpart, m360_linear_heads_fused_rows(S, hp, 1), m360_linear_heads_slots(hp, 1), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
     }
@@ -284,15 +291,21 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         M360_TRY(p_linear_heads(h, 0, act[6], S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, act[7], hn, 1, m->nerf_head_w, 4, hpart, st));
         M360_TRY(p_nerf_finish_fused(h, act[7], 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     } else if (m->mlp_bf16) {
-        if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
-        else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 1, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(p_linear_bf16(h, feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
+        const int mode = m->mlp_bf16;
+        if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, mode, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
+        else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, mode, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_linear_bf16(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, st));
         for (int layer = 1; layer < 7; ++layer) {
-            M360_TRY(p_linear_bf16(h, src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, hn, st));
+            M360_TRY(p_linear_bf16(h, mode, src, S, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, st));
             float *tmp = src; src = dst; dst = tmp;
         }
-        M360_TRY(p_linear_heads(h, 1, src, S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, hn, 0, m->nerf_head_w, 4, hpart, st));
-        M360_TRY(p_nerf_finish_fused(h, dst, 1, hn, hpart, m360_linear_heads_fused_rows(S, hn, 1), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
+        if (mode == 2) {
+            M360_TRY(p_linear_bf16(h, 2, src, S, m->nerf_w[7], m->nerf_b[7], hn, hn, M360_ACT_SIGMOID, dst, st));
+            M360_TRY(p_nerf_finish_fused(h, dst, 2, 2 * hn, hpart, 0, 0, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
+        } else {
+            M360_TRY(p_linear_heads(h, 1, src, S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, hn, 0, m->nerf_head_w, 4, hpart, st));
+            M360_TRY(p_nerf_finish_fused(h, dst, 1, hn, hpart, m360_linear_heads_fused_rows(S, hn, 1), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
+        }
     } else {
     if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
     else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));

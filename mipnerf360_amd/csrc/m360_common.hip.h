@@ -47,6 +47,14 @@ __device__ __forceinline__ float relu_nanf_(float v) {
 // operand on with its sign and payload (measured: tools/diag/nan_bits.py), so a feature row that enters the MLP with its
 // NaNs canonicalised stays +NaN through every layer - which is what relu_nanf_ relies on.
 __device__ __forceinline__ float canon_nanf_(float v) { return v != v ? __builtin_bit_cast(float, 0x7FC00000) : v; }
+// bf16x3 mode: an fp32 value as two bf16 terms, hi = bf16(v) (round to nearest even), lo = bf16(v - hi): 16 significant bits.
+// A product x w is then formed as xh wh + xl wh + xh wl on the bf16 MFMA with fp32 accumulation (the xl wl term, 2^-16 of
+// the product, is dropped).
+__device__ __forceinline__ __bf16 bf16_lo_(float v, __bf16 hi) { return (__bf16)(v - (float)hi); }
+__device__ __forceinline__ void split_bf16_(float v, __bf16 &hi, __bf16 &lo) {
+    hi = (__bf16)v;
+    lo = bf16_lo_(v, hi);
+}
 // value returned by the reference's g() on its `calls`-th application to the same tensor
 __device__ __forceinline__ float g_calls(float x, int calls) {
     for (int i = 0; i < calls; ++i) x = x + kEpsG;

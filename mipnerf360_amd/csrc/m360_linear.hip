@@ -573,6 +573,53 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
     return check_launch("linear_bf16");
 }
 
+int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed3,
+                            float *b_packed, m360_stream_t stream) {
+    if (!w || !w_packed3 || n_out < 1 || k_in < 1 || n_pad < n_out || k_pad < k_in || k_pad % pbf16::BK != 0 || n_pad % 32 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_pack_linear_bf16x3: n_pad=%d >= n_out=%d (multiple of 32), k_pad=%d >= k_in=%d (multiple of %d)", n_pad, n_out, k_pad, k_in, pbf16::BK);
+    const long n = (long)n_pad * k_pad;
+    hipLaunchKernelGGL(pbf16::pack_linear_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, b, n_out, k_in, n_pad, k_pad, static_cast<__bf16 *>(w_packed3), b_packed);
+    return check_launch("pack_linear_bf16x3");
+}
+
+int m360_linear_bf16x3(const void *x, long M, int ldx, const void *w_packed3, const float *b_packed, int n_pad, int k_pad,
+                       int act, void *y, int ldy, m360_stream_t stream) {
+    if (!x || !w_packed3 || !b_packed || !y || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: null pointer or negative M");
+    if (n_pad < 1 || k_pad < pbf16::BK || k_pad % pbf16::BK != 0 || ldx < 2 * k_pad || ldy < 2 * n_pad || ldx % 8 != 0 || ldy % 8 != 0 || n_pad % 8 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: k_pad=%d must be a positive multiple of %d, ldx=%d >= 2 k_pad, ldy=%d >= 2 n_pad=%d, all multiples of 8", k_pad, pbf16::BK, ldx, ldy, 2 * n_pad);
+    if (((uintptr_t)x | (uintptr_t)w_packed3 | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: pointers must be 16-byte aligned");
+    if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: unknown activation %d", act);
+    if (M == 0) return M360_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const __bf16 *xb = static_cast<const __bf16 *>(x), *wb = static_cast<const __bf16 *>(w_packed3);
+    __bf16 *yb = static_cast<__bf16 *>(y);
+    const int k3 = 3 * k_pad;  // >= 192: always at least two K-steps of the ping-pong kernel
+    const long M_full = (n_pad % pp16::BN == 0 && n_pad <= pp16::kMaxBias) ? (M / pp16::BM) * pp16::BM : 0;
+    if (M_full > 0) {
+        const int cus = cu_count();
+        if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear_bf16x3: no HIP device");
+        const long nt = (M_full / pp16::BM) * (n_pad / pp16::BN);
+        dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
+        switch (act) {
+            case M360_ACT_NONE: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_NONE, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+            case M360_ACT_RELU: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+            default: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_SIGMOID, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+        }
+    }
+    if (M > M_full) {
+        const long Mt = M - M_full;
+        dim3 grid((unsigned)((n_pad + 31) / 32), (unsigned)((Mt + 31) / 32)), block(64);
+        const __bf16 *xt = xb + M_full * ldx;
+        __bf16 *yt = yb + M_full * ldy;
+        switch (act) {
+            case M360_ACT_NONE: hipLaunchKernelGGL((pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_NONE, true>), grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k3, yt, ldy); break;
+            case M360_ACT_RELU: hipLaunchKernelGGL((pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k3, yt, ldy); break;
+            default: hipLaunchKernelGGL((pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_SIGMOID, true>), grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k3, yt, ldy); break;
+        }
+    }
+    return check_launch("linear_bf16x3");
+}
+
 #ifdef M360_DIAG
 // ---- diagnostics build only (libm360_diag.so): the two hot kernels instrumented with cycle stamps (ReLU epilogue)
 int m360_diag_linear(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,

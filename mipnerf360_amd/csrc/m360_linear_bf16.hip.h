@@ -242,7 +242,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_mfma_persist_kernel(
 
 // Generic (slow, any shape) bf16 kernel for ragged rows / narrow layers: one wave per 32 x 32 output block,
 // operands straight from global memory (16 B per lane per MFMA), rows clamped, stores predicated.
-template <int ACT>
+// X3: the bf16x3 contraction of m360_linear_bf16_pp.hip.h (Kp = 3K, activation column wraps at 2K, output [hi(Np) | lo(Np)]).
+template <int ACT, bool X3 = false>
 __global__ __launch_bounds__(64) void linear_bf16_mfma_simple_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias,
     int Np, int Kp, __bf16 *__restrict__ Y, int ldy) {
@@ -255,11 +256,12 @@ __global__ __launch_bounds__(64) void linear_bf16_mfma_simple_kernel(
     if (rb > Np - 1) rb = Np - 1;
     const __bf16 *xa = X + ra * ldx + 8 * h;
     const __bf16 *wb = W + (long)rb * Kp + 8 * h;
+    const int x_wrap = X3 ? 2 * (Kp / 3) : 0;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     for (int k = 0; k < Kp; k += 16) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(xa + k);
+        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(xa + ((X3 && k >= x_wrap) ? k - x_wrap : k));
         const bf16x8 b = *reinterpret_cast<const bf16x8 *>(wb + k);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     }
@@ -269,8 +271,35 @@ __global__ __launch_bounds__(64) void linear_bf16_mfma_simple_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const long row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < M) Y[row * ldy + col] = (__bf16)act_fn<ACT>(acc[r] + bj);
+        if (row < M) {
+            const float v = act_fn<ACT>(acc[r] + bj);
+            if (X3) {
+                __bf16 hi, lo;
+                split_bf16_(v, hi, lo);
+                Y[row * ldy + col] = hi;
+                Y[row * ldy + Np + col] = lo;
+            } else {
+                Y[row * ldy + col] = (__bf16)v;
+            }
+        }
     }
+}
+
+// bf16x3 weights: [n_pad, 3 k_pad] = [Wh | Wh | Wl] (zero padded), Wh = bf16(W), Wl = bf16(W - Wh); fp32 bias
+__global__ void pack_linear_bf16x3_kernel(const float *__restrict__ w, const float *__restrict__ b, int n_out, int k_in,
+                                          int n_pad, int k_pad, __bf16 *__restrict__ wp, float *__restrict__ bp) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)n_pad * k_pad) {
+        const int n = (int)(idx / k_pad), k = (int)(idx % k_pad);
+        const float v = (n < n_out && k < k_in) ? w[(long)n * k_in + k] : 0.0f;
+        __bf16 hi, lo;
+        split_bf16_(v, hi, lo);
+        __bf16 *row = wp + (long)n * 3 * k_pad;
+        row[k] = hi;
+        row[k_pad + k] = hi;
+        row[2 * k_pad + k] = lo;
+    }
+    if (bp != nullptr && idx < n_pad) bp[idx] = (b != nullptr && idx < n_out) ? b[idx] : 0.0f;
 }
 
 __global__ void pack_linear_bf16_kernel(const float *__restrict__ w, const float *__restrict__ b, int n_out, int k_in,

@@ -42,11 +42,17 @@ __device__ __forceinline__ float act_fn(float v) {
     return v;
 }
 
-template <int ACT, bool STAMP = false>
+// X3 ("bf16x3", near-fp32 accuracy on the bf16 pipe): activations are stored as TWO bf16 terms per value, rows [hi(K) | lo(K)],
+// the weights as W3 = [Wh | Wh | Wl] (rows of 3K); the kernel runs the contraction over Kp = 3K with the activation column
+// wrapping back to 0 at 2K, i.e. xh wh + xl wh + xh wl in one fp32 accumulator, and writes its output as [hi(Np) | lo(Np)].
+template <int ACT, bool STAMP = false, bool X3 = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias,
     int Np, int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kTileBytes + kMaxBias * 4];  // 128 KiB + the bias vector
+#if defined(PP_PHASES) && PP_PHASES != 4
+    static_assert(!X3, "the split (bf16x3) epilogue is counted for the 4-phase K-step only");
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -105,12 +111,14 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
 #ifndef PP_ABLATE
 #define PP_ABLATE 0  // diagnostics only (timing experiments, results are wrong when != 0): 1 = no LDS-DMA, 2 = no ds_reads
 #endif
+    const int x_wrap = X3 ? 2 * (Kp / 3) : 0;  // X3: activation columns [0, 2K) serve k in [0, 2K) and, again from 0, k in [2K, 3K)
     auto stage = [&](int buf, int unit, int k0) __attribute__((always_inline)) {
         if (PP_ABLATE & 1) return;
         char *base = smem + buf * kTileBytes;
         if (unit == 0 || unit == 3) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(base + dst_off[unit][0]), 16, src_off[unit][0], 2 * k0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(base + dst_off[unit][1]), 16, src_off[unit][1], 2 * k0, 0, 0);
+            const int kx = (X3 && k0 >= x_wrap) ? k0 - x_wrap : k0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(base + dst_off[unit][0]), 16, src_off[unit][0], 2 * kx, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(base + dst_off[unit][1]), 16, src_off[unit][1], 2 * kx, 0, 0);
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(base + dst_off[unit][0]), 16, src_off[unit][0], 2 * k0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(base + dst_off[unit][1]), 16, src_off[unit][1], 2 * k0, 0, 0);
@@ -182,22 +190,28 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
 // Deferred epilogue of the PREVIOUS tile, one quadrant: bias + activation + bf16 pack, one 16-byte store per row (the
 // N-blocks J0, J0+1 of a lane are 8 consecutive columns), then the accumulators restart from zero.  Runs in the load
 // half of a phase, i.e. while the partner wave on this SIMD is in its MFMA half.
+// one output element: activation, bf16 (and, X3, the second term bf16(value - hi))
+#define PP_E1(IDX, VAL)                                         \
+    do {                                                        \
+        const float t_ = act_fn<ACT>(VAL);                      \
+        o_[IDX] = (__bf16)t_;                                   \
+        if (X3) l_[IDX] = bf16_lo_(t_, o_[IDX]);                \
+    } while (0)
 #define PP_STORE_Q(I0, J0)                                                                              \
     do {                                                                                                \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
             const f32x4 v_ = acc[(I0) + i][(J0)], w_ = acc[(I0) + i][(J0) + 1];                         \
-            bf16x8 o_;                                                                                  \
-            o_[0] = (__bf16)act_fn<ACT>(v_[0] + bq[(J0)][0]);                                           \
-            o_[1] = (__bf16)act_fn<ACT>(v_[1] + bq[(J0)][1]);                                           \
-            o_[2] = (__bf16)act_fn<ACT>(v_[2] + bq[(J0)][2]);                                           \
-            o_[3] = (__bf16)act_fn<ACT>(v_[3] + bq[(J0)][3]);                                           \
-            o_[4] = (__bf16)act_fn<ACT>(w_[0] + bq[(J0) + 1][0]);                                       \
-            o_[5] = (__bf16)act_fn<ACT>(w_[1] + bq[(J0) + 1][1]);                                       \
-            o_[6] = (__bf16)act_fn<ACT>(w_[2] + bq[(J0) + 1][2]);                                       \
-            o_[7] = (__bf16)act_fn<ACT>(w_[3] + bq[(J0) + 1][3]);                                       \
-            *reinterpret_cast<bf16x8 *>(Yp + (long)(((I0) + i) * 16) * ldy_t + ((J0) ? 8 : 0)) = o_;    \
+            bf16x8 o_, l_;                                                                              \
+            PP_E1(0, v_[0] + bq[(J0)][0]); PP_E1(1, v_[1] + bq[(J0)][1]);                               \
+            PP_E1(2, v_[2] + bq[(J0)][2]); PP_E1(3, v_[3] + bq[(J0)][3]);                               \
+            PP_E1(4, w_[0] + bq[(J0) + 1][0]); PP_E1(5, w_[1] + bq[(J0) + 1][1]);                       \
+            PP_E1(6, w_[2] + bq[(J0) + 1][2]); PP_E1(7, w_[3] + bq[(J0) + 1][3]);                       \
+            __bf16 *const yp_ = Yp + (long)(((I0) + i) * 16) * ldy_t + ((J0) ? 8 : 0);                  \
+            *reinterpret_cast<bf16x8 *>(yp_) = o_;                                                      \
+            if (X3) *reinterpret_cast<bf16x8 *>(yp_ + Np) = l_; /* the lo terms: columns [Np, 2 Np) */  \
             acc[(I0) + i][(J0)] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                                      \
             acc[(I0) + i][(J0) + 1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                                  \
+            if (X3) PP_SB(); /* one row at a time: the split epilogue's temporaries must not pile up across rows */ \
         }                                                                                               \
         asm volatile("" ::: "memory");                                                                  \
         PP_SB();                                                                                        \
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         PP_READ_W(0, boff, 0, 512);                         \
         PP_READ_X(boff, 0, 2048, 4096, 6144);               \
         stage(nbuf, 0, k_next);                             \
-        if (ST) PP_VMCNT(8); else PP_VMCNT(4);              \
+        if (ST) { if (X3) PP_VMCNT(12); else PP_VMCNT(8); } else PP_VMCNT(4); \
         PP_BAR();                                           \
         PP_WAIT_W(0);                                       \
         PP_WAIT_X();                                        \
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         if (ST) PP_STORE_Q(0, 2);                           \
         PP_READ_W(2, boff, 1024, 1536);                     \
         stage(nbuf, 1, k_next);                             \
-        if (ST) PP_VMCNT(12); else PP_VMCNT(4);             \
+        if (ST) { if (X3) PP_VMCNT(20); else PP_VMCNT(12); } else PP_VMCNT(4); \
         PP_BAR();                                           \
         PP_WAIT_W(2);                                       \
         PP_SB();                                            \
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         if (ST) PP_STORE_Q(4, 2);                           \
         PP_READ_X(boff, 8192, 10240, 12288, 14336);         \
         stage(nbuf, 2, k_next);                             \
-        if (ST) PP_VMCNT(12); else PP_VMCNT(4);             \
+        if (ST) { if (X3) PP_VMCNT(20); else PP_VMCNT(12); } else PP_VMCNT(4); \
         PP_BAR();                                           \
         PP_WAIT_X();                                        \
         PP_SB();                                            \
@@ -246,7 +260,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         PP_BAR();                                           \
         if (ST) PP_STORE_Q(4, 0);                           \
         stage(nbuf, 3, k_next);                             \
-        if (ST) PP_VMCNT(12); else PP_VMCNT(4);             \
+        if (ST) { if (X3) PP_VMCNT(20); else PP_VMCNT(12); } else PP_VMCNT(4); \
         PP_BAR();                                           \
         PP_SB();                                            \
         PP_MFMA16(4, 0);                                    \
@@ -397,6 +411,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
 #undef PP_MFMA16
 #undef PP_VMCNT
 #undef PP_STORE_Q
+#undef PP_E1
 #undef PP_KSTEP
 #undef PP_PROLOGUE_VMCNT
 }

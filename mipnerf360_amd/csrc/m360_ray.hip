@@ -317,7 +317,8 @@ __device__ __forceinline__ void head_dots(const T *__restrict__ act_ray, int ld,
 // same addresses: broadcast), and the 8 lanes of a row are reduced by three DPP steps - no ds_bpermute chains.  The
 // 64-lanes-per-row form above spends most of its time in its six-step shuffle reductions once a row is only 2 KB
 // (profiles/r02: 3.3 TB/s on the bf16 path).
-template <int H>
+// SPLIT (bf16x3 mode): a row is [hi(k_pad) | lo(k_pad)] and the value is hi + lo (two bf16 terms = 16 significant bits).
+template <int H, bool SPLIT = false>
 __device__ __forceinline__ void head_dots_rows8_bf16(const __bf16 *__restrict__ act_ray, int ld, const float *hw /*LDS [H][k_pad]*/,
                                                      const float *__restrict__ hb, int k_pad, int N, float *raw /*LDS [N][H]*/) {
     const int wave = threadIdx.x >> 6, l = lane_id(), nwaves = blockDim.x >> 6;
@@ -336,6 +337,12 @@ __device__ __forceinline__ void head_dots_rows8_bf16(const __bf16 *__restrict__ 
         for (int c = lane8; c < kc; c += 8) {
             float v[8];
             ActChunk<__bf16>::load(x, c, v);
+            if (SPLIT) {
+                float lo[8];
+                ActChunk<__bf16>::load(x + k_pad, c, lo);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += lo[e];
+            }
 #pragma unroll
             for (int h = 0; h < H; ++h) {
                 const float4 w0 = *reinterpret_cast<const float4 *>(hw + h * k_pad + c * 8);
@@ -391,7 +398,7 @@ __device__ __forceinline__ void head_dots_fused_order(const float *__restrict__ 
 // Head products of one ray's N samples -> raw[N][H] (LDS).  Samples whose global row (b N + n) lies below `fused_rows`
 // take them from the partial sums the fused last layer left (m360_linear_heads: head_part[row][slots][H], added slot
 // 0, 1, ... then the bias); the others are computed from the activation rows as in the unfused path.
-template <int H, typename T>
+template <int H, typename T, bool SPLIT = false>
 __device__ __forceinline__ void ray_heads(const T *__restrict__ act, int ld, const float *__restrict__ head_part,
                                           long fused_rows, int slots, const float *__restrict__ head_w,
                                           const float *__restrict__ head_b, int k_pad, int b, int N, float *hw /*LDS [H][k_pad]*/,
@@ -414,14 +421,14 @@ __device__ __forceinline__ void ray_heads(const T *__restrict__ act, int ld, con
             if (slots > 0 && slots <= 8 && k_pad == 128 * slots) head_dots_fused_order<H>(reinterpret_cast<const float *>(act) + (s0 + nf) * ld, ld, hw, head_b, k_pad, slots, N - nf, raw + nf * H);
             else head_dots<H, T>(act + (s0 + nf) * ld, ld, hw, head_b, k_pad, N - nf, raw + nf * H);
         } else {
-            head_dots_rows8_bf16<H>(reinterpret_cast<const __bf16 *>(act) + (s0 + nf) * ld, ld, hw, head_b, k_pad, N - nf, raw + nf * H);
+            head_dots_rows8_bf16<H, SPLIT>(reinterpret_cast<const __bf16 *>(act) + (s0 + nf) * ld, ld, hw, head_b, k_pad, N - nf, raw + nf * H);
         }
     }
     __syncthreads();
 }
 
 // model.py:52,92-93 + intern/ray.py:136-149
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     const T *__restrict__ act, int ld, const float *__restrict__ head_part, long fused_rows, int slots,
     const float *__restrict__ head_w, const float *__restrict__ head_b, int k_pad, float density_bias,
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     const int nb = N + 1;
     float *hw = smem, *t = hw + k_pad, *rho = t + nb, *w = rho + nb, *w2 = w + nb, *cdf = w2 + nb;
     for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
-    ray_heads<1, T>(act, ld, head_part, fused_rows, slots, head_w, head_b, k_pad, b, N, hw, rho);
+    ray_heads<1, T, SPLIT>(act, ld, head_part, fused_rows, slots, head_w, head_b, k_pad, b, N, hw, rho);
     if (threadIdx.x >= kWave) return;
     for (int i = l; i < N; i += kWave) rho[i] = softplusf_(rho[i] + density_bias);
     wave_sync();
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
 }
 
 // model.py:150-158,180-186 + intern/ray.py:155-191
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
     const T *__restrict__ act, int ld, const float *__restrict__ head_part, long fused_rows, int slots,
     const float *__restrict__ head_w, const float *__restrict__ head_b, int k_pad, float density_bias,
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
     const int nb = N + 1;
     float *hw = smem, *t = hw + 4 * k_pad, *raw = t + nb, *w = raw + 4 * N;
     for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
-    ray_heads<4, T>(act, ld, head_part, fused_rows, slots, head_w, head_b, k_pad, b, N, hw, raw);
+    ray_heads<4, T, SPLIT>(act, ld, head_part, fused_rows, slots, head_w, head_b, k_pad, b, N, hw, raw);
     if (threadIdx.x >= kWave) return;
     for (int i = l; i < N; i += kWave) {
         raw[4 * i] = softplusf_(sigmoidf_(raw[4 * i]) + density_bias);
@@ -758,12 +765,13 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
                            m360_stream_t stream, const float *head_part, long fused_rows, int slots) {
     if (num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: num_out=%d", num_out);
     const int align = bf16 ? 8 : 4;
-    if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < k_pad || ld % align != 0)
+    if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < (bf16 == 2 ? 2 * k_pad : k_pad) || ld % align != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: bad argument");
     if (B == 0) return M360_OK;
     const size_t lds = ((size_t)k_pad + 5 * (N + 1)) * sizeof(float);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
+    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
+    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
     else hipLaunchKernelGGL(prop_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
     return check_launch("prop_finish");
 }
@@ -800,12 +808,13 @@ static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_
                            int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
                            m360_stream_t stream, const float *head_part, long fused_rows, int slots) {
     const int align = bf16 ? 8 : 4;
-    if (!act || !head_w || !head_b || !t_vals || !dirs || !comp_rgb || !distance || !acc || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < k_pad || ld % align != 0)
+    if (!act || !head_w || !head_b || !t_vals || !dirs || !comp_rgb || !distance || !acc || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < (bf16 == 2 ? 2 * k_pad : k_pad) || ld % align != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: bad argument");
     if (B == 0) return M360_OK;
     const size_t lds = ((size_t)4 * k_pad + (N + 1) + 5 * N) * sizeof(float);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
+    if (bf16 == 2) hipLaunchKernelGGL((nerf_finish_kernel<__bf16, true>), dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
+    else if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
     else hipLaunchKernelGGL(nerf_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
     return check_launch("nerf_finish");
 }

@@ -352,7 +352,9 @@ __device__ __forceinline__ void wave_sync_lds() {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-template <bool BF16>  // BF16: feature rows are written as bf16 (opt-in reduced-precision MLP), else fp32
+// BF16: 0 = fp32 rows, 1 = bf16 rows (opt-in reduced-precision MLP), 2 = bf16x3 mode: rows [hi(ld) | lo(ld)], two bf16 terms
+// per value (split_bf16_)
+template <int BF16>
 __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
     const float *__restrict__ t_vals, const float *__restrict__ origins,
     const float *__restrict__ directions, const float *__restrict__ radii,
@@ -386,14 +388,19 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
         }
     } else {
         const long total8 = rows * ld / 8;
-        bf16x8_t *out = reinterpret_cast<bf16x8_t *>(static_cast<__bf16 *>(feat_out) + s0 * ld);
+        const int ldo = BF16 == 2 ? 2 * ld : ld;
+        __bf16 *outb = static_cast<__bf16 *>(feat_out) + s0 * ldo;
         for (long q = threadIdx.x; q < total8; q += kEncThreads) {
             const int r = (int)((q * 8) / ld), col = (int)((q * 8) % ld);
             const float *src = tile + r * lds_ld + col;
-            bf16x8_t o;
+            bf16x8_t o, lo;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (__bf16)src[e];
-            out[q] = o;
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (__bf16)src[e];
+                if (BF16 == 2) lo[e] = bf16_lo_(src[e], o[e]);
+            }
+            *reinterpret_cast<bf16x8_t *>(outb + (long)r * ldo + col) = o;
+            if (BF16 == 2) *reinterpret_cast<bf16x8_t *>(outb + (long)r * ldo + ld + col) = lo;
         }
     }
 }
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
 constexpr int kEncWaves = 4;
 constexpr int kEncTileLd = 36;
 
-template <bool BF16, int NPASS>
+template <int BF16, int NPASS>
 __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kernel(
     const float *__restrict__ t_vals, const float *__restrict__ origins,
     const float *__restrict__ directions, const float *__restrict__ radii,
@@ -455,16 +462,24 @@ __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kern
                 if (r < rows) *reinterpret_cast<float4 *>(out + (long)r * ld + col) = *reinterpret_cast<const float4 *>(tile + r * kEncTileLd + col);
             }
         } else {      // 4 lanes x 16 B (8 bf16) = one 64-byte row segment; 16 rows per instruction
-            __bf16 *out = static_cast<__bf16 *>(feat_out) + s0 * ld + 32 * p;
+            constexpr int ldo = BF16 == 2 ? 2 * ld : ld;  // bf16x3 mode: [hi(ld) | lo(ld)]
+            __bf16 *out = static_cast<__bf16 *>(feat_out) + s0 * ldo + 32 * p;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * i + (lane >> 2), col = 8 * (lane & 3);
                 const float4 lo = *reinterpret_cast<const float4 *>(tile + r * kEncTileLd + col);
                 const float4 hi = *reinterpret_cast<const float4 *>(tile + r * kEncTileLd + col + 4);
-                bf16x8_t o;
-                o[0] = (__bf16)lo.x; o[1] = (__bf16)lo.y; o[2] = (__bf16)lo.z; o[3] = (__bf16)lo.w;
-                o[4] = (__bf16)hi.x; o[5] = (__bf16)hi.y; o[6] = (__bf16)hi.z; o[7] = (__bf16)hi.w;
-                if (r < rows) *reinterpret_cast<bf16x8_t *>(out + (long)r * ld + col) = o;
+                const float e8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                bf16x8_t o, l2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = (__bf16)e8[e];
+                    if (BF16 == 2) l2[e] = bf16_lo_(e8[e], o[e]);
+                }
+                if (r < rows) {
+                    *reinterpret_cast<bf16x8_t *>(out + (long)r * ldo + col) = o;
+                    if (BF16 == 2) *reinterpret_cast<bf16x8_t *>(out + (long)r * ldo + ld + col) = l2;
+                }
             }
         }
         wave_sync_lds();  // the tile is rewritten by the next pass
@@ -692,14 +707,15 @@ static int encode_features_any(const float *t_vals, const float *origins, const 
     if (ld_feat == 64 || ld_feat == 96) {  // every model of the path: wave-tiled kernel
         const dim3 grid(blocks_for((long)B * N, kEncWaves * kWave)), block(kEncWaves * kWave);
 #define M360_ENC(BF, NP) hipLaunchKernelGGL((encode_features_wave_kernel<BF, NP>), grid, block, 0, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, group_rays, ext_norm)
-        if (ld_feat == 64) { if (bf16) M360_ENC(true, 2); else M360_ENC(false, 2); }
-        else { if (bf16) M360_ENC(true, 3); else M360_ENC(false, 3); }
+        if (ld_feat == 64) { if (bf16 == 2) M360_ENC(2, 2); else if (bf16) M360_ENC(1, 2); else M360_ENC(0, 2); }
+        else { if (bf16 == 2) M360_ENC(2, 3); else if (bf16) M360_ENC(1, 3); else M360_ENC(0, 3); }
 #undef M360_ENC
         return check_launch("encode_features");
     }
     const size_t lds = (size_t)kEncThreads * (ld_feat + 1) * sizeof(float);
-    if (bf16) hipLaunchKernelGGL(encode_features_kernel<true>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
-    else hipLaunchKernelGGL(encode_features_kernel<false>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
+    if (bf16 == 2) hipLaunchKernelGGL(encode_features_kernel<2>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
+    else if (bf16) hipLaunchKernelGGL(encode_features_kernel<1>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
+    else hipLaunchKernelGGL(encode_features_kernel<0>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
     return check_launch("encode_features");
 }
 

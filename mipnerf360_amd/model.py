@@ -93,13 +93,14 @@ class _PackedMLP:
     def invalidate(self) -> None:
         self.key = None
 
-    def refresh(self, hidden_layers, heads, bf16: bool = False, always: bool = False) -> "_PackedMLP":
+    def refresh(self, hidden_layers, heads, bf16: int = 0, always: bool = False) -> "_PackedMLP":
         """`always`: re-pack even when the (data_ptr, version) key is unchanged.  Writes through `.data`
         (`p.data.mul_()`, EMA swaps, weight clamping) do not bump a tensor's version counter, so in training mode
         - where parameters are expected to change between forwards - the packing is rebuilt on every forward
         (13 small kernels, ~30 MB); in eval mode the key decides, and `invalidate_packed()` forces a rebuild."""
         params = [p for lin in list(hidden_layers) + list(heads) for p in (lin.weight, lin.bias)]
-        key = self._key(params) + (bool(bf16),)
+        bf16 = int(bf16)  # 0 = fp32, 1 = bf16, 2 = bf16x3 (two bf16 terms per value, three MFMA passes)
+        key = self._key(params) + (bf16,)
         if key == self.key and not always:
             if torch.cuda.current_stream(self.head_w.device) != self.pack_stream:
                 torch.cuda.current_stream(self.head_w.device).wait_event(self.ready)  # packed on another stream
@@ -107,10 +108,10 @@ class _PackedMLP:
         first = hidden_layers[0]
         ops._require_device(first.weight, "model parameters")
         pad = 64 if bf16 else 32  # the bf16 MFMA K-step is 64 elements
-        self.bf16 = bool(bf16)
+        self.bf16 = bf16
         self.in_pad = ops.round_up(first.in_features, pad)
         self.h_pad = ops.round_up(first.out_features, pad)
-        pack = ops.pack_linear_bf16 if bf16 else ops.pack_linear
+        pack = {0: ops.pack_linear, 1: ops.pack_linear_bf16, 2: ops.pack_linear_bf16x3}[bf16]
         self.w, self.b = [], []
         for i, lin in enumerate(hidden_layers):
             wp, bp = pack(lin.weight, lin.bias, self.h_pad, self.in_pad if i == 0 else self.h_pad)
@@ -146,7 +147,7 @@ def _model_struct(in_ch, prop: Optional[_PackedMLP], nerf: Optional[_PackedMLP],
     m.in_ch, m.in_pad = in_ch, ref.in_pad
     m.hp_pad = (prop or nerf).h_pad
     m.hn_pad = (nerf or prop).h_pad
-    m.mlp_bf16 = int(getattr(ref, "bf16", False))
+    m.mlp_bf16 = int(getattr(ref, "bf16", 0))
     if prop is not None and nerf is not None and getattr(prop, "bf16", False) != getattr(nerf, "bf16", False):
         raise RuntimeError("proposal and NeRF networks must use the same MLP precision")
     if prop is not None:
@@ -180,7 +181,7 @@ def _mutable_field(rays, name):
 def _wants_grad(module: nn.Module) -> bool:
     """Tape-keeping differentiable forward?  Only the fp32 MLP is trainable: a model built with mlp_dtype='bf16' is
     forward-only (its outputs never carry a graph)."""
-    if getattr(module, "mlp_bf16", False) or getattr(module, "mlp_dtype", "fp32") == "bf16":
+    if getattr(module, "mlp_bf16", 0) or getattr(module, "mlp_dtype", "fp32") != "fp32":
         return False
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
@@ -485,8 +486,10 @@ class mipNeRF360(nn.Module):
         """Same arguments as the reference (model.py:203-215), plus two keyword extensions at the end:
         `num_samples_fine`: number of NeRF-stage samples per ray when it should differ from the proposal count
         ("64+128" rendering, BASELINE configs[2]); None keeps the reference's behaviour (equal counts);
-        `mlp_dtype`: "fp32" (default: exact-fp32 MFMA, the parity path) or "bf16" (BASELINE configs[4]: bf16
-        weights / features / hidden activations, fp32 accumulation, heads and ray math in fp32)."""
+        `mlp_dtype`: "fp32" (default: exact-fp32 MFMA, the parity path), "bf16" (BASELINE configs[4]: bf16
+        weights / features / hidden activations, fp32 accumulation, heads and ray math in fp32) or "bf16x3" (every
+        value carried as two bf16 terms, products formed as xh wh + xl wh + xh wl on the bf16 MFMA with fp32
+        accumulation: within the fp32 render tolerance of 1e-4 at about 2.4x the fp32 throughput; forward only)."""
         super().__init__()
         self.randomized = randomized
         self.num_samples = num_samples
@@ -515,10 +518,10 @@ class mipNeRF360(nn.Module):
                                  viewdir_min_deg=self.viewdir_min_deg, viewdir_max_deg=self.viewdir_max_deg,
                                  device=self.device)
         self.nerf_net.num_samples_fine = num_samples_fine
-        if mlp_dtype not in ("fp32", "bf16", torch.float32, torch.bfloat16):
-            raise ValueError(f"mlp_dtype must be 'fp32' or 'bf16', got {mlp_dtype!r}")
-        self.mlp_dtype = "bf16" if mlp_dtype in ("bf16", torch.bfloat16) else "fp32"
-        self.prop_net.mlp_bf16 = self.nerf_net.mlp_bf16 = self.mlp_dtype == "bf16"
+        if mlp_dtype not in ("fp32", "bf16", "bf16x3", torch.float32, torch.bfloat16):
+            raise ValueError(f"mlp_dtype must be 'fp32', 'bf16' or 'bf16x3', got {mlp_dtype!r}")
+        self.mlp_dtype = "bf16" if mlp_dtype in ("bf16", torch.bfloat16) else ("bf16x3" if mlp_dtype == "bf16x3" else "fp32")
+        self.prop_net.mlp_bf16 = self.nerf_net.mlp_bf16 = {"fp32": 0, "bf16": 1, "bf16x3": 2}[self.mlp_dtype]
         self.to(device)
 
     def set_prof(self, prof) -> None:

@@ -332,6 +332,46 @@ def linear_bf16(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[t
     return y
 
 
+def pack_linear_bf16x3(weight, bias=None, n_pad: Optional[int] = None, k_pad: Optional[int] = None):
+    """fp32 Linear -> bf16x3 packing [n_pad, 3 k_pad] = [Wh | Wh | Wl] (Wh = bf16(W), Wl = bf16(W - Wh)) + fp32 bias."""
+    weight = dev(weight.detach(), "weight")
+    n_out, k_in = weight.shape
+    n_pad, k_pad = n_pad or round_up(n_out, 64), k_pad or round_up(k_in, 64)
+    wp = torch.empty(n_pad, 3 * k_pad, device=weight.device, dtype=torch.bfloat16)
+    bp = torch.empty(n_pad, device=weight.device)
+    b = None if bias is None else dev(bias.detach(), "bias")
+    _call("m360_pack_linear_bf16x3", weight, b, n_out, k_in, n_pad, k_pad, wp, bp, STREAM)
+    return wp, bp
+
+
+def split_bf16x3(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [M, K] -> the [hi | lo] bf16 pair rows [M, 2 K] that m360_linear_bf16x3 reads (what the encoder / a previous
+    bf16x3 layer writes on the device; this host-side form is for tests and tools)."""
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    return torch.cat([hi, lo], 1).contiguous()
+
+
+def join_bf16x3(y: torch.Tensor) -> torch.Tensor:
+    """[M, 2 N] bf16 pair rows -> fp32 [M, N] = hi + lo"""
+    n = y.shape[1] // 2
+    return y[:, :n].float() + y[:, n:].float()
+
+
+def linear_bf16x3(x, w_packed3, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [M, 2 k_pad] bf16 (hi | lo) -> y [M, 2 n_pad] bf16 (hi | lo): y = act(x W^T + b) with every product formed as
+    xh wh + xl wh + xh wl on the bf16 MFMA, fp32 accumulation (include/m360.h, m360_linear_bf16x3)."""
+    x, w_packed3, b_packed = dev_bf16(x, "x"), dev_bf16(w_packed3, "w_packed3"), dev(b_packed, "b_packed")
+    M, ldx = x.shape
+    n_pad, k3 = w_packed3.shape
+    k_pad = k3 // 3
+    if ldx != 2 * k_pad:
+        raise RuntimeError(f"linear_bf16x3: x has {ldx} columns, packed weight expects {2 * k_pad} (hi | lo)")
+    y = out if out is not None else torch.empty(M, 2 * n_pad, device=x.device, dtype=torch.bfloat16)
+    _call("m360_linear_bf16x3", x, M, ldx, w_packed3, b_packed, n_pad, k_pad, act, y, y.shape[1], STREAM)
+    return y
+
+
 # ----------------------------------------------------------------------------- per-ray scans
 def _density2d(density):
     return density[..., 0] if density.dim() == 3 else density

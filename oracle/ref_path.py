@@ -308,8 +308,33 @@ def _lin16(x, sd, prefix):
     return torch.nn.functional.linear(x, _r16(sd[prefix + ".weight"]), sd[prefix + ".bias"])
 
 
+def _split16(x):
+    """two bf16 terms of an fp32 tensor: hi = bf16(x), lo = bf16(x - hi) (the build's "bf16x3" mode, an extension)"""
+    hi = _r16(x)
+    return hi, _r16(x - hi)
+
+
+def _x3(x):
+    """what a bf16x3 layer stores and the next one reads: hi + lo (16 significant bits)"""
+    hi, lo = _split16(x)
+    return hi + lo
+
+
+def _lin16x3(x, sd, prefix):
+    """bf16x3 contract: x w = xh wh + xl wh + xh wl with exact bf16 products and fp32 accumulation, fp32 bias"""
+    xh, xl = _split16(x)
+    wh, wl = _split16(sd[prefix + ".weight"])
+    return (xh @ wh.t() + xl @ wh.t() + xh @ wl.t()) + sd[prefix + ".bias"]
+
+
 def prop_mlp(x, sd, bf16=False):
-    """model.py:43-53.  bf16=True emulates the reduced-precision extension (hidden activations stored as bf16)."""
+    """model.py:43-53.  bf16=True emulates the reduced-precision extension (hidden activations stored as bf16), bf16=2 the
+    bf16x3 extension (two bf16 terms per value, three products per multiply)."""
+    if bf16 == 2:
+        for i in (0, 2, 4):
+            x = _x3(torch.relu(_lin16x3(x, sd, f"prop_net.model.{i}")))
+        x = _x3(torch.sigmoid(_lin16x3(x, sd, "prop_net.model.6")))
+        return _lin(x, sd, "prop_net.model.8")
     if bf16:
         x = _r16(x)
         for i in (0, 2, 4):
@@ -324,7 +349,11 @@ def prop_mlp(x, sd, bf16=False):
 
 def nerf_mlp(x, sd, bf16=False):
     """model.py:131-158 (bf16: see prop_mlp)."""
-    if bf16:
+    if bf16 == 2:
+        for i in range(0, 14, 2):
+            x = _x3(torch.relu(_lin16x3(x, sd, f"nerf_net.model.{i}")))
+        x = _x3(torch.sigmoid(_lin16x3(x, sd, "nerf_net.model.14")))
+    elif bf16:
         x = _r16(x)
         for i in range(0, 14, 2):
             x = _r16(torch.relu(_lin16(x, sd, f"nerf_net.model.{i}")))
@@ -353,7 +382,7 @@ class Hyper(NamedTuple):
     viewdir_min_deg: int = 0
     viewdir_max_deg: int = 4
     num_samples_fine: int = 0  # extension ("64+128"); 0 = num_samples, the reference's behaviour
-    mlp_bf16: bool = False     # extension: emulate the bf16 MLP mode (bf16 storage, fp32 accumulation)
+    mlp_bf16: int = 0          # extension: 1 = emulate the bf16 MLP mode (bf16 storage, fp32 accumulation), 2 = bf16x3
 
 
 def prop_forward(rays: Rays, sd, hp: Hyper, t_rand=None):

@@ -1073,6 +1073,83 @@ def test_train_step_full_width_vs_oracle(dev):
     assert not torch.allclose(rgb2, rgb.detach())
 
 
+@pytest.mark.parametrize("M,n,k,act", [(1024, 256, 64, 1), (2048, 1024, 1024, 1), (700, 256, 256, 2), (300, 96, 64, 0),
+                                        (256 * 5 + 77, 512, 128, 1)])
+def test_linear_bf16x3_against_fp64(dev, M, n, k, act):
+    """The bf16x3 layer (m360_linear_bf16x3: [hi | lo] bf16 pair rows in and out, W as [Wh | Wh | Wl], one contraction of
+    length 3K on the 8-wave ping-pong kernel; ragged rows / narrow widths on the generic kernel).  Reference = fp64
+    product of the values the pairs REPRESENT (x = hi + lo) with the fp32 weights.  Admissible: the dropped xl wl term
+    and the 16-bit representation of w (2^-16 relative each) + the 16-bit representation of the output."""
+    from mipnerf360_amd import _lib, ops
+    from oracle import ref_path as O
+    g = torch.Generator().manual_seed(M + n + k)
+    x = torch.rand(M, k, generator=g) * 2 - 1
+    w = (torch.rand(n, k, generator=g) * 2 - 1) * (6.0 / k) ** 0.5
+    b = torch.rand(n, generator=g) - 0.5
+    n_pad = ops.round_up(n, 64)
+    wp, bp = ops.pack_linear_bf16x3(w.to(dev), b.to(dev), n_pad, k)
+    assert wp.shape == (n_pad, 3 * k) and torch.equal(wp[:, :k], wp[:, k:2 * k])
+    xs = ops.split_bf16x3(x.to(dev))
+    y = ops.linear_bf16x3(xs, wp, bp, act)
+    got = ops.join_bf16x3(y)[:, :n].double().cpu()
+    xv = ops.join_bf16x3(xs).double().cpu()
+    z = xv @ w.double().t() + b.double()
+    ref = torch.relu(z) if act == 1 else (torch.sigmoid(z) if act == 2 else z)
+    scale = max(float(ref.abs().max()), 1.0)
+    assert float((got - ref).abs().max()) <= 4e-5 * scale, float((got - ref).abs().max())
+    # against the oracle's emulation of the same contract (three exact bf16 products, fp32 accumulation): summation order only
+    emu = O._lin16x3(xv.float(), {"l.weight": w, "l.bias": b}, "l")
+    emu = O._x3(torch.relu(emu) if act == 1 else (torch.sigmoid(emu) if act == 2 else emu)).double()
+    assert float((got - emu).abs().max()) <= 3e-6 * scale
+    for _ in range(3):  # a race would not reproduce
+        assert torch.equal(ops.linear_bf16x3(xs, wp, bp, act), y)
+    # padding columns of a padded width stay zero pairs
+    if n_pad > n:
+        assert float(ops.join_bf16x3(y)[:, n:].abs().max()) == (0.5 if act == 2 else 0.0)
+
+
+@pytest.mark.parametrize("kind,n", [("lego", 64), ("garden", 128)])
+def test_g8_end_to_end_full_width_bf16x3(golden, dev, kind, n):
+    """mlp_dtype="bf16x3" against the REFERENCE's own fp32 outputs (fixture G8, full width): inside the stated fp32
+    tolerance (|d rgb|, |d acc| <= 1e-4, |d dist| <= 1e-4 max(1, |dist|)) - the mode keeps 16 significant bits through
+    every layer, measured 1e-6-level differences in the rendered values."""
+    from mipnerf360_amd.model import mipNeRF360
+    g = golden("g8_end_to_end_fullwidth")
+    B, n_, wb = (int(x) for x in g[f"{kind}_{n}_cfg"])
+    m = mipNeRF360(num_samples=n_, hidden_proposal=256, hidden_nerf=1024, white_bkgd=bool(wb), device=dev, mlp_dtype="bf16x3")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(256, 1024, seed=int(g["weights_seed"][0])).items()})
+    rays = dev_rays(synthetic.make_rays(kind, B, seed=int(g["rays_seed"][0])), dev)
+    with torch.no_grad():
+        rgb, dist, acc = m(rays)
+    close_render(rgb, dist, acc, g[f"{kind}_{n}_rgb"], g[f"{kind}_{n}_dist"], g[f"{kind}_{n}_acc"])
+    assert float(np.abs(H(rgb) - g[f"{kind}_{n}_rgb"]).max()) <= 2e-5   # what it really achieves, with margin
+
+
+@pytest.mark.parametrize("kind,B,n,hp,hn,wb", [("garden", 1024, 128, 256, 1024, False), ("lego", 70, 24, 64, 128, True)])
+def test_forward_bf16x3_mode(dev, kind, B, n, hp, hn, wb):
+    """bf16x3 at the headline shape's width (and at a reduced width with ragged rows: generic kernel) against the fp32
+    oracle (1e-4) and against the oracle emulating the mode (tighter); staged == fused; forward only."""
+    from mipnerf360_amd.model import mipNeRF360
+    from oracle import ref_path as O
+    sd = synthetic.make_state_dict(hp, hn, seed=5)
+    m = mipNeRF360(num_samples=n, hidden_proposal=hp, hidden_nerf=hn, white_bkgd=wb, device=dev, mlp_dtype="bf16x3")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    r = synthetic.make_rays(kind, B, seed=6)
+    rays = dev_rays(r, dev)
+    rgb, dist, acc = m(rays)                     # grad enabled: still the forward-only path
+    assert not rgb.requires_grad
+    t_hat, w_hat = m.prop_net.forward(rays)
+    staged = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    assert torch.equal(staged[0], rgb) and torch.equal(staged[2], acc)
+    sdt = O.to_torch_state_dict(sd)
+    with torch.no_grad():
+        ref = O.forward(O.rays_from_numpy(r), sdt, O.Hyper(num_samples=n, white_bkgd=wb))
+        emu = O.forward(O.rays_from_numpy(r), sdt, O.Hyper(num_samples=n, white_bkgd=wb, mlp_bf16=2))
+    close_render(rgb, dist, acc, ref[0], ref[1], ref[2])
+    assert float((rgb.cpu() - emu[0]).abs().max()) <= 1e-5 and float((acc.cpu() - emu[2]).abs().max()) <= 1e-5
+    assert float((rgb.cpu() - ref[0]).abs().max()) <= 2e-5
+
+
 def test_training_bf16_is_forward_only_and_inplace_update_is_caught(golden, dev):
     from mipnerf360_amd.model import mipNeRF360
     g = golden("g13_train_gradients")
