@@ -10,6 +10,8 @@ for s in $steps; do
     newtests) timeout 1800 python -m pytest tests/test_gpu_configs.py -m gpu -q --tb=short -p no:cacheprovider > $out/pytest_new.log 2>&1; echo "pytest rc=$?" >> $out/pytest_new.log; tail -15 $out/pytest_new.log ;;
     bench)   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 3000 $out/bench.json ;;
     bf16)    timeout 900 python bench.py --mlp-dtype bf16 --cpu-rays 0 > $out/bench_bf16.json 2> $out/bench_bf16.err; tail -c 2500 $out/bench_bf16.json ;;
+    x3)      timeout 900 python bench.py --mlp-dtype bf16x3 > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err; tail -c 1500 $out/bench_bf16x3.json ;;
+    gloo2)   timeout 900 python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --frame-size 400x300 > $out/bench_gloo2.json 2> $out/bench_gloo2.err; tail -c 1200 $out/bench_gloo2.json ;;
     c5)      timeout 900 python bench.py --config c5 > $out/bench_c5.json 2> $out/bench_c5.err; tail -c 2500 $out/bench_c5.json ;;
     ceiling) timeout 300 tools/mfma_ceiling.bin > $out/mfma_ceiling.jsonl 2>&1; cat $out/mfma_ceiling.jsonl ;;
     clock)   timeout 600 python tools/linear_bench.py --dtype fp32 --clock --json $out/linear_clock.jsonl > $out/linear_fp32.log 2>&1; tail -3 $out/linear_fp32.log
