@@ -548,3 +548,19 @@ def test_generated_kernel_schedules_are_current(tmp_path):
         finally:
             sys.argv = argv
         assert open(mod.OUT).read() == committed, f"{rel} is stale: run python tools/{tool}"
+
+
+def test_design_md_numbers_are_generated_from_profiles():
+    """DESIGN.md carries its measured numbers (headline, per-launch table, named workloads) in a block that
+    tools/summarize_profiles.py --markdown regenerates from profiles/<tag>/: the block in the file must be exactly what the
+    tool prints today - numbers in the docs are never typed in."""
+    import re
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    m = re.search(r"<!-- profiles:begin (\w+) -->\n(.*?)<!-- profiles:end -->", design, re.S)
+    assert m, "DESIGN.md lost its <!-- profiles:begin <tag> --> ... <!-- profiles:end --> block"
+    tag, block = m.group(1), m.group(2)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_profiles.py"), "--markdown", tag],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert block == res.stdout, "DESIGN.md's profile block is stale: re-run tools/summarize_profiles.py --markdown " + tag
+    assert "rays/s" in block and "last_step_kernel_trace.csv" in block
