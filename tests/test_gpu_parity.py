@@ -1330,6 +1330,30 @@ def test_bf16_pingpong_kernel_race_screen(dev):
         assert float(diff.max()) <= 2.0 ** -7 * max(float(ref.abs().max()), 1.0)   # one bf16 rounding of the output
 
 
+def test_bf16x3_kernel_race_screen(dev):
+    """The same screen for the X3 instantiation of the ping-pong kernel (contraction 3K with the activation column wrapping
+    at 2K, split [hi | lo] epilogue with twice the stores and its own counted waits): 40 back-to-back launches at the
+    BASELINE layer shape and at a small odd one, every launch bit-identical, every sampled row within the mode's
+    accuracy of an fp64 product."""
+    from mipnerf360_amd import _lib, ops
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    for M, n, k in ((4096 * 128, 1024, 1024), (256 * 29, 768, 192)):
+        x = (torch.rand(M, k, generator=gen) * 2 - 1).to(dev)
+        w = ((torch.rand(n, k, generator=gen) * 2 - 1) * (6.0 / k) ** 0.5).to(dev)
+        b = (torch.rand(n, generator=gen) - 0.5).to(dev)
+        wp, bp = ops.pack_linear_bf16x3(w, b, n, k)
+        xs = ops.split_bf16x3(x)
+        first = ops.linear_bf16x3(xs, wp, bp, _lib.ACT_RELU)
+        out = torch.empty_like(first)
+        for _ in range(40):
+            ops.linear_bf16x3(xs, wp, bp, _lib.ACT_RELU, out=out)
+            assert torch.equal(out, first)
+        sub = slice(None, None, 1 if M < 100000 else 97)
+        ref = (ops.join_bf16x3(xs[sub]).double() @ w.double().T + b.double()).clamp_min(0)
+        diff = (ops.join_bf16x3(first[sub]).double() - ref).abs()
+        assert float(diff.max()) <= 4e-5 * max(float(ref.abs().max()), 1.0)
+
+
 def test_train_gradients_with_unequal_sample_counts(dev):
     """The num_samples_fine extension ("64+128" style) through the training path: tape and backward are sized by the
     NeRF stage's own sample count; gradients vs autograd through the oracle's same extension."""
