@@ -78,15 +78,24 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
     return v;
 }
-// inclusive Hillis-Steele scan in fp64: torch's CPU cumsum accumulates fp32 inputs in double
-// and rounds every prefix once, which also keeps the CDF monotone.
+// inclusive wave scan in fp64 (torch's CPU cumsum accumulates fp32 inputs in double and rounds every prefix once, which also
+// keeps the CDF monotone), on the DPP network - no LDS traffic, no ds_bpermute chains: four row_shr steps scan each row of
+// 16 lanes, row_bcast:15 adds lane 15 of rows 0 / 2 to rows 1 / 3, row_bcast:31 adds lane 31 to rows 2 and 3.  A double
+// travels as its two 32-bit halves under the same DPP control; lanes without a source receive 0.0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift_d_(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
 __device__ __forceinline__ double wave_incl_scan_d(double v) {
-    const int l = lane_id();
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        double n = __shfl_up(v, o, kWave);
-        if (l >= o) v += n;
-    }
+    v += dpp_shift_d_<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_shift_d_<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_shift_d_<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_shift_d_<0x118, 0xF>(v);  // row_shr:8
+    v += dpp_shift_d_<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_shift_d_<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
