@@ -573,6 +573,9 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
     return check_launch("linear_bf16");
 }
 
+#ifndef M360_X3_MODE
+#define M360_X3_MODE 2  // 2 = the three products of a 64-deep block share operand tiles (product); 1 = one 3K-deep contraction (A/B builds)
+#endif
 int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed3,
                             float *b_packed, m360_stream_t stream) {
     if (!w || !w_packed3 || n_out < 1 || k_in < 1 || n_pad < n_out || k_pad < k_in || k_pad % pbf16::BK != 0 || n_pad % 32 != 0)
@@ -601,9 +604,9 @@ int m360_linear_bf16x3(const void *x, long M, int ldx, const void *w_packed3, co
         const long nt = (M_full / pp16::BM) * (n_pad / pp16::BN);
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
         switch (act) {
-            case M360_ACT_NONE: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_NONE, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
-            case M360_ACT_RELU: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
-            default: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_SIGMOID, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+            case M360_ACT_NONE: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_NONE, false, M360_X3_MODE>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+            case M360_ACT_RELU: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, false, M360_X3_MODE>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
+            default: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_SIGMOID, false, M360_X3_MODE>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
         }
     }
     if (M > M_full) {

@@ -43,9 +43,15 @@ __device__ __forceinline__ float act_fn(float v) {
 }
 
 // X3 ("bf16x3", near-fp32 accuracy on the bf16 pipe): activations are stored as TWO bf16 terms per value, rows [hi(K) | lo(K)],
-// the weights as W3 = [Wh | Wh | Wl] (rows of 3K); the kernel runs the contraction over Kp = 3K with the activation column
-// wrapping back to 0 at 2K, i.e. xh wh + xl wh + xh wl in one fp32 accumulator, and writes its output as [hi(Np) | lo(Np)].
-template <int ACT, bool STAMP = false, bool X3 = false>
+// the weights as W3 = [Wh | Wh | Wl] (rows of 3K); the kernel forms xh wh + xl wh + xh wl in one fp32 accumulator and writes its
+// output as [hi(Np) | lo(Np)].
+//   X3 = 1: ONE contraction over Kp = 3K, the activation column wrapping back to 0 at 2K (6 operand tiles staged per 64-deep block);
+//   X3 = 2: per 64-deep block the three products run as  xl wh -> xh wh -> xh wl,  so consecutive K-steps SHARE an operand tile:
+//           the second keeps Wh, the third keeps Xh - 4 operand tiles staged per block instead of 6 (a third less L2 -> LDS
+//           traffic and LDS-DMA issue, the two things that bound this kernel: DESIGN.md 4.3).  The A and B halves of the two LDS
+//           buffers are switched independently: T1 reads (A0, B0) and stages Xh into A1; T2 reads (A1, B0) and stages Wl into
+//           B1; T3 reads (A1, B1) and stages the next block's Xl / Wh into A0 / B0.
+template <int ACT, bool STAMP = false, int X3 = 0>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias,
     int Np, int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
@@ -111,18 +117,23 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
 #ifndef PP_ABLATE
 #define PP_ABLATE 0  // diagnostics only (timing experiments, results are wrong when != 0): 1 = no LDS-DMA, 2 = no ds_reads
 #endif
-    const int x_wrap = X3 ? 2 * (Kp / 3) : 0;  // X3: activation columns [0, 2K) serve k in [0, 2K) and, again from 0, k in [2K, 3K)
-    auto stage = [&](int buf, int unit, int k0) __attribute__((always_inline)) {
+    const int x_wrap = X3 ? 2 * (Kp / 3) : 0;  // X3 = 1: activation columns [0, 2K) serve k in [0, 2K) and, again from 0, k in [2K, 3K)
+    // one unit (two instructions) into tile buffer `buf`: X units (0, 3) at activation column kx, W units (1, 2) at weight column kw
+    auto stage_x = [&](int buf, int unit, int kx) __attribute__((always_inline)) {
         if (PP_ABLATE & 1) return;
         char *base = smem + buf * kTileBytes;
-        if (unit == 0 || unit == 3) {
-            const int kx = (X3 && k0 >= x_wrap) ? k0 - x_wrap : k0;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(base + dst_off[unit][0]), 16, src_off[unit][0], 2 * kx, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(base + dst_off[unit][1]), 16, src_off[unit][1], 2 * kx, 0, 0);
-        } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(base + dst_off[unit][0]), 16, src_off[unit][0], 2 * k0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(base + dst_off[unit][1]), 16, src_off[unit][1], 2 * k0, 0, 0);
-        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(base + dst_off[unit][0]), 16, src_off[unit][0], 2 * kx, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(base + dst_off[unit][1]), 16, src_off[unit][1], 2 * kx, 0, 0);
+    };
+    auto stage_w = [&](int buf, int unit, int kw) __attribute__((always_inline)) {
+        if (PP_ABLATE & 1) return;
+        char *base = smem + buf * kTileBytes;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(base + dst_off[unit][0]), 16, src_off[unit][0], 2 * kw, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(base + dst_off[unit][1]), 16, src_off[unit][1], 2 * kw, 0, 0);
+    };
+    auto stage = [&](int buf, int unit, int k0) __attribute__((always_inline)) {
+        if (unit == 0 || unit == 3) stage_x(buf, unit, (X3 == 1 && k0 >= x_wrap) ? k0 - x_wrap : k0);
+        else stage_w(buf, unit, k0);
     };
 
     // ---- fragment addresses: lane (row l15 of a 16-row block, k-chunk g4), K-substep s: chunk 4s + g4
@@ -314,17 +325,77 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
 #define PP_PROLOGUE_VMCNT() PP_VMCNT(2)
 #endif
 
+// X3 = 2: the three K-steps of one 64-deep block.  TYPE 1: xl wh (stages Xh for TYPE 2), TYPE 2: xh wh (keeps Wh, stages Wl for
+// TYPE 3), TYPE 3: xh wl (keeps Xh, stages the next block's Xl and Wh).  A phase stages a unit only when the next K-step does not
+// reuse it; the counted waits retire exactly what the NEXT phase reads and was staged (ops issued after that unit's pair):
+//   T1: p0 WB of this K-step (previous T3 p2) 4 | p1 its XB (T3 p3) 2 | p3 XA' (T1 p0) 2;  with the previous tile's stores (8 per
+//       phase, issued before the phase's pair) 12 | 18 | 26
+//   T2: p1 XB' (T1 p3) 2 | p3 WA'' (T2 p1) 2          T3: p0 WB'' (T2 p2) 2 | p3 XA*, WA* (T3 p0, p1) 4
+// Staging distances as in the 4-unit K-step: every unit is staged >= 3 phases before its first read and re-staged >= 4 phases
+// after its last one.
+#define PP_KSTEP_T(TYPE, ST)                                                                    \
+    do {                                                                                        \
+        PP_SB();                                                                                \
+        if (ST) PP_STORE_Q(0, 0);                                                               \
+        PP_READ_W(0, woff, 0, 512);                                                             \
+        PP_READ_X(aoff, 0, 2048, 4096, 6144);                                                   \
+        if ((TYPE) != 2) stage_x(sx_buf, 0, sx_k);                                              \
+        if ((TYPE) == 1) { if (ST) PP_VMCNT(12); else PP_VMCNT(4); } else if ((TYPE) == 3) PP_VMCNT(2); \
+        PP_BAR();                                                                               \
+        PP_WAIT_W(0);                                                                           \
+        PP_WAIT_X();                                                                            \
+        PP_SB();                                                                                \
+        PP_MFMA16(0, 0);                                                                        \
+        PP_SB();                                                                                \
+        PP_BAR();                                                                               \
+        if (ST) PP_STORE_Q(0, 2);                                                               \
+        PP_READ_W(2, woff, 1024, 1536);                                                         \
+        if ((TYPE) != 1) stage_w(sw_buf, 1, sw_k);                                              \
+        if ((TYPE) == 1) { if (ST) PP_VMCNT(18); else PP_VMCNT(2); } else if ((TYPE) == 2) PP_VMCNT(2); \
+        PP_BAR();                                                                               \
+        PP_WAIT_W(2);                                                                           \
+        PP_SB();                                                                                \
+        PP_MFMA16(0, 2);                                                                        \
+        PP_SB();                                                                                \
+        PP_BAR();                                                                               \
+        if (ST) PP_STORE_Q(4, 2);                                                               \
+        PP_READ_X(aoff, 8192, 10240, 12288, 14336);                                             \
+        if ((TYPE) != 1) stage_w(sw_buf, 2, sw_k);                                              \
+        PP_BAR();                                                                               \
+        PP_WAIT_X();                                                                            \
+        PP_SB();                                                                                \
+        PP_MFMA16(4, 2);                                                                        \
+        PP_SB();                                                                                \
+        PP_BAR();                                                                               \
+        if (ST) PP_STORE_Q(4, 0);                                                               \
+        if ((TYPE) != 2) stage_x(sx_buf, 3, sx_k);                                              \
+        if ((TYPE) == 1) { if (ST) PP_VMCNT(26); else PP_VMCNT(2); } else if ((TYPE) == 2) PP_VMCNT(2); else PP_VMCNT(4); \
+        PP_BAR();                                                                               \
+        PP_SB();                                                                                \
+        PP_MFMA16(4, 0);                                                                        \
+        PP_SB();                                                                                \
+        PP_BAR();                                                                               \
+    } while (0)
+
     // ---- bias -> LDS once (before any LDS-DMA is in flight)
     float *const bias_lds = reinterpret_cast<float *>(smem + 2 * kTileBytes);
     for (int i = tid; i < Np; i += kThreads) bias_lds[i] = bias[i];
     __syncthreads();
     const unsigned bias_addr = lds0 + 2 * kTileBytes + 4u * (wn * 64 + 16 * g4);  // + 4 * n0 of the tile, + 16 * jb
 
-    // ---- prologue: the four units of K-step 0 in the order they are first read
-    stage(0, 0, 0);
-    stage(0, 1, 0);
-    stage(0, 2, 0);
-    stage(0, 3, 0);
+    // ---- prologue: the four units of K-step 0 in the order they are first read (X3 = 2: K-step 0 is xl wh of block 0)
+    const int K1 = X3 ? Kp / 3 : Kp;  // the layer's contraction length
+    if (X3 == 2) {
+        stage_x(0, 0, K1);
+        stage_w(0, 1, 0);
+        stage_w(0, 2, 0);
+        stage_x(0, 3, K1);
+    } else {
+        stage(0, 0, 0);
+        stage(0, 1, 0);
+        stage(0, 2, 0);
+        stage(0, 3, 0);
+    }
     PP_PROLOGUE_VMCNT();  // what phase 0 of the first K-step reads has landed (this wave's rows)
     PP_BAR();
     if (wm == 1) PP_BAR();  // the second M half runs one barrier behind the first
@@ -342,6 +413,41 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     bool have_prev = false;
     for (; tile_id < ntiles; tile_id += G) {
         tile_coords(tile_id, m0, n0);
+        if (X3 == 2) {
+            const int nblk = K1 / BK;
+            for (int kb = 0; kb < nblk; ++kb) {
+                {   // T1: xl wh from (A0, B0); Xh of this block -> A1
+                    const unsigned aoff = 0u, woff = 0u;
+                    const int sx_buf = 1, sx_k = kb * BK, sw_buf = 0, sw_k = 0;
+                    (void)sw_buf; (void)sw_k;
+                    const bool st = have_prev && kb == 0;
+                    PP_KSTEP_T(1, st);
+                }
+                {   // T2: xh wh from (A1, B0); Wl of this block -> B1
+                    const unsigned aoff = (unsigned)kTileBytes, woff = 0u;
+                    const int sx_buf = 0, sx_k = 0, sw_buf = 1, sw_k = 2 * K1 + kb * BK;
+                    (void)sx_buf; (void)sx_k;
+                    PP_KSTEP_T(2, false);
+                }
+                {   // T3: xh wl from (A1, B1); the next block's Xl / Wh -> (A0, B0): of this tile, of the workgroup's next tile, else
+                    // (harmlessly) block 0 of this tile again
+                    int nb = (kb + 1) * BK;
+                    if (kb + 1 == nblk) {
+                        nb = 0;
+                        if (tile_id + G < ntiles) {
+                            long nm0;
+                            int nn0;
+                            tile_coords(tile_id + G, nm0, nn0);
+                            rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(X + nm0 * ldx), 0, 0x7fffffff, 0x00020000);
+                            rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)nn0 * Kp), 0, 0x7fffffff, 0x00020000);
+                        }
+                    }
+                    const unsigned aoff = (unsigned)kTileBytes, woff = (unsigned)kTileBytes;
+                    const int sx_buf = 0, sx_k = K1 + nb, sw_buf = 0, sw_k = nb;
+                    PP_KSTEP_T(3, false);
+                }
+            }
+        } else
         for (int kt = 0; kt < ksteps; ++kt) {
             // what this K-step stages: the next K-step of this tile, else K-step 0 of this workgroup's next tile, else
             // (harmlessly) K-step 0 of the current tile again - nobody reads it
@@ -413,6 +519,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
 #undef PP_STORE_Q
 #undef PP_E1
 #undef PP_KSTEP
+#undef PP_KSTEP_T
 #undef PP_PROLOGUE_VMCNT
 }
 
