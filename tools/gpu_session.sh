@@ -11,6 +11,8 @@ for s in $steps; do
     bench)   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 3000 $out/bench.json ;;
     bf16)    timeout 900 python bench.py --mlp-dtype bf16 --cpu-rays 0 > $out/bench_bf16.json 2> $out/bench_bf16.err; tail -c 2500 $out/bench_bf16.json ;;
     x3)      timeout 900 python bench.py --mlp-dtype bf16x3 > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err; tail -c 1500 $out/bench_bf16x3.json ;;
+    x3c5)    timeout 900 python bench.py --config c5 --mlp-dtype bf16x3 > $out/bench_c5_bf16x3.json 2> $out/bench_c5_bf16x3.err; tail -c 900 $out/bench_c5_bf16x3.json ;;
+    x3prof)  R=$PWD; O=$R/$out; ( cd /tmp && export TMPDIR=/tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_x3 -- python3 $R/bench.py --mlp-dtype bf16x3 --steps 5 --warmup 2 --cpu-rays 0 > $O/bench_x3_under_rocprof.log 2>&1 ); find $O/stats_x3 -name "*.db" -delete 2>/dev/null; cp $O/stats_x3/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_bench_bf16x3.csv 2>/dev/null; head -12 $O/rocprofv3_kernel_stats_bench_bf16x3.csv | cut -c1-160 ;;
     gloo2)   timeout 900 python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --frame-size 400x300 > $out/bench_gloo2.json 2> $out/bench_gloo2.err; tail -c 1200 $out/bench_gloo2.json ;;
     c5)      timeout 900 python bench.py --config c5 > $out/bench_c5.json 2> $out/bench_c5.err; tail -c 2500 $out/bench_c5.json ;;
     ceiling) timeout 300 tools/mfma_ceiling.bin > $out/mfma_ceiling.jsonl 2>&1; cat $out/mfma_ceiling.jsonl ;;
