@@ -184,7 +184,8 @@ int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_b
  * fp32 accumulation (the xl wl term, 2^-16 of the product, is dropped): three bf16 MFMA passes in ONE contraction of
  * length 3K.  Layouts: activations [M, 2 K] = [hi | lo]; packed weights [n_pad, 3 k_pad] = [Wh | Wh | Wl]; the output is
  * written as [M, 2 n_pad] = [hi | lo] again.  Measured against the fp32 path: hidden activations differ by <= 2e-5, rendered
- * colours by <= 1e-4 (the fp32 tolerance of SURVEY.md 8c) at ~2.4x the fp32 MFMA throughput.  Never the default. */
+ * colours by <= 2e-5 against the reference's own outputs (fixture G8; the stated fp32 tolerance is 1e-4) at ~2.3x the
+ * fp32 rays/s.  Never the default. */
 int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                             void *w_packed3_bf16 /*[n_pad, 3 k_pad]*/, float *b_packed, m360_stream_t stream);
 int m360_linear_bf16x3(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M, int ldx, const void *w_packed3_bf16,

@@ -156,7 +156,8 @@ _MAX_GATHERS = 4
 
 def pixel_gather_for(num_rays: int, chunks: int, device, group=None, slots: int = 1) -> PixelGather:
     """Cached PixelGather per frame shape (at most 4 shapes are kept: a renderer alternates between very few)."""
-    key = (int(num_rays), int(chunks), str(torch.device(device)), id(group), _world_rank(group), int(slots))
+    # the group object itself is part of the key (kept alive by the cache: no id() reuse by a later group)
+    key = (int(num_rays), int(chunks), str(torch.device(device)), group, _world_rank(group), int(slots))
     pg = _GATHERS.get(key)
     if pg is None:
         pg = _GATHERS[key] = PixelGather(num_rays, chunks, device, group, slots)
@@ -202,19 +203,21 @@ def replica_fingerprint(model) -> Optional[torch.Tensor]:
         bits = p.detach().contiguous().view(torch.int32).to(torch.int64)
         acc = acc + bits.sum() * (2 * i + 1)  # position-dependent weight: swapped layers do not cancel
     ns = int(getattr(model, "num_samples", 0)) * 100003 + int(getattr(model, "num_samples_fine", 0) or 0)
+    ns = ns * 7 + {"fp32": 0, "bf16": 1, "bf16x3": 2}.get(getattr(model, "mlp_dtype", "fp32"), 3)  # the MLP precision too
     return torch.stack([torch.tensor(ns, dtype=torch.int64, device=dev), acc])
 
 
 def check_replicas(model, group=None) -> None:
     """Every rank must render with the same weights and sample counts or the frame is silently inconsistent.  Once per
     (model, parameter versions): one all-reduce (MAX) of 4 int64 = (f, -f) - all ranks agree iff max(f) == -max(-f)."""
-    if _world_rank(group)[0] == 1:
+    if _world_rank(group)[0] == 1 or not hasattr(model, "parameters"):
+        return
+    key = (id(model), group, getattr(model, "mlp_dtype", None), getattr(model, "num_samples", None),
+           tuple(p._version for p in model.parameters()), tuple(p.data_ptr() for p in model.parameters()))
+    if _CHECKED.get(key):  # nothing changed since the last agreement: no kernels, no collective
         return
     fp = replica_fingerprint(model)
     if fp is None:
-        return
-    key = (id(model), id(group), tuple(p._version for p in model.parameters()), tuple(p.data_ptr() for p in model.parameters()))
-    if _CHECKED.get(key):
         return
     both = torch.cat([fp, -fp])
     _all_reduce(both, dist.ReduceOp.MAX, group)
