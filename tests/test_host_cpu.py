@@ -381,6 +381,19 @@ def test_sharded_frame_pipeline_world2_gloo(tmp_path, h, w, chunks):
     assert res.stdout.count("OK") == 2
 
 
+def test_sharded_frame_pipeline_world8_gloo(tmp_path):
+    """The same at the node size the driver scales to: 8 ranks, 143 rays in 9 chunks of 16 -> 2 chunks per rank, ranks 0-3
+    full, rank 4 a full + the ragged chunk, ranks 5-7 WITHOUT rays (empty spans must gather, assemble and fingerprint too)."""
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_FRAME_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29688", str(script), ROOT, "11", "13", "16"]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert res.stdout.count("OK") == 8
+
+
 def test_bench_dry_launch_prints_the_child_command():
     """bench.py --gpus N without a launcher starts the ranks itself: N fresh processes under torch.distributed.run."""
     import json
