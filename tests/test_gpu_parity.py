@@ -283,6 +283,26 @@ def test_g9_render_image(golden, dev, chunks):
     close(dist, g[f"c{chunks}_dist"], atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("chunks", [128, 4096])
+def test_g9_render_image_bf16x3(golden, dev, chunks):
+    """render_image (model.py:254-274) in bf16x3 mode against the reference's frames (fixture G9), both chunk sizes: the
+    chunk partition (per-chunk contraction norms, many chunks per launch) is the fp32 path's; the MLP arithmetic keeps the
+    frame inside the same tolerances - the uint8 image within one level, distance / acc within 1e-4."""
+    from mipnerf360_amd.intern.ray import Rays
+    from mipnerf360_amd.model import mipNeRF360
+    g = golden("g9_render_image")
+    h, w, n = (int(x) for x in g["cfg"])
+    m = mipNeRF360(num_samples=n, hidden_proposal=32, hidden_nerf=64, device=dev, mlp_dtype="bf16x3")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in _sd(g).items()})
+    rays_cpu = Rays(*[torch.from_numpy(g["rays_" + k]) for k in synthetic.RAY_FIELDS])
+    rgb8, dist, acc = m.render_image(rays_cpu, h, w, chunks=chunks)
+    assert rgb8.dtype == np.uint8 and rgb8.shape == (h, w, 3)
+    assert np.abs(rgb8.astype(int) - g[f"c{chunks}_rgb8"].astype(int)).max() <= 1
+    assert (rgb8 != g[f"c{chunks}_rgb8"]).mean() < 0.02
+    close(acc, g[f"c{chunks}_acc"], atol=RGB_TOL, rtol=0)
+    close(dist, g[f"c{chunks}_dist"], atol=1e-4, rtol=1e-4)
+
+
 # =============================================================================== oracle, seeded inputs
 def test_linear_mfma_against_fp64(dev):
     """The MFMA GEMM for ragged M / N / K, all activations, vs an fp64 CPU product."""
