@@ -387,11 +387,18 @@ int m360_linear_heads_slots(int n_pad, int bf16);
 int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad,
                       int k_pad, int act /* M360_ACT_SIGMOID */, float *y, int ldy, int store_y, const float *head_w,
                       int heads, float *head_part, m360_stream_t stream);
-/* bf16 counterpart (x, w_packed, y: bf16 as for m360_linear_bf16; head_w, head_part: fp32; the head product uses the
- * bf16-ROUNDED activations, i.e. exactly what m360_nerf_finish_bf16 would read back) */
+/* bf16 counterpart (x, w_packed, y: bf16 as for m360_linear_bf16; head_w, head_part: fp32).  Round 3: the head products of
+ * the full 256-row tiles (widths 256 / 512 / 768 / 1024) are formed on the matrix pipe inside the layer's epilogue - the
+ * packed bf16 row segments the epilogue holds are B fragments of v_mfma_f32_16x16x32_bf16, the head rows (as two bf16 terms)
+ * the A fragments - from the bf16-ROUNDED activations, i.e. from what m360_nerf_finish_bf16 would read back;
+ * m360_linear_heads_slots(n_pad, 1) = 8 per 256 columns (one partial sum per wave column group and 8-column half).
+ * The bf16x3 form takes / writes [hi | lo] pair rows like m360_linear_bf16x3 and adds the lo activations' term. */
 int m360_linear_heads_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
                            int k_pad, int act, void *y, int ldy, int store_y, const float *head_w, int heads,
                            float *head_part, m360_stream_t stream);
+int m360_linear_heads_bf16x3(const void *x_hi_lo, long M, int ldx, const void *w_packed3, const float *b_packed, int n_pad,
+                             int k_pad, int act, void *y_hi_lo, int ldy, int store_y, const float *head_w, int heads,
+                             float *head_part, m360_stream_t stream);
 
 /* m360_prop_finish_n / m360_nerf_finish whose head products of the samples [0, fused_rows) come from
  * head_part[fused_rows][slots][heads] (summed slot 0, 1, ... + bias) and of the remaining samples from the activation

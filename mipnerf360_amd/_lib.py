@@ -119,6 +119,7 @@ SIGNATURES = {
     "m360_linear_heads_slots": (_i, [_i, _i]),
     "m360_linear_heads": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "m360_linear_heads_bf16": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "m360_linear_heads_bf16x3": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "m360_prop_finish_fused": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_nerf_finish_fused": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
                                     _vp]),

@@ -170,6 +170,7 @@ static int p_encode_ext_norm(const m360_hyper_t *h, const float *t, const float 
 // last hidden layer + heads fused (fp32 or bf16): partial head sums to `part`, y written only when store_y
 static int p_linear_heads(const m360_hyper_t *h, int bf16, const void *x, long M, int ldx, const void *w, const float *b, int n_pad, int k_pad, void *y, int ldy, int store_y, const float *head_w, int heads, float *part, m360_stream_t st) {
     ProfScope ps(h, st, M360_K_LINEAR_HEADS, M, n_pad, bf16 ? -k_pad : k_pad);
+    if (bf16 == 2) return ps.done(m360_linear_heads_bf16x3(x, M, ldx, w, b, n_pad, k_pad, M360_ACT_SIGMOID, y, ldy, store_y, head_w, heads, part, st));
     if (bf16) return ps.done(m360_linear_heads_bf16(x, M, ldx, w, b, n_pad, k_pad, M360_ACT_SIGMOID, y, ldy, store_y, head_w, heads, part, st));
     return ps.done(m360_linear_heads(static_cast<const float *>(x), M, ldx, static_cast<const float *>(w), b, n_pad, k_pad, M360_ACT_SIGMOID, static_cast<float *>(y), ldy, store_y, head_w, heads, part, st));
 }
@@ -245,12 +246,10 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         M360_TRY(p_linear_bf16(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, st));
         M360_TRY(p_linear_bf16(h, mode, a, S, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, st));
         M360_TRY(p_linear_bf16(h, mode, b, S, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, st));
-        if (mode == 2) {  // the last hidden layer writes its [hi | lo] output, the finisher forms the head from hi + lo
-            M360_TRY(p_linear_bf16(h, 2, a, S, m->prop_w[3], m->prop_b[3], hp, hp, M360_ACT_SIGMOID, b, st));
-            return p_prop_finish_fused(h, b, 2, 2 * hp, hpart, 0, 0, m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
-        }
-        M360_TRY(p_linear_heads(h, 1, a, S, hp, m->prop_w[3], m->prop_b[3], hp, hp, b, hp, 0, m->prop_head_w, 1, hpart, st));
-        return p_prop_finish_fused(h, b, 1, hp, hpart, m360_linear_heads_fused_rows(S, hp, 1), m360_linear_heads_slots(hp, 1), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
+        // last hidden layer + head on the matrix pipe (full 256-row tiles; tail rows through y): ld of y = hp (bf16) / 2 hp ([hi | lo])
+        const int ldl = mode == 2 ? 2 * hp : hp;
+        M360_TRY(p_linear_heads(h, mode, a, S, ldl, m->prop_w[3], m->prop_b[3], hp, hp, b, ldl, 0, m->prop_head_w, 1, hpart, st));
+        return p_prop_finish_fused(h, b, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hp, mode), m360_linear_heads_slots(hp, mode), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
     }
     if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(p_linear(h, &tq, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
@@ -299,13 +298,9 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
             M360_TRY(p_linear_bf16(h, mode, src, S, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, st));
             float *tmp = src; src = dst; dst = tmp;
         }
-        if (mode == 2) {
-            M360_TRY(p_linear_bf16(h, 2, src, S, m->nerf_w[7], m->nerf_b[7], hn, hn, M360_ACT_SIGMOID, dst, st));
-            M360_TRY(p_nerf_finish_fused(h, dst, 2, 2 * hn, hpart, 0, 0, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
-        } else {
-            M360_TRY(p_linear_heads(h, 1, src, S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, hn, 0, m->nerf_head_w, 4, hpart, st));
-            M360_TRY(p_nerf_finish_fused(h, dst, 1, hn, hpart, m360_linear_heads_fused_rows(S, hn, 1), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
-        }
+        const int ldl = mode == 2 ? 2 * hn : hn;
+        M360_TRY(p_linear_heads(h, mode, src, S, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, ldl, 0, m->nerf_head_w, 4, hpart, st));
+        M360_TRY(p_nerf_finish_fused(h, dst, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hn, mode), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     } else {
     if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
     else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));

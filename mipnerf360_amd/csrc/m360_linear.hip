@@ -385,15 +385,21 @@ int m360_linear_balanced(const float *x, long M, int ldx, const float *w_packed,
     return launch_linear(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, nullptr, stream, tile_queue);
 }
 
+#ifndef M360_X3_MODE
+#define M360_X3_MODE 2  // 2 = the three products of a 64-deep block share operand tiles (product); 1 = one 3K-deep contraction (A/B builds)
+#endif
 // ---- last hidden layer of a stage fused with its heads
 long m360_linear_heads_fused_rows(long M, int n_pad, int bf16) {
-    if (bf16) return 0;  // see m360_linear_heads_bf16
+    if (bf16) {  // bf16 / bf16x3: the ping-pong kernel's MFMA-side heads (full 256-row tiles, widths of 256..1024 in steps of 256)
+        if (M < 0 || n_pad < pp16::BN || n_pad % pp16::BN != 0 || n_pad > pp16::kHeadMaxN) return 0;
+        return (M / pp16::BM) * pp16::BM;
+    }
     if (M < 0 || n_pad < persist::BN || n_pad % persist::BN != 0 || n_pad > persist::kHeadMaxN) return 0;
     return (M / persist::BM) * persist::BM;  // full 256-row tiles of a 256-multiple width <= 1024
 }
 
-int m360_linear_heads_slots(int n_pad, int bf16) {  // partial sums per row: one per wave tile (fp32 128 columns, bf16 64)
-    return n_pad >= persist::BN ? (bf16 ? 4 : 2) * (n_pad / persist::BN) : 0;
+int m360_linear_heads_slots(int n_pad, int bf16) {  // partial sums per row: fp32 one per 128-column wave tile, bf16 one per 32 columns
+    return n_pad >= persist::BN ? (bf16 ? 8 : 2) * (n_pad / persist::BN) : 0;
 }
 
 int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
@@ -433,16 +439,62 @@ int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, co
     return M360_OK;
 }
 
+// bf16 (x3 = 0) and bf16x3 (x3 = 1) last hidden layer + heads: the full 256-row tiles on the ping-pong kernel with its MFMA-side
+// head products (y is written only when store_y), the ragged tail rows on the plain layer (the finisher reads y there)
+static int linear_heads_bf16_any(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
+                                 int k_pad, int act, void *y, int ldy, int store_y, const float *head_w, int heads,
+                                 float *head_part, m360_stream_t stream, int x3) {
+    const char *who = x3 ? "m360_linear_heads_bf16x3" : "m360_linear_heads_bf16";
+    if (heads != 1 && heads != 4) return fail(M360_ERR_INVALID_ARGUMENT, "%s: heads=%d (1 or 4)", who, heads);
+    if (act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "%s: the last hidden layer is a sigmoid layer, act=%d", who, act);
+    if (!x || !w_packed || !b_packed || !y || !head_w || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "%s: null pointer or negative M", who);
+    const int xm = x3 ? 2 : 1;  // row-length multiplier of the [hi | lo] layout
+    long M_fused = m360_linear_heads_fused_rows(M, n_pad, 1);
+    if (!x3 && k_pad < 2 * pp16::BK) M_fused = 0;  // a single K-step: not the ping-pong kernel's shape
+    if (M_fused > 0) {
+        if (!head_part || ((uintptr_t)head_part & 15) || ((uintptr_t)head_w & 15)) return fail(M360_ERR_INVALID_ARGUMENT, "%s: head_part / head_w must be 16-byte aligned device pointers", who);
+        if (k_pad < pbf16::BK || k_pad % pbf16::BK != 0 || ldx < xm * k_pad || ldy < xm * n_pad || ldx % 8 != 0 || ldy % 8 != 0)
+            return fail(M360_ERR_INVALID_ARGUMENT, "%s: k_pad=%d must be a positive multiple of %d, ldx=%d, ldy=%d", who, k_pad, pbf16::BK, ldx, ldy);
+        if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "%s: pointers must be 16-byte aligned", who);
+        const int cus = cu_count();
+        if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "%s: no HIP device", who);
+        const long nt = (M_fused / pp16::BM) * (n_pad / pp16::BN);
+        dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
+        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+        const __bf16 *xb = static_cast<const __bf16 *>(x), *wb = static_cast<const __bf16 *>(w_packed);
+        __bf16 *yb = static_cast<__bf16 *>(y);
+        const int kk = x3 ? 3 * k_pad : k_pad, tn = n_pad / pp16::BN;
+#define M360_PP_HEADS(X3M, H, SY) hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_SIGMOID, false, X3M, H, SY>), grid, block, 0, st, xb, M_fused, ldx, wb, b_packed, n_pad, kk, yb, ldy, tn, (int)nt, head_w, head_part)
+        if (x3) {
+            if (heads == 1) { if (store_y) M360_PP_HEADS(M360_X3_MODE, 1, true); else M360_PP_HEADS(M360_X3_MODE, 1, false); }
+            else { if (store_y) M360_PP_HEADS(M360_X3_MODE, 4, true); else M360_PP_HEADS(M360_X3_MODE, 4, false); }
+        } else {
+            if (heads == 1) { if (store_y) M360_PP_HEADS(0, 1, true); else M360_PP_HEADS(0, 1, false); }
+            else { if (store_y) M360_PP_HEADS(0, 4, true); else M360_PP_HEADS(0, 4, false); }
+        }
+#undef M360_PP_HEADS
+        const int rc = check_launch(who);
+        if (rc != M360_OK) return rc;
+    }
+    if (M > M_fused) {  // ragged tail rows / shapes the fused epilogue does not take: the plain layer; the finisher reads y there
+        const char *xt = static_cast<const char *>(x) + (size_t)M_fused * ldx * 2;
+        char *yt = static_cast<char *>(y) + (size_t)M_fused * ldy * 2;
+        if (x3) return m360_linear_bf16x3(xt, M - M_fused, ldx, w_packed, b_packed, n_pad, k_pad, act, yt, ldy, stream);
+        return m360_linear_bf16(xt, M - M_fused, ldx, w_packed, b_packed, n_pad, k_pad, act, yt, ldy, stream);
+    }
+    return M360_OK;
+}
+
 int m360_linear_heads_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
                            int k_pad, int act, void *y, int ldy, int store_y, const float *head_w, int heads,
                            float *head_part, m360_stream_t stream) {
-    if (heads != 1 && heads != 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads_bf16: heads=%d (1 or 4)", heads);
-    if (act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_heads_bf16: the last hidden layer is a sigmoid layer, act=%d", act);
-    // m360_linear_heads_fused_rows(.., bf16 = 1) is 0: the bf16 kernel's deferred epilogue has no registers left for the head
-    // sums (an attempt spilled into the K loop: 4.0 ms instead of 0.97 ms per layer, profiles/r02), so every row goes through
-    // y and the finisher forms the head products from there - the same contract as the tail rows of the fp32 entry point
-    (void)store_y; (void)head_w; (void)head_part;
-    return m360_linear_bf16(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, stream);
+    return linear_heads_bf16_any(x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, ldy, store_y, head_w, heads, head_part, stream, 0);
+}
+
+int m360_linear_heads_bf16x3(const void *x, long M, int ldx, const void *w_packed3, const float *b_packed, int n_pad,
+                             int k_pad, int act, void *y, int ldy, int store_y, const float *head_w, int heads,
+                             float *head_part, m360_stream_t stream) {
+    return linear_heads_bf16_any(x, M, ldx, w_packed3, b_packed, n_pad, k_pad, act, y, ldy, store_y, head_w, heads, head_part, stream, 1);
 }
 
 // ---- training path: input gradient, weight gradient, transposed packing
@@ -573,9 +625,6 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
     return check_launch("linear_bf16");
 }
 
-#ifndef M360_X3_MODE
-#define M360_X3_MODE 2  // 2 = the three products of a 64-deep block share operand tiles (product); 1 = one 3K-deep contraction (A/B builds)
-#endif
 int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed3,
                             float *b_packed, m360_stream_t stream) {
     if (!w || !w_packed3 || n_out < 1 || k_in < 1 || n_pad < n_out || k_pad < k_in || k_pad % pbf16::BK != 0 || n_pad % 32 != 0)

@@ -51,11 +51,21 @@ __device__ __forceinline__ float act_fn(float v) {
 //           traffic and LDS-DMA issue, the two things that bound this kernel: DESIGN.md 4.3).  The A and B halves of the two LDS
 //           buffers are switched independently: T1 reads (A0, B0) and stages Xh into A1; T2 reads (A1, B0) and stages Wl into
 //           B1; T3 reads (A1, B1) and stages the next block's Xl / Wh into A0 / B0.
-template <int ACT, bool STAMP = false, int X3 = 0>
+// HEADS > 0 (the last hidden layer of a stage, round 3): the output heads' dot products are formed ON THE MATRIX PIPE from the packed
+// bf16 rows the epilogue holds anyway - a lane's 8 consecutive output columns of one row ARE a B fragment of
+// v_mfma_f32_16x16x32_bf16, the head rows (as hi / lo bf16 terms, from LDS) the A fragment, so one MFMA per row block and term
+// gives D[head][row]: lanes 0-15 then hold the 4 heads of their row.  No register growth (the fragment registers are free while
+// a quadrant is stored), 8-12 MFMAs per quadrant against 1024 per tile.  One partial sum per row, wave column group and 8-column
+// half goes to head_part[row][(Np / 256) * 8][HEADS]; with STORE_Y = false the layer's own output is never written.
+constexpr int kHeadMaxN = 1024;  // widest layer the fused heads take (their hi / lo rows live in 16 KiB of LDS)
+template <int ACT, bool STAMP = false, int X3 = 0, int HEADS = 0, bool STORE_Y = true>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias,
-    int Np, int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * kTileBytes + kMaxBias * 4];  // 128 KiB + the bias vector
+    int Np, int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, const float *__restrict__ head_w = nullptr,
+    float *__restrict__ head_part = nullptr) {
+    // 128 KiB of stages + the bias vector (+ with HEADS the head rows as bf16 hi / lo terms: 2 x HEADS x Np <= 16 KiB)
+    __shared__ __attribute__((aligned(1024))) char smem[2 * kTileBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0)];
+    static_assert(HEADS == 0 || HEADS == 1 || HEADS == 4, "1 (proposal) or 4 (NeRF) heads");
 #if defined(PP_PHASES) && PP_PHASES != 4
     static_assert(!X3, "the split (bf16x3) epilogue is counted for the 4-phase K-step only");
 #endif
@@ -198,6 +208,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         __builtin_amdgcn_s_setprio(0);                                                                           \
     } while (0)
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define PP_VMCNT_C(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")  // N: a constant expression
+    // vector-memory operations one PP_STORE_Q issues: the layer's own rows (4 stores, 8 as [hi | lo] pairs) and / or the head sums (4)
+    constexpr int SPQ = (STORE_Y ? (X3 ? 8 : 4) : 0) + (HEADS ? 4 : 0);
 // Deferred epilogue of the PREVIOUS tile, one quadrant: bias + activation + bf16 pack, one 16-byte store per row (the
 // N-blocks J0, J0+1 of a lane are 8 consecutive columns), then the accumulators restart from zero.  Runs in the load
 // half of a phase, i.e. while the partner wave on this SIMD is in its MFMA half.
@@ -210,6 +223,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     } while (0)
 #define PP_STORE_Q(I0, J0)                                                                              \
     do {                                                                                                \
+        bf16x8 hh_, hl_;                                                                                \
+        if (HEADS) { /* this lane's head row (hi and lo terms) over the 8 columns of this half: 2 LDS reads, transient */ \
+            const unsigned ha_ = hfrag_addr + ((J0) ? 16u : 0u);                                        \
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"           \
+                         : "=&v"(hh_), "=&v"(hl_) : "v"(ha_), "v"(ha_ + hlo_off) : "memory");            \
+        }                                                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                 \
             const f32x4 v_ = acc[(I0) + i][(J0)], w_ = acc[(I0) + i][(J0) + 1];                         \
             bf16x8 o_, l_;                                                                              \
@@ -217,9 +236,21 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
             PP_E1(2, v_[2] + bq[(J0)][2]); PP_E1(3, v_[3] + bq[(J0)][3]);                               \
             PP_E1(4, w_[0] + bq[(J0) + 1][0]); PP_E1(5, w_[1] + bq[(J0) + 1][1]);                       \
             PP_E1(6, w_[2] + bq[(J0) + 1][2]); PP_E1(7, w_[3] + bq[(J0) + 1][3]);                       \
-            __bf16 *const yp_ = Yp + (long)(((I0) + i) * 16) * ldy_t + ((J0) ? 8 : 0);                  \
-            *reinterpret_cast<bf16x8 *>(yp_) = o_;                                                      \
-            if (X3) *reinterpret_cast<bf16x8 *>(yp_ + Np) = l_; /* the lo terms: columns [Np, 2 Np) */  \
+            if (STORE_Y) {                                                                              \
+                __bf16 *const yp_ = Yp + (long)(((I0) + i) * 16) * ldy_t + ((J0) ? 8 : 0);              \
+                *reinterpret_cast<bf16x8 *>(yp_) = o_;                                                  \
+                if (X3) *reinterpret_cast<bf16x8 *>(yp_ + Np) = l_; /* the lo terms: columns [Np, 2 Np) */ \
+            }                                                                                           \
+            if (HEADS) { /* D[head][row] = sum over this lane group's 8 columns: hi and lo head terms (X3: and the lo activations) */ \
+                f32x4 hq_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh_, o_, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0); \
+                hq_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl_, o_, hq_, 0, 0, 0);                   \
+                if (X3) hq_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh_, l_, hq_, 0, 0, 0);           \
+                if (g4 == 0) {                                                                          \
+                    float *const hp_ = Hp + (long)(((I0) + i) * 16) * hstride + ((J0) ? HEADS : 0);     \
+                    if (HEADS == 4) *reinterpret_cast<f32x4 *>(hp_) = hq_;                              \
+                    else *hp_ = hq_[0];                                                                 \
+                }                                                                                       \
+            }                                                                                           \
             acc[(I0) + i][(J0)] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                                      \
             acc[(I0) + i][(J0) + 1] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                                  \
             if (X3) PP_SB(); /* one row at a time: the split epilogue's temporaries must not pile up across rows */ \
@@ -241,7 +272,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         PP_READ_W(0, boff, 0, 512);                         \
         PP_READ_X(boff, 0, 2048, 4096, 6144);               \
         stage(nbuf, 0, k_next);                             \
-        if (ST) { if (X3) PP_VMCNT(12); else PP_VMCNT(8); } else PP_VMCNT(4); \
+        if (ST) PP_VMCNT_C(SPQ + 4); else PP_VMCNT(4);      \
         PP_BAR();                                           \
         PP_WAIT_W(0);                                       \
         PP_WAIT_X();                                        \
@@ -252,7 +283,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         if (ST) PP_STORE_Q(0, 2);                           \
         PP_READ_W(2, boff, 1024, 1536);                     \
         stage(nbuf, 1, k_next);                             \
-        if (ST) { if (X3) PP_VMCNT(20); else PP_VMCNT(12); } else PP_VMCNT(4); \
+        if (ST) PP_VMCNT_C(2 * SPQ + 4); else PP_VMCNT(4);  \
         PP_BAR();                                           \
         PP_WAIT_W(2);                                       \
         PP_SB();                                            \
@@ -262,7 +293,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         if (ST) PP_STORE_Q(4, 2);                           \
         PP_READ_X(boff, 8192, 10240, 12288, 14336);         \
         stage(nbuf, 2, k_next);                             \
-        if (ST) { if (X3) PP_VMCNT(20); else PP_VMCNT(12); } else PP_VMCNT(4); \
+        if (ST) PP_VMCNT_C(2 * SPQ + 4); else PP_VMCNT(4);  \
         PP_BAR();                                           \
         PP_WAIT_X();                                        \
         PP_SB();                                            \
@@ -271,7 +302,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         PP_BAR();                                           \
         if (ST) PP_STORE_Q(4, 0);                           \
         stage(nbuf, 3, k_next);                             \
-        if (ST) { if (X3) PP_VMCNT(20); else PP_VMCNT(12); } else PP_VMCNT(4); \
+        if (ST) PP_VMCNT_C(2 * SPQ + 4); else PP_VMCNT(4);  \
         PP_BAR();                                           \
         PP_SB();                                            \
         PP_MFMA16(4, 0);                                    \
@@ -328,8 +359,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
 // X3 = 2: the three K-steps of one 64-deep block.  TYPE 1: xl wh (stages Xh for TYPE 2), TYPE 2: xh wh (keeps Wh, stages Wl for
 // TYPE 3), TYPE 3: xh wl (keeps Xh, stages the next block's Xl and Wh).  A phase stages a unit only when the next K-step does not
 // reuse it; the counted waits retire exactly what the NEXT phase reads and was staged (ops issued after that unit's pair):
-//   T1: p0 WB of this K-step (previous T3 p2) 4 | p1 its XB (T3 p3) 2 | p3 XA' (T1 p0) 2;  with the previous tile's stores (8 per
-//       phase, issued before the phase's pair) 12 | 18 | 26
+//   T1: p0 WB of this K-step (previous T3 p2) 4 | p1 its XB (T3 p3) 2 | p3 XA' (T1 p0) 2;  with the previous tile's stores (SPQ per
+//       phase, issued before the phase's pair) SPQ + 4 | 2 SPQ + 2 | 3 SPQ + 2
 //   T2: p1 XB' (T1 p3) 2 | p3 WA'' (T2 p1) 2          T3: p0 WB'' (T2 p2) 2 | p3 XA*, WA* (T3 p0, p1) 4
 // Staging distances as in the 4-unit K-step: every unit is staged >= 3 phases before its first read and re-staged >= 4 phases
 // after its last one.
@@ -340,7 +371,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         PP_READ_W(0, woff, 0, 512);                                                             \
         PP_READ_X(aoff, 0, 2048, 4096, 6144);                                                   \
         if ((TYPE) != 2) stage_x(sx_buf, 0, sx_k);                                              \
-        if ((TYPE) == 1) { if (ST) PP_VMCNT(12); else PP_VMCNT(4); } else if ((TYPE) == 3) PP_VMCNT(2); \
+        if ((TYPE) == 1) { if (ST) PP_VMCNT_C(SPQ + 4); else PP_VMCNT(4); } else if ((TYPE) == 3) PP_VMCNT(2); \
         PP_BAR();                                                                               \
         PP_WAIT_W(0);                                                                           \
         PP_WAIT_X();                                                                            \
@@ -351,7 +382,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         if (ST) PP_STORE_Q(0, 2);                                                               \
         PP_READ_W(2, woff, 1024, 1536);                                                         \
         if ((TYPE) != 1) stage_w(sw_buf, 1, sw_k);                                              \
-        if ((TYPE) == 1) { if (ST) PP_VMCNT(18); else PP_VMCNT(2); } else if ((TYPE) == 2) PP_VMCNT(2); \
+        if ((TYPE) == 1) { if (ST) PP_VMCNT_C(2 * SPQ + 2); else PP_VMCNT(2); } else if ((TYPE) == 2) PP_VMCNT(2); \
         PP_BAR();                                                                               \
         PP_WAIT_W(2);                                                                           \
         PP_SB();                                                                                \
@@ -369,7 +400,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
         PP_BAR();                                                                               \
         if (ST) PP_STORE_Q(4, 0);                                                               \
         if ((TYPE) != 2) stage_x(sx_buf, 3, sx_k);                                              \
-        if ((TYPE) == 1) { if (ST) PP_VMCNT(26); else PP_VMCNT(2); } else if ((TYPE) == 2) PP_VMCNT(2); else PP_VMCNT(4); \
+        if ((TYPE) == 1) { if (ST) PP_VMCNT_C(3 * SPQ + 2); else PP_VMCNT(2); } else if ((TYPE) == 2) PP_VMCNT(2); else PP_VMCNT(4); \
         PP_BAR();                                                                               \
         PP_SB();                                                                                \
         PP_MFMA16(4, 0);                                                                        \
@@ -380,7 +411,22 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
     // ---- bias -> LDS once (before any LDS-DMA is in flight)
     float *const bias_lds = reinterpret_cast<float *>(smem + 2 * kTileBytes);
     for (int i = tid; i < Np; i += kThreads) bias_lds[i] = bias[i];
+    // head rows as two bf16 terms: hfrag[0][h][n] = bf16(w), hfrag[1][h][n] = bf16(w - hi) (HEADS x Np <= 4 x 1024 values each)
+    __bf16 *const hfrag = reinterpret_cast<__bf16 *>(smem + 2 * kTileBytes + kMaxBias * 4);
+    if (HEADS) {
+        for (int i = tid; i < HEADS * Np; i += kThreads) {
+            const float w_ = head_w[i];
+            const __bf16 hi_ = (__bf16)w_;
+            hfrag[i] = hi_;
+            hfrag[HEADS * Np + i] = bf16_lo_(w_, hi_);
+        }
+    }
     __syncthreads();
+    // this lane's head row for MFMA A-fragment row l15 (rows >= HEADS repeat the last head: their D rows are never stored)
+    const unsigned hlo_off = 2u * (unsigned)(HEADS * Np);
+    const int hstride = HEADS ? (Np / BN) * 8 * HEADS : 0;  // floats per row of head_part: [(Np / 256) * 8 slots][HEADS]
+    unsigned hfrag_addr = 0;  // LDS byte address of the fragment for the tile being stored (set with Yp)
+    float *Hp = head_part;
     const unsigned bias_addr = lds0 + 2 * kTileBytes + 4u * (wn * 64 + 16 * g4);  // + 4 * n0 of the tile, + 16 * jb
 
     // ---- prologue: the four units of K-step 0 in the order they are first read (X3 = 2: K-step 0 is xl wh of block 0)
@@ -481,6 +527,11 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_pp_kernel(
             PP_DS128(bq[3], ba, 48);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3])::"memory");
             Yp = Y + (m0 + wm * 128 + l15) * ldy_t + n0 + wn * 64 + 16 * g4;
+            if (HEADS) {
+                const int hrow = l15 < HEADS ? l15 : HEADS - 1;
+                hfrag_addr = lds0 + 2 * kTileBytes + kMaxBias * 4 + 2u * (unsigned)(hrow * Np + n0 + wn * 64 + 16 * g4);
+                Hp = head_part + (m0 + wm * 128 + l15) * hstride + ((n0 / BN) * 8 + wn * 2) * HEADS;
+            }
             asm volatile("" : "+s"(ldy_t));
             have_prev = true;
         }

@@ -470,6 +470,27 @@ def linear_heads(x, w_packed, b_packed, head_w, store_y: bool = True):
     return y, part, fused
 
 
+def linear_heads_bf16(x, w_packed, b_packed, head_w, store_y: bool = True, x3: bool = False):
+    """The bf16 (x3 = False: m360_linear_heads_bf16) / bf16x3 (x3 = True: [hi | lo] pair rows, m360_linear_heads_bf16x3) last hidden
+    layer with the heads formed on the matrix pipe -> (y, head_part[fused_rows, slots, heads] fp32, fused_rows)."""
+    x, w_packed, b_packed, head_w = dev_bf16(x, "x"), dev_bf16(w_packed, "w_packed"), dev(b_packed, "b_packed"), dev(head_w, "head_w")
+    M, ldx = x.shape
+    n_pad = w_packed.shape[0]
+    k_pad = w_packed.shape[1] // (3 if x3 else 1)
+    heads = head_w.shape[0]
+    if head_w.shape[1] != n_pad or ldx != (2 if x3 else 1) * k_pad:
+        raise RuntimeError("linear_heads_bf16: shapes of x / w_packed / head_w do not match")
+    lib = _lib.lib()
+    mode = 2 if x3 else 1
+    fused, slots = int(lib.m360_linear_heads_fused_rows(M, n_pad, mode)), int(lib.m360_linear_heads_slots(n_pad, mode))
+    ldy = (2 if x3 else 1) * n_pad
+    y = torch.zeros(M, ldy, device=x.device, dtype=torch.bfloat16)
+    part = torch.zeros(max(fused, 1), max(slots, 1), heads, device=x.device)
+    _call("m360_linear_heads_bf16x3" if x3 else "m360_linear_heads_bf16", x, M, ldx, w_packed, b_packed, n_pad, k_pad,
+          _lib.ACT_SIGMOID, y, ldy, int(bool(store_y)), head_w, heads, part, STREAM)
+    return y, part, fused
+
+
 def nerf_finish_fused(act, head_part, fused_rows, head_w, head_b, density_bias, rgb_padding, t_vals, dirs, white_bkgd):
     act, head_part, head_w, head_b = dev(act, "act"), dev(head_part, "head_part"), dev(head_w, "head_w"), dev(head_b, "head_b")
     t_vals, dirs = dev(t_vals, "t_vals"), dev(dirs, "dirs")

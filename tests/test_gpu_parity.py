@@ -1402,6 +1402,42 @@ def test_bf16_pingpong_kernel_race_screen(dev):
         assert float(diff.max()) <= 2.0 ** -7 * max(float(ref.abs().max()), 1.0)   # one bf16 rounding of the output
 
 
+@pytest.mark.parametrize("x3", [False, True])
+@pytest.mark.parametrize("M,n,k,heads", [(1024, 1024, 1024, 4), (512 + 37, 256, 256, 1), (2048, 512, 128, 4)])
+def test_bf16_last_layer_heads_on_the_matrix_pipe(dev, M, n, k, heads, x3):
+    """m360_linear_heads_bf16 / _bf16x3: the heads' dot products come out of the layer's own epilogue (MFMAs on the packed
+    bf16 row segments x the head rows as two bf16 terms), one partial per row, wave column group and 8-column half.  Summed
+    over the slots they must equal the product of the layer's STORED activations with the fp32 head rows (to the 16 bits
+    the head rows are carried in); with store_y = 0 the fused rows of y stay untouched; tail rows go through y."""
+    from mipnerf360_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + n + k + heads)
+    x = (torch.rand(M, k, generator=g) * 2 - 1).to(dev)
+    w = ((torch.rand(n, k, generator=g) * 2 - 1) * (6.0 / k) ** 0.5).to(dev)
+    b = (torch.rand(n, generator=g) - 0.5).to(dev)
+    hw = ((torch.rand(heads, n, generator=g) * 2 - 1) * (6.0 / n) ** 0.5).to(dev)
+    if x3:
+        wp, bp = ops.pack_linear_bf16x3(w, b, n, k)
+        xs = ops.split_bf16x3(x)
+        y_ref = ops.join_bf16x3(ops.linear_bf16x3(xs, wp, bp, _lib.ACT_SIGMOID))
+    else:
+        wp, bp = ops.pack_linear_bf16(w, b, n, k)
+        xs = x.bfloat16()
+        y_ref = ops.linear_bf16(xs, wp, bp, _lib.ACT_SIGMOID).float()
+    y, part, fused = ops.linear_heads_bf16(xs, wp, bp, hw, store_y=True, x3=x3)
+    assert fused == (M // 256) * 256 and part.shape[1] == 8 * (n // 256)
+    y_val = ops.join_bf16x3(y) if x3 else y.float()
+    assert torch.equal(y_val, y_ref)                                  # the layer itself is unchanged by the fusion
+    want = y_ref[:fused].double() @ hw.double().T                      # [fused, heads]
+    got = part.double().sum(1)
+    assert float((got - want).abs().max()) <= 3e-5 * max(float(want.abs().max()), 1.0)
+    y2, part2, _ = ops.linear_heads_bf16(xs, wp, bp, hw, store_y=False, x3=x3)
+    assert torch.equal(part2, part)
+    assert float(y2[:fused].float().abs().max()) == 0.0                # not written
+    assert torch.equal(y2[fused:], y[fused:])                          # tail rows: the plain layer, the finisher reads them
+    for _ in range(5):
+        assert torch.equal(ops.linear_heads_bf16(xs, wp, bp, hw, store_y=False, x3=x3)[1], part)
+
+
 def test_bf16x3_kernel_race_screen(dev):
     """The same screen for the X3 instantiation of the ping-pong kernel (contraction 3K with the activation column wrapping
     at 2K, split [hi | lo] epilogue with twice the stores and its own counted waits): 40 back-to-back launches at the
