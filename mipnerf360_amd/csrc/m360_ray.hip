@@ -408,12 +408,34 @@ __device__ __forceinline__ void ray_heads(const T *__restrict__ act, int ld, con
     const int nf = nfl <= 0 ? 0 : (nfl >= N ? N : (int)nfl);  // block-uniform
     if (nf < N)
         for (int i = threadIdx.x; i < H * k_pad; i += blockDim.x) hw[i] = head_w[i];
-    for (int idx = threadIdx.x; idx < nf * H; idx += blockDim.x) {
-        const int n = idx / H, hh = idx % H;
-        const float *p = head_part + ((s0 + n) * slots) * H + hh;
-        float a = 0.0f;
-        for (int q = 0; q < slots; ++q) a += p[q * H];
-        raw[idx] = a + head_b[hh];
+    if (sizeof(T) == 2 && H == 4 && slots % 8 == 0) {
+        // bf16 / bf16x3 layers leave 8 slots per 256 columns (32 at width 1024: 512 contiguous bytes per sample): 8 lanes per
+        // sample, each adds slots / 8 consecutive float4, then a DPP butterfly over the 8 lanes - whole lines per wave read
+        // instead of 16-byte pieces 512 bytes apart
+        const int per = slots / 8, lane8 = threadIdx.x & 7;
+        for (int n = threadIdx.x >> 3; n < nf; n += blockDim.x >> 3) {
+            const float4 *p = reinterpret_cast<const float4 *>(head_part + ((s0 + n) * slots + lane8 * per) * 4);
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int q = 0; q < per; ++q) {
+                const float4 v = p[q];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            a.x = row8_sum(a.x); a.y = row8_sum(a.y); a.z = row8_sum(a.z); a.w = row8_sum(a.w);
+            if (lane8 == 0) {
+                raw[n * 4 + 0] = a.x + head_b[0];
+                raw[n * 4 + 1] = a.y + head_b[1];
+                raw[n * 4 + 2] = a.z + head_b[2];
+                raw[n * 4 + 3] = a.w + head_b[3];
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < nf * H; idx += blockDim.x) {
+            const int n = idx / H, hh = idx % H;
+            const float *p = head_part + ((s0 + n) * slots) * H + hh;
+            float a = 0.0f;
+            for (int q = 0; q < slots; ++q) a += p[q * H];
+            raw[idx] = a + head_b[hh];
+        }
     }
     __syncthreads();
     if (nf < N) {
