@@ -686,7 +686,7 @@ int m360_diag_linear(const float *x, long M, int ldx, const float *w_packed, con
 
 int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
                           int k_pad, void *y, int ldy, int variant, int ldw, m360_stream_t stream) {
-    if (!x || !w_packed || !b_packed || !y || M < pp16::BM || M % pp16::BM || n_pad % pp16::BN || k_pad % pp16::BK || k_pad < 2 * pp16::BK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: full 256 x 256 tiles, k_pad >= 128 only");
+    if (!x || !w_packed || !b_packed || !y || M < pp16::BM || M % pp16::BM || n_pad % pp16::BN || k_pad % pp16::BK || k_pad < pp16::BK) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: full 256 x 256 tiles, k_pad a multiple of 64 only");
     const int cus = cu_count();
     const long nt = (M / pp16::BM) * (n_pad / pp16::BN);
     dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);

@@ -13,6 +13,7 @@ for s in $steps; do
     x3)      timeout 900 python bench.py --mlp-dtype bf16x3 > $out/bench_bf16x3.json 2> $out/bench_bf16x3.err; tail -c 1500 $out/bench_bf16x3.json ;;
     x3c5)    timeout 900 python bench.py --config c5 --mlp-dtype bf16x3 > $out/bench_c5_bf16x3.json 2> $out/bench_c5_bf16x3.err; tail -c 900 $out/bench_c5_bf16x3.json ;;
     x3prof)  R=$PWD; O=$R/$out; ( cd /tmp && export TMPDIR=/tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_x3 -- python3 $R/bench.py --mlp-dtype bf16x3 --steps 5 --warmup 2 --cpu-rays 0 > $O/bench_x3_under_rocprof.log 2>&1 ); find $O/stats_x3 -name "*.db" -delete 2>/dev/null; cp $O/stats_x3/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_bench_bf16x3.csv 2>/dev/null; head -12 $O/rocprofv3_kernel_stats_bench_bf16x3.csv | cut -c1-160 ;;
+    b16prof) R=$PWD; O=$R/$out; ( cd /tmp && export TMPDIR=/tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b16 -- python3 $R/bench.py --mlp-dtype bf16 --steps 5 --warmup 2 --cpu-rays 0 > $O/bench_b16_under_rocprof.log 2>&1 ); find $O/stats_b16 -name "*.db" -delete 2>/dev/null; cp $O/stats_b16/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_bench_bf16.csv 2>/dev/null; head -12 $O/rocprofv3_kernel_stats_bench_bf16.csv | cut -c1-160 ;;
     gloo2)   timeout 900 python bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --frame-size 400x300 > $out/bench_gloo2.json 2> $out/bench_gloo2.err; tail -c 1200 $out/bench_gloo2.json ;;
     c5)      timeout 900 python bench.py --config c5 > $out/bench_c5.json 2> $out/bench_c5.err; tail -c 2500 $out/bench_c5.json ;;
     ceiling) timeout 300 tools/mfma_ceiling.bin > $out/mfma_ceiling.jsonl 2>&1; cat $out/mfma_ceiling.jsonl ;;
@@ -41,6 +42,11 @@ for s in $steps; do
              timeout 300 python bench.py --gpus 2 --steps 2 --warmup 1 --frame-steps 0 > $out/nccl2.out 2> $out/nccl2.err; echo "rc=$?" >> $out/nccl2.out; tail -3 $out/nccl2.out; grep -i "nccl\|rccl\|duplicate\|error" $out/nccl2.err | head -12 ;;
     c4)      timeout 900 python bench.py --config c4 --steps 2 --warmup 1 > $out/bench_c4.json 2> $out/bench_c4.err; tail -c 2500 $out/bench_c4.json ;;
     lintests) timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "linear or soak or bit_identical or one_chunk or g8 or g7 or fused" > $out/pytest_linear.log 2>&1; echo "pytest rc=$?" >> $out/pytest_linear.log; tail -6 $out/pytest_linear.log ;;
+    wide)    timeout 300 tools/wide_wave_probe.bin > $out/bf16_wide_wave_probe.jsonl 2>&1; cat $out/bf16_wide_wave_probe.jsonl | cut -c1-330
+             timeout 300 tools/loader_wave_probe.bin > $out/bf16_loader_wave_probe_same_box.jsonl 2>&1; grep '"mode": [14]' $out/bf16_loader_wave_probe_same_box.jsonl | cut -c1-330 ;;
+    k64)     for n in 1024 256; do m=$((n == 1024 ? 524288 : 262144))
+               timeout 300 python tools/linear_bench.py --dtype bf16 --m $m --n $n --k 64 --rounds 5 --json $out/linear_bf16_k64.jsonl > $out/linear_bf16_k64_prod_$n.log 2>&1; tail -2 $out/linear_bf16_k64_prod_$n.log
+               timeout 300 python tools/linear_bench.py --dtype bf16 --variant 3 --m $m --n $n --k 64 --rounds 5 --json $out/linear_bf16_k64.jsonl > $out/linear_bf16_k64_pp_$n.log 2>&1; tail -2 $out/linear_bf16_k64_pp_$n.log; done ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
