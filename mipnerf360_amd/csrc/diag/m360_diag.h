@@ -17,6 +17,7 @@ int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, 
                         m360_stream_t stream);
 /* 4 x uint64 per workgroup of the last m360_diag_linear_bf16 launch with variant 20 + ABL (the w32 kernel): cycles, 100 MHz ticks, slabs, epilogue cycles */
 int m360_diag_read_w32_stamps(unsigned long long *out_host, int n);
+int m360_diag_read_w16_stamps(unsigned long long *out_host, int n);
 /* 4 x uint64 per workgroup of the last (ReLU or ablated) m360_diag_linear_hd launch: cycles, 100 MHz ticks, K-steps */
 int m360_diag_read_hd_stamps(unsigned long long *out_host, int n);
 /* m360_linear of THIS (diagnostics) library: 0 = the shape rule, 1 = always the 256 x 256 kernel, 2 = half tiles where they apply */

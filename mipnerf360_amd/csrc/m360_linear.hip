@@ -18,6 +18,7 @@
 #include "m360_linear_persist.hip.h"
 #include "m360_linear_bf16.hip.h"
 #include "m360_linear_bf16_pp.hip.h"
+#include "m360_linear_bf16_w16.hip.h"
 #include "m360_linear_tn.hip.h"
 #ifdef M360_DIAG  // diagnostics build only: stamped twins of the product kernels + the two bf16 structures that lost the A/B
 #include "diag/m360_diag.h"
@@ -711,6 +712,26 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
 #undef M360_W32_ABL
         return check_launch("diag_linear_bf16_w32");
     }
+    if (variant >= 100 && variant <= 200) {  // the one-wave-per-SIMD 16x16x32 ring kernel (m360_linear_bf16_w16.hip.h): 100 + ABL bits stamped,
+                                             // 200 = the product instantiation; `ldw` carries the start stagger (units of 192 cycles per class)
+        if (k_pad % 128 || k_pad < 256 || n_pad > w16::kMaxBias) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant 100 needs k_pad %% 128 == 0, >= 256");
+        dim3 g4((unsigned)(nt < cus ? nt : cus)), b4(w16::kThreads);
+#define M360_W16_ABL(A, S) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, A, S>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, ldw)
+        switch (variant - 100) {
+            case 0: M360_W16_ABL(0, true); break;
+            case 1: M360_W16_ABL(1, true); break;
+            case 2: M360_W16_ABL(2, true); break;
+            case 4: M360_W16_ABL(4, true); break;
+            case 7: M360_W16_ABL(7, true); break;
+            case 16: M360_W16_ABL(16, true); break;
+            case 32: M360_W16_ABL(32, true); break;
+            case 39: M360_W16_ABL(39, true); break;
+            case 100: M360_W16_ABL(0, false); break;
+            default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);
+        }
+#undef M360_W16_ABL
+        return check_launch("diag_linear_bf16_w16");
+    }
     switch (variant) {  // ReLU epilogue throughout
         case 0: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / pp16::BN, (int)nt); break;
         case 1: hipLaunchKernelGGL((sp16::linear_bf16_sp_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / sp16::BN, (int)nt, ldw); break;
@@ -773,6 +794,13 @@ int m360_diag_read_w32_stamps(unsigned long long *out_host, int n) {
     if (!out_host || n < 0 || n > 256 * 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_read_w32_stamps: bad argument");
     if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(w32::g_w32_stamps), sizeof(unsigned long long) * n) != hipSuccess)
         return fail(M360_ERR_LAUNCH, "m360_diag_read_w32_stamps: copy failed");
+    return M360_OK;
+}
+
+int m360_diag_read_w16_stamps(unsigned long long *out_host, int n) {
+    if (!out_host || n < 0 || n > 256 * 4) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_read_w16_stamps: bad argument");
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(w16::g_w16_stamps), sizeof(unsigned long long) * n) != hipSuccess)
+        return fail(M360_ERR_LAUNCH, "m360_diag_read_w16_stamps: copy failed");
     return M360_OK;
 }
 
