@@ -713,10 +713,10 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
         return check_launch("diag_linear_bf16_w32");
     }
     if (variant >= 100 && variant <= 200) {  // the one-wave-per-SIMD 16x16x32 ring kernel (m360_linear_bf16_w16.hip.h): 100 + ABL bits stamped,
-                                             // 200 = the product instantiation; `ldw` carries the start stagger (units of 192 cycles per class)
+                                             // 200 = the product instantiation
         if (k_pad % 128 || k_pad < 256 || n_pad > w16::kMaxBias) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant 100 needs k_pad %% 128 == 0, >= 256");
         dim3 g4((unsigned)(nt < cus ? nt : cus)), b4(w16::kThreads);
-#define M360_W16_ABL(A, S) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, A, S>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, ldw)
+#define M360_W16_ABL(A, S) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, A, S>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt)
         switch (variant - 100) {
             case 0: M360_W16_ABL(0, true); break;
             case 1: M360_W16_ABL(1, true); break;

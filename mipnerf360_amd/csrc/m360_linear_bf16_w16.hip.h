@@ -1,31 +1,37 @@
-// Third bf16 linear kernel (round 3): ONE wave per SIMD, 128 x 128 wave tiles on v_mfma_f32_16x16x32_bf16, 4-slab LDS ring.
+// Third bf16 linear kernel (round 3): ONE wave per SIMD, 128 x 128 wave tiles on v_mfma_f32_16x16x32_bf16, whole-line LDS-DMA.
 //
 // Why: the 8-wave ping-pong kernel (m360_linear_bf16_pp.hip.h) reads 192 KiB of fragments and writes 64 KiB of LDS-DMA per 64-deep
 // K-step and CU - the whole 128 B/clk of the LDS in the 2048 cycles the matrix work takes.  A probe of the bare K-step
 // (tools/wide_wave_probe.hip, profiles/r03/bf16_wide_wave_probe.jsonl, same box) puts that geometry's bound at 1.32-1.34 PF
 // and the bound of FOUR waves with 128 x 128 wave tiles (128 KiB of fragment reads) at 1.57-1.58 PF - with the 16-cycle MFMA:
 // the 32-cycle v_mfma_f32_32x32x16_bf16 of round 2's attempt at this geometry (diag/m360_linear_bf16_w32.hip.h, 0.98-1.03 PF)
-// draws more power per flop (1.46 PF at 1.46 GHz in the same probe).  That attempt lost 24 % of its time in an epilogue whose
-// stores all 256 workgroups issued in the same microseconds, 32 bytes per row and instruction; its skeleton is kept:
-//   * a RING of four 32-deep slabs (32 KiB each: 256 activation + 256 weight rows x 64 B, source-side XOR swizzle), a 1-KiB LDS-DMA
-//     piece issued 2.5-3.5 slabs before its first read, one per 8th MFMA gap, counted vmcnt(16), ONE barrier per slab;
-//   * a GENERATED schedule (tools/gen_w16_slab.py -> m360_linear_bf16_w16_gen.inc): every ds_read_b128 / LDS-DMA piece in its own
-//     MFMA gap, ring positions static (slab offsets are instruction immediates), the counted waits from a simulation of the issue
-//     order;
+// draws more power per flop (1.46 PF at 1.46 GHz in the same probe).  That attempt, and the first form of this kernel, staged
+// 32-deep slabs: an LDS-DMA piece of 16 rows x 64 B is HALF of sixteen 128-byte lines, and such pieces stream at 42 GB/s per CU -
+// exactly the rate both kernels ran at (0.79 ms per 1024^2 layer) - where whole-line pieces reach 65 GB/s with as little as 32 KiB
+// in flight (tools/dma_shape_probe.hip, profiles/r03/dma_piece_shape_probe.jsonl).  Hence:
+//   * a stage is 64 deep (128-byte LDS rows, pieces of 8 rows x 128 B, source-side XOR swizzle), the LDS holds two stages.  65 GB/s
+//     per CU is one piece per ~31 cycles: the 64 pieces of a stage need all of the stage's 2048 matrix cycles, so they are issued
+//     at a UNIFORM rate (4 per wave and half k-step, one per 8th MFMA gap) and every REGION of a buffer (weight rows, activation
+//     rows of blocks 0-3, of blocks 4-7) is refilled as soon as its last reader is done - three barriers per stage, every piece
+//     issued >= 1024 matrix cycles before the barrier that needs it (a first form that filled whole buffers in bursts between one
+//     barrier per stage waited 40 % of its time for the last burst: 1.09 PF);
+//   * a GENERATED schedule (tools/gen_w16_slab.py -> m360_linear_bf16_w16_gen.inc): every ds_read_b128 / LDS-DMA piece / store in
+//     its own MFMA gap, buffer offsets static, the counted waits from a simulation of the issue order;
 //   * operands swapped (MFMA A := weight rows, B := activation rows): D[i][j], lane (j = lane & 15, g4 = lane >> 4) holds rows
-//     i = 4 g4 + r of 16 output columns for ONE activation row.
-// New here:
-//   * a slab is ONE k-step of the 16x16x32 MFMA: 8 x 8 blocks = 64 MFMAs in two halves (activation blocks 0-3 | 4-7); fragment
-//     registers: one set of 8 activation fragments (refilled half by half) + two sets of 8 weight fragments = 96 VGPRs;
+//     i = 4 g4 + r of 16 output columns for ONE activation row;
+//   * a k-step is 8 x 8 blocks = 64 MFMAs in two halves (activation blocks 0-3 | 4-7); fragment registers: one set of 8
+//     activation fragments (refilled half by half) + two sets of 8 weight fragments = 96 VGPRs; the 256 accumulators live in
+//     AccVGPRs (the MFMAs are inline assembly with "+a" operands);
 //   * weight rows permuted so that a lane's accumulators of weight blocks 2p, 2p+1 are 8 CONSECUTIVE output columns and the four
 //     lanes of a row cover 32 consecutive columns: MFMA row i of block jb is column 32 (jb >> 1) + 8 (i >> 2) + 4 (jb & 1) + (i & 3)
 //     of the wave's 128.  Epilogue per (activation block, p): 4 packed bias adds, 4 v_cvt_pk_bf16_f32, ReLU as v_pk_max_i16 on the
-//     packed pairs, ONE 16-byte store - 16 rows x 64 contiguous bytes per instruction, no LDS transposition;
-//   * the last slab of a tile also issues the weight pieces its successor would issue in slab 0, so every piece the next tile
-//     needs through ITS slab 3 is older than the epilogue's 32 stores: the first counted wait that covers the stores comes 3.5
-//     slabs (3.8 k cycles) after the epilogue;
-//   * the workgroups of an XCD start up to `stagger` x 3 x 64 cycles apart (4 classes), so that the chip never sees all 256
-//     epilogues in the same microsecond (32 MiB of stores at once: 6 us at the 5.35 TB/s of a pure store kernel).
+//     packed pairs -> one packed 16-byte row piece; lanes l15 = 2j, 2j + 1 then swap one piece each (v_cndmask_b32_dpp) so that a
+//     store instruction writes 8 rows x 128 B = whole lines (142 GB/s per CU against 38 for 16 rows x 64 B); no LDS transposition;
+//   * the epilogue is exposed (vector work is not hidden behind the same wave's MFMAs): ~3.5 k cycles of conversion per tile with
+//     the 32 stores issued as the pieces are packed.  vmcnt retires in order and a store takes ~2.2 k cycles to complete, so the
+//     first counted wait of the next tile waits for the stores (~5 k cycles per tile together); carrying the packed pieces in
+//     128 VGPRs and storing them during the next tile was built and measured WORSE the thinner the stores were spread (8 per
+//     stage: 600 cycles per k-step of those stages, one per k-step: 670 cycles in every k-step - tools/gen_w16_slab.py).
 // Takes full 256 x 256 tiles of layers with K a multiple of 128 (>= 256), bias + {none, ReLU}; the sigmoid / fused-heads layers
 // stay with the ping-pong kernel (its partner wave hides the transcendental epilogue).
 #pragma once
@@ -42,14 +48,14 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
-constexpr int BM = 256, BN = 256, BKS = 32;  // slab depth
+constexpr int BM = 256, BN = 256, BKS = 64;  // stage depth
 constexpr int kThreads = 256;
-constexpr int kXBytes = 256 * 64;            // activation rows of one slab
-constexpr int kSlabBytes = 2 * kXBytes;      // + weight rows
+constexpr int kXBytes = 256 * 128;           // activation rows of one stage
+constexpr int kStageBytes = 2 * kXBytes;     // + weight rows
 constexpr int kMaxBias = 4096;
 
 #ifdef M360_DIAG
-// diagnostics build, per workgroup: [0] cycles (s_memtime) and [1] 100 MHz ticks of the tile loop, [2] slabs, [3] cycles in epilogues
+// diagnostics build, per workgroup: [0] cycles (s_memtime) and [1] 100 MHz ticks of the tile loop, [2] stages, [3] cycles in epilogues
 __device__ unsigned long long g_w16_stamps[256 * 4];
 #endif
 // ABL (diagnostic builds; results are wrong unless 0): 1 = no barrier, 2 = no LDS-DMA, 4 = no fragment reads, 16 = no stores,
@@ -57,8 +63,8 @@ __device__ unsigned long long g_w16_stamps[256 * 4];
 template <int ACT, int ABL = 0, bool STAMP = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
-    int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, int stagger) {
-    __shared__ __attribute__((aligned(1024))) char smem[4 * kSlabBytes + kMaxBias * 4];  // 144 KiB
+    int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4];  // 144 KiB
     static_assert(ACT == M360_ACT_NONE || ACT == M360_ACT_RELU, "bias + {none, ReLU} only");
 
     const int tid = threadIdx.x;
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int G = gridDim.x;
-    const int nslabs = Kp / BKS;  // a multiple of 4, >= 8
+    const int nstages = Kp / BKS;  // even, >= 4
     const int kbytes = 2 * Kp;
 
     auto tile_coords = [&](int id, long &tm0, int &tn0) __attribute__((always_inline)) {
@@ -80,20 +86,25 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     int tile_id = blockIdx.x;
     if (tile_id >= ntiles) return;
 
-    // ---- LDS-DMA: wave w stages rows [64w, 64w + 64) of both operands, 4 pieces of 16 rows x 64 B each.  LDS slot of chunk c of
-    // row r: c ^ f(r), f = (r >> 2) & 3 for activation rows (a 16-lane read group touches 16 consecutive rows) and (r >> 3) & 3 for
-    // weight rows (a read group touches rows C + 8 a + b): either way 16 distinct 16-byte slots of the 256-byte bank line
-    unsigned x_voff[4], w_voff[4];
+    // ---- LDS-DMA: 8 activation + 8 weight pieces of 8 rows x 128 B per wave and stage.  Weight rows [64w, 64w + 64).  Activation
+    // rows: 32 "lo" rows (blocks 0-3 of a wave tile: pieces 0-3) + 32 "hi" rows (blocks 4-7: pieces 4-7) of wave-tile row
+    // w >> 1, so that the lo and hi REGIONS of a buffer can be refilled at different times.  LDS slot of chunk c of row r:
+    // c ^ f(r), f = (r >> 1) & 7 for activation rows (a 16-lane read group touches 16 consecutive rows) and
+    // 2 ((r >> 3) & 3) + ((r >> 1) & 1) for weight rows (a read group touches rows C + 8 a + b, C even): either way 16 distinct
+    // 16-byte slots of the 256-byte bank line
+    const int xrow0 = (wave >> 1) * 128 + (wave & 1) * 32;  // first lo row of this wave; its hi rows start 64 further
+    unsigned x_voff[8], w_voff[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = 64 * wave + 16 * q + (lane >> 2);
-        x_voff[q] = (unsigned)(r * ldx + 8 * ((lane & 3) ^ ((r >> 2) & 3))) * 2u;
-        w_voff[q] = (unsigned)(r * Kp + 8 * ((lane & 3) ^ ((r >> 3) & 3))) * 2u;
+    for (int q = 0; q < 8; ++q) {
+        const int rx = xrow0 + (q >> 2) * 64 + 8 * (q & 3) + (lane >> 3);
+        const int rw = 64 * wave + 8 * q + (lane >> 3);
+        x_voff[q] = (unsigned)(rx * ldx + 8 * ((lane & 7) ^ ((rx >> 1) & 7))) * 2u;
+        w_voff[q] = (unsigned)(rw * Kp + 8 * ((lane & 7) ^ (2 * ((rw >> 3) & 3) + ((rw >> 1) & 1)))) * 2u;
     }
-    char *const dma_x = smem + 64 * wave * 64;            // + slot * kSlabBytes + q * 1024
-    char *const dma_w = smem + kXBytes + 64 * wave * 64;
-    // two cursors run ahead of the matrix work, across tile boundaries: the activation pieces of slab t + 4 and the weight
-    // pieces of slab t + 3 (scalar state: buffer descriptor of the cursor's tile + byte offset of its slab in a row)
+    char *const dma_x = smem + xrow0 * 128;               // + buffer * kStageBytes + (q & 3) * 1024 + (q >> 2) * 8192
+    char *const dma_w = smem + kXBytes + 64 * wave * 128;
+    // two cursors run ahead of the matrix work, across tile boundaries: the activation pieces of stage s + 1 and the weight
+    // pieces of stage s + 2 (scalar state: buffer descriptor of the cursor's tile + byte offset of its stage in a row)
     __amdgpu_buffer_rsrc_t rsrc_xd, rsrc_wd;
     int kx = 0, kw = 0, tile_xd = tile_id, tile_wd = tile_id;
     {
@@ -131,18 +142,19 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
             }                                                                                                                \
         }                                                                                                                    \
     } while (0)
-#define W16_DMA_X(SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_xd, (lds_ptr_t)(dma_x + (SLOT) * kSlabBytes + (Q) * 1024), 16, x_voff[Q], kx, 0, 0)
-#define W16_DMA_W(SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_wd, (lds_ptr_t)(dma_w + (SLOT) * kSlabBytes + (Q) * 1024), 16, w_voff[Q], kw, 0, 0)
+#define W16_DMA_X(SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_xd, (lds_ptr_t)(dma_x + (SLOT) * kStageBytes + ((Q) & 3) * 1024 + ((Q) >> 2) * 8192), 16, x_voff[Q], kx, 0, 0)
+#define W16_DMA_W(SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_wd, (lds_ptr_t)(dma_w + (SLOT) * kStageBytes + (Q) * 1024), 16, w_voff[Q], kw, 0, 0)
 
-    // ---- fragment reads: lane (l15, g4) reads chunk g4 (k = 8 g4 .. 8 g4 + 7) of its row.  Activation block ib: row 16 ib + l15
+    // ---- fragment reads: lane (l15, g4), k-step kk of a stage: chunk 4 kk + g4 of its row.  Activation block ib: row 16 ib + l15
     // of the wave's 128.  Weight block jb: MFMA row i = l15 is LDS row 32 (jb >> 1) + 8 (i >> 2) + 4 (jb & 1) + (i & 3) - so the
     // accumulators acc[.][2p][0..3], acc[.][2p + 1][0..3] of lane group g4 are output columns 32 p + 8 g4 + 0..7
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-    const int wr0 = 8 * (l15 >> 2) + (l15 & 3);  // weight row of block 0
-    // byte addresses in ring slots 0 / 1 (l) and 2 / 3 (h); odd slots and the blocks are instruction immediates
-    const unsigned xal = lds0 + (wm * 128 + l15) * 64 + ((g4 ^ ((l15 >> 2) & 3)) * 16);
-    const unsigned wal = lds0 + kXBytes + (wn * 128 + wr0) * 64 + ((g4 ^ ((wr0 >> 3) & 3)) * 16);
-    const unsigned xah = xal + 2 * kSlabBytes, wah = wal + 2 * kSlabBytes;
+    const int wr0 = 8 * (l15 >> 2) + (l15 & 3);                 // weight row of block 0
+    const int fxs = (l15 >> 1) & 7, fws = 2 * (l15 >> 2) + ((l15 >> 1) & 1);
+    // byte addresses x/wa<kk><buffer>; the blocks are instruction immediates
+    const unsigned xa00 = lds0 + (wm * 128 + l15) * 128 + (((0 + g4) ^ fxs) * 16), xa10 = lds0 + (wm * 128 + l15) * 128 + (((4 + g4) ^ fxs) * 16);
+    const unsigned wa00 = lds0 + kXBytes + (wn * 128 + wr0) * 128 + (((0 + g4) ^ fws) * 16), wa10 = lds0 + kXBytes + (wn * 128 + wr0) * 128 + (((4 + g4) ^ fws) * 16);
+    const unsigned xa01 = xa00 + kStageBytes, xa11 = xa10 + kStageBytes, wa01 = wa00 + kStageBytes, wa11 = wa10 + kStageBytes;
 
     f32x4 acc[8][8];  // [activation block][weight block]
     bf16x8 fx[8], fw0[8], fw1[8];
@@ -160,58 +172,54 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
 #define W16_MFMA_Z(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(A), "v"(B))
 // the fragments a wait has just covered are in/out operands of it, so no use can be scheduled above it
 #define W16_TIE_HI "+v"(fx[4]), "+v"(fx[5]), "+v"(fx[6]), "+v"(fx[7])
+#define W16_WAIT_HI() asm volatile("s_waitcnt lgkmcnt(0)" : W16_TIE_HI::"memory")
 #define W16_WAIT_NEXT(FW)                                                                                                   \
     asm volatile("s_waitcnt lgkmcnt(0)"                                                                                     \
                  : "+v"(fx[0]), "+v"(fx[1]), "+v"(fx[2]), "+v"(fx[3]), "+v"(FW[0]), "+v"(FW[1]), "+v"(FW[2]), "+v"(FW[3]),  \
                    "+v"(FW[4]), "+v"(FW[5]), "+v"(FW[6]), "+v"(FW[7])::"memory")
-// this wave's pieces of the NEXT slab have landed (N younger operations may stay in flight), every wave's reads of this slab are done
-#define W16_BARRIER(N)                                                                                  \
+// The three barriers of a stage.  E0 (end of k-step 0): every wave has read the weight and lo rows of this stage's buffer for the
+// last time.  M1 (middle of k-step 1): this wave's weight and lo pieces of the NEXT stage have landed, every wave has read the hi rows
+// of this buffer for the last time.  E1 (end of k-step 1): the hi pieces of the next stage have landed.  N younger pieces (NS: pieces
+// + stores of the previous tile, if it exists) may stay in flight - a bare counted wait under the wave-uniform branch: two
+// register-tied variants would meet in a join and cost copies.
+#define W16_VMCNT(N, NS)                                                                                \
     do {                                                                                                \
-        if (!(ABL & 1)) asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)\n\ts_barrier" : W16_TIE_HI : "n"(N) : "memory"); \
-        else asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)" : W16_TIE_HI : "n"(N) : "memory");           \
-    } while (0)
-// the first three slabs after an epilogue: its 32 stores are younger than the pieces waited for (a bare counted wait under the
-// branch: two register-tied variants would meet in a join and cost copies)
-#define W16_BARRIER_E(N, NS)                                                                            \
-    do {                                                                                                \
-        if (have_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");                        \
+        if ((NS) > (N) && have_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");          \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                                   \
+    } while (0)
+#define W16_BAR() do { if (!(ABL & 1)) asm volatile("s_barrier" ::: "memory"); } while (0)
+#define W16_BARRIER_E0() W16_BAR()
+#define W16_BARRIER_M1(N, NS)                                                                           \
+    do {                                                                                                \
+        W16_VMCNT(N, NS);                                                                               \
         if (!(ABL & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : W16_TIE_HI::"memory");       \
         else asm volatile("s_waitcnt lgkmcnt(0)" : W16_TIE_HI::"memory");                               \
     } while (0)
+#define W16_BARRIER_E1(N, NS) do { W16_VMCNT(N, NS); W16_BAR(); } while (0)
 #include "m360_linear_bf16_w16_gen.inc"
+    static_assert(W16_STORE_STAGES == 0, "the tile loop below stores in the epilogue");
 
     // ---- bias -> LDS once (before any LDS-DMA is in flight)
-    float *const bias_lds = reinterpret_cast<float *>(smem + 4 * kSlabBytes);
+    float *const bias_lds = reinterpret_cast<float *>(smem + 2 * kStageBytes);
     for (int i = tid; i < Np; i += kThreads) bias_lds[i] = bias[i];
     __syncthreads();
-    const unsigned bias_addr = lds0 + 4 * kSlabBytes + 4u * (wn * 128 + 8 * g4);  // + 4 * n0 of the tile, + 128 * p
+    const unsigned bias_addr = lds0 + 2 * kStageBytes + 4u * (wn * 128 + 8 * g4);  // + 4 * n0 of the tile, + 128 * p
 
-    // ---- start stagger: class c = (workgroup / 8) & 3 of an XCD waits 3 c x stagger x 64 cycles
-    {
-        const int cls = (blockIdx.x >> 3) & 3;
-        for (int i = 0; i < cls * stagger; ++i) { __builtin_amdgcn_s_sleep(3); }
-    }
-
-    // ---- prologue: slabs 0..3 of the first tile in the order of their first reads
-    W16_DMA_X(0, 0); W16_DMA_X(0, 1); W16_DMA_X(0, 2); W16_DMA_X(0, 3); W16_ADV_X();
-    W16_DMA_W(0, 0); W16_DMA_W(0, 1); W16_DMA_W(0, 2); W16_DMA_W(0, 3); W16_ADV_W();
-    W16_DMA_X(1, 0); W16_DMA_X(1, 1); W16_DMA_X(1, 2); W16_DMA_X(1, 3); W16_ADV_X();
-    W16_DMA_W(1, 0); W16_DMA_W(1, 1); W16_DMA_W(1, 2); W16_DMA_W(1, 3); W16_ADV_W();
-    W16_DMA_X(2, 0); W16_DMA_X(2, 1); W16_DMA_X(2, 2); W16_DMA_X(2, 3); W16_ADV_X();
-    W16_DMA_W(2, 0); W16_DMA_W(2, 1); W16_DMA_W(2, 2); W16_DMA_W(2, 3); W16_ADV_W();
-    W16_DMA_X(3, 0); W16_DMA_X(3, 1); W16_DMA_X(3, 2); W16_DMA_X(3, 3); W16_ADV_X();
-    W16_DMA_W(3, 0); W16_DMA_W(3, 1); W16_DMA_W(3, 2); W16_DMA_W(3, 3); W16_ADV_W();
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");  // slab 0 has landed (this wave's rows)
+    // ---- prologue: stage 0 and the weight half of stage 1 of the first tile (the activation half comes with stage 0's body)
+    W16_DMA_X(0, 0); W16_DMA_X(0, 1); W16_DMA_X(0, 2); W16_DMA_X(0, 3); W16_DMA_X(0, 4); W16_DMA_X(0, 5); W16_DMA_X(0, 6); W16_DMA_X(0, 7); W16_ADV_X();
+    W16_DMA_W(0, 0); W16_DMA_W(0, 1); W16_DMA_W(0, 2); W16_DMA_W(0, 3); W16_DMA_W(0, 4); W16_DMA_W(0, 5); W16_DMA_W(0, 6); W16_DMA_W(0, 7); W16_ADV_W();
+    W16_DMA_W(1, 0); W16_DMA_W(1, 1); W16_DMA_W(1, 2); W16_DMA_W(1, 3); W16_DMA_W(1, 4); W16_DMA_W(1, 5); W16_DMA_W(1, 6); W16_DMA_W(1, 7); W16_ADV_W();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage 0 has landed (this wave's rows)
     __builtin_amdgcn_s_barrier();
     W16_SB();
-    W16_RD(fw0[0], wal, 0); W16_RD(fw0[1], wal, 256); W16_RD(fw0[2], wal, 2048); W16_RD(fw0[3], wal, 2304);
-    W16_RD(fw0[4], wal, 4096); W16_RD(fw0[5], wal, 4352); W16_RD(fw0[6], wal, 6144); W16_RD(fw0[7], wal, 6400);
-    W16_RD(fx[0], xal, 0); W16_RD(fx[1], xal, 1024); W16_RD(fx[2], xal, 2048); W16_RD(fx[3], xal, 3072);
+    W16_RD(fw0[0], wa00, 0); W16_RD(fw0[1], wa00, 512); W16_RD(fw0[2], wa00, 4096); W16_RD(fw0[3], wa00, 4608);
+    W16_RD(fw0[4], wa00, 8192); W16_RD(fw0[5], wa00, 8704); W16_RD(fw0[6], wa00, 12288); W16_RD(fw0[7], wa00, 12800);
+    W16_RD(fx[0], xa00, 0); W16_RD(fx[1], xa00, 2048); W16_RD(fx[2], xa00, 4096); W16_RD(fx[3], xa00, 6144);
     W16_WAIT_NEXT(fw0);
     W16_SB();
 
-    const unsigned y_voff = (unsigned)(l15 * ldy + 8 * g4) * 2u;  // this lane's 16 bytes inside a 16-row x 32-column piece
+    // this lane's 16 bytes inside a 16-row x 64-column piece, first of its two stores (row 2 (l15 >> 1); the second: one row further)
+    const unsigned y_voff = (unsigned)(2 * (l15 >> 1) * ldy + 32 * (l15 & 1) + 8 * g4) * 2u;
     bool have_prev = false;
     long m0;
     int n0;
@@ -220,21 +228,13 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt0), "=s"(rt0)::"memory");
     for (; tile_id < ntiles; tile_id += G) {
         tile_coords(tile_id, m0, n0);
-        W16_SLAB0Z();
-        W16_SLAB1E();
-        W16_SLAB2E();
-        W16_SLAB3();
-        for (int s = 4; s < nslabs - 4; s += 4) {
-            W16_SLAB0();
-            W16_SLAB1();
-            W16_SLAB2();
-            W16_SLAB3();
+        W16_STAGE0Z();
+        W16_STAGE1();
+        for (int s = 2; s < nstages; s += 2) {
+            W16_STAGE0();
+            W16_STAGE1();
         }
-        W16_SLAB0();
-        W16_SLAB1();
-        W16_SLAB2();
-        W16_SLAB3L();
-        // ---- epilogue (exposed; the pieces of the next tile's slabs 0-3 are in flight or landed meanwhile)
+        // ---- epilogue (exposed): conversion + stores, while the pieces of the next tile's first stages are in flight
         if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e0)::"memory");
         // the last MFMAs (inline assembly: the hazard recogniser does not see them) have written their accumulators before anything
         // reads them: the 8 tuples of the last 8 MFMAs are redefined by this statement, every other tuple is >= 128 cycles old
@@ -244,44 +244,70 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         if (!(ABL & 32)) {
             const __bf16 *yt = Y + (m0 + wm * 128) * ldy + n0 + wn * 128;  // wave-uniform corner of the wave tile
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                f32x4 b0, b1;  // bias of the lane's columns 32 p + 8 g4 + 0..7
-                const unsigned ba = bias_addr + 4u * (n0 + 32 * p);
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(b0), "=&v"(b1) : "v"(ba) : "memory");
+            for (int P = 0; P < 2; ++P) {  // column pieces p = 2P, 2P + 1: 64 output columns = one 128-byte line per row
+                f32x4 bb[4];  // bias of the lane's columns 32 p + 8 g4 + 0..7, p = 2P (bb[0], bb[1]) and 2P + 1 (bb[2], bb[3])
+                const unsigned ba = bias_addr + 4u * (n0 + 64 * P);
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\t"
+                             "ds_read_b128 %3, %4 offset:144\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]) : "v"(ba) : "memory");
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    // explicit AccVGPR reads, one (activation block, piece) at a time: left to the register allocator, 150 of the
-                    // 256 accumulators were copied out at the top of the epilogue and an address register was spilled
-                    f32x4 v, w;
-                    asm volatile("v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %1, %9\n\tv_accvgpr_read_b32 %2, %10\n\t"
-                                 "v_accvgpr_read_b32 %3, %11\n\tv_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\t"
-                                 "v_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15"
-                                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
-                                 : "a"(acc[i][2 * p][0]), "a"(acc[i][2 * p][1]), "a"(acc[i][2 * p][2]), "a"(acc[i][2 * p][3]),
-                                   "a"(acc[i][2 * p + 1][0]), "a"(acc[i][2 * p + 1][1]), "a"(acc[i][2 * p + 1][2]), "a"(acc[i][2 * p + 1][3]));
-                    u32x4 o;
-#define W16_PACK(e, a0, a1, bb, be)                                                                            \
+                    u32x4 ab[2];  // packed pieces (row l15 of block i): ab[0] = columns 32 (2P) + 8 g4.., ab[1] = 32 (2P + 1) + 8 g4..
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int p = 2 * P + h;
+                        // explicit AccVGPR reads, one (activation block, piece) at a time: left to the register allocator, 150 of
+                        // the 256 accumulators were copied out at the top of the epilogue and an address register was spilled
+                        f32x4 v, w;
+                        asm volatile("v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %1, %9\n\tv_accvgpr_read_b32 %2, %10\n\t"
+                                     "v_accvgpr_read_b32 %3, %11\n\tv_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\t"
+                                     "v_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15"
+                                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                                     : "a"(acc[i][2 * p][0]), "a"(acc[i][2 * p][1]), "a"(acc[i][2 * p][2]), "a"(acc[i][2 * p][3]),
+                                       "a"(acc[i][2 * p + 1][0]), "a"(acc[i][2 * p + 1][1]), "a"(acc[i][2 * p + 1][2]), "a"(acc[i][2 * p + 1][3]));
+#define W16_PACK(e, a0, a1, bb_, be)                                                                           \
     do {                                                                                                       \
-        f32x2 t_ = {a0 + bb[be], a1 + bb[(be) + 1]};                                                           \
+        f32x2 t_ = {a0 + bb_[be], a1 + bb_[(be) + 1]};                                                         \
         s16x2 p_ = __builtin_bit_cast(s16x2, __builtin_convertvector(t_, bf16x2));                             \
         if (ACT == M360_ACT_RELU) p_ = __builtin_elementwise_max(p_, (s16x2){0, 0});                           \
-        o[e] = __builtin_bit_cast(unsigned, p_);                                                               \
+        ab[h][e] = __builtin_bit_cast(unsigned, p_);                                                           \
     } while (0)
-                    W16_PACK(0, v[0], v[1], b0, 0); W16_PACK(1, v[2], v[3], b0, 2);
-                    W16_PACK(2, w[0], w[1], b1, 0); W16_PACK(3, w[2], w[3], b1, 2);
+                        W16_PACK(0, v[0], v[1], bb[2 * h], 0); W16_PACK(1, v[2], v[3], bb[2 * h], 2);
+                        W16_PACK(2, w[0], w[1], bb[2 * h + 1], 0); W16_PACK(3, w[2], w[3], bb[2 * h + 1], 2);
 #undef W16_PACK
-                    const __bf16 *row = yt + (long)(16 * i) * ldy + 32 * p;
+                    }
+                    // Whole-line stores: a lane holds 2 x 16 bytes of ONE row, four lanes 2 x 64 bytes - a store of that shape
+                    // (16 rows x 64 B per instruction) runs at 38 GB/s per CU, whole lines (8 rows x 128 B) at 142
+                    // (tools/store_rate_probe.hip).  Lanes l15 = 2j, 2j + 1 swap one piece each through DPP: s1 = row 2j
+                    // (even lane: its own first piece, odd lane: the even lane's second piece), s2 = row 2j + 1.
+                    u32x4 s1, s2;
+                    asm volatile("s_nop 1\n\ts_mov_b64 vcc, %16\n\ts_nop 1\n\t"
+                                 "v_cndmask_b32_dpp %0, %12, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_cndmask_b32_dpp %1, %13, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_cndmask_b32_dpp %2, %14, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_cndmask_b32_dpp %3, %15, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "s_mov_b64 vcc, %17\n\ts_nop 1\n\t"  /* (s_not_b64 would write SCC, which the compiler may hold a carry in) */
+                                 "v_cndmask_b32_dpp %4, %8, %12, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_cndmask_b32_dpp %5, %9, %13, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_cndmask_b32_dpp %6, %10, %14, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_cndmask_b32_dpp %7, %11, %15, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                                 : "=&v"(s1[0]), "=&v"(s1[1]), "=&v"(s1[2]), "=&v"(s1[3]), "=&v"(s2[0]), "=&v"(s2[1]), "=&v"(s2[2]), "=&v"(s2[3])
+                                 : "v"(ab[0][0]), "v"(ab[0][1]), "v"(ab[0][2]), "v"(ab[0][3]), "v"(ab[1][0]), "v"(ab[1][1]), "v"(ab[1][2]),
+                                   "v"(ab[1][3]), "s"(0x5555555555555555ull), "s"(0xAAAAAAAAAAAAAAAAull)
+                                 : "vcc");
                     // s_nop: a store of more than 8 bytes still reads its data registers in the cycle after issue, and the next
                     // instruction here (an AccVGPR read, invisible to the hazard recogniser like this store) may write them
-                    if (!(ABL & 16)) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(y_voff), "v"(o), "s"(row) : "memory");
-                    else asm volatile("" ::"v"(o));
+                    const __bf16 *row = yt + (long)(16 * i) * ldy + 64 * P;
+                    if (!(ABL & 16))
+                        asm volatile("global_store_dwordx4 %0, %2, %4\n\tglobal_store_dwordx4 %1, %3, %4\n\ts_nop 1"
+                                     ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(s1), "v"(s2), "s"(row) : "memory");
+                    else asm volatile("" ::"v"(s1), "v"(s2));
                 }
-                W16_SB();  // one column piece at a time: 256 accumulator reads hoisted together would not fit the register file
+                W16_SB();  // one pair of column pieces at a time
             }
         }
-        if (STAMP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e1)::"memory"); te += e1 - e0; nsl += nslabs; }
-        have_prev = !(ABL & 48);
+        if (STAMP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e1)::"memory"); te += e1 - e0; nsl += nstages; }
+        have_prev = !(ABL & 32);
     }
     if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt1), "=s"(rt1)::"memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of this wave may land after the workgroup is gone
@@ -303,8 +329,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
 #undef W16_MFMA_Z
 #undef W16_TIE_HI
 #undef W16_WAIT_NEXT
-#undef W16_BARRIER
-#undef W16_BARRIER_E
+#undef W16_WAIT_HI
+#undef W16_VMCNT
+#undef W16_BAR
+#undef W16_BARRIER_E0
+#undef W16_BARRIER_M1
+#undef W16_BARRIER_E1
 }
 
 }  // namespace w16

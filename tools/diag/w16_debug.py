@@ -27,6 +27,7 @@ diag.m360_diag_linear_bf16.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp, vp, 
 
 def run(variant, extra):
     y = torch.full((a.m, a.n), float("nan"), device=dev, dtype=torch.bfloat16)
+    print(f"variant {variant}: x {x.data_ptr():#x} w {wp.data_ptr():#x} b {bp.data_ptr():#x} y {y.data_ptr():#x} .. {y.data_ptr() + y.numel() * 2:#x}", flush=True)
     rc = diag.m360_diag_linear_bf16(x.data_ptr(), a.m, a.k, wp.data_ptr(), bp.data_ptr(), a.n, a.k, y.data_ptr(), a.n, variant, extra,
                                     torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc

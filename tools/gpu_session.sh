@@ -48,14 +48,14 @@ for s in $steps; do
                timeout 300 python tools/linear_bench.py --dtype bf16 --m $m --n $n --k 64 --rounds 5 --json $out/linear_bf16_k64.jsonl > $out/linear_bf16_k64_prod_$n.log 2>&1; tail -2 $out/linear_bf16_k64_prod_$n.log
                timeout 300 python tools/linear_bench.py --dtype bf16 --variant 3 --m $m --n $n --k 64 --rounds 5 --json $out/linear_bf16_k64.jsonl > $out/linear_bf16_k64_pp_$n.log 2>&1; tail -2 $out/linear_bf16_k64_pp_$n.log; done ;;
     w16)     timeout 300 python tools/linear_bench.py --dtype bf16 --variant 200 --rounds 5 --json $out/linear_bf16_w16.jsonl > $out/linear_bf16_w16_200.log 2>&1; tail -3 $out/linear_bf16_w16_200.log
-             for sg in 0 4 8 16 32; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant 100 --stagger $sg --rounds 5 --json $out/linear_bf16_w16.jsonl > $out/linear_bf16_w16_100_$sg.log 2>&1; tail -2 $out/linear_bf16_w16_100_$sg.log; done
+             timeout 300 python tools/linear_bench.py --dtype bf16 --variant 100 --rounds 5 --json $out/linear_bf16_w16.jsonl > $out/linear_bf16_w16_100.log 2>&1; tail -2 $out/linear_bf16_w16_100.log
              for v in 101 102 104 107 116 132 139; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/linear_bf16_w16.jsonl > $out/linear_bf16_w16_$v.log 2>&1; tail -2 $out/linear_bf16_w16_$v.log; done
              timeout 300 python tools/linear_bench.py --dtype bf16 --variant 3 --rounds 5 --json $out/linear_bf16_w16.jsonl > $out/linear_bf16_pp_same_box.log 2>&1; tail -1 $out/linear_bf16_pp_same_box.log
-             timeout 300 python tools/linear_bench.py --dtype bf16 --variant 200 --m 65536 --n 256 --k 256 --json $out/linear_bf16_w16.jsonl > $out/linear_bf16_w16_small.log 2>&1; tail -2 $out/linear_bf16_w16_small.log
-             timeout 300 python tools/linear_bench.py --dtype bf16 --variant 200 --m 77056 --n 768 --k 384 --json $out/linear_bf16_w16.jsonl > $out/linear_bf16_w16_odd.log 2>&1; tail -2 $out/linear_bf16_w16_odd.log ;;
-    w16dbg)  timeout 300 python tools/diag/w16_debug.py > $out/w16_debug_small.log 2>&1; cat $out/w16_debug_small.log | grep -v amdgpu.ids
-             timeout 300 python tools/diag/w16_debug.py --m 4096 --n 256 --k 256 > $out/w16_debug_tiny.log 2>&1; cat $out/w16_debug_tiny.log | grep -v amdgpu.ids
-             timeout 300 python tools/diag/w16_debug.py --m 77056 --n 768 --k 384 --reps 2 > $out/w16_debug_odd.log 2>&1; cat $out/w16_debug_odd.log | grep -v amdgpu.ids ;;
+             timeout 300 python tools/linear_bench.py --dtype bf16 --variant 200 --m 65536 --n 256 --k 1024 --json $out/linear_bf16_w16.jsonl > $out/linear_bf16_w16_small.log 2>&1; tail -2 $out/linear_bf16_w16_small.log
+             timeout 300 python tools/linear_bench.py --dtype bf16 --variant 200 --m 77056 --n 768 --k 1152 --json $out/linear_bf16_w16.jsonl > $out/linear_bf16_w16_odd.log 2>&1; tail -2 $out/linear_bf16_w16_odd.log ;;
+    w16dbg)  timeout 300 python tools/diag/w16_debug.py --k 1024 > $out/w16_debug_small.log 2>&1; cat $out/w16_debug_small.log | grep -v amdgpu.ids
+             timeout 300 python tools/diag/w16_debug.py --m 4096 --n 256 --k 1024 > $out/w16_debug_tiny.log 2>&1; cat $out/w16_debug_tiny.log | grep -v amdgpu.ids
+             timeout 300 python tools/diag/w16_debug.py --m 77056 --n 768 --k 1152 --reps 2 > $out/w16_debug_odd.log 2>&1; cat $out/w16_debug_odd.log | grep -v amdgpu.ids ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac

@@ -38,7 +38,6 @@ def main():
                     help="bf16 only: time a kernel of the diagnostics library instead of the product one (2 = software-pipelined, "
                          "3 = ping-pong); its stamped twin (variant - 2) serves --clock; the output is checked against fp64")
     ap.add_argument("--ld-pad", type=int, default=0, help="bf16 diag variants: pad the row stride of x / y / w by this many elements")
-    ap.add_argument("--stagger", type=int, default=0, help="bf16 variants 100-200 (one-wave 16x16x32 ring kernel): start stagger, units of 192 cycles per class")
     ap.add_argument("--no-check", action="store_true", help="timing-only ablation variants produce wrong results by design")
     ap.add_argument("--soak-s", type=float, default=2.5)
     ap.add_argument("--json", type=str, default=None, help="append the result as one JSON line to this file")
@@ -74,7 +73,7 @@ def main():
 
             def run():
                 rc = diag.m360_diag_linear_bf16(x.data_ptr(), args.m, args.k + pad, wp.data_ptr(), bp.data_ptr(), args.n, args.k,
-                                                y.data_ptr(), args.n + pad, args.variant, args.stagger if args.variant >= 100 else args.k + pad,
+                                                y.data_ptr(), args.n + pad, args.variant, args.k + pad,
                                                 torch.cuda.current_stream().cuda_stream)
                 assert rc == 0, rc
         else:
@@ -120,12 +119,12 @@ def main():
         reader = diag.m360_diag_read_w32_stamps if args.variant < 100 else diag.m360_diag_read_w16_stamps
         reader.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
         assert reader(stt, 1024) == 0
-        res["stagger"] = args.stagger
         a = np.array(stt[:], dtype=np.float64).reshape(256, 4)
+        unit = 32 if args.variant < 100 else 64   # contraction depth of one counted unit: w32 slabs, w16 stages
         res.update(in_kernel_clock_ghz=round(float(np.median(a[:, 0] / np.maximum(a[:, 1], 1)) * 0.1), 3),
-                   cycles_per_slab=round(float(np.median((a[:, 0] - a[:, 3]) / np.maximum(a[:, 2], 1))), 1),
-                   epilogue_cycles_per_tile=round(float(np.median(a[:, 3] / np.maximum(a[:, 2] / (args.k // 32), 1))), 1))
-        print({k: res[k] for k in ("in_kernel_clock_ghz", "cycles_per_slab", "epilogue_cycles_per_tile")})
+                   cycles_per_32_deep=round(float(np.median((a[:, 0] - a[:, 3]) / np.maximum(a[:, 2], 1))) * 32 / unit, 1),
+                   epilogue_cycles_per_tile=round(float(np.median(a[:, 3] / np.maximum(a[:, 2] / (args.k // unit), 1))), 1))
+        print({k: res[k] for k in ("in_kernel_clock_ghz", "cycles_per_32_deep", "epilogue_cycles_per_tile")})
     if args.clock:
         t_end = time.time() + args.soak_s
         while time.time() < t_end:  # back-to-back product launches: the chip settles at its loaded clock
