@@ -27,11 +27,15 @@
 //     of the wave's 128.  Epilogue per (activation block, p): 4 packed bias adds, 4 v_cvt_pk_bf16_f32, ReLU as v_pk_max_i16 on the
 //     packed pairs -> one packed 16-byte row piece; lanes l15 = 2j, 2j + 1 then swap one piece each (v_cndmask_b32_dpp) so that a
 //     store instruction writes 8 rows x 128 B = whole lines (142 GB/s per CU against 38 for 16 rows x 64 B); no LDS transposition;
-//   * the epilogue is exposed (vector work is not hidden behind the same wave's MFMAs): ~3.5 k cycles of conversion per tile with
-//     the 32 stores issued as the pieces are packed.  vmcnt retires in order and a store takes ~2.2 k cycles to complete, so the
-//     first counted wait of the next tile waits for the stores (~5 k cycles per tile together); carrying the packed pieces in
-//     128 VGPRs and storing them during the next tile was built and measured WORSE the thinner the stores were spread (8 per
-//     stage: 600 cycles per k-step of those stages, one per k-step: 670 cycles in every k-step - tools/gen_w16_slab.py).
+//   * the epilogue is exposed (vector work is not hidden behind the same wave's MFMAs): ~5.5 k cycles of conversion per tile with
+//     the 32 stores issued as the pieces are packed.  vmcnt retires in order and a store takes ~2 k cycles to complete, so a
+//     counted wait for a piece issued after a store cannot complete before that store has: the LAST stage of a tile therefore also
+//     issues the activation pieces of the next tile's stage 1 - everything the next tile's first stage waits for is older than the
+//     stores, which stay in flight behind it.  Carrying the packed pieces in 128 VGPRs and storing them during the next tile was
+//     built and measured WORSE the thinner the stores were spread (8 per stage: 600 cycles per k-step of those stages, one per
+//     k-step: 670 cycles in every k-step - tools/gen_w16_slab.py).  With the stores the K loop still runs 10 % slower than without
+//     (1260 against 1136 cycles per 32 deep); starting the workgroups of an XCD up to 30 k cycles apart, so that the 256 epilogues
+//     do not store in the same microseconds, changes nothing (profiles/r03/bf16_w16_start_stagger_REJECTED.jsonl).
 // Takes full 256 x 256 tiles of layers with K a multiple of 128 (>= 256), bias + {none, ReLU}; the sigmoid / fused-heads layers
 // stay with the ping-pong kernel (its partner wave hides the transcendental epilogue).
 #pragma once
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int G = gridDim.x;
-    const int nstages = Kp / BKS;  // even, >= 4
+    const int nstages = Kp / BKS;  // even, >= 4 (first, generic and last stage of a tile are different bodies)
     const int kbytes = 2 * Kp;
 
     auto tile_coords = [&](int id, long &tm0, int &tn0) __attribute__((always_inline)) {
@@ -197,7 +201,6 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     } while (0)
 #define W16_BARRIER_E1(N, NS) do { W16_VMCNT(N, NS); W16_BAR(); } while (0)
 #include "m360_linear_bf16_w16_gen.inc"
-    static_assert(W16_STORE_STAGES == 0, "the tile loop below stores in the epilogue");
 
     // ---- bias -> LDS once (before any LDS-DMA is in flight)
     float *const bias_lds = reinterpret_cast<float *>(smem + 2 * kStageBytes);
@@ -205,11 +208,13 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     __syncthreads();
     const unsigned bias_addr = lds0 + 2 * kStageBytes + 4u * (wn * 128 + 8 * g4);  // + 4 * n0 of the tile, + 128 * p
 
-    // ---- prologue: stage 0 and the weight half of stage 1 of the first tile (the activation half comes with stage 0's body)
+    // ---- prologue: stages 0 and 1 of the first tile (the first stage of a tile issues no activation pieces: the last stage of its
+    // predecessor has)
     W16_DMA_X(0, 0); W16_DMA_X(0, 1); W16_DMA_X(0, 2); W16_DMA_X(0, 3); W16_DMA_X(0, 4); W16_DMA_X(0, 5); W16_DMA_X(0, 6); W16_DMA_X(0, 7); W16_ADV_X();
     W16_DMA_W(0, 0); W16_DMA_W(0, 1); W16_DMA_W(0, 2); W16_DMA_W(0, 3); W16_DMA_W(0, 4); W16_DMA_W(0, 5); W16_DMA_W(0, 6); W16_DMA_W(0, 7); W16_ADV_W();
     W16_DMA_W(1, 0); W16_DMA_W(1, 1); W16_DMA_W(1, 2); W16_DMA_W(1, 3); W16_DMA_W(1, 4); W16_DMA_W(1, 5); W16_DMA_W(1, 6); W16_DMA_W(1, 7); W16_ADV_W();
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage 0 has landed (this wave's rows)
+    W16_DMA_X(1, 0); W16_DMA_X(1, 1); W16_DMA_X(1, 2); W16_DMA_X(1, 3); W16_DMA_X(1, 4); W16_DMA_X(1, 5); W16_DMA_X(1, 6); W16_DMA_X(1, 7); W16_ADV_X();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage 0 has landed (this wave's rows)
     __builtin_amdgcn_s_barrier();
     W16_SB();
     W16_RD(fw0[0], wa00, 0); W16_RD(fw0[1], wa00, 512); W16_RD(fw0[2], wa00, 4096); W16_RD(fw0[3], wa00, 4608);
@@ -230,10 +235,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         tile_coords(tile_id, m0, n0);
         W16_STAGE0Z();
         W16_STAGE1();
-        for (int s = 2; s < nstages; s += 2) {
+        for (int s = 2; s < nstages - 2; s += 2) {
             W16_STAGE0();
             W16_STAGE1();
         }
+        W16_STAGE0();
+        W16_STAGE1L();
         // ---- epilogue (exposed): conversion + stores, while the pieces of the next tile's first stages are in flight
         if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e0)::"memory");
         // the last MFMAs (inline assembly: the hazard recogniser does not see them) have written their accumulators before anything

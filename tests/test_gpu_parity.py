@@ -741,7 +741,9 @@ def test_unequal_sample_counts_extension(dev, np_, nf):
 @pytest.mark.parametrize("M,n,k,act", [(256 * 5, 256, 64, 1), (256 * 9 + 77, 1024, 1024, 1), (300, 96, 128, 2),
                                         (256 * 40, 768, 256, 0), (1, 64, 64, 2), (256 * 70, 1024, 64, 1),
                                         (256 * 301, 256, 128, 1),      # ping-pong kernel: 2 K-steps, 301 tiles on 256 CUs
-                                        (256 * 130, 512, 192, 2)])     # odd K-step count: buffer parity across tiles
+                                        (256 * 130, 512, 192, 2),      # odd K-step count: buffer parity across tiles
+                                        (256 * 301 + 40, 768, 1152, 1),  # one-wave ring kernel: 18 stages, 903 tiles on 256 CUs + ragged rows
+                                        (256 * 33, 256, 384, 0)])      # ... 6 stages, no activation
 def test_linear_bf16_against_fp64(dev, M, n, k, act):
     """Opt-in bf16 MLP kernel (persistent LDS-DMA path + generic ragged path): bf16 inputs, fp32 accumulation,
     bf16 output.  Reference = exact product of the SAME bf16-rounded operands in fp64, then rounded to bf16:
@@ -1380,13 +1382,14 @@ def test_c_abi_without_python(dev, tmp_path):
 
 
 def test_bf16_pingpong_kernel_race_screen(dev):
-    """The ping-pong bf16 kernel orders LDS-DMA, reads and re-staging by counted vmcnt + barriers only; a misplaced read
-    would show as rare wrong tiles.  Screen: 60 back-to-back launches at the BASELINE layer shape (and a small odd one)
-    must all be bit-identical, and agree with an fp64 product of the same bf16 operands to bf16 rounding (EVERY row of
-    the small shape, a strided row sample of the big one)."""
+    """The bf16 layer kernels (one-wave ring kernel for ReLU layers with K a multiple of 128, ping-pong kernel otherwise) order
+    LDS-DMA, reads and re-staging by counted vmcnt + barriers only; a misplaced read would show as rare wrong tiles.  Screen: 60
+    back-to-back launches at the BASELINE layer shape (ring kernel), a small odd one (ping-pong kernel) and a small one with uneven
+    tile counts (ring kernel) must all be bit-identical, and agree with an fp64 product of the same bf16 operands to bf16 rounding
+    (EVERY row of the small shapes, a strided row sample of the big one)."""
     from mipnerf360_amd import _lib, ops
     gen = torch.Generator(device="cpu").manual_seed(5)
-    for M, n, k in ((4096 * 128, 1024, 1024), (256 * 37, 768, 192)):
+    for M, n, k in ((4096 * 128, 1024, 1024), (256 * 37, 768, 192), (256 * 111, 768, 384)):
         x = (torch.rand(M, k, generator=gen) * 2 - 1).bfloat16().to(dev)
         w = ((torch.rand(n, k, generator=gen) * 2 - 1) * (6.0 / k) ** 0.5).to(dev)
         b = (torch.rand(n, generator=gen) - 0.5).to(dev)

@@ -543,12 +543,13 @@ def test_header_is_plain_c99(tmp_path):
 
 
 def test_generated_kernel_schedules_are_current(tmp_path):
-    """The K-step / slab bodies of the two generated kernels are committed next to their sources; they must be exactly what
+    """The K-step / slab / stage bodies of the generated kernels are committed next to their sources; they must be exactly what
     the generators in tools/ emit (a hand edit of the .inc, or a generator change without regenerating, fails here)."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for tool, rel in (("gen_hd_kstep.py", "mipnerf360_amd/csrc/m360_linear_hd_gen.inc"),
-                      ("gen_w32_slab.py", "mipnerf360_amd/csrc/diag/m360_linear_bf16_w32_gen.inc")):
+                      ("gen_w32_slab.py", "mipnerf360_amd/csrc/diag/m360_linear_bf16_w32_gen.inc"),
+                      ("gen_w16_slab.py", "mipnerf360_amd/csrc/m360_linear_bf16_w16_gen.inc")):
         spec = importlib.util.spec_from_file_location(tool[:-3], os.path.join(root, "tools", tool))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)

@@ -23,54 +23,60 @@ cycles and CU: the 64 pieces of a stage need the whole 2048 matrix cycles of a s
                                        gaps 1,9,17,25    weight pieces 4-7 of stage s+2 -> buffer B
     wait fw0, fx[0..3] | vmcnt: "hi" pieces of stage s+1 have landed | s_barrier E1
 Every piece is issued >= 2 half k-steps (1024 matrix cycles) before the barrier that needs it.  The counted vmcnt of M1 and E1 comes
-from a simulation of the issue order (`simulate()`); the stores of the previous tile (STORES per lane, one per k-step of the first
-STORE_STAGES stages of the next tile) are counted like pieces: those younger than the awaited pieces may stay in flight.
-Macros: W16_STAGE<B>() generic, W16_STAGE0Z() first stage of a tile (accumulators restart from 0 through the C operand); with
-STORE_STAGES > 0 also W16_STAGE<B>[Z]S<n>(): stage n of a tile carrying stores of the previous tile (guarded by `have_prev`).
+from a simulation of the issue order (`simulate()`).  The tile's 32 stores are issued in its (exposed) epilogue; the LAST stage of a
+tile (kind L) also issues the activation pieces of the next tile's stage 1, which its first stage (kind Z) then does not: everything
+stage Z waits for is older than the stores, which may stay in flight (counted like pieces).
+Macros: W16_STAGE0Z() first stage of a tile (accumulators restart from 0 through the C operand), W16_STAGE<B>() generic,
+W16_STAGE1L() last stage of a tile.
 """
 import os
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mipnerf360_amd", "csrc", "m360_linear_bf16_w16_gen.inc")
-STORES = 32             # 16-byte stores per lane and tile (8 activation blocks x 4 column pieces)
-STORE_STAGES = 0        # stages of the NEXT tile that carry the stores of a tile (one per k-step, in its second half, gap 5).
-                        # 0 = all stores in the epilogue, which is what the product does: vmcnt retires in order and a store takes
-                        # ~2.2 k cycles to complete, so a counted wait for a piece issued after a store cannot complete before the
-                        # store has.  Measured per 32 deep (1024 matrix cycles): no stores 1150-1170 cycles; 8 stores per stage over
-                        # 4 stages 1760; 2 per stage over 16 stages 1836 (every k-step waits ~670 cycles for its store); all 32 in
-                        # the epilogue: one wait of ~5 k cycles per tile (= 170 per 32 deep).
+STORES = 32             # 16-byte stores per lane and tile (8 activation blocks x 4 column pieces x 2 rows / 2), all in the epilogue
 
 
-def half_ops(s, r, kk, half):
-    """vector-memory operations of one wave in half `half` of k-step kk of stage s (stage r of its tile), in issue order"""
-    what = {(0, 0): ("XL", s + 1), (0, 1): ("XH", s + 1), (1, 0): ("WA", s + 2), (1, 1): ("WB", s + 2)}[(kk, half)]
-    ops = []
-    for g in range(32):
-        if g % 8 == 1:
-            ops.append(what)
-        if r < STORE_STAGES and half == 1 and g == 5:
-            ops.append(("S", None))
-    return ops
+def dma_plan(kind):
+    """{(kk, half): [(gap, operand, part, stage offset)]}: LDS-DMA pieces of one wave in a stage of the given kind.
+    '' generic; 'L' last stage of a tile: also issues the activation pieces its successor would issue in k-step 0, so that every
+    piece the next tile's FIRST stage waits for is older than the epilogue's stores (vmcnt retires in order and a store takes
+    ~2 k cycles to complete: with the generic schedule the first barrier of every tile waited for the stores, 115 cycles per
+    32 deep on average); 'Z' first stage of a tile: accumulators restart from 0, no activation pieces."""
+    plan = {(0, 0): [], (0, 1): [], (1, 0): [], (1, 1): []}
+    if kind != "Z":
+        plan[(0, 0)] += [(1 + 8 * q, "X", q, 1) for q in range(4)]          # lo rows of stage s + 1
+        plan[(0, 1)] += [(1 + 8 * q, "X", 4 + q, 1) for q in range(4)]      # hi rows
+    plan[(1, 0)] += [(1 + 8 * q, "W", q, 2) for q in range(4)]
+    plan[(1, 1)] += [(1 + 8 * q, "W", 4 + q, 2) for q in range(4)]
+    if kind == "L":
+        plan[(1, 0)] += [(5 + 8 * q, "X", q, 2) for q in range(4)]          # lo rows of stage s + 2 (free since barrier E0)
+        plan[(1, 1)] += [(5 + 8 * q, "X", 4 + q, 2) for q in range(4)]      # hi rows (free since barrier M1)
+    return {k: sorted(v) for k, v in plan.items()}
 
 
-def simulate(nst=24):
-    """-> {(r, 'M1' | 'E1'): (pieces, stores) that may stay outstanding at that barrier of stage r of a tile (steady state)}"""
-    ops, mark = [], {}
+def simulate(nst=8):
+    """-> {(kind, 'M1' | 'E1'): (pieces, stores) that may stay outstanding at that barrier (steady state)}"""
+    ops, mark, kinds = [], {}, {}
     for s in range(3 * nst):
         r = s % nst
+        kind = "Z" if r == 0 else "L" if r == nst - 1 else ""
+        kinds[s] = kind
+        plan = dma_plan(kind)
         for kk in range(2):
             for half in range(2):
-                ops += half_ops(s, r, kk, half)
-                if (kk, half) == (1, 0):
-                    mark[(s, "M1")] = len(ops)
-                if (kk, half) == (1, 1):
-                    mark[(s, "E1")] = len(ops)
+                for _, what, part, off in plan[(kk, half)]:
+                    ops.append((what + ("L" if part < 4 else "H"), s + off))
+                mark[(s, "M1" if half == 0 else "E1")] = len(ops) if kk == 1 else mark.get((s, "M1" if half == 0 else "E1"))
+        if kind == "L":
+            ops += [("S", None)] * STORES
     res = {}
     for s in range(nst, 2 * nst):
-        for bar, needs in (("M1", ("XL", "WA", "WB")), ("E1", ("XH",))):
+        for bar, needs in (("M1", ("XL", "WL", "WH")), ("E1", ("XH",))):
             upto = mark[(s, bar)]
             need = max(i for i, o in enumerate(ops[:upto]) if o[0] in needs and o[1] == s + 1)
             younger = ops[need + 1:upto]
-            res[(s % nst, bar)] = (sum(1 for o in younger if o[0] != "S"), sum(1 for o in younger if o[0] == "S"))
+            key = (kinds[s] if kinds[s] else ("after Z" if kinds[s - 1] == "Z" else ""), bar)
+            val = (sum(1 for o in younger if o[0] != "S"), sum(1 for o in younger if o[0] == "S"))
+            assert res.setdefault(key, val) == val, (key, val, res)
     return res
 
 
@@ -79,11 +85,11 @@ def w_off(jb):
     return 4096 * (jb >> 1) + 512 * (jb & 1)
 
 
-def stage(B, kind, vm, r=None):
-    """r: stage of the tile when it carries stores of the previous tile, else None"""
+def stage(B, kind, vm):
     name = f"W16_STAGE{B}{kind}"
     L = [f"#define {name}() do {{"]
     nb = 1 - B
+    plan = dma_plan(kind)
     for kk in range(2):
         cur, nxt = kk, 1 - kk
         for half in range(2):
@@ -95,38 +101,35 @@ def stage(B, kind, vm, r=None):
                 reads = [f"W16_RD(fw{nxt}[{j}], wa{rk}{rb}, {w_off(j)})" for j in range(8)] + \
                         [f"W16_RD(fx[{i}], xa{rk}{rb}, {i * 2048})" for i in range(4)]
                 read_gaps = {2 * k: k for k in range(12)}
-            if kk == 0:
-                dma = {1 + 8 * q: f"W16_DMA_X({nb}, {4 * half + q})" for q in range(4)}
-            else:
-                dma = {1 + 8 * q: f"W16_DMA_W({B}, {4 * half + q})" for q in range(4)}
-            store_gaps = {5: 2 * r + kk} if (r is not None and half == 1) else {}
+            # stage s + 1 lives in the other buffer, stage s + 2 in this one
+            dma = {g: f"W16_DMA_{what}({nb if off == 1 else B}, {part})" for g, what, part, off in plan[(kk, half)]}
             for m in range(32):
                 ib, jb = 4 * half + m // 8, m % 8
-                z = "_Z" if (kind.startswith("Z") and kk == 0) else ""
+                z = "_Z" if (kind == "Z" and kk == 0) else ""
                 L.append(f"    W16_MFMA{z}(acc[{ib}][{jb}], fw{cur}[{jb}], fx[{ib}]);")
                 if m in read_gaps:
                     L.append(f"    {reads[read_gaps[m]]};")
                 if m in dma:
                     L.append(f"    {dma[m]};")
-                if m in store_gaps:
-                    L.append(f"    W16_STORE({store_gaps[m]});")
                 L.append("    W16_SB();")
+            advx = sum(1 for g, what, part, off in plan[(kk, half)] if what == "X" and part == 7)   # the last hi piece: advance
             if half == 0:
                 if kk == 0:
                     L.append("    W16_WAIT_HI();")
                 else:
-                    p, st = vm[(r if r is not None else STORE_STAGES, "M1")]
+                    p, st = vm[(kind if kind in ("Z", "L") else "", "M1")] if kind != "A" else vm[("after Z", "M1")]
                     L.append(f"    W16_BARRIER_M1({p}, {p + st});")
                 L.append("    W16_SB();")
             else:
-                if kk == 0:
+                for _ in range(advx):
                     L.append("    W16_ADV_X();")
+                if kk == 0:
                     L.append(f"    W16_WAIT_NEXT(fw{nxt});")
                     L.append("    W16_BARRIER_E0();")
                 else:
                     L.append("    W16_ADV_W();")
                     L.append(f"    W16_WAIT_NEXT(fw{nxt});")
-                    p, st = vm[(r if r is not None else STORE_STAGES, "E1")]
+                    p, st = vm[(kind if kind in ("Z", "L") else "", "E1")] if kind != "A" else vm[("after Z", "E1")]
                     L.append(f"    W16_BARRIER_E1({p}, {p + st});")
                 L.append("    W16_SB();")
     L.append("} while (0)")
@@ -135,20 +138,17 @@ def stage(B, kind, vm, r=None):
 
 def main():
     vm = simulate()
-    assert all(vm[(r, b)] == vm[(STORE_STAGES, b)] and vm[(r, b)][1] == 0 for r in range(STORE_STAGES, 24) for b in ("M1", "E1")), vm
-    out = ["// GENERATED by tools/gen_w16_slab.py - do not edit.  Stage bodies of m360_linear_bf16_w16.hip.h.\n",
-           f"#define W16_STORE_STAGES {STORE_STAGES}\n"]
-    for n in range(STORE_STAGES):   # stages 0..15 of a tile: stores of the previous tile ride along
-        out.append(stage(n % 2, ("Z" if n == 0 else "") + f"S{n}", vm, r=n))
-    assert vm[(STORE_STAGES, "M1")][1] == 0 and vm[(STORE_STAGES, "E1")][1] == 0, vm   # no store younger than what that stage awaits
-    if STORE_STAGES == 0:
-        out.append(stage(0, "Z", vm))   # first stage of a tile: accumulators restart from 0
+    # the stage after Z awaits what Z issued (nothing but weights) and what itself issued: same counts as a generic stage
+    assert vm[("after Z", "M1")] == vm[("", "M1")] and vm[("after Z", "E1")] == vm[("", "E1")], vm
+    assert vm[("", "M1")][1] == 0 and vm[("", "E1")][1] == 0 and vm[("L", "M1")][1] == 0 and vm[("L", "E1")][1] == 0, vm
+    out = ["// GENERATED by tools/gen_w16_slab.py - do not edit.  Stage bodies of m360_linear_bf16_w16.hip.h.\n"]
+    out.append(stage(0, "Z", vm))
     out.append(stage(0, "", vm))
     out.append(stage(1, "", vm))
+    out.append(stage(1, "L", vm))
     with open(OUT, "w") as f:
         f.write("\n".join(out))
-    print("wrote", OUT, sum(len(o) for o in out), "bytes; barrier counts (pieces, stores) by stage of a tile:",
-          {k: v for k, v in sorted(vm.items()) if k[0] in (0, 1, STORE_STAGES - 1, STORE_STAGES)})
+    print("wrote", OUT, sum(len(o) for o in out), "bytes; barrier counts (pieces, stores):", vm)
 
 
 if __name__ == "__main__":
