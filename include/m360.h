@@ -173,8 +173,12 @@ int m360_linear_wgrad(const float *dz, int ldz, const float *x, int ldx, long M,
                       float *grad_w, float *grad_b, void *workspace, size_t workspace_bytes,
                       m360_stream_t stream);
 
-/* ---- opt-in bf16 MLP (BASELINE configs[4]): bf16 inputs, fp32 accumulate on v_mfma_f32_32x32x16_bf16.
- * bf16 tensors are passed as raw 16-bit storage (void*).  k_pad multiple of 64, ldx/ldy multiples of 8. */
+/* ---- opt-in bf16 MLP (BASELINE configs[4]): bf16 inputs, fp32 accumulate on v_mfma_f32_16x16x32_bf16.
+ * bf16 tensors are passed as raw 16-bit storage (void*).  k_pad multiple of 64, ldx/ldy multiples of 8.  Which kernel takes the
+ * full 256 x 256 tiles depends on the call's shape alone: bias + {none, ReLU} with k_pad a multiple of 128 -> the one-wave ring
+ * kernel (m360_linear_bf16_w16.hip.h); other contractions >= 128 and sigmoid -> the 8-wave ping-pong kernel; k_pad = 64 -> the
+ * first one-wave kernel; ragged rows / widths -> the generic kernel.  All of them accumulate the same 32-deep MFMA k-steps in the
+ * same order: the result does not depend on the kernel. */
 int m360_pack_linear_bf16(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                           void *w_packed_bf16, float *b_packed, m360_stream_t stream);
 int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_bf16, const float *b_packed,
@@ -184,7 +188,7 @@ int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_b
  * fp32 accumulation (the xl wl term, 2^-16 of the product, is dropped): three bf16 MFMA passes in ONE contraction of
  * length 3K.  Layouts: activations [M, 2 K] = [hi | lo]; packed weights [n_pad, 3 k_pad] = [Wh | Wh | Wl]; the output is
  * written as [M, 2 n_pad] = [hi | lo] again.  Measured against the fp32 path: hidden activations differ by <= 2e-5, rendered
- * colours by <= 2e-5 against the reference's own outputs (fixture G8; the stated fp32 tolerance is 1e-4) at ~2.3x the
+ * colours by <= 2e-5 against the reference's own outputs (fixture G8; the stated fp32 tolerance is 1e-4) at ~2.4x the
  * fp32 rays/s.  Never the default. */
 int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                             void *w_packed3_bf16 /*[n_pad, 3 k_pad]*/, float *b_packed, m360_stream_t stream);
