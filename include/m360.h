@@ -177,8 +177,8 @@ int m360_linear_wgrad(const float *dz, int ldz, const float *x, int ldx, long M,
  * bf16 tensors are passed as raw 16-bit storage (void*).  k_pad multiple of 64, ldx/ldy multiples of 8.  Which kernel takes the
  * full 256 x 256 tiles depends on the call's shape alone: bias + {none, ReLU} with k_pad a multiple of 128 -> the one-wave ring
  * kernel (m360_linear_bf16_w16.hip.h); other contractions >= 128 and sigmoid -> the 8-wave ping-pong kernel; k_pad = 64 -> the
- * first one-wave kernel; ragged rows / widths -> the generic kernel.  All of them accumulate the same 32-deep MFMA k-steps in the
- * same order: the result does not depend on the kernel. */
+ * first one-wave kernel; ragged rows / widths -> the generic kernel.  The ring and the ping-pong kernel accumulate the same
+ * 32-deep MFMA k-steps in the same order (bit-identical results); all kernels accumulate in fp32 and round once to bf16. */
 int m360_pack_linear_bf16(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                           void *w_packed_bf16, float *b_packed, m360_stream_t stream);
 int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_bf16, const float *b_packed,
