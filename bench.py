@@ -258,7 +258,7 @@ def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
         else:
             traffic_note = "profiles/traffic.json was measured on different kernel sources (stale): not reported"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
-    kname = ("linear_bf16_pp_kernel<X3> (bf16x3: 3 MFMA passes per product)" if x3 else "linear_bf16_w16_kernel") if bf16 else "linear_f32_hd_kernel"
+    kname = ("linear_bf16_w16_kernel<X3> (bf16x3: 3 MFMA passes per product)" if x3 else "linear_bf16_w16_kernel") if bf16 else "linear_f32_hd_kernel"
     roofline = {"bound": "mfma", "kernel": f"{kname} (1024x1024 layer, M={S})", "achieved": round(achieved, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),

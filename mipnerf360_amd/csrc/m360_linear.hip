@@ -19,6 +19,9 @@
 #include "m360_linear_bf16.hip.h"
 #include "m360_linear_bf16_pp.hip.h"
 #include "m360_linear_bf16_w16.hip.h"
+#ifndef M360_W16_X3
+#define M360_W16_X3 1  // bf16x3 hidden layers on the one-wave ring kernel (0: all on the ping-pong kernel)
+#endif
 #ifndef M360_W16_MIN_K
 #define M360_W16_MIN_K 256  // narrowest contraction the bf16 hidden layers hand to the one-wave ring kernel
 #endif
@@ -663,6 +666,12 @@ int m360_linear_bf16x3(const void *x, long M, int ldx, const void *w_packed3, co
         if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear_bf16x3: no HIP device");
         const long nt = (M_full / pp16::BM) * (n_pad / pp16::BN);
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
+        // hidden layers (bias + {none, ReLU}) of at least two 64-deep blocks: the one-wave ring kernel (same accumulation order)
+        if (M360_W16_X3 && act != M360_ACT_SIGMOID && k_pad >= 2 * w16::BKS && k_pad % w16::BKS == 0) {
+            dim3 blk(w16::kThreads);
+            if (act == M360_ACT_RELU) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, true>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt);
+            else hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_NONE, 0, false, true>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt);
+        } else
         switch (act) {
             case M360_ACT_NONE: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_NONE, false, M360_X3_MODE>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
             case M360_ACT_RELU: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, false, M360_X3_MODE>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;

@@ -58,13 +58,19 @@ constexpr int kXBytes = 256 * 128;           // activation rows of one stage
 constexpr int kStageBytes = 2 * kXBytes;     // + weight rows
 constexpr int kMaxBias = 4096;
 
+struct cursor_t { __amdgpu_buffer_rsrc_t rsrc; int k; int tile; };  // an LDS-DMA cursor: descriptor of its tile, byte offset in a row
+
 #ifdef M360_DIAG
 // diagnostics build, per workgroup: [0] cycles (s_memtime) and [1] 100 MHz ticks of the tile loop, [2] stages, [3] cycles in epilogues
 __device__ unsigned long long g_w16_stamps[256 * 4];
 #endif
 // ABL (diagnostic builds; results are wrong unless 0): 1 = no barrier, 2 = no LDS-DMA, 4 = no fragment reads, 16 = no stores,
 // 32 = no epilogue at all
-template <int ACT, int ABL = 0, bool STAMP = false>
+// X3 ("bf16x3", m360_linear_bf16_pp.hip.h): activations [hi(K) | lo(K)], weights [Wh | Wh | Wl] (rows of Kp = 3K), output
+// [hi(Np) | lo(Np)]; per 64-deep block three stages xl wh -> xh wh -> xh wl that share an operand with their neighbour
+// (tools/gen_w16_slab.py, second half): 4 operand tiles staged per block instead of 6, the same accumulation order as the ping-pong
+// kernel's X3 = 2.
+template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
@@ -77,8 +83,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g4 = lane >> 4;
     const int G = gridDim.x;
-    const int nstages = Kp / BKS;  // even, >= 4 (first, generic and last stage of a tile are different bodies)
-    const int kbytes = 2 * Kp;
+    const int K1 = X3 ? Kp / 3 : Kp;  // the layer's contraction length
+    const int nstages = K1 / BKS;     // 64-deep blocks per tile.  plain: even, >= 4 (first, generic and last stage of a tile are
+                                      // different bodies); X3: >= 2, three stages each
+    const int kbytes = 2 * K1;
 
     auto tile_coords = [&](int id, long &tm0, int &tn0) __attribute__((always_inline)) {
         const int full = (ntiles / 8) * 8;  // XCD-aware (speed only): ids sharing id % 8 cover a contiguous range of tiles
@@ -107,47 +115,49 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     }
     char *const dma_x = smem + xrow0 * 128;               // + buffer * kStageBytes + (q & 3) * 1024 + (q >> 2) * 8192
     char *const dma_w = smem + kXBytes + 64 * wave * 128;
-    // two cursors run ahead of the matrix work, across tile boundaries: the activation pieces of stage s + 1 and the weight
-    // pieces of stage s + 2 (scalar state: buffer descriptor of the cursor's tile + byte offset of its stage in a row)
-    __amdgpu_buffer_rsrc_t rsrc_xd, rsrc_wd;
-    int kx = 0, kw = 0, tile_xd = tile_id, tile_wd = tile_id;
+    // cursors run ahead of the matrix work, across tile boundaries (scalar state: buffer descriptor of the cursor's tile + byte
+    // offset of its 64-deep block in a row).  plain: cx = activation pieces of stage s + 1, cw = weight pieces of stage s + 2.
+    // X3: cx = Xl, cx2 = Xh, cw = Wh of block b + 1, cw2 = Wl of block b (columns K.., 0.., 0.., 2K.. of their rows).
+    cursor_t cx, cx2, cw, cw2;
     {
         long m0_;
         int n0_;
         tile_coords(tile_id, m0_, n0_);
-        rsrc_xd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(X + m0_ * ldx), 0, 0x7fffffff, 0x00020000);
-        rsrc_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)n0_ * Kp), 0, 0x7fffffff, 0x00020000);
+        cx.rsrc = cx2.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(X + m0_ * ldx), 0, 0x7fffffff, 0x00020000);
+        cw.rsrc = cw2.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)n0_ * Kp), 0, 0x7fffffff, 0x00020000);
+        cx.k = cx2.k = cw.k = cw2.k = 0;
+        cx.tile = cx2.tile = cw.tile = cw2.tile = tile_id;
     }
-#define W16_ADV_X()                                                                                                          \
+#define W16_CUR_ADV(C, IS_X)                                                                                                 \
     do {                                                                                                                     \
-        kx += 2 * BKS;                                                                                                       \
-        if (kx == kbytes) { /* next tile of this workgroup (past the last one: harmlessly the same rows again) */            \
-            kx = 0;                                                                                                          \
-            tile_xd += G;                                                                                                    \
-            if (tile_xd < ntiles) {                                                                                          \
+        C.k += 2 * BKS;                                                                                                      \
+        if (C.k == kbytes) { /* next tile of this workgroup (past the last one: harmlessly the same rows again) */           \
+            C.k = 0;                                                                                                         \
+            C.tile += G;                                                                                                     \
+            if (C.tile < ntiles) {                                                                                           \
                 long m0_;                                                                                                    \
                 int n0_;                                                                                                     \
-                tile_coords(tile_xd, m0_, n0_);                                                                              \
-                rsrc_xd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(X + m0_ * ldx), 0, 0x7fffffff, 0x00020000);  \
+                tile_coords(C.tile, m0_, n0_);                                                                               \
+                C.rsrc = (IS_X) ? __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(X + m0_ * ldx), 0, 0x7fffffff, 0x00020000) \
+                                : __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)n0_ * Kp), 0, 0x7fffffff, 0x00020000); \
             }                                                                                                                \
         }                                                                                                                    \
     } while (0)
-#define W16_ADV_W()                                                                                                          \
-    do {                                                                                                                     \
-        kw += 2 * BKS;                                                                                                       \
-        if (kw == kbytes) {                                                                                                  \
-            kw = 0;                                                                                                          \
-            tile_wd += G;                                                                                                    \
-            if (tile_wd < ntiles) {                                                                                          \
-                long m0_;                                                                                                    \
-                int n0_;                                                                                                     \
-                tile_coords(tile_wd, m0_, n0_);                                                                              \
-                rsrc_wd = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)n0_ * Kp), 0, 0x7fffffff, 0x00020000); \
-            }                                                                                                                \
-        }                                                                                                                    \
-    } while (0)
-#define W16_DMA_X(SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_xd, (lds_ptr_t)(dma_x + (SLOT) * kStageBytes + ((Q) & 3) * 1024 + ((Q) >> 2) * 8192), 16, x_voff[Q], kx, 0, 0)
-#define W16_DMA_W(SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_wd, (lds_ptr_t)(dma_w + (SLOT) * kStageBytes + (Q) * 1024), 16, w_voff[Q], kw, 0, 0)
+#define W16_PIECE_X(C, COL, SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(C.rsrc, (lds_ptr_t)(dma_x + (SLOT) * kStageBytes + ((Q) & 3) * 1024 + ((Q) >> 2) * 8192), 16, x_voff[Q], C.k + (COL), 0, 0)
+#define W16_PIECE_W(C, COL, SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(C.rsrc, (lds_ptr_t)(dma_w + (SLOT) * kStageBytes + (Q) * 1024), 16, w_voff[Q], C.k + (COL), 0, 0)
+#define W16_ADV_X() W16_CUR_ADV(cx, true)
+#define W16_ADV_W() W16_CUR_ADV(cw, false)
+#define W16_DMA_X(SLOT, Q) W16_PIECE_X(cx, 0, SLOT, Q)
+#define W16_DMA_W(SLOT, Q) W16_PIECE_W(cw, 0, SLOT, Q)
+// X3: the four operands live in fixed halves of the LDS: Xl -> activation buffer 0, Xh -> 1, Wh -> weight buffer 0, Wl -> 1
+#define W16X_ADV_XL() W16_CUR_ADV(cx, true)
+#define W16X_ADV_XH() W16_CUR_ADV(cx2, true)
+#define W16X_ADV_WH() W16_CUR_ADV(cw, false)
+#define W16X_ADV_WL() W16_CUR_ADV(cw2, false)
+#define W16X_DMA_XL(Q) W16_PIECE_X(cx, kbytes, 0, Q)
+#define W16X_DMA_XH(Q) W16_PIECE_X(cx2, 0, 1, Q)
+#define W16X_DMA_WH(Q) W16_PIECE_W(cw, 0, 0, Q)
+#define W16X_DMA_WL(Q) W16_PIECE_W(cw2, 2 * kbytes, 1, Q)
 
     // ---- fragment reads: lane (l15, g4), k-step kk of a stage: chunk 4 kk + g4 of its row.  Activation block ib: row 16 ib + l15
     // of the wave's 128.  Weight block jb: MFMA row i = l15 is LDS row 32 (jb >> 1) + 8 (i >> 2) + 4 (jb & 1) + (i & 3) - so the
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
 // register-tied variants would meet in a join and cost copies.
 #define W16_VMCNT(N, NS)                                                                                \
     do {                                                                                                \
-        if ((NS) > (N) && have_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");          \
+        if ((NS) > (N) && have_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS) > 63 ? 63 : (NS)) : "memory"); /* 6-bit counter */ \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                                   \
     } while (0)
 #define W16_BAR() do { if (!(ABL & 1)) asm volatile("s_barrier" ::: "memory"); } while (0)
@@ -201,6 +211,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     } while (0)
 #define W16_BARRIER_E1(N, NS) do { W16_VMCNT(N, NS); W16_BAR(); } while (0)
 #include "m360_linear_bf16_w16_gen.inc"
+#include "m360_linear_bf16_w16x3_gen.inc"
 
     // ---- bias -> LDS once (before any LDS-DMA is in flight)
     float *const bias_lds = reinterpret_cast<float *>(smem + 2 * kStageBytes);
@@ -209,11 +220,20 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const unsigned bias_addr = lds0 + 2 * kStageBytes + 4u * (wn * 128 + 8 * g4);  // + 4 * n0 of the tile, + 128 * p
 
     // ---- prologue: stages 0 and 1 of the first tile (the first stage of a tile issues no activation pieces: the last stage of its
-    // predecessor has)
-    W16_DMA_X(0, 0); W16_DMA_X(0, 1); W16_DMA_X(0, 2); W16_DMA_X(0, 3); W16_DMA_X(0, 4); W16_DMA_X(0, 5); W16_DMA_X(0, 6); W16_DMA_X(0, 7); W16_ADV_X();
-    W16_DMA_W(0, 0); W16_DMA_W(0, 1); W16_DMA_W(0, 2); W16_DMA_W(0, 3); W16_DMA_W(0, 4); W16_DMA_W(0, 5); W16_DMA_W(0, 6); W16_DMA_W(0, 7); W16_ADV_W();
-    W16_DMA_W(1, 0); W16_DMA_W(1, 1); W16_DMA_W(1, 2); W16_DMA_W(1, 3); W16_DMA_W(1, 4); W16_DMA_W(1, 5); W16_DMA_W(1, 6); W16_DMA_W(1, 7); W16_ADV_W();
-    W16_DMA_X(1, 0); W16_DMA_X(1, 1); W16_DMA_X(1, 2); W16_DMA_X(1, 3); W16_DMA_X(1, 4); W16_DMA_X(1, 5); W16_DMA_X(1, 6); W16_DMA_X(1, 7); W16_ADV_X();
+    // predecessor has).  X3: Xl, Wh, Xh, Wl of block 0.
+#define W16_ALL8(M, ...) M(__VA_ARGS__, 0); M(__VA_ARGS__, 1); M(__VA_ARGS__, 2); M(__VA_ARGS__, 3); M(__VA_ARGS__, 4); M(__VA_ARGS__, 5); M(__VA_ARGS__, 6); M(__VA_ARGS__, 7)
+    if (X3) {
+        W16_ALL8(W16_PIECE_X, cx, kbytes, 0); W16X_ADV_XL();
+        W16_ALL8(W16_PIECE_W, cw, 0, 0); W16X_ADV_WH();
+        W16_ALL8(W16_PIECE_X, cx2, 0, 1); W16X_ADV_XH();
+        W16_ALL8(W16_PIECE_W, cw2, 2 * kbytes, 1); W16X_ADV_WL();
+    } else {
+        W16_ALL8(W16_PIECE_X, cx, 0, 0); W16_ADV_X();
+        W16_ALL8(W16_PIECE_W, cw, 0, 0); W16_ADV_W();
+        W16_ALL8(W16_PIECE_W, cw, 0, 1); W16_ADV_W();
+        W16_ALL8(W16_PIECE_X, cx, 0, 1); W16_ADV_X();
+    }
+#undef W16_ALL8
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage 0 has landed (this wave's rows)
     __builtin_amdgcn_s_barrier();
     W16_SB();
@@ -233,14 +253,28 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt0), "=s"(rt0)::"memory");
     for (; tile_id < ntiles; tile_id += G) {
         tile_coords(tile_id, m0, n0);
-        W16_STAGE0Z();
-        W16_STAGE1();
-        for (int s = 2; s < nstages - 2; s += 2) {
-            W16_STAGE0();
+        if (X3) {
+            W16X_T1Z_S0();
+            W16X_T2_S1();
+            W16X_T3();
+            for (int b = 1; b < nstages - 1; ++b) {
+                W16X_T1();
+                W16X_T2();
+                W16X_T3();
+            }
+            W16X_T1();
+            W16X_T2();
+            W16X_T3L();
+        } else {
+            W16_STAGE0Z();
             W16_STAGE1();
+            for (int s = 2; s < nstages - 2; s += 2) {
+                W16_STAGE0();
+                W16_STAGE1();
+            }
+            W16_STAGE0();
+            W16_STAGE1L();
         }
-        W16_STAGE0();
-        W16_STAGE1L();
         // ---- epilogue (exposed): conversion + stores, while the pieces of the next tile's first stages are in flight
         if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e0)::"memory");
         // the last MFMAs (inline assembly: the hazard recogniser does not see them) have written their accumulators before anything
@@ -260,6 +294,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     u32x4 ab[2];  // packed pieces (row l15 of block i): ab[0] = columns 32 (2P) + 8 g4.., ab[1] = 32 (2P + 1) + 8 g4..
+                    u32x4 lo[2];  // X3: their second bf16 terms
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int p = 2 * P + h;
@@ -272,12 +307,19 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                                      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
                                      : "a"(acc[i][2 * p][0]), "a"(acc[i][2 * p][1]), "a"(acc[i][2 * p][2]), "a"(acc[i][2 * p][3]),
                                        "a"(acc[i][2 * p + 1][0]), "a"(acc[i][2 * p + 1][1]), "a"(acc[i][2 * p + 1][2]), "a"(acc[i][2 * p + 1][3]));
+// plain: bias, bf16 conversion, ReLU on the packed pair.  X3: bias, ReLU in fp32, hi = bf16(t), lo = bf16(t - hi)
 #define W16_PACK(e, a0, a1, bb_, be)                                                                           \
     do {                                                                                                       \
         f32x2 t_ = {a0 + bb_[be], a1 + bb_[(be) + 1]};                                                         \
-        s16x2 p_ = __builtin_bit_cast(s16x2, __builtin_convertvector(t_, bf16x2));                             \
-        if (ACT == M360_ACT_RELU) p_ = __builtin_elementwise_max(p_, (s16x2){0, 0});                           \
+        if (X3 && ACT == M360_ACT_RELU) { t_[0] = relu_nanf_(t_[0]); t_[1] = relu_nanf_(t_[1]); }              \
+        const bf16x2 h_ = __builtin_convertvector(t_, bf16x2);                                                 \
+        s16x2 p_ = __builtin_bit_cast(s16x2, h_);                                                              \
+        if (!X3 && ACT == M360_ACT_RELU) p_ = __builtin_elementwise_max(p_, (s16x2){0, 0});                    \
         ab[h][e] = __builtin_bit_cast(unsigned, p_);                                                           \
+        if (X3) {                                                                                              \
+            const f32x2 r_ = {t_[0] - (float)h_[0], t_[1] - (float)h_[1]};                                     \
+            lo[h][e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r_, bf16x2));                      \
+        }                                                                                                      \
     } while (0)
                         W16_PACK(0, v[0], v[1], bb[2 * h], 0); W16_PACK(1, v[2], v[3], bb[2 * h], 2);
                         W16_PACK(2, w[0], w[1], bb[2 * h + 1], 0); W16_PACK(3, w[2], w[3], bb[2 * h + 1], 2);
@@ -287,28 +329,35 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                     // (16 rows x 64 B per instruction) runs at 38 GB/s per CU, whole lines (8 rows x 128 B) at 142
                     // (tools/store_rate_probe.hip).  Lanes l15 = 2j, 2j + 1 swap one piece each through DPP: s1 = row 2j
                     // (even lane: its own first piece, odd lane: the even lane's second piece), s2 = row 2j + 1.
-                    u32x4 s1, s2;
-                    asm volatile("s_nop 1\n\ts_mov_b64 vcc, %16\n\ts_nop 1\n\t"
-                                 "v_cndmask_b32_dpp %0, %12, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_cndmask_b32_dpp %1, %13, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_cndmask_b32_dpp %2, %14, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_cndmask_b32_dpp %3, %15, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                 "s_mov_b64 vcc, %17\n\ts_nop 1\n\t"  /* (s_not_b64 would write SCC, which the compiler may hold a carry in) */
-                                 "v_cndmask_b32_dpp %4, %8, %12, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_cndmask_b32_dpp %5, %9, %13, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_cndmask_b32_dpp %6, %10, %14, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_cndmask_b32_dpp %7, %11, %15, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-                                 : "=&v"(s1[0]), "=&v"(s1[1]), "=&v"(s1[2]), "=&v"(s1[3]), "=&v"(s2[0]), "=&v"(s2[1]), "=&v"(s2[2]), "=&v"(s2[3])
-                                 : "v"(ab[0][0]), "v"(ab[0][1]), "v"(ab[0][2]), "v"(ab[0][3]), "v"(ab[1][0]), "v"(ab[1][1]), "v"(ab[1][2]),
-                                   "v"(ab[1][3]), "s"(0x5555555555555555ull), "s"(0xAAAAAAAAAAAAAAAAull)
-                                 : "vcc");
-                    // s_nop: a store of more than 8 bytes still reads its data registers in the cycle after issue, and the next
-                    // instruction here (an AccVGPR read, invisible to the hazard recogniser like this store) may write them
+                    // s_nop after the stores: a store of more than 8 bytes still reads its data registers in the cycle after
+                    // issue, and the next instruction here (an AccVGPR read, invisible to the hazard recogniser like the
+                    // store) may write them.  (s_not_b64 for the second mask would write SCC, which the compiler may hold a carry in.)
+#define W16_SWAP_STORE(A0, A1, ROW)                                                                                             \
+    do {                                                                                                                        \
+        u32x4 s1, s2;                                                                                                           \
+        asm volatile("s_nop 1\n\ts_mov_b64 vcc, %16\n\ts_nop 1\n\t"                                                           \
+                     "v_cndmask_b32_dpp %0, %12, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
+                     "v_cndmask_b32_dpp %1, %13, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
+                     "v_cndmask_b32_dpp %2, %14, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                   \
+                     "v_cndmask_b32_dpp %3, %15, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                   \
+                     "s_mov_b64 vcc, %17\n\ts_nop 1\n\t"                                                                       \
+                     "v_cndmask_b32_dpp %4, %8, %12, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
+                     "v_cndmask_b32_dpp %5, %9, %13, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
+                     "v_cndmask_b32_dpp %6, %10, %14, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                   \
+                     "v_cndmask_b32_dpp %7, %11, %15, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"                        \
+                     : "=&v"(s1[0]), "=&v"(s1[1]), "=&v"(s1[2]), "=&v"(s1[3]), "=&v"(s2[0]), "=&v"(s2[1]), "=&v"(s2[2]), "=&v"(s2[3]) \
+                     : "v"(A0[0]), "v"(A0[1]), "v"(A0[2]), "v"(A0[3]), "v"(A1[0]), "v"(A1[1]), "v"(A1[2]), "v"(A1[3]),          \
+                       "s"(0x5555555555555555ull), "s"(0xAAAAAAAAAAAAAAAAull)                                                    \
+                     : "vcc");                                                                                                  \
+        if (!(ABL & 16))                                                                                                        \
+            asm volatile("global_store_dwordx4 %0, %2, %4\n\tglobal_store_dwordx4 %1, %3, %4\n\ts_nop 1"                       \
+                         ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(s1), "v"(s2), "s"(ROW) : "memory");                \
+        else asm volatile("" ::"v"(s1), "v"(s2));                                                                               \
+    } while (0)
                     const __bf16 *row = yt + (long)(16 * i) * ldy + 64 * P;
-                    if (!(ABL & 16))
-                        asm volatile("global_store_dwordx4 %0, %2, %4\n\tglobal_store_dwordx4 %1, %3, %4\n\ts_nop 1"
-                                     ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(s1), "v"(s2), "s"(row) : "memory");
-                    else asm volatile("" ::"v"(s1), "v"(s2));
+                    W16_SWAP_STORE(ab[0], ab[1], row);
+                    if (X3) W16_SWAP_STORE(lo[0], lo[1], row + Np);  // the second terms: columns [Np, 2 Np)
+#undef W16_SWAP_STORE
                 }
                 W16_SB();  // one pair of column pieces at a time
             }
@@ -326,10 +375,21 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         g_w16_stamps[blockIdx.x * 4 + 3] = te;
     }
 #endif
+#undef W16_CUR_ADV
+#undef W16_PIECE_X
+#undef W16_PIECE_W
 #undef W16_ADV_X
 #undef W16_ADV_W
 #undef W16_DMA_X
 #undef W16_DMA_W
+#undef W16X_ADV_XL
+#undef W16X_ADV_XH
+#undef W16X_ADV_WH
+#undef W16X_ADV_WL
+#undef W16X_DMA_XL
+#undef W16X_DMA_XH
+#undef W16X_DMA_WH
+#undef W16X_DMA_WL
 #undef W16_RD
 #undef W16_SB
 #undef W16_MFMA

@@ -1127,10 +1127,13 @@ def test_train_step_full_width_vs_oracle(dev):
 
 
 @pytest.mark.parametrize("M,n,k,act", [(1024, 256, 64, 1), (2048, 1024, 1024, 1), (700, 256, 256, 2), (300, 96, 64, 0),
-                                        (256 * 5 + 77, 512, 128, 1)])
+                                        (256 * 5 + 77, 512, 128, 1),
+                                        (256 * 301 + 9, 768, 192, 1),   # ring kernel: 3 blocks per tile, 903 tiles on 256 CUs + ragged rows
+                                        (256 * 20, 256, 320, 0)])       # ... 5 blocks, no activation
 def test_linear_bf16x3_against_fp64(dev, M, n, k, act):
-    """The bf16x3 layer (m360_linear_bf16x3: [hi | lo] bf16 pair rows in and out, W as [Wh | Wh | Wl], one contraction of
-    length 3K on the 8-wave ping-pong kernel; ragged rows / narrow widths on the generic kernel).  Reference = fp64
+    """The bf16x3 layer (m360_linear_bf16x3: [hi | lo] bf16 pair rows in and out, W as [Wh | Wh | Wl]; full tiles of ReLU / plain
+    layers with at least two 64-deep blocks on the one-wave ring kernel, sigmoid and 64-deep layers on the 8-wave ping-pong
+    kernel - both run xl wh, xh wh, xh wl per block; ragged rows / narrow widths on the generic kernel).  Reference = fp64
     product of the values the pairs REPRESENT (x = hi + lo) with the fp32 weights.  Admissible: the dropped xl wl term
     and the 16-bit representation of w (2^-16 relative each) + the 16-bit representation of the output."""
     from mipnerf360_amd import _lib, ops

@@ -547,21 +547,25 @@ def test_generated_kernel_schedules_are_current(tmp_path):
     the generators in tools/ emit (a hand edit of the .inc, or a generator change without regenerating, fails here)."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for tool, rel in (("gen_hd_kstep.py", "mipnerf360_amd/csrc/m360_linear_hd_gen.inc"),
-                      ("gen_w32_slab.py", "mipnerf360_amd/csrc/diag/m360_linear_bf16_w32_gen.inc"),
-                      ("gen_w16_slab.py", "mipnerf360_amd/csrc/m360_linear_bf16_w16_gen.inc")):
+    for tool, outs in (("gen_hd_kstep.py", {"OUT": "mipnerf360_amd/csrc/m360_linear_hd_gen.inc"}),
+                       ("gen_w32_slab.py", {"OUT": "mipnerf360_amd/csrc/diag/m360_linear_bf16_w32_gen.inc"}),
+                       ("gen_w16_slab.py", {"OUT": "mipnerf360_amd/csrc/m360_linear_bf16_w16_gen.inc",
+                                            "OUT_X3": "mipnerf360_amd/csrc/m360_linear_bf16_w16x3_gen.inc"})):
         spec = importlib.util.spec_from_file_location(tool[:-3], os.path.join(root, "tools", tool))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        committed = open(os.path.join(root, rel)).read()
-        mod.OUT = str(tmp_path / os.path.basename(rel))
+        for attr, rel in outs.items():
+            setattr(mod, attr, str(tmp_path / os.path.basename(rel)))
         argv = sys.argv
         sys.argv = [tool]
         try:
             mod.main()
+            if hasattr(mod, "main_x3"):
+                mod.main_x3()
         finally:
             sys.argv = argv
-        assert open(mod.OUT).read() == committed, f"{rel} is stale: run python tools/{tool}"
+        for attr, rel in outs.items():
+            assert open(getattr(mod, attr)).read() == open(os.path.join(root, rel)).read(), f"{rel} is stale: run python tools/{tool}"
 
 
 def test_design_md_numbers_are_generated_from_profiles():

@@ -136,6 +136,143 @@ def stage(B, kind, vm):
     return " \\\n".join(L) + "\n"
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# bf16x3 ("X3"): every value is two bf16 terms, a product is xl wh + xh wh + xh wl.  Per 64-deep block b three stages run, sharing
+# an operand with their neighbour, so the activation and weight halves of the two LDS buffers are switched independently:
+#     T1: Xl_b (XA) x Wh_b (WA)      T2: Xh_b (XB) x Wh_b (WA)      T3: Xh_b (XB) x Wl_b (WB)
+# Four operand tiles per block instead of six; each is staged as soon as its region is free:
+#     T1 issues Wl_b -> WB (k-step 0; not the first block of a tile) and Xl_{b+1} -> XA (k-step 1: lo rows after barrier E0, hi after M1)
+#     T2 issues Wh_{b+1} -> WA (k-step 1, after E0)          T3 issues Xh_{b+1} -> XB (k-step 1: lo after E0, hi after M1)
+#     the last T3 of a tile also issues Wl_0 of the next tile, so that what its first stages wait for is older than the stores
+OUT_X3 = OUT.replace("_w16_gen.inc", "_w16x3_gen.inc")
+STORES_X3 = 64
+X3_TYPES = {
+    "T1": dict(xb=0, wb=0, nxb=1, nwb=0, e1=True,
+               dma={(0, 0): [("WL", q) for q in range(4)], (0, 1): [("WL", 4 + q) for q in range(4)],
+                    (1, 0): [("XL", q) for q in range(4)], (1, 1): [("XL", 4 + q) for q in range(4)]}),
+    "T2": dict(xb=1, wb=0, nxb=1, nwb=1, e1=False,
+               dma={(1, 0): [("WH", q) for q in range(4)], (1, 1): [("WH", 4 + q) for q in range(4)]}),
+    "T3": dict(xb=1, wb=1, nxb=0, nwb=0, e1=True,
+               dma={(1, 0): [("XH", q) for q in range(4)], (1, 1): [("XH", 4 + q) for q in range(4)]}),
+}
+X3_DST = {"XL": 0, "XH": 1, "WH": 0, "WL": 1}   # LDS buffer of each operand
+
+
+def x3_plan(t, variant):
+    """[(kk, half, gap, operand, piece)] of one stage; variant: '' | 'Z' (first T1 of a tile) | 'L' (last T3 of a tile)"""
+    plan = []
+    for (kk, half), lst in X3_TYPES[t]["dma"].items():
+        for i, (op, q) in enumerate(lst):
+            if variant == "Z" and op == "WL":
+                continue
+            plan.append((kk, half, 1 + 8 * i, op, q))
+    if variant == "L":
+        plan += [(1, 0, 5 + 8 * q, "WL", q) for q in range(4)] + [(1, 1, 5 + 8 * q, "WL", 4 + q) for q in range(4)]
+    return sorted(plan)
+
+
+def x3_simulate(nb=4):
+    """-> {(type + variant, 'M1' | 'E1'): (pieces, stores) that may stay outstanding at that barrier (steady state)}"""
+    ops, mark, names = [], {}, {}
+    # which block's operand a stage of block g issues: XL, WH, XH of block g + 1; WL of block g (L: of block g + 1)
+    for g in range(3 * nb):
+        b = g % nb
+        for t in ("T1", "T2", "T3"):
+            variant = "Z" if (t == "T1" and b == 0) else "L" if (t == "T3" and b == nb - 1) else ""
+            names[(g, t)] = t + variant
+            for kk in range(2):
+                for half in range(2):
+                    for (k_, h_, gap, op, q) in x3_plan(t, variant):
+                        if (k_, h_) != (kk, half):
+                            continue
+                        blk = g + 1 if (op != "WL" or (variant == "L" and gap % 8 == 5)) else g
+                        ops.append((op + (".lo" if q < 4 else ".hi"), blk))
+                    if kk == 1:
+                        mark[(g, t, "M1" if half == 0 else "E1")] = len(ops)
+            if variant == "L":
+                ops += [("S", None)] * STORES_X3
+    need = {"T1": {"M1": lambda g: [("XH.lo", g)], "E1": lambda g: [("XH.hi", g)]},
+            "T2": {"M1": lambda g: [("WL.lo", g), ("WL.hi", g)]},
+            "T3": {"M1": lambda g: [("WH.lo", g + 1), ("WH.hi", g + 1), ("XL.lo", g + 1)], "E1": lambda g: [("XL.hi", g + 1)]}}
+    res = {}
+    for g in range(nb, 2 * nb):
+        for t in ("T1", "T2", "T3"):
+            for bar, fn in need[t].items():
+                upto = mark[(g, t, bar)]
+                idx = [i for i, o in enumerate(ops[:upto]) if o in fn(g)]
+                assert idx, (g, t, bar)
+                younger = ops[max(idx) + 1:upto]
+                key = (names[(g, t)] if names[(g, t)] != "T1" or names[(g - 0, "T1")] == "T1" else "T1", bar)
+                val = (sum(1 for o in younger if o[0] != "S"), sum(1 for o in younger if o[0] == "S"))
+                # the stages right after a tile boundary may see the stores: keep them apart from the steady-state ones
+                after = 3 * (g % nb) + ("T1", "T2", "T3").index(t)   # stage index inside the tile
+                key = (key[0] + (f"@{after}" if val[1] else ""), bar)
+                assert res.setdefault(key, val) == val, (key, val, res)
+    return res
+
+
+def x3_stage(t, variant, vm, at=None):
+    """at: stage index inside the tile for the variants that still see the previous tile's stores"""
+    T = X3_TYPES[t]
+    name = f"W16X_{t}{variant}" + (f"_S{at}" if at is not None else "")
+    L = [f"#define {name}() do {{"]
+    plan = x3_plan(t, variant)
+    key = t + variant + (f"@{at}" if at is not None else "")
+    for kk in range(2):
+        cur, nxt = kk, 1 - kk
+        for half in range(2):
+            if half == 0:
+                reads = [f"W16_RD(fx[{i}], xa{kk}{T['xb']}, {i * 2048})" for i in range(4, 8)]
+                read_gaps = {0: 0, 2: 1, 4: 2, 6: 3}
+            else:
+                (rx, rw, rk) = (T["xb"], T["wb"], 1) if kk == 0 else (T["nxb"], T["nwb"], 0)
+                reads = [f"W16_RD(fw{nxt}[{j}], wa{rk}{rw}, {w_off(j)})" for j in range(8)] + \
+                        [f"W16_RD(fx[{i}], xa{rk}{rx}, {i * 2048})" for i in range(4)]
+                read_gaps = {2 * k: k for k in range(12)}
+            dma = {gap: f"W16X_DMA_{op}({q})" for (k_, h_, gap, op, q) in plan if (k_, h_) == (kk, half)}
+            for m in range(32):
+                ib, jb = 4 * half + m // 8, m % 8
+                z = "_Z" if (variant == "Z" and kk == 0) else ""
+                L.append(f"    W16_MFMA{z}(acc[{ib}][{jb}], fw{cur}[{jb}], fx[{ib}]);")
+                if m in read_gaps:
+                    L.append(f"    {reads[read_gaps[m]]};")
+                if m in dma:
+                    L.append(f"    {dma[m]};")
+                L.append("    W16_SB();")
+            for op in sorted({op for (k_, h_, gap, op, q) in plan if (k_, h_) == (kk, half) and q == 7}):
+                L.append(f"    W16X_ADV_{op}();")
+            if half == 0:
+                if kk == 0:
+                    L.append("    W16_WAIT_HI();")
+                else:
+                    p, st = vm[(key, "M1")]
+                    L.append(f"    W16_BARRIER_M1({p}, {p + st});")
+                L.append("    W16_SB();")
+            else:
+                L.append(f"    W16_WAIT_NEXT(fw{nxt});")
+                if kk == 0:
+                    L.append("    W16_BARRIER_E0();")
+                elif T["e1"]:
+                    p, st = vm[(key, "E1")]
+                    L.append(f"    W16_BARRIER_E1({p}, {p + st});")
+                L.append("    W16_SB();")
+    L.append("} while (0)")
+    return " \\\n".join(L) + "\n"
+
+
+def main_x3():
+    vm = x3_simulate()
+    out = ["// GENERATED by tools/gen_w16_slab.py - do not edit.  bf16x3 stage bodies of m360_linear_bf16_w16.hip.h.\n"]
+    keys = sorted({k[0] for k in vm})
+    for k in keys:   # e.g. "T1", "T1Z@0", "T2@1", "T3L"
+        base, _, at = k.partition("@")
+        t, variant = base[:2], base[2:]
+        out.append(x3_stage(t, variant, vm, int(at) if at else None))
+    with open(OUT_X3, "w") as f:
+        f.write("\n".join(out))
+    print("wrote", OUT_X3, sum(len(o) for o in out), "bytes; bodies:", keys, "| barrier counts (pieces, stores):", vm)
+
+
 def main():
     vm = simulate()
     # the stage after Z awaits what Z issued (nothing but weights) and what itself issued: same counts as a generic stage
@@ -153,3 +290,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    main_x3()

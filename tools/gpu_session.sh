@@ -58,6 +58,7 @@ for s in $steps; do
              timeout 300 python tools/diag/w16_debug.py --m 77056 --n 768 --k 1152 --reps 2 > $out/w16_debug_odd.log 2>&1; cat $out/w16_debug_odd.log | grep -v amdgpu.ids ;;
     k256)    for v in 3 200; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --m 524288 --n 256 --k 256 --rounds 5 --json $out/linear_bf16_k256.jsonl > $out/linear_bf16_k256_$v.log 2>&1; tail -1 $out/linear_bf16_k256_$v.log; done ;;
     b16tests) timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "bf16 or c5" > $out/pytest_bf16.log 2>&1; echo "pytest rc=$?" >> $out/pytest_bf16.log; tail -6 $out/pytest_bf16.log ;;
+    x3tests) timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "x3" > $out/pytest_x3.log 2>&1; echo "pytest rc=$?" >> $out/pytest_x3.log; tail -12 $out/pytest_x3.log ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
