@@ -666,11 +666,13 @@ int m360_linear_bf16x3(const void *x, long M, int ldx, const void *w_packed3, co
         if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear_bf16x3: no HIP device");
         const long nt = (M_full / pp16::BM) * (n_pad / pp16::BN);
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
-        // hidden layers (bias + {none, ReLU}) of at least two 64-deep blocks: the one-wave ring kernel (same accumulation order)
-        if (M360_W16_X3 && act != M360_ACT_SIGMOID && k_pad >= 2 * w16::BKS && k_pad % w16::BKS == 0) {
+        // hidden layers (bias + {none, ReLU}): the one-wave ring kernel (same accumulation order)
+        if (M360_W16_X3 && act != M360_ACT_SIGMOID && k_pad % w16::BKS == 0) {
             dim3 blk(w16::kThreads);
-            if (act == M360_ACT_RELU) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, true>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt);
-            else hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_NONE, 0, false, true>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt);
+#define M360_W16X(A, ONE) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<A, 0, false, true, ONE>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt)
+            if (k_pad == w16::BKS) { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, true); else M360_W16X(M360_ACT_NONE, true); }
+            else { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, false); else M360_W16X(M360_ACT_NONE, false); }
+#undef M360_W16X
         } else
         switch (act) {
             case M360_ACT_NONE: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_NONE, false, M360_X3_MODE>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;

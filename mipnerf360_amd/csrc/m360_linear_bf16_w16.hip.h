@@ -70,12 +70,13 @@ __device__ unsigned long long g_w16_stamps[256 * 4];
 // [hi(Np) | lo(Np)]; per 64-deep block three stages xl wh -> xh wh -> xh wl that share an operand with their neighbour
 // (tools/gen_w16_slab.py, second half): 4 operand tiles staged per block instead of 6, the same accumulation order as the ping-pong
 // kernel's X3 = 2.
-template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false>
+template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4];  // 144 KiB
     static_assert(ACT == M360_ACT_NONE || ACT == M360_ACT_RELU, "bias + {none, ReLU} only");
+    static_assert(X3 || !ONE_BLOCK, "one-block tiles: the bf16x3 form only");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const int G = gridDim.x;
     const int K1 = X3 ? Kp / 3 : Kp;  // the layer's contraction length
     const int nstages = K1 / BKS;     // 64-deep blocks per tile.  plain: even, >= 4 (first, generic and last stage of a tile are
-                                      // different bodies); X3: >= 2, three stages each
+                                      // different bodies); X3: >= 2 (ONE_BLOCK: == 1), three stages each
     const int kbytes = 2 * K1;
 
     auto tile_coords = [&](int id, long &tm0, int &tn0) __attribute__((always_inline)) {
@@ -256,15 +257,19 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         if (X3) {
             W16X_T1Z_S0();
             W16X_T2_S1();
-            W16X_T3();
-            for (int b = 1; b < nstages - 1; ++b) {
+            if (ONE_BLOCK) {  // a 64-deep layer: the only block of the tile is its first and its last.  (A template parameter: with
+                W16X_T3L();   // this body behind a run-time branch of the general kernel its 1024^2 layer took 2.42 instead of 2.21 ms)
+            } else {
+                W16X_T3();
+                for (int b = 1; b < nstages - 1; ++b) {
+                    W16X_T1();
+                    W16X_T2();
+                    W16X_T3();
+                }
                 W16X_T1();
                 W16X_T2();
-                W16X_T3();
+                W16X_T3L();
             }
-            W16X_T1();
-            W16X_T2();
-            W16X_T3L();
         } else {
             W16_STAGE0Z();
             W16_STAGE1();

@@ -1129,7 +1129,8 @@ def test_train_step_full_width_vs_oracle(dev):
 @pytest.mark.parametrize("M,n,k,act", [(1024, 256, 64, 1), (2048, 1024, 1024, 1), (700, 256, 256, 2), (300, 96, 64, 0),
                                         (256 * 5 + 77, 512, 128, 1),
                                         (256 * 301 + 9, 768, 192, 1),   # ring kernel: 3 blocks per tile, 903 tiles on 256 CUs + ragged rows
-                                        (256 * 20, 256, 320, 0)])       # ... 5 blocks, no activation
+                                        (256 * 20, 256, 320, 0),        # ... 5 blocks, no activation
+                                        (256 * 300 + 5, 512, 64, 1)])   # ... one block per tile (the first layers), 600 tiles
 def test_linear_bf16x3_against_fp64(dev, M, n, k, act):
     """The bf16x3 layer (m360_linear_bf16x3: [hi | lo] bf16 pair rows in and out, W as [Wh | Wh | Wl]; full tiles of ReLU / plain
     layers with at least two 64-deep blocks on the one-wave ring kernel, sigmoid and 64-deep layers on the 8-wave ping-pong
