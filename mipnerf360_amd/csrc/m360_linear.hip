@@ -19,6 +19,9 @@
 #include "m360_linear_bf16.hip.h"
 #include "m360_linear_bf16_pp.hip.h"
 #include "m360_linear_bf16_w16.hip.h"
+#ifndef M360_W16_K64
+#define M360_W16_K64 1  // 64-deep bf16 first layers on the one-wave ring kernel (0: the first one-wave kernel)
+#endif
 #ifndef M360_W16_X3
 #define M360_W16_X3 1  // bf16x3 hidden layers on the one-wave ring kernel (0: all on the ping-pong kernel)
 #endif
@@ -605,10 +608,13 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
         // hidden layers (bias + {none, ReLU}) with a contraction that is a multiple of 128: the one-wave ring kernel with 128 x 128
         // wave tiles (1.22-1.28 PF against the ping-pong kernel's 1.13 on a 1024^2 layer, 0.114 against 0.144 ms on a 256^2 one)
         const bool w16_ok = pp_ok && act != M360_ACT_SIGMOID && k_pad % (2 * w16::BKS) == 0 && k_pad >= M360_W16_MIN_K;
-        if (w16_ok) {
+        const bool w16_one = M360_W16_K64 && act != M360_ACT_SIGMOID && k_pad == w16::BKS && n_pad <= w16::kMaxBias;  // the 64-deep first layers
+        if (w16_ok || w16_one) {
             dim3 grid((unsigned)(nt < cus ? nt : cus)), block(w16::kThreads);
-            if (act == M360_ACT_RELU) hipLaunchKernelGGL(w16::linear_bf16_w16_kernel<M360_ACT_RELU>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
-            else hipLaunchKernelGGL(w16::linear_bf16_w16_kernel<M360_ACT_NONE>, grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
+#define M360_W16(A, ONE) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<A, 0, false, false, ONE>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt)
+            if (w16_one) { if (act == M360_ACT_RELU) M360_W16(M360_ACT_RELU, true); else M360_W16(M360_ACT_NONE, true); }
+            else { if (act == M360_ACT_RELU) M360_W16(M360_ACT_RELU, false); else M360_W16(M360_ACT_NONE, false); }
+#undef M360_W16
         } else if (pp_ok) {  // 8-wave ping-pong kernel, persistent
             dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
             switch (act) {

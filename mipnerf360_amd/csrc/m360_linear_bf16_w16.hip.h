@@ -36,8 +36,9 @@
 //     k-step: 670 cycles in every k-step - tools/gen_w16_slab.py).  With the stores the K loop still runs 10 % slower than without
 //     (1260 against 1136 cycles per 32 deep); starting the workgroups of an XCD up to 30 k cycles apart, so that the 256 epilogues
 //     do not store in the same microseconds, changes nothing (profiles/r03/bf16_w16_start_stagger_REJECTED.jsonl).
-// Takes full 256 x 256 tiles of layers with K a multiple of 128 (>= 256), bias + {none, ReLU}; the sigmoid / fused-heads layers
-// stay with the ping-pong kernel (its partner wave hides the transcendental epilogue).
+// Takes full 256 x 256 tiles of layers with K a multiple of 128 (>= 256) or K = 64 (ONE_BLOCK: the first layers - all epilogue,
+// 1.07 GB of whole-line stores), bias + {none, ReLU}; the sigmoid / fused-heads layers stay with the ping-pong kernel (its partner
+// wave hides the transcendental epilogue).
 #pragma once
 #include "m360_common.hip.h"
 
@@ -76,7 +77,6 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4];  // 144 KiB
     static_assert(ACT == M360_ACT_NONE || ACT == M360_ACT_RELU, "bias + {none, ReLU} only");
-    static_assert(X3 || !ONE_BLOCK, "one-block tiles: the bf16x3 form only");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const int G = gridDim.x;
     const int K1 = X3 ? Kp / 3 : Kp;  // the layer's contraction length
     const int nstages = K1 / BKS;     // 64-deep blocks per tile.  plain: even, >= 4 (first, generic and last stage of a tile are
-                                      // different bodies); X3: >= 2 (ONE_BLOCK: == 1), three stages each
+                                      // different bodies; ONE_BLOCK: == 1); X3: >= 2 (ONE_BLOCK: == 1), three stages each
     const int kbytes = 2 * K1;
 
     auto tile_coords = [&](int id, long &tm0, int &tn0) __attribute__((always_inline)) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
 
     // this lane's 16 bytes inside a 16-row x 64-column piece, first of its two stores (row 2 (l15 >> 1); the second: one row further)
     const unsigned y_voff = (unsigned)(2 * (l15 >> 1) * ldy + 32 * (l15 & 1) + 8 * g4) * 2u;
-    bool have_prev = false;
+    bool have_prev = false, odd_tile = false;
     long m0;
     int n0;
     unsigned long long mt0 = 0, rt0 = 0, mt1 = 0, rt1 = 0, e0 = 0, e1 = 0, te = 0, nsl = 0;
@@ -270,6 +270,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                 W16X_T2();
                 W16X_T3L();
             }
+        } else if (ONE_BLOCK) {  // a 64-deep layer: one stage per tile, the buffers alternate by tile
+            if (odd_tile) W16_STAGE1ZL();
+            else W16_STAGE0ZL();
+            odd_tile = !odd_tile;
         } else {
             W16_STAGE0Z();
             W16_STAGE1();

@@ -40,14 +40,15 @@ def dma_plan(kind):
     '' generic; 'L' last stage of a tile: also issues the activation pieces its successor would issue in k-step 0, so that every
     piece the next tile's FIRST stage waits for is older than the epilogue's stores (vmcnt retires in order and a store takes
     ~2 k cycles to complete: with the generic schedule the first barrier of every tile waited for the stores, 115 cycles per
-    32 deep on average); 'Z' first stage of a tile: accumulators restart from 0, no activation pieces."""
+    32 deep on average); 'Z' first stage of a tile: accumulators restart from 0, no activation pieces; 'ZL' the only stage of a
+    tile (64-deep layers): both."""
     plan = {(0, 0): [], (0, 1): [], (1, 0): [], (1, 1): []}
-    if kind != "Z":
+    if kind not in ("Z", "ZL"):
         plan[(0, 0)] += [(1 + 8 * q, "X", q, 1) for q in range(4)]          # lo rows of stage s + 1
         plan[(0, 1)] += [(1 + 8 * q, "X", 4 + q, 1) for q in range(4)]      # hi rows
     plan[(1, 0)] += [(1 + 8 * q, "W", q, 2) for q in range(4)]
     plan[(1, 1)] += [(1 + 8 * q, "W", 4 + q, 2) for q in range(4)]
-    if kind == "L":
+    if kind in ("L", "ZL"):
         plan[(1, 0)] += [(5 + 8 * q, "X", q, 2) for q in range(4)]          # lo rows of stage s + 2 (free since barrier E0)
         plan[(1, 1)] += [(5 + 8 * q, "X", 4 + q, 2) for q in range(4)]      # hi rows (free since barrier M1)
     return {k: sorted(v) for k, v in plan.items()}
@@ -56,9 +57,10 @@ def dma_plan(kind):
 def simulate(nst=8):
     """-> {(kind, 'M1' | 'E1'): (pieces, stores) that may stay outstanding at that barrier (steady state)}"""
     ops, mark, kinds = [], {}, {}
-    for s in range(3 * nst):
+    total = max(3 * nst, 8)
+    for s in range(total):
         r = s % nst
-        kind = "Z" if r == 0 else "L" if r == nst - 1 else ""
+        kind = "ZL" if nst == 1 else "Z" if r == 0 else "L" if r == nst - 1 else ""
         kinds[s] = kind
         plan = dma_plan(kind)
         for kk in range(2):
@@ -66,10 +68,10 @@ def simulate(nst=8):
                 for _, what, part, off in plan[(kk, half)]:
                     ops.append((what + ("L" if part < 4 else "H"), s + off))
                 mark[(s, "M1" if half == 0 else "E1")] = len(ops) if kk == 1 else mark.get((s, "M1" if half == 0 else "E1"))
-        if kind == "L":
+        if kind in ("L", "ZL"):
             ops += [("S", None)] * STORES
     res = {}
-    for s in range(nst, 2 * nst):
+    for s in range(max(nst, 3), max(2 * nst, 6)):
         for bar, needs in (("M1", ("XL", "WL", "WH")), ("E1", ("XH",))):
             upto = mark[(s, bar)]
             need = max(i for i, o in enumerate(ops[:upto]) if o[0] in needs and o[1] == s + 1)
@@ -105,7 +107,7 @@ def stage(B, kind, vm):
             dma = {g: f"W16_DMA_{what}({nb if off == 1 else B}, {part})" for g, what, part, off in plan[(kk, half)]}
             for m in range(32):
                 ib, jb = 4 * half + m // 8, m % 8
-                z = "_Z" if (kind == "Z" and kk == 0) else ""
+                z = "_Z" if (kind in ("Z", "ZL") and kk == 0) else ""
                 L.append(f"    W16_MFMA{z}(acc[{ib}][{jb}], fw{cur}[{jb}], fx[{ib}]);")
                 if m in read_gaps:
                     L.append(f"    {reads[read_gaps[m]]};")
@@ -117,7 +119,7 @@ def stage(B, kind, vm):
                 if kk == 0:
                     L.append("    W16_WAIT_HI();")
                 else:
-                    p, st = vm[(kind if kind in ("Z", "L") else "", "M1")] if kind != "A" else vm[("after Z", "M1")]
+                    p, st = vm[(kind if kind in ("Z", "L", "ZL") else "", "M1")]
                     L.append(f"    W16_BARRIER_M1({p}, {p + st});")
                 L.append("    W16_SB();")
             else:
@@ -129,7 +131,7 @@ def stage(B, kind, vm):
                 else:
                     L.append("    W16_ADV_W();")
                     L.append(f"    W16_WAIT_NEXT(fw{nxt});")
-                    p, st = vm[(kind if kind in ("Z", "L") else "", "E1")] if kind != "A" else vm[("after Z", "E1")]
+                    p, st = vm[(kind if kind in ("Z", "L", "ZL") else "", "E1")]
                     L.append(f"    W16_BARRIER_E1({p}, {p + st});")
                 L.append("    W16_SB();")
     L.append("} while (0)")
@@ -283,6 +285,10 @@ def main():
     out.append(stage(0, "", vm))
     out.append(stage(1, "", vm))
     out.append(stage(1, "L", vm))
+    vm1 = simulate(nst=1)   # 64-deep layers: every stage is the first and the last of its tile, the buffers alternate by tile
+    out.append(stage(0, "ZL", vm1))
+    out.append(stage(1, "ZL", vm1))
+    vm.update(vm1)
     with open(OUT, "w") as f:
         f.write("\n".join(out))
     print("wrote", OUT, sum(len(o) for o in out), "bytes; barrier counts (pieces, stores):", vm)
