@@ -175,20 +175,20 @@ int m360_linear_wgrad(const float *dz, int ldz, const float *x, int ldx, long M,
 
 /* ---- opt-in bf16 MLP (BASELINE configs[4]): bf16 inputs, fp32 accumulate on v_mfma_f32_16x16x32_bf16.
  * bf16 tensors are passed as raw 16-bit storage (void*).  k_pad multiple of 64, ldx/ldy multiples of 8.  Which kernel takes the
- * full 256 x 256 tiles depends on the call's shape alone: bias + {none, ReLU} with k_pad a multiple of 128 -> the one-wave ring
- * kernel (m360_linear_bf16_w16.hip.h); other contractions >= 128 and sigmoid -> the 8-wave ping-pong kernel; k_pad = 64 -> the
- * first one-wave kernel; ragged rows / widths -> the generic kernel.  The ring and the ping-pong kernel accumulate the same
- * 32-deep MFMA k-steps in the same order (bit-identical results); all kernels accumulate in fp32 and round once to bf16. */
+ * full 256 x 256 tiles depends on the call's shape alone: bias + {none, ReLU} with k_pad a multiple of 128 (>= 256) or k_pad = 64
+ * -> the one-wave ring kernel (m360_linear_bf16_w16.hip.h); other contractions >= 128 and sigmoid -> the 8-wave ping-pong kernel;
+ * ragged rows / widths -> the generic kernel.  The ring and the ping-pong kernel accumulate the same 32-deep MFMA k-steps in the
+ * same order (bit-identical results); all kernels accumulate in fp32 and round once to bf16. */
 int m360_pack_linear_bf16(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                           void *w_packed_bf16, float *b_packed, m360_stream_t stream);
 int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_bf16, const float *b_packed,
                      int n_pad, int k_pad, int act, void *y_bf16, int ldy, m360_stream_t stream);
 /* ---- opt-in "bf16x3" MLP: near-fp32 accuracy on the bf16 matrix pipe.  Every activation and weight is carried as TWO bf16
  * terms (hi = bf16(v), lo = bf16(v - hi): 16 significant bits) and a product x w is formed as xh wh + xl wh + xh wl with
- * fp32 accumulation (the xl wl term, 2^-16 of the product, is dropped): three bf16 MFMA passes in ONE contraction of
- * length 3K.  Layouts: activations [M, 2 K] = [hi | lo]; packed weights [n_pad, 3 k_pad] = [Wh | Wh | Wl]; the output is
+ * fp32 accumulation (the xl wl term, 2^-16 of the product, is dropped): three bf16 MFMA passes per 64-deep block, in the order
+ * xl wh, xh wh, xh wl (bias + {none, ReLU} layers on the one-wave ring kernel, sigmoid layers on the ping-pong kernel).  Layouts: activations [M, 2 K] = [hi | lo]; packed weights [n_pad, 3 k_pad] = [Wh | Wh | Wl]; the output is
  * written as [M, 2 n_pad] = [hi | lo] again.  Measured against the fp32 path: hidden activations differ by <= 2e-5, rendered
- * colours by <= 2e-5 against the reference's own outputs (fixture G8; the stated fp32 tolerance is 1e-4) at ~2.4x the
+ * colours by <= 2e-5 against the reference's own outputs (fixture G8; the stated fp32 tolerance is 1e-4) at ~3x the
  * fp32 rays/s.  Never the default. */
 int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                             void *w_packed3_bf16 /*[n_pad, 3 k_pad]*/, float *b_packed, m360_stream_t stream);

@@ -489,7 +489,7 @@ class mipNeRF360(nn.Module):
         `mlp_dtype`: "fp32" (default: exact-fp32 MFMA, the parity path), "bf16" (BASELINE configs[4]: bf16
         weights / features / hidden activations, fp32 accumulation, heads and ray math in fp32) or "bf16x3" (every
         value carried as two bf16 terms, products formed as xh wh + xl wh + xh wl on the bf16 MFMA with fp32
-        accumulation: within the fp32 render tolerance of 1e-4 at about 2.4x the fp32 rays/s; forward only)."""
+        accumulation: within the fp32 render tolerance of 1e-4 at about 3x the fp32 rays/s; forward only)."""
         super().__init__()
         self.randomized = randomized
         self.num_samples = num_samples
