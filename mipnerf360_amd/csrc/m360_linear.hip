@@ -19,6 +19,9 @@
 #include "m360_linear_bf16.hip.h"
 #include "m360_linear_bf16_pp.hip.h"
 #include "m360_linear_bf16_w16.hip.h"
+#ifndef M360_W16_HEADS_ON
+#define M360_W16_HEADS_ON 1  // fused-heads last layers of the rendering forward on the one-wave ring kernel (0: ping-pong kernel)
+#endif
 #ifndef M360_W16_K64
 #define M360_W16_K64 1  // 64-deep bf16 first layers on the one-wave ring kernel (0: the first one-wave kernel)
 #endif
@@ -475,7 +478,14 @@ static int linear_heads_bf16_any(const void *x, long M, int ldx, const void *w_p
         __bf16 *yb = static_cast<__bf16 *>(y);
         const int kk = x3 ? 3 * k_pad : k_pad, tn = n_pad / pp16::BN;
 #define M360_PP_HEADS(X3M, H, SY) hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_SIGMOID, false, X3M, H, SY>), grid, block, 0, st, xb, M_fused, ldx, wb, b_packed, n_pad, kk, yb, ldy, tn, (int)nt, head_w, head_part)
-        if (x3) {
+#define M360_W16_HEADS(X3B, H) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 0, false, X3B, false, H>), grid, dim3(w16::kThreads), 0, st, xb, M_fused, ldx, wb, b_packed, n_pad, kk, yb, ldy, tn, (int)nt, head_w, head_part)
+        // the rendering forward (the layer's own output is not kept): the one-wave ring kernel - its exposed sigmoid epilogue costs
+        // less than its K loop wins (0.85 against 1.08-1.12 ms for the 1024^2 NeRF layer)
+        const bool ring = M360_W16_HEADS_ON && !store_y && (x3 ? (k_pad % w16::BKS == 0 && k_pad >= 2 * w16::BKS) : (k_pad % (2 * w16::BKS) == 0 && k_pad >= 4 * w16::BKS));
+        if (ring) {
+            if (x3) { if (heads == 1) M360_W16_HEADS(true, 1); else M360_W16_HEADS(true, 4); }
+            else { if (heads == 1) M360_W16_HEADS(false, 1); else M360_W16_HEADS(false, 4); }
+        } else if (x3) {
             if (heads == 1) { if (store_y) M360_PP_HEADS(M360_X3_MODE, 1, true); else M360_PP_HEADS(M360_X3_MODE, 1, false); }
             else { if (store_y) M360_PP_HEADS(M360_X3_MODE, 4, true); else M360_PP_HEADS(M360_X3_MODE, 4, false); }
         } else {
@@ -483,6 +493,7 @@ static int linear_heads_bf16_any(const void *x, long M, int ldx, const void *w_p
             else { if (store_y) M360_PP_HEADS(0, 4, true); else M360_PP_HEADS(0, 4, false); }
         }
 #undef M360_PP_HEADS
+#undef M360_W16_HEADS
         const int rc = check_launch(who);
         if (rc != M360_OK) return rc;
     }
@@ -754,6 +765,7 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
             case 32: M360_W16_ABL(32, true); break;
             case 39: M360_W16_ABL(39, true); break;
             case 100: M360_W16_ABL(0, false); break;
+            case 50: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 16, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // sigmoid epilogue, no stores: what would a last layer cost here?
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);
         }
 #undef M360_W16_ABL

@@ -71,12 +71,25 @@ __device__ unsigned long long g_w16_stamps[256 * 4];
 // [hi(Np) | lo(Np)]; per 64-deep block three stages xl wh -> xh wh -> xh wl that share an operand with their neighbour
 // (tools/gen_w16_slab.py, second half): 4 operand tiles staged per block instead of 6, the same accumulation order as the ping-pong
 // kernel's X3 = 2.
-template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false>
+// HEADS > 0 (the last hidden layer of a stage, sigmoid, as in the ping-pong kernel): the output heads' dot products are formed on
+// the matrix pipe from the packed bf16 pieces the epilogue holds - a lane's 8 consecutive output columns of one row ARE a B fragment
+// of v_mfma_f32_16x16x32_bf16, the head rows (as hi / lo bf16 terms, from 16 KiB of LDS) the A fragment: D[head][row], lanes 0-15
+// hold the heads of their row over the piece's 32 columns.  One partial sum per row and 32-column piece goes to
+// head_part[row][(Np / 256) * 8][HEADS] (slot = 4 wn + p: the ping-pong kernel's layout); the layer's own output is NOT written
+// (the rendering forward; the tape-keeping one stays on the ping-pong kernel).  The sigmoid is exposed here (11.5 k cycles of epilogue
+// per tile instead of 5.4 k), and still the layer takes 0.85 ms against 1.08-1.12 ms (tools/linear_bench.py --variant 150).
+constexpr int kHeadMaxN = 1024;  // widest layer the fused heads take (their hi / lo rows live in 16 KiB of LDS)
+template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
-    int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4];  // 144 KiB
-    static_assert(ACT == M360_ACT_NONE || ACT == M360_ACT_RELU, "bias + {none, ReLU} only");
+    int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, const float *__restrict__ head_w = nullptr,
+    float *__restrict__ head_part = nullptr) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0)];  // 144 (160) KiB
+    static_assert(HEADS == 0 || HEADS == 1 || HEADS == 4, "1 (proposal) or 4 (NeRF) heads");
+    constexpr bool STORE_Y = HEADS == 0;
+    // vector-memory operations of a tile's epilogue: 32 whole-line stores (64 as [hi | lo]) or, with fused heads, 32 partial-sum stores
+    constexpr int W16_STORES = STORE_Y ? (X3 ? 64 : 32) : 32;
+    static_assert(ACT == M360_ACT_NONE || ACT == M360_ACT_RELU || (ACT == M360_ACT_SIGMOID && (ABL != 0 || HEADS > 0)), "bias + {none, ReLU}; sigmoid with fused heads");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -217,7 +230,21 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     // ---- bias -> LDS once (before any LDS-DMA is in flight)
     float *const bias_lds = reinterpret_cast<float *>(smem + 2 * kStageBytes);
     for (int i = tid; i < Np; i += kThreads) bias_lds[i] = bias[i];
+    // head rows as two bf16 terms: hfrag[0][h][n] = bf16(w), hfrag[1][h][n] = bf16(w - hi) (HEADS x Np <= 4 x 1024 values each)
+    __bf16 *const hfrag = reinterpret_cast<__bf16 *>(smem + 2 * kStageBytes + kMaxBias * 4);
+    if (HEADS) {
+        for (int i = tid; i < HEADS * Np; i += kThreads) {
+            const float w_ = head_w[i];
+            const __bf16 hi_ = (__bf16)w_;
+            hfrag[i] = hi_;
+            hfrag[HEADS * Np + i] = bf16_lo_(w_, hi_);
+        }
+    }
     __syncthreads();
+    // this lane's head row for MFMA A-fragment row l15 (rows >= HEADS repeat the last head: their D rows are never stored)
+    const unsigned hfrag_addr = lds0 + 2 * kStageBytes + kMaxBias * 4 + 2u * (unsigned)((l15 < HEADS ? l15 : (HEADS ? HEADS - 1 : 0)) * Np + wn * 128 + 8 * g4);
+    const unsigned hlo_off = 2u * (unsigned)(HEADS * Np);
+    const int hstride = HEADS ? (Np / BN) * 8 * HEADS : 0;  // floats per row of head_part: [(Np / 256) * 8 slots][HEADS]
     const unsigned bias_addr = lds0 + 2 * kStageBytes + 4u * (wn * 128 + 8 * g4);  // + 4 * n0 of the tile, + 128 * p
 
     // ---- prologue: stages 0 and 1 of the first tile (the first stage of a tile issues no activation pieces: the last stage of its
@@ -300,6 +327,13 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                 asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\t"
                              "ds_read_b128 %3, %4 offset:144\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]) : "v"(ba) : "memory");
+                bf16x8 hh[2], hl[2];  // this lane's head row (hi and lo terms) over the 8 columns of pieces 2P, 2P + 1
+                if (HEADS) {
+                    const unsigned ha = hfrag_addr + 2u * (unsigned)(n0 + 64 * P);
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:64\n\tds_read_b128 %2, %5\n\t"
+                                 "ds_read_b128 %3, %5 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(hh[0]), "=&v"(hh[1]), "=&v"(hl[0]), "=&v"(hl[1]) : "v"(ha), "v"(ha + hlo_off) : "memory");
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     u32x4 ab[2];  // packed pieces (row l15 of block i): ab[0] = columns 32 (2P) + 8 g4.., ab[1] = 32 (2P + 1) + 8 g4..
@@ -321,6 +355,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     do {                                                                                                       \
         f32x2 t_ = {a0 + bb_[be], a1 + bb_[(be) + 1]};                                                         \
         if (X3 && ACT == M360_ACT_RELU) { t_[0] = relu_nanf_(t_[0]); t_[1] = relu_nanf_(t_[1]); }              \
+        if (ACT == M360_ACT_SIGMOID) {                                                                         \
+            t_[0] = __builtin_amdgcn_rcpf(1.0f + __expf(-t_[0]));                                              \
+            t_[1] = __builtin_amdgcn_rcpf(1.0f + __expf(-t_[1]));                                              \
+        }                                                                                                      \
         const bf16x2 h_ = __builtin_convertvector(t_, bf16x2);                                                 \
         s16x2 p_ = __builtin_bit_cast(s16x2, h_);                                                              \
         if (!X3 && ACT == M360_ACT_RELU) p_ = __builtin_elementwise_max(p_, (s16x2){0, 0});                    \
@@ -363,10 +401,25 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                          ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(s1), "v"(s2), "s"(ROW) : "memory");                \
         else asm volatile("" ::"v"(s1), "v"(s2));                                                                               \
     } while (0)
-                    const __bf16 *row = yt + (long)(16 * i) * ldy + 64 * P;
-                    W16_SWAP_STORE(ab[0], ab[1], row);
-                    if (X3) W16_SWAP_STORE(lo[0], lo[1], row + Np);  // the second terms: columns [Np, 2 Np)
+                    if (STORE_Y) {
+                        const __bf16 *row = yt + (long)(16 * i) * ldy + 64 * P;
+                        W16_SWAP_STORE(ab[0], ab[1], row);
+                        if (X3) W16_SWAP_STORE(lo[0], lo[1], row + Np);  // the second terms: columns [Np, 2 Np)
+                    }
 #undef W16_SWAP_STORE
+                    if (HEADS) {  // D[head][row] over each piece's 32 columns: hi and lo head terms (X3: and the lo activations)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x4 hq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[h], __builtin_bit_cast(bf16x8, ab[h]), (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                            hq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[h], __builtin_bit_cast(bf16x8, ab[h]), hq, 0, 0, 0);
+                            if (X3) hq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[h], __builtin_bit_cast(bf16x8, lo[h]), hq, 0, 0, 0);
+                            if (g4 == 0 && !(ABL & 16)) {
+                                float *hp = head_part + (m0 + wm * 128 + 16 * i + l15) * hstride + ((n0 / BN) * 8 + wn * 4 + 2 * P + h) * HEADS;
+                                if (HEADS == 4) *reinterpret_cast<f32x4 *>(hp) = hq;
+                                else *hp = hq[0];
+                            }
+                        }
+                    }
                 }
                 W16_SB();  // one pair of column pieces at a time
             }

@@ -1413,7 +1413,7 @@ def test_bf16_pingpong_kernel_race_screen(dev):
 @pytest.mark.parametrize("M,n,k,heads", [(1024, 1024, 1024, 4), (512 + 37, 256, 256, 1), (2048, 512, 128, 4)])
 def test_bf16_last_layer_heads_on_the_matrix_pipe(dev, M, n, k, heads, x3):
     """m360_linear_heads_bf16 / _bf16x3: the heads' dot products come out of the layer's own epilogue (MFMAs on the packed
-    bf16 row segments x the head rows as two bf16 terms), one partial per row, wave column group and 8-column half.  Summed
+    bf16 row segments x the head rows as two bf16 terms), one partial per row and 32-column piece.  Summed
     over the slots they must equal the product of the layer's STORED activations with the fp32 head rows (to the 16 bits
     the head rows are carried in); with store_y = 0 the fused rows of y stay untouched; tail rows go through y."""
     from mipnerf360_amd import _lib, ops
@@ -1437,8 +1437,13 @@ def test_bf16_last_layer_heads_on_the_matrix_pipe(dev, M, n, k, heads, x3):
     want = y_ref[:fused].double() @ hw.double().T                      # [fused, heads]
     got = part.double().sum(1)
     assert float((got - want).abs().max()) <= 3e-5 * max(float(want.abs().max()), 1.0)
+    # store_y = 0 (the rendering forward): layers with a contraction of >= 256 (bf16x3: >= 128) run on the one-wave ring kernel,
+    # whose 8 slots per 256 columns are contiguous 32-column pieces (the ping-pong kernel's: 8 of every 16 columns of a 64-column
+    # group) - only the sum over the slots is comparable
     y2, part2, _ = ops.linear_heads_bf16(xs, wp, bp, hw, store_y=False, x3=x3)
-    assert torch.equal(part2, part)
+    assert part2.shape == part.shape
+    assert float((part2.double().sum(1) - want).abs().max()) <= 3e-5 * max(float(want.abs().max()), 1.0)
+    part = part2
     assert float(y2[:fused].float().abs().max()) == 0.0                # not written
     assert torch.equal(y2[fused:], y[fused:])                          # tail rows: the plain layer, the finisher reads them
     for _ in range(5):

@@ -32,7 +32,9 @@ W16_STAGE1L() last stage of a tile.
 import os
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mipnerf360_amd", "csrc", "m360_linear_bf16_w16_gen.inc")
-STORES = 32             # 16-byte stores per lane and tile (8 activation blocks x 4 column pieces x 2 rows / 2), all in the epilogue
+STORES = 32             # 16-byte stores per lane and tile (8 activation blocks x 4 column pieces x 2 rows / 2), all in the epilogue;
+                        # the bodies name them W16_STORES: the kernel's constant (32; bf16x3: 64; fused heads without the layer's own
+                        # output: 32 small ones) - only "all of a tile's stores sit between these two pieces" is simulated here
 
 
 def dma_plan(kind):
@@ -120,7 +122,8 @@ def stage(B, kind, vm):
                     L.append("    W16_WAIT_HI();")
                 else:
                     p, st = vm[(kind if kind in ("Z", "L", "ZL") else "", "M1")]
-                    L.append(f"    W16_BARRIER_M1({p}, {p + st});")
+                    assert st in (0, STORES)
+                    L.append(f"    W16_BARRIER_M1({p}, {p}{' + W16_STORES' if st else ''});")
                 L.append("    W16_SB();")
             else:
                 for _ in range(advx):
@@ -132,7 +135,8 @@ def stage(B, kind, vm):
                     L.append("    W16_ADV_W();")
                     L.append(f"    W16_WAIT_NEXT(fw{nxt});")
                     p, st = vm[(kind if kind in ("Z", "L", "ZL") else "", "E1")]
-                    L.append(f"    W16_BARRIER_E1({p}, {p + st});")
+                    assert st in (0, STORES)
+                    L.append(f"    W16_BARRIER_E1({p}, {p}{' + W16_STORES' if st else ''});")
                 L.append("    W16_SB();")
     L.append("} while (0)")
     return " \\\n".join(L) + "\n"
@@ -248,7 +252,8 @@ def x3_stage(t, variant, vm, at=None):
                     L.append("    W16_WAIT_HI();")
                 else:
                     p, st = vm[(key, "M1")]
-                    L.append(f"    W16_BARRIER_M1({p}, {p + st});")
+                    assert st in (0, STORES_X3)
+                    L.append(f"    W16_BARRIER_M1({p}, {p}{' + W16_STORES' if st else ''});")
                 L.append("    W16_SB();")
             else:
                 L.append(f"    W16_WAIT_NEXT(fw{nxt});")
@@ -256,7 +261,8 @@ def x3_stage(t, variant, vm, at=None):
                     L.append("    W16_BARRIER_E0();")
                 elif T["e1"]:
                     p, st = vm[(key, "E1")]
-                    L.append(f"    W16_BARRIER_E1({p}, {p + st});")
+                    assert st in (0, STORES_X3)
+                    L.append(f"    W16_BARRIER_E1({p}, {p}{' + W16_STORES' if st else ''});")
                 L.append("    W16_SB();")
     L.append("} while (0)")
     return " \\\n".join(L) + "\n"
