@@ -37,8 +37,9 @@
 //     (1260 against 1136 cycles per 32 deep); starting the workgroups of an XCD up to 30 k cycles apart, so that the 256 epilogues
 //     do not store in the same microseconds, changes nothing (profiles/r03/bf16_w16_start_stagger_REJECTED.jsonl).
 // Takes full 256 x 256 tiles of layers with K a multiple of 128 (>= 256) or K = 64 (ONE_BLOCK: the first layers - all epilogue,
-// 1.07 GB of whole-line stores), bias + {none, ReLU}; the sigmoid / fused-heads layers stay with the ping-pong kernel (its partner
-// wave hides the transcendental epilogue).
+// 1.07 GB of whole-line stores), bias + {none, ReLU}; in its X3 form every K that is a multiple of 64; with HEADS the sigmoid /
+// fused-heads last layers of the rendering forward.  Everything else (K = 128 / 192, sigmoid without heads, fused heads that also
+// keep the layer's output) stays with the ping-pong kernel.
 #pragma once
 #include "m360_common.hip.h"
 
