@@ -1409,6 +1409,22 @@ def test_bf16_pingpong_kernel_race_screen(dev):
         assert float(diff.max()) <= 2.0 ** -7 * max(float(ref.abs().max()), 1.0)   # one bf16 rounding of the output
 
 
+def test_bf16_ring_kernel_is_bitwise_the_pingpong_kernel(dev):
+    """Both bf16 layer kernels accumulate the same 32-deep MFMA k-steps in the same order and round once: on the same operands every
+    output element must be EQUAL, whatever the tile / stage count and the row strides (tools/diag/w16_soak.py through the diagnostics
+    library, which can launch either kernel on any shape; skipped when that library was not built: make -C mipnerf360_amd/csrc diag)."""
+    import os
+    import subprocess
+    import sys
+    from mipnerf360_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(os.path.dirname(_lib.LIB_PATH), "libm360_diag.so")):
+        pytest.skip("libm360_diag.so not built")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "diag", "w16_soak.py"), "--shapes", "6", "--seed", "3"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout[-3000:]
+
+
 @pytest.mark.parametrize("x3", [False, True])
 @pytest.mark.parametrize("M,n,k,heads", [(1024, 1024, 1024, 4), (512 + 37, 256, 256, 1), (2048, 512, 128, 4)])
 def test_bf16_last_layer_heads_on_the_matrix_pipe(dev, M, n, k, heads, x3):
