@@ -568,6 +568,35 @@ def test_generated_kernel_schedules_are_current(tmp_path):
             assert open(getattr(mod, attr)).read() == open(os.path.join(root, rel)).read(), f"{rel} is stale: run python tools/{tool}"
 
 
+def test_ring_kernel_store_instructions_match_its_counted_waits(tmp_path):
+    """The one-wave bf16 ring kernel waits with counted vmcnt across its epilogue: the generated stage bodies assume W16_STORES
+    vector-memory stores per lane and tile (32; 64 as [hi | lo]; 32 partial-sum stores with fused heads).  The head stores are plain
+    C++ the compiler could merge or split - then a counted wait would let a needed LDS-DMA piece stay in flight.  Compile the device
+    code and count: every instantiation must hold exactly the number its waits were generated for."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "mipnerf360_amd", "csrc")
+    out = str(tmp_path / "m360_linear.s")
+    res = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                          "-S", "--cuda-device-only", os.path.join(csrc, "m360_linear.hip"), "-o", out],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    text = open(out).read()
+    seen = 0
+    # _ZN4m3603w1622linear_bf16_w16_kernelILi<ACT>ELi<ABL>ELb<STAMP>ELb<X3>ELb<ONE_BLOCK>ELi<HEADS>EEE...
+    for m in re.finditer(r"^(_ZN4m3603w1622linear_bf16_w16_kernelILi(\d)ELi0ELb0ELb([01])ELb([01])ELi(\d)EEE\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        x3, heads, body = m.group(3) == "1", int(m.group(5)), m.group(6)
+        want = 32 if heads else (64 if x3 else 32)
+        got = len(re.findall(r"\bglobal_store_", body))
+        assert got == want, f"{m.group(1)}: {got} store instructions, the counted waits assume {want}"
+        assert "scratch_" not in body, f"{m.group(1)} spills"
+        seen += 1
+    assert seen >= 10, f"only {seen} ring-kernel instantiations found"
+
+
 def test_design_md_numbers_are_generated_from_profiles():
     """DESIGN.md carries its measured numbers (headline, per-launch table, named workloads) in a block that
     tools/summarize_profiles.py --markdown regenerates from profiles/<tag>/: the block in the file must be exactly what the
