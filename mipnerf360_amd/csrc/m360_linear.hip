@@ -750,6 +750,12 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
 #undef M360_W32_ABL
         return check_launch("diag_linear_bf16_w32");
     }
+    if (variant == 300 || variant == 301) {  // bf16x3 on either kernel (ReLU): x = [hi | lo] rows (ldx >= 2 k_pad), w = [Wh | Wh | Wl], y = [hi | lo]
+        if (k_pad < 2 * w16::BKS || ldx < 2 * k_pad || ldy < 2 * n_pad || n_pad > w16::kMaxBias) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant 300 needs k_pad >= 128, [hi | lo] strides");
+        if (variant == 300) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, true, false>), dim3((unsigned)(nt < cus ? nt : cus)), dim3(w16::kThreads), 0, st, xb, M, ldx, wb, b_packed, n_pad, 3 * k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
+        else hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_RELU, false, 2>), grid, block, 0, st, xb, M, ldx, wb, b_packed, n_pad, 3 * k_pad, yb, ldy, n_pad / pp16::BN, (int)nt);
+        return check_launch("diag_linear_bf16x3");
+    }
     if (variant >= 100 && variant <= 200) {  // the one-wave-per-SIMD 16x16x32 ring kernel (m360_linear_bf16_w16.hip.h): 100 + ABL bits stamped,
                                              // 200 = the product instantiation
         if (k_pad % 128 || k_pad < 256 || n_pad > w16::kMaxBias) return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant 100 needs k_pad %% 128 == 0, >= 256");
