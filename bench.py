@@ -72,9 +72,14 @@ TRAFFIC_SOURCES = ("mipnerf360_amd/csrc/m360_linear_hd.hip.h", "mipnerf360_amd/c
                    "mipnerf360_amd/csrc/m360_linear.hip", "mipnerf360_amd/csrc/m360_common.hip.h")
 
 
-def kernel_source_sha():
+# ... and the dominant kernel of --mlp-dtype bf16 (the one-wave ring kernel)
+TRAFFIC_SOURCES_BF16 = ("mipnerf360_amd/csrc/m360_linear_bf16_w16.hip.h", "mipnerf360_amd/csrc/m360_linear_bf16_w16_gen.inc",
+                        "mipnerf360_amd/csrc/m360_linear.hip", "mipnerf360_amd/csrc/m360_common.hip.h")
+
+
+def kernel_source_sha(sources=None):
     h = hashlib.sha256()
-    for rel in TRAFFIC_SOURCES:
+    for rel in (sources or TRAFFIC_SOURCES):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()
@@ -257,6 +262,15 @@ def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
                             "Infinity-Cache hits included, so W re-streamed per tile counts; algorithmic bytes are 4.30 GB")
         else:
             traffic_note = "profiles/traffic.json was measured on different kernel sources (stale): not reported"
+    elif os.path.exists(tpath) and bf16 and not x3 and config_name == "c2":
+        tb = json.load(open(tpath)).get("bf16_ring_kernel")
+        if tb and tb.get("kernel_source_sha256") == kernel_source_sha(TRAFFIC_SOURCES_BF16):
+            traffic = tb.get("bytes_per_launch")
+            traffic_note = ("fabric-side counter bytes per launch (FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, gfx950 corrections); "
+                            "algorithmic bytes are 2.15 GB (the activation tile is read by the 4 column tiles of an XCD: L2 hits are not counted, "
+                            "Infinity-Cache hits are)")
+        elif tb:
+            traffic_note = "profiles/traffic.json (bf16_ring_kernel) was measured on different kernel sources (stale): not reported"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     kname = ("linear_bf16_w16_kernel<X3> (bf16x3: 3 MFMA passes per product)" if x3 else "linear_bf16_w16_kernel") if bf16 else "linear_f32_hd_kernel"
     roofline = {"bound": "mfma", "kernel": f"{kname} (1024x1024 layer, M={S})", "achieved": round(achieved, 2),

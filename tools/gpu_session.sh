@@ -59,6 +59,12 @@ for s in $steps; do
     k256)    for v in 3 200; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --m 524288 --n 256 --k 256 --rounds 5 --json $out/linear_bf16_k256.jsonl > $out/linear_bf16_k256_$v.log 2>&1; tail -1 $out/linear_bf16_k256_$v.log; done ;;
     b16tests) timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "bf16 or c5" > $out/pytest_bf16.log 2>&1; echo "pytest rc=$?" >> $out/pytest_bf16.log; tail -6 $out/pytest_bf16.log ;;
     x3tests) timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "x3" > $out/pytest_x3.log 2>&1; echo "pytest rc=$?" >> $out/pytest_x3.log; tail -12 $out/pytest_x3.log ;;
+    b16pmc)  R=$PWD; O=$R/$out; PMC="--kernel-trace --output-format csv"; B="python3 $R/bench.py --mlp-dtype bf16 --steps 3 --warmup 1 --cpu-rays 0 --frame-steps 0"
+             ( cd /tmp && export TMPDIR=/tmp
+               timeout 600 rocprofv3 $PMC --pmc FETCH_SIZE -d $O/pmc_b16_fetch -- $B > $O/pmc_b16_fetch.log 2>&1
+               timeout 600 rocprofv3 $PMC --pmc WRITE_SIZE -d $O/pmc_b16_write -- $B > $O/pmc_b16_write.log 2>&1
+               timeout 600 rocprofv3 $PMC --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $O/pmc_b16_sq -- $B > $O/pmc_b16_sq.log 2>&1 )
+             find $O -name "*.db" -delete 2>/dev/null; ls $O/pmc_b16_sq/*/ | head -3 ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
