@@ -65,6 +65,8 @@ for s in $steps; do
                timeout 600 rocprofv3 $PMC --pmc WRITE_SIZE -d $O/pmc_b16_write -- $B > $O/pmc_b16_write.log 2>&1
                timeout 600 rocprofv3 $PMC --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $O/pmc_b16_sq -- $B > $O/pmc_b16_sq.log 2>&1 )
              find $O -name "*.db" -delete 2>/dev/null; ls $O/pmc_b16_sq/*/ | head -3 ;;
+    c4b16)   timeout 900 python bench.py --config c4 --mlp-dtype bf16 --steps 3 --warmup 1 > $out/bench_c4_bf16.json 2> $out/bench_c4_bf16.err; tail -c 700 $out/bench_c4_bf16.json
+             timeout 900 python bench.py --config c4 --mlp-dtype bf16x3 --steps 3 --warmup 1 > $out/bench_c4_bf16x3.json 2> $out/bench_c4_bf16x3.err; tail -c 700 $out/bench_c4_bf16x3.json ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
