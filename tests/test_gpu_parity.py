@@ -1420,7 +1420,8 @@ def test_bf16_ring_kernel_is_bitwise_the_pingpong_kernel(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists(os.path.join(os.path.dirname(_lib.LIB_PATH), "libm360_diag.so")):
         pytest.skip("libm360_diag.so not built")
-    for extra in ([], ["--x3"]):   # bf16, then bf16x3 (xl wh, xh wh, xh wl per block in both kernels)
+    # bf16, then bf16x3 (xl wh, xh wh, xh wl per block in both kernels), then both with NaN / Inf / huge / denormal activations planted
+    for extra in ([], ["--x3"], ["--special"], ["--x3", "--special"]):
         res = subprocess.run([sys.executable, os.path.join(root, "tools", "diag", "w16_soak.py"), "--shapes", "6", "--seed", "3"] + extra,
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout[-3000:]

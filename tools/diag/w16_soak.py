@@ -10,6 +10,7 @@ from mipnerf360_amd import _lib, ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", type=int, default=16)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--special", action="store_true", help="plant NaN / Inf / huge / denormal entries in the activations")
 ap.add_argument("--x3", action="store_true", help="the bf16x3 forms (diag variants 301 / 300): [hi | lo] rows in and out, three products per block")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -25,6 +26,11 @@ for it in range(a.shapes):
     pad_x, pad_y = 8 * int(rng.integers(0, 3)), 8 * int(rng.integers(0, 3))   # row strides that are not the row length
     g = torch.Generator(device=dev).manual_seed(it)
     xf = torch.rand(m, k, device=dev, generator=g) * 2 - 1
+    if a.special:   # a few NaN / +-Inf / huge entries: the NaN-preserving ReLU and the bf16 conversion must agree bit for bit as well
+        rows = torch.randint(0, m, (16,), device=dev, generator=g)
+        cols = torch.randint(0, k, (16,), device=dev, generator=g)
+        vals = torch.tensor([float("nan"), -float("nan"), float("inf"), -float("inf"), 3e38, -3e38, 1e-40, -0.0] * 2, device=dev)
+        xf[rows, cols] = vals
     w = (torch.rand(n, k, device=dev, generator=g) * 2 - 1) * (6.0 / k) ** 0.5
     b = torch.rand(n, device=dev, generator=g) - 0.5
     xm = 2 if a.x3 else 1   # row-length multiplier of the [hi | lo] layout
