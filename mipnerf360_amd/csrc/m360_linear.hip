@@ -770,6 +770,8 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
             case 16: M360_W16_ABL(16, true); break;
             case 32: M360_W16_ABL(32, true); break;
             case 39: M360_W16_ABL(39, true); break;
+            case 64: M360_W16_ABL(64, true); break;
+            case 28: M360_W16_ABL(128, true); break;  // variant 128: plain instead of non-temporal stores
             case 100: M360_W16_ABL(0, false); break;
             case 50: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 16, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // sigmoid epilogue, no stores: what would a last layer cost here?
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);
@@ -821,6 +823,7 @@ int m360_diag_linear_hd(const float *x, long M, int ldx, const float *w_packed, 
             case 7: M360_HD_ABL(7); break;
             case 16: M360_HD_ABL(16); break;
             case 64: M360_HD_ABL(64); break;
+            case 128: M360_HD_ABL(128); break;
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_hd: ablate=%d", ablate);
         }
         return check_launch("diag_linear_hd");

@@ -66,8 +66,9 @@ struct cursor_t { __amdgpu_buffer_rsrc_t rsrc; int k; int tile; };  // an LDS-DM
 // diagnostics build, per workgroup: [0] cycles (s_memtime) and [1] 100 MHz ticks of the tile loop, [2] stages, [3] cycles in epilogues
 __device__ unsigned long long g_w16_stamps[256 * 4];
 #endif
-// ABL (diagnostic builds; results are wrong unless 0): 1 = no barrier, 2 = no LDS-DMA, 4 = no fragment reads, 16 = no stores,
-// 32 = no epilogue at all
+// ABL (diagnostic builds; results are wrong unless 0 or 64): 1 = no barrier, 2 = no LDS-DMA, 4 = no fragment reads, 16 = no stores,
+// 32 = no epilogue at all, 64 = wait for every outstanding operation at the end of the epilogue (how long do the stores take?),
+// 128 = plain instead of non-temporal stores (results correct)
 // X3 ("bf16x3", m360_linear_bf16_pp.hip.h): activations [hi(K) | lo(K)], weights [Wh | Wh | Wl] (rows of Kp = 3K), output
 // [hi(Np) | lo(Np)]; per 64-deep block three stages xl wh -> xh wh -> xh wl that share an operand with their neighbour
 // (tools/gen_w16_slab.py, second half): 4 operand tiles staged per block instead of 6, the same accumulation order as the ping-pong
@@ -397,7 +398,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                      : "v"(A0[0]), "v"(A0[1]), "v"(A0[2]), "v"(A0[3]), "v"(A1[0]), "v"(A1[1]), "v"(A1[2]), "v"(A1[3]),          \
                        "s"(0x5555555555555555ull), "s"(0xAAAAAAAAAAAAAAAAull)                                                    \
                      : "vcc");                                                                                                  \
-        if (!(ABL & 16))                                                                                                        \
+        /* non-temporal: the tile's 128 KiB of output lines otherwise displace the activation tile the 4 column tiles of an XCD share  \
+           from its L2 (1263-1270 against 1241-1242 TF, alternating launches on one box; ABL & 128: the plain stores) */              \
+        if ((ABL & 16) == 0 && (ABL & 128) == 0)                                                                                \
+            asm volatile("global_store_dwordx4 %0, %2, %4 nt\n\tglobal_store_dwordx4 %1, %3, %4 nt\n\ts_nop 1"                 \
+                         ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(s1), "v"(s2), "s"(ROW) : "memory");                \
+        else if ((ABL & 16) == 0)                                                                                               \
             asm volatile("global_store_dwordx4 %0, %2, %4\n\tglobal_store_dwordx4 %1, %3, %4\n\ts_nop 1"                       \
                          ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(s1), "v"(s2), "s"(ROW) : "memory");                \
         else asm volatile("" ::"v"(s1), "v"(s2));                                                                               \
@@ -425,6 +431,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                 W16_SB();  // one pair of column pieces at a time
             }
         }
+        if (ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostics: drain the stores (and everything else) inside the stamped epilogue
         if (STAMP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e1)::"memory"); te += e1 - e0; nsl += nstages; }
         have_prev = !(ABL & 32);
     }

@@ -20,6 +20,13 @@
 #pragma once
 #include "m360_common.hip.h"
 
+// Non-temporal epilogue stores: the output lines of a tile are not read again before the next launch and otherwise displace the
+// operands from L2.  Measured (profiles/r03/hd_nontemporal_stores_ab.jsonl, hd_nontemporal_stores_step_ab.txt): the 64-deep first
+// NeRF layer 0.666 -> 0.61-0.62 ms, 256^2 and 1024^2 layers unchanged, step 53.21-53.25 -> 53.11-53.20 ms alternating on one box.
+#ifndef M360_HD_NT_STORES
+#define M360_HD_NT_STORES 1
+#endif
+
 namespace m360 {
 namespace hd {
 
@@ -43,7 +50,7 @@ constexpr int kMaxBias = 4096;                       // widest layer (bias is se
 __device__ unsigned long long g_hd_stamps[2 * 256 * 4];
 #endif
 // ABL (diagnostic builds only; results are wrong unless 0): 1 = no workgroup barrier, 2 = no LDS-DMA, 4 = no operand reads,
-// 8 = epilogue fillers unguarded, 16 = no epilogue stores, 32 = no epilogue arithmetic, 64 = tiles in natural order (no XCD-aware remap; results stay right)
+// 8 = epilogue fillers unguarded, 16 = no epilogue stores, 32 = no epilogue arithmetic, 64 = tiles in natural order (no XCD-aware remap; results stay right), 128 = non-temporal stores (results stay right)
 // EVENK: Kp / 32 is even -> static LDS stages (see the generated K-steps)
 template <int ACT, bool EVENK = false, int ABL = 0, bool STAMP = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
@@ -169,8 +176,11 @@ __global__ __launch_bounds__(kThreads, 1) void linear_f32_hd_kernel(
     } while (0)
 #define HD_ES(I, J, PP)                                                                                      \
     do {                                                                                                     \
-        if (!(ABL & 16))                                                                                     \
+        if (!(ABL & 16) && !(ABL & 128) && !M360_HD_NT_STORES)                                               \
             asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(y_voff), "v"(ev[PP]),            \
+                         "s"(Yt + (long)((I) * 32 + (PP) * 8) * ldy), "n"((J) * 128) : "memory");            \
+        else if (!(ABL & 16)) /* 128 / M360_HD_NT_STORES: non-temporal stores (results stay right) */        \
+            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" ::"v"(y_voff), "v"(ev[PP]),         \
                          "s"(Yt + (long)((I) * 32 + (PP) * 8) * ldy), "n"((J) * 128) : "memory");            \
     } while (0)
 // an epilogue filler of the generated schedule: skipped (wave-uniform branch) while there is no previous tile
