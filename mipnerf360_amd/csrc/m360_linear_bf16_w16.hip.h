@@ -35,7 +35,8 @@
 //     built and measured WORSE the thinner the stores were spread (8 per stage: 600 cycles per k-step of those stages, one per
 //     k-step: 670 cycles in every k-step - tools/gen_w16_slab.py).  With the stores the K loop still runs 10 % slower than without
 //     (1260 against 1136 cycles per 32 deep); starting the workgroups of an XCD up to 30 k cycles apart, so that the 256 epilogues
-//     do not store in the same microseconds, changes nothing (profiles/r03/bf16_w16_start_stagger_REJECTED.jsonl).
+//     do not store in the same microseconds, changes nothing (profiles/r03/bf16_w16_start_stagger_REJECTED.jsonl), and the stores
+//     retire within ~270 cycles (ABL 64): what costs is their lines in L2 - the stores are non-temporal (+2 %, see W16_SWAP_STORE).
 // Takes full 256 x 256 tiles of layers with K a multiple of 128 (>= 256) or K = 64 (ONE_BLOCK: the first layers - all epilogue,
 // 1.07 GB of whole-line stores), bias + {none, ReLU}; in its X3 form every K that is a multiple of 64; with HEADS the sigmoid /
 // fused-heads last layers of the rendering forward.  Everything else (K = 128 / 192, sigmoid without heads, fused heads that also
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     } while (0)
 #define W16_SB() __builtin_amdgcn_sched_barrier(0)
 // The MFMAs are inline assembly with the accumulator tied to an AccVGPR ("+a"): with the builtin the register allocator kept half
-// of the 64 accumulator tuples in ArchVGPRs across the slab bodies and copied them in and out around every MFMA (4 v_accvgpr_write
+// of the 64 accumulator tuples in ArchVGPRs across the stage bodies and copied them in and out around every MFMA (4 v_accvgpr_write
 // + s_nop per MFMA in the K loop).  The hazard recogniser does not see these MFMAs: the epilogue waits out the last one itself.
 #define W16_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 #define W16_MFMA_Z(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(A), "v"(B))
