@@ -32,6 +32,8 @@ W16_STAGE1L() last stage of a tile.
 import os
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mipnerf360_amd", "csrc", "m360_linear_bf16_w16_gen.inc")
+JB_OUTER = False        # experiment: weight block outer, activation block inner inside a half (same accumulation order per tuple): 1246-1249 against
+                        # 1241-1244 TF alternating on one box (profiles/r03/bf16_w16_mfma_order_ab_NO_EFFECT.txt, tools/diag/w16_order_ab.sh)
 TWO_BARRIERS = False   # experiment: all 8 activation pieces in half 0, the hi rows awaited at barrier M1 as well, no barrier E1 - correct
                         # (bitwise soak), 1228 TF against 1222-1243 with three barriers (profiles/r03/bf16_w16_two_barriers_REJECTED.jsonl)
 STORES = 32             # 16-byte stores per lane and tile (8 activation blocks x 4 column pieces x 2 rows / 2), all in the epilogue;
@@ -113,7 +115,7 @@ def stage(B, kind, vm):
             # stage s + 1 lives in the other buffer, stage s + 2 in this one
             dma = {g: f"W16_DMA_{what}({nb if off == 1 else B}, {part})" for g, what, part, off in plan[(kk, half)]}
             for m in range(32):
-                ib, jb = 4 * half + m // 8, m % 8
+                ib, jb = (4 * half + m // 8, m % 8) if not JB_OUTER else (4 * half + m % 4, m // 4)
                 z = "_Z" if (kind in ("Z", "ZL") and kk == 0) else ""
                 L.append(f"    W16_MFMA{z}(acc[{ib}][{jb}], fw{cur}[{jb}], fx[{ib}]);")
                 if m in read_gaps:
