@@ -772,6 +772,8 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
             case 39: M360_W16_ABL(39, true); break;
             case 64: M360_W16_ABL(64, true); break;
             case 28: M360_W16_ABL(128, true); break;  // variant 128: plain instead of non-temporal stores
+            case 29: M360_W16_ABL(256, true); break;  // variant 129: non-temporal activation pieces
+            case 30: M360_W16_ABL(512, true); break;  // variant 130: non-temporal weight pieces
             case 100: M360_W16_ABL(0, false); break;
             case 50: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 16, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // sigmoid epilogue, no stores: what would a last layer cost here?
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);

@@ -160,8 +160,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
             }                                                                                                                \
         }                                                                                                                    \
     } while (0)
-#define W16_PIECE_X(C, COL, SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(C.rsrc, (lds_ptr_t)(dma_x + (SLOT) * kStageBytes + ((Q) & 3) * 1024 + ((Q) >> 2) * 8192), 16, x_voff[Q], C.k + (COL), 0, 0)
-#define W16_PIECE_W(C, COL, SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(C.rsrc, (lds_ptr_t)(dma_w + (SLOT) * kStageBytes + (Q) * 1024), 16, w_voff[Q], C.k + (COL), 0, 0)
+// (ABL 256 / 512, diagnostics: non-temporal activation / weight pieces; results stay right.  One layer launched back to back gains
+// 1.3 % from non-temporal activation pieces (1278-1285 against 1263-1268 TF) and loses 4 % from non-temporal weight pieces
+// (profiles/r03/bf16_w16_nontemporal_loads_ab_NOT_ADOPTED.jsonl) - but in the step, where a layer reads what the previous one has just written,
+// the activation variant measured 7.04 against 6.96-7.02 ms (bf16x3: 17.5 against 16.9-17.1): not adopted.)
+#define W16_PIECE_X(C, COL, SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(C.rsrc, (lds_ptr_t)(dma_x + (SLOT) * kStageBytes + ((Q) & 3) * 1024 + ((Q) >> 2) * 8192), 16, x_voff[Q], C.k + (COL), 0, (ABL & 256) ? 2 : 0)
+#define W16_PIECE_W(C, COL, SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(C.rsrc, (lds_ptr_t)(dma_w + (SLOT) * kStageBytes + (Q) * 1024), 16, w_voff[Q], C.k + (COL), 0, (ABL & 512) ? 2 : 0)
 #define W16_ADV_X() W16_CUR_ADV(cx, true)
 #define W16_ADV_W() W16_CUR_ADV(cw, false)
 #define W16_DMA_X(SLOT, Q) W16_PIECE_X(cx, 0, SLOT, Q)
