@@ -388,6 +388,10 @@ int m360_visualize_composite(const float *colors, const float *acc, const float 
  * Replaces the last nn.Linear + nn.Sigmoid of model.py:43-53 / :131-148 plus the matrix product of the heads. */
 long m360_linear_heads_fused_rows(long M, int n_pad, int bf16);
 int m360_linear_heads_slots(int n_pad, int bf16);
+/* bf16 / bf16x3 (bf16 = 1 / 2): the number of slots m360_linear_heads_bf16 / _bf16x3 writes for THESE arguments - 2 per 256 columns
+ * when the one-wave ring kernel takes the layer (store_y = 0 and a contraction of its shape: one partial sum per 128-column wave
+ * tile), else 8 (ping-pong kernel).  Never more than m360_linear_heads_slots(n_pad, bf16): size head_part with that. */
+int m360_linear_heads_slots_bf16(int n_pad, int k_pad, int bf16, int store_y);
 int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad,
                       int k_pad, int act /* M360_ACT_SIGMOID */, float *y, int ldy, int store_y, const float *head_w,
                       int heads, float *head_part, m360_stream_t stream);

@@ -117,6 +117,7 @@ SIGNATURES = {
     "m360_nerf_finish": (_i, [_vp, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "m360_linear_heads_fused_rows": (_l, [_l, _i, _i]),
     "m360_linear_heads_slots": (_i, [_i, _i]),
+    "m360_linear_heads_slots_bf16": (_i, [_i, _i, _i, _i]),
     "m360_linear_heads": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "m360_linear_heads_bf16": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "m360_linear_heads_bf16x3": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),

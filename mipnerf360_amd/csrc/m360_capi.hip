@@ -249,7 +249,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         // last hidden layer + head on the matrix pipe (full 256-row tiles; tail rows through y): ld of y = hp (bf16) / 2 hp ([hi | lo])
         const int ldl = mode == 2 ? 2 * hp : hp;
         M360_TRY(p_linear_heads(h, mode, a, S, ldl, m->prop_w[3], m->prop_b[3], hp, hp, b, ldl, 0, m->prop_head_w, 1, hpart, st));
-        return p_prop_finish_fused(h, b, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hp, mode), m360_linear_heads_slots(hp, mode), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
+        return p_prop_finish_fused(h, b, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hp, mode), m360_linear_heads_slots_bf16(hp, hp, mode, 0), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
     }
     if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(p_linear(h, &tq, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
@@ -300,7 +300,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         }
         const int ldl = mode == 2 ? 2 * hn : hn;
         M360_TRY(p_linear_heads(h, mode, src, S, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, ldl, 0, m->nerf_head_w, 4, hpart, st));
-        M360_TRY(p_nerf_finish_fused(h, dst, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hn, mode), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
+        M360_TRY(p_nerf_finish_fused(h, dst, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hn, mode), m360_linear_heads_slots_bf16(hn, hn, mode, 0), m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     } else {
     if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
     else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));

@@ -411,8 +411,19 @@ long m360_linear_heads_fused_rows(long M, int n_pad, int bf16) {
     return (M / persist::BM) * persist::BM;  // full 256-row tiles of a 256-multiple width <= 1024
 }
 
-int m360_linear_heads_slots(int n_pad, int bf16) {  // partial sums per row: fp32 one per 128-column wave tile, bf16 one per 32 columns
+int m360_linear_heads_slots(int n_pad, int bf16) {  // partial sums per row: fp32 one per 128-column wave tile, bf16 at most one per 32 columns
     return n_pad >= persist::BN ? (bf16 ? 8 : 2) * (n_pad / persist::BN) : 0;
+}
+
+// which kernel forms the fused heads of a bf16 / bf16x3 last layer: the one-wave ring kernel (rendering forward: the layer's own
+// output is not kept) when the contraction has its shape, else the ping-pong kernel
+static bool heads_on_ring(int k_pad, int x3, int store_y) {
+    return M360_W16_HEADS_ON && !store_y && (x3 ? (k_pad % w16::BKS == 0 && k_pad >= 2 * w16::BKS) : (k_pad % (2 * w16::BKS) == 0 && k_pad >= 4 * w16::BKS));
+}
+
+int m360_linear_heads_slots_bf16(int n_pad, int k_pad, int bf16, int store_y) {  // slots the call with these arguments writes
+    if (n_pad < pp16::BN) return 0;
+    return (heads_on_ring(k_pad, bf16 == 2, store_y) ? 2 : 8) * (n_pad / pp16::BN);
 }
 
 int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, const float *b_packed, int n_pad, int k_pad,
@@ -481,7 +492,7 @@ static int linear_heads_bf16_any(const void *x, long M, int ldx, const void *w_p
 #define M360_W16_HEADS(X3B, H) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 0, false, X3B, false, H>), grid, dim3(w16::kThreads), 0, st, xb, M_fused, ldx, wb, b_packed, n_pad, kk, yb, ldy, tn, (int)nt, head_w, head_part)
         // the rendering forward (the layer's own output is not kept): the one-wave ring kernel - its exposed sigmoid epilogue costs
         // less than its K loop wins (0.85 against 1.08-1.12 ms for the 1024^2 NeRF layer)
-        const bool ring = M360_W16_HEADS_ON && !store_y && (x3 ? (k_pad % w16::BKS == 0 && k_pad >= 2 * w16::BKS) : (k_pad % (2 * w16::BKS) == 0 && k_pad >= 4 * w16::BKS));
+        const bool ring = heads_on_ring(k_pad, x3, store_y);
         if (ring) {
             if (x3) { if (heads == 1) M360_W16_HEADS(true, 1); else M360_W16_HEADS(true, 4); }
             else { if (heads == 1) M360_W16_HEADS(false, 1); else M360_W16_HEADS(false, 4); }

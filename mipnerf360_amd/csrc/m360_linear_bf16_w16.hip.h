@@ -77,8 +77,9 @@ __device__ unsigned long long g_w16_stamps[256 * 4];
 // HEADS > 0 (the last hidden layer of a stage, sigmoid, as in the ping-pong kernel): the output heads' dot products are formed on
 // the matrix pipe from the packed bf16 pieces the epilogue holds - a lane's 8 consecutive output columns of one row ARE a B fragment
 // of v_mfma_f32_16x16x32_bf16, the head rows (as hi / lo bf16 terms, from 16 KiB of LDS) the A fragment: D[head][row], lanes 0-15
-// hold the heads of their row over the piece's 32 columns.  One partial sum per row and 32-column piece goes to
-// head_part[row][(Np / 256) * 8][HEADS] (slot = 4 wn + p: the ping-pong kernel's layout); the layer's own output is NOT written
+// hold the heads of their row over the piece's 32 columns; the four pieces of a wave are accumulated through the C operand, so ONE
+// partial sum per row and 128-column wave tile goes to head_part[row][(Np / 256) * 2][HEADS] (slot = 2 (n0 / 256) + wn: 128 bytes
+// per sample at width 1024 - the ping-pong kernel writes 8 slots per 256 columns); the layer's own output is NOT written
 // (the rendering forward; the tape-keeping one stays on the ping-pong kernel).  The sigmoid is exposed here (11.5 k cycles of epilogue
 // per tile instead of 5.4 k), and still the layer takes 0.85 ms against 1.08-1.12 ms (tools/linear_bench.py --variant 150).
 constexpr int kHeadMaxN = 1024;  // widest layer the fused heads take (their hi / lo rows live in 16 KiB of LDS)
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0)];  // 144 (160) KiB
     static_assert(HEADS == 0 || HEADS == 1 || HEADS == 4, "1 (proposal) or 4 (NeRF) heads");
     constexpr bool STORE_Y = HEADS == 0;
-    // vector-memory operations of a tile's epilogue: 32 whole-line stores (64 as [hi | lo]) or, with fused heads, 32 partial-sum stores
-    constexpr int W16_STORES = STORE_Y ? (X3 ? 64 : 32) : 32;
+    // vector-memory operations of a tile's epilogue: 32 whole-line stores (64 as [hi | lo]) or, with fused heads, 8 partial-sum stores
+    constexpr int W16_STORES = STORE_Y ? (X3 ? 64 : 32) : 8;
     static_assert(ACT == M360_ACT_NONE || ACT == M360_ACT_RELU || (ACT == M360_ACT_SIGMOID && (ABL != 0 || HEADS > 0)), "bias + {none, ReLU}; sigmoid with fused heads");
 
     const int tid = threadIdx.x;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     // this lane's head row for MFMA A-fragment row l15 (rows >= HEADS repeat the last head: their D rows are never stored)
     const unsigned hfrag_addr = lds0 + 2 * kStageBytes + kMaxBias * 4 + 2u * (unsigned)((l15 < HEADS ? l15 : (HEADS ? HEADS - 1 : 0)) * Np + wn * 128 + 8 * g4);
     const unsigned hlo_off = 2u * (unsigned)(HEADS * Np);
-    const int hstride = HEADS ? (Np / BN) * 8 * HEADS : 0;  // floats per row of head_part: [(Np / 256) * 8 slots][HEADS]
+    const int hstride = HEADS ? (Np / BN) * 2 * HEADS : 0;  // floats per row of head_part: [(Np / 256) * 2 slots][HEADS]
     const unsigned bias_addr = lds0 + 2 * kStageBytes + 4u * (wn * 128 + 8 * g4);  // + 4 * n0 of the tile, + 128 * p
 
     // ---- prologue: stages 0 and 1 of the first tile (the first stage of a tile issues no activation pieces: the last stage of its
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                        "+a"(acc[7][6]), "+a"(acc[7][7])::"memory");
         if (!(ABL & 32)) {
             const __bf16 *yt = Y + (m0 + wm * 128) * ldy + n0 + wn * 128;  // wave-uniform corner of the wave tile
+            f32x4 hacc[8];  // HEADS: the head sums of this lane's rows (one per activation block) over the pieces done so far
 #pragma unroll
             for (int P = 0; P < 2; ++P) {  // column pieces p = 2P, 2P + 1: 64 output columns = one 128-byte line per row
                 f32x4 bb[4];  // bias of the lane's columns 32 p + 8 g4 + 0..7, p = 2P (bb[0], bb[1]) and 2P + 1 (bb[2], bb[3])
@@ -419,17 +421,19 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                         if (X3) W16_SWAP_STORE(lo[0], lo[1], row + Np);  // the second terms: columns [Np, 2 Np)
                     }
 #undef W16_SWAP_STORE
-                    if (HEADS) {  // D[head][row] over each piece's 32 columns: hi and lo head terms (X3: and the lo activations)
+                    if (HEADS) {  // D[head][row] += over each piece's 32 columns: hi and lo head terms (X3: and the lo activations)
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            f32x4 hq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[h], __builtin_bit_cast(bf16x8, ab[h]), (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                            f32x4 hq = (P == 0 && h == 0) ? (f32x4){0.0f, 0.0f, 0.0f, 0.0f} : hacc[i];
+                            hq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[h], __builtin_bit_cast(bf16x8, ab[h]), hq, 0, 0, 0);
                             hq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[h], __builtin_bit_cast(bf16x8, ab[h]), hq, 0, 0, 0);
                             if (X3) hq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[h], __builtin_bit_cast(bf16x8, lo[h]), hq, 0, 0, 0);
-                            if (g4 == 0 && !(ABL & 16)) {
-                                float *hp = head_part + (m0 + wm * 128 + 16 * i + l15) * hstride + ((n0 / BN) * 8 + wn * 4 + 2 * P + h) * HEADS;
-                                if (HEADS == 4) *reinterpret_cast<f32x4 *>(hp) = hq;
-                                else *hp = hq[0];
-                            }
+                            hacc[i] = hq;
+                        }
+                        if (P == 1 && g4 == 0 && !(ABL & 16)) {  // the wave tile's 128 columns are in: one store per row
+                            float *hp = head_part + (m0 + wm * 128 + 16 * i + l15) * hstride + ((n0 / BN) * 2 + wn) * HEADS;
+                            if (HEADS == 4) *reinterpret_cast<f32x4 *>(hp) = hacc[i];
+                            else *hp = hacc[i][0];
                         }
                     }
                 }

@@ -482,7 +482,8 @@ def linear_heads_bf16(x, w_packed, b_packed, head_w, store_y: bool = True, x3: b
         raise RuntimeError("linear_heads_bf16: shapes of x / w_packed / head_w do not match")
     lib = _lib.lib()
     mode = 2 if x3 else 1
-    fused, slots = int(lib.m360_linear_heads_fused_rows(M, n_pad, mode)), int(lib.m360_linear_heads_slots(n_pad, mode))
+    fused = int(lib.m360_linear_heads_fused_rows(M, n_pad, mode))
+    slots = int(lib.m360_linear_heads_slots_bf16(n_pad, k_pad, mode, int(bool(store_y))))  # 2 or 8 per 256 columns: which kernel takes it
     ldy = (2 if x3 else 1) * n_pad
     y = torch.zeros(M, ldy, device=x.device, dtype=torch.bfloat16)
     part = torch.zeros(max(fused, 1), max(slots, 1), heads, device=x.device)

@@ -1459,7 +1459,8 @@ def test_bf16_last_layer_heads_on_the_matrix_pipe(dev, M, n, k, heads, x3):
     # whose 8 slots per 256 columns are contiguous 32-column pieces (the ping-pong kernel's: 8 of every 16 columns of a 64-column
     # group) - only the sum over the slots is comparable
     y2, part2, _ = ops.linear_heads_bf16(xs, wp, bp, hw, store_y=False, x3=x3)
-    assert part2.shape == part.shape
+    ring = (k % 64 == 0 and k >= 128) if x3 else (k % 128 == 0 and k >= 256)
+    assert part2.shape[1] == (2 if ring else 8) * (n // 256)   # the ring kernel: one slot per 128-column wave tile
     assert float((part2.double().sum(1) - want).abs().max()) <= 3e-5 * max(float(want.abs().max()), 1.0)
     part = part2
     assert float(y2[:fused].float().abs().max()) == 0.0                # not written

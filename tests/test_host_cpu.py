@@ -570,7 +570,7 @@ def test_generated_kernel_schedules_are_current(tmp_path):
 
 def test_ring_kernel_store_instructions_match_its_counted_waits(tmp_path):
     """The one-wave bf16 ring kernel waits with counted vmcnt across its epilogue: the generated stage bodies assume W16_STORES
-    vector-memory stores per lane and tile (32; 64 as [hi | lo]; 32 partial-sum stores with fused heads).  The head stores are plain
+    vector-memory stores per lane and tile (32; 64 as [hi | lo]; 8 partial-sum stores with fused heads).  The head stores are plain
     C++ the compiler could merge or split - then a counted wait would let a needed LDS-DMA piece stay in flight.  Compile the device
     code and count: every instantiation must hold exactly the number its waits were generated for."""
     import re
@@ -589,7 +589,7 @@ def test_ring_kernel_store_instructions_match_its_counted_waits(tmp_path):
     # _ZN4m3603w1622linear_bf16_w16_kernelILi<ACT>ELi<ABL>ELb<STAMP>ELb<X3>ELb<ONE_BLOCK>ELi<HEADS>EEE...
     for m in re.finditer(r"^(_ZN4m3603w1622linear_bf16_w16_kernelILi(\d)ELi0ELb0ELb([01])ELb([01])ELi(\d)EEE\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
         x3, heads, body = m.group(3) == "1", int(m.group(5)), m.group(6)
-        want = 32 if heads else (64 if x3 else 32)
+        want = 8 if heads else (64 if x3 else 32)
         got = len(re.findall(r"\bglobal_store_", body))
         assert got == want, f"{m.group(1)}: {got} store instructions, the counted waits assume {want}"
         assert "scratch_" not in body, f"{m.group(1)} spills"
