@@ -399,7 +399,9 @@ int m360_linear_heads(const float *x, long M, int ldx, const float *w_packed, co
  * the full 256-row tiles (widths 256 / 512 / 768 / 1024) are formed on the matrix pipe inside the layer's epilogue - the
  * packed bf16 row segments the epilogue holds are B fragments of v_mfma_f32_16x16x32_bf16, the head rows (as two bf16 terms)
  * the A fragments - from the bf16-ROUNDED activations, i.e. from what m360_nerf_finish_bf16 would read back;
- * m360_linear_heads_slots(n_pad, 1) = 8 per 256 columns (one partial sum per wave column group and 8-column half).
+ * the call writes m360_linear_heads_slots_bf16(n_pad, k_pad, mode, store_y) slots per row: 8 per 256 columns on the ping-pong
+ * kernel (one partial sum per wave column group and 8-column half), 2 per 256 columns on the one-wave ring kernel (store_y = 0
+ * and a contraction of its shape: one per 128-column wave tile) - pass that number to the *_finish_fused calls.
  * The bf16x3 form takes / writes [hi | lo] pair rows like m360_linear_bf16x3 and adds the lo activations' term. */
 int m360_linear_heads_bf16(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad,
                            int k_pad, int act, void *y, int ldy, int store_y, const float *head_w, int heads,
