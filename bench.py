@@ -18,8 +18,10 @@ Nothing is ever exec'ed in place (`--dry-launch` prints the child command instea
 Default workload (c2, weak scaling): every rank renders its own 4096-ray batch (rays shard with no data-path
 collective) and the rendered pixels (20 B per ray) are all-gathered over RCCL each step, as the path's one exchange
 step.  Rank 0 prints ONE JSON line; for N > 1 it carries `rccl.ranks`, the world size read back from an all-reduce.
-After the timed region the same processes render ONE 1237 x 822 frame sharded over the N ranks (BASELINE configs[3],
-strong scaling; `strong_scaling_frame` in the line, `--frame-steps 0` to skip).
+After the timed region the same processes render ONE 1237 x 822 frame sharded over the N ranks at 64 proposal + 128 NeRF
+samples per ray (BASELINE configs[2] as written; configs[3] for N > 1, strong scaling; `strong_scaling_frame` in the line,
+`--frame-steps 0` to skip), and at N = 1 the process then times the other single-GPU workloads for a few steps each
+(`named_workloads`: configs[4]'s shape in bf16, configs[1] in bf16 and bf16x3, one train.py iteration; `--no-named` to skip).
 
 Other named workloads (never the default line):
   --config c4          BASELINE configs[3] as the timed workload: frames of 1237 x 822 rays, each rank generates and
@@ -107,6 +109,8 @@ def parse_args(argv=None):
     ap.add_argument("--frame-size", type=str, default=None, metavar="WxH",
                     help="(diagnostics) frame size of the c4 workload / strong_scaling_frame instead of 1237x822; the line "
                          "then says so in config.workload")
+    ap.add_argument("--no-named", action="store_true",
+                    help="c2 / fp32 / 1 GPU only: skip the `named_workloads` block (the other single-GPU configs, a few steps each)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the child command as JSON and exit")
     return ap.parse_args(argv)
@@ -125,6 +129,31 @@ def child_command(args, argv, port):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + passed
 
 
+def visible_gpu_count(sysfs="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process tree can use, counted WITHOUT initialising HIP (the parent must never touch a GPU): the KFD topology
+    lists every node with its `simd_count` (0 = a CPU node); ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES narrow the set like the runtime does.  None when the topology cannot be read (no driver)."""
+    try:
+        nodes = sorted(os.listdir(sysfs), key=lambda v: int(v) if v.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(sysfs, node, "properties")) as f:
+                props = dict(line.split(None, 1) for line in f if len(line.split(None, 1)) == 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            continue
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(listed))
+    return n
+
+
 def launch(args, argv) -> int:
     """Parent of an N > 1 run started without a launcher.  Imports no torch, touches no GPU: the ranks are fresh child
     processes of `torch.distributed.run`, itself a child of this process (never an exec in place)."""
@@ -132,6 +161,12 @@ def launch(args, argv) -> int:
     if args.dry_launch:
         print(json.dumps({"launch": cmd, "ranks": args.gpus}), flush=True)
         return 0
+    if args.backend == "nccl":  # RCCL wants one device per rank: refuse here, before N processes have initialised a GPU each
+        have = visible_gpu_count()
+        if have is not None and args.gpus > have:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible here (KFD topology / *_VISIBLE_DEVICES); "
+                  f"RCCL needs one device per rank (--backend gloo lets ranks share a GPU, diagnostics only)", file=sys.stderr)
+            return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports
     env.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -169,14 +204,15 @@ def launch(args, argv) -> int:
 # ------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(sd_np, rays_np, n_rays, samples):
     """The oracle (CPU restatement of the reference path, kind="port") on the first n_rays of the batch as ONE chunk:
-    one timed pass for >= 2048 rays (about 20 s), else the median of 3, after a small warm-up."""
+    two timed passes for >= 2048 rays (about 20 s each on the GPU box's 128 threads; the single passes of rounds 1-3 read
+    175 / 191 / 210 rays/s, +-10 %: both times are reported), else the median of 3, after a small warm-up."""
     from oracle import ref_path as O
     sd = O.to_torch_state_dict(sd_np)
     sub = {k: v[:n_rays] for k, v in rays_np.items()}
     hp = O.Hyper(num_samples=samples)
     O.forward(O.rays_from_numpy({k: v[:32] for k, v in rays_np.items()}), sd, hp)  # page in / thread pool warm-up
     times, out = [], None
-    for _ in range(1 if n_rays >= 2048 else 3):
+    for _ in range(2 if n_rays >= 2048 else 3):
         t0 = time.perf_counter()
         out = O.forward(O.rays_from_numpy(sub), sd, hp)
         times.append(time.perf_counter() - t0)
@@ -294,8 +330,12 @@ def hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib, x3=False):
     in_pad = enc[0]["n_pad"] if enc else 64  # row length of the MLP input the encoder writes (58 channels, zero-padded)
 
     def finish_in_bytes(width, heads):
-        fused = int(lib.m360_linear_heads_fused_rows(S, width, int(bf16)))  # 0 on the bf16 pipe: the finishers read the activations
-        return fused * int(lib.m360_linear_heads_slots(width, int(bf16))) * heads * 4 + (S - fused) * width * el
+        # rows whose head products the last layer's epilogue formed: the finisher reads their partial sums [slots][heads] fp32
+        # (fp32 kernel: 2 slots per 256 columns; bf16 / bf16x3 rendering forward, store_y = 0: the ring kernel's 2 per 256 -
+        # m360_linear_heads_slots_bf16 answers for the kernel the library picks), the other rows' activations
+        fused = int(lib.m360_linear_heads_fused_rows(S, width, int(bf16)))
+        slots = int(lib.m360_linear_heads_slots_bf16(width, width, 2 if x3 else 1, 0)) if bf16 else int(lib.m360_linear_heads_slots(width, 0))
+        return fused * slots * heads * 4 + (S - fused) * width * el
 
     out = {}
     fused_last = [r["ms"] for r in recs if r["kind"] == _lib.K_LINEAR_HEADS and r["n_pad"] == HN and r["M"] == S]
@@ -313,6 +353,7 @@ def hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib, x3=False):
             out[name] = {"avg_launch_ms": round(ms, 4), "algorithmic_bytes": nbytes,
                          "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
                          "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 3), "launches": len(d)}
+            assert out[name]["frac_of_8TBps"] <= 1.0, f"{name}: {out[name]} is above the HBM peak - the byte count is wrong"
     return out
 
 
@@ -397,6 +438,135 @@ def frame_pipeline(model, comm, frames, warmup, overlap, width=FRAME_W, height=F
             "overlap": bool(side is not None), "finite": finite,
             "per_rank": [{"rank": r, "rays": int(v[2]), "compute_ms_median": round(v[0], 2),
                           "all_gather_ms_median": round(v[1], 3)} for r, v in enumerate(per_rank)]}
+
+
+def timed_forward(model, rays, steps, warm, _lib, torch):
+    """`steps` public forwards under no_grad after `warm` untimed ones -> (ms per step, event records of the timed steps)."""
+    with torch.no_grad():
+        for _ in range(warm):
+            model(rays)
+        prof = _lib.Prof(48 * max(steps, 1))
+        model.set_prof(prof)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model(rays)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    model.set_prof(None)
+    recs = prof.records()
+    prof.close()
+    return ms, recs
+
+
+def named_workloads(sd_np, dev, _lib):
+    """The other single-GPU configurations of BASELINE.json, timed in this process after the headline's timed region, a few
+    steps each: the driver's default run then carries a number for every single-GPU config.  Every entry
+    has its own dtype, rays/s, ms/step and the dominant kernel's roofline fraction from HIP-event records of its own steps.
+    None of this touches the headline fields."""
+    import torch
+
+    from mipnerf360_amd import ops, synthetic
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
+    from mipnerf360_amd.intern.ray import Rays
+    from mipnerf360_amd.model import mipNeRF360
+    out = {}
+    t_all = time.perf_counter()
+
+    def forward_entry(name, cfg, mlp_dtype, steps, warm):
+        n_rays, samples, _, metric, workload = CONFIGS[cfg]
+        m = mipNeRF360(randomized=False, num_samples=samples, hidden_proposal=HP, hidden_nerf=HN, white_bkgd=False, device=dev,
+                       mlp_dtype=mlp_dtype)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        m.eval()
+        r = synthetic.make_rays("garden", n_rays, seed=1)
+        rays = Rays(*[torch.from_numpy(r[k]).to(dev) for k in synthetic.RAY_FIELDS])
+        ms, recs = timed_forward(m, rays, steps, warm, _lib, torch)
+        with torch.no_grad():
+            rgb, d, a = m(rays)
+        finite = bool(torch.isfinite(rgb).all() and torch.isfinite(d).all() and torch.isfinite(a).all())
+        x3 = mlp_dtype == "bf16x3"
+        roof = roofline_from_records(recs, n_rays * samples, mlp_dtype != "fp32", cfg, _lib, x3)
+        out[name] = {"config": cfg, "workload": workload.format(mlp=MLP_NAMES[mlp_dtype]), "dtype": mlp_dtype if mlp_dtype != "fp32" else "f32",
+                     "metric": metric, "rays_per_s": round(n_rays / ms * 1e3, 1), "ms_per_step": round(ms, 3), "steps": steps,
+                     "warmup": warm, "finite": finite,
+                     "whole_path_tflops": round(n_rays / ms * 1e3 * FLOPS_PER_SAMPLE * samples / 1e12, 1),
+                     "roofline": None if roof is None else {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")}}
+        del m, rays
+        torch.cuda.empty_cache()
+
+    forward_entry("c5_bf16", "c5", "bf16", 8, 2)        # BASELINE configs[4]'s per-GPU shape: 8192 x 256, bf16 MLP
+    forward_entry("c2_bf16", "c2", "bf16", 20, 3)       # configs[1]'s shape with the opt-in bf16 MLP
+    forward_entry("c2_bf16x3", "c2", "bf16x3", 10, 2)   # ... and with two bf16 terms per value (inside the fp32 tolerance)
+
+    # ---- one iteration of the reference's training loop body (train.py:53-82: two proposal updates, one NeRF update, AdamW)
+    n_rays, samples = CONFIGS["c2"][0], CONFIGS["c2"][1]
+    model = mipNeRF360(randomized=False, num_samples=samples, hidden_proposal=HP, hidden_nerf=HN, device=dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    model.train()
+    r = synthetic.make_rays("garden", n_rays, seed=1)
+    rays = Rays(*[torch.from_numpy(r[k]).to(dev) for k in synthetic.RAY_FIELDS])
+    pixels = torch.rand(n_rays, 3, device=dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
+
+    def prop_step():
+        t_hat, w_hat = model.prop_net.forward(rays)
+        with torch.no_grad():
+            _, _, _, t, w_, _ = model.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+        loss = Loss_prop(t=t, w=w_, t_hat=t_hat, w_hat=w_hat)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    def nerf_step():
+        with torch.no_grad():
+            t_hat, w_hat = model.prop_net.forward(rays)
+        rgb, _, _, _, fw, sv = model.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        ln, _ = Loss_nerf(input=rgb, target=pixels)
+        ld = Loss_dist(s_vals=sv, weights=fw)
+        opt.zero_grad()
+        (ln + 0.01 * ld).backward()
+        opt.step()
+
+    def timed(fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    prop_ms, nerf_ms = timed(prop_step, 1), timed(nerf_step, 2)
+    it_ms = 2 * prop_ms + nerf_ms
+    del model, opt
+    torch.cuda.empty_cache()
+    M = n_rays * samples
+    dz = torch.randn(M, HN, device=dev)
+    x = torch.relu(torch.randn(M, HN, device=dev))
+    wt = ops.pack_linear_transposed(torch.randn(HN, HN, device=dev) / 32)
+    dx = torch.empty(M, HN, device=dev)
+    flops = 2.0 * M * HN * HN
+    wgrad_ms = timed(lambda: ops.linear_wgrad(dz, x), 3)
+    dgrad_ms = timed(lambda: ops.linear_dgrad(dz, wt, x, out=dx), 3)
+    del dz, x, dx, wt
+    torch.cuda.empty_cache()
+    out["c2_training_iteration"] = {
+        "config": "c2", "dtype": "f32",
+        "workload": "one iteration of the reference's training loop body (train.py:53-82) at 4096 rays x 128 samples, full width, fp32: "
+                    "two proposal updates (forward both nets, Loss_prop, backward of the proposal net, AdamW) + one NeRF update "
+                    "(forward both nets, Loss_nerf + 0.01 Loss_dist, backward of the NeRF net, AdamW); tape-keeping forwards, "
+                    "hand-written backward (m360_prop_backward / m360_nerf_backward), torch.optim.AdamW",
+        "iteration_ms": round(it_ms, 2), "prop_update_ms": round(prop_ms, 2), "nerf_update_ms": round(nerf_ms, 2),
+        "train_rays_per_s": round(n_rays / it_ms * 1e3, 1),
+        "nerf_update_tflops": round(M * (423424 + 3 * 14807040) / nerf_ms / 1e9, 1),
+        "wgrad_1024x1024": {"ms": round(wgrad_ms, 3), "tflops": round(flops / wgrad_ms / 1e9, 1), "frac": round(flops / wgrad_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+                            "kernel": "linear_tn_kernel + tn_reduce_kernel (dW = dZ^T X, bias gradient fused)"},
+        "dgrad_1024x1024": {"ms": round(dgrad_ms, 3), "tflops": round(flops / dgrad_ms / 1e9, 1), "frac": round(flops / dgrad_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+                            "kernel": "linear_f32_mfma_persist_kernel<RELU_MASK> (dX = (dZ W) * [a > 0])"},
+        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+    out["seconds"] = round(time.perf_counter() - t_all, 2)
+    return out
 
 
 def worker(args):
@@ -541,16 +711,43 @@ def worker(args):
     line["rccl"] = comm.info
 
     if not frame_cfg and args.frame_steps > 0:
-        # BASELINE configs[3] beside the headline: the same processes render one frame together (strong scaling)
+        # BASELINE configs[2] as written ("hierarchical 64+128 samples") beside the headline, and configs[3] for N > 1: the
+        # same processes render one frame together (strong scaling).  64 proposal + 128 NeRF samples per ray is the build's
+        # `num_samples_fine` extension (the reference draws as many NeRF as proposal samples, intern/ray.py:147).
         fw, fh = frame_size(args)
-        fr = frame_pipeline(model, comm, args.frame_steps, 0, overlap=False, width=fw, height=fh)
+        fmodel = mipNeRF360(randomized=False, num_samples=64, num_samples_fine=128, hidden_proposal=HP, hidden_nerf=HN,
+                            white_bkgd=False, device=dev, mlp_dtype=mlp_dtype)
+        fmodel.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        fmodel.eval()
+        fprof = _lib.Prof(40 * ((fw * fh + FRAME_CHUNKS - 1) // FRAME_CHUNKS // world + 2) * args.frame_steps + 64)
+        fmodel.set_prof(fprof)
+        fr = frame_pipeline(fmodel, comm, args.frame_steps, 0, overlap=False, width=fw, height=fh)
+        fmodel.set_prof(None)
+        frecs = fprof.records()
+        fprof.close()
+        fr["samples_per_ray"] = "64 proposal + 128 NeRF (BASELINE configs[2]: 'hierarchical 64+128 samples')"
+        fr["flops_per_ray"] = 423424 * 64 + 14807040 * 128
+        fr["whole_path_tflops"] = round(fr["rays_per_s"] * fr["flops_per_ray"] / 1e12, 2)
+        froof = roofline_from_records(frecs, FRAME_CHUNKS * 128, bf16, "c2", _lib, x3)
+        fr["roofline"] = None if froof is None else {k: froof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")}
         fr["workload"] = (f"DIAGNOSTIC frame size {fw}x{fh} instead of 1237x822; " if args.frame_size else "") + \
-            CONFIGS["c4"][4].format(mlp="fp32")
+            CONFIGS["c4"][4].format(mlp=MLP_NAMES[mlp_dtype]).replace("x 128 samples/ray", "x (64 proposal + 128 NeRF) samples/ray")
         line["strong_scaling_frame"] = fr
+        del fmodel
+        torch.cuda.empty_cache()
 
     if rank != 0:
         comm.close()
         return
+
+    if args.config == "c2" and mlp_dtype == "fp32" and world == 1 and not args.no_named:
+        line["named_workloads"] = named_workloads(sd_np, dev, _lib)
+        if "strong_scaling_frame" in line:  # BASELINE configs[2] is the frame leg above: listed with the others
+            fr = line["strong_scaling_frame"]
+            line["named_workloads"]["c3_frame_64+128"] = {
+                "config": "c3", "dtype": "f32", "workload": fr["workload"], "rays_per_s": fr["rays_per_s"],
+                "ms_per_step": round(1e3 * fr["seconds_per_frame"], 1), "steps": fr["frames"], "roofline": fr["roofline"],
+                "whole_path_tflops": fr["whole_path_tflops"], "see": "strong_scaling_frame"}
 
     if not frame_cfg and world == 1 and args.cpu_rays > 0:
         n_cpu = min(args.cpu_rays, n_rays)

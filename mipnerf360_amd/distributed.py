@@ -17,6 +17,7 @@ send / receive pairs so that the all-gather of frame i (on a side stream) overla
 from __future__ import annotations
 
 import inspect
+import weakref
 from collections import OrderedDict
 from typing import List, Optional, Tuple
 
@@ -186,48 +187,66 @@ def gather_pixels(local: torch.Tensor, spans: List[Tuple[int, int]], group=None)
 
 
 # ------------------------------------------------------------------------------------------- replica agreement
-_CHECKED: "OrderedDict[tuple, bool]" = OrderedDict()
+# model -> (parameter versions, data pointers, fingerprint): a LOCAL cache of a local computation, keyed by the object itself
+# (weakly: no id() reuse after garbage collection).  Whether the collective runs never depends on it.
+_FP_CACHE: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_FP_MOD = 65521
 
 
 def replica_fingerprint(model) -> Optional[torch.Tensor]:
-    """int64[2] = (sample counts, wrapped sum of all parameter bit patterns) of a torch model, on its device; None for
-    renderers without parameters (test doubles)."""
+    """int64[2] = (sample counts / MLP precision, hash of all parameter bit patterns) of a torch model, on its device; None
+    for renderers without parameters (test doubles).  The hash weights every element with its position inside its tensor
+    (1 + index mod 65521) and every tensor with its position in the model, in wrapping int64 arithmetic: permuted or
+    compensating values inside one tensor change it, as do swapped layers."""
     if not hasattr(model, "parameters"):
         return None
     params = list(model.parameters())
     if not params:
         return None
+    key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params), getattr(model, "mlp_dtype", None),
+           getattr(model, "num_samples", None), getattr(model, "num_samples_fine", None))
+    try:
+        hit = _FP_CACHE.get(model)
+    except TypeError:  # an unhashable / non-weakref-able renderer: recompute every time
+        hit = None
+    if hit is not None and hit[0] == key:
+        return hit[1].clone()
     dev = params[0].device
     acc = torch.zeros((), dtype=torch.int64, device=dev)
     for i, p in enumerate(params):
-        bits = p.detach().contiguous().view(torch.int32).to(torch.int64)
-        acc = acc + bits.sum() * (2 * i + 1)  # position-dependent weight: swapped layers do not cancel
+        bits = p.detach().contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+        pos = torch.arange(bits.numel(), dtype=torch.int64, device=dev).remainder_(_FP_MOD).add_(1)
+        acc = acc + (bits * pos).sum() * (2 * i + 1)
     ns = int(getattr(model, "num_samples", 0)) * 100003 + int(getattr(model, "num_samples_fine", 0) or 0)
     ns = ns * 7 + {"fp32": 0, "bf16": 1, "bf16x3": 2}.get(getattr(model, "mlp_dtype", "fp32"), 3)  # the MLP precision too
-    return torch.stack([torch.tensor(ns, dtype=torch.int64, device=dev), acc])
+    fp = torch.stack([torch.tensor(ns, dtype=torch.int64, device=dev), acc])
+    try:
+        _FP_CACHE[model] = (key, fp.clone())
+    except TypeError:
+        pass
+    return fp
 
 
 def check_replicas(model, group=None) -> None:
-    """Every rank must render with the same weights and sample counts or the frame is silently inconsistent.  Once per
-    (model, parameter versions): one all-reduce (MAX) of 4 int64 = (f, -f) - all ranks agree iff max(f) == -max(-f)."""
-    if _world_rank(group)[0] == 1 or not hasattr(model, "parameters"):
-        return
-    key = (id(model), group, getattr(model, "mlp_dtype", None), getattr(model, "num_samples", None),
-           tuple(p._version for p in model.parameters()), tuple(p.data_ptr() for p in model.parameters()))
-    if _CHECKED.get(key):  # nothing changed since the last agreement: no kernels, no collective
+    """Every rank must render with the same weights and sample counts or the frame is silently inconsistent.  EVERY call on a
+    process group of more than one rank issues the same collective on every rank - one all-reduce (MAX) of 4 int64 =
+    (f, -f): all ranks agree iff max(f) == -max(-f) - so a rank whose weights changed can never be the only one inside a
+    collective (a per-rank cache deciding that would pair its all-reduce with the other ranks' all-gather: a hang or
+    corrupted data instead of this error).  Only the local fingerprint computation is cached (per model object and parameter
+    versions).  A renderer without parameters contributes zeros."""
+    if _world_rank(group)[0] == 1:
         return
     fp = replica_fingerprint(model)
     if fp is None:
-        return
+        dev = getattr(model, "device", None)
+        dev = torch.device(dev) if dev is not None and dist.get_backend(group) == "nccl" else torch.device("cpu")
+        fp = torch.zeros(2, dtype=torch.int64, device=dev)
     both = torch.cat([fp, -fp])
     _all_reduce(both, dist.ReduceOp.MAX, group)
     both = both.cpu()
     if not (both[0] == -both[2] and both[1] == -both[3]):
         raise RuntimeError("mipnerf360_amd.distributed: the ranks of this process group hold different weights or sample "
                            "counts (replica fingerprint mismatch) - load the same checkpoint on every rank")
-    _CHECKED[key] = True
-    while len(_CHECKED) > 8:
-        _CHECKED.popitem(last=False)
 
 
 # ------------------------------------------------------------------------------------------- sharded rendering

@@ -46,11 +46,18 @@ def rays_from_numpy(d: Mapping[str, np.ndarray]) -> Rays:
 
 # 21 unit directions of the icosahedron/dodecahedron basis, intern/encoding.py:9-30
 _A, _B, _C, _D = 0.8506508, 0.5257311, 0.809017, 0.309017
-IPE_BASIS = torch.tensor([
+_IPE_ROWS = [
     [_A, 0, _B], [_C, 0.5, _D], [_B, _A, 0], [1, 0, 0], [_C, 0.5, -_D], [_A, 0, -_B],
     [_D, _C, -0.5], [0, _B, -_A], [0.5, _D, -_C], [0, 1, 0], [-_B, _A, 0], [-_D, _C, -0.5],
     [0, _B, _A], [-_D, _C, 0.5], [_D, _C, 0.5], [0.5, _D, _C], [0.5, -_D, _C], [0, 0, 1],
-    [-0.5, _D, _C], [-_C, 0.5, _D], [-_C, 0.5, -_D]], dtype=torch.float32)
+    [-0.5, _D, _C], [-_C, 0.5, _D], [-_C, 0.5, -_D]]
+IPE_BASIS = torch.tensor(_IPE_ROWS, dtype=torch.float32)
+
+
+def ipe_basis(dtype=torch.float32):
+    """the basis in the dtype of the data (the reference builds it with torch.tensor(<python floats>): in its fp64 runs -
+    tests/golden/make_golden.py reference_in_fp64 - the rows are the doubles nearest to the decimal literals)"""
+    return IPE_BASIS if dtype == torch.float32 else torch.tensor(_IPE_ROWS, dtype=dtype)
 
 
 # --------------------------------------------------------------------------- t <-> s
@@ -179,7 +186,7 @@ def mean_sumsq(t_vals, directions, radii) -> torch.Tensor:
 # --------------------------------------------------------------------------- encodings
 def ipe(mean, cov):
     """intern/encoding.py:33-56 (single-scale integrated positional encoding)."""
-    P = IPE_BASIS
+    P = ipe_basis(mean.dtype)
     gamma = torch.matmul(mean, P.T)                     # [...,21]
     A = torch.matmul(cov, P.T)                          # [...,3,21]
     sigma = torch.sum(P.T * A, dim=-2)                  # [...,21]
@@ -189,7 +196,7 @@ def ipe(mean, cov):
 
 def viewdir_enc(viewdirs, min_deg: int = 0, max_deg: int = 4):
     """intern/encoding.py:69-90 (theta/phi encoding; atan, not atan2)."""
-    scales = torch.tensor([2.0 ** i for i in range(min_deg, max_deg)], dtype=torch.float32)
+    scales = torch.tensor([2.0 ** i for i in range(min_deg, max_deg)], dtype=viewdirs.dtype)
     x, y, z = viewdirs[..., 0:1], viewdirs[..., 1:2], viewdirs[..., 2:3]
     theta = torch.arccos(z) * scales
     phi = torch.arctan(y / (x + 1e-6)) * scales

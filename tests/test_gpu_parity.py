@@ -9,7 +9,8 @@ per-op kernels are held much tighter (1e-6 .. 1e-5).
 import numpy as np
 import pytest
 import torch
-from conftest import assert_cov_within_reference_error
+from conftest import (G19_STAGE_NAMES, assert_cov_within_reference_error, assert_within_reference_error, g19_case,
+                      oracle_stages)
 
 from mipnerf360_amd import synthetic
 
@@ -301,6 +302,139 @@ def test_g9_render_image_bf16x3(golden, dev, chunks):
     assert (rgb8 != g[f"c{chunks}_rgb8"]).mean() < 0.02
     close(acc, g[f"c{chunks}_acc"], atol=RGB_TOL, rtol=0)
     close(dist, g[f"c{chunks}_dist"], atol=1e-4, rtol=1e-4)
+
+
+# =============================================================================== G19: trained-like weights
+G19_KINDS = ["lego", "garden", "mixed"]
+# rendered values: the stated fp32 tolerance; stage outputs: c x the reference's own fp32 error against its fp64 run
+G19_C = {"fp32": 4.0, "bf16x3": 4.0}
+_C2_ORACLE = {}
+
+
+def _g19_model(sd, dev, n, hp_, hn_, wb, mlp_dtype="fp32"):
+    from mipnerf360_amd.model import mipNeRF360
+    m = mipNeRF360(randomized=False, num_samples=n, hidden_proposal=hp_, hidden_nerf=hn_, white_bkgd=wb, device=dev, mlp_dtype=mlp_dtype)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m
+
+
+@pytest.mark.parametrize("kind", G19_KINDS)
+@pytest.mark.parametrize("scope", ["small", "full"])
+def test_g19_structured_weights_fp32(golden, dev, scope, kind):
+    """Whole-path parity outside the flat regime (reference: model.py:80-94,163-200,247-252,
+    intern/ray.py:136-149,155-191): the HIP path against what the REFERENCE produced on trained-like weights - both stage
+    forwards, every output.  Rendered values: the stated fp32 tolerance (1e-4) against the reference's fp32 outputs.  Every
+    output: no further from the reference's fp64 run than 4 x the reference's own fp32 run is (the path is ill-conditioned
+    here: w_hat of the reference's fp32 run is up to 9e-4 from its fp64 run, resampled t up to 2e-3)."""
+    g = golden("g19_structured_weights")
+    tag = f"{scope}.{kind}"
+    (B, n, wb, hp_, hn_, seed), r, sd = g19_case(g, tag)
+    m = _g19_model(sd, dev, n, hp_, hn_, wb)
+    rays = dev_rays(r, dev)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+        out = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        rgb, dist, acc = m(rays)
+    close(t_hat, g[tag + "_t_hat"], atol=0, rtol=2e-6)
+    worst = {}
+    for nm, v in zip(G19_STAGE_NAMES, (w_hat,) + tuple(out)):
+        worst[nm] = assert_within_reference_error(H(v), g[f"{tag}_{nm}"], g[f"{tag}_{nm}64"], c=G19_C["fp32"], floor=5e-6,
+                                                  relative_above_one=nm in ("dist", "t_vals"), what=f"{tag} {nm}")
+    print(f"G19 {tag} fp32 (error vs fp64 reference / the fp32 reference's own): " + "  ".join(f"{k} {a:.1e}/{b:.1e}" for k, (a, b) in worst.items()))
+    close_render(rgb, dist, acc, g[tag + "_rgb"], g[tag + "_dist"], g[tag + "_acc"])
+    for a, b in zip((rgb, dist, acc), out[:3]):
+        assert torch.equal(a, b)               # fused forward == staged forward, bit for bit
+
+
+@pytest.mark.parametrize("kind", G19_KINDS)
+def test_g19_structured_weights_bf16x3(golden, dev, kind):
+    """mlp_dtype="bf16x3" on trained-like weights at full width against the REFERENCE: rendered values inside the stated fp32
+    tolerance, every stage output within 4 x the reference's own fp32 error of the reference's fp64 run - the same bound the
+    exact-fp32 path is held to (the first layers run at full fp32 accuracy on the matrix pipe)."""
+    g = golden("g19_structured_weights")
+    tag = "full." + kind
+    (B, n, wb, hp_, hn_, seed), r, sd = g19_case(g, tag)
+    m = _g19_model(sd, dev, n, hp_, hn_, wb, "bf16x3")
+    rays = dev_rays(r, dev)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+        out = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    worst = {}
+    for nm, v in zip(G19_STAGE_NAMES, (w_hat,) + tuple(out)):
+        worst[nm] = assert_within_reference_error(H(v), g[f"{tag}_{nm}"], g[f"{tag}_{nm}64"], c=G19_C["bf16x3"], floor=5e-6,
+                                                  relative_above_one=nm in ("dist", "t_vals"), what=f"{tag} {nm}")
+    print(f"G19 {tag} bf16x3: " + "  ".join(f"{k} {a:.1e}/{b:.1e}" for k, (a, b) in worst.items()))
+    close_render(out[0], out[1], out[2], g[tag + "_rgb"], g[tag + "_dist"], g[tag + "_acc"])
+
+
+@pytest.mark.parametrize("kind", G19_KINDS)
+def test_g19_structured_weights_bf16(golden, dev, kind):
+    """mlp_dtype="bf16" on trained-like weights at full width against the REFERENCE.  Stated tolerance of the mode in this
+    regime: |d rgb| <= 2e-2, |d acc| <= 1e-2, |d distance| <= 2e-2 max(1, |distance|), rms |d rgb| <= 4e-3 (PSNR of the
+    build's render against the reference's > 48 dB); the 0.1 dB acceptance is test_psnr_within_tenth_db_of_reference."""
+    g = golden("g19_structured_weights")
+    tag = "full." + kind
+    (B, n, wb, hp_, hn_, seed), r, sd = g19_case(g, tag)
+    m = _g19_model(sd, dev, n, hp_, hn_, wb, "bf16")
+    with torch.no_grad():
+        rgb, dist, acc = m(dev_rays(r, dev))
+    d_rgb = np.abs(H(rgb) - g[tag + "_rgb"])
+    d_acc = np.abs(H(acc) - g[tag + "_acc"])
+    d_dist = np.abs(H(dist) - g[tag + "_dist"]) / np.maximum(1.0, np.abs(g[tag + "_dist"]))
+    print(f"G19 {tag} bf16: max |d rgb| {d_rgb.max():.2e} rms {np.sqrt((d_rgb ** 2).mean()):.2e} |d acc| {d_acc.max():.2e} |d dist| {d_dist.max():.2e}")
+    assert d_rgb.max() <= 2e-2 and np.sqrt((d_rgb ** 2).mean()) <= 4e-3 and d_acc.max() <= 1e-2 and d_dist.max() <= 2e-2
+
+
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("chunks", [128, 4096])
+def test_g19_render_image_on_structured_weights(golden, dev, chunks, mlp_dtype):
+    """render_image (model.py:254-274) on trained-like weights, both chunk sizes (different contraction norms: the shells sit
+    elsewhere), against the reference's frames: uint8 image within one level, acc / distance within 4 x the reference's own
+    fp32 error of its fp64 frame."""
+    from mipnerf360_amd.intern.ray import Rays
+    g = golden("g19_structured_weights")
+    h, w, n, hp_, hn_, seed = (int(x) for x in g["frame_cfg"])
+    sd = {k[len("frame_sd."):]: v for k, v in g.items() if k.startswith("frame_sd.")}
+    m = _g19_model(sd, dev, n, hp_, hn_, True, mlp_dtype)
+    rays_cpu = Rays(*[torch.from_numpy(g["frame_rays_" + k]) for k in synthetic.RAY_FIELDS])
+    rgb8, dist, acc = m.render_image(rays_cpu, h, w, chunks=chunks)
+    want = g[f"frame_c{chunks}_rgb8"]
+    assert rgb8.dtype == np.uint8 and np.abs(rgb8.astype(int) - want.astype(int)).max() <= 1 and (rgb8 != want).mean() < 0.02
+    assert_within_reference_error(acc, g[f"frame_c{chunks}_acc"], g[f"frame_c{chunks}_acc64"], c=4.0, floor=5e-6, what="acc")
+    assert_within_reference_error(dist, g[f"frame_c{chunks}_dist"], g[f"frame_c{chunks}_dist64"], c=4.0, floor=5e-6,
+                                  relative_above_one=True, what="distance")
+
+
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3", "bf16"])
+def test_c2_headline_batch_on_structured_weights_vs_oracle_as_one_chunk(dev, mlp_dtype):
+    """configs[1]'s exact ray batch (seed-1 garden rays, 4096 x 128, full width) as ONE chunk on trained-like weights fitted
+    to that chunk (the G19 generator; the reference needs ~10 min for this size, so truth = the oracle in fp64, which
+    tests/test_oracle_golden.py pins to the reference's fp64 runs at 2e-6, and the error budget = the oracle's fp32 run
+    against it).  fp32 and bf16x3: rendered values within the stated 1e-4, every stage output within 4 x the fp32 oracle's
+    own error; bf16: the mode's stated tolerance (see test_g19_structured_weights_bf16)."""
+    r = synthetic.make_rays("garden", 4096, seed=1)
+    sd = synthetic.make_structured_state_dict(256, 1024, 19, r, 128)
+    if not _C2_ORACLE:                           # two CPU passes over 4096 x 128 x full width: once for the three modes
+        _C2_ORACLE["o32"] = oracle_stages(r, sd, 128, False, "float32")
+        _C2_ORACLE["o64"] = oracle_stages(r, sd, 128, False, "float64")
+    o32, o64 = _C2_ORACLE["o32"], _C2_ORACLE["o64"]
+    assert o32["rgb"].std(0).mean() >= 0.15
+    m = _g19_model(sd, dev, 128, 256, 1024, False, mlp_dtype)
+    rays = dev_rays(r, dev)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+        out = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    got = dict(zip(G19_STAGE_NAMES, (H(w_hat),) + tuple(H(v) for v in out)))
+    if mlp_dtype == "bf16":
+        d_rgb = np.abs(got["rgb"] - o64["rgb"])
+        assert d_rgb.max() <= 2e-2 and np.sqrt((d_rgb ** 2).mean()) <= 4e-3 and np.abs(got["acc"] - o64["acc"]).max() <= 1e-2
+        return
+    worst = {}
+    for nm in G19_STAGE_NAMES:
+        worst[nm] = assert_within_reference_error(got[nm], o32[nm], o64[nm], c=4.0, floor=5e-6, relative_above_one=nm in ("dist", "t_vals"),
+                                                  what=f"c2 structured {mlp_dtype} {nm}")
+    print(f"c2 structured {mlp_dtype}: " + "  ".join(f"{k} {a:.1e}/{b:.1e}" for k, (a, b) in worst.items()))
+    close_render(out[0], out[1], out[2], o32["rgb"], o32["dist"], o32["acc"])
 
 
 # =============================================================================== oracle, seeded inputs
@@ -1550,30 +1684,33 @@ def test_train_gradients_with_unequal_sample_counts(dev):
             _grad_close(p.grad, o_grads[name], name)
 
 
-@pytest.mark.parametrize("kind,n", [("lego", 64), ("garden", 128)])
+@pytest.mark.parametrize("kind", ["lego", "garden", "mixed"])
 @pytest.mark.parametrize("mlp_dtype,limit_db", [("fp32", 1e-3), ("bf16", 0.1), ("bf16x3", 1e-3)])
-def test_psnr_within_tenth_db_of_reference(golden, dev, kind, n, mlp_dtype, limit_db):
+def test_psnr_within_tenth_db_of_reference(golden, dev, kind, mlp_dtype, limit_db):
     """north_star / SURVEY.md §8c acceptance: 'PSNR within 0.1 dB of reference'.  No dataset exists, so both renders -
-    the reference's own (fixture G8, full-width weights) and the build's - are scored against the SAME synthetic target
-    image with the standard definition -10 log10(mean((a - b)^2)) on [0, 1]; the difference must be <= 0.1 dB.
-    The fp32 path is held to 1e-3 dB, the opt-in bf16 MLP to the 0.1 dB of the acceptance, bf16x3 to the fp32 path's 1e-3 dB."""
+    the reference's own and the build's - are scored against the SAME synthetic target image with the standard definition
+    -10 log10(mean((a - b)^2)) on [0, 1]; the difference must be <= 0.1 dB.  Since round 4 the renders are those of fixture
+    G19 (full width, trained-like weights: rgb std over rays 0.2-0.4, peaked proposal weights, saturated and empty rays) -
+    on the near-uniform grey renders of Kaiming weights (fixture G8, rgb std 0.01) there was almost no signal to lose.
+    The fp32 path and bf16x3 are held to 1e-3 dB, the opt-in bf16 MLP to the 0.1 dB of the acceptance."""
     from mipnerf360_amd.model import mipNeRF360
-    g = golden("g8_end_to_end_fullwidth")
-    B, n_, wb = (int(x) for x in g[f"{kind}_{n}_cfg"])
-    sd = synthetic.make_state_dict(256, 1024, seed=int(g["weights_seed"][0]))
-    m = mipNeRF360(randomized=False, num_samples=n_, hidden_proposal=256, hidden_nerf=1024, white_bkgd=bool(wb), device=dev,
+    g = golden("g19_structured_weights")
+    tag = "full." + kind
+    (B, n, wb, hp_, hn_, seed), r, sd = g19_case(g, tag)
+    m = mipNeRF360(randomized=False, num_samples=n, hidden_proposal=hp_, hidden_nerf=hn_, white_bkgd=wb, device=dev,
                    mlp_dtype=mlp_dtype)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    rays = dev_rays(synthetic.make_rays(kind, B, seed=int(g["rays_seed"][0])), dev)
     with torch.no_grad():
-        rgb, _, _ = m(rays)
-    ref_rgb = g[f"{kind}_{n}_rgb"].astype(np.float64)
+        rgb, _, _ = m(dev_rays(r, dev))
+    ref_rgb = g[tag + "_rgb"].astype(np.float64)
+    assert ref_rgb.std(0).mean() >= 0.15
     gen = np.random.Generator(np.random.PCG64(808))
     worst = 0.0
-    for noise in (0.02, 0.1, 0.3):            # targets from "almost the reference render" to "far from it"
+    for noise in (0.02, 0.1, 0.3):            # targets from "almost the reference render" (34 dB) to "far from it" (10 dB)
         target = np.clip(ref_rgb + noise * gen.normal(size=ref_rgb.shape), 0.0, 1.0)
         psnr = lambda a: -10.0 * np.log10(np.mean((np.clip(a, 0, 1) - target) ** 2))  # noqa: E731
         worst = max(worst, abs(psnr(H(rgb).astype(np.float64)) - psnr(ref_rgb)))
+    print(f"G19 {kind} {mlp_dtype}: PSNR differs from the reference's by {worst:.5f} dB, max |d rgb| {np.abs(H(rgb) - ref_rgb).max():.2e}")
     assert worst <= limit_db, f"PSNR differs from the reference's by {worst:.4f} dB"
 
 

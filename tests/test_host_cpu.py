@@ -361,6 +361,29 @@ try:
 except RuntimeError as ex:
     assert "different weights" in str(ex)
 check_replicas(m)
+# ONE rank changes its weights in place after an agreeing check (ADVICE r3): every rank still enters the same collective
+# (no per-rank cache decides that) and every rank gets the error - not a hang, not a mismatched collective
+if rank == world - 1:
+    with torch.no_grad():
+        m.p.add_(0.5)
+try:
+    check_replicas(m)
+    raise SystemExit("check_replicas missed an in-place update on one rank")
+except RuntimeError as ex:
+    assert "different weights" in str(ex)
+if rank == world - 1:
+    with torch.no_grad():
+        m.p.sub_(0.5)
+check_replicas(m)
+# the same values in another order inside one tensor (equal plain sums of the bit patterns) are different weights
+perm = OracleRenderer()
+with torch.no_grad():
+    perm.p.copy_(torch.tensor([1.0, 2.0, 3.0] if rank % 2 == 0 else [3.0, 2.0, 1.0]))
+try:
+    check_replicas(perm)
+    raise SystemExit("check_replicas accepted permuted weights")
+except RuntimeError as ex:
+    assert "different weights" in str(ex)
 dist.barrier()
 dist.destroy_process_group()
 print("OK", rank)
