@@ -196,6 +196,22 @@ int m360_linear_bf16x3(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M,
                        const float *b_packed, int n_pad, int k_pad, int act, void *y_hi_lo_bf16 /*[M, ldy >= 2 n_pad]*/,
                        int ldy, m360_stream_t stream);
 
+/* ---- first layers of the bf16 / bf16x3 modes at fp32 accuracy ("x6", round 4).  The reference contracts a whole chunk by its
+ * Frobenius norm (intern/parameterization.py:23-29, called at :75): a ray's samples end up within ~1e-2 of each other in the
+ * encoder's coordinates, so a network that resolves anything along a ray has first-layer gains of 1e3-1e4 on differences of the
+ * sin / cos features (intern/encoding.py:33-56) and needs all 24 bits of them.  Features go to the first layer as THREE bf16 terms
+ * (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid); exact) in "x6" rows [lo | mid | hi | mid | hi | hi] of k_pad
+ * columns each (m360_encode_features_grouped / _ext_norm with bf16 = 3), the first-layer weights (model.py:44,132) are packed as
+ * [n_pad, 6 k_pad] = [Wh | Wm | Wl | Wh | Wm | Wh], and ONE plain bf16 contraction of length 6 k_pad forms
+ * xl wh + xm wm + xh wl + xm wh + xh wm + xh wh, small terms first, fp32 accumulation: the fp32 product up to 2^-24 terms.
+ * m360_linear_bf16 (bf16 rows out) runs it in the bf16 mode, m360_linear_bf16_split ([hi | lo] pair rows out, the row format of
+ * m360_linear_bf16x3; bias + {none, ReLU}) in the bf16x3 mode; 6 k_pad = 384 takes the one-wave ring kernel. */
+int m360_pack_linear_bf16x6(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
+                            void *w_packed6_bf16 /*[n_pad, 6 k_pad]*/, float *b_packed, m360_stream_t stream);
+int m360_linear_bf16_split(const void *x_bf16 /*[M, ldx >= k_pad]*/, long M, int ldx, const void *w_packed_bf16,
+                           const float *b_packed, int n_pad, int k_pad, int act, void *y_hi_lo_bf16 /*[M, ldy >= 2 n_pad]*/,
+                           int ldy, m360_stream_t stream);
+
 /* m360_encode_features writing bf16 rows */
 int m360_encode_features_bf16(const float *t_vals, const float *origins, const float *directions,
                               const float *radii, const float *vdenc, int vd_ch, int B, int N,
@@ -447,9 +463,11 @@ typedef struct {
     const float *nerf_head_w; /* [4,hn_pad]: final_density row, final_color rows */
     const float *nerf_head_b; /* [4] */
     int mlp_bf16; /* extension: 0 = fp32 MLP (default, the parity path); 1 = prop_w / nerf_w point to bf16
-                     weights from m360_pack_linear_bf16 (pads multiples of 64), features and hidden activations
+                     weights from m360_pack_linear_bf16 (pads multiples of 64), hidden activations
                      are bf16, accumulation / biases / heads stay fp32; 2 = "bf16x3": weights from
-                     m360_pack_linear_bf16x3, features and hidden activations as [hi | lo] bf16 pairs (m360_linear_bf16x3) */
+                     m360_pack_linear_bf16x3, hidden activations as [hi | lo] bf16 pairs (m360_linear_bf16x3).
+                     In BOTH modes prop_w[0] / nerf_w[0] (the first layers) are packed with m360_pack_linear_bf16x6 and the
+                     features are x6 rows (three bf16 terms per value, 12 in_pad bytes per sample): see "x6" above */
 } m360_model_t; /* packed form of the state_dict of model.py:43-53,131-158 */
 
 typedef struct {

@@ -88,6 +88,8 @@ SIGNATURES = {
     "m360_linear_bf16": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_pack_linear_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear_bf16x3": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "m360_pack_linear_bf16x6": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "m360_linear_bf16_split": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_encode_features_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "m360_prop_finish_bf16": (_i, [_vp, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_nerf_finish_bf16": (_i, [_vp, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

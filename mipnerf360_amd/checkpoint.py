@@ -57,7 +57,8 @@ def to_reference_state_dict(model) -> "OrderedDict[str, torch.Tensor]":
 def export_packed(model) -> Dict[str, np.ndarray]:
     """Packed weights exactly as the kernels read them (include/m360.h, m360_model_t): per layer a zero-padded
     [n_pad, k_pad] matrix (k contiguous; float32, or bf16 bit patterns as uint16 for mlp_dtype='bf16'; for
-    mlp_dtype='bf16x3' the [n_pad, 3 k_pad] = [Wh | Wh | Wl] layout of m360_pack_linear_bf16x3) and a [n_pad] fp32 bias;
+    mlp_dtype='bf16x3' the [n_pad, 3 k_pad] = [Wh | Wh | Wl] layout of m360_pack_linear_bf16x3; in both bf16 modes layer 0 is
+    the [n_pad, 6 in_pad] "x6" layout of m360_pack_linear_bf16x6) and a [n_pad] fp32 bias;
     heads as fp32 [H, h_pad] + [H]; meta[4] = m360_model_t.mlp_bf16 (0 / 1 / 2).  Needs a HIP device (packing runs in
     m360_pack_linear*)."""
     prop, nerf = model.prop_net._pack(), model.nerf_net._pack()

@@ -107,7 +107,8 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     L.t1 = take((size_t)B * (N + 1) * sizeof(float));
     L.t0 = take((size_t)B * (N + 1) * sizeof(float));
     L.what = take((size_t)B * N * sizeof(float));
-    L.feat = take(S * m->in_pad * sizeof(float));
+    // MLP input rows: fp32 [in_pad]; bf16 / bf16x3 modes: x6 rows of 6 in_pad bf16 (three bf16 terms per feature, see prop_stage)
+    L.feat = take(S * m->in_pad * (m->mlp_bf16 ? 6 * sizeof(unsigned short) : sizeof(float)));
     L.act_a = take(S * wmax * sizeof(float));
     L.act_b = take(S * wmax * sizeof(float));
     // partial head sums of the fused last layer: [S][slots][heads] fp32 (67 MB at 4096 x 128, width 1024)
@@ -152,6 +153,18 @@ static int validate(const m360_rays_t *r, const m360_model_t *m, const m360_hype
 static int p_linear(const m360_hyper_t *h, TileQueues *q, const float *x, long M, int ldx, const float *w, const float *b, int n_pad, int k_pad, int act, float *y, int ldy, m360_stream_t st) {
     ProfScope ps(h, st, M360_K_LINEAR, M, n_pad, k_pad);
     return ps.done(m360_linear_balanced(x, M, ldx, w, b, n_pad, k_pad, act, y, ldy, q->take(), st));
+}
+// First layer of the bf16 (mode 1) / bf16x3 (mode 2) MLP.  The encoder hands it "x6" rows - every feature as THREE bf16 terms,
+// all 24 bits - and the weights are packed the same way (m360_pack_linear_bf16x6), so one plain bf16 contraction of length
+// 6 in_pad forms the fp32 product up to 2^-24 terms; the output is the mode's own row format.  Why: the reference contracts a whole
+// chunk by its Frobenius norm (intern/parameterization.py:23-29), which squeezes a ray's samples into ~1e-2 of the unit ball, so a
+// net that resolves anything along a ray has first-layer gains of ~1e3-1e4 on DIFFERENCES of the sin / cos features: bf16
+// features (8 bits) put the density shells of fixture G19 at the wrong depth (PSNR off by 3-6 dB), two-term features (16 bits)
+// leave |d rgb| ~2e-4; with 24 bits both modes are back inside their tolerances.
+static int p_linear_first(const m360_hyper_t *h, int mode, const void *feat, long M, const void *w6, const float *b, int n_pad, int in_pad, void *y, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, 6 * in_pad);
+    if (mode == 2) return ps.done(m360_linear_bf16_split(feat, M, 6 * in_pad, w6, b, n_pad, 6 * in_pad, M360_ACT_RELU, y, 2 * n_pad, st));
+    return ps.done(m360_linear_bf16(feat, M, 6 * in_pad, w6, b, n_pad, 6 * in_pad, M360_ACT_RELU, y, n_pad, st));
 }
 // mode 1: bf16 rows of k_pad / n_pad columns; mode 2 (bf16x3): [hi | lo] rows of 2 k_pad / 2 n_pad columns
 static int p_linear_bf16(const m360_hyper_t *h, int mode, const void *x, long M, const void *w, const float *b, int n_pad, int k_pad, int act, void *y, m360_stream_t st) {
@@ -238,12 +251,12 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hp = m->hp_pad;
     if (ext_norm) {  // the caller supplies the (all-reduced) contraction norm; the layers below are shared
-        M360_TRY(p_encode_ext_norm(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));  /* mlp_bf16 = 0 / 1 / 2 selects the row format */
+        M360_TRY(p_encode_ext_norm(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16 ? 3 : 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));  /* row format: fp32, or x6 for both bf16 modes */
     }
     if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers; mode 2 = bf16x3: [hi | lo] pairs)
         const int mode = m->mlp_bf16;
-        if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, mode, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(p_linear_bf16(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, st));
+        if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 3, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_linear_first(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, a, st));
         M360_TRY(p_linear_bf16(h, mode, a, S, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, st));
         M360_TRY(p_linear_bf16(h, mode, b, S, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, st));
         // last hidden layer + head on the matrix pipe (full 256-row tiles; tail rows through y): ld of y = hp (bf16) / 2 hp ([hi | lo])
@@ -291,9 +304,9 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         M360_TRY(p_nerf_finish_fused(h, act[7], 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
     } else if (m->mlp_bf16) {
         const int mode = m->mlp_bf16;
-        if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, mode, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
-        else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, mode, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(p_linear_bf16(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, st));
+        if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 3, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
+        else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 3, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_linear_first(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, a, st));
         for (int layer = 1; layer < 7; ++layer) {
             M360_TRY(p_linear_bf16(h, mode, src, S, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, st));
             float *tmp = src; src = dst; dst = tmp;

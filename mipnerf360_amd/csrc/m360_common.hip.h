@@ -50,10 +50,25 @@ __device__ __forceinline__ float canon_nanf_(float v) { return v != v ? __builti
 // bf16x3 mode: an fp32 value as two bf16 terms, hi = bf16(v) (round to nearest even), lo = bf16(v - hi): 16 significant bits.
 // A product x w is then formed as xh wh + xl wh + xh wl on the bf16 MFMA with fp32 accumulation (the xl wl term, 2^-16 of
 // the product, is dropped).
-__device__ __forceinline__ __bf16 bf16_lo_(float v, __bf16 hi) { return (__bf16)(v - (float)hi); }
+// A non-finite hi carries the whole value: lo = 0 (Inf - Inf would make the second term NaN and turn an Inf activation into NaN
+// one layer earlier than the fp32 path does).
+__device__ __forceinline__ __bf16 bf16_lo_(float v, __bf16 hi) {
+    const float h = (float)hi;
+    return (__bf16)(__builtin_isfinite(h) ? v - h : 0.0f);
+}
 __device__ __forceinline__ void split_bf16_(float v, __bf16 &hi, __bf16 &lo) {
     hi = (__bf16)v;
     lo = bf16_lo_(v, hi);
+}
+// Three bf16 terms hi + mid + lo: all 24 significant bits of an fp32 value (v - hi and (v - hi) - mid are exact in fp32).  The
+// first layers of the bf16 / bf16x3 modes multiply such triples ("x6" rows, m360_linear.hip): six products
+// xl wh + xm wm + xh wl + xm wh + xh wm + xh wh on the bf16 MFMA with fp32 accumulation give the fp32 product up to 2^-24 terms.
+__device__ __forceinline__ void split3_bf16_(float v, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
+    hi = (__bf16)v;
+    const float h = (float)hi;
+    const float r = __builtin_isfinite(h) ? v - h : 0.0f;
+    mid = (__bf16)r;
+    lo = (__bf16)(r - (float)mid);
 }
 // value returned by the reference's g() on its `calls`-th application to the same tensor
 __device__ __forceinline__ float g_calls(float x, int calls) {

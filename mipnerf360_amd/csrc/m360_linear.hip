@@ -239,9 +239,11 @@ __global__ void pack_linear_kernel(const float *__restrict__ w, const float *__r
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long)n_pad * k_pad) {
         const int n = (int)(idx / k_pad), k = (int)(idx % k_pad);
-        wp[idx] = (n < n_out && k < k_in) ? w[(long)n * k_in + k] : 0.0f;
+        // NaN parameters are packed as +NaN (0x7FC00000): the ReLU epilogues keep exactly the NaNs with a clear sign bit
+        // (relu_nanf_), and a checkpoint may hold -NaN (x86's 0/0) where nn.ReLU propagates every NaN
+        wp[idx] = (n < n_out && k < k_in) ? canon_nanf_(w[(long)n * k_in + k]) : 0.0f;
     }
-    if (bp != nullptr && idx < n_pad) bp[idx] = (b != nullptr && idx < n_out) ? b[idx] : 0.0f;
+    if (bp != nullptr && idx < n_pad) bp[idx] = (b != nullptr && idx < n_out) ? canon_nanf_(b[idx]) : 0.0f;
 }
 
 int launch_colsum(const float *in, long R, int C, int ld, float *scratch, int slices, float *out, hipStream_t st) {
@@ -665,6 +667,49 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
         }
     }
     return check_launch("linear_bf16");
+}
+
+int m360_pack_linear_bf16x6(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed6,
+                            float *b_packed, m360_stream_t stream) {
+    if (!w || !w_packed6 || n_out < 1 || k_in < 1 || n_pad < n_out || k_pad < k_in || k_pad % pbf16::BK != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_pack_linear_bf16x6: n_pad=%d >= n_out=%d, k_pad=%d >= k_in=%d (multiple of %d)", n_pad, n_out, k_pad, k_in, pbf16::BK);
+    const long n = (long)n_pad * k_pad;
+    hipLaunchKernelGGL(pbf16::pack_linear_bf16x6_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, b, n_out, k_in, n_pad, k_pad, static_cast<__bf16 *>(w_packed6), b_packed);
+    return check_launch("pack_linear_bf16x6");
+}
+
+// plain bf16 rows in, [hi | lo] pair rows out: the x6 first layer of the bf16x3 mode (K = 6 in_pad = 384: the one-wave ring kernel's
+// plain K loop with the split epilogue); any other shape on the generic kernel
+int m360_linear_bf16_split(const void *x, long M, int ldx, const void *w_packed, const float *b_packed, int n_pad, int k_pad,
+                           int act, void *y, int ldy, m360_stream_t stream) {
+    if (!x || !w_packed || !b_packed || !y || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: null pointer or negative M");
+    if (n_pad < 1 || k_pad < pbf16::BK || k_pad % pbf16::BK != 0 || ldx < k_pad || ldy < 2 * n_pad || ldx % 8 != 0 || ldy % 8 != 0 || n_pad % 8 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad, ldy=%d >= 2 n_pad=%d, all multiples of 8", k_pad, pbf16::BK, ldx, ldy, 2 * n_pad);
+    if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: pointers must be 16-byte aligned");
+    if (act != M360_ACT_NONE && act != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: activation %d (none or ReLU)", act);
+    if (M == 0) return M360_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const __bf16 *xb = static_cast<const __bf16 *>(x), *wb = static_cast<const __bf16 *>(w_packed);
+    __bf16 *yb = static_cast<__bf16 *>(y);
+    const bool ring = n_pad % w16::BN == 0 && n_pad <= w16::kMaxBias && k_pad % (2 * w16::BKS) == 0 && k_pad >= M360_W16_MIN_K;
+    const long M_full = ring ? (M / w16::BM) * w16::BM : 0;
+    if (M_full > 0) {
+        const int cus = cu_count();
+        if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear_bf16_split: no HIP device");
+        const long nt = (M_full / w16::BM) * (n_pad / w16::BN);
+        dim3 grid((unsigned)(nt < cus ? nt : cus)), block(w16::kThreads);
+        if (act == M360_ACT_RELU) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, false, false, 0, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
+        else hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_NONE, 0, false, false, false, 0, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
+    }
+    if (M > M_full) {
+        const long Mt = M - M_full;
+        dim3 grid((unsigned)((n_pad + 31) / 32), (unsigned)((Mt + 31) / 32)), block(64);
+        const __bf16 *xt = xb + M_full * ldx;
+        __bf16 *yt = yb + M_full * ldy;
+        if (act == M360_ACT_RELU) hipLaunchKernelGGL((pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_RELU, false, true>), grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k_pad, yt, ldy);
+        else hipLaunchKernelGGL((pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_NONE, false, true>), grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k_pad, yt, ldy);
+    }
+    return check_launch("linear_bf16_split");
 }
 
 int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed3,

@@ -243,7 +243,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_mfma_persist_kernel(
 // Generic (slow, any shape) bf16 kernel for ragged rows / narrow layers: one wave per 32 x 32 output block,
 // operands straight from global memory (16 B per lane per MFMA), rows clamped, stores predicated.
 // X3: the bf16x3 contraction of m360_linear_bf16_pp.hip.h (Kp = 3K, activation column wraps at 2K, output [hi(Np) | lo(Np)]).
-template <int ACT, bool X3 = false>
+// SPLIT: a plain contraction over bf16 rows whose output is written as [hi(Np) | lo(Np)] (m360_linear_bf16_split: the x6 first
+// layer of the bf16x3 mode).
+template <int ACT, bool X3 = false, bool SPLIT = X3>
 __global__ __launch_bounds__(64) void linear_bf16_mfma_simple_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias,
     int Np, int Kp, __bf16 *__restrict__ Y, int ldy) {
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(64) void linear_bf16_mfma_simple_kernel(
         const long row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < M) {
             const float v = act_fn<ACT>(acc[r] + bj);
-            if (X3) {
+            if (SPLIT) {
                 __bf16 hi, lo;
                 split_bf16_(v, hi, lo);
                 Y[row * ldy + col] = hi;
@@ -291,7 +293,7 @@ __global__ void pack_linear_bf16x3_kernel(const float *__restrict__ w, const flo
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long)n_pad * k_pad) {
         const int n = (int)(idx / k_pad), k = (int)(idx % k_pad);
-        const float v = (n < n_out && k < k_in) ? w[(long)n * k_in + k] : 0.0f;
+        const float v = (n < n_out && k < k_in) ? canon_nanf_(w[(long)n * k_in + k]) : 0.0f;
         __bf16 hi, lo;
         split_bf16_(v, hi, lo);
         __bf16 *row = wp + (long)n * 3 * k_pad;
@@ -299,7 +301,29 @@ __global__ void pack_linear_bf16x3_kernel(const float *__restrict__ w, const flo
         row[k_pad + k] = hi;
         row[2 * k_pad + k] = lo;
     }
-    if (bp != nullptr && idx < n_pad) bp[idx] = (b != nullptr && idx < n_out) ? b[idx] : 0.0f;
+    if (bp != nullptr && idx < n_pad) bp[idx] = (b != nullptr && idx < n_out) ? canon_nanf_(b[idx]) : 0.0f;
+}
+
+// "x6" weights of a first layer: [n_pad, 6 k_pad] = [Wh | Wm | Wl | Wh | Wm | Wh] (three bf16 terms per weight, split3_bf16_),
+// the blocks matched to the encoder's x6 rows [xl | xm | xh | xm | xh | xh]: one plain bf16 contraction of length 6 k_pad forms
+// xl wh + xm wm + xh wl + xm wh + xh wm + xh wh, small terms first
+__global__ void pack_linear_bf16x6_kernel(const float *__restrict__ w, const float *__restrict__ b, int n_out, int k_in,
+                                          int n_pad, int k_pad, __bf16 *__restrict__ wp, float *__restrict__ bp) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)n_pad * k_pad) {
+        const int n = (int)(idx / k_pad), k = (int)(idx % k_pad);
+        const float v = (n < n_out && k < k_in) ? canon_nanf_(w[(long)n * k_in + k]) : 0.0f;
+        __bf16 hi, mid, lo;
+        split3_bf16_(v, hi, mid, lo);
+        __bf16 *row = wp + (long)n * 6 * k_pad + k;
+        row[0] = hi;
+        row[k_pad] = mid;
+        row[2 * k_pad] = lo;
+        row[3 * k_pad] = hi;
+        row[4 * k_pad] = mid;
+        row[5 * k_pad] = hi;
+    }
+    if (bp != nullptr && idx < n_pad) bp[idx] = (b != nullptr && idx < n_out) ? canon_nanf_(b[idx]) : 0.0f;
 }
 
 __global__ void pack_linear_bf16_kernel(const float *__restrict__ w, const float *__restrict__ b, int n_out, int k_in,
@@ -307,9 +331,9 @@ __global__ void pack_linear_bf16_kernel(const float *__restrict__ w, const float
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long)n_pad * k_pad) {
         const int n = (int)(idx / k_pad), k = (int)(idx % k_pad);
-        wp[idx] = (__bf16)((n < n_out && k < k_in) ? w[(long)n * k_in + k] : 0.0f);
+        wp[idx] = (__bf16)((n < n_out && k < k_in) ? canon_nanf_(w[(long)n * k_in + k]) : 0.0f);
     }
-    if (bp != nullptr && idx < n_pad) bp[idx] = (b != nullptr && idx < n_out) ? b[idx] : 0.0f;
+    if (bp != nullptr && idx < n_pad) bp[idx] = (b != nullptr && idx < n_out) ? canon_nanf_(b[idx]) : 0.0f;
 }
 
 }  // namespace pbf16

@@ -83,16 +83,19 @@ __device__ unsigned long long g_w16_stamps[256 * 4];
 // (the rendering forward; the tape-keeping one stays on the ping-pong kernel).  The sigmoid is exposed here (11.5 k cycles of epilogue
 // per tile instead of 5.4 k), and still the layer takes 0.85 ms against 1.08-1.12 ms (tools/linear_bench.py --variant 150).
 constexpr int kHeadMaxN = 1024;  // widest layer the fused heads take (their hi / lo rows live in 16 KiB of LDS)
-template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0>
+// SPLIT (defaults to X3): the output rows are [hi(Np) | lo(Np)] pairs.  SPLIT without X3 is the x6 first layer of the bf16x3 mode
+// (m360_linear_bf16_split): a plain contraction over bf16 rows whose fp32 result goes out as two bf16 terms.
+template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0, bool SPLIT = X3>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, const float *__restrict__ head_w = nullptr,
     float *__restrict__ head_part = nullptr) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0)];  // 144 (160) KiB
     static_assert(HEADS == 0 || HEADS == 1 || HEADS == 4, "1 (proposal) or 4 (NeRF) heads");
+    static_assert(SPLIT == X3 || (SPLIT && !X3 && HEADS == 0), "split output without the X3 loop: hidden-layer epilogue only");
     constexpr bool STORE_Y = HEADS == 0;
     // vector-memory operations of a tile's epilogue: 32 whole-line stores (64 as [hi | lo]) or, with fused heads, 8 partial-sum stores
-    constexpr int W16_STORES = STORE_Y ? (X3 ? 64 : 32) : 8;
+    constexpr int W16_STORES = STORE_Y ? (SPLIT ? 64 : 32) : 8;
     static_assert(ACT == M360_ACT_NONE || ACT == M360_ACT_RELU || (ACT == M360_ACT_SIGMOID && (ABL != 0 || HEADS > 0)), "bias + {none, ReLU}; sigmoid with fused heads");
 
     const int tid = threadIdx.x;
@@ -363,16 +366,16 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
 #define W16_PACK(e, a0, a1, bb_, be)                                                                           \
     do {                                                                                                       \
         f32x2 t_ = {a0 + bb_[be], a1 + bb_[(be) + 1]};                                                         \
-        if (X3 && ACT == M360_ACT_RELU) { t_[0] = relu_nanf_(t_[0]); t_[1] = relu_nanf_(t_[1]); }              \
+        if (SPLIT && ACT == M360_ACT_RELU) { t_[0] = relu_nanf_(t_[0]); t_[1] = relu_nanf_(t_[1]); }              \
         if (ACT == M360_ACT_SIGMOID) {                                                                         \
             t_[0] = __builtin_amdgcn_rcpf(1.0f + __expf(-t_[0]));                                              \
             t_[1] = __builtin_amdgcn_rcpf(1.0f + __expf(-t_[1]));                                              \
         }                                                                                                      \
         const bf16x2 h_ = __builtin_convertvector(t_, bf16x2);                                                 \
         s16x2 p_ = __builtin_bit_cast(s16x2, h_);                                                              \
-        if (!X3 && ACT == M360_ACT_RELU) p_ = __builtin_elementwise_max(p_, (s16x2){0, 0});                    \
+        if (!SPLIT && ACT == M360_ACT_RELU) p_ = __builtin_elementwise_max(p_, (s16x2){0, 0});                    \
         ab[h][e] = __builtin_bit_cast(unsigned, p_);                                                           \
-        if (X3) {                                                                                              \
+        if (SPLIT) {                                                                                           \
             const f32x2 r_ = {t_[0] - (float)h_[0], t_[1] - (float)h_[1]};                                     \
             lo[h][e] = __builtin_bit_cast(unsigned, __builtin_convertvector(r_, bf16x2));                      \
         }                                                                                                      \
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                     if (STORE_Y) {
                         const __bf16 *row = yt + (long)(16 * i) * ldy + 64 * P;
                         W16_SWAP_STORE(ab[0], ab[1], row);
-                        if (X3) W16_SWAP_STORE(lo[0], lo[1], row + Np);  // the second terms: columns [Np, 2 Np)
+                        if (SPLIT) W16_SWAP_STORE(lo[0], lo[1], row + Np);  // the second terms: columns [Np, 2 Np)
                     }
 #undef W16_SWAP_STORE
                     if (HEADS) {  // D[head][row] += over each piece's 32 columns: hi and lo head terms (X3: and the lo activations)

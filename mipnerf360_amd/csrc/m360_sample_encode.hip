@@ -352,8 +352,9 @@ __device__ __forceinline__ void wave_sync_lds() {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-// BF16: 0 = fp32 rows, 1 = bf16 rows (opt-in reduced-precision MLP), 2 = bf16x3 mode: rows [hi(ld) | lo(ld)], two bf16 terms
-// per value (split_bf16_)
+// BF16: 0 = fp32 rows, 1 = bf16 rows, 2 = rows [hi(ld) | lo(ld)], two bf16 terms per value (split_bf16_), 3 = "x6" rows
+// [lo | mid | hi | mid | hi | hi] of ld columns each, three bf16 terms per value (split3_bf16_): the MLP input of the bf16 and
+// bf16x3 modes since round 4 - their first layers multiply all 24 bits of every feature (m360_pack_linear_bf16x6)
 template <int BF16>
 __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
     const float *__restrict__ t_vals, const float *__restrict__ origins,
@@ -388,19 +389,35 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
         }
     } else {
         const long total8 = rows * ld / 8;
-        const int ldo = BF16 == 2 ? 2 * ld : ld;
+        const int ldo = BF16 == 3 ? 6 * ld : (BF16 == 2 ? 2 * ld : ld);
         __bf16 *outb = static_cast<__bf16 *>(feat_out) + s0 * ldo;
         for (long q = threadIdx.x; q < total8; q += kEncThreads) {
             const int r = (int)((q * 8) / ld), col = (int)((q * 8) % ld);
             const float *src = tile + r * lds_ld + col;
-            bf16x8_t o, lo;
+            bf16x8_t o, lo, mid;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                o[e] = (__bf16)src[e];
-                if (BF16 == 2) lo[e] = bf16_lo_(src[e], o[e]);
+                if (BF16 == 3) {
+                    __bf16 h_, m_, l_;
+                    split3_bf16_(src[e], h_, m_, l_);
+                    o[e] = h_, mid[e] = m_, lo[e] = l_;
+                } else {
+                    o[e] = (__bf16)src[e];
+                    if (BF16 == 2) lo[e] = bf16_lo_(src[e], o[e]);
+                }
             }
-            *reinterpret_cast<bf16x8_t *>(outb + (long)r * ldo + col) = o;
-            if (BF16 == 2) *reinterpret_cast<bf16x8_t *>(outb + (long)r * ldo + ld + col) = lo;
+            __bf16 *dst = outb + (long)r * ldo + col;
+            if (BF16 == 3) {
+                *reinterpret_cast<bf16x8_t *>(dst) = lo;
+                *reinterpret_cast<bf16x8_t *>(dst + ld) = mid;
+                *reinterpret_cast<bf16x8_t *>(dst + 2 * ld) = o;
+                *reinterpret_cast<bf16x8_t *>(dst + 3 * ld) = mid;
+                *reinterpret_cast<bf16x8_t *>(dst + 4 * ld) = o;
+                *reinterpret_cast<bf16x8_t *>(dst + 5 * ld) = o;
+            } else {
+                *reinterpret_cast<bf16x8_t *>(dst) = o;
+                if (BF16 == 2) *reinterpret_cast<bf16x8_t *>(dst + ld) = lo;
+            }
         }
     }
 }
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kern
                 if (r < rows) *reinterpret_cast<float4 *>(out + (long)r * ld + col) = *reinterpret_cast<const float4 *>(tile + r * kEncTileLd + col);
             }
         } else {      // 4 lanes x 16 B (8 bf16) = one 64-byte row segment; 16 rows per instruction
-            constexpr int ldo = BF16 == 2 ? 2 * ld : ld;  // bf16x3 mode: [hi(ld) | lo(ld)]
+            constexpr int ldo = BF16 == 3 ? 6 * ld : (BF16 == 2 ? 2 * ld : ld);  // [hi | lo] pairs / x6 rows
             __bf16 *out = static_cast<__bf16 *>(feat_out) + s0 * ldo + 32 * p;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -470,15 +487,31 @@ __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kern
                 const float4 lo = *reinterpret_cast<const float4 *>(tile + r * kEncTileLd + col);
                 const float4 hi = *reinterpret_cast<const float4 *>(tile + r * kEncTileLd + col + 4);
                 const float e8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                bf16x8_t o, l2;
+                bf16x8_t o, l2, m2;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    o[e] = (__bf16)e8[e];
-                    if (BF16 == 2) l2[e] = bf16_lo_(e8[e], o[e]);
+                    if (BF16 == 3) {
+                        __bf16 h_, m_, l_;
+                        split3_bf16_(e8[e], h_, m_, l_);
+                        o[e] = h_, m2[e] = m_, l2[e] = l_;
+                    } else {
+                        o[e] = (__bf16)e8[e];
+                        if (BF16 == 2) l2[e] = bf16_lo_(e8[e], o[e]);
+                    }
                 }
                 if (r < rows) {
-                    *reinterpret_cast<bf16x8_t *>(out + (long)r * ldo + col) = o;
-                    if (BF16 == 2) *reinterpret_cast<bf16x8_t *>(out + (long)r * ldo + ld + col) = l2;
+                    __bf16 *dst = out + (long)r * ldo + col;
+                    if (BF16 == 3) {  // [lo | mid | hi | mid | hi | hi]: the order the first layer accumulates its six products in
+                        *reinterpret_cast<bf16x8_t *>(dst) = l2;
+                        *reinterpret_cast<bf16x8_t *>(dst + ld) = m2;
+                        *reinterpret_cast<bf16x8_t *>(dst + 2 * ld) = o;
+                        *reinterpret_cast<bf16x8_t *>(dst + 3 * ld) = m2;
+                        *reinterpret_cast<bf16x8_t *>(dst + 4 * ld) = o;
+                        *reinterpret_cast<bf16x8_t *>(dst + 5 * ld) = o;
+                    } else {
+                        *reinterpret_cast<bf16x8_t *>(dst) = o;
+                        if (BF16 == 2) *reinterpret_cast<bf16x8_t *>(dst + ld) = l2;
+                    }
                 }
             }
         }
@@ -700,6 +733,7 @@ static int encode_features_any(const float *t_vals, const float *origins, const 
     if (!t_vals || !origins || !directions || !radii || !feat || B < 0 || N < 1 || vd_ch < 0 || (vd_ch > 0 && !vdenc))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: bad argument");
     if (ld_feat % 32 != 0 || ld_feat < kIpeCh + vd_ch) return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: ld_feat=%d must be a multiple of 32 and >= %d", ld_feat, kIpeCh + vd_ch);
+    if (bf16 < 0 || bf16 > 3) return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: row format %d (0 fp32, 1 bf16, 2 [hi | lo], 3 x6)", bf16);
     if (!workspace || workspace_bytes < sizeof(NormScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_encode_features: workspace %zu < %zu", workspace_bytes, sizeof(NormScratch));
     if (B == 0) return M360_OK;
     NormScratch *ws = static_cast<NormScratch *>(workspace);
@@ -707,13 +741,14 @@ static int encode_features_any(const float *t_vals, const float *origins, const 
     if (ld_feat == 64 || ld_feat == 96) {  // every model of the path: wave-tiled kernel
         const dim3 grid(blocks_for((long)B * N, kEncWaves * kWave)), block(kEncWaves * kWave);
 #define M360_ENC(BF, NP) hipLaunchKernelGGL((encode_features_wave_kernel<BF, NP>), grid, block, 0, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, group_rays, ext_norm)
-        if (ld_feat == 64) { if (bf16 == 2) M360_ENC(2, 2); else if (bf16) M360_ENC(1, 2); else M360_ENC(0, 2); }
-        else { if (bf16 == 2) M360_ENC(2, 3); else if (bf16) M360_ENC(1, 3); else M360_ENC(0, 3); }
+        if (ld_feat == 64) { if (bf16 == 3) M360_ENC(3, 2); else if (bf16 == 2) M360_ENC(2, 2); else if (bf16) M360_ENC(1, 2); else M360_ENC(0, 2); }
+        else { if (bf16 == 3) M360_ENC(3, 3); else if (bf16 == 2) M360_ENC(2, 3); else if (bf16) M360_ENC(1, 3); else M360_ENC(0, 3); }
 #undef M360_ENC
         return check_launch("encode_features");
     }
     const size_t lds = (size_t)kEncThreads * (ld_feat + 1) * sizeof(float);
-    if (bf16 == 2) hipLaunchKernelGGL(encode_features_kernel<2>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
+    if (bf16 == 3) hipLaunchKernelGGL(encode_features_kernel<3>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
+    else if (bf16 == 2) hipLaunchKernelGGL(encode_features_kernel<2>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
     else if (bf16) hipLaunchKernelGGL(encode_features_kernel<1>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
     else hipLaunchKernelGGL(encode_features_kernel<0>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
     return check_launch("encode_features");

@@ -114,7 +114,10 @@ class _PackedMLP:
         pack = {0: ops.pack_linear, 1: ops.pack_linear_bf16, 2: ops.pack_linear_bf16x3}[bf16]
         self.w, self.b = [], []
         for i, lin in enumerate(hidden_layers):
-            wp, bp = pack(lin.weight, lin.bias, self.h_pad, self.in_pad if i == 0 else self.h_pad)
+            if i == 0 and bf16:  # both reduced-precision modes: the first layer multiplies all 24 bits of features and weights ("x6")
+                wp, bp = ops.pack_linear_bf16x6(lin.weight, lin.bias, self.h_pad, self.in_pad)
+            else:
+                wp, bp = pack(lin.weight, lin.bias, self.h_pad, self.in_pad if i == 0 else self.h_pad)
             self.w.append(wp), self.b.append(bp)
         hw = torch.cat([h.weight.detach() for h in heads], 0).float()
         hb = torch.cat([h.bias.detach() for h in heads], 0).float().contiguous()
@@ -487,9 +490,12 @@ class mipNeRF360(nn.Module):
         `num_samples_fine`: number of NeRF-stage samples per ray when it should differ from the proposal count
         ("64+128" rendering, BASELINE configs[2]); None keeps the reference's behaviour (equal counts);
         `mlp_dtype`: "fp32" (default: exact-fp32 MFMA, the parity path), "bf16" (BASELINE configs[4]: bf16
-        weights / features / hidden activations, fp32 accumulation, heads and ray math in fp32) or "bf16x3" (every
+        weights / hidden activations, fp32 accumulation, heads and ray math in fp32) or "bf16x3" (every
         value carried as two bf16 terms, products formed as xh wh + xl wh + xh wl on the bf16 MFMA with fp32
-        accumulation: within the fp32 render tolerance of 1e-4 at about 3x the fp32 rays/s; forward only)."""
+        accumulation: within the fp32 render tolerance of 1e-4 at about 3x the fp32 rays/s; forward only).  In both
+        reduced-precision modes the FIRST layers (model.py:44,132) see all 24 bits of the encoded features and of their
+        weights (three bf16 terms each, six products: include/m360.h "x6") - positions inside a contracted chunk differ
+        in their low-order bits only."""
         super().__init__()
         self.randomized = randomized
         self.num_samples = num_samples

@@ -207,17 +207,26 @@ def viewdir_enc(viewdirs, min_deg: int, max_deg: int) -> torch.Tensor:
     return enc
 
 
-def encode_features(t_vals, origins, directions, radii, vdenc, ld_feat: Optional[int] = None) -> torch.Tensor:
+def encode_features(t_vals, origins, directions, radii, vdenc, ld_feat: Optional[int] = None, row_format: int = 0) -> torch.Tensor:
+    """MLP input rows of one chunk (model.py:82-88).  row_format 0: fp32 [S, ld]; 1: bf16 [S, ld]; 2: bf16 [hi | lo] pairs
+    [S, 2 ld]; 3: bf16 "x6" rows [S, 6 ld] = [lo | mid | hi | mid | hi | hi] (what the bf16 / bf16x3 MLPs read)."""
     t_vals, origins = dev(t_vals, "t_vals"), dev(origins, "origins")
     directions, radii, vdenc = dev(directions, "directions"), dev(radii, "radii"), dev(vdenc, "vdenc")
     B, M = t_vals.shape
     N = M - 1
     vd_ch = vdenc.shape[-1]
     ld = ld_feat or round_up(IPE_CH + vd_ch)
-    feat = torch.empty(B * N, ld, device=t_vals.device)
     ws = _ws(t_vals.device)
-    _call("m360_encode_features", t_vals, origins, directions, radii, vdenc, vd_ch, B, N,
-          feat, ld, ws, ws.numel(), STREAM)
+    if row_format == 0:
+        feat = torch.empty(B * N, ld, device=t_vals.device)
+        _call("m360_encode_features", t_vals, origins, directions, radii, vdenc, vd_ch, B, N,
+              feat, ld, ws, ws.numel(), STREAM)
+        return feat
+    if row_format not in (1, 2, 3):
+        raise ValueError(f"encode_features: row_format {row_format}")
+    feat = torch.empty(B * N, {1: 1, 2: 2, 3: 6}[row_format] * ld, device=t_vals.device, dtype=torch.bfloat16)
+    _call("m360_encode_features_grouped", t_vals, origins, directions, radii, vdenc, vd_ch, B, N, feat, ld, row_format, 0,
+          ws, ws.numel(), STREAM)
     return feat
 
 
@@ -369,6 +378,41 @@ def linear_bf16x3(x, w_packed3, b_packed, act: int = _lib.ACT_NONE, out: Optiona
         raise RuntimeError(f"linear_bf16x3: x has {ldx} columns, packed weight expects {2 * k_pad} (hi | lo)")
     y = out if out is not None else torch.empty(M, 2 * n_pad, device=x.device, dtype=torch.bfloat16)
     _call("m360_linear_bf16x3", x, M, ldx, w_packed3, b_packed, n_pad, k_pad, act, y, y.shape[1], STREAM)
+    return y
+
+
+def pack_linear_bf16x6(weight, bias=None, n_pad: Optional[int] = None, k_pad: Optional[int] = None):
+    """fp32 Linear -> "x6" packing [n_pad, 6 k_pad] = [Wh | Wm | Wl | Wh | Wm | Wh] (three bf16 terms per weight: all 24 bits)
+    + fp32 bias: the first layers of the bf16 / bf16x3 modes (include/m360.h, m360_pack_linear_bf16x6)."""
+    weight = dev(weight.detach(), "weight")
+    n_out, k_in = weight.shape
+    n_pad, k_pad = n_pad or round_up(n_out, 64), k_pad or round_up(k_in, 64)
+    wp = torch.empty(n_pad, 6 * k_pad, device=weight.device, dtype=torch.bfloat16)
+    bp = torch.empty(n_pad, device=weight.device)
+    b = None if bias is None else dev(bias.detach(), "bias")
+    _call("m360_pack_linear_bf16x6", weight, b, n_out, k_in, n_pad, k_pad, wp, bp, STREAM)
+    return wp, bp
+
+
+def split_bf16x6(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [M, K] -> the x6 rows [M, 6 K] = [lo | mid | hi | mid | hi | hi] the first layers read (what the encoder writes on the
+    device with row format 3; this host-side form is for tests and tools)."""
+    hi = x.bfloat16()
+    r = torch.where(torch.isfinite(hi.float()), x - hi.float(), torch.zeros_like(x))
+    mid = r.bfloat16()
+    lo = (r - mid.float()).bfloat16()
+    return torch.cat([lo, mid, hi, mid, hi, hi], 1).contiguous()
+
+
+def linear_bf16_split(x, w_packed, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 x [M, k_pad] * bf16 W^T + fp32 bias -> [M, 2 n_pad] bf16 (hi | lo) pair rows (m360_linear_bf16_split)."""
+    x, w_packed, b_packed = dev_bf16(x, "x"), dev_bf16(w_packed, "w_packed"), dev(b_packed, "b_packed")
+    M, ldx = x.shape
+    n_pad, k_pad = w_packed.shape
+    if ldx != k_pad:
+        raise RuntimeError(f"linear_bf16_split: x has {ldx} columns, packed weight expects {k_pad}")
+    y = out if out is not None else torch.empty(M, 2 * n_pad, device=x.device, dtype=torch.bfloat16)
+    _call("m360_linear_bf16_split", x, M, ldx, w_packed, b_packed, n_pad, k_pad, act, y, y.shape[1], STREAM)
     return y
 
 

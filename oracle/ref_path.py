@@ -334,17 +334,35 @@ def _lin16x3(x, sd, prefix):
     return (xh @ wh.t() + xl @ wh.t() + xh @ wl.t()) + sd[prefix + ".bias"]
 
 
+def _split16x3(x):
+    """three bf16 terms hi + mid + lo = all 24 bits of an fp32 value (a non-finite hi carries the whole value)"""
+    hi = _r16(x)
+    r = torch.where(torch.isfinite(hi), x - hi, torch.zeros_like(x))
+    mid = _r16(r)
+    return hi, mid, _r16(r - mid)
+
+
+def _lin16x6(x, sd, prefix):
+    """first layer of the build's bf16 / bf16x3 modes ("x6", include/m360.h): features and weights as three bf16 terms each, six
+    exact bf16 products xl wh + xm wm + xh wl + xm wh + xh wm + xh wh with fp32 accumulation, fp32 bias - the fp32 product up to
+    2^-24 terms"""
+    xh, xm, xl = _split16x3(x)
+    wh, wm, wl = _split16x3(sd[prefix + ".weight"])
+    return (xl @ wh.t() + xm @ wm.t() + xh @ wl.t() + xm @ wh.t() + xh @ wm.t() + xh @ wh.t()) + sd[prefix + ".bias"]
+
+
 def prop_mlp(x, sd, bf16=False):
     """model.py:43-53.  bf16=True emulates the reduced-precision extension (hidden activations stored as bf16), bf16=2 the
-    bf16x3 extension (two bf16 terms per value, three products per multiply)."""
+    bf16x3 extension (two bf16 terms per value, three products per multiply); in both the first layer is `_lin16x6`."""
     if bf16 == 2:
-        for i in (0, 2, 4):
+        x = _x3(torch.relu(_lin16x6(x, sd, "prop_net.model.0")))
+        for i in (2, 4):
             x = _x3(torch.relu(_lin16x3(x, sd, f"prop_net.model.{i}")))
         x = _x3(torch.sigmoid(_lin16x3(x, sd, "prop_net.model.6")))
         return _lin(x, sd, "prop_net.model.8")
     if bf16:
-        x = _r16(x)
-        for i in (0, 2, 4):
+        x = _r16(torch.relu(_lin16x6(x, sd, "prop_net.model.0")))
+        for i in (2, 4):
             x = _r16(torch.relu(_lin16(x, sd, f"prop_net.model.{i}")))
         x = _r16(torch.sigmoid(_lin16(x, sd, "prop_net.model.6")))
         return _lin(x, sd, "prop_net.model.8")
@@ -357,12 +375,13 @@ def prop_mlp(x, sd, bf16=False):
 def nerf_mlp(x, sd, bf16=False):
     """model.py:131-158 (bf16: see prop_mlp)."""
     if bf16 == 2:
-        for i in range(0, 14, 2):
+        x = _x3(torch.relu(_lin16x6(x, sd, "nerf_net.model.0")))
+        for i in range(2, 14, 2):
             x = _x3(torch.relu(_lin16x3(x, sd, f"nerf_net.model.{i}")))
         x = _x3(torch.sigmoid(_lin16x3(x, sd, "nerf_net.model.14")))
     elif bf16:
-        x = _r16(x)
-        for i in range(0, 14, 2):
+        x = _r16(torch.relu(_lin16x6(x, sd, "nerf_net.model.0")))
+        for i in range(2, 14, 2):
             x = _r16(torch.relu(_lin16(x, sd, f"nerf_net.model.{i}")))
         x = _r16(torch.sigmoid(_lin16(x, sd, "nerf_net.model.14")))
     else:

@@ -304,6 +304,66 @@ def test_g9_render_image_bf16x3(golden, dev, chunks):
     close(dist, g[f"c{chunks}_dist"], atol=1e-4, rtol=1e-4)
 
 
+# =============================================================================== x6: first layers of the bf16 modes
+def test_x6_feature_rows_and_weight_packing(dev):
+    """Row format 3 of the encoder and m360_pack_linear_bf16x6: three bf16 terms per value (exact: hi + mid + lo == the fp32
+    value), blocks in the order [lo | mid | hi | mid | hi | hi] / [Wh | Wm | Wl | Wh | Wm | Wh]."""
+    from mipnerf360_amd import ops
+    r = synthetic.make_rays("lego", 70, seed=41)
+    rays = dev_rays(r, dev)
+    n = 24
+    t = ops.sample_t(rays.near, rays.far, n)
+    vd = ops.viewdir_enc(rays.viewdirs, 0, 4)
+    f32 = ops.encode_features(t, rays.origins, rays.directions, rays.radii, vd, 64)
+    x6 = ops.encode_features(t, rays.origins, rays.directions, rays.radii, vd, 64, row_format=3)
+    assert x6.shape == (70 * n, 384) and x6.dtype == torch.bfloat16
+    assert torch.equal(x6, ops.split_bf16x6(f32))
+    lo, mid, hi = x6[:, :64].float(), x6[:, 64:128].float(), x6[:, 128:192].float()
+    assert torch.equal(hi + mid + lo, f32)                     # all 24 bits
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(200, 58, generator=g) * 3).to(dev)
+    b = torch.randn(200, generator=g).to(dev)
+    w[3, 7] = float("inf")
+    wp, bp = ops.pack_linear_bf16x6(w, b, 256, 64)
+    assert wp.shape == (256, 384) and torch.equal(bp[:200], b) and float(bp[200:].abs().max()) == 0.0
+    wh, wm, wl = wp[:, :64].float(), wp[:, 64:128].float(), wp[:, 128:192].float()
+    assert torch.equal(wp[:, 192:256].float(), wh) and torch.equal(wp[:, 256:320].float(), wm) and torch.equal(wp[:, 320:].float(), wh)
+    ref = torch.zeros(256, 64, device=dev)
+    ref[:200, :58] = w
+    fin = torch.isfinite(ref)
+    assert torch.equal((wh + wm + wl)[fin], ref[fin]) and wh[3, 7] == float("inf") and wm[3, 7] == 0 and wl[3, 7] == 0
+
+
+@pytest.mark.parametrize("M,n_out", [(700, 256), (256 * 5 + 33, 1024), (90, 96)])
+@pytest.mark.parametrize("split", [False, True])
+def test_x6_first_layer_is_an_fp32_product(dev, M, n_out, split):
+    """The x6 first layer (m360_linear_bf16 / m360_linear_bf16_split on x6 rows and x6 weights, K = 384: full tiles on the ring
+    kernel's plain K loop, ragged rows on the generic kernel) against the fp64 product of the fp32 operands: fp32-level error
+    (<= 2e-6 of the row's sum of |x w| + |b|), where bf16 features alone are 1e-3 and two-term features 1e-5 away."""
+    from mipnerf360_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + n_out)
+    x = torch.randn(M, 58, generator=g)
+    x = torch.cat([torch.sin(3 * x[:, :42]), x[:, 42:]], 1)          # feature-like magnitudes
+    w = torch.randn(n_out, 58, generator=g) * 5
+    b = torch.randn(n_out, generator=g)
+    xp = torch.zeros(M, 64)
+    xp[:, :58] = x
+    n_pad = ops.round_up(n_out, 64)
+    wp, bp = ops.pack_linear_bf16x6(w.to(dev), b.to(dev), n_pad, 64)
+    x6 = ops.split_bf16x6(xp.to(dev))
+    if split:
+        y = ops.join_bf16x3(ops.linear_bf16_split(x6, wp, bp, _lib.ACT_RELU))
+    else:
+        y = ops.linear_bf16(x6, wp, bp, _lib.ACT_RELU).float()
+    want = torch.relu(x.double() @ w.double().t() + b.double())
+    scale = (x.double().abs() @ w.double().abs().t() + b.double().abs())
+    out_eps = 2.0 ** -17 if split else 2.0 ** -9                   # the OUTPUT's own rounding: two bf16 terms / one
+    err = (y[:, :n_out].cpu().double() - want).abs()
+    assert bool((err <= 1.01 * out_eps * want.abs() + 2e-6 * scale).all()), float((err / scale).max())
+    if n_pad > n_out:
+        assert float(y[:, n_out:n_pad].abs().max()) == 0.0
+
+
 # =============================================================================== G19: trained-like weights
 G19_KINDS = ["lego", "garden", "mixed"]
 # rendered values: the stated fp32 tolerance; stage outputs: c x the reference's own fp32 error against its fp64 run
