@@ -438,6 +438,16 @@ int m360_nerf_finish_fused(const void *act, int act_bf16, int ld, const float *h
                            const float *t_vals, const float *dirs, int B, int N, int white_bkgd, float *comp_rgb,
                            float *distance, float *acc, float *weights, m360_stream_t stream);
 
+/* m360_nerf_finish_fused that also writes, in the same launch, the two tensors nerf_net.forward returns beside the composite
+ * (model.py:194-196): t_vals_out[B,N+1] = t_vals + 1e-6 (what the in-place g() inside t_to_s leaves in the stored t_vals,
+ * intern/parameterization.py:5-8,15-21) and s_vals_out[B,N+1] = t_to_s(t_vals, near, far) with near / far having gone through
+ * g() `near_far_calls` times already (m360_t_to_s's near_calls = far_calls); either may be NULL.  Same arithmetic as m360_t_to_s. */
+int m360_nerf_finish_outputs(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots,
+                             const float *head_w, const float *head_b, int k_pad, float density_bias, float rgb_padding,
+                             const float *t_vals, const float *dirs, const float *near, const float *far, int near_far_calls,
+                             int B, int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
+                             float *t_vals_out, float *s_vals_out, m360_stream_t stream);
+
 /* ------------------------------------------------------------------ whole forward ----- */
 
 typedef struct {

@@ -126,6 +126,8 @@ SIGNATURES = {
     "m360_prop_finish_fused": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _i, _fl, _vp, _vp, _vp, _i, _i, _i, _fl, _vp, _vp, _vp]),
     "m360_nerf_finish_fused": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp,
                                     _vp]),
+    "m360_nerf_finish_outputs": (_i, [_vp, _i, _i, _vp, _l, _i, _vp, _vp, _i, _fl, _fl, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp,
+                                      _vp, _vp, _vp, _vp, _vp]),
     "m360_forward_workspace_bytes": (_sz, [_i, _i, _P(ModelStruct)]),
     "m360_prop_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "m360_nerf_forward": (_i, [_P(RaysStruct), _P(ModelStruct), _P(HyperStruct), _i, _vp, _vp, _vp,

@@ -42,6 +42,13 @@ struct m360_prof {
 
 namespace m360 {
 
+// m360_sample_encode.hip (stage drivers only, not part of the C-ABI)
+int stage_prologue(const m360_rays_t *r, int B, int N, int min_deg, int max_deg, float *t_vals, float *vdenc,
+                   unsigned *queue_words, int n_queue_words, int ld_feat, void *norm_ws, m360_stream_t stream);
+int encode_prepared(const float *t_vals, const float *origins, const float *directions, const float *radii, const float *vdenc,
+                    int vd_ch, int B, int N, void *feat, int ld_feat, int row_format, int prepared_parts, void *workspace,
+                    size_t workspace_bytes, m360_stream_t stream);
+
 // brackets the launches of ONE public entry point with two HIP events on the launch stream
 struct ProfScope {
     m360_prof *p;
@@ -70,11 +77,6 @@ struct ProfScope {
         if (rc_ != M360_OK) return rc_;                      \
     } while (0)
 
-__global__ void add_eps_kernel(const float *__restrict__ x, long n, float *__restrict__ y) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < n) y[idx] = x[idx] + kEpsG;
-}
-
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FwdLayout {
@@ -87,10 +89,13 @@ struct TileQueues {
     int next = 0;
     unsigned *take() { return (base && next < kQueueSlots) ? base + kQueueStride * next++ : nullptr; }
 };
-static int queues_begin(TileQueues *q, char *ws, size_t off, m360_stream_t st) {
-    q->base = reinterpret_cast<unsigned *>(ws + off);
+// the workspace holds one set of queue words per stage (set 0: proposal, set 1: NeRF); `cleared`: the proposal stage's fused
+// prologue has already zeroed both sets in this forward (stage_prologue) - no memset launch
+constexpr int kQueueWords = kQueueSlots * kQueueStride;
+static int queues_begin(TileQueues *q, char *ws, size_t off, int set, bool cleared, m360_stream_t st) {
+    q->base = reinterpret_cast<unsigned *>(ws + off) + set * kQueueWords;
     q->next = 0;
-    if (hipMemsetAsync(q->base, 0, (size_t)kQueueSlots * kQueueStride * sizeof(unsigned), reinterpret_cast<hipStream_t>(st)) != hipSuccess)
+    if (!cleared && hipMemsetAsync(q->base, 0, (size_t)kQueueWords * sizeof(unsigned), reinterpret_cast<hipStream_t>(st)) != hipSuccess)
         return fail(M360_ERR_LAUNCH, "tile queues: memset failed");
     return M360_OK;
 }
@@ -117,7 +122,7 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     const size_t hp_rows = (size_t)m360_linear_heads_fused_rows((long)S, m->hp_pad, m->mlp_bf16), hn_rows = (size_t)m360_linear_heads_fused_rows((long)S, m->hn_pad, m->mlp_bf16);
     const size_t hp_b = hp_rows * hp_slots * 1 * sizeof(float), hn_b = hn_rows * hn_slots * 4 * sizeof(float);
     L.hpart = take(hp_b > hn_b ? hp_b : hn_b);
-    L.queues = take((size_t)kQueueSlots * kQueueStride * sizeof(unsigned));
+    L.queues = take((size_t)2 * kQueueSlots * kQueueStride * sizeof(unsigned));  // one set per stage
     L.total = off;
     return L;
 }
@@ -172,8 +177,10 @@ static int p_linear_bf16(const m360_hyper_t *h, int mode, const void *x, long M,
     if (mode == 2) return ps.done(m360_linear_bf16x3(x, M, 2 * k_pad, w, b, n_pad, k_pad, act, y, 2 * n_pad, st));
     return ps.done(m360_linear_bf16(x, M, k_pad, w, b, n_pad, k_pad, act, y, n_pad, st));
 }
-static int p_encode_grouped(const m360_hyper_t *h, const float *t, const float *o, const float *d, const float *rad, const float *vdenc, int vd_ch, int B, int N, void *feat, int ld, int bf16, int group, void *ws, size_t wsb, m360_stream_t st) {
+// prepared_parts > 0: the norm's partial sums are already in the scratch (stage_prologue)
+static int p_encode_grouped(const m360_hyper_t *h, const float *t, const float *o, const float *d, const float *rad, const float *vdenc, int vd_ch, int B, int N, void *feat, int ld, int bf16, int group, void *ws, size_t wsb, m360_stream_t st, int prepared_parts = 0) {
     ProfScope ps(h, st, M360_K_ENCODE, (long)B * N, ld, bf16);
+    if (prepared_parts > 0) return ps.done(encode_prepared(t, o, d, rad, vdenc, vd_ch, B, N, feat, ld, bf16, prepared_parts, ws, wsb, st));
     return ps.done(m360_encode_features_grouped(t, o, d, rad, vdenc, vd_ch, B, N, feat, ld, bf16, group, ws, wsb, st));
 }
 static int p_encode_ext_norm(const m360_hyper_t *h, const float *t, const float *o, const float *d, const float *rad, const float *vdenc, int vd_ch, int B, int N, void *feat, int ld, int bf16, const float *norm, void *ws, size_t wsb, m360_stream_t st) {
@@ -191,9 +198,12 @@ static int p_prop_finish_fused(const m360_hyper_t *h, const void *act, int bf16,
     ProfScope ps(h, st, M360_K_PROP_FINISH, (long)B * N, k_pad, bf16);
     return ps.done(m360_prop_finish_fused(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st));
 }
-static int p_nerf_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, const m360_outputs_t *out, m360_stream_t st) {
+// heads + composite, and in the same launch the t_vals + 1e-6 and s_vals nerf_net.forward returns (model.py:194-196; until round 3
+// an add_eps and a t_to_s launch).  near / far went through g() once in sample_along_rays (numerically, or physically when
+// rays_mutated: then t_to_s starts from the values it is handed).
+static int p_nerf_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const m360_rays_t *r, int B, int N, const m360_outputs_t *out, m360_stream_t st) {
     ProfScope ps(h, st, M360_K_NERF_FINISH, (long)B * N, k_pad, bf16);
-    return ps.done(m360_nerf_finish_fused(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, dirs, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, st));
+    return ps.done(m360_nerf_finish_outputs(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, r->directions, r->near, r->far, h->rays_mutated ? 0 : 1, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, out->t_vals, out->s_vals, st));
 }
 
 // Training tape of one stage (caller-owned): everything the backward needs from the forward.
@@ -216,9 +226,11 @@ static TapeLayout tape_for(int B, int N, const m360_model_t *m, int stage) {
 }
 
 // sample (or take) t -> features -> 4 proposal layers -> head + weights (+ fused resample)
+// fused: out-flag, set when this call ran the one-launch prologue (stage_prologue): the view-direction encoding in the workspace
+// and BOTH stages' tile-queue words are then ready for a NeRF stage that follows in the same forward (m360_forward)
 static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hyper_t *h, int B,
                       const float *t_rand, float *t_hat, float *w_hat, float *t_new, char *ws,
-                      m360_stream_t st, char *tape = nullptr, const float *ext_norm = nullptr) {
+                      m360_stream_t st, char *tape = nullptr, const float *ext_norm = nullptr, bool *fused = nullptr) {
     const int N = h->num_samples;
     const FwdLayout L = layout_for(B, n_max(h), m);
     const int vd_ch = m->in_ch - kIpeCh;
@@ -228,7 +240,15 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     float *hpart = reinterpret_cast<float *>(ws + L.hpart);
     const long S = (long)B * N;
     TileQueues tq;
-    M360_TRY(queues_begin(&tq, ws, L.queues, st));
+    // rendering forward on a chunk of its own norm, deterministic samples: ONE prologue launch (t, view directions, norm partials,
+    // queue words) instead of five; the encoder's workgroups finish the norm themselves
+    int parts = 0;
+    if (!tape && !ext_norm && !t_rand && h->norm_group_rays == 0) {
+        parts = stage_prologue(r, B, N, h->viewdir_min_deg, h->viewdir_max_deg, t_hat, vdenc, reinterpret_cast<unsigned *>(ws + L.queues), 2 * kQueueWords, m->in_pad, ws + L.norm, st);
+        if (parts < 0) return M360_ERR_LAUNCH;
+    }
+    if (fused) *fused = parts > 0;
+    M360_TRY(queues_begin(&tq, ws, L.queues, 0, parts > 0, st));
     if (tape) {  // training: fp32 only, every layer output kept
         const TapeLayout T = tape_for(B, N, m, 0);
         const int hp = m->hp_pad;
@@ -247,15 +267,17 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         M360_TRY(p_linear_heads(h, 0, act[2], S, hp, m->prop_w[3], m->prop_b[3], hp, hp, act[3], hp, 1, m->prop_head_w, 1, hpart, st));
         return p_prop_finish_fused(h, act[3], 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp, 0), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st);
     }
-    if (!ext_norm) M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, t_hat, st));  // sharded batch: t_hat is given
-    M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
+    if (parts == 0) {
+        if (!ext_norm) M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, t_hat, st));  // sharded batch: t_hat is given
+        M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
+    }
     const int hp = m->hp_pad;
     if (ext_norm) {  // the caller supplies the (all-reduced) contraction norm; the layers below are shared
         M360_TRY(p_encode_ext_norm(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16 ? 3 : 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));  /* row format: fp32, or x6 for both bf16 modes */
     }
     if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers; mode 2 = bf16x3: [hi | lo] pairs)
         const int mode = m->mlp_bf16;
-        if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 3, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 3, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st, parts));
         M360_TRY(p_linear_first(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, a, st));
         M360_TRY(p_linear_bf16(h, mode, a, S, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, st));
         M360_TRY(p_linear_bf16(h, mode, b, S, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, st));
@@ -264,7 +286,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         M360_TRY(p_linear_heads(h, mode, a, S, ldl, m->prop_w[3], m->prop_b[3], hp, hp, b, ldl, 0, m->prop_head_w, 1, hpart, st));
         return p_prop_finish_fused(h, b, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hp, mode), m360_linear_heads_slots_bf16(hp, hp, mode, 0), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
     }
-    if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+    if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st, parts));
     M360_TRY(p_linear(h, &tq, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
     M360_TRY(p_linear(h, &tq, a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
     M360_TRY(p_linear(h, &tq, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
@@ -274,9 +296,11 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
 }
 
 // resampled t -> features -> 8 NeRF layers -> heads + composite
+// after_fused_prop: the proposal stage of the same forward ran the fused prologue - the view-direction encoding (identical in
+// both stages, intern/encoding.py:69-90) and this stage's queue words are in place
 static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hyper_t *h, int B,
                       const float *t1, const m360_outputs_t *out, char *ws, m360_stream_t st, char *tape = nullptr,
-                      const float *ext_norm = nullptr) {
+                      const float *ext_norm = nullptr, bool after_fused_prop = false) {
     const int N = n_fine(h);  // the NeRF stage runs on the resampled intervals
     const FwdLayout L = layout_for(B, n_max(h), m);
     const int vd_ch = m->in_ch - kIpeCh;
@@ -286,8 +310,8 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     float *hpart = reinterpret_cast<float *>(ws + L.hpart);
     const long S = (long)B * N;
     TileQueues tq;
-    M360_TRY(queues_begin(&tq, ws, L.queues, st));
-    M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
+    M360_TRY(queues_begin(&tq, ws, L.queues, 1, after_fused_prop, st));
+    if (!after_fused_prop) M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     const int hn = m->hn_pad;
     const int slots = m360_linear_heads_slots(hn, m->mlp_bf16);
     float *src = a, *dst = b;
@@ -301,7 +325,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         for (int l = 1; l < 7; ++l)
             M360_TRY(p_linear(h, &tq, act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, M360_ACT_RELU, act[l], hn, st));
         M360_TRY(p_linear_heads(h, 0, act[6], S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, act[7], hn, 1, m->nerf_head_w, 4, hpart, st));
-        M360_TRY(p_nerf_finish_fused(h, act[7], 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
+        M360_TRY(p_nerf_finish_fused(h, act[7], 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st));
     } else if (m->mlp_bf16) {
         const int mode = m->mlp_bf16;
         if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 3, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
@@ -313,7 +337,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         }
         const int ldl = mode == 2 ? 2 * hn : hn;
         M360_TRY(p_linear_heads(h, mode, src, S, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, ldl, 0, m->nerf_head_w, 4, hpart, st));
-        M360_TRY(p_nerf_finish_fused(h, dst, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hn, mode), m360_linear_heads_slots_bf16(hn, hn, mode, 0), m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
+        M360_TRY(p_nerf_finish_fused(h, dst, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hn, mode), m360_linear_heads_slots_bf16(hn, hn, mode, 0), m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st));
     } else {
     if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
     else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
@@ -324,16 +348,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     }
     // last hidden layer + the 4 heads fused: its 2.15 GB output never goes to HBM (store_y = 0; ragged tail rows excepted)
     M360_TRY(p_linear_heads(h, 0, src, S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, hn, 0, m->nerf_head_w, 4, hpart, st));
-    M360_TRY(p_nerf_finish_fused(h, dst, 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r->directions, B, N, out, st));
-    }
-    if (out->t_vals) {  // model.py:194,196: g() inside t_to_s bumps the stored t_vals by 1e-6
-        const long n = (long)B * (N + 1);
-        hipLaunchKernelGGL(add_eps_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(st), t1, n, out->t_vals);
-        M360_TRY(check_launch("add_eps"));
-    }
-    if (out->s_vals) {  // near / far went through g() once in sample_along_rays (numerically, or physically when rays_mutated)
-        const int done = h->rays_mutated ? 0 : 1;
-        M360_TRY(m360_t_to_s(t1, r->near, r->far, B, N + 1, done, done, out->s_vals, st));
+    M360_TRY(p_nerf_finish_fused(h, dst, 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st));
     }
     return M360_OK;
 }
@@ -442,8 +457,9 @@ int m360_forward(const m360_rays_t *rays, const m360_model_t *model, const m360_
     float *t0 = out->t_hat ? out->t_hat : reinterpret_cast<float *>(ws + L.t0);
     float *what = out->w_hat ? out->w_hat : reinterpret_cast<float *>(ws + L.what);
     float *t1 = reinterpret_cast<float *>(ws + L.t1);
-    M360_TRY(prop_stage(rays, model, hyper, B, nullptr, t0, what, t1, ws, stream));
-    return nerf_stage(rays, model, hyper, B, t1, out, ws, stream);
+    bool fused = false;
+    M360_TRY(prop_stage(rays, model, hyper, B, nullptr, t0, what, t1, ws, stream, nullptr, nullptr, &fused));
+    return nerf_stage(rays, model, hyper, B, t1, out, ws, stream, nullptr, nullptr, fused);
 }
 
 /* ------------------------------------------------------------------ training path (row f3) */

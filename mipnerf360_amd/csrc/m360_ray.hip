@@ -449,29 +449,89 @@ __device__ __forceinline__ void ray_heads(const T *__restrict__ act, int ld, con
     __syncthreads();
 }
 
+// The same sums for a ray whose N samples ALL lie below `fused_rows`, formed by ONE wave (the wave-per-ray path of the
+// finishers below): every element is added by one lane in the order of ray_heads - slots 0, 1, ... then the bias; on the
+// 8-slots-per-256-columns layout 8 lanes per sample and the same DPP butterfly - so both paths give the same bits.
+template <int H, typename T>
+__device__ __forceinline__ void ray_heads_fused_wave(const float *__restrict__ head_part, int slots, const float *__restrict__ head_b,
+                                                     long s0, int N, float *raw /*LDS [N][H], this wave's*/) {
+    const int l = lane_id();
+    if (sizeof(T) == 2 && H == 4 && slots % 8 == 0) {
+        const int per = slots / 8, lane8 = l & 7;
+        for (int n = l >> 3; n < N; n += kWave >> 3) {
+            const float4 *p = reinterpret_cast<const float4 *>(head_part + ((s0 + n) * slots + lane8 * per) * 4);
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int q = 0; q < per; ++q) {
+                const float4 v = p[q];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            a.x = row8_sum(a.x); a.y = row8_sum(a.y); a.z = row8_sum(a.z); a.w = row8_sum(a.w);
+            if (lane8 == 0) {
+                raw[n * 4 + 0] = a.x + head_b[0];
+                raw[n * 4 + 1] = a.y + head_b[1];
+                raw[n * 4 + 2] = a.z + head_b[2];
+                raw[n * 4 + 3] = a.w + head_b[3];
+            }
+        }
+    } else {
+        for (int idx = l; idx < N * H; idx += kWave) {
+            const int n = idx / H, hh = idx % H;
+            const float *p = head_part + ((s0 + n) * slots) * H + hh;
+            float a = 0.0f;
+            for (int q = 0; q < slots; ++q) a += p[q * H];
+            raw[idx] = a + head_b[hh];
+        }
+    }
+}
+
+// Rays per workgroup of the stage finishers.  Round 4: a workgroup takes kFinishRays rays.  When the fused last layer covered
+// all of their samples (every ray of the rendering forward but the last partial 256-row tile) each WAVE finishes one ray on its
+// own - partial head sums, activations, fp64 transmittance scan, resampling / composite - with no workgroup barrier; until
+// round 3 one 256-thread workgroup per ray parked three of its four waves after the head sums (0.07 / 0.27 of the HBM peak).
+// A workgroup that holds rows the fused layer did not cover runs its rays one after the other in the old workgroup-wide form.
+constexpr int kFinishRays = kFinishThreads / kWave;
+
 // model.py:52,92-93 + intern/ray.py:136-149
 template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     const T *__restrict__ act, int ld, const float *__restrict__ head_part, long fused_rows, int slots,
     const float *__restrict__ head_w, const float *__restrict__ head_b, int k_pad, float density_bias,
-    const float *__restrict__ t_vals, const float *__restrict__ dirs, const float *__restrict__ u_rand, int N, int ns,
+    const float *__restrict__ t_vals, const float *__restrict__ dirs, const float *__restrict__ u_rand, int B, int N, int ns,
     float padding, float *__restrict__ weights, float *__restrict__ t_new) {
     extern __shared__ float smem[];
-    const int b = blockIdx.x, l = lane_id();
+    const int l = lane_id(), wave = threadIdx.x >> 6;
     const int nb = N + 1;
+    const int b0 = blockIdx.x * kFinishRays;
+    const int b_end = (b0 + kFinishRays < B) ? b0 + kFinishRays : B;
+    // the tail of one ray: activation, weights (model.py:59-78), blur + inverse-CDF resampling (intern/ray.py:136-149), by one wave
+    auto finish_ray = [&](int b, float *t, float *rho, float *w, float *w2, float *cdf) __attribute__((always_inline)) {
+        for (int i = l; i < N; i += kWave) rho[i] = softplusf_(rho[i] + density_bias);
+        wave_sync();
+        wave_weights(t, rho, 1, dir_norm(dirs, b), N, w);
+        wave_sync();
+        for (int i = l; i < N; i += kWave) weights[(long)b * N + i] = w[i];
+        if (t_new == nullptr) return;
+        wave_blur(w, N, padding, w2);
+        wave_sync();
+        wave_sorted_pdf(t, w2, cdf, nb, ns, u_rand ? u_rand + (long)b * ns : nullptr, t_new + (long)b * ns);
+    };
+    if (fused_rows >= (long)b_end * N) {  // workgroup-uniform: one wave per ray, no workgroup barrier
+        const int b = b0 + wave;
+        if (b >= B) return;
+        float *t = smem + wave * 5 * nb, *rho = t + nb, *w = rho + nb, *w2 = w + nb, *cdf = w2 + nb;
+        for (int i = l; i < nb; i += kWave) t[i] = t_vals[(long)b * nb + i];
+        ray_heads_fused_wave<1, T>(head_part, slots, head_b, (long)b * N, N, rho);
+        wave_sync();
+        finish_ray(b, t, rho, w, w2, cdf);
+        return;
+    }
     float *hw = smem, *t = hw + k_pad, *rho = t + nb, *w = rho + nb, *w2 = w + nb, *cdf = w2 + nb;
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
-    ray_heads<1, T, SPLIT>(act, ld, head_part, fused_rows, slots, head_w, head_b, k_pad, b, N, hw, rho);
-    if (threadIdx.x >= kWave) return;
-    for (int i = l; i < N; i += kWave) rho[i] = softplusf_(rho[i] + density_bias);
-    wave_sync();
-    wave_weights(t, rho, 1, dir_norm(dirs, b), N, w);
-    wave_sync();
-    for (int i = l; i < N; i += kWave) weights[(long)b * N + i] = w[i];
-    if (t_new == nullptr) return;
-    wave_blur(w, N, padding, w2);
-    wave_sync();
-    wave_sorted_pdf(t, w2, cdf, nb, ns, u_rand ? u_rand + (long)b * ns : nullptr, t_new + (long)b * ns);
+    for (int b = b0; b < b_end; ++b) {
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
+        ray_heads<1, T, SPLIT>(act, ld, head_part, fused_rows, slots, head_w, head_b, k_pad, b, N, hw, rho);
+        if (threadIdx.x < kWave) finish_ray(b, t, rho, w, w2, cdf);
+        __syncthreads();  // the next ray reuses the buffers
+    }
 }
 
 // model.py:150-158,180-186 + intern/ray.py:155-191
@@ -479,35 +539,62 @@ template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
     const T *__restrict__ act, int ld, const float *__restrict__ head_part, long fused_rows, int slots,
     const float *__restrict__ head_w, const float *__restrict__ head_b, int k_pad, float density_bias,
-    float rgb_padding, const float *__restrict__ t_vals, const float *__restrict__ dirs, int N, int white_bkgd,
+    float rgb_padding, const float *__restrict__ t_vals, const float *__restrict__ dirs, int B, int N, int white_bkgd,
     float *__restrict__ comp_rgb, float *__restrict__ distance, float *__restrict__ acc,
-    float *__restrict__ weights) {
+    float *__restrict__ weights, float *__restrict__ t_out, float *__restrict__ s_out, const float *__restrict__ near,
+    const float *__restrict__ far, int ts_calls) {
     extern __shared__ float smem[];
-    const int b = blockIdx.x, l = lane_id();
+    const int l = lane_id(), wave = threadIdx.x >> 6;
     const int nb = N + 1;
-    float *hw = smem, *t = hw + 4 * k_pad, *raw = t + nb, *w = raw + 4 * N;
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
-    ray_heads<4, T, SPLIT>(act, ld, head_part, fused_rows, slots, head_w, head_b, k_pad, b, N, hw, raw);
-    if (threadIdx.x >= kWave) return;
-    for (int i = l; i < N; i += kWave) {
-        raw[4 * i] = softplusf_(sigmoidf_(raw[4 * i]) + density_bias);
+    const int b0 = blockIdx.x * kFinishRays;
+    const int b_end = (b0 + kFinishRays < B) ? b0 + kFinishRays : B;
+    // the tail of one ray by one wave: head activations (model.py:180-186), composite (intern/ray.py:155-191) and the two
+    // tensors nerf_net.forward returns beside it (model.py:194-196): t_vals + 1e-6 (what g() inside t_to_s leaves behind) and
+    // s_vals = t_to_s(t_vals, near, far) - until round 3 two more launches (add_eps_kernel, t_to_s_kernel), same arithmetic
+    auto finish_ray = [&](int b, float *t, float *raw, float *w) __attribute__((always_inline)) {
+        for (int i = l; i < N; i += kWave) {
+            raw[4 * i] = softplusf_(sigmoidf_(raw[4 * i]) + density_bias);
 #pragma unroll
-        for (int c = 1; c < 4; ++c)
-            raw[4 * i + c] = sigmoidf_(raw[4 * i + c]) * (1.0f + 2.0f * rgb_padding) - rgb_padding;
+            for (int c = 1; c < 4; ++c)
+                raw[4 * i + c] = sigmoidf_(raw[4 * i + c]) * (1.0f + 2.0f * rgb_padding) - rgb_padding;
+        }
+        wave_sync();
+        wave_weights(t, raw, 4, dir_norm(dirs, b), N, w);
+        wave_sync();
+        const Composite c = wave_composite(t, w, raw + 1, 4, N, white_bkgd != 0);
+        if (l == 0) {
+            comp_rgb[3 * b] = c.r;
+            comp_rgb[3 * b + 1] = c.g;
+            comp_rgb[3 * b + 2] = c.b;
+            distance[b] = c.dist;
+            acc[b] = c.acc;
+        }
+        if (weights != nullptr)
+            for (int i = l; i < N; i += kWave) weights[(long)b * N + i] = w[i];
+        if (t_out != nullptr)
+            for (int i = l; i < nb; i += kWave) t_out[(long)b * nb + i] = t[i] + kEpsG;
+        if (s_out != nullptr) {
+            const float gn1 = g_calls(near[b], ts_calls + 1), gf = g_calls(far[b], ts_calls + 1), gn2 = g_calls(near[b], ts_calls + 2);
+            for (int i = l; i < nb; i += kWave) s_out[(long)b * nb + i] = (1.0f / (t[i] + kEpsG) - gn1) / (gf - gn2);
+        }
+    };
+    if (fused_rows >= (long)b_end * N) {  // workgroup-uniform: one wave per ray, no workgroup barrier
+        const int b = b0 + wave;
+        if (b >= B) return;
+        float *t = smem + wave * (2 * nb + 4 * N), *raw = t + nb, *w = raw + 4 * N;
+        for (int i = l; i < nb; i += kWave) t[i] = t_vals[(long)b * nb + i];
+        ray_heads_fused_wave<4, T>(head_part, slots, head_b, (long)b * N, N, raw);
+        wave_sync();
+        finish_ray(b, t, raw, w);
+        return;
     }
-    wave_sync();
-    wave_weights(t, raw, 4, dir_norm(dirs, b), N, w);
-    wave_sync();
-    const Composite c = wave_composite(t, w, raw + 1, 4, N, white_bkgd != 0);
-    if (l == 0) {
-        comp_rgb[3 * b] = c.r;
-        comp_rgb[3 * b + 1] = c.g;
-        comp_rgb[3 * b + 2] = c.b;
-        distance[b] = c.dist;
-        acc[b] = c.acc;
+    float *hw = smem, *t = hw + 4 * k_pad, *raw = t + nb, *w = raw + 4 * N;
+    for (int b = b0; b < b_end; ++b) {
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
+        ray_heads<4, T, SPLIT>(act, ld, head_part, fused_rows, slots, head_w, head_b, k_pad, b, N, hw, raw);
+        if (threadIdx.x < kWave) finish_ray(b, t, raw, w);
+        __syncthreads();  // the next ray reuses the buffers
     }
-    if (weights != nullptr)
-        for (int i = l; i < N; i += kWave) weights[(long)b * N + i] = w[i];
 }
 
 
@@ -790,18 +877,27 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
     if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < (bf16 == 2 ? 2 * k_pad : k_pad) || ld % align != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: bad argument");
     if (B == 0) return M360_OK;
-    const size_t lds = ((size_t)k_pad + 5 * (N + 1)) * sizeof(float);
+    // workgroup-wide form: head row + one ray's buffers; wave-per-ray form: kFinishRays rays' buffers
+    const size_t lds_wg = ((size_t)k_pad + 5 * (N + 1)) * sizeof(float), lds_wave = (size_t)kFinishRays * 5 * (N + 1) * sizeof(float);
+    const size_t lds = lds_wg > lds_wave ? lds_wg : lds_wave;
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
-    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
-    else hipLaunchKernelGGL(prop_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, N, num_out, resample_padding, weights, t_new);
+    const dim3 grid((unsigned)((B + kFinishRays - 1) / kFinishRays));
+    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new);
+    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new);
+    else hipLaunchKernelGGL(prop_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new);
     return check_launch("prop_finish");
 }
 
+struct FinishExtras {  // what nerf_net.forward returns beside the composite (model.py:194-196), written by the same kernel
+    float *t_out = nullptr, *s_out = nullptr;
+    const float *near = nullptr, *far = nullptr;
+    int calls = 1;  // applications of the reference's in-place g() that near / far have behind them (t_to_s_kernel)
+};
 static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
                            int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
-                           m360_stream_t stream, const float *head_part = nullptr, long fused_rows = 0, int slots = 0);
+                           m360_stream_t stream, const float *head_part = nullptr, long fused_rows = 0, int slots = 0,
+                           FinishExtras ex = FinishExtras());
 
 int m360_nerf_finish(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
                      float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
@@ -825,19 +921,34 @@ int m360_nerf_finish_fused(const void *act, int act_bf16, int ld, const float *h
     return nerf_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, stream, head_part, fused_rows, slots);
 }
 
+int m360_nerf_finish_outputs(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots,
+                             const float *head_w, const float *head_b, int k_pad, float density_bias, float rgb_padding,
+                             const float *t_vals, const float *dirs, const float *near, const float *far, int near_far_calls,
+                             int B, int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
+                             float *t_vals_out, float *s_vals_out, m360_stream_t stream) {
+    if (fused_rows < 0 || (fused_rows > 0 && (!head_part || slots < 1))) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish_outputs: fused_rows=%ld slots=%d head_part=%p", fused_rows, slots, (const void *)head_part);
+    if (s_vals_out && (!near || !far || near_far_calls < 0)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish_outputs: s_vals needs near, far and near_far_calls >= 0");
+    FinishExtras ex;
+    ex.t_out = t_vals_out, ex.s_out = s_vals_out, ex.near = near, ex.far = far, ex.calls = near_far_calls;
+    return nerf_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, stream, head_part, fused_rows, slots, ex);
+}
+
 static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
                            int N, int white_bkgd, float *comp_rgb, float *distance, float *acc, float *weights,
-                           m360_stream_t stream, const float *head_part, long fused_rows, int slots) {
+                           m360_stream_t stream, const float *head_part, long fused_rows, int slots, FinishExtras ex) {
     const int align = bf16 ? 8 : 4;
     if (!act || !head_w || !head_b || !t_vals || !dirs || !comp_rgb || !distance || !acc || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < (bf16 == 2 ? 2 * k_pad : k_pad) || ld % align != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: bad argument");
     if (B == 0) return M360_OK;
-    const size_t lds = ((size_t)4 * k_pad + (N + 1) + 5 * N) * sizeof(float);
+    const size_t ray_floats = (size_t)2 * (N + 1) + 4 * N;
+    const size_t lds_wg = ((size_t)4 * k_pad + ray_floats) * sizeof(float), lds_wave = (size_t)kFinishRays * ray_floats * sizeof(float);
+    const size_t lds = lds_wg > lds_wave ? lds_wg : lds_wave;
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    if (bf16 == 2) hipLaunchKernelGGL((nerf_finish_kernel<__bf16, true>), dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
-    else if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
-    else hipLaunchKernelGGL(nerf_finish_kernel<float>, dim3(B), dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, comp_rgb, distance, acc, weights);
+    const dim3 grid((unsigned)((B + kFinishRays - 1) / kFinishRays));
+    if (bf16 == 2) hipLaunchKernelGGL((nerf_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls);
+    else if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls);
+    else hipLaunchKernelGGL(nerf_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls);
     return check_launch("nerf_finish");
 }
 

@@ -245,6 +245,81 @@ __global__ __launch_bounds__(256) void norm_final_kernel(NormScratch *__restrict
     }
 }
 
+// norm_final_kernel's reduction run by EVERY 256-thread workgroup of a consumer kernel (round 4: one launch less per stage):
+// thread t adds partials t, t + 256, ...; wave_sum_d; the four wave sums are added 0 + 1 + 2 + 3 - the same order, hence the same
+// bits in every workgroup and the same bits as the separate kernel.  The partials (<= 8 KB) sit in L2.  All 256 threads must call.
+__device__ __forceinline__ float block_norm_from_partials(const NormScratch *__restrict__ ws, int nparts, double *sumsq_out = nullptr) {
+    __shared__ double red_[4];
+    double v = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 256) v += ws->partial[p];
+    v = wave_sum_d(v);
+    if (lane_id() == 0) red_[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double ss = red_[0] + red_[1] + red_[2] + red_[3];
+    if (sumsq_out) *sumsq_out = ss;
+    return (float)sqrt(ss);
+}
+
+// Proposal-stage prologue of the rendering forward in ONE launch (round 4; until round 3: sample_t, viewdir_enc, norm_partial,
+// norm_final and a memset): on the grid of the norm's partial sums (`parts` workgroups of 256 threads, grid-stride)
+//   * t_vals = the deterministic samples of intern/ray.py:99-101 (sample_t_kernel's arithmetic);
+//   * the view-direction encoding of intern/encoding.py:69-90 (viewdir_enc_kernel's arithmetic);
+//   * the partial sums of the whole-chunk contraction norm (parameterization.py:25) in norm_partial_from_t_kernel's partition
+//     and order, with t0 / t1 RECOMPUTED from near / far - the same instructions as the stored values, so the same bits - instead
+//     of read back; the final sum is taken by the encoder's workgroups (block_norm_from_partials);
+//   * workgroup 0 clears the tile-queue words of both stages' balanced linear launches.
+__global__ __launch_bounds__(256) void stage_prologue_kernel(
+    const float *__restrict__ near, const float *__restrict__ far, const float *__restrict__ viewdirs,
+    const float *__restrict__ directions, const float *__restrict__ radii, int B, int N, int min_deg, int L,
+    float *__restrict__ t_vals, float *__restrict__ vdenc, unsigned *__restrict__ queue_words, int n_queue_words,
+    NormScratch *__restrict__ ws) {
+    const int M = N + 1;
+    const long stride = (long)gridDim.x * blockDim.x, first = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    auto t_at = [&](float gn, float gf, int j) {
+        const float sl = linspacef_(0.0f, 1.0f, M, j);
+        const float mix = sl * gf + (1.0f - sl) * gn;
+        return 1.0f / (mix + kEpsG);
+    };
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_queue_words; i += blockDim.x) queue_words[i] = 0u;
+    for (long idx = first; idx < (long)B * M; idx += stride) {
+        const int b = (int)(idx / M), i = (int)(idx % M);
+        t_vals[idx] = t_at(1.0f / (near[b] + kEpsG), 1.0f / (far[b] + kEpsG), i);
+    }
+    if (L > 0)
+        for (long b = first; b < B; b += stride) {
+            const float x = viewdirs[3 * b], y = viewdirs[3 * b + 1], z = viewdirs[3 * b + 2];
+            const float theta = acosf(z);
+            const float phi = atanf(y / (x + 1e-6f));
+            float *row = vdenc + b * 4 * L;
+            for (int i = 0; i < L; ++i) {
+                const float sc = ldexpf(1.0f, min_deg + i);
+                float sn, cs;
+                sincosf(sc * theta, &sn, &cs);
+                row[i] = sn;
+                row[L + i] = cs;
+                sincosf(sc * phi, &sn, &cs);
+                row[2 * L + i] = sn;
+                row[3 * L + i] = cs;
+            }
+        }
+    const long S = (long)B * N;
+    double acc = 0.0;
+    for (long idx = first; idx < S; idx += stride) {
+        const int b = (int)(idx / N), n = (int)(idx % N);
+        const float gn = 1.0f / (near[b] + kEpsG), gf = 1.0f / (far[b] + kEpsG);
+        const float t0 = t_at(gn, gf, n), t1 = t_at(gn, gf, n + 1);
+        float tm, tv, rv;
+        frustum_moments(t0, t1, radii[b], tm, tv, rv);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float m = directions[3 * b + i] * tm;
+            acc += (double)m * (double)m;
+        }
+    }
+    block_store_partial(acc, ws->partial);
+}
+
 // intern/parameterization.py:64-83 on materialised tensors
 __global__ void contract_apply_kernel(const float *__restrict__ mean_in,
                                       const float *__restrict__ cov_in, long S,
@@ -436,11 +511,23 @@ __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kern
     const float *__restrict__ t_vals, const float *__restrict__ origins,
     const float *__restrict__ directions, const float *__restrict__ radii,
     const float *__restrict__ vdenc, int vd_ch, int B, int N, const NormScratch *__restrict__ ws,
-    void *__restrict__ feat_out, int group_rays, const float *__restrict__ ext_norm) {
+    void *__restrict__ feat_out, int group_rays, const float *__restrict__ ext_norm, int norm_parts) {
     __shared__ __attribute__((aligned(16))) float tiles[kEncWaves][kWave * kEncTileLd];
     constexpr int ld = 32 * NPASS;
     const long S = (long)B * N;
     const int wave = threadIdx.x >> 6, lane = lane_id();
+    // norm_parts > 0: the whole-chunk norm is still `norm_parts` partial sums - every workgroup takes the final sum itself, in
+    // norm_final_kernel's order (before any wave leaves: the reduction has a workgroup barrier)
+    float gn_block = 0.0f;
+    if (norm_parts > 0) {
+        double ss;
+        gn_block = block_norm_from_partials(ws, norm_parts, &ss);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {  // kept for readers of the scratch (tests, m360_mean_sumsq's layout)
+            NormScratch *wsw = const_cast<NormScratch *>(ws);
+            wsw->sumsq = ss;
+            wsw->gnorm = gn_block;
+        }
+    }
     const long s0 = ((long)blockIdx.x * kEncWaves + wave) * kWave;  // first sample of this wave
     if (s0 >= S) return;
     const long idx = s0 + lane;
@@ -452,7 +539,7 @@ __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kern
         b = (int)(idx / N);
         const int n = (int)(idx % N);
         float m[3], c[9];
-        const float gn = ext_norm ? *ext_norm : (group_rays > 0 ? ws->gnorms[b / group_rays] : ws->gnorm);
+        const float gn = norm_parts > 0 ? gn_block : (ext_norm ? *ext_norm : (group_rays > 0 ? ws->gnorms[b / group_rays] : ws->gnorm));
         sample_gaussian(t_vals, origins, directions, radii, N, b, n, gn, m, c);
         ipe_sample<true, true>(m, c, [&](int k, float val) { v[k] = val; });
     } else {
@@ -526,6 +613,33 @@ using namespace m360;
 
 static inline hipStream_t S_(m360_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline unsigned blocks_for(long n, int threads) { return (unsigned)((n + threads - 1) / threads); }
+
+extern "C" {  // (defined inside the extern "C" block below)
+static int norm_parts(long work);
+static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
+                               const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
+                               int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream,
+                               int group_rays, const float *ext_norm, int prepared_parts);
+}
+
+namespace m360 {
+// Stage drivers only (m360_capi.hip; not part of the C-ABI).  stage_prologue: one launch for t_vals, the view-direction encoding,
+// the norm's partial sums and the tile-queue words; returns the number of partial sums (> 0) to hand to encode_prepared, 0 when
+// the chunk is not of the shape the fused prologue takes (the caller then runs the separate entry points), < 0 on a launch error.
+int stage_prologue(const m360_rays_t *r, int B, int N, int min_deg, int max_deg, float *t_vals, float *vdenc,
+                   unsigned *queue_words, int n_queue_words, int ld_feat, void *norm_ws, m360_stream_t stream) {
+    if ((long)B * N <= kSmallGroup || !(ld_feat == 64 || ld_feat == 96)) return 0;
+    const int parts = norm_parts((long)B * N);
+    hipLaunchKernelGGL(stage_prologue_kernel, dim3(parts), dim3(256), 0, S_(stream), r->near, r->far, r->viewdirs, r->directions, r->radii,
+                       B, N, min_deg, max_deg - min_deg, t_vals, vdenc, queue_words, n_queue_words, static_cast<NormScratch *>(norm_ws));
+    return check_launch("stage_prologue") == M360_OK ? parts : -1;
+}
+int encode_prepared(const float *t_vals, const float *origins, const float *directions, const float *radii, const float *vdenc,
+                    int vd_ch, int B, int N, void *feat, int ld_feat, int row_format, int prepared_parts, void *workspace,
+                    size_t workspace_bytes, m360_stream_t stream) {
+    return encode_features_any(t_vals, origins, directions, radii, vdenc, vd_ch, B, N, feat, ld_feat, row_format, workspace, workspace_bytes, stream, 0, nullptr, prepared_parts);
+}
+}  // namespace m360
 
 extern "C" {
 
@@ -633,16 +747,20 @@ int m360_gaussian_contract(const float *mean_in, const float *cov_in, long S, fl
 }
 
 // norm pre-pass shared by para_rays / encode_features
-static void launch_norm_from_t(const float *t_vals, const float *directions, const float *radii, int B,
-                               int N, NormScratch *ws, hipStream_t st, int group_rays = 0) {
+// defer_final: leave the last step (norm_final_kernel) to the consumer, which then gets the number of partial sums (the return
+// value; 0 = the norm(s) are final in ws, nothing deferred)
+static int launch_norm_from_t(const float *t_vals, const float *directions, const float *radii, int B,
+                              int N, NormScratch *ws, hipStream_t st, int group_rays = 0, bool defer_final = false) {
     if (group_rays > 0 || (long)B * N <= kSmallGroup) {  // per-chunk norms, or one small chunk: same kernel, same order
         const int gr = group_rays > 0 ? group_rays : B;
         hipLaunchKernelGGL(norm_group_from_t_kernel, dim3((B + gr - 1) / gr), dim3(256), 0, st, t_vals, directions, radii, B, N, gr, ws);
-        return;
+        return 0;
     }
     const int parts = norm_parts((long)B * N);
     hipLaunchKernelGGL(norm_partial_from_t_kernel, dim3(parts), dim3(256), 0, st, t_vals, directions, radii, B, N, ws);
+    if (defer_final) return parts;
     hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, ws, parts);
+    return 0;
 }
 
 int m360_para_rays(const float *t_vals, const float *origins, const float *directions,
@@ -677,7 +795,7 @@ int m360_viewdir_enc(const float *viewdirs, int B, int min_deg, int max_deg, flo
 static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
                                const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
                                int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream,
-                               int group_rays = 0, const float *ext_norm = nullptr);
+                               int group_rays = 0, const float *ext_norm = nullptr, int prepared_parts = 0);  // (defaults: this declaration)
 
 // one logical batch sharded over several devices: this shard's sum of squares of the un-contracted
 // means, reduced exactly like the norm the encode stage would compute for these rays alone
@@ -729,7 +847,7 @@ int m360_encode_features_bf16(const float *t_vals, const float *origins, const f
 static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
                                const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
                                int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream,
-                               int group_rays, const float *ext_norm) {
+                               int group_rays, const float *ext_norm, int prepared_parts) {
     if (!t_vals || !origins || !directions || !radii || !feat || B < 0 || N < 1 || vd_ch < 0 || (vd_ch > 0 && !vdenc))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: bad argument");
     if (ld_feat % 32 != 0 || ld_feat < kIpeCh + vd_ch) return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: ld_feat=%d must be a multiple of 32 and >= %d", ld_feat, kIpeCh + vd_ch);
@@ -737,15 +855,20 @@ static int encode_features_any(const float *t_vals, const float *origins, const 
     if (!workspace || workspace_bytes < sizeof(NormScratch)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_encode_features: workspace %zu < %zu", workspace_bytes, sizeof(NormScratch));
     if (B == 0) return M360_OK;
     NormScratch *ws = static_cast<NormScratch *>(workspace);
-    if (!ext_norm) launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream), group_rays);
-    if (ld_feat == 64 || ld_feat == 96) {  // every model of the path: wave-tiled kernel
+    const bool wave_kernel = ld_feat == 64 || ld_feat == 96;  // every model of the path
+    // the whole-chunk norm: given (ext_norm), already `prepared_parts` partial sums in ws (stage_prologue), or computed here - with
+    // the final sum left to the wave kernel's workgroups when it is the large-chunk two-step reduction
+    int parts = prepared_parts;
+    if (!ext_norm && prepared_parts == 0) parts = launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream), group_rays, wave_kernel);
+    if (wave_kernel) {
         const dim3 grid(blocks_for((long)B * N, kEncWaves * kWave)), block(kEncWaves * kWave);
-#define M360_ENC(BF, NP) hipLaunchKernelGGL((encode_features_wave_kernel<BF, NP>), grid, block, 0, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, group_rays, ext_norm)
+#define M360_ENC(BF, NP) hipLaunchKernelGGL((encode_features_wave_kernel<BF, NP>), grid, block, 0, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, group_rays, ext_norm, parts)
         if (ld_feat == 64) { if (bf16 == 3) M360_ENC(3, 2); else if (bf16 == 2) M360_ENC(2, 2); else if (bf16) M360_ENC(1, 2); else M360_ENC(0, 2); }
         else { if (bf16 == 3) M360_ENC(3, 3); else if (bf16 == 2) M360_ENC(2, 3); else if (bf16) M360_ENC(1, 3); else M360_ENC(0, 3); }
 #undef M360_ENC
         return check_launch("encode_features");
     }
+    if (parts > 0) hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, S_(stream), ws, parts);  // prepared partials, generic kernel
     const size_t lds = (size_t)kEncThreads * (ld_feat + 1) * sizeof(float);
     if (bf16 == 3) hipLaunchKernelGGL(encode_features_kernel<3>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
     else if (bf16 == 2) hipLaunchKernelGGL(encode_features_kernel<2>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);

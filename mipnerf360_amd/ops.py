@@ -549,6 +549,23 @@ def nerf_finish_fused(act, head_part, fused_rows, head_w, head_b, density_bias, 
     return comp, dist, acc, w
 
 
+def nerf_finish_outputs(act, head_part, fused_rows, head_w, head_b, density_bias, rgb_padding, t_vals, dirs, near, far,
+                        white_bkgd, near_far_calls: int = 1):
+    """nerf_finish_fused that also returns t_vals + 1e-6 and s_vals = t_to_s(t_vals, near, far) from the same launch
+    (m360_nerf_finish_outputs; model.py:194-196) -> (rgb, distance, acc, weights, t_vals_out, s_vals)."""
+    act, head_part, head_w, head_b = dev(act, "act"), dev(head_part, "head_part"), dev(head_w, "head_w"), dev(head_b, "head_b")
+    t_vals, dirs, near, far = dev(t_vals, "t_vals"), dev(dirs, "dirs"), dev(near, "near"), dev(far, "far")
+    B, M = t_vals.shape
+    N = M - 1
+    d = act.device
+    comp, dist, acc, w = torch.empty(B, 3, device=d), torch.empty(B, device=d), torch.empty(B, device=d), torch.empty(B, N, device=d)
+    t_out, s_out = torch.empty_like(t_vals), torch.empty_like(t_vals)
+    _call("m360_nerf_finish_outputs", act, 0, act.shape[1], head_part, int(fused_rows), head_part.shape[1], head_w, head_b,
+          head_w.shape[1], float(density_bias), float(rgb_padding), t_vals, dirs, near, far, int(near_far_calls), B, N,
+          int(bool(white_bkgd)), comp, dist, acc, w, t_out, s_out, STREAM)
+    return comp, dist, acc, w, t_out, s_out
+
+
 def prop_finish_fused(act, head_part, fused_rows, head_w, head_b, density_bias, t_vals, dirs, resample_padding):
     act, head_part, head_w, head_b = dev(act, "act"), dev(head_part, "head_part"), dev(head_w, "head_w"), dev(head_b, "head_b")
     t_vals, dirs = dev(t_vals, "t_vals"), dev(dirs, "dirs")

@@ -41,15 +41,22 @@ def test_packed_export_matches_padded_weights(tmp_path, dtype):
     assert (in_ch, in_pad, is_bf16) == (58, 64, int(dtype == "bf16"))
     assert hp_pad == -(-100 // pad) * pad and hn_pad == -(-200 // pad) * pad
     w0 = packed["nerf.w0"]
-    assert w0.shape == (hn_pad, in_pad)
     ref = np.zeros((hn_pad, in_pad), np.float32)
     ref[:200, :58] = sd["nerf_net.model.0.weight"]
     if dtype == "bf16":
-        assert w0.dtype == np.uint16
+        # the first layer of the bf16 modes is the "x6" packing [Wh | Wm | Wl | Wh | Wm | Wh]: three bf16 terms = the fp32 weight
+        assert w0.dtype == np.uint16 and w0.shape == (hn_pad, 6 * in_pad)
         got = torch.from_numpy(w0.view(np.int16).copy()).view(torch.bfloat16).float().numpy()
-        assert np.array_equal(got, torch.from_numpy(ref).bfloat16().float().numpy())
+        hi, mid, lo = got[:, :in_pad], got[:, in_pad:2 * in_pad], got[:, 2 * in_pad:3 * in_pad]
+        assert np.array_equal(hi, torch.from_numpy(ref).bfloat16().float().numpy()) and np.array_equal(hi + mid + lo, ref)
+        assert np.array_equal(got[:, 3 * in_pad:4 * in_pad], hi) and np.array_equal(got[:, 4 * in_pad:5 * in_pad], mid) and np.array_equal(got[:, 5 * in_pad:], hi)
+        w1 = packed["nerf.w1"]              # hidden layers: plain bf16 [n_pad, k_pad]
+        ref1 = np.zeros((hn_pad, hn_pad), np.float32)
+        ref1[:200, :200] = sd["nerf_net.model.2.weight"]
+        got1 = torch.from_numpy(w1.view(np.int16).copy()).view(torch.bfloat16).float().numpy()
+        assert w1.shape == (hn_pad, hn_pad) and np.array_equal(got1, torch.from_numpy(ref1).bfloat16().float().numpy())
     else:
-        assert np.array_equal(w0, ref)
+        assert w0.shape == (hn_pad, in_pad) and np.array_equal(w0, ref)
     assert packed["nerf.head_w"].shape == (4, hn_pad) and packed["prop.head_w"].shape == (1, hp_pad)
     assert np.array_equal(packed["nerf.head_w"][0, :200], sd["nerf_net.final_density.0.weight"][0])
     assert np.array_equal(packed["nerf.head_w"][1:, :200], sd["nerf_net.final_color.0.weight"])
