@@ -402,6 +402,12 @@ int m360_visualize_composite(const float *colors, const float *acc, const float 
  * fused_rows = m360_linear_heads_fused_rows(M, n_pad, bf16) (ragged tail; every row when n_pad % 256 != 0 or n_pad > 1024)
  * are computed as by m360_linear into y, and the *_finish_fused entry points take their head products from there.
  * Replaces the last nn.Linear + nn.Sigmoid of model.py:43-53 / :131-148 plus the matrix product of the heads. */
+/* (bf16 = 1 with k_pad < 128 and full tiles - a shape the stage drivers never produce, their last layers are square - is rejected by
+ * m360_linear_heads_bf16 with M360_ERR_INVALID_ARGUMENT: no kernel fuses the heads of a single 64-deep K-step.  bf16 / bf16x3: the
+ * ragged tail rows are formed by the generic kernel (v_mfma_f32_32x32x16_bf16, one 3K-deep contraction in bf16x3) and the full
+ * tiles by the ring / ping-pong kernels (v_mfma_f32_16x16x32_bf16, xl wh -> xh wh -> xh wl per 64-deep block): the same products,
+ * a different fp32 summation order - a row's low-order bits depend on which side of fused_rows it lies; only the fp32 path
+ * promises the same bits from every kernel.) */
 long m360_linear_heads_fused_rows(long M, int n_pad, int bf16);
 int m360_linear_heads_slots(int n_pad, int bf16);
 /* bf16 / bf16x3 (bf16 = 1 / 2): the number of slots m360_linear_heads_bf16 / _bf16x3 writes for THESE arguments - 2 per 256 columns

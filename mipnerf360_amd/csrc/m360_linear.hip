@@ -52,7 +52,7 @@ constexpr int TM = 4, TN = 2;   // 32x32 MFMA tiles per wave (M, N)
 template <int ACT>
 __device__ __forceinline__ float activate(float v) {
     if (ACT == M360_ACT_RELU) return relu_nanf_(v);
-    if (ACT == M360_ACT_SIGMOID) return persist::act_fn<M360_ACT_SIGMOID>(v);  // the same hardware exp / rcp form as the persistent kernel: rows of one layer never differ by kernel
+    if (ACT == M360_ACT_SIGMOID) return persist::act_fn<M360_ACT_SIGMOID>(v);  // the same hardware exp / rcp form as the persistent kernel (fp32: all three kernels give the same bits for a row)
     return v;
 }
 
@@ -475,8 +475,11 @@ static int linear_heads_bf16_any(const void *x, long M, int ldx, const void *w_p
     if (act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "%s: the last hidden layer is a sigmoid layer, act=%d", who, act);
     if (!x || !w_packed || !b_packed || !y || !head_w || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "%s: null pointer or negative M", who);
     const int xm = x3 ? 2 : 1;  // row-length multiplier of the [hi | lo] layout
-    long M_fused = m360_linear_heads_fused_rows(M, n_pad, 1);
-    if (!x3 && k_pad < 2 * pp16::BK) M_fused = 0;  // a single K-step: not the ping-pong kernel's shape
+    const long M_fused = m360_linear_heads_fused_rows(M, n_pad, 1);
+    // callers (and the finishers) take the fused row count from m360_linear_heads_fused_rows(M, n_pad, bf16), which does not see the
+    // contraction: a shape whose tiles this call could not fuse is an error, never a silently different row count
+    if (M_fused > 0 && !x3 && k_pad < 2 * pp16::BK)
+        return fail(M360_ERR_INVALID_ARGUMENT, "%s: k_pad=%d < %d with full %d-row tiles of a %d-wide layer: no kernel fuses the heads of a single 64-deep K-step (use m360_linear_bf16 + the unfused finisher)", who, k_pad, 2 * pp16::BK, pp16::BM, n_pad);
     if (M_fused > 0) {
         if (!head_part || ((uintptr_t)head_part & 15) || ((uintptr_t)head_w & 15)) return fail(M360_ERR_INVALID_ARGUMENT, "%s: head_part / head_w must be 16-byte aligned device pointers", who);
         if (k_pad < pbf16::BK || k_pad % pbf16::BK != 0 || ldx < xm * k_pad || ldy < xm * n_pad || ldx % 8 != 0 || ldy % 8 != 0)
@@ -830,6 +833,8 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
             case 28: M360_W16_ABL(128, true); break;  // variant 128: plain instead of non-temporal stores
             case 29: M360_W16_ABL(256, true); break;  // variant 129: non-temporal activation pieces
             case 30: M360_W16_ABL(512, true); break;  // variant 130: non-temporal weight pieces
+            case 31: M360_W16_ABL(1024, true); break;        // variant 131: pieces issued, never awaited: what does WAITING for LDS-DMA cost?
+            case 33: M360_W16_ABL(1024 + 16, true); break;   // variant 133: the same without the stores
             case 100: M360_W16_ABL(0, false); break;
             case 50: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 16, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // sigmoid epilogue, no stores: what would a last layer cost here?
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);

@@ -69,7 +69,7 @@ __device__ unsigned long long g_w16_stamps[256 * 4];
 #endif
 // ABL (diagnostic builds; results are wrong unless 0 or 64): 1 = no barrier, 2 = no LDS-DMA, 4 = no fragment reads, 16 = no stores,
 // 32 = no epilogue at all, 64 = wait for every outstanding operation at the end of the epilogue (how long do the stores take?),
-// 128 = plain instead of non-temporal stores (results correct)
+// 128 = plain instead of non-temporal stores (results correct), 1024 = no counted vmcnt waits in the K loop (wrong results)
 // X3 ("bf16x3", m360_linear_bf16_pp.hip.h): activations [hi(K) | lo(K)], weights [Wh | Wh | Wl] (rows of Kp = 3K), output
 // [hi(Np) | lo(Np)]; per 64-deep block three stages xl wh -> xh wh -> xh wl that share an operand with their neighbour
 // (tools/gen_w16_slab.py, second half): 4 operand tiles staged per block instead of 6, the same accumulation order as the ping-pong
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
 // register-tied variants would meet in a join and cost copies.
 #define W16_VMCNT(N, NS)                                                                                \
     do {                                                                                                \
+        if (ABL & 1024) break; /* diagnostics: the pieces are issued but never awaited (wrong results): ISSUE cost vs WAITING */ \
         if ((NS) > (N) && have_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS) > 63 ? 63 : (NS)) : "memory"); /* 6-bit counter */ \
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");                                   \
     } while (0)

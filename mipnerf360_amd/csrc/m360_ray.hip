@@ -456,8 +456,44 @@ template <int H, typename T>
 __device__ __forceinline__ void ray_heads_fused_wave(const float *__restrict__ head_part, int slots, const float *__restrict__ head_b,
                                                      long s0, int N, float *raw /*LDS [N][H], this wave's*/) {
     const int l = lane_id();
-    if (sizeof(T) == 2 && H == 4 && slots % 8 == 0) {
+    if (sizeof(T) == 4 && H == 4 && slots == 8) {
+        // fp32 NeRF stage at width 1024: a sample's 8 slots x 4 heads are 128 contiguous bytes.  Lane (sample l >> 3, slot l & 7)
+        // loads one float4 - a wave instruction reads 8 whole lines - and the slots are added in order 0, 1, ... 7 by a chain of
+        // row_shl DPP adds that ends in the group's first lane: ((((0 + x0) + x1) + x2) ... + x7) + bias, the order of ray_heads.
+        // Four independent loads in flight per lane (the kernel is latency-bound).
+        const int q = l & 7;
+        for (int n0 = l >> 3; n0 < N; n0 += 4 * (kWave >> 3)) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = n0 + u * (kWave >> 3);
+                v[u] = n < N ? *reinterpret_cast<const float4 *>(head_part + ((s0 + n) * 8 + q) * 4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = n0 + u * (kWave >> 3);
+                float a[4] = {0.0f + v[u].x, 0.0f + v[u].y, 0.0f + v[u].z, 0.0f + v[u].w};
+                const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#define M360_SHL_ADD(K)                                                                                                                  \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                                        \
+        a[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[c]), 0x100 + (K), 0xF, 0xF, true));
+                M360_SHL_ADD(1) M360_SHL_ADD(2) M360_SHL_ADD(3) M360_SHL_ADD(4) M360_SHL_ADD(5) M360_SHL_ADD(6) M360_SHL_ADD(7)
+#undef M360_SHL_ADD
+                if (q == 0 && n < N) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) raw[n * 4 + c] = a[c] + head_b[c];
+                }
+            }
+        }
+    } else if (H == 1 && slots == 2) {
+        // proposal stage at width 256 (fp32 kernel and the bf16 ring kernel alike): two partial sums per sample, one float2 per lane
+        for (int n = l; n < N; n += kWave) {
+            const float2 v = *reinterpret_cast<const float2 *>(head_part + (s0 + n) * 2);
+            raw[n] = ((0.0f + v.x) + v.y) + head_b[0];
+        }
+    } else if (sizeof(T) == 2 && H == 4 && slots % 8 == 0) {
         const int per = slots / 8, lane8 = l & 7;
+#pragma unroll 4
         for (int n = l >> 3; n < N; n += kWave >> 3) {
             const float4 *p = reinterpret_cast<const float4 *>(head_part + ((s0 + n) * slots + lane8 * per) * 4);
             float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -497,12 +533,12 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     const T *__restrict__ act, int ld, const float *__restrict__ head_part, long fused_rows, int slots,
     const float *__restrict__ head_w, const float *__restrict__ head_b, int k_pad, float density_bias,
     const float *__restrict__ t_vals, const float *__restrict__ dirs, const float *__restrict__ u_rand, int B, int N, int ns,
-    float padding, float *__restrict__ weights, float *__restrict__ t_new) {
+    float padding, float *__restrict__ weights, float *__restrict__ t_new, int rpb /* rays per workgroup: kFinishRays, or 1 when four rays' buffers exceed the LDS */) {
     extern __shared__ float smem[];
     const int l = lane_id(), wave = threadIdx.x >> 6;
     const int nb = N + 1;
-    const int b0 = blockIdx.x * kFinishRays;
-    const int b_end = (b0 + kFinishRays < B) ? b0 + kFinishRays : B;
+    const int b0 = blockIdx.x * rpb;
+    const int b_end = (b0 + rpb < B) ? b0 + rpb : B;
     // the tail of one ray: activation, weights (model.py:59-78), blur + inverse-CDF resampling (intern/ray.py:136-149), by one wave
     auto finish_ray = [&](int b, float *t, float *rho, float *w, float *w2, float *cdf) __attribute__((always_inline)) {
         for (int i = l; i < N; i += kWave) rho[i] = softplusf_(rho[i] + density_bias);
@@ -517,7 +553,7 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     };
     if (fused_rows >= (long)b_end * N) {  // workgroup-uniform: one wave per ray, no workgroup barrier
         const int b = b0 + wave;
-        if (b >= B) return;
+        if (wave >= rpb || b >= B) return;
         float *t = smem + wave * 5 * nb, *rho = t + nb, *w = rho + nb, *w2 = w + nb, *cdf = w2 + nb;
         for (int i = l; i < nb; i += kWave) t[i] = t_vals[(long)b * nb + i];
         ray_heads_fused_wave<1, T>(head_part, slots, head_b, (long)b * N, N, rho);
@@ -542,12 +578,12 @@ __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
     float rgb_padding, const float *__restrict__ t_vals, const float *__restrict__ dirs, int B, int N, int white_bkgd,
     float *__restrict__ comp_rgb, float *__restrict__ distance, float *__restrict__ acc,
     float *__restrict__ weights, float *__restrict__ t_out, float *__restrict__ s_out, const float *__restrict__ near,
-    const float *__restrict__ far, int ts_calls) {
+    const float *__restrict__ far, int ts_calls, int rpb) {
     extern __shared__ float smem[];
     const int l = lane_id(), wave = threadIdx.x >> 6;
     const int nb = N + 1;
-    const int b0 = blockIdx.x * kFinishRays;
-    const int b_end = (b0 + kFinishRays < B) ? b0 + kFinishRays : B;
+    const int b0 = blockIdx.x * rpb;
+    const int b_end = (b0 + rpb < B) ? b0 + rpb : B;
     // the tail of one ray by one wave: head activations (model.py:180-186), composite (intern/ray.py:155-191) and the two
     // tensors nerf_net.forward returns beside it (model.py:194-196): t_vals + 1e-6 (what g() inside t_to_s leaves behind) and
     // s_vals = t_to_s(t_vals, near, far) - until round 3 two more launches (add_eps_kernel, t_to_s_kernel), same arithmetic
@@ -580,7 +616,7 @@ __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
     };
     if (fused_rows >= (long)b_end * N) {  // workgroup-uniform: one wave per ray, no workgroup barrier
         const int b = b0 + wave;
-        if (b >= B) return;
+        if (wave >= rpb || b >= B) return;
         float *t = smem + wave * (2 * nb + 4 * N), *raw = t + nb, *w = raw + 4 * N;
         for (int i = l; i < nb; i += kWave) t[i] = t_vals[(long)b * nb + i];
         ray_heads_fused_wave<4, T>(head_part, slots, head_b, (long)b * N, N, raw);
@@ -879,12 +915,13 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
     if (B == 0) return M360_OK;
     // workgroup-wide form: head row + one ray's buffers; wave-per-ray form: kFinishRays rays' buffers
     const size_t lds_wg = ((size_t)k_pad + 5 * (N + 1)) * sizeof(float), lds_wave = (size_t)kFinishRays * 5 * (N + 1) * sizeof(float);
-    const size_t lds = lds_wg > lds_wave ? lds_wg : lds_wave;
+    const int rpb = (lds_wave <= kMaxDynLds) ? kFinishRays : 1;  // very long rays: one ray per workgroup, as before round 4
+    const size_t lds = rpb == 1 ? lds_wg : (lds_wg > lds_wave ? lds_wg : lds_wave);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    const dim3 grid((unsigned)((B + kFinishRays - 1) / kFinishRays));
-    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new);
-    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new);
-    else hipLaunchKernelGGL(prop_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new);
+    const dim3 grid((unsigned)((B + rpb - 1) / rpb));
+    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb);
+    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb);
+    else hipLaunchKernelGGL(prop_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb);
     return check_launch("prop_finish");
 }
 
@@ -943,12 +980,13 @@ static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_
     if (B == 0) return M360_OK;
     const size_t ray_floats = (size_t)2 * (N + 1) + 4 * N;
     const size_t lds_wg = ((size_t)4 * k_pad + ray_floats) * sizeof(float), lds_wave = (size_t)kFinishRays * ray_floats * sizeof(float);
-    const size_t lds = lds_wg > lds_wave ? lds_wg : lds_wave;
+    const int rpb = (lds_wave <= kMaxDynLds) ? kFinishRays : 1;
+    const size_t lds = rpb == 1 ? lds_wg : (lds_wg > lds_wave ? lds_wg : lds_wave);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
-    const dim3 grid((unsigned)((B + kFinishRays - 1) / kFinishRays));
-    if (bf16 == 2) hipLaunchKernelGGL((nerf_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls);
-    else if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls);
-    else hipLaunchKernelGGL(nerf_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls);
+    const dim3 grid((unsigned)((B + rpb - 1) / rpb));
+    if (bf16 == 2) hipLaunchKernelGGL((nerf_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb);
+    else if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb);
+    else hipLaunchKernelGGL(nerf_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb);
     return check_launch("nerf_finish");
 }
 

@@ -108,6 +108,51 @@ def test_c5_full_size_bf16_properties(dev):
     assert float((rgb_p - rgb[perm]).abs().mean()) <= 1e-4
 
 
+def test_c5_full_size_fp32_properties(dev):
+    """The exact-fp32 kernels at the largest single-GPU shape of BASELINE.json (configs[4]'s 8192 rays x 256 samples; the fp32
+    activation buffers are [2 097 152, 1024] = exactly 2^31 elements each - the index arithmetic of the half-tile / persistent
+    linear kernels, the encoder and the finishers past 32 bits): determinism, ranges, sorted resampled t, distance inside
+    [t_0, t_N], ray-permutation equivariance, and PARITY: the first and the last 128 rays of the batch, rendered by the oracle with
+    the whole batch's two contraction norms (what m360_*_forward_from_t take: intern/parameterization.py:23-29 spans all 8192
+    rays), against the rows of the full-size forward - the stated fp32 tolerance (model.py:163-200)."""
+    from mipnerf360_amd.intern.ray import Rays
+    from oracle import ref_path as O
+    B, N = 8192, 256
+    m, sd = make_model(dev, N)
+    r = synthetic.make_rays("garden", B, seed=33)
+    rays = dev_rays(r, dev)
+    with torch.no_grad():
+        rgb, dist, acc = m(rays)
+        tv = m.nerf_net.t_vals.clone()
+        rgb2, dist2, acc2 = m(rays)
+    assert torch.equal(rgb, rgb2) and torch.equal(dist, dist2) and torch.equal(acc, acc2)
+    assert torch.isfinite(rgb).all() and torch.isfinite(dist).all() and torch.isfinite(acc).all()
+    assert float(acc.min()) >= 0 and float(acc.max()) <= 1 + 1e-5
+    assert float(rgb.min()) >= -0.001 - 1e-6 and float(rgb.max()) <= 1.001 + 1e-6 and float(rgb.std()) > 1e-3
+    assert tv.shape == (B, N + 1) and torch.all(tv[:, 1:] >= tv[:, :-1])
+    assert torch.all(dist >= tv[:, 0] - 2e-6) and torch.all(dist <= tv[:, -1])
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to(dev)
+    with torch.no_grad():
+        rgb_p, dist_p, acc_p = m(Rays(*[f[perm].contiguous() for f in rays]))
+    assert float((rgb_p - rgb[perm]).abs().max()) <= 2e-5 and float((acc_p - acc[perm]).abs().max()) <= 2e-5
+    # the two whole-batch norms, from the device (fp64 sums of squares), then the oracle on two 128-ray slices with them
+    with torch.no_grad():
+        t_hat = m.sharded_sample(rays)
+        norm0 = m.sharded_sumsq(rays, t_hat).sqrt().float()
+        _, t_new = m.sharded_prop(rays, t_hat, norm0)
+        norm1 = m.sharded_sumsq(rays, t_new).sqrt().float()
+        again = m.sharded_nerf(rays, t_new, norm1)
+    assert float((again[0] - rgb).abs().max()) <= 2e-6             # the sharded entry points ARE the forward, up to the norm's bits
+    o_sd, hp = O.to_torch_state_dict(sd), O.Hyper(num_samples=N)
+    for sl in (slice(0, 128), slice(B - 128, B)):
+        sub = O.rays_from_numpy({k: v[sl] for k, v in r.items()})
+        with torch.no_grad():
+            _, o_t_new = O.prop_forward_from_t(sub, o_sd, hp, t_hat[sl].cpu(), norm0.cpu())
+            o_rgb, o_dist, o_acc = O.nerf_forward_from_t(sub, o_sd, hp, o_t_new, norm1.cpu())
+        assert float((rgb[sl].cpu() - o_rgb).abs().max()) <= 1e-4 and float((acc[sl].cpu() - o_acc).abs().max()) <= 1e-4
+        assert bool(torch.all((dist[sl].cpu() - o_dist).abs() <= 1e-4 * torch.clamp(o_dist.abs(), min=1.0)))
+
+
 def test_bench_c5_named_workload(dev):
     """`bench.py --config c5`: the configs[4] shape as a named bench workload (dtype bf16), never the default line."""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c5", "--steps", "3", "--warmup", "1"],

@@ -35,6 +35,8 @@ for s in $steps; do
                timeout 600 rocprofv3 $PMC --pmc FETCH_SIZE -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
                timeout 600 rocprofv3 $PMC --pmc WRITE_SIZE -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
                timeout 600 rocprofv3 $PMC --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1 )
+             # the sources these counters were measured on, stamped HERE (the summariser copies it, it never recomputes it)
+             python3 -c "import bench, json; print(json.dumps({'fp32': bench.kernel_source_sha(), 'bf16': bench.kernel_source_sha(bench.TRAFFIC_SOURCES_BF16)}))" > $O/kernel_source_sha256_at_measurement.json
              # raw traces are large: keep the csv files the summariser needs, drop the rest
              find $O -name "*.db" -delete 2>/dev/null; du -sh $O; tail -2 $O/bench_under_rocprof.log | cut -c1-300 ;;
     r3new)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "span or one_chunk or bench_ or two_ranks or c2_full or rccl or g18 or nan_rows" > $out/pytest_r3new.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r3new.log; tail -25 $out/pytest_r3new.log ;;
@@ -64,10 +66,13 @@ for s in $steps; do
                timeout 600 rocprofv3 $PMC --pmc FETCH_SIZE -d $O/pmc_b16_fetch -- $B > $O/pmc_b16_fetch.log 2>&1
                timeout 600 rocprofv3 $PMC --pmc WRITE_SIZE -d $O/pmc_b16_write -- $B > $O/pmc_b16_write.log 2>&1
                timeout 600 rocprofv3 $PMC --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS -d $O/pmc_b16_sq -- $B > $O/pmc_b16_sq.log 2>&1 )
+             python3 -c "import bench, json; print(json.dumps({'fp32': bench.kernel_source_sha(), 'bf16': bench.kernel_source_sha(bench.TRAFFIC_SOURCES_BF16)}))" > $O/kernel_source_sha256_at_measurement_b16.json
              find $O -name "*.db" -delete 2>/dev/null; ls $O/pmc_b16_sq/*/ | head -3 ;;
     c4b16)   timeout 900 python bench.py --config c4 --mlp-dtype bf16 --steps 3 --warmup 1 > $out/bench_c4_bf16.json 2> $out/bench_c4_bf16.err; tail -c 700 $out/bench_c4_bf16.json
              timeout 900 python bench.py --config c4 --mlp-dtype bf16x3 --steps 3 --warmup 1 > $out/bench_c4_bf16x3.json 2> $out/bench_c4_bf16x3.err; tail -c 700 $out/bench_c4_bf16x3.json ;;
     r4new)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s -k "g19 or x6 or psnr or structured or bf16" > $out/pytest_r4new.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r4new.log; grep -a "^G19\|^c2 structured\|passed\|failed\|FAILED\|Error" $out/pytest_r4new.log | tail -60 ;;
+    r4fin)   timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "finish or forward_vs_oracle or g7 or g9 or g14 or one_chunk or grouped or fused or c5_full_size_fp32 or x6 or checkpoint" > $out/pytest_r4fin.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r4fin.log; tail -8 $out/pytest_r4fin.log | cut -c1-300 ;;
+    nowait)  for v in 100 116 131 133; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/bf16_w16_no_wait_ablation.jsonl > $out/linear_bf16_w16_$v.log 2>&1; tail -2 $out/linear_bf16_w16_$v.log | cut -c1-400; done ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
