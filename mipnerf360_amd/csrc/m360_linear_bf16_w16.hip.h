@@ -331,7 +331,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                      : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
                        "+a"(acc[7][6]), "+a"(acc[7][7])::"memory");
         if (!(ABL & 32)) {
-            const __bf16 *yt = Y + (m0 + wm * 128) * ldy + n0 + wn * 128;  // wave-uniform corner of the wave tile
+            // (ABL 2048, diagnostics, wrong results: every tile of a workgroup is written over the SAME 256 rows - the stores keep their
+            // count, shape and TA occupancy but their lines stay in the XCD's L2: what does the HBM side of the output cost the K loop?)
+            const __bf16 *yt = Y + (((ABL & 2048) ? (long)blockIdx.x * BM : m0) + wm * 128) * ldy + n0 + wn * 128;  // wave-uniform corner of the wave tile
             f32x4 hacc[8];  // HEADS: the head sums of this lane's rows (one per activation block) over the pieces done so far
 #pragma unroll
             for (int P = 0; P < 2; ++P) {  // column pieces p = 2P, 2P + 1: 64 output columns = one 128-byte line per row

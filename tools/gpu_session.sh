@@ -72,7 +72,7 @@ for s in $steps; do
              timeout 900 python bench.py --config c4 --mlp-dtype bf16x3 --steps 3 --warmup 1 > $out/bench_c4_bf16x3.json 2> $out/bench_c4_bf16x3.err; tail -c 700 $out/bench_c4_bf16x3.json ;;
     r4new)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s -k "g19 or x6 or psnr or structured or bf16" > $out/pytest_r4new.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r4new.log; grep -a "^G19\|^c2 structured\|passed\|failed\|FAILED\|Error" $out/pytest_r4new.log | tail -60 ;;
     r4fin)   timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "finish or forward_vs_oracle or g7 or g9 or g14 or one_chunk or grouped or fused or c5_full_size_fp32 or x6 or checkpoint" > $out/pytest_r4fin.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r4fin.log; tail -8 $out/pytest_r4fin.log | cut -c1-300 ;;
-    nowait)  for v in 100 116 131 133; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/bf16_w16_no_wait_ablation.jsonl > $out/linear_bf16_w16_$v.log 2>&1; tail -2 $out/linear_bf16_w16_$v.log | cut -c1-400; done ;;
+    nowait)  for v in 100 116 131 133 134 135 100; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/bf16_w16_no_wait_ablation.jsonl > $out/linear_bf16_w16_$v.log 2>&1; tail -2 $out/linear_bf16_w16_$v.log | cut -c1-400; done ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
