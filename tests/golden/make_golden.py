@@ -816,10 +816,57 @@ def g19():
     save("g19_structured_weights", **out)
 
 
+def g20():
+    """A checkpoint TRAINED by the build's own training loop, rendered by the REFERENCE (optional part; rows
+    f3 + f4 + the whole path).  `tools/train_demo.py --steps 500 --rays 1024 --samples 32 --hidden 32 64 --lr 3e-3 --kind lego
+    --teacher structured --white-bkgd --save ...` ran on an MI355X: the reference's loop body (train.py:53-82) on the HIP mirrors
+    (tape-keeping forwards, hand-written backward, AdamW), a Kaiming-initialised student fitted to the pixels a structured
+    (G19) teacher renders for 1024 lego rays; the student's state_dict was written with torch.save in the reference's checkpoint
+    layout (train.py:98-103) and is committed as tests/golden/g20_trained_checkpoint.pt.  Here the reference's own class loads
+    that file and renders the same 1024 rays as ONE chunk (the chunk size it was trained at), in fp32 and in fp64."""
+    path = os.path.join(HERE, "g20_trained_checkpoint.pt")
+    sd_t = torch.load(path, map_location="cpu")
+    sd = {k: N(v) for k, v in sd_t.items()}
+    meta = __import__("json").load(open(os.path.join(HERE, "g20_training_run.json")))
+    B, n, hp_, hn_, wb = int(meta["rays"]), int(meta["samples"]), int(meta["hidden"][0]), int(meta["hidden"][1]), bool(meta["white_bkgd"])
+    r = synthetic.make_rays(meta["kind"], B, seed=int(meta["rays_seed"]))
+    out = {"cfg": np.array([B, n, int(wb), hp_, hn_, int(meta["rays_seed"])])}
+    for k in synthetic.RAY_FIELDS:
+        out["rays_" + k] = r[k]
+    m = build_ref_model(sd, n, hp_, hn_, wb)
+    t0 = time.time()
+    with torch.no_grad():
+        rays = ref_rays(r)
+        t_hat, w_hat = m.prop_net.forward(rays)
+        t_hat_np, w_hat_np = N(t_hat), N(w_hat)
+        o = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    print(f"  G20 fp32: {time.time() - t0:.1f}s")
+    t0 = time.time()
+    with reference_in_fp64():
+        m64 = build_ref_model(sd, n, hp_, hn_, wb)
+        m64.load_state_dict({k: T64(v) for k, v in sd.items()})
+        m64 = m64.double()
+        with torch.no_grad():
+            rays64 = ref_ray.Rays(*[T64(r[k]) for k in synthetic.RAY_FIELDS])
+            t_hat64, w_hat64 = m64.prop_net.forward(rays64)
+            w_hat64_np = N(w_hat64)
+            o64 = m64.nerf_net.forward(rays64, t_vals=t_hat64, coarse_weights=w_hat64)
+    print(f"  G20 fp64: {time.time() - t0:.1f}s")
+    out["t_hat"], out["w_hat"], out["w_hat64"] = t_hat_np, w_hat_np, w_hat64_np.astype(np.float32)
+    for nm, v, v64 in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), o, o64):
+        out[nm], out[nm + "64"] = N(v), N(v64).astype(np.float32)
+    rgb, acc = out["rgb"], out["acc"]
+    peak = w_hat_np.max(1) / np.maximum(w_hat_np.mean(1), 1e-30)
+    print(f"  G20: rgb std over rays {rgb.std(0).round(3)}  acc [{acc.min():.3f}, {acc.max():.3f}]  w_hat max/mean median {np.median(peak):.1f}; "
+          f"student on the GPU after training: rgb std {meta.get('student_rgb_std_over_rays')}, PSNR trajectory "
+          f"{[t['psnr'] for t in meta['trajectory']][:3]} ... {[t['psnr'] for t in meta['trajectory']][-2:]}")
+    save("g20_trained_checkpoint_render", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
     table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14,
-                 g15=g15, g16=g16, g17=g17, g18=g18, g19=g19)
+                 g15=g15, g16=g16, g17=g17, g18=g18, g19=g19, g20=g20)
     for k in which:
         print(k)
         table[k]()

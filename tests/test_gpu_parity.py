@@ -343,6 +343,34 @@ def test_finishers_wave_per_ray_match_one_ray_at_a_time(dev, B, N, width):
                 assert torch.equal(a, c)
 
 
+# =============================================================================== one-launch prologue
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3"])
+def test_fused_prologue_matches_the_separate_kernels_bit_for_bit(dev, mlp_dtype):
+    """Round 4: the rendering forward of a large chunk starts with ONE prologue launch (t, view-direction encoding, the norm's partial
+    sums from t RECOMPUTED instead of read back, queue words) and the encoder's workgroups take the norm's final sum themselves.
+    Against the separate entry points, which still exist: t_hat == m360_sample_t bit for bit, and the proposal weights / resampled t ==
+    m360_prop_forward_from_t fed with the norm that m360_mean_sumsq computes with norm_partial_from_t_kernel + norm_final_kernel (the
+    same partition and order: the same bits), NeRF stage likewise."""
+    from mipnerf360_amd import ops
+    B, N = 2048, 128                      # 262 144 samples: above the one-workgroup norm's 131 072
+    sd = synthetic.make_state_dict(64, 128, seed=21)
+    m = _g19_model(sd, dev, N, 64, 128, False, mlp_dtype)
+    rays = dev_rays(synthetic.make_rays("lego", B, seed=22), dev)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+        out = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        rgb, dist, acc = m(rays)
+        assert torch.equal(t_hat, ops.sample_t(rays.near, rays.far, N))
+        norm0 = m.sharded_sumsq(rays, t_hat).sqrt().float()
+        w2, t_new = m.sharded_prop(rays, t_hat, norm0)
+        assert torch.equal(w2, w_hat)
+        norm1 = m.sharded_sumsq(rays, t_new).sqrt().float()
+        rgb2, dist2, acc2 = m.sharded_nerf(rays, t_new, norm1)
+    for a, b in ((rgb2, out[0]), (dist2, out[1]), (acc2, out[2]), (rgb, out[0]), (dist, out[1]), (acc, out[2])):
+        assert torch.equal(a, b)
+    assert torch.equal(out[3], t_new + 1e-6)
+
+
 # =============================================================================== x6: first layers of the bf16 modes
 def test_x6_feature_rows_and_weight_packing(dev):
     """Row format 3 of the encoder and m360_pack_linear_bf16x6: three bf16 terms per value (exact: hi + mid + lo == the fp32
@@ -534,6 +562,49 @@ def test_c2_headline_batch_on_structured_weights_vs_oracle_as_one_chunk(dev, mlp
                                                   what=f"c2 structured {mlp_dtype} {nm}")
     print(f"c2 structured {mlp_dtype}: " + "  ".join(f"{k} {a:.1e}/{b:.1e}" for k, (a, b) in worst.items()))
     close_render(out[0], out[1], out[2], o32["rgb"], o32["dist"], o32["acc"])
+
+
+# =============================================================================== G20: a trained checkpoint
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3", "bf16"])
+def test_g20_trained_checkpoint_renders_like_the_reference(golden, dev, mlp_dtype):
+    """Rows f3 + f4 + the whole path on weights that OPTIMISATION produced: tests/golden/g20_trained_checkpoint.pt was trained on an
+    MI355X by the reference's loop body running on the HIP mirrors (tools/train_demo.py, 500 iterations, PSNR 2 -> 29-34 dB), saved
+    in the reference's checkpoint layout (train.py:98-103) and rendered by the reference's own class (fixture G20, fp32 + fp64).
+    `load_reference_checkpoint` loads the file (architecture inferred from the tensor shapes) and the HIP path renders the 1024
+    training rays as ONE chunk: fp32 and bf16x3 within 4 x the reference's own fp32 error on every stage output and inside the stated
+    1e-4 on the rendered values; bf16: PSNR within 0.1 dB of the reference's against the training target's noise levels."""
+    import json
+    import os
+    from conftest import GOLDEN_DIR
+    from mipnerf360_amd import checkpoint
+    g = golden("g20_trained_checkpoint_render")
+    meta = json.load(open(os.path.join(GOLDEN_DIR, "g20_training_run.json")))
+    B, n, wb, hp_, hn_, seed = (int(x) for x in g["cfg"])
+    m = checkpoint.load_reference_checkpoint(os.path.join(GOLDEN_DIR, "g20_trained_checkpoint.pt"), device=dev, num_samples=n,
+                                             white_bkgd=bool(wb), mlp_dtype=mlp_dtype)
+    assert (m.hidden_proposal, m.hidden_nerf) == (hp_, hn_)
+    rays = dev_rays({k: g["rays_" + k] for k in synthetic.RAY_FIELDS}, dev)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+        out = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    got = dict(zip(G19_STAGE_NAMES, (H(w_hat),) + tuple(H(v) for v in out)))
+    if mlp_dtype == "bf16":
+        ref_rgb = g["rgb"].astype(np.float64)
+        gen = np.random.Generator(np.random.PCG64(2020))
+        worst = 0.0
+        for noise in (0.02, 0.1, 0.3):
+            target = np.clip(ref_rgb + noise * gen.normal(size=ref_rgb.shape), 0.0, 1.0)
+            psnr = lambda a: -10.0 * np.log10(np.mean((np.clip(a, 0, 1) - target) ** 2))  # noqa: E731
+            worst = max(worst, abs(psnr(got["rgb"].astype(np.float64)) - psnr(ref_rgb)))
+        print(f"G20 bf16: PSNR differs from the reference's by {worst:.5f} dB, max |d rgb| {np.abs(got['rgb'] - g['rgb']).max():.2e}")
+        assert worst <= 0.1 and np.abs(got["rgb"] - g["rgb"]).max() <= 2e-2
+        return
+    worst = {}
+    for nm in G19_STAGE_NAMES:
+        worst[nm] = assert_within_reference_error(got[nm], g[nm], g[nm + "64"], c=4.0, floor=5e-6, relative_above_one=nm in ("dist", "t_vals"),
+                                                  what=f"G20 {mlp_dtype} {nm}")
+    print(f"G20 {mlp_dtype}: " + "  ".join(f"{k} {a:.1e}/{b:.1e}" for k, (a, b) in worst.items()))
+    close_render(out[0], out[1], out[2], g["rgb"], g["dist"], g["acc"])
 
 
 # =============================================================================== oracle, seeded inputs

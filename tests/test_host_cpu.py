@@ -448,11 +448,42 @@ def test_bench_launcher_starts_ranks_and_reports_their_failure():
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
         assert res.returncode == 0 and '"n_gpus": 2' in res.stdout
         return
+    if torch.cuda.is_available():  # a 1-GPU box: the parent's pre-flight refuses before any rank exists (see the test below)
+        assert res.returncode == 2 and "only 1 GPU(s) are visible" in res.stderr
+        return
     assert res.returncode != 0
     assert "launch with torch.distributed.run" not in res.stderr
     assert "2-rank child run failed" in res.stderr
     if not torch.cuda.is_available():
         assert "needs a HIP device" in res.stderr
+
+
+def test_bench_preflight_counts_gpus_without_touching_them(tmp_path, monkeypatch):
+    """`bench.py --gpus N` beyond the visible GPUs is refused by the PARENT with one line and rc = 2 (round 3
+    failed only after N processes had initialised, with RCCL's 'Duplicate GPU').  The count comes from the KFD topology in sysfs
+    (simd_count > 0 = a GPU node) narrowed by *_VISIBLE_DEVICES - no HIP call, no torch import.  Here: a fake topology."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for i, simd in enumerate((0, 0, 256, 256, 256)):       # two CPU nodes, three GPU nodes
+        d = tmp_path / "nodes" / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {16 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count(str(tmp_path / "nodes")) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count(str(tmp_path / "nodes")) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpu_count(str(tmp_path / "nodes")) == 1
+    assert bench.visible_gpu_count(str(tmp_path / "missing")) is None     # no driver: unknown, the ranks report it themselves
+    # and the refusal itself, through launch(): 4 ranks on (fake) 1 visible GPU
+    monkeypatch.setattr(bench, "visible_gpu_count", lambda sysfs=None: 1)
+    args = bench.parse_args(["--gpus", "4"])
+    assert bench.launch(args, ["--gpus", "4"]) == 2
+    args = bench.parse_args(["--gpus", "4", "--dry-launch"])
+    assert bench.launch(args, ["--gpus", "4", "--dry-launch"]) == 0       # printing the command needs no GPU
 
 
 def test_dropin_falls_through_to_reference_helpers(tmp_path):

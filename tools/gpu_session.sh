@@ -73,6 +73,9 @@ for s in $steps; do
     r4new)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s -k "g19 or x6 or psnr or structured or bf16" > $out/pytest_r4new.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r4new.log; grep -a "^G19\|^c2 structured\|passed\|failed\|FAILED\|Error" $out/pytest_r4new.log | tail -60 ;;
     r4fin)   timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "finish or forward_vs_oracle or g7 or g9 or g14 or one_chunk or grouped or fused or c5_full_size_fp32 or x6 or checkpoint" > $out/pytest_r4fin.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r4fin.log; tail -8 $out/pytest_r4fin.log | cut -c1-300 ;;
     nowait)  for v in 100 116 131 133 134 135 100; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/bf16_w16_no_wait_ablation.jsonl > $out/linear_bf16_w16_$v.log 2>&1; tail -2 $out/linear_bf16_w16_$v.log | cut -c1-400; done ;;
+    k384)    for v in 100 128 100 128; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --k 384 --no-check --rounds 5 --json $out/bf16_w16_k384.jsonl > $out/linear_bf16_k384_$v.log 2>&1; tail -1 $out/linear_bf16_k384_$v.log | cut -c1-400; done
+             for v in 100 116; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --k 384 --n 256 --no-check --rounds 5 --json $out/bf16_w16_k384.jsonl > $out/linear_bf16_k384_n256_$v.log 2>&1; tail -1 $out/linear_bf16_k384_n256_$v.log | cut -c1-400; done ;;
+    g20)     timeout 900 python tools/train_demo.py --steps 500 --rays 1024 --samples 32 --hidden 32 64 --lr 3e-3 --kind lego --teacher structured --white-bkgd --save $out/g20_trained_student.pt > $out/g20_train.json 2> $out/g20_train.err; cat $out/g20_train.json | cut -c1-1500 ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac

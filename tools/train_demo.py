@@ -25,15 +25,20 @@ from mipnerf360_amd.model import mipNeRF360  # noqa: E402
 
 
 def run(steps=150, rays_n=1024, samples=32, hp=64, hn=128, lr=2e-3, dist_weight=0.01, seed=0, device="cuda:0", log_every=25,
-        randomized=False):
+        randomized=False, kind="garden", teacher_kind="kaiming", save=None, white_bkgd=False):
+    """teacher_kind="structured": the teacher carries the trained-like weights of fixture G19 (high-contrast colours, density
+    shells), so the student is fitted to an image with signal.  save: write the trained student's state_dict in the reference's
+    checkpoint layout (train.py:98-103) - fixture G20 is such a file, rendered by the reference itself."""
     dev = torch.device(device)
     torch.manual_seed(seed)
-    kw = dict(randomized=False, num_samples=samples, hidden_proposal=hp, hidden_nerf=hn, white_bkgd=False, device=dev)
+    kw = dict(randomized=False, num_samples=samples, hidden_proposal=hp, hidden_nerf=hn, white_bkgd=white_bkgd, device=dev)
     teacher = mipNeRF360(**kw)
     student = mipNeRF360(**dict(kw, randomized=randomized))   # train.py's default is randomized=True (config.py:14)
-    teacher.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(hp, hn, seed=100 + seed).items()})
+    r = synthetic.make_rays(kind, rays_n, seed=300 + seed)
+    t_sd = (synthetic.make_structured_state_dict(hp, hn, 100 + seed, r, samples) if teacher_kind == "structured"
+            else synthetic.make_state_dict(hp, hn, seed=100 + seed))
+    teacher.load_state_dict({k: torch.from_numpy(v) for k, v in t_sd.items()})
     student.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(hp, hn, seed=200 + seed).items()})
-    r = synthetic.make_rays("garden", rays_n, seed=300 + seed)
     rays = Rays(*[torch.from_numpy(r[f]).to(dev) for f in synthetic.RAY_FIELDS])
     with torch.no_grad():
         pixels, _, _ = teacher(rays)
@@ -62,8 +67,20 @@ def run(steps=150, rays_n=1024, samples=32, hp=64, hn=128, lr=2e-3, dist_weight=
             traj.append({"step": step, "psnr": round(float(psnr), 3), "loss_prop": round(float(loss_prop.detach()), 4),
                          "loss_dist": round(float(loss_dist.detach()), 5)})
     torch.cuda.synchronize()
-    return {"steps": steps, "rays": rays_n, "samples": samples, "hidden": [hp, hn], "seconds": round(time.perf_counter() - t0, 2),
-            "trajectory": traj}
+    out = {"steps": steps, "rays": rays_n, "samples": samples, "hidden": [hp, hn], "seconds": round(time.perf_counter() - t0, 2),
+           "kind": kind, "teacher": teacher_kind, "rays_seed": 300 + seed, "white_bkgd": bool(white_bkgd),
+           "target_rgb_std_over_rays": [round(float(v), 4) for v in pixels.std(0)], "trajectory": traj}
+    if save:
+        from mipnerf360_amd import checkpoint
+        student.eval()
+        with torch.no_grad():
+            rgb, _, acc = student(rays)
+        out["student_rgb_std_over_rays"] = [round(float(v), 4) for v in rgb.std(0)]
+        out["student_acc_range"] = [round(float(acc.min()), 4), round(float(acc.max()), 4)]
+        os.makedirs(os.path.dirname(os.path.abspath(save)), exist_ok=True)
+        torch.save(checkpoint.to_reference_state_dict(student), save)
+        out["saved"] = save
+    return out
 
 
 def main():
@@ -74,8 +91,13 @@ def main():
     ap.add_argument("--hidden", type=int, nargs=2, default=[64, 128])
     ap.add_argument("--lr", type=float, default=2e-3)
     ap.add_argument("--randomized", action="store_true", help="stratified jitter in both stages, as train.py does by default")
+    ap.add_argument("--kind", default="garden", choices=("garden", "lego", "mixed"))
+    ap.add_argument("--teacher", default="kaiming", choices=("kaiming", "structured"))
+    ap.add_argument("--white-bkgd", action="store_true")
+    ap.add_argument("--save", default=None, help="write the trained student's state_dict (reference checkpoint layout) here")
     a = ap.parse_args()
-    print(json.dumps(run(a.steps, a.rays, a.samples, a.hidden[0], a.hidden[1], a.lr, randomized=a.randomized)))
+    print(json.dumps(run(a.steps, a.rays, a.samples, a.hidden[0], a.hidden[1], a.lr, randomized=a.randomized, kind=a.kind,
+                         teacher_kind=a.teacher, save=a.save, white_bkgd=a.white_bkgd)))
 
 
 if __name__ == "__main__":
