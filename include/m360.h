@@ -205,7 +205,11 @@ int m360_linear_bf16x3(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M,
  * [n_pad, 6 k_pad] = [Wh | Wm | Wl | Wh | Wm | Wh], and ONE plain bf16 contraction of length 6 k_pad forms
  * xl wh + xm wm + xh wl + xm wh + xh wm + xh wh, small terms first, fp32 accumulation: the fp32 product up to 2^-24 terms.
  * m360_linear_bf16 (bf16 rows out) runs it in the bf16 mode, m360_linear_bf16_split ([hi | lo] pair rows out, the row format of
- * m360_linear_bf16x3; bias + {none, ReLU}) in the bf16x3 mode; 6 k_pad = 384 takes the one-wave ring kernel. */
+ * m360_linear_bf16x3; bias + {none, ReLU}) in the bf16x3 mode; 6 k_pad = 384 takes the one-wave ring kernel.
+ * Non-finite values: a NaN feature or weight makes its row NaN as in fp32 (hi carries it, mid = lo = 0).  An INFINITE weight
+ * differs: the fp32 product x * Inf is +-Inf, the split products contain 0 * Inf = NaN whenever a term of x is zero (any x
+ * that bf16 represents exactly) - such a checkpoint renders NaN one layer earlier than the fp32 path (which turns it into NaN
+ * in the next layer's mixed-sign sum); the same holds for the two-term products of m360_linear_bf16x3. */
 int m360_pack_linear_bf16x6(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                             void *w_packed6_bf16 /*[n_pad, 6 k_pad]*/, float *b_packed, m360_stream_t stream);
 int m360_linear_bf16_split(const void *x_bf16 /*[M, ldx >= k_pad]*/, long M, int ldx, const void *w_packed_bf16,

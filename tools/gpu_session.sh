@@ -29,9 +29,9 @@ for s in $steps; do
              for v in 10 11 12 13; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/linear_bf16_rg.jsonl > $out/linear_bf16_v$v.log 2>&1; tail -1 $out/linear_bf16_v$v.log; done
              timeout 300 python tools/linear_bench.py --dtype bf16 --variant 9 --m 77056 --n 768 --k 192 > $out/linear_bf16_v9_odd.log 2>&1; tail -2 $out/linear_bf16_v9_odd.log
              timeout 300 python tools/linear_bench.py --dtype bf16 --variant 9 --m 65536 --n 256 --k 128 > $out/linear_bf16_v9_k128.log 2>&1; tail -2 $out/linear_bf16_v9_k128.log ;;
-    prof)    R=$PWD; O=$R/$out; PMC="--kernel-trace --output-format csv"; B="python3 $R/bench.py --steps 3 --warmup 1 --cpu-rays 0 --frame-steps 0"
+    prof)    R=$PWD; O=$R/$out; PMC="--kernel-trace --output-format csv"; B="python3 $R/bench.py --steps 3 --warmup 1 --cpu-rays 0 --frame-steps 0 --no-named"
              ( cd /tmp && export TMPDIR=/tmp
-               timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-rays 0 --frame-steps 0 > $O/bench_under_rocprof.log 2>&1
+               timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-rays 0 --frame-steps 0 --no-named > $O/bench_under_rocprof.log 2>&1
                timeout 600 rocprofv3 $PMC --pmc FETCH_SIZE -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
                timeout 600 rocprofv3 $PMC --pmc WRITE_SIZE -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
                timeout 600 rocprofv3 $PMC --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1 )

@@ -66,8 +66,12 @@ def step_trace(d, out):
     first, last_k = ("stage_prologue_kernel", "nerf_finish_kernel") if any("stage_prologue_kernel" in n for n in names) else ("sample_t_kernel", "t_to_s_kernel")
     starts = [i for i, n in enumerate(names) if first in n and any(last_k in m for m in names[i:])]
     ends = [min(j for j, n in enumerate(names) if last_k in n and j > i) for i in starts]
+    # rendering forwards only (18 launches since round 4, 26 before): the named workloads of the same process also train
+    keep = [k for k, (s_, e_) in enumerate(zip(starts, ends)) if e_ - s_ + 1 <= 26 and any("linear_f32" in n for n in names[s_:e_ + 1])]
+    starts, ends = [starts[k] for k in keep], [ends[k] for k in keep]
     spans = [int(rows[e]["End_Timestamp"]) - int(rows[s]["Start_Timestamp"]) for s, e in zip(starts, ends)]
-    full = [k for k, sp in enumerate(spans) if sp > 0.8 * max(spans)]  # the 4096-ray bench steps (not the 1024-ray parity pass)
+    med = sorted(spans)[len(spans) // 2]
+    full = [k for k, sp in enumerate(spans) if 0.9 * med < sp < 1.1 * med]  # the 4096-ray bench steps (not a frame's partial chunk, not c5)
     last, end = starts[full[-1]], ends[full[-1]]
     with open(out, "w") as f:
         f.write("order,kernel,duration_us\n")
