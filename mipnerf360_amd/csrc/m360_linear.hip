@@ -837,6 +837,8 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
             case 33: M360_W16_ABL(1024 + 16, true); break;   // variant 133: the same without the stores
             case 34: M360_W16_ABL(2048, true); break;        // variant 134: the stores rewrite the workgroup's first 256 rows (L2-resident output)
             case 35: M360_W16_ABL(2048 + 128, true); break;  // variant 135: the same with plain (temporal) stores
+            case 36: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, true, false, false, 0, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // variant 136: the LDS epilogue, stamped (results correct)
+            case 37: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 16, true, false, false, 0, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // variant 137: ... without its stores
             case 100: M360_W16_ABL(0, false); break;
             case 50: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 16, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // sigmoid epilogue, no stores: what would a last layer cost here?
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);

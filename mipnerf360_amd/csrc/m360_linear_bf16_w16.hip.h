@@ -85,12 +85,17 @@ __device__ unsigned long long g_w16_stamps[256 * 4];
 constexpr int kHeadMaxN = 1024;  // widest layer the fused heads take (their hi / lo rows live in 16 KiB of LDS)
 // SPLIT (defaults to X3): the output rows are [hi(Np) | lo(Np)] pairs.  SPLIT without X3 is the x6 first layer of the bf16x3 mode
 // (m360_linear_bf16_split): a plain contraction over bf16 rows whose fp32 result goes out as two bf16 terms.
-template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0, bool SPLIT = X3>
+// LDSEPI (round 4, plain bf16 output only): the epilogue moves the accumulators through a wave-private LDS tile instead of the vector
+// pipe - ds_write_b128 straight from the AccVGPRs (16 rows x 64 fp32 columns, XOR-swizzled 16-byte chunks: no bank conflicts),
+// ds_read_b128 back with lane (row L >> 3, columns 8 (L & 7) ..+7), so that 8 lanes hold one 128-byte line of bf16 output: no
+// v_accvgpr_read, no DPP exchange - 24 instead of 48 vector instructions per 16 outputs, same bias add / conversion / ReLU: same bits.
+template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0, bool SPLIT = X3, bool LDSEPI = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, const float *__restrict__ head_w = nullptr,
     float *__restrict__ head_part = nullptr) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0)];  // 144 (160) KiB
+    __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0) + (LDSEPI ? 4 * 4096 : 0)];  // 144 (160) KiB
+    static_assert(!LDSEPI || (HEADS == 0 && !SPLIT && !X3), "the LDS epilogue: plain bf16 output (its 16 KiB sit where the head rows would)");
     static_assert(HEADS == 0 || HEADS == 1 || HEADS == 4, "1 (proposal) or 4 (NeRF) heads");
     static_assert(SPLIT == X3 || (SPLIT && !X3 && HEADS == 0), "split output without the X3 loop: hidden-layer epilogue only");
     constexpr bool STORE_Y = HEADS == 0;
@@ -330,7 +335,58 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         asm volatile("s_nop 15\n\ts_nop 15"
                      : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
                        "+a"(acc[7][6]), "+a"(acc[7][7])::"memory");
-        if (!(ABL & 32)) {
+        if (LDSEPI && !(ABL & 32)) {
+            const __bf16 *yt = Y + (m0 + wm * 128) * ldy + n0 + wn * 128;  // wave-uniform corner of the wave tile
+            // wave-private staging tile: 16 rows x 256 B; 16-byte chunk c of row r lives in slot c ^ r
+            const unsigned stg = lds0 + 2 * kStageBytes + kMaxBias * 4 + (unsigned)wave * 4096u;
+            unsigned wad[4], rad[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // accumulator tuple q of a column half: chunk 8 (q >> 1) + 2 g4 + (q & 1) of row l15
+                const int c = 8 * (q >> 1) + 2 * g4 + (q & 1);
+                wad[q] = stg + (unsigned)(l15 * 256 + ((c ^ l15) * 16));
+            }
+            const int rr = lane >> 3, c0 = 2 * (lane & 7);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // rows rr (q < 2) and rr + 8 (q >= 2), chunks c0, c0 + 1
+                const int r = rr + 8 * (q >> 1), c = c0 + (q & 1);
+                rad[q] = stg + (unsigned)(r * 256 + ((c ^ r) * 16));
+            }
+            const unsigned y_voff2 = (unsigned)(rr * ldy + 8 * (lane & 7)) * 2u;
+            const unsigned bias2 = lds0 + 2 * kStageBytes + 4u * (unsigned)(wn * 128 + 8 * (lane & 7));
+#pragma unroll
+            for (int P = 0; P < 2; ++P) {
+                f32x4 b0, b1;  // bias of this lane's 8 columns of the half
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(b0), "=&v"(b1) : "v"(bias2 + 4u * (unsigned)(n0 + 64 * P)) : "memory");
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    asm volatile("ds_write_b128 %0, %4\n\tds_write_b128 %1, %5\n\tds_write_b128 %2, %6\n\tds_write_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                                 ::"v"(wad[0]), "v"(wad[1]), "v"(wad[2]), "v"(wad[3]), "a"(acc[i][4 * P + 0]), "a"(acc[i][4 * P + 1]),
+                                 "a"(acc[i][4 * P + 2]), "a"(acc[i][4 * P + 3]) : "memory");
+                    f32x4 v0, v1, v2, v3;
+                    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(rad[0]), "v"(rad[1]), "v"(rad[2]), "v"(rad[3]) : "memory");
+                    u32x4 s1, s2;
+#define W16_PK(DST, e, A, be, B_)                                                                     \
+    do {                                                                                              \
+        f32x2 t_ = {A[be] + B_[be], A[(be) + 1] + B_[(be) + 1]};                                     \
+        const bf16x2 h_ = __builtin_convertvector(t_, bf16x2);                                        \
+        s16x2 p_ = __builtin_bit_cast(s16x2, h_);                                                     \
+        if (ACT == M360_ACT_RELU) p_ = __builtin_elementwise_max(p_, (s16x2){0, 0});                  \
+        DST[e] = __builtin_bit_cast(unsigned, p_);                                                    \
+    } while (0)
+                    W16_PK(s1, 0, v0, 0, b0); W16_PK(s1, 1, v0, 2, b0); W16_PK(s1, 2, v1, 0, b1); W16_PK(s1, 3, v1, 2, b1);
+                    W16_PK(s2, 0, v2, 0, b0); W16_PK(s2, 1, v2, 2, b0); W16_PK(s2, 2, v3, 0, b1); W16_PK(s2, 3, v3, 2, b1);
+#undef W16_PK
+                    const __bf16 *row = yt + (long)(16 * i) * ldy + 64 * P;
+                    if (!(ABL & 16))
+                        asm volatile("global_store_dwordx4 %0, %1, %3 nt\n\tglobal_store_dwordx4 %0, %2, %4 nt\n\ts_nop 1"
+                                     ::"v"(y_voff2), "v"(s1), "v"(s2), "s"(row), "s"(row + 8 * (long)ldy) : "memory");
+                    else asm volatile("" ::"v"(s1), "v"(s2));
+                }
+                W16_SB();
+            }
+        } else if (!(ABL & 32)) {
             // (ABL 2048, diagnostics, wrong results: every tile of a workgroup is written over the SAME 256 rows - the stores keep their
             // count, shape and TA occupancy but their lines stay in the XCD's L2: what does the HBM side of the output cost the K loop?)
             const __bf16 *yt = Y + (((ABL & 2048) ? (long)blockIdx.x * BM : m0) + wm * 128) * ldy + n0 + wn * 128;  // wave-uniform corner of the wave tile

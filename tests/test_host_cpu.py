@@ -640,9 +640,9 @@ def test_ring_kernel_store_instructions_match_its_counted_waits(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     text = open(out).read()
     seen = 0
-    # _ZN4m3603w1622linear_bf16_w16_kernelILi<ACT>ELi<ABL>ELb<STAMP>ELb<X3>ELb<ONE_BLOCK>ELi<HEADS>ELb<SPLIT>EEE...
+    # _ZN4m3603w1622linear_bf16_w16_kernelILi<ACT>ELi<ABL>ELb<STAMP>ELb<X3>ELb<ONE_BLOCK>ELi<HEADS>ELb<SPLIT>ELb<LDSEPI>EEE...
     split_without_x3 = 0
-    for m in re.finditer(r"^(_ZN4m3603w1622linear_bf16_w16_kernelILi(\d)ELi0ELb0ELb([01])ELb([01])ELi(\d)ELb([01])EEE\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN4m3603w1622linear_bf16_w16_kernelILi(\d)ELi0ELb0ELb([01])ELb([01])ELi(\d)ELb([01])ELb0EEE\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
         x3, heads, split, body = m.group(3) == "1", int(m.group(5)), m.group(6) == "1", m.group(7)
         want = 8 if heads else (64 if split else 32)
         split_without_x3 += int(split and not x3)

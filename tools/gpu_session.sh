@@ -76,6 +76,8 @@ for s in $steps; do
     k384)    for v in 100 128 100 128; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --k 384 --no-check --rounds 5 --json $out/bf16_w16_k384.jsonl > $out/linear_bf16_k384_$v.log 2>&1; tail -1 $out/linear_bf16_k384_$v.log | cut -c1-400; done
              for v in 100 116; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --k 384 --n 256 --no-check --rounds 5 --json $out/bf16_w16_k384.jsonl > $out/linear_bf16_k384_n256_$v.log 2>&1; tail -1 $out/linear_bf16_k384_n256_$v.log | cut -c1-400; done ;;
     g20)     timeout 900 python tools/train_demo.py --steps 500 --rays 1024 --samples 32 --hidden 32 64 --lr 3e-3 --kind lego --teacher structured --white-bkgd --save $out/g20_trained_student.pt > $out/g20_train.json 2> $out/g20_train.err; cat $out/g20_train.json | cut -c1-1500 ;;
+    ldsepi)  for v in 136 100 136 100 137 116; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --rounds 5 --json $out/bf16_w16_lds_epilogue.jsonl $( [ $v = 137 -o $v = 116 ] && echo --no-check ) > $out/linear_bf16_ldsepi_$v.log 2>&1; tail -2 $out/linear_bf16_ldsepi_$v.log | cut -c1-300; done
+             for v in 136 100; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --k 384 --rounds 5 --json $out/bf16_w16_lds_epilogue.jsonl > $out/linear_bf16_ldsepi_k384_$v.log 2>&1; tail -1 $out/linear_bf16_ldsepi_k384_$v.log | cut -c1-300; done ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac

@@ -217,7 +217,7 @@ def bf16_ring_counters(src):
             return None
         acc = collections.defaultdict(dict)
         for r in csv.DictReader(open(fs[0])):
-            if "w16_kernel<1, 0, false, false, false, 0, false>" in r["Kernel_Name"] or "w16_kernel<1, 0, false, false, false, 0>" in r["Kernel_Name"]:
+            if any(k in r["Kernel_Name"] for k in ("w16_kernel<1, 0, false, false, false, 0, false, false>", "w16_kernel<1, 0, false, false, false, 0, false>", "w16_kernel<1, 0, false, false, false, 0>")):
                 acc[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
                 acc[r["Dispatch_Id"]]["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         return [x for x in acc.values() if x["_ns"] > 600000]   # the NeRF layers (the 256-wide proposal layers are 7 x shorter)
