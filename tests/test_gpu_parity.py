@@ -343,6 +343,34 @@ def test_finishers_wave_per_ray_match_one_ray_at_a_time(dev, B, N, width):
                 assert torch.equal(a, c)
 
 
+# =============================================================================== NaN parameters
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("where", ["nerf_net.model.4.weight", "prop_net.model.2.bias", "nerf_net.model.0.weight"])
+def test_negative_nan_parameter_propagates_like_nn_relu(dev, mlp_dtype, where):
+    """a checkpoint may hold NaN parameters with the SIGN bit set (x86's 0/0 is 0xFFC00000).  nn.ReLU propagates every NaN
+    (model.py:43-53,131-148), so the reference renders NaN; the ReLU epilogues here are an integer max on the bit pattern, which keeps
+    only NaNs with a clear sign bit - the packing kernels therefore canonicalise NaN parameters to +NaN.  One -NaN weight / bias in a
+    hidden layer, the first layer (the x6 packing of the bf16 modes) or the proposal net: every ray must come out NaN, as from the oracle."""
+    from oracle import ref_path as O
+    sd = synthetic.make_state_dict(64, 128, seed=77)
+    neg_nan = np.frombuffer(np.uint32(0xFFC00000).tobytes(), dtype=np.float32)[0]
+    assert np.isnan(neg_nan) and np.signbit(neg_nan)
+    sd[where] = sd[where].copy()
+    sd[where].reshape(-1)[3] = neg_nan
+    m = _g19_model(sd, dev, 16, 64, 128, False, mlp_dtype)
+    r = synthetic.make_rays("lego", 40, seed=78)
+    with torch.no_grad():
+        rgb, dist, acc = m(dev_rays(r, dev))
+    o_rgb, o_dist, o_acc = O.forward(O.rays_from_numpy(r), O.to_torch_state_dict(sd), O.Hyper(num_samples=16))
+    # NeRF-net NaN: every ray renders NaN; proposal-net NaN: w_hat is NaN, the resampled t collapse onto t[0] (intern/ray.py:43-50 on a
+    # NaN cdf) and the NeRF stage renders finite values from there - either way exactly where the oracle (= nn.ReLU semantics) has them
+    assert bool(torch.isnan(o_rgb).all()) == where.startswith("nerf_net")
+    assert torch.equal(torch.isnan(rgb).cpu(), torch.isnan(o_rgb)) and torch.equal(torch.isnan(acc).cpu(), torch.isnan(o_acc))
+    assert bool(torch.isfinite(dist).all()) and bool(torch.isfinite(o_dist).all())   # nan_to_num + clamp (intern/ray.py:187)
+    if mlp_dtype == "fp32" and not where.startswith("nerf_net"):
+        close_render(rgb, dist, acc, o_rgb, o_dist, o_acc)
+
+
 # =============================================================================== one-launch prologue
 @pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3"])
 def test_fused_prologue_matches_the_separate_kernels_bit_for_bit(dev, mlp_dtype):
