@@ -45,9 +45,19 @@ namespace m360 {
 // m360_sample_encode.hip (stage drivers only, not part of the C-ABI)
 int stage_prologue(const m360_rays_t *r, int B, int N, int min_deg, int max_deg, float *t_vals, float *vdenc,
                    unsigned *queue_words, int n_queue_words, int ld_feat, void *norm_ws, m360_stream_t stream);
-int encode_prepared(const float *t_vals, const float *origins, const float *directions, const float *radii, const float *vdenc,
-                    int vd_ch, int B, int N, void *feat, int ld_feat, int row_format, int prepared_parts, void *workspace,
-                    size_t workspace_bytes, m360_stream_t stream);
+int encode_stage(const float *t_vals, const float *origins, const float *directions, const float *radii, const float *vdenc,
+                 int vd_ch, int B, int N, void *feat, int ld_feat, int row_format, int group_rays, const float *ext_norm,
+                 int prepared_parts, unsigned char *nanflag, void *workspace, size_t workspace_bytes, m360_stream_t stream);
+// m360_ray.hip (stage drivers only)
+int prop_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
+                      const float *head_b, int k_pad, float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
+                      int B, int N, int num_out, float resample_padding, float *weights, float *t_new, const unsigned char *nanflag,
+                      m360_stream_t stream);
+int nerf_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
+                      const float *head_b, int k_pad, float density_bias, float rgb_padding, const float *t_vals, const float *dirs,
+                      const float *near, const float *far, int near_far_calls, int B, int N, int white_bkgd, float *comp_rgb,
+                      float *distance, float *acc, float *weights, float *t_vals_out, float *s_vals_out, const unsigned char *nanflag,
+                      m360_stream_t stream);
 
 // brackets the launches of ONE public entry point with two HIP events on the launch stream
 struct ProfScope {
@@ -80,7 +90,7 @@ struct ProfScope {
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FwdLayout {
-    size_t norm, vdenc, t1, t0, what, feat, act_a, act_b, hpart, queues, total;
+    size_t norm, vdenc, t1, t0, what, feat, act_a, act_b, hpart, queues, nanflag, total;
 };
 // tile-queue words of the balanced linear launches of one stage (m360_linear_balanced): 16 words, one per 64-byte line
 constexpr int kQueueSlots = 16, kQueueStride = 16;
@@ -123,6 +133,8 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     const size_t hp_b = hp_rows * hp_slots * 1 * sizeof(float), hn_b = hn_rows * hn_slots * 4 * sizeof(float);
     L.hpart = take(hp_b > hn_b ? hp_b : hn_b);
     L.queues = take((size_t)2 * kQueueSlots * kQueueStride * sizeof(unsigned));  // one set per stage
+    // bf16 modes: one byte per sample, "a feature of this sample is NaN" (the bf16 pipe's ReLU drops NaN: the finishers restore it)
+    L.nanflag = take(m->mlp_bf16 ? S : 0);
     L.total = off;
     return L;
 }
@@ -177,15 +189,11 @@ static int p_linear_bf16(const m360_hyper_t *h, int mode, const void *x, long M,
     if (mode == 2) return ps.done(m360_linear_bf16x3(x, M, 2 * k_pad, w, b, n_pad, k_pad, act, y, 2 * n_pad, st));
     return ps.done(m360_linear_bf16(x, M, k_pad, w, b, n_pad, k_pad, act, y, n_pad, st));
 }
-// prepared_parts > 0: the norm's partial sums are already in the scratch (stage_prologue)
-static int p_encode_grouped(const m360_hyper_t *h, const float *t, const float *o, const float *d, const float *rad, const float *vdenc, int vd_ch, int B, int N, void *feat, int ld, int bf16, int group, void *ws, size_t wsb, m360_stream_t st, int prepared_parts = 0) {
-    ProfScope ps(h, st, M360_K_ENCODE, (long)B * N, ld, bf16);
-    if (prepared_parts > 0) return ps.done(encode_prepared(t, o, d, rad, vdenc, vd_ch, B, N, feat, ld, bf16, prepared_parts, ws, wsb, st));
-    return ps.done(m360_encode_features_grouped(t, o, d, rad, vdenc, vd_ch, B, N, feat, ld, bf16, group, ws, wsb, st));
-}
-static int p_encode_ext_norm(const m360_hyper_t *h, const float *t, const float *o, const float *d, const float *rad, const float *vdenc, int vd_ch, int B, int N, void *feat, int ld, int bf16, const float *norm, void *ws, size_t wsb, m360_stream_t st) {
-    ProfScope ps(h, st, M360_K_ENCODE, (long)B * N, ld, bf16);
-    return ps.done(m360_encode_features_ext_norm(t, o, d, rad, vdenc, vd_ch, B, N, feat, ld, bf16, norm, ws, wsb, st));
+// the encode step of a stage (encode_stage: per-chunk norms, an external norm, or partial sums left by stage_prologue); flags: the
+// per-sample NaN flags of the bf16 modes (NULL in fp32)
+static int p_encode(const m360_hyper_t *h, const float *t, const m360_rays_t *r, const float *vdenc, int vd_ch, int B, int N, void *feat, int ld, int row_format, int group, const float *ext_norm, int prepared_parts, unsigned char *flags, void *ws, size_t wsb, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_ENCODE, (long)B * N, ld, row_format);
+    return ps.done(encode_stage(t, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, ld, row_format, group, ext_norm, prepared_parts, flags, ws, wsb, st));
 }
 // last hidden layer + heads fused (fp32 or bf16): partial head sums to `part`, y written only when store_y
 static int p_linear_heads(const m360_hyper_t *h, int bf16, const void *x, long M, int ldx, const void *w, const float *b, int n_pad, int k_pad, void *y, int ldy, int store_y, const float *head_w, int heads, float *part, m360_stream_t st) {
@@ -194,16 +202,16 @@ static int p_linear_heads(const m360_hyper_t *h, int bf16, const void *x, long M
     if (bf16) return ps.done(m360_linear_heads_bf16(x, M, ldx, w, b, n_pad, k_pad, M360_ACT_SIGMOID, y, ldy, store_y, head_w, heads, part, st));
     return ps.done(m360_linear_heads(static_cast<const float *>(x), M, ldx, static_cast<const float *>(w), b, n_pad, k_pad, M360_ACT_SIGMOID, static_cast<float *>(y), ldy, store_y, head_w, heads, part, st));
 }
-static int p_prop_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, float *w_hat, float *t_new, m360_stream_t st) {
+static int p_prop_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, float *w_hat, float *t_new, m360_stream_t st, const unsigned char *flags = nullptr) {
     ProfScope ps(h, st, M360_K_PROP_FINISH, (long)B * N, k_pad, bf16);
-    return ps.done(m360_prop_finish_fused(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, st));
+    return ps.done(prop_finish_stage(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, flags, st));
 }
 // heads + composite, and in the same launch the t_vals + 1e-6 and s_vals nerf_net.forward returns (model.py:194-196; until round 3
 // an add_eps and a t_to_s launch).  near / far went through g() once in sample_along_rays (numerically, or physically when
 // rays_mutated: then t_to_s starts from the values it is handed).
-static int p_nerf_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const m360_rays_t *r, int B, int N, const m360_outputs_t *out, m360_stream_t st) {
+static int p_nerf_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const m360_rays_t *r, int B, int N, const m360_outputs_t *out, m360_stream_t st, const unsigned char *flags = nullptr) {
     ProfScope ps(h, st, M360_K_NERF_FINISH, (long)B * N, k_pad, bf16);
-    return ps.done(m360_nerf_finish_outputs(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, r->directions, r->near, r->far, h->rays_mutated ? 0 : 1, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, out->t_vals, out->s_vals, st));
+    return ps.done(nerf_finish_stage(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, r->directions, r->near, r->far, h->rays_mutated ? 0 : 1, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, out->t_vals, out->s_vals, flags, st));
 }
 
 // Training tape of one stage (caller-owned): everything the backward needs from the forward.
@@ -239,6 +247,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     float *a = reinterpret_cast<float *>(ws + L.act_a), *b = reinterpret_cast<float *>(ws + L.act_b);
     float *hpart = reinterpret_cast<float *>(ws + L.hpart);
     const long S = (long)B * N;
+    unsigned char *flags = m->mlp_bf16 ? reinterpret_cast<unsigned char *>(ws + L.nanflag) : nullptr;  // per-sample NaN flags (bf16 modes)
     TileQueues tq;
     // rendering forward on a chunk of its own norm, deterministic samples: ONE prologue launch (t, view directions, norm partials,
     // queue words) instead of five; the encoder's workgroups finish the norm themselves
@@ -259,7 +268,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         if (hipMemcpyAsync(t_hat, tt, (size_t)B * (N + 1) * sizeof(float), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(st)) != hipSuccess)
             return fail(M360_ERR_LAUNCH, "m360_prop_forward_train: copy of t_hat failed");
         M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
-        M360_TRY(p_encode_grouped(h, tt, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_encode(h, tt, r, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, nullptr, 0, nullptr, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(p_linear(h, &tq, tf, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, act[0], hp, st));
         for (int l = 1; l < 3; ++l)
             M360_TRY(p_linear(h, &tq, act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, M360_ACT_RELU, act[l], hp, st));
@@ -273,20 +282,20 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     }
     const int hp = m->hp_pad;
     if (ext_norm) {  // the caller supplies the (all-reduced) contraction norm; the layers below are shared
-        M360_TRY(p_encode_ext_norm(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16 ? 3 : 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));  /* row format: fp32, or x6 for both bf16 modes */
+        M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16 ? 3 : 0, 0, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));  /* row format: fp32, or x6 for both bf16 modes */
     }
     if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers; mode 2 = bf16x3: [hi | lo] pairs)
         const int mode = m->mlp_bf16;
-        if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 3, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st, parts));
+        if (!ext_norm) M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, 3, h->norm_group_rays, nullptr, parts, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(p_linear_first(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, a, st));
         M360_TRY(p_linear_bf16(h, mode, a, S, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, st));
         M360_TRY(p_linear_bf16(h, mode, b, S, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, st));
         // last hidden layer + head on the matrix pipe (full 256-row tiles; tail rows through y): ld of y = hp (bf16) / 2 hp ([hi | lo])
         const int ldl = mode == 2 ? 2 * hp : hp;
         M360_TRY(p_linear_heads(h, mode, a, S, ldl, m->prop_w[3], m->prop_b[3], hp, hp, b, ldl, 0, m->prop_head_w, 1, hpart, st));
-        return p_prop_finish_fused(h, b, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hp, mode), m360_linear_heads_slots_bf16(hp, hp, mode, 0), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st);
+        return p_prop_finish_fused(h, b, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hp, mode), m360_linear_heads_slots_bf16(hp, hp, mode, 0), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st, flags);
     }
-    if (!ext_norm) M360_TRY(p_encode_grouped(h, t_hat, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st, parts));
+    if (!ext_norm) M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, nullptr, parts, nullptr, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(p_linear(h, &tq, feat, S, m->in_pad, m->prop_w[0], m->prop_b[0], hp, m->in_pad, M360_ACT_RELU, a, hp, st));
     M360_TRY(p_linear(h, &tq, a, S, hp, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, hp, st));
     M360_TRY(p_linear(h, &tq, b, S, hp, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, hp, st));
@@ -309,6 +318,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     float *a = reinterpret_cast<float *>(ws + L.act_a), *b = reinterpret_cast<float *>(ws + L.act_b);
     float *hpart = reinterpret_cast<float *>(ws + L.hpart);
     const long S = (long)B * N;
+    unsigned char *flags = m->mlp_bf16 ? reinterpret_cast<unsigned char *>(ws + L.nanflag) : nullptr;  // per-sample NaN flags (bf16 modes)
     TileQueues tq;
     M360_TRY(queues_begin(&tq, ws, L.queues, 1, after_fused_prop, st));
     if (!after_fused_prop) M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
@@ -320,7 +330,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         float *tf = reinterpret_cast<float *>(tape + T.feat);
         float *act[8];
         for (int l = 0; l < 8; ++l) act[l] = reinterpret_cast<float *>(tape + T.act[l]);
-        M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, tf, m->in_pad, 0, h->norm_group_rays, nullptr, 0, nullptr, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(p_linear(h, &tq, tf, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, act[0], hn, st));
         for (int l = 1; l < 7; ++l)
             M360_TRY(p_linear(h, &tq, act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, M360_ACT_RELU, act[l], hn, st));
@@ -328,8 +338,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         M360_TRY(p_nerf_finish_fused(h, act[7], 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st));
     } else if (m->mlp_bf16) {
         const int mode = m->mlp_bf16;
-        if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 3, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
-        else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 3, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, feat, m->in_pad, 3, ext_norm ? 0 : h->norm_group_rays, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(p_linear_first(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, a, st));
         for (int layer = 1; layer < 7; ++layer) {
             M360_TRY(p_linear_bf16(h, mode, src, S, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, st));
@@ -337,10 +346,9 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         }
         const int ldl = mode == 2 ? 2 * hn : hn;
         M360_TRY(p_linear_heads(h, mode, src, S, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, ldl, 0, m->nerf_head_w, 4, hpart, st));
-        M360_TRY(p_nerf_finish_fused(h, dst, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hn, mode), m360_linear_heads_slots_bf16(hn, hn, mode, 0), m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st));
+        M360_TRY(p_nerf_finish_fused(h, dst, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hn, mode), m360_linear_heads_slots_bf16(hn, hn, mode, 0), m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st, flags));
     } else {
-    if (ext_norm) M360_TRY(p_encode_ext_norm(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm, ws + L.norm, m360_contract_workspace_bytes(), st));
-    else M360_TRY(p_encode_grouped(h, t1, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, ws + L.norm, m360_contract_workspace_bytes(), st));
+    M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm ? 0 : h->norm_group_rays, ext_norm, 0, nullptr, ws + L.norm, m360_contract_workspace_bytes(), st));
     M360_TRY(p_linear(h, &tq, feat, S, m->in_pad, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, M360_ACT_RELU, a, hn, st));
     for (int layer = 1; layer < 7; ++layer) {
         M360_TRY(p_linear(h, &tq, src, S, hn, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, hn, st));

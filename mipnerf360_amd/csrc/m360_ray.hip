@@ -533,7 +533,8 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     const T *__restrict__ act, int ld, const float *__restrict__ head_part, long fused_rows, int slots,
     const float *__restrict__ head_w, const float *__restrict__ head_b, int k_pad, float density_bias,
     const float *__restrict__ t_vals, const float *__restrict__ dirs, const float *__restrict__ u_rand, int B, int N, int ns,
-    float padding, float *__restrict__ weights, float *__restrict__ t_new, int rpb /* rays per workgroup: kFinishRays, or 1 when four rays' buffers exceed the LDS */) {
+    float padding, float *__restrict__ weights, float *__restrict__ t_new, int rpb /* rays per workgroup: kFinishRays, or 1 when four rays' buffers exceed the LDS */,
+    const unsigned char *__restrict__ nanflag /* bf16 modes: 1 = the sample had a NaN feature (encode_features_wave_kernel), or NULL */) {
     extern __shared__ float smem[];
     const int l = lane_id(), wave = threadIdx.x >> 6;
     const int nb = N + 1;
@@ -541,7 +542,12 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     const int b_end = (b0 + rpb < B) ? b0 + rpb : B;
     // the tail of one ray: activation, weights (model.py:59-78), blur + inverse-CDF resampling (intern/ray.py:136-149), by one wave
     auto finish_ray = [&](int b, float *t, float *rho, float *w, float *w2, float *cdf) __attribute__((always_inline)) {
-        for (int i = l; i < N; i += kWave) rho[i] = softplusf_(rho[i] + density_bias);
+        // bf16 modes: the head output of a sample with a NaN feature is NaN, as nn.ReLU would have carried it here (the bf16 pipe's
+        // ReLU drops every NaN: see the encoder)
+        for (int i = l; i < N; i += kWave) {
+            const float raw = (nanflag != nullptr && nanflag[(long)b * N + i]) ? __builtin_nanf("") : rho[i];
+            rho[i] = softplusf_(raw + density_bias);
+        }
         wave_sync();
         wave_weights(t, rho, 1, dir_norm(dirs, b), N, w);
         wave_sync();
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
     float rgb_padding, const float *__restrict__ t_vals, const float *__restrict__ dirs, int B, int N, int white_bkgd,
     float *__restrict__ comp_rgb, float *__restrict__ distance, float *__restrict__ acc,
     float *__restrict__ weights, float *__restrict__ t_out, float *__restrict__ s_out, const float *__restrict__ near,
-    const float *__restrict__ far, int ts_calls, int rpb) {
+    const float *__restrict__ far, int ts_calls, int rpb, const unsigned char *__restrict__ nanflag) {
     extern __shared__ float smem[];
     const int l = lane_id(), wave = threadIdx.x >> 6;
     const int nb = N + 1;
@@ -589,6 +595,10 @@ __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
     // s_vals = t_to_s(t_vals, near, far) - until round 3 two more launches (add_eps_kernel, t_to_s_kernel), same arithmetic
     auto finish_ray = [&](int b, float *t, float *raw, float *w) __attribute__((always_inline)) {
         for (int i = l; i < N; i += kWave) {
+            if (nanflag != nullptr && nanflag[(long)b * N + i]) {  // bf16 modes: see prop_finish_kernel
+#pragma unroll
+                for (int c = 0; c < 4; ++c) raw[4 * i + c] = __builtin_nanf("");
+            }
             raw[4 * i] = softplusf_(sigmoidf_(raw[4 * i]) + density_bias);
 #pragma unroll
             for (int c = 1; c < 4; ++c)
@@ -880,7 +890,8 @@ int m360_prop_finish(const float *act, int ld, const float *head_w, const float 
 static int prop_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                            int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
-                           m360_stream_t stream, const float *head_part = nullptr, long fused_rows = 0, int slots = 0);
+                           m360_stream_t stream, const float *head_part = nullptr, long fused_rows = 0, int slots = 0,
+                           const unsigned char *nanflag = nullptr);
 
 int m360_prop_finish_n(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
                        float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
@@ -907,7 +918,7 @@ int m360_prop_finish_fused(const void *act, int act_bf16, int ld, const float *h
 static int prop_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                            int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
-                           m360_stream_t stream, const float *head_part, long fused_rows, int slots) {
+                           m360_stream_t stream, const float *head_part, long fused_rows, int slots, const unsigned char *nanflag) {
     if (num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: num_out=%d", num_out);
     const int align = bf16 ? 8 : 4;
     if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < (bf16 == 2 ? 2 * k_pad : k_pad) || ld % align != 0)
@@ -919,9 +930,9 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
     const size_t lds = rpb == 1 ? lds_wg : (lds_wg > lds_wave ? lds_wg : lds_wave);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
     const dim3 grid((unsigned)((B + rpb - 1) / rpb));
-    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb);
-    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb);
-    else hipLaunchKernelGGL(prop_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb);
+    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag);
+    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag);
+    else hipLaunchKernelGGL(prop_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag);
     return check_launch("prop_finish");
 }
 
@@ -929,6 +940,7 @@ struct FinishExtras {  // what nerf_net.forward returns beside the composite (mo
     float *t_out = nullptr, *s_out = nullptr;
     const float *near = nullptr, *far = nullptr;
     int calls = 1;  // applications of the reference's in-place g() that near / far have behind them (t_to_s_kernel)
+    const unsigned char *nanflag = nullptr;  // bf16 modes: per-sample NaN flags of the encoder
 };
 static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
@@ -984,9 +996,9 @@ static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_
     const size_t lds = rpb == 1 ? lds_wg : (lds_wg > lds_wave ? lds_wg : lds_wave);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
     const dim3 grid((unsigned)((B + rpb - 1) / rpb));
-    if (bf16 == 2) hipLaunchKernelGGL((nerf_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb);
-    else if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb);
-    else hipLaunchKernelGGL(nerf_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb);
+    if (bf16 == 2) hipLaunchKernelGGL((nerf_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb, ex.nanflag);
+    else if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb, ex.nanflag);
+    else hipLaunchKernelGGL(nerf_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb, ex.nanflag);
     return check_launch("nerf_finish");
 }
 
@@ -1049,3 +1061,26 @@ int m360_nerf_finish_backward(const float *act, int ld, const float *head_w, con
 }
 
 }  // extern "C"
+
+namespace m360 {
+// Stage drivers only (m360_capi.hip; not part of the C-ABI): the fused finishers with the encoder's per-sample NaN flags (bf16 / bf16x3
+// modes; NULL = none) - and, for the NeRF stage, the t_vals + 1e-6 / s_vals outputs of m360_nerf_finish_outputs.
+int prop_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
+                      const float *head_b, int k_pad, float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
+                      int B, int N, int num_out, float resample_padding, float *weights, float *t_new, const unsigned char *nanflag,
+                      m360_stream_t stream) {
+    if (fused_rows < 0 || (fused_rows > 0 && (!head_part || slots < 1))) return fail(M360_ERR_INVALID_ARGUMENT, "prop_finish_stage: fused_rows=%ld slots=%d", fused_rows, slots);
+    return prop_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, stream, head_part, fused_rows, slots, nanflag);
+}
+int nerf_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
+                      const float *head_b, int k_pad, float density_bias, float rgb_padding, const float *t_vals, const float *dirs,
+                      const float *near, const float *far, int near_far_calls, int B, int N, int white_bkgd, float *comp_rgb,
+                      float *distance, float *acc, float *weights, float *t_vals_out, float *s_vals_out, const unsigned char *nanflag,
+                      m360_stream_t stream) {
+    if (fused_rows < 0 || (fused_rows > 0 && (!head_part || slots < 1))) return fail(M360_ERR_INVALID_ARGUMENT, "nerf_finish_stage: fused_rows=%ld slots=%d", fused_rows, slots);
+    if (s_vals_out && (!near || !far || near_far_calls < 0)) return fail(M360_ERR_INVALID_ARGUMENT, "nerf_finish_stage: s_vals needs near, far and near_far_calls >= 0");
+    FinishExtras ex;
+    ex.t_out = t_vals_out, ex.s_out = s_vals_out, ex.near = near, ex.far = far, ex.calls = near_far_calls, ex.nanflag = nanflag;
+    return nerf_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, stream, head_part, fused_rows, slots, ex);
+}
+}  // namespace m360

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
     const float *__restrict__ t_vals, const float *__restrict__ origins,
     const float *__restrict__ directions, const float *__restrict__ radii,
     const float *__restrict__ vdenc, int vd_ch, int B, int N, const NormScratch *__restrict__ ws,
-    void *__restrict__ feat_out, int ld, int group_rays, const float *__restrict__ ext_norm) {
+    void *__restrict__ feat_out, int ld, int group_rays, const float *__restrict__ ext_norm, unsigned char *__restrict__ nanflag) {
     extern __shared__ float tile[];  // [kEncThreads][ld + 1]
     const long S = (long)B * N;
     const long s0 = (long)blockIdx.x * kEncThreads;
@@ -448,9 +448,15 @@ __global__ __launch_bounds__(kEncThreads) void encode_features_kernel(
         const float gn = ext_norm ? *ext_norm : (group_rays > 0 ? ws->gnorms[b / group_rays] : ws->gnorm);
         sample_gaussian(t_vals, origins, directions, radii, N, b, n, gn, m, c);
         // NaN features are written as +NaN (canon_nanf_): the MLP's ReLU keeps exactly those
-        ipe_sample<true>(m, c, [&](int k, float v) { row[k] = canon_nanf_(v); });
-        for (int k = 0; k < vd_ch; ++k) row[kIpeCh + k] = canon_nanf_(vdenc[(long)b * vd_ch + k]);
+        int bad = 0;  // does this sample carry a NaN feature?  (see encode_features_wave_kernel)
+        ipe_sample<true>(m, c, [&](int k, float v) { bad |= (v != v); row[k] = canon_nanf_(v); });
+        for (int k = 0; k < vd_ch; ++k) {
+            const float v = vdenc[(long)b * vd_ch + k];
+            bad |= (v != v);
+            row[kIpeCh + k] = canon_nanf_(v);
+        }
         for (int k = kIpeCh + vd_ch; k < ld; ++k) row[k] = 0.0f;
+        if (nanflag) nanflag[idx] = (unsigned char)bad;
     }
     __syncthreads();
     const long rows = (S - s0 < kEncThreads) ? (S - s0) : kEncThreads;
@@ -511,7 +517,13 @@ __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kern
     const float *__restrict__ t_vals, const float *__restrict__ origins,
     const float *__restrict__ directions, const float *__restrict__ radii,
     const float *__restrict__ vdenc, int vd_ch, int B, int N, const NormScratch *__restrict__ ws,
-    void *__restrict__ feat_out, int group_rays, const float *__restrict__ ext_norm, int norm_parts) {
+    void *__restrict__ feat_out, int group_rays, const float *__restrict__ ext_norm, int norm_parts,
+    unsigned char *__restrict__ nanflag) {
+    // nanflag (bf16 / bf16x3 stage drivers): one byte per sample, 1 = some feature of the sample is NaN.  torch.relu(NaN) is NaN, so in
+    // the reference such a sample stays NaN through every layer (model.py:43-53,131-148); the fp32 kernels keep it too (integer-max ReLU
+    // on +NaN).  The bf16 matrix pipe answers ANY NaN operand with the default NaN 0xFFC00000 - sign bit set (tools/diag/nan_bits_bf16.py) -
+    // which the packed integer-max ReLU reads as a negative number: no NaN survives a ReLU layer there.  The finishers therefore poison
+    // the head outputs of flagged samples, which is where the reference's NaN would have arrived.
     __shared__ __attribute__((aligned(16))) float tiles[kEncWaves][kWave * kEncTileLd];
     constexpr int ld = 32 * NPASS;
     const long S = (long)B * N;
@@ -547,6 +559,7 @@ __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kern
         for (int k = 0; k < kIpeCh; ++k) v[k] = 0.0f;
     }
     const long rows = (S - s0 < kWave) ? (S - s0) : kWave;
+    int bad = 0;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
 #pragma unroll
@@ -555,6 +568,7 @@ __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kern
             float val;
             if (ch < kIpeCh) val = v[ch];
             else val = (live && ch - kIpeCh < vd_ch) ? vdenc[(long)b * vd_ch + (ch - kIpeCh)] : 0.0f;
+            if (BF16) bad |= (val != val);
             tile[lane * kEncTileLd + cc] = canon_nanf_(val);  // NaN features go out as +NaN: the MLP's ReLU keeps exactly those
         }
         wave_sync_lds();
@@ -604,6 +618,7 @@ __global__ __launch_bounds__(kEncWaves *kWave, 4) void encode_features_wave_kern
         }
         wave_sync_lds();  // the tile is rewritten by the next pass
     }
+    if (BF16 && nanflag != nullptr && live) nanflag[idx] = (unsigned char)bad;
 }
 
 }  // namespace m360
@@ -619,7 +634,7 @@ static int norm_parts(long work);
 static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
                                const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
                                int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream,
-                               int group_rays, const float *ext_norm, int prepared_parts);
+                               int group_rays, const float *ext_norm, int prepared_parts, unsigned char *nanflag);
 }
 
 namespace m360 {
@@ -634,10 +649,15 @@ int stage_prologue(const m360_rays_t *r, int B, int N, int min_deg, int max_deg,
                        B, N, min_deg, max_deg - min_deg, t_vals, vdenc, queue_words, n_queue_words, static_cast<NormScratch *>(norm_ws));
     return check_launch("stage_prologue") == M360_OK ? parts : -1;
 }
-int encode_prepared(const float *t_vals, const float *origins, const float *directions, const float *radii, const float *vdenc,
-                    int vd_ch, int B, int N, void *feat, int ld_feat, int row_format, int prepared_parts, void *workspace,
-                    size_t workspace_bytes, m360_stream_t stream) {
-    return encode_features_any(t_vals, origins, directions, radii, vdenc, vd_ch, B, N, feat, ld_feat, row_format, workspace, workspace_bytes, stream, 0, nullptr, prepared_parts);
+// the encode step of a stage: per-chunk norms (group_rays > 0), a norm given by the caller (ext_norm), partial sums left by
+// stage_prologue (prepared_parts > 0), or computed here; nanflag: one byte per sample for the bf16 modes' finishers (or NULL)
+int encode_stage(const float *t_vals, const float *origins, const float *directions, const float *radii, const float *vdenc,
+                 int vd_ch, int B, int N, void *feat, int ld_feat, int row_format, int group_rays, const float *ext_norm,
+                 int prepared_parts, unsigned char *nanflag, void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    if (group_rays < 0) return fail(M360_ERR_INVALID_ARGUMENT, "encode_stage: group_rays=%d", group_rays);
+    if (group_rays > 0 && ((long)group_rays * N > kSmallGroup || (B + group_rays - 1) / group_rays > kMaxNormGroups))
+        return fail(M360_ERR_INVALID_ARGUMENT, "encode_stage: group_rays=%d x N=%d exceeds %ld samples per group, or more than %d groups", group_rays, N, kSmallGroup, kMaxNormGroups);
+    return encode_features_any(t_vals, origins, directions, radii, vdenc, vd_ch, B, N, feat, ld_feat, row_format, workspace, workspace_bytes, stream, group_rays, ext_norm, prepared_parts, nanflag);
 }
 }  // namespace m360
 
@@ -795,7 +815,8 @@ int m360_viewdir_enc(const float *viewdirs, int B, int min_deg, int max_deg, flo
 static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
                                const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
                                int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream,
-                               int group_rays = 0, const float *ext_norm = nullptr, int prepared_parts = 0);  // (defaults: this declaration)
+                               int group_rays = 0, const float *ext_norm = nullptr, int prepared_parts = 0,
+                               unsigned char *nanflag = nullptr);  // (defaults: this declaration)
 
 // one logical batch sharded over several devices: this shard's sum of squares of the un-contracted
 // means, reduced exactly like the norm the encode stage would compute for these rays alone
@@ -847,7 +868,7 @@ int m360_encode_features_bf16(const float *t_vals, const float *origins, const f
 static int encode_features_any(const float *t_vals, const float *origins, const float *directions,
                                const float *radii, const float *vdenc, int vd_ch, int B, int N, void *feat,
                                int ld_feat, int bf16, void *workspace, size_t workspace_bytes, m360_stream_t stream,
-                               int group_rays, const float *ext_norm, int prepared_parts) {
+                               int group_rays, const float *ext_norm, int prepared_parts, unsigned char *nanflag) {
     if (!t_vals || !origins || !directions || !radii || !feat || B < 0 || N < 1 || vd_ch < 0 || (vd_ch > 0 && !vdenc))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: bad argument");
     if (ld_feat % 32 != 0 || ld_feat < kIpeCh + vd_ch) return fail(M360_ERR_INVALID_ARGUMENT, "m360_encode_features: ld_feat=%d must be a multiple of 32 and >= %d", ld_feat, kIpeCh + vd_ch);
@@ -862,7 +883,7 @@ static int encode_features_any(const float *t_vals, const float *origins, const 
     if (!ext_norm && prepared_parts == 0) parts = launch_norm_from_t(t_vals, directions, radii, B, N, ws, S_(stream), group_rays, wave_kernel);
     if (wave_kernel) {
         const dim3 grid(blocks_for((long)B * N, kEncWaves * kWave)), block(kEncWaves * kWave);
-#define M360_ENC(BF, NP) hipLaunchKernelGGL((encode_features_wave_kernel<BF, NP>), grid, block, 0, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, group_rays, ext_norm, parts)
+#define M360_ENC(BF, NP) hipLaunchKernelGGL((encode_features_wave_kernel<BF, NP>), grid, block, 0, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, group_rays, ext_norm, parts, nanflag)
         if (ld_feat == 64) { if (bf16 == 3) M360_ENC(3, 2); else if (bf16 == 2) M360_ENC(2, 2); else if (bf16) M360_ENC(1, 2); else M360_ENC(0, 2); }
         else { if (bf16 == 3) M360_ENC(3, 3); else if (bf16 == 2) M360_ENC(2, 3); else if (bf16) M360_ENC(1, 3); else M360_ENC(0, 3); }
 #undef M360_ENC
@@ -870,10 +891,10 @@ static int encode_features_any(const float *t_vals, const float *origins, const 
     }
     if (parts > 0) hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, S_(stream), ws, parts);  // prepared partials, generic kernel
     const size_t lds = (size_t)kEncThreads * (ld_feat + 1) * sizeof(float);
-    if (bf16 == 3) hipLaunchKernelGGL(encode_features_kernel<3>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
-    else if (bf16 == 2) hipLaunchKernelGGL(encode_features_kernel<2>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
-    else if (bf16) hipLaunchKernelGGL(encode_features_kernel<1>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
-    else hipLaunchKernelGGL(encode_features_kernel<0>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm);
+    if (bf16 == 3) hipLaunchKernelGGL(encode_features_kernel<3>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm, nanflag);
+    else if (bf16 == 2) hipLaunchKernelGGL(encode_features_kernel<2>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm, nanflag);
+    else if (bf16) hipLaunchKernelGGL(encode_features_kernel<1>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm, nanflag);
+    else hipLaunchKernelGGL(encode_features_kernel<0>, dim3(blocks_for((long)B * N, kEncThreads)), dim3(kEncThreads), lds, S_(stream), t_vals, origins, directions, radii, vdenc, vd_ch, B, N, ws, feat, ld_feat, group_rays, ext_norm, nanflag);
     return check_launch("encode_features");
 }
 

@@ -113,6 +113,13 @@ class _PackedMLP:
         self.h_pad = ops.round_up(first.out_features, pad)
         pack = {0: ops.pack_linear, 1: ops.pack_linear_bf16, 2: ops.pack_linear_bf16x3}[bf16]
         self.w, self.b = [], []
+        if bf16:
+            # The bf16 matrix pipe answers a NaN operand with the default NaN 0xFFC00000 (sign bit set), which its packed integer-max
+            # ReLU reads as a negative number: no NaN survives a ReLU layer.  NaN FEATURES are carried around the MLP by per-sample
+            # flags (the finishers poison those samples, as nn.ReLU would have); a NaN PARAMETER cannot be - refuse it loudly.
+            if any(bool(torch.isnan(p.detach()).any()) for p in params):
+                raise RuntimeError("mlp_dtype='bf16' / 'bf16x3': the parameters hold NaN values; the bf16 matrix pipe cannot propagate them "
+                                   "the way nn.ReLU does (the reference renders NaN) - use mlp_dtype='fp32' for this checkpoint")
         for i, lin in enumerate(hidden_layers):
             if i == 0 and bf16:  # both reduced-precision modes: the first layer multiplies all 24 bits of features and weights ("x6")
                 wp, bp = ops.pack_linear_bf16x6(lin.weight, lin.bias, self.h_pad, self.in_pad)

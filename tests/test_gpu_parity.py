@@ -206,6 +206,33 @@ def test_g18_weights_and_composite_degenerate(golden, dev):
         same_nans_and_close(d, g[tag + "_dist"], what="dist"), same_nans_and_close(w, g[tag + "_w"], what="w")
 
 
+@pytest.mark.parametrize("mlp_dtype", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("tag", ["local", "nan_origin", "nan_direction"])
+def test_g18_stage_forwards_degenerate_reduced_precision(golden, dev, tag, mlp_dtype):
+    """The same batches in the bf16 modes: NaN EXACTLY where the reference has it.  The bf16 matrix pipe answers a NaN operand with
+    0xFFC00000, which its integer-max ReLU reads as negative (tools/diag/nan_bits_bf16.py: no NaN survives a ReLU layer there; found in
+    round 4 - until then a |z| > 1 view direction rendered finite values in these modes), so the encoder flags the samples that carry a
+    NaN feature and the finishers poison their head outputs, where nn.ReLU (model.py:43-53,131-148) would have delivered the NaN.
+    Finite values: the modes' own tolerances against the reference's fp32 outputs."""
+    from mipnerf360_amd.model import mipNeRF360
+    g = golden("g18_degenerate")
+    n, hp, hn = (int(x) for x in g["e2e_cfg"])
+    m = mipNeRF360(num_samples=n, hidden_proposal=hp, hidden_nerf=hn, device=dev, mlp_dtype=mlp_dtype)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in _sd(g).items()})
+    rays = dev_rays({k: g[f"e2e_{tag}_rays_{k}"] for k in synthetic.RAY_FIELDS}, dev)
+    tol = dict(atol=2e-2, rtol=2e-2) if mlp_dtype == "bf16" else dict(atol=1e-4, rtol=1e-4)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+        out = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        fused = m(rays)
+    same_nans_and_close(t_hat, g[f"e2e_{tag}_t_hat"], atol=0, rtol=2e-6, what="t_hat")
+    same_nans_and_close(w_hat, g[f"e2e_{tag}_w_hat"], what="w_hat", **tol)
+    for nm, v in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), out):
+        same_nans_and_close(v, g[f"e2e_{tag}_{nm}"], what=nm, **tol)
+    for nm, v in zip(("rgb", "dist", "acc"), fused):
+        same_nans_and_close(v, g[f"e2e_{tag}_{nm}"], what="fused " + nm, **tol)
+
+
 @pytest.mark.parametrize("tag", ["local", "nan_origin", "nan_direction"])
 def test_g18_stage_forwards_degenerate(golden, dev, tag):
     """Both stage forwards and the fused forward on a batch that holds degenerate rays: viewdir |z| > 1 (NaN features ->
@@ -348,9 +375,10 @@ def test_finishers_wave_per_ray_match_one_ray_at_a_time(dev, B, N, width):
 @pytest.mark.parametrize("where", ["nerf_net.model.4.weight", "prop_net.model.2.bias", "nerf_net.model.0.weight"])
 def test_negative_nan_parameter_propagates_like_nn_relu(dev, mlp_dtype, where):
     """a checkpoint may hold NaN parameters with the SIGN bit set (x86's 0/0 is 0xFFC00000).  nn.ReLU propagates every NaN
-    (model.py:43-53,131-148), so the reference renders NaN; the ReLU epilogues here are an integer max on the bit pattern, which keeps
-    only NaNs with a clear sign bit - the packing kernels therefore canonicalise NaN parameters to +NaN.  One -NaN weight / bias in a
-    hidden layer, the first layer (the x6 packing of the bf16 modes) or the proposal net: every ray must come out NaN, as from the oracle."""
+    (model.py:43-53,131-148), so the reference renders NaN; the fp32 ReLU epilogues are an integer max on the bit pattern, which keeps
+    only NaNs with a clear sign bit - the packing kernels therefore canonicalise NaN parameters to +NaN, and the fp32 path renders NaN
+    exactly where the oracle does.  The bf16 modes cannot carry a NaN parameter through their ReLU layers (the bf16 matrix pipe's NaN
+    has the sign bit set): they REFUSE such a checkpoint instead of rendering finite values."""
     from oracle import ref_path as O
     sd = synthetic.make_state_dict(64, 128, seed=77)
     neg_nan = np.frombuffer(np.uint32(0xFFC00000).tobytes(), dtype=np.float32)[0]
@@ -359,6 +387,11 @@ def test_negative_nan_parameter_propagates_like_nn_relu(dev, mlp_dtype, where):
     sd[where].reshape(-1)[3] = neg_nan
     m = _g19_model(sd, dev, 16, 64, 128, False, mlp_dtype)
     r = synthetic.make_rays("lego", 40, seed=78)
+    if mlp_dtype != "fp32":
+        with pytest.raises(RuntimeError, match="parameters hold NaN"):
+            with torch.no_grad():
+                m(dev_rays(r, dev))
+        return
     with torch.no_grad():
         rgb, dist, acc = m(dev_rays(r, dev))
     o_rgb, o_dist, o_acc = O.forward(O.rays_from_numpy(r), O.to_torch_state_dict(sd), O.Hyper(num_samples=16))
@@ -367,7 +400,7 @@ def test_negative_nan_parameter_propagates_like_nn_relu(dev, mlp_dtype, where):
     assert bool(torch.isnan(o_rgb).all()) == where.startswith("nerf_net")
     assert torch.equal(torch.isnan(rgb).cpu(), torch.isnan(o_rgb)) and torch.equal(torch.isnan(acc).cpu(), torch.isnan(o_acc))
     assert bool(torch.isfinite(dist).all()) and bool(torch.isfinite(o_dist).all())   # nan_to_num + clamp (intern/ray.py:187)
-    if mlp_dtype == "fp32" and not where.startswith("nerf_net"):
+    if not where.startswith("nerf_net"):
         close_render(rgb, dist, acc, o_rgb, o_dist, o_acc)
 
 

@@ -78,6 +78,7 @@ for s in $steps; do
     g20)     timeout 900 python tools/train_demo.py --steps 500 --rays 1024 --samples 32 --hidden 32 64 --lr 3e-3 --kind lego --teacher structured --white-bkgd --save $out/g20_trained_student.pt > $out/g20_train.json 2> $out/g20_train.err; cat $out/g20_train.json | cut -c1-1500 ;;
     ldsepi)  for v in 136 100 136 100 137 116; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --rounds 5 --json $out/bf16_w16_lds_epilogue.jsonl $( [ $v = 137 -o $v = 116 ] && echo --no-check ) > $out/linear_bf16_ldsepi_$v.log 2>&1; tail -2 $out/linear_bf16_ldsepi_$v.log | cut -c1-300; done
              for v in 136 100; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --k 384 --rounds 5 --json $out/bf16_w16_lds_epilogue.jsonl > $out/linear_bf16_ldsepi_k384_$v.log 2>&1; tail -1 $out/linear_bf16_ldsepi_k384_$v.log | cut -c1-300; done ;;
+    r4nan)   timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "g18 or nan or bf16 or g19 or g20 or finish" > $out/pytest_r4nan.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r4nan.log; grep -a "^FAILED\|passed\|failed" $out/pytest_r4nan.log | tail -12 ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
