@@ -409,3 +409,29 @@ def test_grouped_chunks_bit_identical_at_fusable_widths(dev):
     m.super_batch_rays = 4096
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_bench_default_line_carries_every_single_gpu_config(dev):
+    """the DEFAULT `python bench.py` line (what the driver records) carries a number for every single-GPU
+    configuration of BASELINE.json - the headline (configs[1], fp32) untouched, `strong_scaling_frame` at 64 proposal + 128 NeRF samples
+    (configs[2] as written; here a small diagnostic frame), and `named_workloads`: configs[4]'s shape in bf16, configs[1] in bf16 and
+    bf16x3, one train.py iteration - each with its own dtype, rays/s, ms/step and roofline fraction.  (Short: 3 steps, no CPU pass.)"""
+    res, line = _run_bench("--steps", "3", "--warmup", "1", "--cpu-rays", "0", "--frame-size", "200x160")
+    assert res.returncode == 0 and line is not None, (res.stdout[-1500:], res.stderr[-3000:])
+    assert line["dtype"] == "f32" and line["config"]["name"] == "c2" and line["n_gpus"] == 1 and line["vs_baseline"] is None
+    assert line["metric"] == "rendered rays/sec at 128 samples/ray" and line["unit"] == "rays/s" and line["higher_is_better"] is True
+    assert line["roofline"]["bound"] == "mfma" and 0.9 < line["roofline"]["frac"] < 1.0 and line["value"] > 6e4
+    for k in ("encode_features", "prop_finish", "nerf_finish"):
+        assert 0 < line["hbm_kernels"][k]["frac_of_8TBps"] <= 1.0
+    fr = line["strong_scaling_frame"]
+    assert fr["finite"] and "64 proposal + 128 NeRF" in fr["samples_per_ray"] and fr["flops_per_ray"] == 423424 * 64 + 14807040 * 128
+    nw = line["named_workloads"]
+    assert set(nw) >= {"c5_bf16", "c2_bf16", "c2_bf16x3", "c2_training_iteration", "c3_frame_64+128", "seconds"}
+    assert nw["c5_bf16"]["dtype"] == "bf16" and nw["c5_bf16"]["config"] == "c5" and "8192 rays x 256 samples" in nw["c5_bf16"]["workload"]
+    assert nw["c2_bf16"]["dtype"] == "bf16" and nw["c2_bf16x3"]["dtype"] == "bf16x3"
+    for k in ("c5_bf16", "c2_bf16", "c2_bf16x3"):
+        assert nw[k]["finite"] and nw[k]["rays_per_s"] > 5e4 and 0.3 < nw[k]["roofline"]["frac"] < 1.0 and nw[k]["roofline"]["peak"] == 2500.0
+    assert nw["c2_bf16"]["rays_per_s"] > 3 * line["value"] and nw["c2_bf16x3"]["rays_per_s"] > 2 * line["value"]
+    tr = nw["c2_training_iteration"]
+    assert tr["dtype"] == "f32" and 100 < tr["iteration_ms"] < 1000 and tr["wgrad_1024x1024"]["frac"] > 0.7 and tr["dgrad_1024x1024"]["frac"] > 0.7
+    assert nw["seconds"] < 30

@@ -573,7 +573,7 @@ def test_g19_structured_weights_bf16(golden, dev, kind):
     assert d_rgb.max() <= 2e-2 and np.sqrt((d_rgb ** 2).mean()) <= 4e-3 and d_acc.max() <= 1e-2 and d_dist.max() <= 2e-2
 
 
-@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3", "bf16"])
 @pytest.mark.parametrize("chunks", [128, 4096])
 def test_g19_render_image_on_structured_weights(golden, dev, chunks, mlp_dtype):
     """render_image (model.py:254-274) on trained-like weights, both chunk sizes (different contraction norms: the shells sit
@@ -587,6 +587,11 @@ def test_g19_render_image_on_structured_weights(golden, dev, chunks, mlp_dtype):
     rays_cpu = Rays(*[torch.from_numpy(g["frame_rays_" + k]) for k in synthetic.RAY_FIELDS])
     rgb8, dist, acc = m.render_image(rays_cpu, h, w, chunks=chunks)
     want = g[f"frame_c{chunks}_rgb8"]
+    if mlp_dtype == "bf16":   # the mode's own tolerance (many chunks per launch at chunks = 128: per-chunk norms, x6 rows, NaN flags)
+        assert rgb8.dtype == np.uint8 and np.abs(rgb8.astype(int) - want.astype(int)).max() <= 6 and (np.abs(rgb8.astype(int) - want.astype(int)) > 1).mean() < 0.02
+        assert np.abs(acc - g[f"frame_c{chunks}_acc"]).max() <= 1e-2
+        assert np.all(np.abs(dist - g[f"frame_c{chunks}_dist"]) <= 2e-2 * np.maximum(1.0, np.abs(g[f"frame_c{chunks}_dist"])))
+        return
     assert rgb8.dtype == np.uint8 and np.abs(rgb8.astype(int) - want.astype(int)).max() <= 1 and (rgb8 != want).mean() < 0.02
     assert_within_reference_error(acc, g[f"frame_c{chunks}_acc"], g[f"frame_c{chunks}_acc64"], c=4.0, floor=5e-6, what="acc")
     assert_within_reference_error(dist, g[f"frame_c{chunks}_dist"], g[f"frame_c{chunks}_dist64"], c=4.0, floor=5e-6,
