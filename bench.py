@@ -344,8 +344,8 @@ def hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib, x3=False):
         out["nerf_last_layer_fused_heads"] = {"avg_launch_ms": round(ms, 4), "tflops": round(2.0 * S * HN * HN / ms / 1e9, 1),
                                               "launches": len(fused_last), "note": "MFMA-bound; listed for completeness"}
     for kind, name, nbytes in (
-            # feature rows: fp32 [in_pad], or the x6 rows of both bf16 modes (three bf16 terms per value, six blocks: 12 bytes)
-            (_lib.K_ENCODE, "encode_features", S * in_pad * (12 if bf16 else 4) + n_rays * (48 + 4 * (samples + 1))),
+            # feature rows: fp32 [in_pad] and the bf16 mode's [hi | lo] pairs: 4 bytes per value; bf16x3: x6 rows (three bf16 terms, six blocks: 12)
+            (_lib.K_ENCODE, "encode_features", S * in_pad * (12 if x3 else 4) + n_rays * (48 + 4 * (samples + 1))),
             (_lib.K_PROP_FINISH, "prop_finish", finish_in_bytes(HP, 1) + n_rays * (4 * (samples + 1) + 12 + 4 * samples + 4 * (samples + 1))),
             (_lib.K_NERF_FINISH, "nerf_finish", finish_in_bytes(HN, 4) + n_rays * (4 * (samples + 1) + 12 + 20))):
         d = [r["ms"] for r in recs if r["kind"] == kind and r["M"] == S]  # full chunks only (a frame ends with a partial one)

@@ -204,12 +204,19 @@ int m360_linear_bf16x3(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M,
  * columns each (m360_encode_features_grouped / _ext_norm with bf16 = 3), the first-layer weights (model.py:44,132) are packed as
  * [n_pad, 6 k_pad] = [Wh | Wm | Wl | Wh | Wm | Wh], and ONE plain bf16 contraction of length 6 k_pad forms
  * xl wh + xm wm + xh wl + xm wh + xh wm + xh wh, small terms first, fp32 accumulation: the fp32 product up to 2^-24 terms.
- * m360_linear_bf16 (bf16 rows out) runs it in the bf16 mode, m360_linear_bf16_split ([hi | lo] pair rows out, the row format of
- * m360_linear_bf16x3; bias + {none, ReLU}) in the bf16x3 mode; 6 k_pad = 384 takes the one-wave ring kernel.
+ * m360_linear_bf16_split ([hi | lo] pair rows out, the row format of m360_linear_bf16x3; bias + {none, ReLU}) runs it in the bf16x3
+ * mode (m360_linear_bf16 takes x6 rows too: bf16 rows out); 6 k_pad = 384 takes the one-wave ring kernel.
  * Non-finite values: a NaN feature or weight makes its row NaN as in fp32 (hi carries it, mid = lo = 0).  An INFINITE weight
  * differs: the fp32 product x * Inf is +-Inf, the split products contain 0 * Inf = NaN whenever a term of x is zero (any x
  * that bf16 represents exactly) - such a checkpoint renders NaN one layer earlier than the fp32 path (which turns it into NaN
  * in the next layer's mixed-sign sum); the same holds for the two-term products of m360_linear_bf16x3. */
+/* The bf16 mode's first layers need 16 of those bits, not 24 (their output is rounded to bf16 anyway; fixture G19: PSNR within
+ * 0.013 dB of the reference's): two-term features [hi | lo] and weights [Wh | Wh | Wl] as for m360_linear_bf16x3, ONE bf16 term out -
+ * m360_linear_bf16x3_bf16out (bias + {none, ReLU}; the ring kernel's three-product loop with the plain bf16 epilogue: a 64-deep layer
+ * stays one block per tile and store-bound, 0.30 instead of the 0.53 ms of the x6 form at 1024 x 58 on 524 288 rows). */
+int m360_linear_bf16x3_bf16out(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M, int ldx, const void *w_packed3_bf16,
+                               const float *b_packed, int n_pad, int k_pad, int act, void *y_bf16 /*[M, ldy >= n_pad]*/, int ldy,
+                               m360_stream_t stream);
 int m360_pack_linear_bf16x6(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                             void *w_packed6_bf16 /*[n_pad, 6 k_pad]*/, float *b_packed, m360_stream_t stream);
 int m360_linear_bf16_split(const void *x_bf16 /*[M, ldx >= k_pad]*/, long M, int ldx, const void *w_packed_bf16,
@@ -486,8 +493,10 @@ typedef struct {
                      weights from m360_pack_linear_bf16 (pads multiples of 64), hidden activations
                      are bf16, accumulation / biases / heads stay fp32; 2 = "bf16x3": weights from
                      m360_pack_linear_bf16x3, hidden activations as [hi | lo] bf16 pairs (m360_linear_bf16x3).
-                     In BOTH modes prop_w[0] / nerf_w[0] (the first layers) are packed with m360_pack_linear_bf16x6 and the
-                     features are x6 rows (three bf16 terms per value, 12 in_pad bytes per sample): see "x6" above */
+                     The FIRST layers (prop_w[0] / nerf_w[0]) see more bits of the features than the hidden layers do (see "x6"
+                     above): mode 1: weights from m360_pack_linear_bf16x3, features as [hi | lo] pairs (4 in_pad bytes per sample,
+                     m360_linear_bf16x3_bf16out); mode 2: weights from m360_pack_linear_bf16x6, features as x6 rows (three bf16
+                     terms per value, 12 in_pad bytes per sample, m360_linear_bf16_split) */
 } m360_model_t; /* packed form of the state_dict of model.py:43-53,131-158 */
 
 typedef struct {

@@ -88,6 +88,7 @@ SIGNATURES = {
     "m360_linear_bf16": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_pack_linear_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear_bf16x3": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "m360_linear_bf16x3_bf16out": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_pack_linear_bf16x6": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear_bf16_split": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_encode_features_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),

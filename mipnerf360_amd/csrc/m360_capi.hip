@@ -123,7 +123,7 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     L.t0 = take((size_t)B * (N + 1) * sizeof(float));
     L.what = take((size_t)B * N * sizeof(float));
     // MLP input rows: fp32 [in_pad]; bf16 / bf16x3 modes: x6 rows of 6 in_pad bf16 (three bf16 terms per feature, see prop_stage)
-    L.feat = take(S * m->in_pad * (m->mlp_bf16 ? 6 * sizeof(unsigned short) : sizeof(float)));
+    L.feat = take(S * m->in_pad * (m->mlp_bf16 == 2 ? 6 * sizeof(unsigned short) : sizeof(float)));  // bf16: [hi | lo] pairs = 4 bytes per value too
     L.act_a = take(S * wmax * sizeof(float));
     L.act_b = take(S * wmax * sizeof(float));
     // partial head sums of the fused last layer: [S][slots][heads] fp32 (67 MB at 4096 x 128, width 1024)
@@ -178,10 +178,14 @@ static int p_linear(const m360_hyper_t *h, TileQueues *q, const float *x, long M
 // net that resolves anything along a ray has first-layer gains of ~1e3-1e4 on DIFFERENCES of the sin / cos features: bf16
 // features (8 bits) put the density shells of fixture G19 at the wrong depth (PSNR off by 3-6 dB), two-term features (16 bits)
 // leave |d rgb| ~2e-4; with 24 bits both modes are back inside their tolerances.
-static int p_linear_first(const m360_hyper_t *h, int mode, const void *feat, long M, const void *w6, const float *b, int n_pad, int in_pad, void *y, m360_stream_t st) {
-    ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, 6 * in_pad);
-    if (mode == 2) return ps.done(m360_linear_bf16_split(feat, M, 6 * in_pad, w6, b, n_pad, 6 * in_pad, M360_ACT_RELU, y, 2 * n_pad, st));
-    return ps.done(m360_linear_bf16(feat, M, 6 * in_pad, w6, b, n_pad, 6 * in_pad, M360_ACT_RELU, y, n_pad, st));
+// The bf16 mode rounds the layer's output to bf16 anyway and gets by with 16 bits of each operand (PSNR within 0.013 dB on G19):
+// [hi | lo] features, [Wh | Wh | Wl] weights, the ring kernel's three-product loop with the plain bf16 epilogue - one 64-deep block per
+// tile, store-bound like round 3's first layer (0.30 instead of the x6 form's 0.53 ms for the NeRF net).
+static inline int first_row_format(int mode) { return mode == 2 ? 3 : (mode == 1 ? 2 : 0); }  // encoder row format of the MLP input
+static int p_linear_first(const m360_hyper_t *h, int mode, const void *feat, long M, const void *w0, const float *b, int n_pad, int in_pad, void *y, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, (mode == 2 ? 6 : 3) * in_pad);
+    if (mode == 2) return ps.done(m360_linear_bf16_split(feat, M, 6 * in_pad, w0, b, n_pad, 6 * in_pad, M360_ACT_RELU, y, 2 * n_pad, st));
+    return ps.done(m360_linear_bf16x3_bf16out(feat, M, 2 * in_pad, w0, b, n_pad, in_pad, M360_ACT_RELU, y, n_pad, st));
 }
 // mode 1: bf16 rows of k_pad / n_pad columns; mode 2 (bf16x3): [hi | lo] rows of 2 k_pad / 2 n_pad columns
 static int p_linear_bf16(const m360_hyper_t *h, int mode, const void *x, long M, const void *w, const float *b, int n_pad, int k_pad, int act, void *y, m360_stream_t st) {
@@ -282,11 +286,11 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     }
     const int hp = m->hp_pad;
     if (ext_norm) {  // the caller supplies the (all-reduced) contraction norm; the layers below are shared
-        M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, m->mlp_bf16 ? 3 : 0, 0, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));  /* row format: fp32, or x6 for both bf16 modes */
+        M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(m->mlp_bf16), 0, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));  /* row format: fp32, or x6 for both bf16 modes */
     }
     if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers; mode 2 = bf16x3: [hi | lo] pairs)
         const int mode = m->mlp_bf16;
-        if (!ext_norm) M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, 3, h->norm_group_rays, nullptr, parts, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
+        if (!ext_norm) M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(mode), h->norm_group_rays, nullptr, parts, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(p_linear_first(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, a, st));
         M360_TRY(p_linear_bf16(h, mode, a, S, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, st));
         M360_TRY(p_linear_bf16(h, mode, b, S, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, st));
@@ -338,7 +342,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         M360_TRY(p_nerf_finish_fused(h, act[7], 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st));
     } else if (m->mlp_bf16) {
         const int mode = m->mlp_bf16;
-        M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, feat, m->in_pad, 3, ext_norm ? 0 : h->norm_group_rays, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(mode), ext_norm ? 0 : h->norm_group_rays, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
         M360_TRY(p_linear_first(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, a, st));
         for (int layer = 1; layer < 7; ++layer) {
             M360_TRY(p_linear_bf16(h, mode, src, S, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, st));

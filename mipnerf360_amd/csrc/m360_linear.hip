@@ -724,11 +724,27 @@ int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in,
     return check_launch("pack_linear_bf16x3");
 }
 
+// split_out = true: m360_linear_bf16x3 ([hi | lo] rows out); false: m360_linear_bf16x3_bf16out (one bf16 term out: the first layer of the
+// bf16 mode - bias + {none, ReLU}, full tiles on the ring kernel's X3 loop with the plain epilogue, ragged rows on the generic kernel)
+static int linear_bf16x3_any(const void *x, long M, int ldx, const void *w_packed3, const float *b_packed, int n_pad, int k_pad,
+                             int act, void *y, int ldy, m360_stream_t stream, bool split_out);
+
 int m360_linear_bf16x3(const void *x, long M, int ldx, const void *w_packed3, const float *b_packed, int n_pad, int k_pad,
                        int act, void *y, int ldy, m360_stream_t stream) {
+    return linear_bf16x3_any(x, M, ldx, w_packed3, b_packed, n_pad, k_pad, act, y, ldy, stream, true);
+}
+
+int m360_linear_bf16x3_bf16out(const void *x, long M, int ldx, const void *w_packed3, const float *b_packed, int n_pad, int k_pad,
+                               int act, void *y, int ldy, m360_stream_t stream) {
+    if (act != M360_ACT_NONE && act != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3_bf16out: activation %d (none or ReLU)", act);
+    return linear_bf16x3_any(x, M, ldx, w_packed3, b_packed, n_pad, k_pad, act, y, ldy, stream, false);
+}
+
+static int linear_bf16x3_any(const void *x, long M, int ldx, const void *w_packed3, const float *b_packed, int n_pad, int k_pad,
+                             int act, void *y, int ldy, m360_stream_t stream, bool split_out) {
     if (!x || !w_packed3 || !b_packed || !y || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: null pointer or negative M");
-    if (n_pad < 1 || k_pad < pbf16::BK || k_pad % pbf16::BK != 0 || ldx < 2 * k_pad || ldy < 2 * n_pad || ldx % 8 != 0 || ldy % 8 != 0 || n_pad % 8 != 0)
-        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: k_pad=%d must be a positive multiple of %d, ldx=%d >= 2 k_pad, ldy=%d >= 2 n_pad=%d, all multiples of 8", k_pad, pbf16::BK, ldx, ldy, 2 * n_pad);
+    if (n_pad < 1 || k_pad < pbf16::BK || k_pad % pbf16::BK != 0 || ldx < 2 * k_pad || ldy < (split_out ? 2 : 1) * n_pad || ldx % 8 != 0 || ldy % 8 != 0 || n_pad % 8 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: k_pad=%d must be a positive multiple of %d, ldx=%d >= 2 k_pad, ldy=%d >= %s n_pad=%d, all multiples of 8", k_pad, pbf16::BK, ldx, ldy, split_out ? "2" : "1", n_pad);
     if (((uintptr_t)x | (uintptr_t)w_packed3 | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: pointers must be 16-byte aligned");
     if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: unknown activation %d", act);
     if (M == 0) return M360_OK;
@@ -745,10 +761,17 @@ int m360_linear_bf16x3(const void *x, long M, int ldx, const void *w_packed3, co
         // hidden layers (bias + {none, ReLU}): the one-wave ring kernel (same accumulation order)
         if (M360_W16_X3 && act != M360_ACT_SIGMOID && k_pad % w16::BKS == 0) {
             dim3 blk(w16::kThreads);
-#define M360_W16X(A, ONE) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<A, 0, false, true, ONE>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt)
-            if (k_pad == w16::BKS) { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, true); else M360_W16X(M360_ACT_NONE, true); }
-            else { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, false); else M360_W16X(M360_ACT_NONE, false); }
+#define M360_W16X(A, ONE, SP) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<A, 0, false, true, ONE, 0, SP>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt)
+            if (split_out) {
+                if (k_pad == w16::BKS) { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, true, true); else M360_W16X(M360_ACT_NONE, true, true); }
+                else { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, false, true); else M360_W16X(M360_ACT_NONE, false, true); }
+            } else {
+                if (k_pad == w16::BKS) { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, true, false); else M360_W16X(M360_ACT_NONE, true, false); }
+                else { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, false, false); else M360_W16X(M360_ACT_NONE, false, false); }
+            }
 #undef M360_W16X
+        } else if (!split_out) {
+            return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3_bf16out: no full-tile kernel for this shape");  // (unreachable: k_pad is a multiple of 64)
         } else
         switch (act) {
             case M360_ACT_NONE: hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_NONE, false, M360_X3_MODE>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / pp16::BN, (int)nt); break;
@@ -761,6 +784,10 @@ int m360_linear_bf16x3(const void *x, long M, int ldx, const void *w_packed3, co
         dim3 grid((unsigned)((n_pad + 31) / 32), (unsigned)((Mt + 31) / 32)), block(64);
         const __bf16 *xt = xb + M_full * ldx;
         __bf16 *yt = yb + M_full * ldy;
+        if (!split_out) {
+            if (act == M360_ACT_RELU) hipLaunchKernelGGL((pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_RELU, true, false>), grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k3, yt, ldy);
+            else hipLaunchKernelGGL((pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_NONE, true, false>), grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k3, yt, ldy);
+        } else
         switch (act) {
             case M360_ACT_NONE: hipLaunchKernelGGL((pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_NONE, true>), grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k3, yt, ldy); break;
             case M360_ACT_RELU: hipLaunchKernelGGL((pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_RELU, true>), grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k3, yt, ldy); break;

@@ -84,7 +84,8 @@ __device__ unsigned long long g_w16_stamps[256 * 4];
 // per tile instead of 5.4 k), and still the layer takes 0.85 ms against 1.08-1.12 ms (tools/linear_bench.py --variant 150).
 constexpr int kHeadMaxN = 1024;  // widest layer the fused heads take (their hi / lo rows live in 16 KiB of LDS)
 // SPLIT (defaults to X3): the output rows are [hi(Np) | lo(Np)] pairs.  SPLIT without X3 is the x6 first layer of the bf16x3 mode
-// (m360_linear_bf16_split): a plain contraction over bf16 rows whose fp32 result goes out as two bf16 terms.
+// (m360_linear_bf16_split): a plain contraction over bf16 rows whose fp32 result goes out as two bf16 terms.  X3 without SPLIT is the
+// first layer of the bf16 mode (m360_linear_bf16x3_bf16out): the three products of two-term features and weights, one bf16 term out.
 // LDSEPI (round 4, plain bf16 output only): the epilogue moves the accumulators through a wave-private LDS tile instead of the vector
 // pipe - ds_write_b128 straight from the AccVGPRs (16 rows x 64 fp32 columns, XOR-swizzled 16-byte chunks: no bank conflicts),
 // ds_read_b128 back with lane (row L >> 3, columns 8 (L & 7) ..+7), so that 8 lanes hold one 128-byte line of bf16 output: no
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0) + (LDSEPI ? 4 * 4096 : 0)];  // 144 (160) KiB
     static_assert(!LDSEPI || (HEADS == 0 && !SPLIT && !X3), "the LDS epilogue: plain bf16 output (its 16 KiB sit where the head rows would)");
     static_assert(HEADS == 0 || HEADS == 1 || HEADS == 4, "1 (proposal) or 4 (NeRF) heads");
-    static_assert(SPLIT == X3 || (SPLIT && !X3 && HEADS == 0), "split output without the X3 loop: hidden-layer epilogue only");
+    // X3 loop + plain bf16 output: the first layer of the bf16 mode (two-term features and weights in, one bf16 term out)
+    static_assert(SPLIT == X3 || HEADS == 0, "X3 loop and split output go together wherever the heads are fused");
     constexpr bool STORE_Y = HEADS == 0;
     // vector-memory operations of a tile's epilogue: 32 whole-line stores (64 as [hi | lo]) or, with fused heads, 8 partial-sum stores
     constexpr int W16_STORES = STORE_Y ? (SPLIT ? 64 : 32) : 8;

@@ -121,8 +121,10 @@ class _PackedMLP:
                 raise RuntimeError("mlp_dtype='bf16' / 'bf16x3': the parameters hold NaN values; the bf16 matrix pipe cannot propagate them "
                                    "the way nn.ReLU does (the reference renders NaN) - use mlp_dtype='fp32' for this checkpoint")
         for i, lin in enumerate(hidden_layers):
-            if i == 0 and bf16:  # both reduced-precision modes: the first layer multiplies all 24 bits of features and weights ("x6")
+            if i == 0 and bf16 == 2:  # bf16x3: the first layer multiplies all 24 bits of features and weights ("x6")
                 wp, bp = ops.pack_linear_bf16x6(lin.weight, lin.bias, self.h_pad, self.in_pad)
+            elif i == 0 and bf16 == 1:  # bf16: 16 bits of each (two bf16 terms, three products), one bf16 term out
+                wp, bp = ops.pack_linear_bf16x3(lin.weight, lin.bias, self.h_pad, self.in_pad)
             else:
                 wp, bp = pack(lin.weight, lin.bias, self.h_pad, self.in_pad if i == 0 else self.h_pad)
             self.w.append(wp), self.b.append(bp)
@@ -500,9 +502,9 @@ class mipNeRF360(nn.Module):
         weights / hidden activations, fp32 accumulation, heads and ray math in fp32) or "bf16x3" (every
         value carried as two bf16 terms, products formed as xh wh + xl wh + xh wl on the bf16 MFMA with fp32
         accumulation: within the fp32 render tolerance of 1e-4 at about 3x the fp32 rays/s; forward only).  In both
-        reduced-precision modes the FIRST layers (model.py:44,132) see all 24 bits of the encoded features and of their
-        weights (three bf16 terms each, six products: include/m360.h "x6") - positions inside a contracted chunk differ
-        in their low-order bits only."""
+        reduced-precision modes the FIRST layers (model.py:44,132) see more bits of the encoded features and of their weights
+        than the hidden layers - bf16: 16 (two bf16 terms, three products), bf16x3: all 24 (three terms, six products:
+        include/m360.h "x6") - because positions inside a contracted chunk differ in their low-order bits only."""
         super().__init__()
         self.randomized = randomized
         self.num_samples = num_samples

@@ -381,6 +381,20 @@ def linear_bf16x3(x, w_packed3, b_packed, act: int = _lib.ACT_NONE, out: Optiona
     return y
 
 
+def linear_bf16x3_bf16out(x, w_packed3, b_packed, act: int = _lib.ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [M, 2 k_pad] bf16 (hi | lo), weights [Wh | Wh | Wl] -> y [M, n_pad] bf16: the three products of m360_linear_bf16x3 with ONE bf16
+    term out (m360_linear_bf16x3_bf16out: the first layers of the bf16 mode)."""
+    x, w_packed3, b_packed = dev_bf16(x, "x"), dev_bf16(w_packed3, "w_packed3"), dev(b_packed, "b_packed")
+    M, ldx = x.shape
+    n_pad, k3 = w_packed3.shape
+    k_pad = k3 // 3
+    if ldx != 2 * k_pad:
+        raise RuntimeError(f"linear_bf16x3_bf16out: x has {ldx} columns, packed weight expects {2 * k_pad} (hi | lo)")
+    y = out if out is not None else torch.empty(M, n_pad, device=x.device, dtype=torch.bfloat16)
+    _call("m360_linear_bf16x3_bf16out", x, M, ldx, w_packed3, b_packed, n_pad, k_pad, act, y, y.shape[1], STREAM)
+    return y
+
+
 def pack_linear_bf16x6(weight, bias=None, n_pad: Optional[int] = None, k_pad: Optional[int] = None):
     """fp32 Linear -> "x6" packing [n_pad, 6 k_pad] = [Wh | Wm | Wl | Wh | Wm | Wh] (three bf16 terms per weight: all 24 bits)
     + fp32 bias: the first layers of the bf16 / bf16x3 modes (include/m360.h, m360_pack_linear_bf16x6)."""

@@ -353,7 +353,8 @@ def _lin16x6(x, sd, prefix):
 
 def prop_mlp(x, sd, bf16=False):
     """model.py:43-53.  bf16=True emulates the reduced-precision extension (hidden activations stored as bf16), bf16=2 the
-    bf16x3 extension (two bf16 terms per value, three products per multiply); in both the first layer is `_lin16x6`."""
+    bf16x3 extension (two bf16 terms per value, three products per multiply); the first layers see more bits than the hidden ones:
+    bf16: `_lin16x3` (16 bits of features and weights) with one bf16 term out; bf16x3: `_lin16x6` (all 24 bits)."""
     if bf16 == 2:
         x = _x3(torch.relu(_lin16x6(x, sd, "prop_net.model.0")))
         for i in (2, 4):
@@ -361,7 +362,7 @@ def prop_mlp(x, sd, bf16=False):
         x = _x3(torch.sigmoid(_lin16x3(x, sd, "prop_net.model.6")))
         return _lin(x, sd, "prop_net.model.8")
     if bf16:
-        x = _r16(torch.relu(_lin16x6(x, sd, "prop_net.model.0")))
+        x = _r16(torch.relu(_lin16x3(x, sd, "prop_net.model.0")))   # the bf16 mode's first layer: two terms in, one out
         for i in (2, 4):
             x = _r16(torch.relu(_lin16(x, sd, f"prop_net.model.{i}")))
         x = _r16(torch.sigmoid(_lin16(x, sd, "prop_net.model.6")))
@@ -380,7 +381,7 @@ def nerf_mlp(x, sd, bf16=False):
             x = _x3(torch.relu(_lin16x3(x, sd, f"nerf_net.model.{i}")))
         x = _x3(torch.sigmoid(_lin16x3(x, sd, "nerf_net.model.14")))
     elif bf16:
-        x = _r16(torch.relu(_lin16x6(x, sd, "nerf_net.model.0")))
+        x = _r16(torch.relu(_lin16x3(x, sd, "nerf_net.model.0")))
         for i in range(2, 14, 2):
             x = _r16(torch.relu(_lin16(x, sd, f"nerf_net.model.{i}")))
         x = _r16(torch.sigmoid(_lin16(x, sd, "nerf_net.model.14")))

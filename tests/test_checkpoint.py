@@ -44,12 +44,12 @@ def test_packed_export_matches_padded_weights(tmp_path, dtype):
     ref = np.zeros((hn_pad, in_pad), np.float32)
     ref[:200, :58] = sd["nerf_net.model.0.weight"]
     if dtype == "bf16":
-        # the first layer of the bf16 modes is the "x6" packing [Wh | Wm | Wl | Wh | Wm | Wh]: three bf16 terms = the fp32 weight
-        assert w0.dtype == np.uint16 and w0.shape == (hn_pad, 6 * in_pad)
+        # the first layer of the bf16 mode carries 16 bits of each weight: the [Wh | Wh | Wl] packing of m360_pack_linear_bf16x3
+        assert w0.dtype == np.uint16 and w0.shape == (hn_pad, 3 * in_pad)
         got = torch.from_numpy(w0.view(np.int16).copy()).view(torch.bfloat16).float().numpy()
-        hi, mid, lo = got[:, :in_pad], got[:, in_pad:2 * in_pad], got[:, 2 * in_pad:3 * in_pad]
-        assert np.array_equal(hi, torch.from_numpy(ref).bfloat16().float().numpy()) and np.array_equal(hi + mid + lo, ref)
-        assert np.array_equal(got[:, 3 * in_pad:4 * in_pad], hi) and np.array_equal(got[:, 4 * in_pad:5 * in_pad], mid) and np.array_equal(got[:, 5 * in_pad:], hi)
+        hi, lo = got[:, :in_pad], got[:, 2 * in_pad:]
+        assert np.array_equal(hi, torch.from_numpy(ref).bfloat16().float().numpy()) and np.array_equal(got[:, in_pad:2 * in_pad], hi)
+        assert np.array_equal(lo, (torch.from_numpy(ref) - torch.from_numpy(ref).bfloat16().float()).bfloat16().float().numpy())
         w1 = packed["nerf.w1"]              # hidden layers: plain bf16 [n_pad, k_pad]
         ref1 = np.zeros((hn_pad, hn_pad), np.float32)
         ref1[:200, :200] = sd["nerf_net.model.2.weight"]

@@ -492,6 +492,32 @@ def test_x6_first_layer_is_an_fp32_product(dev, M, n_out, split):
         assert float(y[:, n_out:n_pad].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,n_out,k_in", [(700, 256, 58), (256 * 5 + 33, 1024, 58), (90, 96, 58), (1024, 256, 200)])
+def test_bf16_mode_first_layer_two_terms_in_one_out(dev, M, n_out, k_in):
+    """m360_linear_bf16x3_bf16out: the first layer of the bf16 mode - [hi | lo] features, [Wh | Wh | Wl] weights, the three products of
+    the bf16x3 contract, ONE bf16 term out (full tiles: the ring kernel's X3 loop with the plain epilogue; ragged rows: the generic
+    kernel).  Against fp64: the product at 16-bit operand accuracy (<= 4 x 2^-16 of the row's sum of |x w|) plus the output's own bf16
+    rounding; and bit for bit the hi half of what m360_linear_bf16x3 writes for the same operands... rounded once instead of split."""
+    from mipnerf360_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + n_out)
+    x = torch.randn(M, k_in, generator=g)
+    w = torch.randn(n_out, k_in, generator=g) * 3
+    b = torch.randn(n_out, generator=g)
+    k_pad, n_pad = ops.round_up(k_in, 64), ops.round_up(n_out, 64)
+    xp = torch.zeros(M, k_pad)
+    xp[:, :k_in] = x
+    wp, bp = ops.pack_linear_bf16x3(w.to(dev), b.to(dev), n_pad, k_pad)
+    xs = ops.split_bf16x3(xp.to(dev))
+    y = ops.linear_bf16x3_bf16out(xs, wp, bp, _lib.ACT_RELU)
+    assert y.shape == (M, n_pad) and y.dtype == torch.bfloat16
+    want = torch.relu(x.double() @ w.double().t() + b.double())
+    scale = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    err = (y[:, :n_out].float().cpu().double() - want).abs()
+    assert bool((err <= 1.01 * 2.0 ** -8 * want.abs() + 4 * 2.0 ** -16 * scale).all()), float((err / scale).max())
+    full = ops.join_bf16x3(ops.linear_bf16x3(xs, wp, bp, _lib.ACT_RELU))             # the same products, two terms out
+    assert bool(((y.float() - full).abs() <= 2.0 ** -8 * full.abs() + 1e-30).all())
+
+
 # =============================================================================== G19: trained-like weights
 G19_KINDS = ["lego", "garden", "mixed"]
 # rendered values: the stated fp32 tolerance; stage outputs: c x the reference's own fp32 error against its fp64 run
