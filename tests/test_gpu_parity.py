@@ -1994,11 +1994,14 @@ def test_generate_rays_span_bit_identical_to_the_full_frame(dev):
         R.generate_rays(poses, h, w, 0.9 * w, 0.0, 1.0, True, span=(0, 3 * h * w + 1))
 
 
-def test_full_size_forward_soak_is_deterministic(dev):
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16", "bf16x3"])
+def test_full_size_forward_soak_is_deterministic(dev, mlp_dtype):
     """Race screen at the BASELINE shape (4096 x 128, full width): 40 back-to-back forwards must be bit-identical
-    (LDS-DMA double buffering, tile hand-over, deferred stores: any ordering bug shows up as sporadic mismatches)."""
+    (LDS-DMA double buffering, tile hand-over, deferred stores: any ordering bug shows up as sporadic mismatches).  The bf16 modes
+    run the ring kernel in five forms per forward (first layer: three-product loop with one term out / x6 with split output, hidden,
+    last + heads), the one-launch prologue and the NaN flags."""
     sd = synthetic.make_state_dict(256, 1024, seed=0)
-    m = build_model(sd, dev, 128, 256, 1024, False)
+    m = _g19_model(sd, dev, 128, 256, 1024, False, mlp_dtype)
     rays = dev_rays(synthetic.make_rays("garden", 4096, seed=1), dev)
     with torch.no_grad():
         first = [t.clone() for t in m(rays)]
