@@ -99,3 +99,23 @@ def oracle_stages(rays_np, sd_np, num_samples, white_bkgd, dtype="float32", mlp_
     res = {nm: v.numpy() for nm, v in zip(G19_STAGE_NAMES, (w_hat,) + tuple(out))}
     res["t_hat"] = t_hat.numpy()
     return res
+
+
+def g21_case(g, kind):
+    from mipnerf360_amd import synthetic
+    B, n, wb, hp, hn = (int(x) for x in g[kind + "_cfg"])
+    pre = kind + "_sd."
+    sd = {k[len(pre):]: v for k, v in g.items() if k.startswith(pre)}
+    rays = {k: g[f"{kind}_rays_{k}"] for k in synthetic.RAY_FIELDS}
+    return (B, n, bool(wb), hp, hn), rays, sd, g[kind + "_pixels"]
+
+
+def assert_grad_within_reference_error(got, ref32, ref64, c=4.0, floor=2e-4, what=""):
+    """A parameter gradient on ill-conditioned (G19 / G21) weights: no further from the reference's fp64 gradient than c x the
+    reference's own fp32 gradient is, all relative to the tensor's largest entry; floor = the flat regime's 2e-4."""
+    got, ref32, ref64 = (np.asarray(a, dtype=np.float64) for a in (got, ref32, ref64))
+    scale = max(float(np.abs(ref64).max()), 1e-30)
+    e_ref = float(np.abs(ref32 - ref64).max()) / scale
+    e_got = float(np.abs(got - ref64).max()) / scale
+    assert np.isfinite(e_got) and e_got <= c * max(e_ref, floor), f"{what}: {e_got:.3e} of the tensor's scale from the fp64 gradient; the reference's fp32 gradient is {e_ref:.3e} away"
+    return e_got, e_ref

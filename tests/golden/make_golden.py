@@ -863,10 +863,66 @@ def g20():
     save("g20_trained_checkpoint_render", **out)
 
 
+def g21():
+    """Training gradients OUTSIDE the flat regime (row f3 on fixture G19's weights): the parameter gradients of the reference's
+    train.py loop body (train.py:55-62 proposal step, :69-80 NeRF step) on the reduced-width structured weights of G19, fp32 and
+    fp64.  Through a density shell the proposal loss - relu(bound - w_hat)^2 / (w_hat + 1e-6) with w_hat over decades - is
+    ill-conditioned, so the tests take their tolerance from the reference's own fp32 error (as for G19)."""
+    from intern import loss as ref_loss
+    out = {}
+    hp_, hn_, seed = 32, 64, 19
+    gen = np.random.Generator(np.random.PCG64(2121))
+    for kind, B, n, wb in (("lego", 12, 16, True), ("mixed", 16, 32, True)):
+        r = synthetic.make_rays(kind, B, seed=seed)
+        sd = synthetic.make_structured_state_dict(hp_, hn_, seed, r, n)
+        pixels = gen.uniform(0, 1, size=(B, 3)).astype(np.float32)
+        for k, v in sd.items():
+            out[f"{kind}_sd." + k] = v
+        for k in synthetic.RAY_FIELDS:
+            out[f"{kind}_rays_{k}"] = r[k]
+        out[f"{kind}_cfg"], out[f"{kind}_pixels"] = np.array([B, n, int(wb), hp_, hn_]), pixels
+        for dt, tag in ((torch.float32, ""), (torch.float64, "64")):
+            ctx = reference_in_fp64() if dt == torch.float64 else __import__("contextlib").nullcontext()
+            with ctx:
+                m = build_ref_model(sd, n, hp_, hn_, wb)
+                m.load_state_dict({k: torch.from_numpy(v).to(dt) for k, v in sd.items()})
+                m = m.to(dt)
+                m.train()
+                mk = lambda: ref_ray.Rays(*[torch.from_numpy(r[k]).to(dt).clone() for k in synthetic.RAY_FIELDS])  # noqa: E731
+                m.zero_grad()
+                rays = mk()
+                t_hat, w_hat = m.prop_net.forward(rays)
+                _, _, _, t, w, _ = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+                loss_prop = ref_loss.Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
+                loss_prop.backward()
+                out[f"{kind}_loss_prop{tag}"] = N(loss_prop).astype(np.float64)
+                for name, p in m.named_parameters():
+                    if name.startswith("prop_net"):
+                        out[f"{kind}_propstep{tag}.{name}"] = N(p.grad).astype(np.float32)
+                m.zero_grad()
+                rays = mk()
+                t_hat, w_hat = m.prop_net.forward(rays)
+                rgb, _, _, _, fine_w, s_vals = m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+                loss_nerf, _ = ref_loss.Loss_nerf(input=rgb, target=torch.from_numpy(pixels).to(dt))
+                loss_dist = ref_loss.Loss_dist(s_vals=s_vals, weights=fine_w)
+                (loss_nerf + 0.01 * loss_dist).backward()
+                out[f"{kind}_loss_nerf{tag}"], out[f"{kind}_loss_dist{tag}"] = N(loss_nerf).astype(np.float64), N(loss_dist).astype(np.float64)
+                for name, p in m.named_parameters():
+                    if name.startswith("nerf_net"):
+                        out[f"{kind}_nerfstep{tag}.{name}"] = N(p.grad).astype(np.float32)
+        worst = max(np.abs(out[f"{kind}_propstep.{nm}"] - out[f"{kind}_propstep64.{nm}"]).max() / max(np.abs(out[f"{kind}_propstep64.{nm}"]).max(), 1e-30)
+                    for nm in sd if nm.startswith("prop_net"))
+        worst_n = max(np.abs(out[f"{kind}_nerfstep.{nm}"] - out[f"{kind}_nerfstep64.{nm}"]).max() / max(np.abs(out[f"{kind}_nerfstep64.{nm}"]).max(), 1e-30)
+                      for nm in sd if nm.startswith("nerf_net"))
+        print(f"  G21 {kind}: loss_prop {float(out[kind + '_loss_prop']):.6g} loss_nerf {float(out[kind + '_loss_nerf']):.6g}; the reference's own fp32 error of the "
+              f"gradients (relative to each tensor's max): proposal step {worst:.2e}, NeRF step {worst_n:.2e}")
+    save("g21_structured_gradients", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
     table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14,
-                 g15=g15, g16=g16, g17=g17, g18=g18, g19=g19, g20=g20)
+                 g15=g15, g16=g16, g17=g17, g18=g18, g19=g19, g20=g20, g21=g21)
     for k in which:
         print(k)
         table[k]()

@@ -656,6 +656,47 @@ def test_c2_headline_batch_on_structured_weights_vs_oracle_as_one_chunk(dev, mlp
     close_render(out[0], out[1], out[2], o32["rgb"], o32["dist"], o32["acc"])
 
 
+# =============================================================================== G21: gradients on structured weights
+@pytest.mark.parametrize("kind", ["lego", "mixed"])
+def test_g21_training_gradients_on_structured_weights(golden, dev, kind):
+    """Row f3 outside the flat regime: the reference's train.py loop body, run unchanged on the mirrors (tape-keeping forwards, the
+    hand-written backward of both stages, intern.loss), on the trained-like weights of G19 - every parameter gradient of the proposal
+    step (train.py:55-62) and of the NeRF step (:69-80) against the reference's autograd, no further from its fp64 gradients than 4 x
+    its own fp32 gradients are (the proposal loss through a density shell is ill-conditioned: the reference's fp32 run is ~1 % of a
+    tensor's scale from its fp64 run)."""
+    from conftest import assert_grad_within_reference_error, g21_case
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
+    g = golden("g21_structured_gradients")
+    (B, n, wb, hp_, hn_), r, sd, pixels = g21_case(g, kind)
+    model = build_model(sd, dev, n, hp_, hn_, wb)
+    model.train()
+    rays = dev_rays(r, dev)
+    t_hat, w_hat = model.prop_net.forward(rays)
+    _, _, _, t, w, _ = model.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    loss_prop = Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
+    model.zero_grad()
+    loss_prop.backward()
+    close(loss_prop, g[kind + "_loss_prop"], rtol=2e-3, atol=0)
+    worst = 0.0
+    for name, p in model.named_parameters():
+        if name.startswith("prop_net"):
+            e, e_ref = assert_grad_within_reference_error(H(p.grad), g[f"{kind}_propstep.{name}"], g[f"{kind}_propstep64.{name}"], what=f"prop step {name}")
+            worst = max(worst, e / max(e_ref, 2e-4))
+    model.zero_grad()
+    t_hat, w_hat = model.prop_net.forward(rays)
+    rgb, _, _, _, fine_w, s_vals = model.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+    loss_nerf, _ = Loss_nerf(rgb, D(pixels, dev))
+    loss_dist = Loss_dist(s_vals, fine_w)
+    (loss_nerf + 0.01 * loss_dist).backward()
+    close(loss_nerf, g[kind + "_loss_nerf"], rtol=1e-4, atol=0)
+    worst_n = 0.0
+    for name, p in model.named_parameters():
+        if name.startswith("nerf_net"):
+            e, e_ref = assert_grad_within_reference_error(H(p.grad), g[f"{kind}_nerfstep.{name}"], g[f"{kind}_nerfstep64.{name}"], what=f"nerf step {name}")
+            worst_n = max(worst_n, e / max(e_ref, 2e-4))
+    print(f"G21 {kind}: worst gradient error / max(the reference's own fp32 error, 2e-4): proposal step {worst:.2f}, NeRF step {worst_n:.2f}")
+
+
 # =============================================================================== G20: a trained checkpoint
 @pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3", "bf16"])
 def test_g20_trained_checkpoint_renders_like_the_reference(golden, dev, mlp_dtype):

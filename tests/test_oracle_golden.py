@@ -564,3 +564,26 @@ def test_g20_trained_checkpoint_oracle(golden):
     for nm in G19_STAGE_NAMES:
         assert_within_reference_error(o32[nm], g[nm], g[nm + "64"], c=4.0, floor=5e-6, relative_above_one=nm in ("dist", "t_vals"), what="G20 " + nm)
     close(o32["rgb"], g["rgb"], atol=1e-4, rtol=0), close(o32["acc"], g["acc"], atol=1e-4, rtol=0)
+
+
+# ------------------------------------------------------------------ G21: training gradients on structured weights
+@pytest.mark.parametrize("kind", ["lego", "mixed"])
+def test_g21_oracle_gradients_on_structured_weights(golden, kind):
+    """The oracle's autograd against the reference's (train.py:55-62, :69-80) on the trained-like weights of G19 (reduced width).
+    The proposal step is ill-conditioned there - relu(bound - w_hat)^2 / (w_hat + 1e-6) through density shells: the reference's own
+    fp32 gradients are 0.8-1.0 % of a tensor's scale away from its fp64 gradients - so every gradient is held to 4 x the reference's own
+    fp32 error (floor: the flat regime's 2e-4)."""
+    from conftest import assert_grad_within_reference_error, g21_case
+    g = golden("g21_structured_gradients")
+    (B, n, wb, hp_, hn_), r, sd, pixels = g21_case(g, kind)
+    hp = O.Hyper(num_samples=n, white_bkgd=wb)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    lp, grads = O.prop_step_gradients(O.rays_from_numpy(r), tsd, hp)
+    np.testing.assert_allclose(float(lp), float(g[kind + "_loss_prop"]), rtol=1e-4)
+    for name, gr in grads.items():
+        assert_grad_within_reference_error(gr.numpy(), g[f"{kind}_propstep.{name}"], g[f"{kind}_propstep64.{name}"], what=f"prop step {name}")
+    ln, ld, grads = O.nerf_step_gradients(O.rays_from_numpy(r), tsd, hp, torch.from_numpy(pixels))
+    np.testing.assert_allclose(float(ln), float(g[kind + "_loss_nerf"]), rtol=1e-5)
+    np.testing.assert_allclose(float(ld), float(g[kind + "_loss_dist"]), rtol=1e-4)
+    for name, gr in grads.items():
+        assert_grad_within_reference_error(gr.numpy(), g[f"{kind}_nerfstep.{name}"], g[f"{kind}_nerfstep64.{name}"], what=f"nerf step {name}")
