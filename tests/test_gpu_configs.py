@@ -165,12 +165,13 @@ def test_bench_c5_named_workload(dev):
 
 
 # ------------------------------------------------------------------------------- configs[2]
-def test_c3_hierarchical_64_128_full_width_vs_oracle(dev):
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16x3"])
+def test_c3_hierarchical_64_128_full_width_vs_oracle(dev, mlp_dtype):
     """configs[2]'s sampling ("64+128": 64 proposal, 128 NeRF samples) at FULL width against the oracle's same
-    extension (the reference itself cannot express unequal counts, intern/ray.py:147), 256 rays as one chunk."""
+    extension (the reference itself cannot express unequal counts, intern/ray.py:147), 256 rays as one chunk; fp32 and bf16x3."""
     from oracle import ref_path as O
     B = 256
-    m, sd = make_model(dev, 64, n_fine=128)
+    m, sd = make_model(dev, 64, n_fine=128, mlp_dtype=mlp_dtype)
     r = synthetic.make_rays("garden", B, seed=34)
     with torch.no_grad():
         rgb, dist, acc = (t.cpu() for t in m(dev_rays(r, dev)))

@@ -987,7 +987,7 @@ def test_randomized_mode_is_statistically_sane(dev):
 
 
 @pytest.mark.parametrize("kind,B,n,wb", [("lego", 96, 32, True), ("garden", 64, 48, False)])
-def test_randomized_mode_with_replayed_uniforms_vs_oracle(dev, kind, B, n, wb):
+def test_randomized_mode_with_replayed_uniforms_vs_oracle(dev, kind, B, n, wb, mlp_dtype="fp32"):
     """randomized=True beyond statistics: the mirrors draw their uniforms with torch.rand on the device (t_rand [B, N+1] in
     prop_net.forward, then u_rand [B, N+1] in nerf_net.forward), so re-seeding torch's device generator and drawing the same
     two tensors gives the oracle the SAME uniforms - stratified jitter (intern/ray.py:103-108) and the randomized inverse-CDF
@@ -995,7 +995,7 @@ def test_randomized_mode_with_replayed_uniforms_vs_oracle(dev, kind, B, n, wb):
     from mipnerf360_amd.model import mipNeRF360
     from oracle import ref_path as O
     sd = synthetic.make_state_dict(64, 128, seed=8)
-    m = mipNeRF360(randomized=True, num_samples=n, hidden_proposal=64, hidden_nerf=128, white_bkgd=wb, device=dev)
+    m = mipNeRF360(randomized=True, num_samples=n, hidden_proposal=64, hidden_nerf=128, white_bkgd=wb, device=dev, mlp_dtype=mlp_dtype)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     r = synthetic.make_rays(kind, B, seed=9)
     rays = dev_rays(r, dev)
@@ -1010,11 +1010,16 @@ def test_randomized_mode_with_replayed_uniforms_vs_oracle(dev, kind, B, n, wb):
     with torch.no_grad():
         o_t, o_w = O.prop_forward(O.rays_from_numpy(r), sdt, hp, t_rand=t_rand)
         o = O.nerf_forward(O.rays_from_numpy(r), o_t, o_w, sdt, hp, u_rand=u_rand)
-    close(t_hat, o_t, atol=2e-6, rtol=1e-5), close(w_hat, o_w, atol=5e-6)
+    close(t_hat, o_t, atol=2e-6, rtol=1e-5), close(w_hat, o_w, atol=5e-6 if mlp_dtype == "fp32" else 2e-5)
     close_render(out[0], out[1], out[2], o[0], o[1], o[2])
-    close(out[3], o[3], atol=1e-5, rtol=1e-4), close(out[4], o[4], atol=2e-5, rtol=1e-4)
+    close(out[3], o[3], atol=1e-5 if mlp_dtype == "fp32" else 1e-4, rtol=1e-4), close(out[4], o[4], atol=2e-5 if mlp_dtype == "fp32" else 1e-4, rtol=1e-4)
     # the jitter really happened: the same rays without it sample elsewhere
     assert float((t_hat.cpu() - O.prop_forward(O.rays_from_numpy(r), sdt, hp)[0]).abs().max()) > 1e-3 * float(o_t.max())
+
+
+def test_randomized_mode_with_replayed_uniforms_bf16x3(dev):
+    """The same in the bf16x3 mode (the jittered samples take the separate prologue kernels: t_rand rules out the one-launch form)."""
+    test_randomized_mode_with_replayed_uniforms_vs_oracle(dev, "lego", 40, 24, True, mlp_dtype="bf16x3")
 
 
 # =============================================================================== BASELINE.json full size
@@ -1715,13 +1720,15 @@ def test_training_bf16_is_forward_only_and_inplace_update_is_caught(golden, dev)
 
 
 # ------------------------------------------------------------------ many render_image chunks per launch
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("rays,chunks,super_rays", [(1000, 96, 480), (768, 128, 4096), (300, 7, 64)])
-def test_grouped_chunks_bit_identical_to_chunk_loop(dev, rays, chunks, super_rays):
+def test_grouped_chunks_bit_identical_to_chunk_loop(dev, rays, chunks, super_rays, mlp_dtype):
     """render_rays launches several of the reference's chunks (model.py:262-264) at once, each with its own contraction
     norm (m360_hyper_t.norm_group_rays).  Must equal the one-launch-per-chunk loop bit for bit, including a ragged last
-    chunk and a ragged last super-batch, and must differ from rendering everything as one chunk (the norm is real)."""
+    chunk and a ragged last super-batch, and must differ from rendering everything as one chunk (the norm is real).
+    In the bf16 modes too (their feature rows, first layers and NaN flags ride on the same grouping)."""
     sd = synthetic.make_state_dict(64, 128, seed=11)
-    m = build_model(sd, dev, 32, 64, 128, False)
+    m = _g19_model(sd, dev, 32, 64, 128, False, mlp_dtype)
     r = synthetic.make_rays("garden", rays, seed=12)
     r["origins"] = r["origins"] * 3.0            # push the means outside the unit ball so the norm matters
     m.super_batch_rays = super_rays
