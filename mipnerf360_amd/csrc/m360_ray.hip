@@ -493,7 +493,6 @@ __device__ __forceinline__ void ray_heads_fused_wave(const float *__restrict__ h
         }
     } else if (sizeof(T) == 2 && H == 4 && slots % 8 == 0) {
         const int per = slots / 8, lane8 = l & 7;
-#pragma unroll 4
         for (int n = l >> 3; n < N; n += kWave >> 3) {
             const float4 *p = reinterpret_cast<const float4 *>(head_part + ((s0 + n) * slots + lane8 * per) * 4);
             float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
