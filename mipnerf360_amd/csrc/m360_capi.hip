@@ -122,7 +122,7 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     L.t1 = take((size_t)B * (N + 1) * sizeof(float));
     L.t0 = take((size_t)B * (N + 1) * sizeof(float));
     L.what = take((size_t)B * N * sizeof(float));
-    // MLP input rows: fp32 [in_pad]; bf16 / bf16x3 modes: x6 rows of 6 in_pad bf16 (three bf16 terms per feature, see prop_stage)
+    // MLP input rows: fp32 [in_pad]; bf16: [hi | lo] pairs of in_pad bf16 each; bf16x3: x6 rows of 6 in_pad bf16 (see p_linear_first)
     L.feat = take(S * m->in_pad * (m->mlp_bf16 == 2 ? 6 * sizeof(unsigned short) : sizeof(float)));  // bf16: [hi | lo] pairs = 4 bytes per value too
     L.act_a = take(S * wmax * sizeof(float));
     L.act_b = take(S * wmax * sizeof(float));
@@ -171,13 +171,14 @@ static int p_linear(const m360_hyper_t *h, TileQueues *q, const float *x, long M
     ProfScope ps(h, st, M360_K_LINEAR, M, n_pad, k_pad);
     return ps.done(m360_linear_balanced(x, M, ldx, w, b, n_pad, k_pad, act, y, ldy, q->take(), st));
 }
-// First layer of the bf16 (mode 1) / bf16x3 (mode 2) MLP.  The encoder hands it "x6" rows - every feature as THREE bf16 terms,
-// all 24 bits - and the weights are packed the same way (m360_pack_linear_bf16x6), so one plain bf16 contraction of length
-// 6 in_pad forms the fp32 product up to 2^-24 terms; the output is the mode's own row format.  Why: the reference contracts a whole
+// First layer of the bf16 (mode 1) / bf16x3 (mode 2) MLP: it sees more bits of the features than the hidden layers do.  bf16x3: the
+// encoder hands it "x6" rows - every feature as THREE bf16 terms, all 24 bits - and the weights are packed the same way
+// (m360_pack_linear_bf16x6), so one plain bf16 contraction of length 6 in_pad forms the fp32 product up to 2^-24 terms, written out as
+// [hi | lo] pairs.  Why: the reference contracts a whole
 // chunk by its Frobenius norm (intern/parameterization.py:23-29), which squeezes a ray's samples into ~1e-2 of the unit ball, so a
 // net that resolves anything along a ray has first-layer gains of ~1e3-1e4 on DIFFERENCES of the sin / cos features: bf16
 // features (8 bits) put the density shells of fixture G19 at the wrong depth (PSNR off by 3-6 dB), two-term features (16 bits)
-// leave |d rgb| ~2e-4; with 24 bits both modes are back inside their tolerances.
+// leave the bf16x3 mode at |d rgb| ~2e-4, outside the fp32 tolerance.
 // The bf16 mode rounds the layer's output to bf16 anyway and gets by with 16 bits of each operand (PSNR within 0.013 dB on G19):
 // [hi | lo] features, [Wh | Wh | Wl] weights, the ring kernel's three-product loop with the plain bf16 epilogue - one 64-deep block per
 // tile, store-bound like round 3's first layer (0.30 instead of the x6 form's 0.53 ms for the NeRF net).
@@ -286,7 +287,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     }
     const int hp = m->hp_pad;
     if (ext_norm) {  // the caller supplies the (all-reduced) contraction norm; the layers below are shared
-        M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(m->mlp_bf16), 0, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));  /* row format: fp32, or x6 for both bf16 modes */
+        M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(m->mlp_bf16), 0, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));  /* row format of the mode */
     }
     if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers; mode 2 = bf16x3: [hi | lo] pairs)
         const int mode = m->mlp_bf16;
