@@ -677,7 +677,7 @@ def test_g21_training_gradients_on_structured_weights(golden, dev, kind):
     model.zero_grad()
     loss_prop.backward()
     lp64, lp32 = float(g[kind + "_loss_prop64"]), float(g[kind + "_loss_prop"])    # the loss itself is ill-conditioned: 0.1-0.2 % fp32 vs fp64
-    assert abs(float(loss_prop) - lp64) <= 4.0 * max(abs(lp32 - lp64), 1e-3 * abs(lp64)), (float(loss_prop), lp32, lp64)
+    assert abs(float(loss_prop.detach()) - lp64) <= 4.0 * max(abs(lp32 - lp64), 1e-3 * abs(lp64)), (float(loss_prop.detach()), lp32, lp64)
     worst = 0.0
     for name, p in model.named_parameters():
         if name.startswith("prop_net"):
