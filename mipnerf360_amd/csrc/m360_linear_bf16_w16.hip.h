@@ -25,7 +25,7 @@
 //   * weight rows permuted so that a lane's accumulators of weight blocks 2p, 2p+1 are 8 CONSECUTIVE output columns and the four
 //     lanes of a row cover 32 consecutive columns: MFMA row i of block jb is column 32 (jb >> 1) + 8 (i >> 2) + 4 (jb & 1) + (i & 3)
 //     of the wave's 128.  Epilogue per (activation block, p): 4 packed bias adds, 4 v_cvt_pk_bf16_f32, ReLU as v_pk_max_i16 on the
-//     packed pairs -> one packed 16-byte row piece; lanes l15 = 2j, 2j + 1 then swap one piece each (v_cndmask_b32_dpp) so that a
+//     packed pairs -> one packed 16-byte row piece; lanes l15 = 2j, 2j + 1 then swap one piece each (v_cmp + v_cndmask_b32_dpp) so that a
 //     store instruction writes 8 rows x 128 B = whole lines (142 GB/s per CU against 38 for 16 rows x 64 B); no LDS transposition;
 //   * the epilogue is exposed (vector work is not hidden behind the same wave's MFMAs): ~5.5 k cycles of conversion per tile with
 //     the 32 stores issued as the pieces are packed.  vmcnt retires in order and a store takes ~2 k cycles to complete, so a
@@ -292,6 +292,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
 
     // this lane's 16 bytes inside a 16-row x 64-column piece, first of its two stores (row 2 (l15 >> 1); the second: one row further)
     const unsigned y_voff = (unsigned)(2 * (l15 >> 1) * ldy + 32 * (l15 & 1) + 8 * g4) * 2u;
+    const unsigned lane_odd = (unsigned)(l15 & 1);  // which of a pair of lanes keeps which piece
     bool have_prev = false, odd_tile = false;
     long m0;
     int n0;
@@ -393,8 +394,11 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
             // count, shape and TA occupancy but their lines stay in the XCD's L2: what does the HBM side of the output cost the K loop?)
             const __bf16 *yt = Y + (((ABL & 2048) ? (long)blockIdx.x * BM : m0) + wm * 128) * ldy + n0 + wn * 128;  // wave-uniform corner of the wave tile
             f32x4 hacc[8];  // HEADS: the head sums of this lane's rows (one per activation block) over the pieces done so far
+            const unsigned row_step = 16u * (unsigned)ldy;  // elements per activation block
 #pragma unroll
             for (int P = 0; P < 2; ++P) {  // column pieces p = 2P, 2P + 1: 64 output columns = one 128-byte line per row
+                const __bf16 *rowp = yt;   // rows 16 i .. of the wave tile, i = 0
+                asm volatile("" : "+s"(rowp));
                 f32x4 bb[4];  // bias of the lane's columns 32 p + 8 g4 + 0..7, p = 2P (bb[0], bb[1]) and 2P + 1 (bb[2], bb[3])
                 const unsigned ba = bias_addr + 4u * (n0 + 64 * P);
                 asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\t"
@@ -449,42 +453,57 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                     // (16 rows x 64 B per instruction) runs at 38 GB/s per CU, whole lines (8 rows x 128 B) at 142
                     // (tools/store_rate_probe.hip).  Lanes l15 = 2j, 2j + 1 swap one piece each through DPP: s1 = row 2j
                     // (even lane: its own first piece, odd lane: the even lane's second piece), s2 = row 2j + 1.
+                    // Round 4: one wave per SIMD issues ONE instruction of any kind per 4.3-5 cycles (tools/valu_issue_probe.hip,
+                    // profiles/r04/valu_issue_probe.jsonl), so the epilogue is priced by its instruction count - and a v_cndmask_b32
+                    // whose VCC was NOT written by the vector instruction just before it holds VCC's read path for ~19 cycles (64
+                    // selects in a row: 19.4 cycles each, DPP or not, scalar write of VCC before each or not; 4.8 behind a v_cmp; 5.0
+                    // on an SGPR pair, which DPP cannot encode): round 3's 8 selects on two masks moved into VCC cost a block of 48
+                    // vector instructions ~65 of its 336 cycles.  Hence a v_cmp on the lane's parity in front of EVERY select (8 more
+                    // instructions, 34 cycles).  Measured and rejected (profiles/r04/bf16_w16_epilogue_*_REJECTED.jsonl): the
+                    // exchange as 4 copies + 8 v_mov_b32_dpp with bank masks (lanes r / r + 8 as partners: no VCC, packing 5.4 k ->
+                    // 4.4 k cycles per tile, but stores whose lanes of a quad lie in four lines instead of two: 0.5 k -> 4.0 k), and
+                    // the selects issued one per pair of AccVGPR reads of the NEXT block (each in its own statement with its own
+                    // s_mov_b64 vcc: 26 more scalar instructions per block than it saves in waiting).
+                    // s_nop 0 + the first v_cmp: VALU write -> DPP read of the same register needs 2 wait states.
                     // s_nop after the stores: a store of more than 8 bytes still reads its data registers in the cycle after
                     // issue, and the next instruction here (an AccVGPR read, invisible to the hazard recogniser like the
-                    // store) may write them.  (s_not_b64 for the second mask would write SCC, which the compiler may hold a carry in.)
-#define W16_SWAP_STORE(A0, A1, ROW)                                                                                             \
+                    // store) may write them.
+#define W16_SEL_(D, OTHER, OWN, CMP)                                                                                             \
+    "v_cmp_" CMP "_u32_e32 vcc, 0, %16\n\tv_cndmask_b32_dpp " D ", " OTHER ", " OWN ", vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define W16_SWAP_STORE(A0, A1, ROW, IMM)                                                                                        \
     do {                                                                                                                        \
         u32x4 s1, s2;                                                                                                           \
-        asm volatile("s_nop 1\n\ts_mov_b64 vcc, %16\n\ts_nop 1\n\t"                                                           \
-                     "v_cndmask_b32_dpp %0, %12, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
-                     "v_cndmask_b32_dpp %1, %13, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
-                     "v_cndmask_b32_dpp %2, %14, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                   \
-                     "v_cndmask_b32_dpp %3, %15, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                   \
-                     "s_mov_b64 vcc, %17\n\ts_nop 1\n\t"                                                                       \
-                     "v_cndmask_b32_dpp %4, %8, %12, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
-                     "v_cndmask_b32_dpp %5, %9, %13, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                    \
-                     "v_cndmask_b32_dpp %6, %10, %14, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                   \
-                     "v_cndmask_b32_dpp %7, %11, %15, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"                        \
+        asm volatile("s_nop 0\n\t"                                                                                             \
+                     W16_SEL_("%0", "%12", "%8", "eq") W16_SEL_("%1", "%13", "%9", "eq")                                         \
+                     W16_SEL_("%2", "%14", "%10", "eq") W16_SEL_("%3", "%15", "%11", "eq")                                       \
+                     W16_SEL_("%4", "%8", "%12", "ne") W16_SEL_("%5", "%9", "%13", "ne")                                         \
+                     W16_SEL_("%6", "%10", "%14", "ne") W16_SEL_("%7", "%11", "%15", "ne")                                       \
                      : "=&v"(s1[0]), "=&v"(s1[1]), "=&v"(s1[2]), "=&v"(s1[3]), "=&v"(s2[0]), "=&v"(s2[1]), "=&v"(s2[2]), "=&v"(s2[3]) \
-                     : "v"(A0[0]), "v"(A0[1]), "v"(A0[2]), "v"(A0[3]), "v"(A1[0]), "v"(A1[1]), "v"(A1[2]), "v"(A1[3]),          \
-                       "s"(0x5555555555555555ull), "s"(0xAAAAAAAAAAAAAAAAull)                                                    \
+                     : "v"(A0[0]), "v"(A0[1]), "v"(A0[2]), "v"(A0[3]), "v"(A1[0]), "v"(A1[1]), "v"(A1[2]), "v"(A1[3]), "v"(lane_odd) \
                      : "vcc");                                                                                                  \
         /* non-temporal: the tile's 128 KiB of output lines otherwise displace the activation tile the 4 column tiles of an XCD share  \
            from its L2 (1263-1270 against 1241-1242 TF, alternating launches on one box; ABL & 128: the plain stores) */              \
         if ((ABL & 16) == 0 && (ABL & 128) == 0)                                                                                \
-            asm volatile("global_store_dwordx4 %0, %2, %4 nt\n\tglobal_store_dwordx4 %1, %3, %4 nt\n\ts_nop 1"                 \
+            asm volatile("global_store_dwordx4 %0, %2, %4 offset:" IMM " nt\n\tglobal_store_dwordx4 %1, %3, %4 offset:" IMM " nt\n\ts_nop 1" \
                          ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(s1), "v"(s2), "s"(ROW) : "memory");                \
         else if ((ABL & 16) == 0)                                                                                               \
-            asm volatile("global_store_dwordx4 %0, %2, %4\n\tglobal_store_dwordx4 %1, %3, %4\n\ts_nop 1"                       \
+            asm volatile("global_store_dwordx4 %0, %2, %4 offset:" IMM "\n\tglobal_store_dwordx4 %1, %3, %4 offset:" IMM "\n\ts_nop 1" \
                          ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(s1), "v"(s2), "s"(ROW) : "memory");                \
         else asm volatile("" ::"v"(s1), "v"(s2));                                                                               \
     } while (0)
                     if (STORE_Y) {
-                        const __bf16 *row = yt + (long)(16 * i) * ldy + 64 * P;
-                        W16_SWAP_STORE(ab[0], ab[1], row);
-                        if (SPLIT) W16_SWAP_STORE(lo[0], lo[1], row + Np);  // the second terms: columns [Np, 2 Np)
+                        // rows 16 i .. of the wave tile: a running pointer (one 64-bit scalar add per block - left to the compiler,
+                        // every block's address was 8-10 scalar instructions from the tile's corner); column half P is the
+                        // stores' immediate offset
+                        if (P == 0) W16_SWAP_STORE(ab[0], ab[1], rowp, "0"); else W16_SWAP_STORE(ab[0], ab[1], rowp, "128");
+                        if (SPLIT) {  // the second terms: columns [Np, 2 Np)
+                            if (P == 0) W16_SWAP_STORE(lo[0], lo[1], rowp + Np, "0"); else W16_SWAP_STORE(lo[0], lo[1], rowp + Np, "128");
+                        }
+                        rowp += row_step;
+                        asm volatile("" : "+s"(rowp));
                     }
 #undef W16_SWAP_STORE
+#undef W16_SEL_
                     if (HEADS) {  // D[head][row] += over each piece's 32 columns: hi and lo head terms (X3: and the lo activations)
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {

@@ -80,6 +80,7 @@ for s in $steps; do
              for v in 136 100; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --k 384 --rounds 5 --json $out/bf16_w16_lds_epilogue.jsonl > $out/linear_bf16_ldsepi_k384_$v.log 2>&1; tail -1 $out/linear_bf16_ldsepi_k384_$v.log | cut -c1-300; done ;;
     r4nan)   timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "g18 or nan or bf16 or g19 or g20 or finish" > $out/pytest_r4nan.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r4nan.log; grep -a "^FAILED\|passed\|failed" $out/pytest_r4nan.log | tail -12 ;;
     valu)    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/valu_issue_probe.hip -o /tmp/valu_issue_probe.bin 2> $out/valu_issue_probe.err && timeout 300 /tmp/valu_issue_probe.bin > $out/valu_issue_probe.jsonl 2>> $out/valu_issue_probe.err; cut -c1-260 $out/valu_issue_probe.jsonl ;;
+    epi)     for v in 100 116 100; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v $( [ $v = 116 ] && echo --no-check ) --rounds 5 --json $out/bf16_w16_epilogue.jsonl > $out/linear_bf16_epi_$v.log 2>&1; tail -2 $out/linear_bf16_epi_$v.log | cut -c1-400; done ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
