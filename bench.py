@@ -111,6 +111,9 @@ def parse_args(argv=None):
                          "then says so in config.workload")
     ap.add_argument("--no-named", action="store_true",
                     help="c2 / fp32 / 1 GPU only: skip the `named_workloads` block (the other single-GPU configs, a few steps each)")
+    ap.add_argument("--plain-rows", action="store_true",
+                    help="(diagnostics, bf16 modes) m360_set_paired_rows(0): plain instead of paired rows between the layers - same bits; "
+                         "the line then carries config.plain_rows")
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the child command as JSON and exit")
     return ap.parse_args(argv)
@@ -595,6 +598,8 @@ def worker(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    if args.plain_rows:
+        _lib.lib().m360_set_paired_rows(0)
     ndev = torch.cuda.device_count()
     # one GPU per rank.  With fewer devices than ranks the ranks wrap around: RCCL then refuses the duplicate device
     # with its own error (the gloo diagnostics backend lets ranks share a GPU).
@@ -702,6 +707,8 @@ def worker(args):
                                          (f", RCCL all-gather of the [{n_rays},5] pixel block per step" if world > 1 else ""),
                           "flops_per_ray": FLOPS_PER_SAMPLE * samples,
                           "whole_path_tflops": round(value * FLOPS_PER_SAMPLE * samples / 1e12, 2)}
+        if args.plain_rows:
+            line["config"]["plain_rows"] = True
         if per_rank:
             line["per_rank"] = per_rank
 

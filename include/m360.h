@@ -40,6 +40,20 @@ enum {
 };
 
 enum { M360_ACT_NONE = 0, M360_ACT_RELU = 1, M360_ACT_SIGMOID = 2, M360_ACT_RELU_MASK = 3 /* internal: m360_linear_dgrad */ };
+/* "Paired rows": the layout of bf16 / bf16x3 hidden activations BETWEEN two layers that both run on the one-wave ring kernel
+ * (model.py:44-50,132-146: the hidden activations never leave the MLP).  OR these flags into `act` of m360_linear_bf16 /
+ * m360_linear_bf16x3 (both), m360_linear_bf16_split / m360_linear_bf16x3_bf16out (OUT: first layers), m360_linear_heads_bf16 /
+ * m360_linear_heads_bf16x3 (IN: last layers, store_y = 0).  Inside every block of 2 rows x 64 columns of the full 256-row tiles the
+ * four 64-byte quarters are transposed: the 128 bytes at row 2R hold [row 2R, columns 0-31 | row 2R + 1, columns 0-31], the 128
+ * bytes at row 2R + 1 the columns 32-63 of both rows ([hi | lo] rows: each half the same way; same buffer, same strides).  The
+ * kernel's epilogue holds exactly these lines in its lanes, so its stores need no exchange between lanes (16 of 65 instructions
+ * per 16 x 64 block); its loader reads either layout at the same rate.  Rows beyond the last full 256-row tile stay plain.  A call
+ * whose shape is not the ring kernel's (m360_linear_bf16_rows_pairable) fails with M360_ERR_INVALID_ARGUMENT; OUT needs ReLU. */
+#define M360_ROWS_PAIRED_IN 0x100
+#define M360_ROWS_PAIRED_OUT 0x200
+#define M360_ROWS_PAIRED_MASK 0x300
+enum { M360_PAIRABLE_LINEAR = 0 /* m360_linear_bf16 */, M360_PAIRABLE_X3 = 1 /* m360_linear_bf16x3 */, M360_PAIRABLE_SPLIT = 2 /* m360_linear_bf16_split */,
+       M360_PAIRABLE_X3_BF16OUT = 3 /* m360_linear_bf16x3_bf16out */, M360_PAIRABLE_HEADS = 4 /* m360_linear_heads_bf16 */, M360_PAIRABLE_HEADS_X3 = 5 /* m360_linear_heads_bf16x3 */ };
 
 int m360_version(void);
 const char *m360_last_error(void);
@@ -214,6 +228,11 @@ int m360_linear_bf16x3(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M,
  * 0.013 dB of the reference's): two-term features [hi | lo] and weights [Wh | Wh | Wl] as for m360_linear_bf16x3, ONE bf16 term out -
  * m360_linear_bf16x3_bf16out (bias + {none, ReLU}; the ring kernel's three-product loop with the plain bf16 epilogue: a 64-deep layer
  * stays one block per tile and store-bound, 0.30 instead of the 0.53 ms of the x6 form at 1024 x 58 on 524 288 rows). */
+/* 1 when the call `kind` (M360_PAIRABLE_*) with these pads runs its full tiles on the one-wave ring kernel, i.e. takes paired rows */
+int m360_linear_bf16_rows_pairable(int kind, int n_pad, int k_pad);
+/* m360_forward / m360_prop_forward / m360_nerf_forward (bf16 modes) use paired rows between the layers of an MLP whose layers are all
+ * pairable; 0 switches that off process-wide (diagnostics: A/B on one box - the outputs are the same bits), returns the old setting */
+int m360_set_paired_rows(int on);
 int m360_linear_bf16x3_bf16out(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M, int ldx, const void *w_packed3_bf16,
                                const float *b_packed, int n_pad, int k_pad, int act, void *y_bf16 /*[M, ldy >= n_pad]*/, int ldy,
                                m360_stream_t stream);

@@ -183,14 +183,27 @@ static int p_linear(const m360_hyper_t *h, TileQueues *q, const float *x, long M
 // [hi | lo] features, [Wh | Wh | Wl] weights, the ring kernel's three-product loop with the plain bf16 epilogue - one 64-deep block per
 // tile, store-bound like round 3's first layer (0.30 instead of the x6 form's 0.53 ms for the NeRF net).
 static inline int first_row_format(int mode) { return mode == 2 ? 3 : (mode == 1 ? 2 : 0); }  // encoder row format of the MLP input
-static int p_linear_first(const m360_hyper_t *h, int mode, const void *feat, long M, const void *w0, const float *b, int n_pad, int in_pad, void *y, m360_stream_t st) {
-    ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, (mode == 2 ? 6 : 3) * in_pad);
-    if (mode == 2) return ps.done(m360_linear_bf16_split(feat, M, 6 * in_pad, w0, b, n_pad, 6 * in_pad, M360_ACT_RELU, y, 2 * n_pad, st));
-    return ps.done(m360_linear_bf16x3_bf16out(feat, M, 2 * in_pad, w0, b, n_pad, in_pad, M360_ACT_RELU, y, n_pad, st));
+// Paired rows (m360.h) between the layers of one bf16 / bf16x3 MLP: only when EVERY layer of it runs its full tiles on the one-wave ring
+// kernel - first layer out, hidden layers in and out, fused-heads last layer in (rendering forward: the tape-keeping one keeps plain rows)
+static int g_paired_rows = 1;  // m360_set_paired_rows: A/B of the two layouts (same bits either way)
+extern "C" int m360_set_paired_rows(int on) { const int was = g_paired_rows; g_paired_rows = on ? 1 : 0; return was; }
+static bool mlp_rows_pairable(int mode, int width, int in_pad) {
+    if (!g_paired_rows) return false;
+    if (mode == 2) return m360_linear_bf16_rows_pairable(M360_PAIRABLE_SPLIT, width, 6 * in_pad) && m360_linear_bf16_rows_pairable(M360_PAIRABLE_X3, width, width) && m360_linear_bf16_rows_pairable(M360_PAIRABLE_HEADS_X3, width, width);
+    return m360_linear_bf16_rows_pairable(M360_PAIRABLE_X3_BF16OUT, width, in_pad) && m360_linear_bf16_rows_pairable(M360_PAIRABLE_LINEAR, width, width) && m360_linear_bf16_rows_pairable(M360_PAIRABLE_HEADS, width, width);
 }
+
+static int p_linear_first(const m360_hyper_t *h, int mode, const void *feat, long M, const void *w0, const float *b, int n_pad, int in_pad, void *y, int pair, m360_stream_t st) {
+    ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, (mode == 2 ? 6 : 3) * in_pad);
+    const int act = M360_ACT_RELU | (pair ? M360_ROWS_PAIRED_OUT : 0);
+    if (mode == 2) return ps.done(m360_linear_bf16_split(feat, M, 6 * in_pad, w0, b, n_pad, 6 * in_pad, act, y, 2 * n_pad, st));
+    return ps.done(m360_linear_bf16x3_bf16out(feat, M, 2 * in_pad, w0, b, n_pad, in_pad, act, y, n_pad, st));
+}
+
 // mode 1: bf16 rows of k_pad / n_pad columns; mode 2 (bf16x3): [hi | lo] rows of 2 k_pad / 2 n_pad columns
-static int p_linear_bf16(const m360_hyper_t *h, int mode, const void *x, long M, const void *w, const float *b, int n_pad, int k_pad, int act, void *y, m360_stream_t st) {
+static int p_linear_bf16(const m360_hyper_t *h, int mode, const void *x, long M, const void *w, const float *b, int n_pad, int k_pad, int act, void *y, int pair, m360_stream_t st) {
     ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, mode == 2 ? 3 * k_pad : k_pad);
+    if (pair) act |= M360_ROWS_PAIRED_IN | M360_ROWS_PAIRED_OUT;
     if (mode == 2) return ps.done(m360_linear_bf16x3(x, M, 2 * k_pad, w, b, n_pad, k_pad, act, y, 2 * n_pad, st));
     return ps.done(m360_linear_bf16(x, M, k_pad, w, b, n_pad, k_pad, act, y, n_pad, st));
 }
@@ -201,10 +214,11 @@ static int p_encode(const m360_hyper_t *h, const float *t, const m360_rays_t *r,
     return ps.done(encode_stage(t, r->origins, r->directions, r->radii, vdenc, vd_ch, B, N, feat, ld, row_format, group, ext_norm, prepared_parts, flags, ws, wsb, st));
 }
 // last hidden layer + heads fused (fp32 or bf16): partial head sums to `part`, y written only when store_y
-static int p_linear_heads(const m360_hyper_t *h, int bf16, const void *x, long M, int ldx, const void *w, const float *b, int n_pad, int k_pad, void *y, int ldy, int store_y, const float *head_w, int heads, float *part, m360_stream_t st) {
+static int p_linear_heads(const m360_hyper_t *h, int bf16, const void *x, long M, int ldx, const void *w, const float *b, int n_pad, int k_pad, void *y, int ldy, int store_y, const float *head_w, int heads, float *part, m360_stream_t st, int pair = 0) {
     ProfScope ps(h, st, M360_K_LINEAR_HEADS, M, n_pad, bf16 ? -k_pad : k_pad);
-    if (bf16 == 2) return ps.done(m360_linear_heads_bf16x3(x, M, ldx, w, b, n_pad, k_pad, M360_ACT_SIGMOID, y, ldy, store_y, head_w, heads, part, st));
-    if (bf16) return ps.done(m360_linear_heads_bf16(x, M, ldx, w, b, n_pad, k_pad, M360_ACT_SIGMOID, y, ldy, store_y, head_w, heads, part, st));
+    const int sig = M360_ACT_SIGMOID | (pair ? M360_ROWS_PAIRED_IN : 0);
+    if (bf16 == 2) return ps.done(m360_linear_heads_bf16x3(x, M, ldx, w, b, n_pad, k_pad, sig, y, ldy, store_y, head_w, heads, part, st));
+    if (bf16) return ps.done(m360_linear_heads_bf16(x, M, ldx, w, b, n_pad, k_pad, sig, y, ldy, store_y, head_w, heads, part, st));
     return ps.done(m360_linear_heads(static_cast<const float *>(x), M, ldx, static_cast<const float *>(w), b, n_pad, k_pad, M360_ACT_SIGMOID, static_cast<float *>(y), ldy, store_y, head_w, heads, part, st));
 }
 static int p_prop_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, float *w_hat, float *t_new, m360_stream_t st, const unsigned char *flags = nullptr) {
@@ -292,12 +306,13 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers; mode 2 = bf16x3: [hi | lo] pairs)
         const int mode = m->mlp_bf16;
         if (!ext_norm) M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(mode), h->norm_group_rays, nullptr, parts, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(p_linear_first(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, a, st));
-        M360_TRY(p_linear_bf16(h, mode, a, S, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, st));
-        M360_TRY(p_linear_bf16(h, mode, b, S, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, st));
+        const int pair = mlp_rows_pairable(mode, hp, m->in_pad) ? 1 : 0;  // paired rows between the layers (m360.h)
+        M360_TRY(p_linear_first(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, a, pair, st));
+        M360_TRY(p_linear_bf16(h, mode, a, S, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, pair, st));
+        M360_TRY(p_linear_bf16(h, mode, b, S, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, pair, st));
         // last hidden layer + head on the matrix pipe (full 256-row tiles; tail rows through y): ld of y = hp (bf16) / 2 hp ([hi | lo])
         const int ldl = mode == 2 ? 2 * hp : hp;
-        M360_TRY(p_linear_heads(h, mode, a, S, ldl, m->prop_w[3], m->prop_b[3], hp, hp, b, ldl, 0, m->prop_head_w, 1, hpart, st));
+        M360_TRY(p_linear_heads(h, mode, a, S, ldl, m->prop_w[3], m->prop_b[3], hp, hp, b, ldl, 0, m->prop_head_w, 1, hpart, st, pair));
         return p_prop_finish_fused(h, b, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hp, mode), m360_linear_heads_slots_bf16(hp, hp, mode, 0), m->prop_head_w, m->prop_head_b, hp, t_hat, r->directions, B, N, w_hat, t_new, st, flags);
     }
     if (!ext_norm) M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, 0, h->norm_group_rays, nullptr, parts, nullptr, ws + L.norm, m360_contract_workspace_bytes(), st));
@@ -344,13 +359,14 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     } else if (m->mlp_bf16) {
         const int mode = m->mlp_bf16;
         M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(mode), ext_norm ? 0 : h->norm_group_rays, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
-        M360_TRY(p_linear_first(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, a, st));
+        const int pair = mlp_rows_pairable(mode, hn, m->in_pad) ? 1 : 0;  // paired rows between the layers (m360.h)
+        M360_TRY(p_linear_first(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, a, pair, st));
         for (int layer = 1; layer < 7; ++layer) {
-            M360_TRY(p_linear_bf16(h, mode, src, S, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, st));
+            M360_TRY(p_linear_bf16(h, mode, src, S, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, pair, st));
             float *tmp = src; src = dst; dst = tmp;
         }
         const int ldl = mode == 2 ? 2 * hn : hn;
-        M360_TRY(p_linear_heads(h, mode, src, S, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, ldl, 0, m->nerf_head_w, 4, hpart, st));
+        M360_TRY(p_linear_heads(h, mode, src, S, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, ldl, 0, m->nerf_head_w, 4, hpart, st, pair));
         M360_TRY(p_nerf_finish_fused(h, dst, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hn, mode), m360_linear_heads_slots_bf16(hn, hn, mode, 0), m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st, flags));
     } else {
     M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm ? 0 : h->norm_group_rays, ext_norm, 0, nullptr, ws + L.norm, m360_contract_workspace_bytes(), st));

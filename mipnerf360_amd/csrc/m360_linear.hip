@@ -423,6 +423,23 @@ static bool heads_on_ring(int k_pad, int x3, int store_y) {
     return M360_W16_HEADS_ON && !store_y && (x3 ? (k_pad % w16::BKS == 0 && k_pad >= 2 * w16::BKS) : (k_pad % (2 * w16::BKS) == 0 && k_pad >= 4 * w16::BKS));
 }
 
+// paired rows (m360.h: M360_ROWS_PAIRED_IN / _OUT): the layout only the one-wave ring kernel reads and writes - does the call `kind`
+// put the full tiles of an n_pad-wide layer with this contraction on it?  (The predicates of the dispatchers below, in one place.)
+int m360_linear_bf16_rows_pairable(int kind, int n_pad, int k_pad) {
+    if (n_pad < w16::BN || n_pad % w16::BN != 0 || k_pad < w16::BKS || k_pad % w16::BKS != 0) return 0;
+    switch (kind) {
+        case M360_PAIRABLE_LINEAR:
+            if (k_pad == w16::BKS) return M360_W16_K64 && n_pad <= w16::kMaxBias;
+            return n_pad <= pp16::kMaxBias && k_pad % (2 * w16::BKS) == 0 && k_pad >= M360_W16_MIN_K && k_pad >= 2 * pp16::BK;
+        case M360_PAIRABLE_X3:
+        case M360_PAIRABLE_X3_BF16OUT: return M360_W16_X3 && n_pad <= pp16::kMaxBias;
+        case M360_PAIRABLE_SPLIT: return n_pad <= w16::kMaxBias && k_pad % (2 * w16::BKS) == 0 && k_pad >= M360_W16_MIN_K;
+        case M360_PAIRABLE_HEADS: return n_pad <= pp16::kHeadMaxN && heads_on_ring(k_pad, 0, 0);
+        case M360_PAIRABLE_HEADS_X3: return n_pad <= pp16::kHeadMaxN && heads_on_ring(k_pad, 1, 0);
+        default: return 0;
+    }
+}
+
 int m360_linear_heads_slots_bf16(int n_pad, int k_pad, int bf16, int store_y) {  // slots the call with these arguments writes
     if (n_pad < pp16::BN) return 0;
     return (heads_on_ring(k_pad, bf16 == 2, store_y) ? 2 : 8) * (n_pad / pp16::BN);
@@ -472,7 +489,12 @@ static int linear_heads_bf16_any(const void *x, long M, int ldx, const void *w_p
                                  float *head_part, m360_stream_t stream, int x3) {
     const char *who = x3 ? "m360_linear_heads_bf16x3" : "m360_linear_heads_bf16";
     if (heads != 1 && heads != 4) return fail(M360_ERR_INVALID_ARGUMENT, "%s: heads=%d (1 or 4)", who, heads);
+    const int layout = act & M360_ROWS_PAIRED_MASK;  // paired INPUT rows (m360.h): where the one-wave ring kernel forms the heads
+    act &= ~M360_ROWS_PAIRED_MASK;
     if (act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "%s: the last hidden layer is a sigmoid layer, act=%d", who, act);
+    if (layout && (layout != M360_ROWS_PAIRED_IN || store_y || !m360_linear_bf16_rows_pairable(x3 ? M360_PAIRABLE_HEADS_X3 : M360_PAIRABLE_HEADS, n_pad, k_pad)))
+        return fail(M360_ERR_INVALID_ARGUMENT, "%s: paired rows: input only, store_y = 0, a shape of the one-wave ring kernel (n_pad=%d k_pad=%d)", who, n_pad, k_pad);
+    const int xin = layout ? 1 : 0;
     if (!x || !w_packed || !b_packed || !y || !head_w || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "%s: null pointer or negative M", who);
     const int xm = x3 ? 2 : 1;  // row-length multiplier of the [hi | lo] layout
     const long M_fused = m360_linear_heads_fused_rows(M, n_pad, 1);
@@ -494,7 +516,7 @@ static int linear_heads_bf16_any(const void *x, long M, int ldx, const void *w_p
         __bf16 *yb = static_cast<__bf16 *>(y);
         const int kk = x3 ? 3 * k_pad : k_pad, tn = n_pad / pp16::BN;
 #define M360_PP_HEADS(X3M, H, SY) hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_SIGMOID, false, X3M, H, SY>), grid, block, 0, st, xb, M_fused, ldx, wb, b_packed, n_pad, kk, yb, ldy, tn, (int)nt, head_w, head_part)
-#define M360_W16_HEADS(X3B, H) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 0, false, X3B, false, H>), grid, dim3(w16::kThreads), 0, st, xb, M_fused, ldx, wb, b_packed, n_pad, kk, yb, ldy, tn, (int)nt, head_w, head_part)
+#define M360_W16_HEADS(X3B, H) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 0, false, X3B, false, H>), grid, dim3(w16::kThreads), 0, st, xb, M_fused, ldx, wb, b_packed, n_pad, kk, yb, ldy, tn, (int)nt, head_w, head_part, xin)
         // the rendering forward (the layer's own output is not kept): the one-wave ring kernel - its exposed sigmoid epilogue costs
         // less than its K loop wins (0.85 against 1.08-1.12 ms for the 1024^2 NeRF layer)
         const bool ring = heads_on_ring(k_pad, x3, store_y);
@@ -621,11 +643,18 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
     if (n_pad < 1 || k_pad < pbf16::BK || k_pad % pbf16::BK != 0 || ldx < k_pad || ldy < n_pad || ldx % 8 != 0 || ldy % 8 != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad, ldy=%d >= n_pad=%d, both multiples of 8", k_pad, pbf16::BK, ldx, ldy, n_pad);
     if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: pointers must be 16-byte aligned");
+    const int layout = act & M360_ROWS_PAIRED_MASK;  // paired rows in / out (m360.h): the ring kernel's shapes only
+    act &= ~M360_ROWS_PAIRED_MASK;
     if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: unknown activation %d", act);
+    if (layout && !m360_linear_bf16_rows_pairable(M360_PAIRABLE_LINEAR, n_pad, k_pad))
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: paired rows with n_pad=%d k_pad=%d: not a shape of the one-wave ring kernel (m360_linear_bf16_rows_pairable)", n_pad, k_pad);
+    if ((layout & M360_ROWS_PAIRED_OUT) && act != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: paired output rows: ReLU layers only (act=%d)", act);
+    if ((layout & M360_ROWS_PAIRED_IN) && k_pad == w16::BKS) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: paired input rows: not for the 64-deep first layers (their input is the encoder's)");
     if (M == 0) return M360_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *xb = static_cast<const __bf16 *>(x), *wb = static_cast<const __bf16 *>(w_packed);
     __bf16 *yb = static_cast<__bf16 *>(y);
+    const int xin = (layout & M360_ROWS_PAIRED_IN) ? 1 : 0;
     const long M_full = (n_pad % pbf16::BN == 0) ? (M / pbf16::BM) * pbf16::BM : 0;
     if (M_full > 0) {
         const int cus = cu_count();
@@ -638,9 +667,10 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
         const bool w16_one = M360_W16_K64 && act != M360_ACT_SIGMOID && k_pad == w16::BKS && n_pad <= w16::kMaxBias;  // the 64-deep first layers
         if (w16_ok || w16_one) {
             dim3 grid((unsigned)(nt < cus ? nt : cus)), block(w16::kThreads);
-#define M360_W16(A, ONE) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<A, 0, false, false, ONE>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt)
-            if (w16_one) { if (act == M360_ACT_RELU) M360_W16(M360_ACT_RELU, true); else M360_W16(M360_ACT_NONE, true); }
-            else { if (act == M360_ACT_RELU) M360_W16(M360_ACT_RELU, false); else M360_W16(M360_ACT_NONE, false); }
+#define M360_W16(A, ONE, PR) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<A, 0, false, false, ONE, 0, false, false, PR>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, xin)
+            if (layout & M360_ROWS_PAIRED_OUT) { if (w16_one) M360_W16(M360_ACT_RELU, true, true); else M360_W16(M360_ACT_RELU, false, true); }
+            else if (w16_one) { if (act == M360_ACT_RELU) M360_W16(M360_ACT_RELU, true, false); else M360_W16(M360_ACT_NONE, true, false); }
+            else { if (act == M360_ACT_RELU) M360_W16(M360_ACT_RELU, false, false); else M360_W16(M360_ACT_NONE, false, false); }
 #undef M360_W16
         } else if (pp_ok) {  // 8-wave ping-pong kernel, persistent
             dim3 grid((unsigned)(nt < cus ? nt : cus)), block(pp16::kThreads);
@@ -689,7 +719,11 @@ int m360_linear_bf16_split(const void *x, long M, int ldx, const void *w_packed,
     if (n_pad < 1 || k_pad < pbf16::BK || k_pad % pbf16::BK != 0 || ldx < k_pad || ldy < 2 * n_pad || ldx % 8 != 0 || ldy % 8 != 0 || n_pad % 8 != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad, ldy=%d >= 2 n_pad=%d, all multiples of 8", k_pad, pbf16::BK, ldx, ldy, 2 * n_pad);
     if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: pointers must be 16-byte aligned");
+    const int layout = act & M360_ROWS_PAIRED_MASK;  // paired OUTPUT rows (the input rows are the encoder's)
+    act &= ~M360_ROWS_PAIRED_MASK;
     if (act != M360_ACT_NONE && act != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: activation %d (none or ReLU)", act);
+    if (layout && (layout != M360_ROWS_PAIRED_OUT || act != M360_ACT_RELU || !m360_linear_bf16_rows_pairable(M360_PAIRABLE_SPLIT, n_pad, k_pad)))
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: paired rows: output only, ReLU, a shape of the one-wave ring kernel (n_pad=%d k_pad=%d)", n_pad, k_pad);
     if (M == 0) return M360_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *xb = static_cast<const __bf16 *>(x), *wb = static_cast<const __bf16 *>(w_packed);
@@ -701,7 +735,8 @@ int m360_linear_bf16_split(const void *x, long M, int ldx, const void *w_packed,
         if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear_bf16_split: no HIP device");
         const long nt = (M_full / w16::BM) * (n_pad / w16::BN);
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(w16::kThreads);
-        if (act == M360_ACT_RELU) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, false, false, 0, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
+        if (layout) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, false, false, 0, true, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
+        else if (act == M360_ACT_RELU) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, false, false, 0, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
         else hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_NONE, 0, false, false, false, 0, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
     }
     if (M > M_full) {
@@ -736,7 +771,7 @@ int m360_linear_bf16x3(const void *x, long M, int ldx, const void *w_packed3, co
 
 int m360_linear_bf16x3_bf16out(const void *x, long M, int ldx, const void *w_packed3, const float *b_packed, int n_pad, int k_pad,
                                int act, void *y, int ldy, m360_stream_t stream) {
-    if (act != M360_ACT_NONE && act != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3_bf16out: activation %d (none or ReLU)", act);
+    if ((act & ~M360_ROWS_PAIRED_MASK) != M360_ACT_NONE && (act & ~M360_ROWS_PAIRED_MASK) != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3_bf16out: activation %d (none or ReLU)", act);
     return linear_bf16x3_any(x, M, ldx, w_packed3, b_packed, n_pad, k_pad, act, y, ldy, stream, false);
 }
 
@@ -746,7 +781,14 @@ static int linear_bf16x3_any(const void *x, long M, int ldx, const void *w_packe
     if (n_pad < 1 || k_pad < pbf16::BK || k_pad % pbf16::BK != 0 || ldx < 2 * k_pad || ldy < (split_out ? 2 : 1) * n_pad || ldx % 8 != 0 || ldy % 8 != 0 || n_pad % 8 != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: k_pad=%d must be a positive multiple of %d, ldx=%d >= 2 k_pad, ldy=%d >= %s n_pad=%d, all multiples of 8", k_pad, pbf16::BK, ldx, ldy, split_out ? "2" : "1", n_pad);
     if (((uintptr_t)x | (uintptr_t)w_packed3 | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: pointers must be 16-byte aligned");
+    const int layout = act & M360_ROWS_PAIRED_MASK;  // paired rows in / out (m360.h); the bf16-out first layer: out only
+    act &= ~M360_ROWS_PAIRED_MASK;
     if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: unknown activation %d", act);
+    if (layout && !m360_linear_bf16_rows_pairable(split_out ? M360_PAIRABLE_X3 : M360_PAIRABLE_X3_BF16OUT, n_pad, k_pad))
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: paired rows with n_pad=%d k_pad=%d: not a shape of the one-wave ring kernel (m360_linear_bf16_rows_pairable)", n_pad, k_pad);
+    if ((layout & M360_ROWS_PAIRED_OUT) && act != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: paired output rows: ReLU layers only (act=%d)", act);
+    if ((layout & M360_ROWS_PAIRED_IN) && !split_out) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3_bf16out: its input rows are the encoder's: paired output only");
+    const int xin = (layout & M360_ROWS_PAIRED_IN) ? 1 : 0;
     if (M == 0) return M360_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *xb = static_cast<const __bf16 *>(x), *wb = static_cast<const __bf16 *>(w_packed3);
@@ -761,8 +803,12 @@ static int linear_bf16x3_any(const void *x, long M, int ldx, const void *w_packe
         // hidden layers (bias + {none, ReLU}): the one-wave ring kernel (same accumulation order)
         if (M360_W16_X3 && act != M360_ACT_SIGMOID && k_pad % w16::BKS == 0) {
             dim3 blk(w16::kThreads);
-#define M360_W16X(A, ONE, SP) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<A, 0, false, true, ONE, 0, SP>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt)
-            if (split_out) {
+#define M360_W16X(A, ONE, SP) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<A, 0, false, true, ONE, 0, SP>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, xin)
+#define M360_W16XP(ONE, SP) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, true, ONE, 0, SP, false, true>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, xin)
+            if (layout & M360_ROWS_PAIRED_OUT) {
+                if (split_out) { if (k_pad == w16::BKS) M360_W16XP(true, true); else M360_W16XP(false, true); }
+                else { if (k_pad == w16::BKS) M360_W16XP(true, false); else M360_W16XP(false, false); }
+            } else if (split_out) {
                 if (k_pad == w16::BKS) { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, true, true); else M360_W16X(M360_ACT_NONE, true, true); }
                 else { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, false, true); else M360_W16X(M360_ACT_NONE, false, true); }
             } else {
@@ -770,6 +816,7 @@ static int linear_bf16x3_any(const void *x, long M, int ldx, const void *w_packe
                 else { if (act == M360_ACT_RELU) M360_W16X(M360_ACT_RELU, false, false); else M360_W16X(M360_ACT_NONE, false, false); }
             }
 #undef M360_W16X
+#undef M360_W16XP
         } else if (!split_out) {
             return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3_bf16out: no full-tile kernel for this shape");  // (unreachable: k_pad is a multiple of 64)
         } else
@@ -866,6 +913,8 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
             case 35: M360_W16_ABL(2048 + 128, true); break;  // variant 135: the same with plain (temporal) stores
             case 36: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, true, false, false, 0, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // variant 136: the LDS epilogue, stamped (results correct)
             case 37: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 16, true, false, false, 0, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // variant 137: ... without its stores
+            case 40: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, true, false, false, 0, false, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, 1); break;   // variant 140: paired rows in and out (y comes out paired, x is read as if it were)
+            case 41: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 16, true, false, false, 0, false, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, 1); break;  // variant 141: ... without the stores
             case 100: M360_W16_ABL(0, false); break;
             case 50: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 16, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // sigmoid epilogue, no stores: what would a last layer cost here?
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);

@@ -90,13 +90,24 @@ constexpr int kHeadMaxN = 1024;  // widest layer the fused heads take (their hi 
 // pipe - ds_write_b128 straight from the AccVGPRs (16 rows x 64 fp32 columns, XOR-swizzled 16-byte chunks: no bank conflicts),
 // ds_read_b128 back with lane (row L >> 3, columns 8 (L & 7) ..+7), so that 8 lanes hold one 128-byte line of bf16 output: no
 // v_accvgpr_read, no DPP exchange - 24 instead of 48 vector instructions per 16 outputs, same bias add / conversion / ReLU: same bits.
-template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0, bool SPLIT = X3, bool LDSEPI = false>
+// PAIR (round 4) / xpair: "paired rows" - the layout the hidden activations have BETWEEN two launches of this kernel (m360.h:
+// M360_ROWS_PAIRED_OUT / _IN).  A lane of the epilogue holds two 16-byte pieces of ONE row (columns 32 (2P) + 8 g4.. and
+// 32 (2P + 1) + 8 g4..), and a store instruction reaches the chip's store rate only when it writes whole 128-byte lines with the two
+// lanes of a line next to each other (W16_SWAP_STORE) - which is why the plain layout needs the lanes' exchange: 16 of the block's
+// 65 instructions.  Paired rows need none: inside every block of 2 rows x 64 columns the four 64-byte quarters are transposed - the
+// line at row 2R holds [row 2R, columns 0-31 | row 2R + 1, columns 0-31], the line at row 2R + 1 the columns 32-63 of both rows - so
+// the first pieces of a lane pair ARE one whole line, the second pieces the other: same store instructions, same addresses, no
+// exchange.  The reader is this kernel's LDS-DMA, whose lanes carry their own source addresses: xpair != 0 fetches chunk c of row r
+// from line 2 (r >> 1) + (c >> 2), bytes 64 (r & 1) + 16 (c & 3) - the same eight whole lines per piece, a different lane order.
+// Rows beyond the last full 256-row tile are other kernels' rows and stay plain in both layouts.
+template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0, bool SPLIT = X3, bool LDSEPI = false, bool PAIR = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, const float *__restrict__ head_w = nullptr,
-    float *__restrict__ head_part = nullptr) {
+    float *__restrict__ head_part = nullptr, int xpair = 0) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0) + (LDSEPI ? 4 * 4096 : 0)];  // 144 (160) KiB
-    static_assert(!LDSEPI || (HEADS == 0 && !SPLIT && !X3), "the LDS epilogue: plain bf16 output (its 16 KiB sit where the head rows would)");
+    static_assert(!LDSEPI || (HEADS == 0 && !SPLIT && !X3 && !PAIR), "the LDS epilogue: plain bf16 output (its 16 KiB sit where the head rows would)");
+    static_assert(!PAIR || HEADS == 0, "paired rows are a layout of the layer's own output");
     static_assert(HEADS == 0 || HEADS == 1 || HEADS == 4, "1 (proposal) or 4 (NeRF) heads");
     // X3 loop + plain bf16 output: the first layer of the bf16 mode (two-term features and weights in, one bf16 term out)
     static_assert(SPLIT == X3 || HEADS == 0, "X3 loop and split output go together wherever the heads are fused");
@@ -138,7 +149,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     for (int q = 0; q < 8; ++q) {
         const int rx = xrow0 + (q >> 2) * 64 + 8 * (q & 3) + (lane >> 3);
         const int rw = 64 * wave + 8 * q + (lane >> 3);
-        x_voff[q] = (unsigned)(rx * ldx + 8 * ((lane & 7) ^ ((rx >> 1) & 7))) * 2u;
+        const int cx_ = (lane & 7) ^ ((rx >> 1) & 7);  // the 16-byte chunk of row rx this lane fetches
+        x_voff[q] = xpair ? (unsigned)((2 * (rx >> 1) + (cx_ >> 2)) * ldx + 32 * (rx & 1) + 8 * (cx_ & 3)) * 2u : (unsigned)(rx * ldx + 8 * cx_) * 2u;
         w_voff[q] = (unsigned)(rw * Kp + 8 * ((lane & 7) ^ (2 * ((rw >> 3) & 3) + ((rw >> 1) & 1)))) * 2u;
     }
     char *const dma_x = smem + xrow0 * 128;               // + buffer * kStageBytes + (q & 3) * 1024 + (q >> 2) * 8192
@@ -470,6 +482,18 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                     // store) may write them.
 #define W16_SEL_(D, OTHER, OWN, CMP)                                                                                             \
     "v_cmp_" CMP "_u32_e32 vcc, 0, %16\n\tv_cndmask_b32_dpp " D ", " OTHER ", " OWN ", vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define W16_STORE2(S1, S2, ROW, IMM)                                                                                            \
+    do {                                                                                                                        \
+        /* non-temporal: the tile's 128 KiB of output lines otherwise displace the activation tile the 4 column tiles of an XCD share  \
+           from its L2 (1263-1270 against 1241-1242 TF, alternating launches on one box; ABL & 128: the plain stores) */              \
+        if ((ABL & 16) == 0 && (ABL & 128) == 0)                                                                                \
+            asm volatile("global_store_dwordx4 %0, %2, %4 offset:" IMM " nt\n\tglobal_store_dwordx4 %1, %3, %4 offset:" IMM " nt\n\ts_nop 1" \
+                         ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(S1), "v"(S2), "s"(ROW) : "memory");                \
+        else if ((ABL & 16) == 0)                                                                                               \
+            asm volatile("global_store_dwordx4 %0, %2, %4 offset:" IMM "\n\tglobal_store_dwordx4 %1, %3, %4 offset:" IMM "\n\ts_nop 1" \
+                         ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(S1), "v"(S2), "s"(ROW) : "memory");                \
+        else asm volatile("" ::"v"(S1), "v"(S2));                                                                               \
+    } while (0)
 #define W16_SWAP_STORE(A0, A1, ROW, IMM)                                                                                        \
     do {                                                                                                                        \
         u32x4 s1, s2;                                                                                                           \
@@ -481,28 +505,26 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                      : "=&v"(s1[0]), "=&v"(s1[1]), "=&v"(s1[2]), "=&v"(s1[3]), "=&v"(s2[0]), "=&v"(s2[1]), "=&v"(s2[2]), "=&v"(s2[3]) \
                      : "v"(A0[0]), "v"(A0[1]), "v"(A0[2]), "v"(A0[3]), "v"(A1[0]), "v"(A1[1]), "v"(A1[2]), "v"(A1[3]), "v"(lane_odd) \
                      : "vcc");                                                                                                  \
-        /* non-temporal: the tile's 128 KiB of output lines otherwise displace the activation tile the 4 column tiles of an XCD share  \
-           from its L2 (1263-1270 against 1241-1242 TF, alternating launches on one box; ABL & 128: the plain stores) */              \
-        if ((ABL & 16) == 0 && (ABL & 128) == 0)                                                                                \
-            asm volatile("global_store_dwordx4 %0, %2, %4 offset:" IMM " nt\n\tglobal_store_dwordx4 %1, %3, %4 offset:" IMM " nt\n\ts_nop 1" \
-                         ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(s1), "v"(s2), "s"(ROW) : "memory");                \
-        else if ((ABL & 16) == 0)                                                                                               \
-            asm volatile("global_store_dwordx4 %0, %2, %4 offset:" IMM "\n\tglobal_store_dwordx4 %1, %3, %4 offset:" IMM "\n\ts_nop 1" \
-                         ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(s1), "v"(s2), "s"(ROW) : "memory");                \
-        else asm volatile("" ::"v"(s1), "v"(s2));                                                                               \
+        W16_STORE2(s1, s2, ROW, IMM);                                                                                           \
     } while (0)
                     if (STORE_Y) {
                         // rows 16 i .. of the wave tile: a running pointer (one 64-bit scalar add per block - left to the compiler,
                         // every block's address was 8-10 scalar instructions from the tile's corner); column half P is the
                         // stores' immediate offset
-                        if (P == 0) W16_SWAP_STORE(ab[0], ab[1], rowp, "0"); else W16_SWAP_STORE(ab[0], ab[1], rowp, "128");
-                        if (SPLIT) {  // the second terms: columns [Np, 2 Np)
-                            if (P == 0) W16_SWAP_STORE(lo[0], lo[1], rowp + Np, "0"); else W16_SWAP_STORE(lo[0], lo[1], rowp + Np, "128");
+                        if (PAIR) {  // paired rows: the lanes' own pieces are whole lines
+                            if (P == 0) W16_STORE2(ab[0], ab[1], rowp, "0"); else W16_STORE2(ab[0], ab[1], rowp, "128");
+                            if (SPLIT) { if (P == 0) W16_STORE2(lo[0], lo[1], rowp + Np, "0"); else W16_STORE2(lo[0], lo[1], rowp + Np, "128"); }
+                        } else {
+                            if (P == 0) W16_SWAP_STORE(ab[0], ab[1], rowp, "0"); else W16_SWAP_STORE(ab[0], ab[1], rowp, "128");
+                            if (SPLIT) {  // the second terms: columns [Np, 2 Np)
+                                if (P == 0) W16_SWAP_STORE(lo[0], lo[1], rowp + Np, "0"); else W16_SWAP_STORE(lo[0], lo[1], rowp + Np, "128");
+                            }
                         }
                         rowp += row_step;
                         asm volatile("" : "+s"(rowp));
                     }
 #undef W16_SWAP_STORE
+#undef W16_STORE2
 #undef W16_SEL_
                     if (HEADS) {  // D[head][row] += over each piece's 32 columns: hi and lo head terms (X3: and the lo activations)
 #pragma unroll

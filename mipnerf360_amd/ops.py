@@ -528,7 +528,31 @@ def linear_heads(x, w_packed, b_packed, head_w, store_y: bool = True):
     return y, part, fused
 
 
-def linear_heads_bf16(x, w_packed, b_packed, head_w, store_y: bool = True, x3: bool = False):
+def pair_rows(x: torch.Tensor) -> torch.Tensor:
+    """Plain bf16 rows <-> the "paired rows" of include/m360.h (M360_ROWS_PAIRED_IN / _OUT), host-side form for tests and tools: in
+    every block of 2 rows x 64 columns of the full 256-row tiles the four 64-byte quarters are transposed (its own inverse); rows
+    beyond the last full tile stay as they are.  [hi | lo] pair rows: the same call (their halves are multiples of 64 columns)."""
+    M, C = x.shape
+    if C % 64:
+        raise RuntimeError(f"pair_rows: {C} columns (a multiple of 64)")
+    full = (M // 256) * 256
+    y = x.clone()
+    if full:
+        y[:full] = x[:full].reshape(full // 2, 2, C // 64, 2, 32).transpose(1, 3).reshape(full, C)
+    return y
+
+
+def rows_pairable(kind: int, n_pad: int, k_pad: int) -> bool:
+    """m360_linear_bf16_rows_pairable: does the call `kind` (_lib.PAIRABLE_*) take paired rows at these pads?"""
+    return bool(_lib.lib().m360_linear_bf16_rows_pairable(int(kind), int(n_pad), int(k_pad)))
+
+
+def set_paired_rows(on: bool) -> bool:
+    """m360_set_paired_rows (diagnostics): paired rows between the layers of the bf16 / bf16x3 MLPs on / off; returns the old setting"""
+    return bool(_lib.lib().m360_set_paired_rows(int(bool(on))))
+
+
+def linear_heads_bf16(x, w_packed, b_packed, head_w, store_y: bool = True, x3: bool = False, paired_in: bool = False):
     """The bf16 (x3 = False: m360_linear_heads_bf16) / bf16x3 (x3 = True: [hi | lo] pair rows, m360_linear_heads_bf16x3) last hidden
     layer with the heads formed on the matrix pipe -> (y, head_part[fused_rows, slots, heads] fp32, fused_rows)."""
     x, w_packed, b_packed, head_w = dev_bf16(x, "x"), dev_bf16(w_packed, "w_packed"), dev(b_packed, "b_packed"), dev(head_w, "head_w")
@@ -546,7 +570,7 @@ def linear_heads_bf16(x, w_packed, b_packed, head_w, store_y: bool = True, x3: b
     y = torch.zeros(M, ldy, device=x.device, dtype=torch.bfloat16)
     part = torch.zeros(max(fused, 1), max(slots, 1), heads, device=x.device)
     _call("m360_linear_heads_bf16x3" if x3 else "m360_linear_heads_bf16", x, M, ldx, w_packed, b_packed, n_pad, k_pad,
-          _lib.ACT_SIGMOID, y, ldy, int(bool(store_y)), head_w, heads, part, STREAM)
+          _lib.ACT_SIGMOID | (_lib.ROWS_PAIRED_IN if paired_in else 0), y, ldy, int(bool(store_y)), head_w, heads, part, STREAM)
     return y, part, fused
 
 

@@ -492,6 +492,112 @@ def test_x6_first_layer_is_an_fp32_product(dev, M, n_out, split):
         assert float(y[:, n_out:n_pad].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,width,k", [(256 * 3 + 57, 512, 256), (256 * 6, 1024, 1024), (256 * 2 + 1, 256, 384)])
+def test_paired_rows_of_the_bf16_layers_are_a_permutation(dev, M, width, k):
+    """include/m360.h "paired rows" (M360_ROWS_PAIRED_IN / _OUT): the ring kernel reads and writes the same numbers, 64-byte quarters
+    of every 2-row x 64-column block of the full tiles transposed - for m360_linear_bf16, m360_linear_bf16x3, the first-layer calls
+    (out only) and the fused-heads calls (in only).  Bit for bit against the plain calls through ops.pair_rows; ragged rows stay plain."""
+    from mipnerf360_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + width + k)
+    x = torch.randn(M, k, generator=g).to(dev)
+    w = (torch.randn(width, k, generator=g) * (2.0 / k) ** 0.5).to(dev)
+    b = (torch.randn(width, generator=g) * 0.1).to(dev)
+    IN, OUT, RELU = _lib.ROWS_PAIRED_IN, _lib.ROWS_PAIRED_OUT, _lib.ACT_RELU
+    # hidden layer, bf16
+    wp, bp = ops.pack_linear_bf16(w, b, width, k)
+    xb = x.bfloat16()
+    y = ops.linear_bf16(xb, wp, bp, RELU)
+    assert ops.rows_pairable(_lib.PAIRABLE_LINEAR, width, k)
+    assert torch.equal(ops.pair_rows(ops.linear_bf16(xb, wp, bp, RELU | OUT)), y)
+    assert torch.equal(ops.linear_bf16(ops.pair_rows(xb), wp, bp, RELU | IN), y)
+    assert torch.equal(ops.pair_rows(ops.linear_bf16(ops.pair_rows(xb), wp, bp, RELU | IN | OUT)), y)
+    assert M % 256 == 0 or torch.equal(ops.linear_bf16(xb, wp, bp, RELU | OUT)[(M // 256) * 256:], y[(M // 256) * 256:])
+    # hidden layer, bf16x3 ([hi | lo] rows in and out)
+    w3, b3 = ops.pack_linear_bf16x3(w, b, width, k)
+    x3 = ops.split_bf16x3(x)
+    y3 = ops.linear_bf16x3(x3, w3, b3, RELU)
+    assert ops.rows_pairable(_lib.PAIRABLE_X3, width, k)
+    assert torch.equal(ops.pair_rows(ops.linear_bf16x3(ops.pair_rows(x3), w3, b3, RELU | IN | OUT)), y3)
+    assert torch.equal(ops.linear_bf16x3(ops.pair_rows(x3), w3, b3, RELU | IN), y3)
+    # fused-heads last layers (in only): the same partial sums
+    if width <= 1024:
+        hw = torch.randn(4, width, generator=g).to(dev)
+        for x3_mode, xin, wpk, bpk, kind in ((False, xb, wp, bp, _lib.PAIRABLE_HEADS), (True, x3, w3, b3, _lib.PAIRABLE_HEADS_X3)):
+            if not ops.rows_pairable(kind, width, k):
+                continue
+            _, part, fused = ops.linear_heads_bf16(xin, wpk, bpk, hw, store_y=False, x3=x3_mode)
+            _, part_p, fused_p = ops.linear_heads_bf16(ops.pair_rows(xin), wpk, bpk, hw, store_y=False, x3=x3_mode, paired_in=True)
+            assert fused == fused_p == (M // 256) * 256 and torch.equal(part, part_p)
+
+
+@pytest.mark.parametrize("M,width", [(256 * 4 + 100, 256), (256 * 3, 1024)])
+def test_paired_rows_out_of_the_first_layers(dev, M, width):
+    """The first layers of the two reduced-precision modes (m360_linear_bf16x3_bf16out: [hi | lo] features, one bf16 term out;
+    m360_linear_bf16_split: x6 features, [hi | lo] rows out) with M360_ROWS_PAIRED_OUT: the plain call's rows, paired."""
+    from mipnerf360_amd import _lib, ops
+    g = torch.Generator().manual_seed(M + width)
+    x = torch.zeros(M, 64)
+    x[:, :58] = torch.randn(M, 58, generator=g)
+    w = torch.randn(width, 58, generator=g).to(dev)
+    b = torch.randn(width, generator=g).to(dev)
+    OUT, RELU = _lib.ROWS_PAIRED_OUT, _lib.ACT_RELU
+    w3, b3 = ops.pack_linear_bf16x3(w, b, width, 64)
+    x2 = ops.split_bf16x3(x.to(dev))
+    assert ops.rows_pairable(_lib.PAIRABLE_X3_BF16OUT, width, 64)
+    assert torch.equal(ops.pair_rows(ops.linear_bf16x3_bf16out(x2, w3, b3, RELU | OUT)), ops.linear_bf16x3_bf16out(x2, w3, b3, RELU))
+    w6, b6 = ops.pack_linear_bf16x6(w, b, width, 64)
+    x6 = ops.split_bf16x6(x.to(dev))
+    assert ops.rows_pairable(_lib.PAIRABLE_SPLIT, width, 384)
+    assert torch.equal(ops.pair_rows(ops.linear_bf16_split(x6, w6, b6, RELU | OUT)), ops.linear_bf16_split(x6, w6, b6, RELU))
+
+
+def test_paired_rows_are_refused_where_no_kernel_takes_them(dev):
+    """A shape the one-wave ring kernel does not take, an activation other than ReLU on the way out, paired input of a first layer:
+    M360_ERR_INVALID_ARGUMENT with the reason, never a silently plain result."""
+    from mipnerf360_amd import _lib, ops
+    IN, OUT, RELU = _lib.ROWS_PAIRED_IN, _lib.ROWS_PAIRED_OUT, _lib.ACT_RELU
+    x = torch.randn(512, 192, device=dev).bfloat16()
+    wp, bp = ops.pack_linear_bf16(torch.randn(256, 192, device=dev), None, 256, 192)          # K = 192: the ping-pong kernel's
+    assert not ops.rows_pairable(_lib.PAIRABLE_LINEAR, 256, 192)
+    with pytest.raises(RuntimeError, match="paired rows"):
+        ops.linear_bf16(x, wp, bp, RELU | OUT)
+    x = torch.randn(512, 256, device=dev).bfloat16()
+    wp, bp = ops.pack_linear_bf16(torch.randn(256, 256, device=dev), None, 256, 256)
+    with pytest.raises(RuntimeError, match="ReLU"):
+        ops.linear_bf16(x, wp, bp, _lib.ACT_NONE | OUT)
+    wq, bq = ops.pack_linear_bf16(torch.randn(96, 256, device=dev), None, 128, 256)           # 128 wide: no full tile
+    with pytest.raises(RuntimeError, match="paired rows"):
+        ops.linear_bf16(x, wq, bq, RELU | IN)
+    x6 = ops.split_bf16x6(torch.randn(512, 64, device=dev))
+    w6, b6 = ops.pack_linear_bf16x6(torch.randn(256, 58, device=dev), None, 256, 64)
+    with pytest.raises(RuntimeError, match="output only"):
+        ops.linear_bf16_split(x6, w6, b6, RELU | IN)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_forward_is_the_same_bits_with_and_without_paired_rows(dev, mode):
+    """m360_forward in the reduced-precision modes uses paired rows between the layers of both MLPs (full width: every layer on the
+    ring kernel); m360_set_paired_rows(0) keeps plain rows: the six outputs must not differ in a bit - 1000 rays x 32 samples, i.e.
+    125 full tiles + 0 ragged rows for the NeRF stage, and 999 x 33 with ragged rows in every layer."""
+    from mipnerf360_amd import ops
+    from mipnerf360_amd.model import mipNeRF360
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(256, 1024, seed=5).items()}
+    for B, N in ((1000, 32), (999, 33)):
+        model = mipNeRF360(num_samples=N, hidden_proposal=256, hidden_nerf=1024, mlp_dtype=mode, device=dev, randomized=False).eval()
+        model.load_state_dict(sd)
+        rays = dev_rays(synthetic.make_rays("garden", B, seed=3), dev)
+        outs = {}
+        for on in (True, False):
+            was = ops.set_paired_rows(on)
+            try:
+                with torch.no_grad():
+                    outs[on] = [o.clone() for o in model(rays)]
+            finally:
+                ops.set_paired_rows(was)
+        for a, b in zip(outs[True], outs[False]):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("M,n_out,k_in", [(700, 256, 58), (256 * 5 + 33, 1024, 58), (90, 96, 58), (1024, 256, 200)])
 def test_bf16_mode_first_layer_two_terms_in_one_out(dev, M, n_out, k_in):
     """m360_linear_bf16x3_bf16out: the first layer of the bf16 mode - [hi | lo] features, [Wh | Wh | Wl] weights, the three products of

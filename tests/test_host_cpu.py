@@ -35,6 +35,27 @@ def test_header_symbols_are_exported_and_bound(lib):
     assert lib.m360_contract_workspace_bytes() >= 8192
 
 
+def test_paired_rows_host_side(lib):
+    """include/m360.h "paired rows": ops.pair_rows is its own inverse, moves 64-byte quarters inside 2-row x 64-column blocks of the
+    full 256-row tiles only, and m360_linear_bf16_rows_pairable (host logic, no device) names the ring kernel's shapes."""
+    from mipnerf360_amd import _lib, ops
+    x = torch.arange(300 * 128, dtype=torch.float32).reshape(300, 128).bfloat16()
+    y = ops.pair_rows(x)
+    assert torch.equal(ops.pair_rows(y), x) and torch.equal(y[256:], x[256:])
+    assert torch.equal(y[0, :32], x[0, :32]) and torch.equal(y[0, 32:64], x[1, :32]) and torch.equal(y[1, :32], x[0, 32:64]) and torch.equal(y[1, 32:64], x[1, 32:64])
+    assert torch.equal(y[7, 64:96], x[6, 96:128]) and torch.equal(y[6, 96:128], x[7, 64:96])
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.pair_rows(torch.zeros(256, 96))
+    q = lib.m360_linear_bf16_rows_pairable
+    assert q(_lib.PAIRABLE_LINEAR, 1024, 1024) and q(_lib.PAIRABLE_LINEAR, 256, 256) and q(_lib.PAIRABLE_LINEAR, 1024, 64) and q(_lib.PAIRABLE_LINEAR, 256, 384)
+    assert not q(_lib.PAIRABLE_LINEAR, 256, 192) and not q(_lib.PAIRABLE_LINEAR, 128, 256) and not q(_lib.PAIRABLE_LINEAR, 1000, 256) and not q(_lib.PAIRABLE_LINEAR, 256, 128)
+    assert q(_lib.PAIRABLE_X3, 1024, 1024) and q(_lib.PAIRABLE_X3, 256, 192) and q(_lib.PAIRABLE_X3_BF16OUT, 1024, 64) and not q(_lib.PAIRABLE_X3, 96, 64)
+    assert q(_lib.PAIRABLE_SPLIT, 1024, 384) and not q(_lib.PAIRABLE_SPLIT, 1024, 64)
+    assert q(_lib.PAIRABLE_HEADS, 1024, 1024) and q(_lib.PAIRABLE_HEADS_X3, 256, 256) and not q(_lib.PAIRABLE_HEADS, 2048, 1024) and not q(_lib.PAIRABLE_HEADS, 256, 128)
+    assert not q(99, 1024, 1024)
+    assert lib.m360_set_paired_rows(0) == 1 and lib.m360_set_paired_rows(1) == 0 and lib.m360_set_paired_rows(1) == 1
+
+
 def test_header_cites_reference_lines():
     hdr = open(os.path.join(ROOT, "include", "m360.h")).read()
     assert len(re.findall(r"(intern/\w+\.py|model\.py):\d+", hdr)) >= 25

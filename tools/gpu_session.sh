@@ -81,6 +81,15 @@ for s in $steps; do
     r4nan)   timeout 1800 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "g18 or nan or bf16 or g19 or g20 or finish" > $out/pytest_r4nan.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r4nan.log; grep -a "^FAILED\|passed\|failed" $out/pytest_r4nan.log | tail -12 ;;
     valu)    /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/valu_issue_probe.hip -o /tmp/valu_issue_probe.bin 2> $out/valu_issue_probe.err && timeout 300 /tmp/valu_issue_probe.bin > $out/valu_issue_probe.jsonl 2>> $out/valu_issue_probe.err; cut -c1-260 $out/valu_issue_probe.jsonl ;;
     epi)     for v in 100 116 100; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v $( [ $v = 116 ] && echo --no-check ) --rounds 5 --json $out/bf16_w16_epilogue.jsonl > $out/linear_bf16_epi_$v.log 2>&1; tail -2 $out/linear_bf16_epi_$v.log | cut -c1-400; done ;;
+    pairtests) timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "paired or soak or bit_identical or g19 or x6 or bf16 or c5 or fused" > $out/pytest_paired.log 2>&1; echo "pytest rc=$?" >> $out/pytest_paired.log; tail -12 $out/pytest_paired.log | cut -c1-300 ;;
+    pairab)  for r in 1 2; do for f in "" "--plain-rows"; do for d in bf16 bf16x3; do timeout 600 python bench.py --mlp-dtype $d --cpu-rays 0 --frame-steps 0 $f >> $out/paired_rows_ab.jsonl 2>> $out/paired_rows_ab.err; done; done; done
+             python3 - <<PYEOF
+import json
+for l in open("$out/paired_rows_ab.jsonl"):
+    d = json.loads(l); print(d["dtype"], "plain" if d["config"].get("plain_rows") else "paired", d["ms_per_step"], d["ms_per_step_median"], d["roofline"]["avg_launch_ms"])
+PYEOF
+             ;;
+    epipair) for v in 140 100 141 116 140 100; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v $( [ $v != 100 ] && echo --no-check ) --rounds 5 --json $out/bf16_w16_paired_rows.jsonl > $out/linear_bf16_pair_$v.log 2>&1; tail -1 $out/linear_bf16_pair_$v.log | cut -c1-400; done ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac

@@ -93,11 +93,16 @@ __device__ __forceinline__ void block() {
     if (T == 33) asm volatile(HALF_AS_EMITTED(0) REPT(4, "v_pk_max_i16 v[24+pi], v[16+2*pi], 0") HALF_AS_EMITTED(8) REPT(4, "v_pk_max_i16 v[32+pi], v[16+2*pi], 0") "s_nop 1\n\t"
                               REPT(4, "s_mov_b64 vcc, %0\n\tv_cndmask_b32_dpp v[40+pi], v[32+pi], v[24+pi], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                                       "s_mov_b64 vcc, %1\n\tv_cndmask_b32_dpp v[44+pi], v[24+pi], v[32+pi], vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") ::"s"(m0), "s"(m1) : CLOB);
+    // 34-37: the sigmoid of the fused-heads layers: do v_exp_f32 / v_rcp_f32 (quarter rate) overlap with other vector instructions?
+    if (T == 34) asm volatile(REPT(64, "v_exp_f32_e32 v[16+pi], v[80]") ::"s"(m0), "s"(m1) : CLOB);
+    if (T == 35) asm volatile(REPT(16, "v_exp_f32_e32 v[16+pi], v[80]\n\tv_pk_max_i16 v[32+pi], v[82], 0\n\tv_pk_max_i16 v[48+pi], v[83], 0\n\tv_pk_max_i16 v[64+pi], v[84], 0") ::"s"(m0), "s"(m1) : CLOB);
+    if (T == 36) asm volatile(REPT(32, "v_exp_f32_e32 v[16+pi], v[80]\n\tv_pk_max_i16 v[48+pi], v[82], 0") ::"s"(m0), "s"(m1) : CLOB);
+    if (T == 37) asm volatile(REPT(32, "v_exp_f32_e32 v[16+pi], v[80]\n\tv_rcp_f32_e32 v[48+pi], v[81]") ::"s"(m0), "s"(m1) : CLOB);
     // 31: one compare into VCC, then 3 selects on it (the 4-wide vector selects the compiler emits), x 16
     if (T == 31) asm volatile(REPT(16, "v_cmp_lt_f32_e32 vcc, v[80], v[81+pi]\n\tv_cndmask_b32_e32 v[16+pi], v[82], v[83], vcc\n\tv_cndmask_b32_e32 v[32+pi], v[82], v[83], vcc\n\tv_cndmask_b32_e32 v[48+pi], v[82], v[83], vcc") ::"s"(m0), "s"(m1) : CLOB);
 }
 
-constexpr int kTests = 34;
+constexpr int kTests = 38;
 __host__ __device__ constexpr int valu_in(int t) { return t == 9 || t == 10 || t == 33 ? 48 : t == 11 ? 40 : t == 12 ? 48 : t == 13 ? 16 : t == 20 ? 52 : t == 25 ? 56 : 64; }
 
 template <int T>
@@ -119,7 +124,8 @@ void run(int cus, int iters, unsigned long long *cyc, unsigned long long *h) {
         "v_add_u32_dpp quad_perm, independent", "the block with 4 copies + 8 masked DPP moves for the 8 selects (52)", "v_mov_b32_dpp row_shr:1, independent", "v_cndmask_b32_dpp row_ror:8, independent",
         "1 select + 3 v_pk_max_i16, x 16", "1 select + 7 v_pk_max_i16, x 8", "the block with the previous block's selects spread over it, + 8 copies (56)",
         "v_cmp -> VCC + v_cndmask on VCC, x 32", "v_cmp -> SGPR pair + v_cndmask on it, x 32", "v_cmp -> VCC, independent", "v_add_co / v_addc_co through VCC, x 32", "v_add_co / v_addc_co through an SGPR pair, x 32",
-        "v_cmp -> VCC + 3 v_cndmask on VCC, x 16", "s_mov_b64 vcc before EVERY select (two masks alternating), x 64", "the block with s_mov_b64 vcc before every select (48)"};
+        "v_cmp -> VCC + 3 v_cndmask on VCC, x 16", "s_mov_b64 vcc before EVERY select (two masks alternating), x 64", "the block with s_mov_b64 vcc before every select (48)",
+        "v_exp_f32, independent", "1 v_exp_f32 + 3 v_pk_max_i16, x 16", "v_exp_f32 / v_pk_max_i16 alternating", "v_exp_f32 / v_rcp_f32 alternating"};
     for (int waves = 4; waves <= 8; waves += 4) {
         for (int rep = 0; rep < 2; ++rep) {
             hipLaunchKernelGGL(probe_kernel<T>, dim3(cus), dim3(64 * waves), 0, 0, iters, cyc);
@@ -146,5 +152,6 @@ int main() {
     run<15>(cus, iters, cyc, h); run<16>(cus, iters, cyc, h); run<17>(cus, iters, cyc, h); run<18>(cus, iters, cyc, h); run<19>(cus, iters, cyc, h); run<20>(cus, iters, cyc, h);
     run<21>(cus, iters, cyc, h); run<22>(cus, iters, cyc, h); run<23>(cus, iters, cyc, h); run<24>(cus, iters, cyc, h); run<25>(cus, iters, cyc, h);
     run<26>(cus, iters, cyc, h); run<27>(cus, iters, cyc, h); run<28>(cus, iters, cyc, h); run<29>(cus, iters, cyc, h); run<30>(cus, iters, cyc, h); run<31>(cus, iters, cyc, h); run<32>(cus, iters, cyc, h); run<33>(cus, iters, cyc, h);
+    run<34>(cus, iters, cyc, h); run<35>(cus, iters, cyc, h); run<36>(cus, iters, cyc, h); run<37>(cus, iters, cyc, h);
     return 0;
 }
