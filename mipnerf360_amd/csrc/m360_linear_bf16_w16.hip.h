@@ -508,9 +508,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         W16_STORE2(s1, s2, ROW, IMM);                                                                                           \
     } while (0)
                     if (STORE_Y) {
-                        // rows 16 i .. of the wave tile: a running pointer (one 64-bit scalar add per block - left to the compiler,
-                        // every block's address was 8-10 scalar instructions from the tile's corner); column half P is the
-                        // stores' immediate offset
+                        // rows 16 i .. of the wave tile: a running pointer (one 64-bit scalar add per block, pinned by the empty
+                        // statement below - every instruction of the epilogue costs the lone wave an issue slot); column half P is
+                        // the stores' immediate offset
                         if (PAIR) {  // paired rows: the lanes' own pieces are whole lines
                             if (P == 0) W16_STORE2(ab[0], ab[1], rowp, "0"); else W16_STORE2(ab[0], ab[1], rowp, "128");
                             if (SPLIT) { if (P == 0) W16_STORE2(lo[0], lo[1], rowp + Np, "0"); else W16_STORE2(lo[0], lo[1], rowp + Np, "128"); }
