@@ -444,9 +444,14 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     do {                                                                                                       \
         f32x2 t_ = {a0 + bb_[be], a1 + bb_[(be) + 1]};                                                         \
         if (SPLIT && ACT == M360_ACT_RELU) { t_[0] = relu_nanf_(t_[0]); t_[1] = relu_nanf_(t_[1]); }              \
-        if (ACT == M360_ACT_SIGMOID) {                                                                         \
-            t_[0] = __builtin_amdgcn_rcpf(1.0f + __expf(-t_[0]));                                              \
-            t_[1] = __builtin_amdgcn_rcpf(1.0f + __expf(-t_[1]));                                              \
+        if (ACT == M360_ACT_SIGMOID) { /* rcp(1 + __expf(-t)), __expf(-t) = v_exp_f32(t * -log2 e): the same operations, the   \
+               multiply and the two adds as PACKED instructions (written per element the compiler splits the bias add as well: 8   \
+               instead of 5 instructions per pair, and every instruction costs the lone wave an issue slot) */                      \
+            f32x2 u_ = t_ * (f32x2){-1.44269502162933349609375f, -1.44269502162933349609375f};                \
+            f32x2 e_ = {__builtin_amdgcn_exp2f(u_[0]), __builtin_amdgcn_exp2f(u_[1])};                         \
+            e_ = e_ + (f32x2){1.0f, 1.0f};                                                                     \
+            t_[0] = __builtin_amdgcn_rcpf(e_[0]);                                                              \
+            t_[1] = __builtin_amdgcn_rcpf(e_[1]);                                                              \
         }                                                                                                      \
         const bf16x2 h_ = __builtin_convertvector(t_, bf16x2);                                                 \
         s16x2 p_ = __builtin_bit_cast(s16x2, h_);                                                              \
