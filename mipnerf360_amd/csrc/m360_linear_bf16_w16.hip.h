@@ -69,7 +69,8 @@ __device__ unsigned long long g_w16_stamps[256 * 4];
 #endif
 // ABL (diagnostic builds; results are wrong unless 0 or 64): 1 = no barrier, 2 = no LDS-DMA, 4 = no fragment reads, 16 = no stores,
 // 32 = no epilogue at all, 64 = wait for every outstanding operation at the end of the epilogue (how long do the stores take?),
-// 128 = plain instead of non-temporal stores (results correct), 1024 = no counted vmcnt waits in the K loop (wrong results)
+// 128 = plain instead of non-temporal stores (results correct), 1024 = no counted vmcnt waits in the K loop (wrong results),
+// 4096 / 8192 = agent- / system-scope stores (results correct)
 // X3 ("bf16x3", m360_linear_bf16_pp.hip.h): activations [hi(K) | lo(K)], weights [Wh | Wh | Wl] (rows of Kp = 3K), output
 // [hi(Np) | lo(Np)]; per 64-deep block three stages xl wh -> xh wh -> xh wl that share an operand with their neighbour
 // (tools/gen_w16_slab.py, second half): 4 operand tiles staged per block instead of 6, the same accumulation order as the ping-pong
@@ -487,17 +488,22 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                     // store) may write them.
 #define W16_SEL_(D, OTHER, OWN, CMP)                                                                                             \
     "v_cmp_" CMP "_u32_e32 vcc, 0, %16\n\tv_cndmask_b32_dpp " D ", " OTHER ", " OWN ", vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+#define W16_STORE2_(S1, S2, ROW, IMM, POLICY)                                                                                   \
+    asm volatile("global_store_dwordx4 %0, %2, %4 offset:" IMM POLICY "\n\tglobal_store_dwordx4 %1, %3, %4 offset:" IMM POLICY "\n\ts_nop 1" \
+                 ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(S1), "v"(S2), "s"(ROW) : "memory")
 #define W16_STORE2(S1, S2, ROW, IMM)                                                                                            \
     do {                                                                                                                        \
         /* non-temporal: the tile's 128 KiB of output lines otherwise displace the activation tile the 4 column tiles of an XCD share  \
-           from its L2 (1263-1270 against 1241-1242 TF, alternating launches on one box; ABL & 128: the plain stores) */              \
-        if ((ABL & 16) == 0 && (ABL & 128) == 0)                                                                                \
-            asm volatile("global_store_dwordx4 %0, %2, %4 offset:" IMM " nt\n\tglobal_store_dwordx4 %1, %3, %4 offset:" IMM " nt\n\ts_nop 1" \
-                         ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(S1), "v"(S2), "s"(ROW) : "memory");                \
-        else if ((ABL & 16) == 0)                                                                                               \
-            asm volatile("global_store_dwordx4 %0, %2, %4 offset:" IMM "\n\tglobal_store_dwordx4 %1, %3, %4 offset:" IMM "\n\ts_nop 1" \
-                         ::"v"(y_voff), "v"(y_voff + 2u * (unsigned)ldy), "v"(S1), "v"(S2), "s"(ROW) : "memory");                \
-        else asm volatile("" ::"v"(S1), "v"(S2));                                                                               \
+           from its L2 (1263-1270 against 1241-1242 TF, alternating launches on one box; ABL & 128: the plain stores;                 \
+           ABL & 4096 / 8192, diagnostics: agent- / system-scope stores (sc1 / sc0 sc1), with and without nt: all 1-2 % slower,      \
+           profiles/r04/bf16_w16_store_scope_NOT_ADOPTED.jsonl) */                                                                    \
+        if (ABL & 16) asm volatile("" ::"v"(S1), "v"(S2));                                                                      \
+        else if ((ABL & 4096) && (ABL & 128)) W16_STORE2_(S1, S2, ROW, IMM, " sc1");                                            \
+        else if (ABL & 4096) W16_STORE2_(S1, S2, ROW, IMM, " sc1 nt");                                                          \
+        else if ((ABL & 8192) && (ABL & 128)) W16_STORE2_(S1, S2, ROW, IMM, " sc0 sc1");                                        \
+        else if (ABL & 8192) W16_STORE2_(S1, S2, ROW, IMM, " sc0 sc1 nt");                                                      \
+        else if (ABL & 128) W16_STORE2_(S1, S2, ROW, IMM, "");                                                                  \
+        else W16_STORE2_(S1, S2, ROW, IMM, " nt");                                                                              \
     } while (0)
 #define W16_SWAP_STORE(A0, A1, ROW, IMM)                                                                                        \
     do {                                                                                                                        \
@@ -530,6 +536,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                     }
 #undef W16_SWAP_STORE
 #undef W16_STORE2
+#undef W16_STORE2_
 #undef W16_SEL_
                     if (HEADS) {  // D[head][row] += over each piece's 32 columns: hi and lo head terms (X3: and the lo activations)
 #pragma unroll
