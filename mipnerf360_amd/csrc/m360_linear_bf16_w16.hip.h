@@ -60,6 +60,10 @@ constexpr int kThreads = 256;
 constexpr int kXBytes = 256 * 128;           // activation rows of one stage
 constexpr int kStageBytes = 2 * kXBytes;     // + weight rows
 constexpr int kMaxBias = 4096;
+#ifndef M360_W16_ACC_V_BLOCKS
+#define M360_W16_ACC_V_BLOCKS 3
+#endif
+constexpr int kAccVBlocks = M360_W16_ACC_V_BLOCKS;  // activation blocks (of 8) whose accumulators live in ArchVGPRs (W16_ACC_V)
 
 struct cursor_t { __amdgpu_buffer_rsrc_t rsrc; int k; int tile; };  // an LDS-DMA cursor: descriptor of its tile, byte offset in a row
 
@@ -113,6 +117,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     // X3 loop + plain bf16 output: the first layer of the bf16 mode (two-term features and weights in, one bf16 term out)
     static_assert(SPLIT == X3 || HEADS == 0, "X3 loop and split output go together wherever the heads are fused");
     constexpr bool STORE_Y = HEADS == 0;
+    // accumulators in ArchVGPRs (W16_ACC_V): not in the plain 64-deep form, whose single stage keeps more fragments live (256 ArchVGPRs + spills)
+    constexpr int kAccV = (ONE_BLOCK && !X3) ? 0 : kAccVBlocks;
     // vector-memory operations of a tile's epilogue: 32 whole-line stores (64 as [hi | lo]) or, with fused heads, 8 partial-sum stores
     constexpr int W16_STORES = STORE_Y ? (SPLIT ? 64 : 32) : 8;
     static_assert(ACT == M360_ACT_NONE || ACT == M360_ACT_RELU || (ACT == M360_ACT_SIGMOID && (ABL != 0 || HEADS > 0)), "bias + {none, ReLU}; sigmoid with fused heads");
@@ -227,8 +233,20 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
 // The MFMAs are inline assembly with the accumulator tied to an AccVGPR ("+a"): with the builtin the register allocator kept half
 // of the 64 accumulator tuples in ArchVGPRs across the stage bodies and copied them in and out around every MFMA (4 v_accvgpr_write
 // + s_nop per MFMA in the K loop).  The hazard recogniser does not see these MFMAs: the epilogue waits out the last one itself.
-#define W16_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
-#define W16_MFMA_Z(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(A), "v"(B))
+// Where the 256 accumulators live: activation blocks [0, 8 - kAccVBlocks) in AccVGPRs, the last kAccVBlocks blocks (8 tuples each) in
+// ArchVGPRs - the kernel needs ~130 of the 256 ArchVGPRs for everything else, and an accumulator the epilogue finds in an ArchVGPR costs
+// it no v_accvgpr_read_b32 (one issue slot each, tools/valu_issue_probe.hip).  MFMA C and D share a register file: the tuple's own.
+#define W16_ACC_V(I) ((I) >= 8 - kAccV)
+#define W16_MFMA(I, J, A, B)                                                                                                  \
+    do {                                                                                                                      \
+        if constexpr (W16_ACC_V(I)) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[I][J]) : "v"(A), "v"(B)); \
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[I][J]) : "v"(A), "v"(B));                      \
+    } while (0)
+#define W16_MFMA_Z(I, J, A, B)                                                                                                \
+    do {                                                                                                                      \
+        if constexpr (W16_ACC_V(I)) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(acc[I][J]) : "v"(A), "v"(B)); \
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc[I][J]) : "v"(A), "v"(B));                       \
+    } while (0)
 // the fragments a wait has just covered are in/out operands of it, so no use can be scheduled above it
 #define W16_TIE_HI "+v"(fx[4]), "+v"(fx[5]), "+v"(fx[6]), "+v"(fx[7])
 #define W16_WAIT_HI() asm volatile("s_waitcnt lgkmcnt(0)" : W16_TIE_HI::"memory")
@@ -348,9 +366,20 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         if (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e0)::"memory");
         // the last MFMAs (inline assembly: the hazard recogniser does not see them) have written their accumulators before anything
         // reads them: the 8 tuples of the last 8 MFMAs are redefined by this statement, every other tuple is >= 128 cycles old
-        asm volatile("s_nop 15\n\ts_nop 15"
-                     : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
-                       "+a"(acc[7][6]), "+a"(acc[7][7])::"memory");
+        if constexpr (W16_ACC_V(7))
+            asm volatile("s_nop 15\n\ts_nop 15"
+                         : "+v"(acc[7][0]), "+v"(acc[7][1]), "+v"(acc[7][2]), "+v"(acc[7][3]), "+v"(acc[7][4]), "+v"(acc[7][5]),
+                           "+v"(acc[7][6]), "+v"(acc[7][7])::"memory");
+        else
+            asm volatile("s_nop 15\n\ts_nop 15"
+                         : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]),
+                           "+a"(acc[7][6]), "+a"(acc[7][7])::"memory");
+        // the other accumulators that live in ArchVGPRs are ordinary values to the compiler, whose uses it may hoist: pin them behind the
+        // statement above (an MFMA result read too early is a software hazard, not an interlock)
+#pragma unroll
+        for (int i = 8 - kAccV; i < 7; ++i)
+            asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]), "+v"(acc[i][4]), "+v"(acc[i][5]),
+                              "+v"(acc[i][6]), "+v"(acc[i][7]));
         if (LDSEPI && !(ABL & 32)) {
             const __bf16 *yt = Y + (m0 + wm * 128) * ldy + n0 + wn * 128;  // wave-uniform corner of the wave tile
             // wave-private staging tile: 16 rows x 256 B; 16-byte chunk c of row r lives in slot c ^ r
@@ -434,6 +463,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                         // explicit AccVGPR reads, one (activation block, piece) at a time: left to the register allocator, 150 of
                         // the 256 accumulators were copied out at the top of the epilogue and an address register was spilled
                         f32x4 v, w;
+                        if (W16_ACC_V(i)) { v = acc[i][2 * p]; w = acc[i][2 * p + 1]; }  // already in ArchVGPRs
+                        else
                         asm volatile("v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %1, %9\n\tv_accvgpr_read_b32 %2, %10\n\t"
                                      "v_accvgpr_read_b32 %3, %11\n\tv_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\t"
                                      "v_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15"

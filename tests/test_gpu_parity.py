@@ -549,6 +549,13 @@ def test_paired_rows_out_of_the_first_layers(dev, M, width):
     x6 = ops.split_bf16x6(x.to(dev))
     assert ops.rows_pairable(_lib.PAIRABLE_SPLIT, width, 384)
     assert torch.equal(ops.pair_rows(ops.linear_bf16_split(x6, w6, b6, RELU | OUT)), ops.linear_bf16_split(x6, w6, b6, RELU))
+    # round 3's plain 64-deep first layer (m360_linear_bf16 on bf16 features): the same kernel form, still reachable through the C-ABI
+    w1, b1 = ops.pack_linear_bf16(w, b, width, 64)
+    x1 = x.to(dev).bfloat16()
+    assert ops.rows_pairable(_lib.PAIRABLE_LINEAR, width, 64)
+    assert torch.equal(ops.pair_rows(ops.linear_bf16(x1, w1, b1, RELU | OUT)), ops.linear_bf16(x1, w1, b1, RELU))
+    with pytest.raises(RuntimeError, match="first layers"):
+        ops.linear_bf16(x1, w1, b1, RELU | _lib.ROWS_PAIRED_IN)
 
 
 def test_paired_rows_are_refused_where_no_kernel_takes_them(dev):

@@ -117,7 +117,7 @@ def stage(B, kind, vm):
             for m in range(32):
                 ib, jb = (4 * half + m // 8, m % 8) if not JB_OUTER else (4 * half + m % 4, m // 4)
                 z = "_Z" if (kind in ("Z", "ZL") and kk == 0) else ""
-                L.append(f"    W16_MFMA{z}(acc[{ib}][{jb}], fw{cur}[{jb}], fx[{ib}]);")
+                L.append(f"    W16_MFMA{z}({ib}, {jb}, fw{cur}[{jb}], fx[{ib}]);")
                 if m in read_gaps:
                     L.append(f"    {reads[read_gaps[m]]};")
                 if m in dma:
@@ -249,7 +249,7 @@ def x3_stage(t, variant, vm, at=None):
             for m in range(32):
                 ib, jb = 4 * half + m // 8, m % 8
                 z = "_Z" if (variant == "Z" and kk == 0) else ""
-                L.append(f"    W16_MFMA{z}(acc[{ib}][{jb}], fw{cur}[{jb}], fx[{ib}]);")
+                L.append(f"    W16_MFMA{z}({ib}, {jb}, fw{cur}[{jb}], fx[{ib}]);")
                 if m in read_gaps:
                     L.append(f"    {reads[read_gaps[m]]};")
                 if m in dma:
