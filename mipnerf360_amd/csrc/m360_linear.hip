@@ -915,6 +915,8 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
             case 37: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 16, true, false, false, 0, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // variant 137: ... without its stores
             case 40: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, true, false, false, 0, false, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, 1); break;   // variant 140: paired rows in and out (y comes out paired, x is read as if it were)
             case 41: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 16, true, false, false, 0, false, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, 1); break;  // variant 141: ... without the stores
+            case 46: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 16384, true, false, false, 0, false, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, 1); break;  // variant 146: paired rows, epilogue of stores only
+            case 47: M360_W16_ABL(16384, true); break;       // variant 147: plain rows, epilogue of exchange + stores only
             case 42: M360_W16_ABL(4096, true); break;        // variant 142: agent-scope non-temporal stores (sc1 nt)
             case 43: M360_W16_ABL(4096 + 128, true); break;  // variant 143: agent-scope stores (sc1)
             case 44: M360_W16_ABL(8192, true); break;        // variant 144: system-scope non-temporal stores (sc0 sc1 nt)

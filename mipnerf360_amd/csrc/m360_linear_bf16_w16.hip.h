@@ -74,7 +74,7 @@ __device__ unsigned long long g_w16_stamps[256 * 4];
 // ABL (diagnostic builds; results are wrong unless 0 or 64): 1 = no barrier, 2 = no LDS-DMA, 4 = no fragment reads, 16 = no stores,
 // 32 = no epilogue at all, 64 = wait for every outstanding operation at the end of the epilogue (how long do the stores take?),
 // 128 = plain instead of non-temporal stores (results correct), 1024 = no counted vmcnt waits in the K loop (wrong results),
-// 4096 / 8192 = agent- / system-scope stores (results correct)
+// 4096 / 8192 = agent- / system-scope stores (results correct), 16384 = epilogue of stores only (no AccVGPR reads, no packing)
 // X3 ("bf16x3", m360_linear_bf16_pp.hip.h): activations [hi(K) | lo(K)], weights [Wh | Wh | Wl] (rows of Kp = 3K), output
 // [hi(Np) | lo(Np)]; per 64-deep block three stages xl wh -> xh wh -> xh wl that share an operand with their neighbour
 // (tools/gen_w16_slab.py, second half): 4 operand tiles staged per block instead of 6, the same accumulation order as the ping-pong
@@ -463,6 +463,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                         // explicit AccVGPR reads, one (activation block, piece) at a time: left to the register allocator, 150 of
                         // the 256 accumulators were copied out at the top of the epilogue and an address register was spilled
                         f32x4 v, w;
+                        if (ABL & 16384) {  // diagnostics (wrong results): no reads, no packing - what do the tile's stores alone take?
+                            ab[h] = lo[h] = (u32x4){(unsigned)lane, (unsigned)lane, (unsigned)lane, (unsigned)lane};
+                            continue;
+                        }
                         if (W16_ACC_V(i)) { v = acc[i][2 * p]; w = acc[i][2 * p + 1]; }  // already in ArchVGPRs
                         else
                         asm volatile("v_accvgpr_read_b32 %0, %8\n\tv_accvgpr_read_b32 %1, %9\n\tv_accvgpr_read_b32 %2, %10\n\t"
