@@ -24,10 +24,11 @@ M_BENCH, N_BENCH = 4096 * 128, 1024
 
 
 def one(pattern):
+    """the NEWEST match: gpurun merges every call's files into gpurun_out/<tag>, so older runs of the same step lie next to it"""
     hits = glob.glob(pattern)
     if not hits:
         raise SystemExit(f"missing {pattern}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)
 
 
 def durations(d):
@@ -216,8 +217,10 @@ def bf16_ring_counters(src):
         if not fs:
             return None
         acc = collections.defaultdict(dict)
-        for r in csv.DictReader(open(fs[0])):
-            if any(k in r["Kernel_Name"] for k in ("w16_kernel<1, 0, false, false, false, 0, false, false>", "w16_kernel<1, 0, false, false, false, 0, false>", "w16_kernel<1, 0, false, false, false, 0>")):
+        for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
+            # the ReLU hidden layers: <ACT = 1, ABL = 0, no stamps, no X3, not ONE_BLOCK, no heads, no split, no LDS epilogue[, paired rows or not]>
+            if any(k in r["Kernel_Name"] for k in ("w16_kernel<1, 0, false, false, false, 0, false, false, true>", "w16_kernel<1, 0, false, false, false, 0, false, false, false>",
+                                                   "w16_kernel<1, 0, false, false, false, 0, false, false>", "w16_kernel<1, 0, false, false, false, 0, false>", "w16_kernel<1, 0, false, false, false, 0>")):
                 acc[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
                 acc[r["Dispatch_Id"]]["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         return [x for x in acc.values() if x["_ns"] > 600000]   # the NeRF layers (the 256-wide proposal layers are 7 x shorter)
