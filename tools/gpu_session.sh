@@ -94,6 +94,9 @@ PYEOF
     chain256) timeout 600 python tools/mlp_chain_bench.py --dtype bf16 --width 256 --layers 3 --blocks 0,262144,131072,65536,32768 --rounds 7 --json $out/mlp_chain_row_blocks_w256.jsonl > $out/mlp_chain_w256.log 2>&1; cut -c1-300 $out/mlp_chain_w256.log | grep -v amdgpu.ids ;;
     storeonly) for v in 146 140 141 146; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/bf16_w16_store_only_epilogue.jsonl > $out/linear_bf16_so_$v.log 2>&1; tail -1 $out/linear_bf16_so_$v.log | cut -c1-400; done ;;
     ldpad16) for pad in 0 64 128 32 0; do for v in 146 140; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --ld-pad $pad --no-check --rounds 5 --json $out/bf16_w16_ld_pad.jsonl > $out/linear_bf16_ldpad_${v}_$pad.log 2>&1; tail -1 $out/linear_bf16_ldpad_${v}_$pad.log | cut -c1-330; done; done ;;
+    soak)    timeout 900 python tools/diag/w16_soak.py --shapes 60 > $out/w16_soak.log 2>&1; tail -2 $out/w16_soak.log
+             timeout 900 python tools/diag/w16_soak.py --shapes 40 --special --seed 7 > $out/w16_soak_special.log 2>&1; tail -2 $out/w16_soak_special.log
+             timeout 900 python tools/diag/w16_soak.py --shapes 40 --x3 --seed 3 > $out/w16_soak_x3.log 2>&1; tail -2 $out/w16_soak_x3.log ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
