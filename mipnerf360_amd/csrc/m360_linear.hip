@@ -320,6 +320,7 @@ static int launch_linear_hd(const float *x, long M, int ldx, const float *w_pack
 #ifdef M360_DIAG
 // diagnostics build only (A/B of the two kernels): 0 = the rule, 1 = 256 x 256, 2 = half tiles; M360_DIAG_FORCE_KERNEL presets it
 static int g_diag_force_kernel = [] { const char *e = getenv("M360_DIAG_FORCE_KERNEL"); return e ? atoi(e) : 0; }();
+static int g_diag_stagger = [] { const char *e = getenv("M360_DIAG_STAGGER"); return e ? atoi(e) : 0; }();  // ring kernel, variant 140: start stagger (x ~1 k cycles per row-block phase)
 #endif
 static bool prefer_half_tiles(long M, int n_pad, int k_pad, int act) {
     if ((act != M360_ACT_NONE && act != M360_ACT_RELU) || n_pad % hd::BN != 0 || n_pad > hd::kMaxBias || k_pad < 2 * hd::BK || M < hd::BM) return false;
@@ -913,9 +914,10 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
             case 35: M360_W16_ABL(2048 + 128, true); break;  // variant 135: the same with plain (temporal) stores
             case 36: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, true, false, false, 0, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // variant 136: the LDS epilogue, stamped (results correct)
             case 37: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 16, true, false, false, 0, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // variant 137: ... without its stores
-            case 40: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, true, false, false, 0, false, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, 1); break;   // variant 140: paired rows in and out (y comes out paired, x is read as if it were)
+            case 40: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, true, false, false, 0, false, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, 1, g_diag_stagger); break;   // variant 140: paired rows in and out (y comes out paired, x is read as if it were)
             case 41: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 16, true, false, false, 0, false, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, 1); break;  // variant 141: ... without the stores
             case 46: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 16384, true, false, false, 0, false, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, 1); break;  // variant 146: paired rows, epilogue of stores only
+            case 48: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 16384 + 128, true, false, false, 0, false, false, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, 1); break;  // variant 148: ... of plain (temporal) stores only
             case 47: M360_W16_ABL(16384, true); break;       // variant 147: plain rows, epilogue of exchange + stores only
             case 42: M360_W16_ABL(4096, true); break;        // variant 142: agent-scope non-temporal stores (sc1 nt)
             case 43: M360_W16_ABL(4096 + 128, true); break;  // variant 143: agent-scope stores (sc1)

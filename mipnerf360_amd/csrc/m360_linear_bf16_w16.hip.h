@@ -109,7 +109,7 @@ template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BL
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, const float *__restrict__ head_w = nullptr,
-    float *__restrict__ head_part = nullptr, int xpair = 0) {
+    float *__restrict__ head_part = nullptr, int xpair = 0, int stagger = 0) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0) + (LDSEPI ? 4 * 4096 : 0)];  // 144 (160) KiB
     static_assert(!LDSEPI || (HEADS == 0 && !SPLIT && !X3 && !PAIR), "the LDS epilogue: plain bf16 output (its 16 KiB sit where the head rows would)");
     static_assert(!PAIR || HEADS == 0, "paired rows are a layout of the layer's own output");
@@ -143,6 +143,15 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     };
     int tile_id = blockIdx.x;
     if (tile_id >= ntiles) return;
+#ifdef M360_DIAG
+    // diagnostics (round 4): start the eight row blocks an XCD works on at once `stagger` x ~1 k cycles apart (the four column tiles of a
+    // row block stay together: they share its activation rows through the L2), so that the 256 CUs do not store their tiles in the same
+    // microseconds - does the epilogue's store floor (32 MB from all CUs at once) give way?
+    if (stagger > 0) {
+        const int phase = ((blockIdx.x >> 3) / tiles_n) & 7;
+        for (int i = 0; i < phase * stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
 
     // ---- LDS-DMA: 8 activation + 8 weight pieces of 8 rows x 128 B per wave and stage.  Weight rows [64w, 64w + 64).  Activation
     // rows: 32 "lo" rows (blocks 0-3 of a wave tile: pieces 0-3) + 32 "hi" rows (blocks 4-7: pieces 4-7) of wave-tile row

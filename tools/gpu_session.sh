@@ -97,6 +97,8 @@ PYEOF
     soak)    timeout 900 python tools/diag/w16_soak.py --shapes 60 > $out/w16_soak.log 2>&1; tail -2 $out/w16_soak.log
              timeout 900 python tools/diag/w16_soak.py --shapes 40 --special --seed 7 > $out/w16_soak_special.log 2>&1; tail -2 $out/w16_soak_special.log
              timeout 900 python tools/diag/w16_soak.py --shapes 40 --x3 --seed 3 > $out/w16_soak_x3.log 2>&1; tail -2 $out/w16_soak_x3.log ;;
+    stagger) for st in 0 3 6 0 6 12; do M360_DIAG_STAGGER=$st timeout 300 python tools/linear_bench.py --dtype bf16 --variant 140 --no-check --rounds 7 > $out/linear_bf16_stagger_$st.log 2>&1; echo "stagger $st: $(tail -1 $out/linear_bf16_stagger_$st.log | cut -c1-330)" | tee -a $out/bf16_w16_start_stagger.txt; done ;;
+    storeonly2) for v in 146 148 146 148; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/bf16_w16_store_only_plain_vs_nt.jsonl > $out/linear_bf16_so2_$v.log 2>&1; tail -1 $out/linear_bf16_so2_$v.log | cut -c1-400; done ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
