@@ -111,6 +111,10 @@ def parse_args(argv=None):
                          "then says so in config.workload")
     ap.add_argument("--no-named", action="store_true",
                     help="c2 / fp32 / 1 GPU only: skip the `named_workloads` block (the other single-GPU configs, a few steps each)")
+    ap.add_argument("--row-blocks", type=int, default=None, metavar="ROWS",
+                    help="(diagnostics, bf16 modes) m360_set_row_blocks: 0 = layer by layer, -1 = automatic (default), > 0 rows per block; "
+                         "the line then carries config.row_blocks")
+    ap.add_argument("--row-block-streams", type=int, default=None, choices=(1, 2), help="(diagnostics) m360_set_row_block_streams")
     ap.add_argument("--plain-rows", action="store_true",
                     help="(diagnostics, bf16 modes) m360_set_paired_rows(0): plain instead of paired rows between the layers - same bits; "
                          "the line then carries config.plain_rows")
@@ -285,10 +289,14 @@ class Comm:
 def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
     lin_kind = _lib.K_LINEAR_BF16 if bf16 else _lib.K_LINEAR
     kk = 3 * HN if x3 else HN  # bf16x3: one contraction of length 3K (xh wh + xl wh + xh wl)
-    durs = [r["ms"] for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == kk and r["M"] == S]
-    if not durs:
+    # the 1024 x 1024 layers: one launch over all S rows, or (bf16 modes, m360_set_row_blocks) one per block of rows - all of one size but a
+    # shorter last one, which is left out
+    hits = [r for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == kk]
+    if not hits:
         return None
-    flops = 2.0 * S * HN * kk  # what the matrix pipe executes (bf16x3: three times the layer's algorithmic FLOPs)
+    rows = max(r["M"] for r in hits)
+    durs = [r["ms"] for r in hits if r["M"] == rows]
+    flops = 2.0 * rows * HN * kk  # what the matrix pipe executes (bf16x3: three times the layer's algorithmic FLOPs)
     avg_ms = sum(durs) / len(durs)
     achieved = flops / (avg_ms * 1e-3) / 1e12
     traffic, traffic_note = None, None
@@ -312,7 +320,7 @@ def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
             traffic_note = "profiles/traffic.json (bf16_ring_kernel) was measured on different kernel sources (stale): not reported"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     kname = ("linear_bf16_w16_kernel<X3> (bf16x3: 3 MFMA passes per product)" if x3 else "linear_bf16_w16_kernel") if bf16 else "linear_f32_hd_kernel"
-    roofline = {"bound": "mfma", "kernel": f"{kname} (1024x1024 layer, M={S})", "achieved": round(achieved, 2),
+    roofline = {"bound": "mfma", "kernel": f"{kname} (1024x1024 layer, M={rows}" + (f": row blocks of the {S} rows" if rows != S else "") + ")", "achieved": round(achieved, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),
                 "median_launch_ms": round(statistics.median(durs), 4), "flops_per_launch": flops}
@@ -341,10 +349,12 @@ def hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib, x3=False):
         return fused * slots * heads * 4 + (S - fused) * width * el
 
     out = {}
-    fused_last = [r["ms"] for r in recs if r["kind"] == _lib.K_LINEAR_HEADS and r["n_pad"] == HN and r["M"] == S]
-    if fused_last:
+    heads_recs = [r for r in recs if r["kind"] == _lib.K_LINEAR_HEADS and r["n_pad"] == HN]
+    if heads_recs:  # one launch over all rows, or one per row block (the shorter last block left out)
+        rows = max(r["M"] for r in heads_recs)
+        fused_last = [r["ms"] for r in heads_recs if r["M"] == rows]
         ms = sum(fused_last) / len(fused_last)
-        out["nerf_last_layer_fused_heads"] = {"avg_launch_ms": round(ms, 4), "tflops": round(2.0 * S * HN * HN / ms / 1e9, 1),
+        out["nerf_last_layer_fused_heads"] = {"avg_launch_ms": round(ms, 4), "rows": rows, "tflops": round(2.0 * rows * HN * HN / ms / 1e9, 1),
                                               "launches": len(fused_last), "note": "MFMA-bound; listed for completeness"}
     for kind, name, nbytes in (
             # feature rows: fp32 [in_pad] and the bf16 mode's [hi | lo] pairs: 4 bytes per value; bf16x3: x6 rows (three bf16 terms, six blocks: 12)
@@ -449,7 +459,7 @@ def timed_forward(model, rays, steps, warm, _lib, torch):
     with torch.no_grad():
         for _ in range(warm):
             model(rays)
-        prof = _lib.Prof(48 * max(steps, 1))
+        prof = _lib.Prof(800 * max(steps, 1))
         model.set_prof(prof)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -600,6 +610,10 @@ def worker(args):
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     if args.plain_rows:
         _lib.lib().m360_set_paired_rows(0)
+    if args.row_blocks is not None:
+        _lib.lib().m360_set_row_blocks(args.row_blocks)
+    if args.row_block_streams is not None:
+        _lib.lib().m360_set_row_block_streams(args.row_block_streams)
     ndev = torch.cuda.device_count()
     # one GPU per rank.  With fewer devices than ranks the ranks wrap around: RCCL then refuses the duplicate device
     # with its own error (the gloo diagnostics backend lets ranks share a GPU).
@@ -676,7 +690,7 @@ def worker(args):
 
         for _ in range(warmup):
             step()
-        prof = _lib.Prof(40 * max(steps, 1))  # caller-owned HIP-event recorder: every kernel of the stage drivers
+        prof = _lib.Prof(800 * max(steps, 1))  # caller-owned HIP-event recorder: every kernel of the stage drivers
         model.set_prof(prof)
         comm.fence()
         t0 = time.perf_counter()
@@ -709,6 +723,10 @@ def worker(args):
                           "whole_path_tflops": round(value * FLOPS_PER_SAMPLE * samples / 1e12, 2)}
         if args.plain_rows:
             line["config"]["plain_rows"] = True
+        if args.row_blocks is not None:
+            line["config"]["row_blocks"] = args.row_blocks
+        if args.row_block_streams is not None:
+            line["config"]["row_block_streams"] = args.row_block_streams
         if per_rank:
             line["per_rank"] = per_rank
 

@@ -52,6 +52,11 @@ enum { M360_ACT_NONE = 0, M360_ACT_RELU = 1, M360_ACT_SIGMOID = 2, M360_ACT_RELU
 #define M360_ROWS_PAIRED_IN 0x100
 #define M360_ROWS_PAIRED_OUT 0x200
 #define M360_ROWS_PAIRED_MASK 0x300
+/* With M360_ROWS_PAIRED_OUT: temporal instead of non-temporal output stores - for a caller that runs a BLOCK of rows through all layers of
+ * an MLP before the next block, so that the block's ping / pong pair stays in the 256 MiB Infinity Cache between the layer that writes it
+ * and the layer that reads it (non-temporal stores stream past it; what m360_nerf_forward / m360_forward do in the bf16 modes, below). */
+#define M360_STORES_TEMPORAL 0x400
+#define M360_ACT_FLAGS_MASK 0x700
 enum { M360_PAIRABLE_LINEAR = 0 /* m360_linear_bf16 */, M360_PAIRABLE_X3 = 1 /* m360_linear_bf16x3 */, M360_PAIRABLE_SPLIT = 2 /* m360_linear_bf16_split */,
        M360_PAIRABLE_X3_BF16OUT = 3 /* m360_linear_bf16x3_bf16out */, M360_PAIRABLE_HEADS = 4 /* m360_linear_heads_bf16 */, M360_PAIRABLE_HEADS_X3 = 5 /* m360_linear_heads_bf16x3 */ };
 
@@ -233,6 +238,17 @@ int m360_linear_bf16_rows_pairable(int kind, int n_pad, int k_pad);
 /* m360_forward / m360_prop_forward / m360_nerf_forward (bf16 modes) use paired rows between the layers of an MLP whose layers are all
  * pairable; 0 switches that off process-wide (diagnostics: A/B on one box - the outputs are the same bits), returns the old setting */
 int m360_set_paired_rows(int on);
+/* Row blocks of the NeRF MLP in the bf16 modes (paired rows only): m360_forward / m360_nerf_forward run blocks of rows through all eight
+ * layers, block after block, on the SAME ping / pong rows with temporal stores (M360_STORES_TEMPORAL): the hidden activations then live in
+ * the Infinity Cache instead of making a round trip through HBM per layer (model.py:131-158: the layers are row-independent; same bits).
+ * rows: 0 = off (default: one launch per layer over all rows), -1 = automatic (bf16 mode: pairs of 192 MiB in all, e.g. 49152 rows of
+ * 1024 bf16, when the batch has at least two blocks), > 0 = this many rows per block (a multiple of 256).  Returns the old setting.
+ * Measured (profiles/r04): the layers run 7 % faster per row and the additional launches take it back - a switch for experiments. */
+long m360_set_row_blocks(long rows);
+/* With row blocks on - 2 (default): odd row blocks run on a second, library-owned stream (forked from and joined to the caller's stream with events; their
+ * own ping / pong rows), so that one block's kernels fill the ~7 us between two dependent kernels of the other; 1: all blocks on the
+ * caller's stream.  The automatic block size halves with 2 (the two pairs together stay 192 MiB).  Returns the old setting. */
+int m360_set_row_block_streams(int n);
 int m360_linear_bf16x3_bf16out(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M, int ldx, const void *w_packed3_bf16,
                                const float *b_packed, int n_pad, int k_pad, int act, void *y_bf16 /*[M, ldy >= n_pad]*/, int ldy,
                                m360_stream_t stream);

@@ -17,7 +17,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 M360_OK = 0
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 # include/m360.h: "paired rows" flags (OR-ed into act of the bf16 linear calls) and the call kinds of m360_linear_bf16_rows_pairable
-ROWS_PAIRED_IN, ROWS_PAIRED_OUT = 0x100, 0x200
+ROWS_PAIRED_IN, ROWS_PAIRED_OUT, STORES_TEMPORAL = 0x100, 0x200, 0x400
 PAIRABLE_LINEAR, PAIRABLE_X3, PAIRABLE_SPLIT, PAIRABLE_X3_BF16OUT, PAIRABLE_HEADS, PAIRABLE_HEADS_X3 = range(6)
 # record kinds of the event recorder (include/m360.h, "measurement")
 K_LINEAR, K_LINEAR_BF16, K_ENCODE, K_PROP_FINISH, K_NERF_FINISH, K_WGRAD, K_DGRAD, K_LINEAR_HEADS = range(8)
@@ -94,6 +94,8 @@ SIGNATURES = {
     "m360_linear_bf16x3_bf16out": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_linear_bf16_rows_pairable": (_i, [_i, _i, _i]),
     "m360_set_paired_rows": (_i, [_i]),
+    "m360_set_row_blocks": (_l, [_l]),
+    "m360_set_row_block_streams": (_i, [_i]),
     "m360_pack_linear_bf16x6": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear_bf16_split": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_encode_features_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),

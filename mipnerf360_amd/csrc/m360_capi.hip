@@ -185,6 +185,45 @@ static int p_linear(const m360_hyper_t *h, TileQueues *q, const float *x, long M
 static inline int first_row_format(int mode) { return mode == 2 ? 3 : (mode == 1 ? 2 : 0); }  // encoder row format of the MLP input
 // Paired rows (m360.h) between the layers of one bf16 / bf16x3 MLP: only when EVERY layer of it runs its full tiles on the one-wave ring
 // kernel - first layer out, hidden layers in and out, fused-heads last layer in (rendering forward: the tape-keeping one keeps plain rows)
+static long g_row_blocks = 0;  // m360_set_row_blocks: 0 off (default: no gain in the step, see nerf_row_block), -1 automatic, > 0 rows per block
+static int g_row_block_streams = 2;  // m360_set_row_block_streams
+extern "C" int m360_set_row_block_streams(int n) { const int was = g_row_block_streams; g_row_block_streams = n >= 2 ? 2 : 1; return was; }
+// The second stream of the row blocks (odd blocks): its own launches depend on each other, not on the other stream's, so one block's
+// kernels run in the ~7 us that lie between two dependent kernels of the other block.  Created on first use, for the device current then.
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; int device = -1; bool ok = false, tried = false; };
+static SideStream g_side;
+static SideStream *side_stream() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (!g_side.tried) {
+        g_side.tried = true;
+        g_side.device = dev;
+        g_side.ok = hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) == hipSuccess;
+        if (!g_side.ok) (void)hipGetLastError();
+    }
+    return (g_side.ok && g_side.device == dev) ? &g_side : nullptr;
+}
+extern "C" long m360_set_row_blocks(long rows) {
+    const long was = g_row_blocks;
+    g_row_blocks = rows < 0 ? -1 : (rows / 256) * 256;
+    return was;
+}
+// rows per block of the NeRF MLP in the bf16 modes (0: layer by layer): a ping / pong pair of 192 MiB - 49152 rows of 1024 bf16 measured
+// best in a chain of six hidden layers (tools/mlp_chain_bench.py --reuse, profiles/r04/mlp_chain_plain_vs_nt_blocks.log: 0.80 against
+// 0.85-0.89 ms per layer with 8 times the launches; 256 MiB pairs 0.80-0.81, 128 MiB 0.82; with non-temporal stores no gain) - and only when
+// the batch has at least two blocks.  In the rendering forward the kernels do run 7 % faster per row (1394 against 1300 TF), and the 80-160
+// additional launches take it all back (6.66-6.71 against 6.67 ms per forward at 4096 x 128, 26.35-26.7 against 26.45-26.48 at 8192 x 256,
+// one or two streams: profiles/r04/row_blocks_ab_no_recorder*.jsonl): OFF by default, kept as a switch (same bits, tested).
+static long nerf_row_block(long S, long row_bytes, int mode) {
+    long rows = g_row_blocks;
+    // automatic: the bf16 mode only - the bf16x3 layers do three times the matrix work per byte of activations and lose more to the
+    // shorter launches than they win (17.2 -> 19.6 ms per step with blocks of 24576 rows, profiles/r04)
+    if (rows < 0 && mode != 1) return 0;
+    if (rows < 0) rows = ((96l << 20) / (g_row_block_streams >= 2 ? 2 : 1) / row_bytes / 256) * 256;
+    return (rows >= 256 && S >= 2 * rows) ? rows : 0;
+}
 static int g_paired_rows = 1;  // m360_set_paired_rows: A/B of the two layouts (same bits either way)
 extern "C" int m360_set_paired_rows(int on) { const int was = g_paired_rows; g_paired_rows = on ? 1 : 0; return was; }
 static bool mlp_rows_pairable(int mode, int width, int in_pad) {
@@ -193,17 +232,18 @@ static bool mlp_rows_pairable(int mode, int width, int in_pad) {
     return m360_linear_bf16_rows_pairable(M360_PAIRABLE_X3_BF16OUT, width, in_pad) && m360_linear_bf16_rows_pairable(M360_PAIRABLE_LINEAR, width, width) && m360_linear_bf16_rows_pairable(M360_PAIRABLE_HEADS, width, width);
 }
 
-static int p_linear_first(const m360_hyper_t *h, int mode, const void *feat, long M, const void *w0, const float *b, int n_pad, int in_pad, void *y, int pair, m360_stream_t st) {
+static int p_linear_first(const m360_hyper_t *h, int mode, const void *feat, long M, const void *w0, const float *b, int n_pad, int in_pad, void *y, int pair, m360_stream_t st, int temporal = 0) {
     ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, (mode == 2 ? 6 : 3) * in_pad);
-    const int act = M360_ACT_RELU | (pair ? M360_ROWS_PAIRED_OUT : 0);
+    const int act = M360_ACT_RELU | (pair ? M360_ROWS_PAIRED_OUT : 0) | (temporal ? M360_STORES_TEMPORAL : 0);
     if (mode == 2) return ps.done(m360_linear_bf16_split(feat, M, 6 * in_pad, w0, b, n_pad, 6 * in_pad, act, y, 2 * n_pad, st));
     return ps.done(m360_linear_bf16x3_bf16out(feat, M, 2 * in_pad, w0, b, n_pad, in_pad, act, y, n_pad, st));
 }
 
 // mode 1: bf16 rows of k_pad / n_pad columns; mode 2 (bf16x3): [hi | lo] rows of 2 k_pad / 2 n_pad columns
-static int p_linear_bf16(const m360_hyper_t *h, int mode, const void *x, long M, const void *w, const float *b, int n_pad, int k_pad, int act, void *y, int pair, m360_stream_t st) {
+static int p_linear_bf16(const m360_hyper_t *h, int mode, const void *x, long M, const void *w, const float *b, int n_pad, int k_pad, int act, void *y, int pair, m360_stream_t st, int temporal = 0) {
     ProfScope ps(h, st, M360_K_LINEAR_BF16, M, n_pad, mode == 2 ? 3 * k_pad : k_pad);
     if (pair) act |= M360_ROWS_PAIRED_IN | M360_ROWS_PAIRED_OUT;
+    if (temporal) act |= M360_STORES_TEMPORAL;
     if (mode == 2) return ps.done(m360_linear_bf16x3(x, M, 2 * k_pad, w, b, n_pad, k_pad, act, y, 2 * n_pad, st));
     return ps.done(m360_linear_bf16(x, M, k_pad, w, b, n_pad, k_pad, act, y, n_pad, st));
 }
@@ -360,13 +400,49 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         const int mode = m->mlp_bf16;
         M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(mode), ext_norm ? 0 : h->norm_group_rays, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
         const int pair = mlp_rows_pairable(mode, hn, m->in_pad) ? 1 : 0;  // paired rows between the layers (m360.h)
+        const int ldl = mode == 2 ? 2 * hn : hn;
+        const long rb = pair ? nerf_row_block(S, (long)ldl * 2, mode) : 0;
+        if (rb > 0) {
+            // Row blocks (m360_set_row_blocks): all eight layers on rows [r0, r0 + rb) before the next block, every block on the SAME rows
+            // [0, rb) of the ping / pong buffers, temporal stores: the hidden activations stay in the Infinity Cache.  The features are read
+            // and the heads' partial sums written at the block's own rows; y of the fused-heads layer holds ragged rows only (last block).
+            const size_t feat_row = (size_t)m->in_pad * (mode == 2 ? 12 : 4);
+            const int slots = m360_linear_heads_slots_bf16(hn, hn, mode, 0);
+            // odd blocks on a second stream with their own ping / pong rows [rb, 2 rb) (m360_set_row_block_streams)
+            SideStream *side = g_row_block_streams >= 2 ? side_stream() : nullptr;
+            hipStream_t main_st = reinterpret_cast<hipStream_t>(st);
+            if (side && (hipEventRecord(side->fork, main_st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)) { (void)hipGetLastError(); side = nullptr; }
+            int rc_blocks = M360_OK;
+            long blk = 0;
+            for (long r0 = 0; r0 < S && rc_blocks == M360_OK; r0 += rb, ++blk) {
+                const long rows = S - r0 < rb ? S - r0 : rb;
+                const bool odd = side && (blk & 1);
+                m360_stream_t bst = odd ? reinterpret_cast<m360_stream_t>(side->s) : st;
+                float *ba = odd ? reinterpret_cast<float *>(reinterpret_cast<char *>(a) + (size_t)rb * ldl * 2) : a;
+                float *bb = odd ? reinterpret_cast<float *>(reinterpret_cast<char *>(b) + (size_t)rb * ldl * 2) : b;
+                rc_blocks = p_linear_first(h, mode, reinterpret_cast<const char *>(feat) + (size_t)r0 * feat_row, rows, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, ba, pair, bst, 1);
+                float *bs = ba, *bd = bb;
+                for (int layer = 1; layer < 7 && rc_blocks == M360_OK; ++layer) {
+                    rc_blocks = p_linear_bf16(h, mode, bs, rows, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, bd, pair, bst, 1);
+                    float *tmp = bs; bs = bd; bd = tmp;
+                }
+                char *yb = reinterpret_cast<char *>(b) + (size_t)r0 * ldl * 2;  // ragged rows of the batch at their own place in b
+                if (rc_blocks == M360_OK)
+                    rc_blocks = p_linear_heads(h, mode, bs, rows, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, yb, ldl, 0, m->nerf_head_w, 4, hpart + (size_t)r0 * slots * 4, bst, pair);
+            }
+            // the join is issued whatever happened: the caller's stream must not run ahead of work already queued on the second one
+            if (side && (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(main_st, side->join, 0) != hipSuccess))
+                return fail(M360_ERR_LAUNCH, "m360_nerf_forward: joining the row blocks' second stream failed: %s", hipGetErrorString(hipGetLastError()));
+            if (rc_blocks != M360_OK) return rc_blocks;
+            src = a; dst = b;
+        } else {
         M360_TRY(p_linear_first(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, a, pair, st));
         for (int layer = 1; layer < 7; ++layer) {
             M360_TRY(p_linear_bf16(h, mode, src, S, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, pair, st));
             float *tmp = src; src = dst; dst = tmp;
         }
-        const int ldl = mode == 2 ? 2 * hn : hn;
         M360_TRY(p_linear_heads(h, mode, src, S, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, ldl, 0, m->nerf_head_w, 4, hpart, st, pair));
+        }
         M360_TRY(p_nerf_finish_fused(h, dst, mode, ldl, hpart, m360_linear_heads_fused_rows(S, hn, mode), m360_linear_heads_slots_bf16(hn, hn, mode, 0), m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st, flags));
     } else {
     M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, feat, m->in_pad, 0, ext_norm ? 0 : h->norm_group_rays, ext_norm, 0, nullptr, ws + L.norm, m360_contract_workspace_bytes(), st));

@@ -490,8 +490,8 @@ static int linear_heads_bf16_any(const void *x, long M, int ldx, const void *w_p
                                  float *head_part, m360_stream_t stream, int x3) {
     const char *who = x3 ? "m360_linear_heads_bf16x3" : "m360_linear_heads_bf16";
     if (heads != 1 && heads != 4) return fail(M360_ERR_INVALID_ARGUMENT, "%s: heads=%d (1 or 4)", who, heads);
-    const int layout = act & M360_ROWS_PAIRED_MASK;  // paired INPUT rows (m360.h): where the one-wave ring kernel forms the heads
-    act &= ~M360_ROWS_PAIRED_MASK;
+    const int layout = act & M360_ACT_FLAGS_MASK;  // paired INPUT rows (m360.h): where the one-wave ring kernel forms the heads
+    act &= ~M360_ACT_FLAGS_MASK;
     if (act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "%s: the last hidden layer is a sigmoid layer, act=%d", who, act);
     if (layout && (layout != M360_ROWS_PAIRED_IN || store_y || !m360_linear_bf16_rows_pairable(x3 ? M360_PAIRABLE_HEADS_X3 : M360_PAIRABLE_HEADS, n_pad, k_pad)))
         return fail(M360_ERR_INVALID_ARGUMENT, "%s: paired rows: input only, store_y = 0, a shape of the one-wave ring kernel (n_pad=%d k_pad=%d)", who, n_pad, k_pad);
@@ -645,8 +645,10 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad, ldy=%d >= n_pad=%d, both multiples of 8", k_pad, pbf16::BK, ldx, ldy, n_pad);
     if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: pointers must be 16-byte aligned");
     const int layout = act & M360_ROWS_PAIRED_MASK;  // paired rows in / out (m360.h): the ring kernel's shapes only
-    act &= ~M360_ROWS_PAIRED_MASK;
+    const bool temporal = (act & M360_STORES_TEMPORAL) != 0;
+    act &= ~M360_ACT_FLAGS_MASK;
     if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: unknown activation %d", act);
+    if (temporal && !(layout & M360_ROWS_PAIRED_OUT)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: M360_STORES_TEMPORAL goes with M360_ROWS_PAIRED_OUT");
     if (layout && !m360_linear_bf16_rows_pairable(M360_PAIRABLE_LINEAR, n_pad, k_pad))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: paired rows with n_pad=%d k_pad=%d: not a shape of the one-wave ring kernel (m360_linear_bf16_rows_pairable)", n_pad, k_pad);
     if ((layout & M360_ROWS_PAIRED_OUT) && act != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: paired output rows: ReLU layers only (act=%d)", act);
@@ -669,7 +671,10 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
         if (w16_ok || w16_one) {
             dim3 grid((unsigned)(nt < cus ? nt : cus)), block(w16::kThreads);
 #define M360_W16(A, ONE, PR) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<A, 0, false, false, ONE, 0, false, false, PR>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, xin)
-            if (layout & M360_ROWS_PAIRED_OUT) { if (w16_one) M360_W16(M360_ACT_RELU, true, true); else M360_W16(M360_ACT_RELU, false, true); }
+            if (temporal) {
+                if (w16_one) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16: M360_STORES_TEMPORAL: hidden layers (k_pad >= %d)", M360_W16_MIN_K);
+                hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 128, false, false, false, 0, false, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, xin);
+            } else if (layout & M360_ROWS_PAIRED_OUT) { if (w16_one) M360_W16(M360_ACT_RELU, true, true); else M360_W16(M360_ACT_RELU, false, true); }
             else if (w16_one) { if (act == M360_ACT_RELU) M360_W16(M360_ACT_RELU, true, false); else M360_W16(M360_ACT_NONE, true, false); }
             else { if (act == M360_ACT_RELU) M360_W16(M360_ACT_RELU, false, false); else M360_W16(M360_ACT_NONE, false, false); }
 #undef M360_W16
@@ -721,7 +726,9 @@ int m360_linear_bf16_split(const void *x, long M, int ldx, const void *w_packed,
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: k_pad=%d must be a positive multiple of %d, ldx=%d >= k_pad, ldy=%d >= 2 n_pad=%d, all multiples of 8", k_pad, pbf16::BK, ldx, ldy, 2 * n_pad);
     if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: pointers must be 16-byte aligned");
     const int layout = act & M360_ROWS_PAIRED_MASK;  // paired OUTPUT rows (the input rows are the encoder's)
-    act &= ~M360_ROWS_PAIRED_MASK;
+    const bool temporal = (act & M360_STORES_TEMPORAL) != 0;
+    act &= ~M360_ACT_FLAGS_MASK;
+    if (temporal && !layout) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: M360_STORES_TEMPORAL goes with M360_ROWS_PAIRED_OUT");
     if (act != M360_ACT_NONE && act != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: activation %d (none or ReLU)", act);
     if (layout && (layout != M360_ROWS_PAIRED_OUT || act != M360_ACT_RELU || !m360_linear_bf16_rows_pairable(M360_PAIRABLE_SPLIT, n_pad, k_pad)))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16_split: paired rows: output only, ReLU, a shape of the one-wave ring kernel (n_pad=%d k_pad=%d)", n_pad, k_pad);
@@ -736,7 +743,8 @@ int m360_linear_bf16_split(const void *x, long M, int ldx, const void *w_packed,
         if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_linear_bf16_split: no HIP device");
         const long nt = (M_full / w16::BM) * (n_pad / w16::BN);
         dim3 grid((unsigned)(nt < cus ? nt : cus)), block(w16::kThreads);
-        if (layout) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, false, false, 0, true, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
+        if (temporal) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 128, false, false, false, 0, true, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
+        else if (layout) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, false, false, 0, true, false, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
         else if (act == M360_ACT_RELU) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, false, false, 0, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
         else hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_NONE, 0, false, false, false, 0, true>), grid, block, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt);
     }
@@ -772,7 +780,7 @@ int m360_linear_bf16x3(const void *x, long M, int ldx, const void *w_packed3, co
 
 int m360_linear_bf16x3_bf16out(const void *x, long M, int ldx, const void *w_packed3, const float *b_packed, int n_pad, int k_pad,
                                int act, void *y, int ldy, m360_stream_t stream) {
-    if ((act & ~M360_ROWS_PAIRED_MASK) != M360_ACT_NONE && (act & ~M360_ROWS_PAIRED_MASK) != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3_bf16out: activation %d (none or ReLU)", act);
+    if ((act & ~M360_ACT_FLAGS_MASK) != M360_ACT_NONE && (act & ~M360_ACT_FLAGS_MASK) != M360_ACT_RELU) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3_bf16out: activation %d (none or ReLU)", act);
     return linear_bf16x3_any(x, M, ldx, w_packed3, b_packed, n_pad, k_pad, act, y, ldy, stream, false);
 }
 
@@ -783,7 +791,9 @@ static int linear_bf16x3_any(const void *x, long M, int ldx, const void *w_packe
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: k_pad=%d must be a positive multiple of %d, ldx=%d >= 2 k_pad, ldy=%d >= %s n_pad=%d, all multiples of 8", k_pad, pbf16::BK, ldx, ldy, split_out ? "2" : "1", n_pad);
     if (((uintptr_t)x | (uintptr_t)w_packed3 | (uintptr_t)b_packed | (uintptr_t)y) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: pointers must be 16-byte aligned");
     const int layout = act & M360_ROWS_PAIRED_MASK;  // paired rows in / out (m360.h); the bf16-out first layer: out only
-    act &= ~M360_ROWS_PAIRED_MASK;
+    const bool temporal = (act & M360_STORES_TEMPORAL) != 0;
+    act &= ~M360_ACT_FLAGS_MASK;
+    if (temporal && !(layout & M360_ROWS_PAIRED_OUT)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: M360_STORES_TEMPORAL goes with M360_ROWS_PAIRED_OUT");
     if (act != M360_ACT_NONE && act != M360_ACT_RELU && act != M360_ACT_SIGMOID) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: unknown activation %d", act);
     if (layout && !m360_linear_bf16_rows_pairable(split_out ? M360_PAIRABLE_X3 : M360_PAIRABLE_X3_BF16OUT, n_pad, k_pad))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: paired rows with n_pad=%d k_pad=%d: not a shape of the one-wave ring kernel (m360_linear_bf16_rows_pairable)", n_pad, k_pad);
@@ -806,7 +816,11 @@ static int linear_bf16x3_any(const void *x, long M, int ldx, const void *w_packe
             dim3 blk(w16::kThreads);
 #define M360_W16X(A, ONE, SP) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<A, 0, false, true, ONE, 0, SP>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, xin)
 #define M360_W16XP(ONE, SP) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, true, ONE, 0, SP, false, true>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, xin)
-            if (layout & M360_ROWS_PAIRED_OUT) {
+#define M360_W16XT(ONE, SP) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 128, false, true, ONE, 0, SP, false, true>), grid, blk, 0, st, xb, M_full, ldx, wb, b_packed, n_pad, k3, yb, ldy, n_pad / w16::BN, (int)nt, nullptr, nullptr, xin)
+            if (temporal) {  // temporal stores: the hidden layers of the bf16x3 mode, the first layer of the bf16 mode
+                if (split_out) { if (k_pad == w16::BKS) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3: M360_STORES_TEMPORAL: k_pad > %d", w16::BKS); M360_W16XT(false, true); }
+                else { if (k_pad == w16::BKS) M360_W16XT(true, false); else M360_W16XT(false, false); }
+            } else if (layout & M360_ROWS_PAIRED_OUT) {
                 if (split_out) { if (k_pad == w16::BKS) M360_W16XP(true, true); else M360_W16XP(false, true); }
                 else { if (k_pad == w16::BKS) M360_W16XP(true, false); else M360_W16XP(false, false); }
             } else if (split_out) {
@@ -818,6 +832,7 @@ static int linear_bf16x3_any(const void *x, long M, int ldx, const void *w_packe
             }
 #undef M360_W16X
 #undef M360_W16XP
+#undef M360_W16XT
         } else if (!split_out) {
             return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_bf16x3_bf16out: no full-tile kernel for this shape");  // (unreachable: k_pad is a multiple of 64)
         } else

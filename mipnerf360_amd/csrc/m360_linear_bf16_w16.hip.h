@@ -60,6 +60,9 @@ constexpr int kThreads = 256;
 constexpr int kXBytes = 256 * 128;           // activation rows of one stage
 constexpr int kStageBytes = 2 * kXBytes;     // + weight rows
 constexpr int kMaxBias = 4096;
+#ifndef M360_W16_PLAIN_STORES
+#define M360_W16_PLAIN_STORES 0  // A/B builds: 1 = temporal instead of non-temporal output stores in every instantiation
+#endif
 #ifndef M360_W16_ACC_V_BLOCKS
 #define M360_W16_ACC_V_BLOCKS 3
 #endif
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         else if (ABL & 4096) W16_STORE2_(S1, S2, ROW, IMM, " sc1 nt");                                                          \
         else if ((ABL & 8192) && (ABL & 128)) W16_STORE2_(S1, S2, ROW, IMM, " sc0 sc1");                                        \
         else if (ABL & 8192) W16_STORE2_(S1, S2, ROW, IMM, " sc0 sc1 nt");                                                      \
-        else if (ABL & 128) W16_STORE2_(S1, S2, ROW, IMM, "");                                                                  \
+        else if ((ABL & 128) || M360_W16_PLAIN_STORES) W16_STORE2_(S1, S2, ROW, IMM, "");                                       \
         else W16_STORE2_(S1, S2, ROW, IMM, " nt");                                                                              \
     } while (0)
 #define W16_SWAP_STORE(A0, A1, ROW, IMM)                                                                                        \

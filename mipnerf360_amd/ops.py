@@ -552,6 +552,11 @@ def set_paired_rows(on: bool) -> bool:
     return bool(_lib.lib().m360_set_paired_rows(int(bool(on))))
 
 
+def set_row_blocks(rows: int) -> int:
+    """m360_set_row_blocks: rows per block of the NeRF MLP in the bf16 modes (0 off, -1 automatic, > 0 explicit); returns the old setting"""
+    return int(_lib.lib().m360_set_row_blocks(int(rows)))
+
+
 def linear_heads_bf16(x, w_packed, b_packed, head_w, store_y: bool = True, x3: bool = False, paired_in: bool = False):
     """The bf16 (x3 = False: m360_linear_heads_bf16) / bf16x3 (x3 = True: [hi | lo] pair rows, m360_linear_heads_bf16x3) last hidden
     layer with the heads formed on the matrix pipe -> (y, head_part[fused_rows, slots, heads] fp32, fused_rows)."""

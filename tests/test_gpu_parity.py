@@ -605,6 +605,60 @@ def test_forward_is_the_same_bits_with_and_without_paired_rows(dev, mode):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_forward_is_the_same_bits_with_and_without_row_blocks(dev, mode):
+    """m360_set_row_blocks: the NeRF MLP of the reduced-precision modes run block of rows after block of rows (all eight layers on
+    the same ping / pong rows, temporal stores) against layer by layer: the six outputs must not differ in a bit.  Blocks of 1024 and
+    2304 rows on 200 rays x 33 samples (6600 rows: ragged rows in the last block, which is shorter than the others) and the
+    automatic block size on 1024 rays x 128 samples (131072 rows: two blocks of 49152 + one of 32768 in bf16)."""
+    from mipnerf360_amd import _lib, ops
+    from mipnerf360_amd.model import mipNeRF360
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(256, 1024, seed=6).items()}
+    for B, N, settings in ((200, 33, (1024, 2304)), (1024, 128, (-1,))):
+        model = mipNeRF360(num_samples=N, hidden_proposal=256, hidden_nerf=1024, mlp_dtype=mode, device=dev, randomized=False).eval()
+        model.load_state_dict(sd)
+        rays = dev_rays(synthetic.make_rays("garden", B, seed=4), dev)
+        was = ops.set_row_blocks(0)
+        try:
+            with torch.no_grad():
+                want = [o.clone() for o in model(rays)]
+            for rows in settings:
+                for streams in (2, 1):  # odd blocks on the library's second stream, or all on the caller's
+                    ops.set_row_blocks(rows)
+                    was_streams = _lib.lib().m360_set_row_block_streams(streams)
+                    try:
+                        with torch.no_grad():
+                            got = model(rays)
+                    finally:
+                        _lib.lib().m360_set_row_block_streams(was_streams)
+                    for a, b in zip(got, want):
+                        assert torch.equal(a, b), (rows, streams)
+        finally:
+            ops.set_row_blocks(was)
+
+
+def test_temporal_stores_flag(dev):
+    """M360_STORES_TEMPORAL (what the row blocks use): the same rows as with non-temporal stores; refused without paired output rows."""
+    from mipnerf360_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1024, 256, generator=g).to(dev)
+    w = (torch.randn(512, 256, generator=g) * 0.1).to(dev)
+    b = torch.randn(512, generator=g).to(dev)
+    IN, OUT, T, RELU = _lib.ROWS_PAIRED_IN, _lib.ROWS_PAIRED_OUT, _lib.STORES_TEMPORAL, _lib.ACT_RELU
+    wp, bp = ops.pack_linear_bf16(w, b, 512, 256)
+    xb = x.bfloat16()
+    assert torch.equal(ops.linear_bf16(xb, wp, bp, RELU | OUT | T), ops.linear_bf16(xb, wp, bp, RELU | OUT))
+    w3, b3 = ops.pack_linear_bf16x3(w, b, 512, 256)
+    x3 = ops.split_bf16x3(x)
+    assert torch.equal(ops.linear_bf16x3(x3, w3, b3, RELU | OUT | T), ops.linear_bf16x3(x3, w3, b3, RELU | OUT))
+    assert torch.equal(ops.linear_bf16x3_bf16out(x3, w3, b3, RELU | OUT | T), ops.linear_bf16x3_bf16out(x3, w3, b3, RELU | OUT))
+    w6, b6 = ops.pack_linear_bf16x6(w[:, :58].contiguous(), b, 512, 64)
+    x6 = ops.split_bf16x6(torch.nn.functional.pad(x[:, :58], (0, 6)))
+    assert torch.equal(ops.linear_bf16_split(x6, w6, b6, RELU | OUT | T), ops.linear_bf16_split(x6, w6, b6, RELU | OUT))
+    with pytest.raises(RuntimeError, match="M360_STORES_TEMPORAL"):
+        ops.linear_bf16(xb, wp, bp, RELU | T)
+
+
 @pytest.mark.parametrize("M,n_out,k_in", [(700, 256, 58), (256 * 5 + 33, 1024, 58), (90, 96, 58), (1024, 256, 200)])
 def test_bf16_mode_first_layer_two_terms_in_one_out(dev, M, n_out, k_in):
     """m360_linear_bf16x3_bf16out: the first layer of the bf16 mode - [hi | lo] features, [Wh | Wh | Wl] weights, the three products of

@@ -54,6 +54,8 @@ def test_paired_rows_host_side(lib):
     assert q(_lib.PAIRABLE_HEADS, 1024, 1024) and q(_lib.PAIRABLE_HEADS_X3, 256, 256) and not q(_lib.PAIRABLE_HEADS, 2048, 1024) and not q(_lib.PAIRABLE_HEADS, 256, 128)
     assert not q(99, 1024, 1024)
     assert lib.m360_set_paired_rows(0) == 1 and lib.m360_set_paired_rows(1) == 0 and lib.m360_set_paired_rows(1) == 1
+    assert lib.m360_set_row_blocks(1000) == 0 and lib.m360_set_row_blocks(-5) == 768 and lib.m360_set_row_blocks(0) == -1 and lib.m360_set_row_blocks(0) == 0
+    assert lib.m360_set_row_block_streams(1) == 2 and lib.m360_set_row_block_streams(2) == 1
 
 
 def test_header_cites_reference_lines():

@@ -99,6 +99,19 @@ PYEOF
              timeout 900 python tools/diag/w16_soak.py --shapes 40 --x3 --seed 3 > $out/w16_soak_x3.log 2>&1; tail -2 $out/w16_soak_x3.log ;;
     stagger) for st in 0 3 6 0 6 12; do M360_DIAG_STAGGER=$st timeout 300 python tools/linear_bench.py --dtype bf16 --variant 140 --no-check --rounds 7 > $out/linear_bf16_stagger_$st.log 2>&1; echo "stagger $st: $(tail -1 $out/linear_bf16_stagger_$st.log | cut -c1-330)" | tee -a $out/bf16_w16_start_stagger.txt; done ;;
     storeonly2) for v in 146 148 146 148; do timeout 300 python tools/linear_bench.py --dtype bf16 --variant $v --no-check --rounds 5 --json $out/bf16_w16_store_only_plain_vs_nt.jsonl > $out/linear_bf16_so2_$v.log 2>&1; tail -1 $out/linear_bf16_so2_$v.log | cut -c1-400; done ;;
+    chainplain) for lib in libm360.so libm360_plainstores.so libm360.so libm360_plainstores.so; do echo "== $lib" | tee -a $out/mlp_chain_plain_vs_nt.log; M360_LIB=$PWD/mipnerf360_amd/$lib timeout 600 python tools/mlp_chain_bench.py --dtype bf16 --width 1024 --layers 6 --blocks 0,131072,65536,32768 --rounds 5 2>&1 | grep rows_per_block | cut -c1-300 | tee -a $out/mlp_chain_plain_vs_nt.log; done ;;
+    chainplain2) for mode in "" "--reuse"; do for lib in libm360_plainstores.so libm360.so; do echo "== $lib $mode" | tee -a $out/mlp_chain_plain_vs_nt_blocks.log; M360_LIB=$PWD/mipnerf360_amd/$lib timeout 600 python tools/mlp_chain_bench.py --dtype bf16 --width 1024 --layers 6 --blocks 0,131072,98304,65536,49152,32768 --rounds 5 $mode 2>&1 | grep rows_per_block | cut -c1-330 | tee -a $out/mlp_chain_plain_vs_nt_blocks.log; done; done ;;
+    chainplain3) for lib in libm360_plainstores.so libm360.so; do echo "== $lib --reuse width 256" | tee -a $out/mlp_chain_plain_vs_nt_blocks.log; M360_LIB=$PWD/mipnerf360_amd/$lib timeout 600 python tools/mlp_chain_bench.py --dtype bf16 --width 256 --layers 3 --blocks 0,262144,131072,65536 --rounds 7 --reuse 2>&1 | grep rows_per_block | cut -c1-330 | tee -a $out/mlp_chain_plain_vs_nt_blocks.log; done ;;
+    rbtests) timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "row_blocks or temporal or paired or g19 or bf16 or c5 or fused or soak" > $out/pytest_rowblocks.log 2>&1; echo "pytest rc=$?" >> $out/pytest_rowblocks.log; tail -12 $out/pytest_rowblocks.log | cut -c1-300 ;;
+    rbab)    for cfg in "--row-blocks 0" "--row-blocks 49152 --row-block-streams 1" "--row-blocks 24576 --row-block-streams 2" "--row-blocks 49152 --row-block-streams 2" "--row-blocks 32768 --row-block-streams 2" "--row-blocks 65536 --row-block-streams 2" "--row-blocks 0" "--row-blocks 24576 --row-block-streams 2"; do timeout 600 python bench.py --mlp-dtype bf16 --cpu-rays 0 --frame-steps 0 $cfg >> $out/row_blocks_ab.jsonl 2>> $out/row_blocks_ab.err; done
+             python3 - <<PYEOF
+import json
+for l in open("$out/row_blocks_ab.jsonl"):
+    d = json.loads(l); c = d["config"]; print(c.get("row_blocks"), c.get("row_block_streams"), d["ms_per_step"], d["ms_per_step_median"], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"], d["parity"] if "parity" in d else "")
+PYEOF
+             ;;
+    rbab2)   timeout 900 python tools/diag/row_blocks_ab.py > $out/row_blocks_ab_no_recorder.jsonl 2> $out/row_blocks_ab2.err; cat $out/row_blocks_ab_no_recorder.jsonl
+             timeout 900 python tools/diag/row_blocks_ab.py --c5 --iters 20 --configs 0:1,24576:2,49152:1,32768:2,0:1 > $out/row_blocks_ab_no_recorder_c5.jsonl 2>> $out/row_blocks_ab2.err; cat $out/row_blocks_ab_no_recorder_c5.jsonl ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
