@@ -459,7 +459,7 @@ def timed_forward(model, rays, steps, warm, _lib, torch):
     with torch.no_grad():
         for _ in range(warm):
             model(rays)
-        prof = _lib.Prof(800 * max(steps, 1))
+        prof = _lib.Prof(48 * max(steps, 1))
         model.set_prof(prof)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -690,7 +690,7 @@ def worker(args):
 
         for _ in range(warmup):
             step()
-        prof = _lib.Prof(800 * max(steps, 1))  # caller-owned HIP-event recorder: every kernel of the stage drivers
+        prof = _lib.Prof((800 if args.row_blocks else 48) * max(steps, 1))  # caller-owned HIP-event recorder: every kernel of the stage drivers
         model.set_prof(prof)
         comm.fence()
         t0 = time.perf_counter()
