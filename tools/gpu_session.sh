@@ -112,6 +112,29 @@ PYEOF
              ;;
     rbab2)   timeout 900 python tools/diag/row_blocks_ab.py > $out/row_blocks_ab_no_recorder.jsonl 2> $out/row_blocks_ab2.err; cat $out/row_blocks_ab_no_recorder.jsonl
              timeout 900 python tools/diag/row_blocks_ab.py --c5 --iters 20 --configs 0:1,24576:2,49152:1,32768:2,0:1 > $out/row_blocks_ab_no_recorder_c5.jsonl 2>> $out/row_blocks_ab2.err; cat $out/row_blocks_ab_no_recorder_c5.jsonl ;;
+    rbtrace) R=$PWD; O=$R/$out; for cfg in 0:1 49152:1 24576:2; do ( cd /tmp && export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/rbtrace_${cfg/:/_} -- python3 $R/tools/diag/row_blocks_ab.py --iters 3 --configs $cfg > $O/rbtrace_${cfg/:/_}.log 2>&1 ); done
+             python3 - <<PYEOF
+import csv, glob, os
+for cfg in ("0_1", "49152_1", "24576_2"):
+    fs = glob.glob("$out/rbtrace_" + cfg + "/*/*_kernel_trace.csv")
+    if not fs: print(cfg, "no trace"); continue
+    rows = sorted(csv.DictReader(open(max(fs, key=os.path.getmtime))), key=lambda r: int(r["Start_Timestamp"]))
+    # the last forward: from the last stage_prologue with a preceding gap back to ... take the final N kernels between the last two 'sample/prologue' of the prop stage
+    idx = [i for i, r in enumerate(rows) if "stage_prologue" in r["Kernel_Name"]]
+    a, b = idx[-2], len(rows)     # the last forward starts at the second-to-last prologue (prop stage), ends at the end
+    fw = rows[a:b]
+    t0, t1 = int(fw[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in fw)
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in fw)
+    # union of intervals (two streams overlap)
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in fw)
+    u, cs, ce = 0, iv[0][0], iv[0][1]
+    for s_, e_ in iv[1:]:
+        if s_ > ce: u += ce - cs; cs, ce = s_, e_
+        else: ce = max(ce, e_)
+    u += ce - cs
+    print(cfg, "launches", len(fw), "span_us", (t1 - t0) / 1e3, "sum_of_kernels_us", busy / 1e3, "union_busy_us", u / 1e3, "idle_us", (t1 - t0 - u) / 1e3)
+PYEOF
+             ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
