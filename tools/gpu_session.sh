@@ -135,6 +135,7 @@ for cfg in ("0_1", "49152_1", "24576_2"):
     print(cfg, "launches", len(fw), "span_us", (t1 - t0) / 1e3, "sum_of_kernels_us", busy / 1e3, "union_busy_us", u / 1e3, "idle_us", (t1 - t0 - u) / 1e3)
 PYEOF
              ;;
+    xcc)     /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 tools/xcc_probe.hip -o /tmp/xcc_probe.bin 2> $out/xcc_probe.err && timeout 120 /tmp/xcc_probe.bin > $out/xcc_probe.txt 2>> $out/xcc_probe.err; cat $out/xcc_probe.txt ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
