@@ -115,6 +115,7 @@ def parse_args(argv=None):
                     help="(diagnostics, bf16 modes) m360_set_row_blocks: 0 = layer by layer, -1 = automatic (default), > 0 rows per block; "
                          "the line then carries config.row_blocks")
     ap.add_argument("--row-block-streams", type=int, default=None, choices=(1, 2), help="(diagnostics) m360_set_row_block_streams")
+    ap.add_argument("--no-chain", action="store_true", help="(diagnostics, bf16 mode) m360_set_hidden_chain(0): six launches for the six hidden NeRF layers")
     ap.add_argument("--plain-rows", action="store_true",
                     help="(diagnostics, bf16 modes) m360_set_paired_rows(0): plain instead of paired rows between the layers - same bits; "
                          "the line then carries config.plain_rows")
@@ -292,11 +293,15 @@ def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
     # the 1024 x 1024 layers: one launch over all S rows, or (bf16 modes, m360_set_row_blocks) one per block of rows - all of one size but a
     # shorter last one, which is left out
     hits = [r for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == kk]
+    chained = [r for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == 6 * HN] if bf16 and not x3 else []
+    nlay = 1
+    if chained and (not hits or max(r["M"] for r in chained) >= max(r["M"] for r in hits)):
+        hits, nlay = chained, 6  # bf16 mode: the six hidden layers in ONE launch (m360_mlp_chain_bf16), recorded as one kernel
     if not hits:
         return None
     rows = max(r["M"] for r in hits)
     durs = [r["ms"] for r in hits if r["M"] == rows]
-    flops = 2.0 * rows * HN * kk  # what the matrix pipe executes (bf16x3: three times the layer's algorithmic FLOPs)
+    flops = 2.0 * rows * HN * kk * nlay  # what the matrix pipe executes (bf16x3: three times the layer's algorithmic FLOPs)
     avg_ms = sum(durs) / len(durs)
     achieved = flops / (avg_ms * 1e-3) / 1e12
     traffic, traffic_note = None, None
@@ -313,14 +318,19 @@ def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
         tb = json.load(open(tpath)).get("bf16_ring_kernel")
         if tb and tb.get("kernel_source_sha256") == kernel_source_sha(TRAFFIC_SOURCES_BF16):
             traffic = tb.get("bytes_per_launch")
+            if tb.get("layers_per_launch", 1) != nlay:
+                traffic = None
             traffic_note = ("fabric-side counter bytes per launch (FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, gfx950 corrections); "
-                            "algorithmic bytes are 2.15 GB (the activation tile is read by the 4 column tiles of an XCD: L2 hits are not counted, "
-                            "Infinity-Cache hits are)")
+                            + ("algorithmic bytes of the six-layer launch are 2.16 GB (rows in, rows out, six weight matrices); the five hidden "
+                               "activations in between are counted here whenever they cross the fabric (Infinity-Cache hits included)" if nlay == 6 else
+                               "algorithmic bytes are 2.15 GB (the activation tile is read by the 4 column tiles of an XCD: L2 hits are not counted, "
+                               "Infinity-Cache hits are)"))
         elif tb:
             traffic_note = "profiles/traffic.json (bf16_ring_kernel) was measured on different kernel sources (stale): not reported"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     kname = ("linear_bf16_w16_kernel<X3> (bf16x3: 3 MFMA passes per product)" if x3 else "linear_bf16_w16_kernel") if bf16 else "linear_f32_hd_kernel"
-    roofline = {"bound": "mfma", "kernel": f"{kname} (1024x1024 layer, M={rows}" + (f": row blocks of the {S} rows" if rows != S else "") + ")", "achieved": round(achieved, 2),
+    shape = "six 1024x1024 layers in one launch (m360_mlp_chain_bf16)" if nlay == 6 else "1024x1024 layer"
+    roofline = {"bound": "mfma", "kernel": f"{kname} ({shape}, M={rows}" + (f" of the {S} rows" if rows != S else "") + ")", "achieved": round(achieved, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),
                 "median_launch_ms": round(statistics.median(durs), 4), "flops_per_launch": flops}
@@ -610,6 +620,8 @@ def worker(args):
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     if args.plain_rows:
         _lib.lib().m360_set_paired_rows(0)
+    if args.no_chain:
+        _lib.lib().m360_set_hidden_chain(0)
     if args.row_blocks is not None:
         _lib.lib().m360_set_row_blocks(args.row_blocks)
     if args.row_block_streams is not None:
@@ -723,6 +735,8 @@ def worker(args):
                           "whole_path_tflops": round(value * FLOPS_PER_SAMPLE * samples / 1e12, 2)}
         if args.plain_rows:
             line["config"]["plain_rows"] = True
+        if args.no_chain:
+            line["config"]["no_chain"] = True
         if args.row_blocks is not None:
             line["config"]["row_blocks"] = args.row_blocks
         if args.row_block_streams is not None:

@@ -233,6 +233,15 @@ int m360_linear_bf16x3(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M,
  * 0.013 dB of the reference's): two-term features [hi | lo] and weights [Wh | Wh | Wl] as for m360_linear_bf16x3, ONE bf16 term out -
  * m360_linear_bf16x3_bf16out (bias + {none, ReLU}; the ring kernel's three-product loop with the plain bf16 epilogue: a 64-deep layer
  * stays one block per tile and store-bound, 0.30 instead of the 0.53 ms of the x6 form at 1024 x 58 on 524 288 rows). */
+/* `layers` (1..8) equally shaped hidden layers (model.py:134-146: Linear(width, width) + ReLU; bf16 weights of m360_pack_linear_bf16, PAIRED
+ * rows in and out) in ONE launch: layer j reads act[j & 1] and writes act[(j + 1) & 1] (the result is in act[layers & 1]), the activations
+ * handed over through the L2 of the XCD whose four CUs own a row block (a counter per row block and layer in `workspace`, zeroed by the
+ * call) instead of a kernel boundary - same bits as `layers` calls of m360_linear_bf16.  Shapes: width 1024, M a multiple of 32768; a
+ * 256-CU device whose workgroup b runs on XCD b % 8 (checked once per device): m360_mlp_chain_bf16_supported answers. */
+int m360_mlp_chain_bf16_supported(long M, int width, int layers);
+size_t m360_mlp_chain_bf16_workspace(long M, int layers);
+int m360_mlp_chain_bf16(void *act0_bf16, void *act1_bf16, long M, int ld, const void *const *w_packed_bf16 /*[layers]*/, const float *const *b_packed /*[layers]*/,
+                        int layers, int width, void *workspace, m360_stream_t stream);
 /* 1 when the call `kind` (M360_PAIRABLE_*) with these pads runs its full tiles on the one-wave ring kernel, i.e. takes paired rows */
 int m360_linear_bf16_rows_pairable(int kind, int n_pad, int k_pad);
 /* m360_forward / m360_prop_forward / m360_nerf_forward (bf16 modes) use paired rows between the layers of an MLP whose layers are all
@@ -244,6 +253,9 @@ int m360_set_paired_rows(int on);
  * rows: 0 = off (default: one launch per layer over all rows), -1 = automatic (bf16 mode: pairs of 192 MiB in all, e.g. 49152 rows of
  * 1024 bf16, when the batch has at least two blocks), > 0 = this many rows per block (a multiple of 256).  Returns the old setting.
  * Measured (profiles/r04): the layers run 7 % faster per row and the additional launches take it back - a switch for experiments. */
+/* m360_forward / m360_nerf_forward, bf16 mode: the six hidden NeRF layers as ONE launch (m360_mlp_chain_bf16) for the rows it takes
+ * (multiples of 32768; width 1024; paired rows), 1 = on (default), 0 = six launches.  Same bits.  Returns the old setting. */
+int m360_set_hidden_chain(int on);
 long m360_set_row_blocks(long rows);
 /* With row blocks on - 2 (default): odd row blocks run on a second, library-owned stream (forked from and joined to the caller's stream with events; their
  * own ping / pong rows), so that one block's kernels fill the ~7 us between two dependent kernels of the other; 1: all blocks on the

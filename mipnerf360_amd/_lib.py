@@ -92,8 +92,12 @@ SIGNATURES = {
     "m360_pack_linear_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear_bf16x3": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_linear_bf16x3_bf16out": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "m360_mlp_chain_bf16_supported": (_i, [_l, _i, _i]),
+    "m360_mlp_chain_bf16_workspace": (C.c_size_t, [_l, _i]),
+    "m360_mlp_chain_bf16": (_i, [_vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "m360_linear_bf16_rows_pairable": (_i, [_i, _i, _i]),
     "m360_set_paired_rows": (_i, [_i]),
+    "m360_set_hidden_chain": (_i, [_i]),
     "m360_set_row_blocks": (_l, [_l]),
     "m360_set_row_block_streams": (_i, [_i]),
     "m360_pack_linear_bf16x6": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

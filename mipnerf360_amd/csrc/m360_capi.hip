@@ -90,7 +90,7 @@ struct ProfScope {
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FwdLayout {
-    size_t norm, vdenc, t1, t0, what, feat, act_a, act_b, hpart, queues, nanflag, total;
+    size_t norm, vdenc, t1, t0, what, feat, act_a, act_b, hpart, queues, nanflag, chain, total;
 };
 // tile-queue words of the balanced linear launches of one stage (m360_linear_balanced): 16 words, one per 64-byte line
 constexpr int kQueueSlots = 16, kQueueStride = 16;
@@ -135,6 +135,8 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     L.queues = take((size_t)2 * kQueueSlots * kQueueStride * sizeof(unsigned));  // one set per stage
     // bf16 modes: one byte per sample, "a feature of this sample is NaN" (the bf16 pipe's ReLU drops NaN: the finishers restore it)
     L.nanflag = take(m->mlp_bf16 ? S : 0);
+    // bf16 mode: the counters of the hidden-layer chain (m360_mlp_chain_bf16)
+    L.chain = take(m->mlp_bf16 == 1 ? m360_mlp_chain_bf16_workspace((long)S, 6) : 0);
     L.total = off;
     return L;
 }
@@ -185,6 +187,8 @@ static int p_linear(const m360_hyper_t *h, TileQueues *q, const float *x, long M
 static inline int first_row_format(int mode) { return mode == 2 ? 3 : (mode == 1 ? 2 : 0); }  // encoder row format of the MLP input
 // Paired rows (m360.h) between the layers of one bf16 / bf16x3 MLP: only when EVERY layer of it runs its full tiles on the one-wave ring
 // kernel - first layer out, hidden layers in and out, fused-heads last layer in (rendering forward: the tape-keeping one keeps plain rows)
+static int g_hidden_chain = 1;  // m360_set_hidden_chain
+extern "C" int m360_set_hidden_chain(int on) { const int was = g_hidden_chain; g_hidden_chain = on ? 1 : 0; return was; }
 static long g_row_blocks = 0;  // m360_set_row_blocks: 0 off (default: no gain in the step, see nerf_row_block), -1 automatic, > 0 rows per block
 static int g_row_block_streams = 2;  // m360_set_row_block_streams
 extern "C" int m360_set_row_block_streams(int n) { const int was = g_row_block_streams; g_row_block_streams = n >= 2 ? 2 : 1; return was; }
@@ -437,9 +441,24 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
             src = a; dst = b;
         } else {
         M360_TRY(p_linear_first(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, a, pair, st));
-        for (int layer = 1; layer < 7; ++layer) {
-            M360_TRY(p_linear_bf16(h, mode, src, S, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, dst, pair, st));
-            float *tmp = src; src = dst; dst = tmp;
+        // the six hidden layers: ONE launch for the rows the chain takes (bf16 mode, paired rows, width 1024, multiples of 32768 rows:
+        // m360_mlp_chain_bf16 - the activations handed over through the XCDs' L2s instead of six kernel boundaries), layer by layer the rest
+        const long Mc = (mode == 1 && pair && g_hidden_chain) ? (S / 32768) * 32768 : 0;
+        const bool chain = Mc > 0 && m360_mlp_chain_bf16_supported(Mc, hn, 6);
+        if (chain) {
+            const void *cw[6];
+            const float *cb[6];
+            for (int layer = 1; layer < 7; ++layer) { cw[layer - 1] = m->nerf_w[layer]; cb[layer - 1] = m->nerf_b[layer]; }
+            ProfScope ps(h, st, M360_K_LINEAR_BF16, Mc, hn, 6 * hn);  // k_pad = 6 hn: six layers in one record
+            M360_TRY(ps.done(m360_mlp_chain_bf16(a, b, Mc, hn, cw, cb, 6, hn, ws + L.chain, st)));
+        }
+        const long r0 = chain ? Mc : 0;  // rows [r0, S) layer by layer (both parts end in `a`: six swaps)
+        if (r0 < S) {
+            float *ts = reinterpret_cast<float *>(reinterpret_cast<char *>(a) + (size_t)r0 * ldl * 2), *td = reinterpret_cast<float *>(reinterpret_cast<char *>(b) + (size_t)r0 * ldl * 2);
+            for (int layer = 1; layer < 7; ++layer) {
+                M360_TRY(p_linear_bf16(h, mode, ts, S - r0, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, td, pair, st));
+                float *tmp = ts; ts = td; td = tmp;
+            }
         }
         M360_TRY(p_linear_heads(h, mode, src, S, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, ldl, 0, m->nerf_head_w, 4, hpart, st, pair));
         }

@@ -708,6 +708,64 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
     return check_launch("linear_bf16");
 }
 
+// ---- the chain of equally shaped bf16 ReLU layers in one launch (w16::chain_t, m360_linear_bf16_w16.hip.h)
+__global__ void xcc_probe_kernel(int *xcc) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    if (threadIdx.x == 0) xcc[blockIdx.x] = (int)x;
+}
+// does workgroup b of a 256-workgroup launch run on XCD b % 8 on this device (what lets a quartet hand its rows over through ONE L2)?
+static bool chain_xcd_map_ok() {
+    static int cached[64];  // 0 unknown, 1 yes, 2 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
+    if (cached[dev]) return cached[dev] == 1;
+    int *d = nullptr, h[256];
+    bool ok = hipMalloc(&d, sizeof(h)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(256), dim3(64), 0, 0, d);
+        ok = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(d);
+        for (int b = 8; ok && b < 256; ++b) ok = h[b] == h[b & 7];
+        for (int b = 0; ok && b < 8; ++b) for (int c = 0; c < b; ++c) ok = ok && h[b] != h[c];
+    }
+    if (!ok) (void)hipGetLastError();
+    cached[dev] = ok ? 1 : 2;
+    return ok;
+}
+
+int m360_mlp_chain_bf16_supported(long M, int width, int layers) {
+    if (M <= 0 || M % (128l * w16::BM) != 0 || width != 4 * w16::BN || layers < 1 || layers > 8) return 0;
+    return cu_count() == 256 && chain_xcd_map_ok();
+}
+
+size_t m360_mlp_chain_bf16_workspace(long M, int layers) { return ((size_t)(M / w16::BM) * (size_t)layers + 1) * sizeof(unsigned); }
+
+int m360_mlp_chain_bf16(void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed, int layers,
+                        int width, void *workspace, m360_stream_t stream) {
+    if (!act0 || !act1 || !w_packed || !b_packed || !workspace) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: null pointer");
+    if (ld < width || ld % 8 != 0 || (((uintptr_t)act0 | (uintptr_t)act1 | (uintptr_t)workspace) & 15))
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: ld=%d >= width=%d, a multiple of 8; 16-byte aligned pointers", ld, width);
+    if (!m360_mlp_chain_bf16_supported(M, width, layers))
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: M=%ld (a multiple of %ld), width=%d (%d), layers=%d (1..8), a 256-CU device whose workgroup b runs on XCD b %% 8 (m360_mlp_chain_bf16_supported)", M, 128l * w16::BM, width, 4 * w16::BN, layers);
+    w16::chain_t ch;
+    for (int l = 0; l < 8; ++l) {
+        ch.w[l] = static_cast<const __bf16 *>(w_packed[l < layers ? l : layers - 1]);
+        ch.b[l] = b_packed[l < layers ? l : layers - 1];
+        if (!ch.w[l] || !ch.b[l] || (((uintptr_t)ch.w[l] | (uintptr_t)ch.b[l]) & 15)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: layer %d: null or unaligned weights / bias", l);
+    }
+    ch.act[0] = static_cast<__bf16 *>(act0);
+    ch.act[1] = static_cast<__bf16 *>(act1);
+    ch.done = static_cast<unsigned *>(workspace);
+    ch.layers = layers;
+    ch.row_blocks = (int)(M / w16::BM);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(workspace, 0, m360_mlp_chain_bf16_workspace(M, layers), st) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_mlp_chain_bf16: hipMemsetAsync failed");
+    hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 128, false, false, false, 0, false, false, true, true>), dim3(256), dim3(w16::kThreads), 0, st,
+                       ch.act[0], M, ld, ch.w[0], ch.b[0], width, width, ch.act[1], ld, 4, ch.row_blocks * 4, nullptr, nullptr, 1, 0, ch);
+    return check_launch("mlp_chain_bf16");
+}
+
 int m360_pack_linear_bf16x6(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed6,
                             float *b_packed, m360_stream_t stream) {
     if (!w || !w_packed6 || n_out < 1 || k_in < 1 || n_pad < n_out || k_pad < k_in || k_pad % pbf16::BK != 0)

@@ -70,6 +70,24 @@ constexpr int kAccVBlocks = M360_W16_ACC_V_BLOCKS;  // activation blocks (of 8) 
 
 struct cursor_t { __amdgpu_buffer_rsrc_t rsrc; int k; int tile; };  // an LDS-DMA cursor: descriptor of its tile, byte offset in a row
 
+// CHAIN (round 4): up to 8 equally shaped ReLU layers (width x width, paired rows) in ONE launch of exactly 256 workgroups, the hidden
+// activations handed from layer to layer through the XCD's L2 instead of a kernel boundary.  Workgroup b is column tile c = (b / 8) & 3 of
+// quartet Q = 8 (b % 8) + (b / 8) / 4: the four workgroups of a quartet run on four CUs of XCD b % 8 (profiles/r04/xcc_of_workgroups.txt;
+// the host checks it once) and own the row blocks Q + 64 i, which they walk in pairs - (Ra, 0), (Rb, 0), (Ra, 1), (Rb, 1), ... - so that the
+// tile whose activation pieces a last stage prefetches never depends on the running one.  Layer j reads act[j & 1], writes act[(j + 1) & 1];
+// tile number t of the sequence - (R, j) - may fetch its activations once all 128 waves of the XCD have stored their tile t - 2, which for
+// its own quartet is (R, j - 1): done[8-entry-per-XCD][t - 2] == 128 (a wave adds 1 after `s_waitcnt vmcnt(0)`: its stores are in the L2
+// both sides share; the readers' pieces carry sc1 and bypass the CU's L1).  That wait also covers the write-after-read on act[(j + 1) & 1].  The spin is bounded: a lost wake-up ends as done[last] = ~0u
+// (the host's error), not as a hang.
+struct chain_t {
+    const __bf16 *w[8];
+    const float *b[8];
+    __bf16 *act[2];
+    unsigned *done;   // [8 XCDs][tiles of a workgroup's sequence] (<= row blocks x layers words) + 1 error word at [row blocks x layers], zeroed by the host
+    int layers;
+    int row_blocks;   // a multiple of 128: every quartet owns an even number
+};
+
 #ifdef M360_DIAG
 // diagnostics build, per workgroup: [0] cycles (s_memtime) and [1] 100 MHz ticks of the tile loop, [2] stages, [3] cycles in epilogues
 __device__ unsigned long long g_w16_stamps[256 * 4];
@@ -108,14 +126,15 @@ constexpr int kHeadMaxN = 1024;  // widest layer the fused heads take (their hi 
 // exchange.  The reader is this kernel's LDS-DMA, whose lanes carry their own source addresses: xpair != 0 fetches chunk c of row r
 // from line 2 (r >> 1) + (c >> 2), bytes 64 (r & 1) + 16 (c & 3) - the same eight whole lines per piece, a different lane order.
 // Rows beyond the last full 256-row tile are other kernels' rows and stay plain in both layouts.
-template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0, bool SPLIT = X3, bool LDSEPI = false, bool PAIR = false>
+template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0, bool SPLIT = X3, bool LDSEPI = false, bool PAIR = false, bool CHAIN = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, const float *__restrict__ head_w = nullptr,
-    float *__restrict__ head_part = nullptr, int xpair = 0, int stagger = 0) {
+    float *__restrict__ head_part = nullptr, int xpair = 0, int stagger = 0, chain_t ch = chain_t()) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0) + (LDSEPI ? 4 * 4096 : 0)];  // 144 (160) KiB
     static_assert(!LDSEPI || (HEADS == 0 && !SPLIT && !X3 && !PAIR), "the LDS epilogue: plain bf16 output (its 16 KiB sit where the head rows would)");
     static_assert(!PAIR || HEADS == 0, "paired rows are a layout of the layer's own output");
+    static_assert(!CHAIN || (PAIR && !X3 && !ONE_BLOCK && !SPLIT && HEADS == 0 && ACT == M360_ACT_RELU), "the layer chain: plain bf16 ReLU layers on paired rows");
     static_assert(HEADS == 0 || HEADS == 1 || HEADS == 4, "1 (proposal) or 4 (NeRF) heads");
     // X3 loop + plain bf16 output: the first layer of the bf16 mode (two-term features and weights in, one bf16 term out)
     static_assert(SPLIT == X3 || HEADS == 0, "X3 loop and split output go together wherever the heads are fused");
@@ -146,6 +165,15 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     };
     int tile_id = blockIdx.x;
     if (tile_id >= ntiles) return;
+    // CHAIN: this workgroup's column tile and quartet; its sequence of tiles t -> (row block, layer)
+    const int ch_col = (blockIdx.x >> 3) & 3, ch_q = 8 * (blockIdx.x & 7) + (blockIdx.x >> 5);
+    const int ch_T = CHAIN ? (ch.row_blocks / 64) * ch.layers : 0;
+    auto chain_seq = [&](int t, int &R, int &j) __attribute__((always_inline)) {
+        const int two_l = 2 * ch.layers, p_ = t / two_l, rem = t - p_ * two_l;
+        j = rem >> 1;
+        R = ch_q + 64 * (2 * p_ + (rem & 1));
+    };
+    if (CHAIN) tile_id = 0;
 #ifdef M360_DIAG
     // diagnostics (round 4): start the eight row blocks an XCD works on at once `stagger` x ~1 k cycles apart (the four column tiles of a
     // row block stay together: they share its activation rows through the L2), so that the 256 CUs do not store their tiles in the same
@@ -182,16 +210,47 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         long m0_;
         int n0_;
         tile_coords(tile_id, m0_, n0_);
-        cx.rsrc = cx2.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(X + m0_ * ldx), 0, 0x7fffffff, 0x00020000);
-        cw.rsrc = cw2.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)n0_ * Kp), 0, 0x7fffffff, 0x00020000);
+        const __bf16 *x0 = X + m0_ * ldx, *w0 = W + (long)n0_ * Kp;
+        if (CHAIN) {
+            int R_, j_;
+            chain_seq(0, R_, j_);
+            x0 = ch.act[0] + (long)R_ * BM * ldx;
+            w0 = ch.w[0] + (long)(ch_col * BN) * Kp;
+        }
+        cx.rsrc = cx2.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(x0), 0, 0x7fffffff, 0x00020000);
+        cw.rsrc = cw2.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(w0), 0, 0x7fffffff, 0x00020000);
         cx.k = cx2.k = cw.k = cw2.k = 0;
         cx.tile = cx2.tile = cw.tile = cw2.tile = tile_id;
     }
+    // CHAIN: wait (bounded) until all 128 waves of this XCD have stored their tile number t of the sequence: the quartet's own (whose rows
+    // tile t + 2 fetches) and the seven others' - the 32 workgroups of an XCD stay on the same layer, i.e. on the same 2 MB of weights in
+    // their L2 (without this the quartets drift apart over a long sequence: 8192 x 256 rows ran no faster than layer by layer)
+    auto chain_wait = [&](int t) __attribute__((always_inline)) {
+        unsigned *flag = ch.done + (long)(blockIdx.x & 7) * ch_T + t;
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 128u) {
+            if (++spins > (1 << 20)) { __hip_atomic_store(ch.done + (long)ch.row_blocks * ch.layers, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    };
 #define W16_CUR_ADV(C, IS_X)                                                                                                 \
     do {                                                                                                                     \
         C.k += 2 * BKS;                                                                                                      \
         if (C.k == kbytes) { /* next tile of this workgroup (past the last one: harmlessly the same rows again) */           \
             C.k = 0;                                                                                                         \
+            if (CHAIN) {                                                                                                     \
+                C.tile += 1;                                                                                                 \
+                if (C.tile < ch_T) {                                                                                         \
+                    int R_, j_;                                                                                              \
+                    chain_seq(C.tile, R_, j_);                                                                               \
+                    if (IS_X) {                                                                                              \
+                        if (C.tile >= 2) chain_wait(C.tile - 2);                                                             \
+                        C.rsrc = __builtin_amdgcn_make_buffer_rsrc(ch.act[j_ & 1] + (long)R_ * BM * ldx, 0, 0x7fffffff, 0x00020000); \
+                    } else {                                                                                                 \
+                        C.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(ch.w[j_]) + (long)(ch_col * BN) * Kp, 0, 0x7fffffff, 0x00020000); \
+                    }                                                                                                        \
+                }                                                                                                            \
+            } else {                                                                                                         \
             C.tile += G;                                                                                                     \
             if (C.tile < ntiles) {                                                                                           \
                 long m0_;                                                                                                    \
@@ -200,13 +259,14 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                 C.rsrc = (IS_X) ? __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(X + m0_ * ldx), 0, 0x7fffffff, 0x00020000) \
                                 : __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(W + (long)n0_ * Kp), 0, 0x7fffffff, 0x00020000); \
             }                                                                                                                \
+            }                                                                                                                \
         }                                                                                                                    \
     } while (0)
 // (ABL 256 / 512, diagnostics: non-temporal activation / weight pieces; results stay right.  One layer launched back to back gains
 // 1.3 % from non-temporal activation pieces (1278-1285 against 1263-1268 TF) and loses 4 % from non-temporal weight pieces
 // (profiles/r03/bf16_w16_nontemporal_loads_ab_NOT_ADOPTED.jsonl) - but in the step, where a layer reads what the previous one has just written,
 // the activation variant measured 7.04 against 6.96-7.02 ms (bf16x3: 17.5 against 16.9-17.1): not adopted.)
-#define W16_PIECE_X(C, COL, SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(C.rsrc, (lds_ptr_t)(dma_x + (SLOT) * kStageBytes + ((Q) & 3) * 1024 + ((Q) >> 2) * 8192), 16, x_voff[Q], C.k + (COL), 0, (ABL & 256) ? 2 : 0)
+#define W16_PIECE_X(C, COL, SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(C.rsrc, (lds_ptr_t)(dma_x + (SLOT) * kStageBytes + ((Q) & 3) * 1024 + ((Q) >> 2) * 8192), 16, x_voff[Q], C.k + (COL), 0, CHAIN ? 16 : (ABL & 256) ? 2 : 0)
 #define W16_PIECE_W(C, COL, SLOT, Q) if (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(C.rsrc, (lds_ptr_t)(dma_w + (SLOT) * kStageBytes + (Q) * 1024), 16, w_voff[Q], C.k + (COL), 0, (ABL & 512) ? 2 : 0)
 #define W16_ADV_X() W16_CUR_ADV(cx, true)
 #define W16_ADV_W() W16_CUR_ADV(cw, false)
@@ -291,6 +351,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
 
     // ---- bias -> LDS once (before any LDS-DMA is in flight)
     float *const bias_lds = reinterpret_cast<float *>(smem + 2 * kStageBytes);
+    if (CHAIN) {  // [layer][the 256 columns of this workgroup's column tile]
+        for (int i = tid; i < ch.layers * BN; i += kThreads) bias_lds[i] = ch.b[i / BN][ch_col * BN + (i % BN)];
+    } else
     for (int i = tid; i < Np; i += kThreads) bias_lds[i] = bias[i];
     // head rows as two bf16 terms: hfrag[0][h][n] = bf16(w), hfrag[1][h][n] = bf16(w - hi) (HEADS x Np <= 4 x 1024 values each)
     __bf16 *const hfrag = reinterpret_cast<__bf16 *>(smem + 2 * kStageBytes + kMaxBias * 4);
@@ -342,8 +405,19 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     unsigned long long mt0 = 0, rt0 = 0, mt1 = 0, rt1 = 0, e0 = 0, e1 = 0, te = 0, nsl = 0;
     (void)mt1; (void)rt1; (void)e0; (void)e1; (void)te; (void)nsl;
     if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt0), "=s"(rt0)::"memory");
-    for (; tile_id < ntiles; tile_id += G) {
-        tile_coords(tile_id, m0, n0);
+    int nbias = 0, ch_R = 0, ch_j = 0;  // where the tile's bias starts in the LDS (n0; CHAIN: 256 x layer), CHAIN: the tile's row block and layer
+    __bf16 *Yt = Y;
+    for (; tile_id < (CHAIN ? ch_T : ntiles); tile_id += (CHAIN ? 1 : G)) {
+        if (CHAIN) {
+            chain_seq(tile_id, ch_R, ch_j);
+            m0 = (long)ch_R * BM;
+            n0 = ch_col * BN;
+            nbias = ch_j * BN;
+            Yt = ch.act[(ch_j + 1) & 1];
+        } else {
+            tile_coords(tile_id, m0, n0);
+            nbias = n0;
+        }
         if (X3) {
             W16X_T1Z_S0();
             W16X_T2_S1();
@@ -446,7 +520,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         } else if (!(ABL & 32)) {
             // (ABL 2048, diagnostics, wrong results: every tile of a workgroup is written over the SAME 256 rows - the stores keep their
             // count, shape and TA occupancy but their lines stay in the XCD's L2: what does the HBM side of the output cost the K loop?)
-            const __bf16 *yt = Y + (((ABL & 2048) ? (long)blockIdx.x * BM : m0) + wm * 128) * ldy + n0 + wn * 128;  // wave-uniform corner of the wave tile
+            const __bf16 *yt = Yt + (((ABL & 2048) ? (long)blockIdx.x * BM : m0) + wm * 128) * ldy + n0 + wn * 128;  // wave-uniform corner of the wave tile
             f32x4 hacc[8];  // HEADS: the head sums of this lane's rows (one per activation block) over the pieces done so far
             const unsigned row_step = 16u * (unsigned)ldy;  // elements per activation block
 #pragma unroll
@@ -454,7 +528,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                 const __bf16 *rowp = yt;   // rows 16 i .. of the wave tile, i = 0
                 asm volatile("" : "+s"(rowp));
                 f32x4 bb[4];  // bias of the lane's columns 32 p + 8 g4 + 0..7, p = 2P (bb[0], bb[1]) and 2P + 1 (bb[2], bb[3])
-                const unsigned ba = bias_addr + 4u * (n0 + 64 * P);
+                const unsigned ba = bias_addr + 4u * (nbias + 64 * P);
                 asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\t"
                              "ds_read_b128 %3, %4 offset:144\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(bb[0]), "=&v"(bb[1]), "=&v"(bb[2]), "=&v"(bb[3]) : "v"(ba) : "memory");
@@ -603,6 +677,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                 }
                 W16_SB();  // one pair of column pieces at a time
             }
+        }
+        if (CHAIN) {  // this wave's rows of tile (R, j) are in the L2: count it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(ch.done + (long)(blockIdx.x & 7) * ch_T + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostics: drain the stores (and everything else) inside the stamped epilogue
         if (STAMP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e1)::"memory"); te += e1 - e0; nsl += nstages; }

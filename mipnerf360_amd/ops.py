@@ -552,6 +552,27 @@ def set_paired_rows(on: bool) -> bool:
     return bool(_lib.lib().m360_set_paired_rows(int(bool(on))))
 
 
+def mlp_chain_bf16_supported(M: int, width: int, layers: int) -> bool:
+    return bool(_lib.lib().m360_mlp_chain_bf16_supported(int(M), int(width), int(layers)))
+
+
+def mlp_chain_bf16(act0, act1, packs):
+    """m360_mlp_chain_bf16: the equally shaped ReLU layers `packs` = [(w_packed, b_packed), ...] in one launch on PAIRED rows: layer j reads
+    act[j & 1], writes act[(j + 1) & 1]; returns the buffer that holds the result."""
+    import ctypes as C
+    act0, act1 = dev_bf16(act0, "act0"), dev_bf16(act1, "act1")
+    M, ld = act0.shape
+    L = len(packs)
+    width = packs[0][0].shape[0]
+    ws = torch.empty(int(_lib.lib().m360_mlp_chain_bf16_workspace(M, L)) // 4 + 4, device=act0.device, dtype=torch.int32)
+    wl = (C.c_void_p * L)(*[dev_bf16(w, "w").data_ptr() for w, _ in packs])
+    bl = (C.c_void_p * L)(*[dev(b, "b").data_ptr() for _, b in packs])
+    _call("m360_mlp_chain_bf16", act0, act1, M, ld, C.cast(wl, C.c_void_p), C.cast(bl, C.c_void_p), L, width, ws, STREAM)
+    if int(ws[(M // 256) * L].item()) != 0:
+        raise RuntimeError("m360_mlp_chain_bf16: a workgroup gave up waiting for its quartet (error word set)")
+    return act0 if L % 2 == 0 else act1
+
+
 def set_row_blocks(rows: int) -> int:
     """m360_set_row_blocks: rows per block of the NeRF MLP in the bf16 modes (0 off, -1 automatic, > 0 explicit); returns the old setting"""
     return int(_lib.lib().m360_set_row_blocks(int(rows)))

@@ -637,6 +637,53 @@ def test_forward_is_the_same_bits_with_and_without_row_blocks(dev, mode):
             ops.set_row_blocks(was)
 
 
+@pytest.mark.parametrize("M,layers", [(32768, 6), (65536, 3), (32768, 1)])
+def test_hidden_layer_chain_in_one_launch(dev, M, layers):
+    """m360_mlp_chain_bf16: `layers` 1024 x 1024 ReLU layers in ONE launch, a row block's next layer waiting for the quartet of workgroups
+    that owns it instead of a kernel boundary - bit for bit what `layers` calls of m360_linear_bf16 on paired rows give, repeatedly (the
+    hand-over through the L2 has no second chance to be wrong quietly: three runs, fresh inputs each)."""
+    from mipnerf360_amd import _lib, ops
+    if not ops.mlp_chain_bf16_supported(M, 1024, layers):
+        pytest.skip("needs a 256-CU device whose workgroup b runs on XCD b % 8")
+    g = torch.Generator().manual_seed(M + layers)
+    packs = []
+    for _ in range(layers):
+        w = (torch.randn(1024, 1024, generator=g) * (2.0 / 1024) ** 0.5).to(dev)
+        b = (torch.randn(1024, generator=g) * 0.1).to(dev)
+        packs.append(ops.pack_linear_bf16(w, b, 1024, 1024))
+    flags = _lib.ACT_RELU | _lib.ROWS_PAIRED_IN | _lib.ROWS_PAIRED_OUT
+    for rep in range(3):
+        x = ops.pair_rows(torch.randn(M, 1024, generator=g).to(dev).bfloat16())
+        want = x
+        for wp, bp in packs:
+            want = ops.linear_bf16(want, wp, bp, flags)
+        a, b2 = x.clone(), torch.full_like(x, float("nan"))
+        got = ops.mlp_chain_bf16(a, b2, packs)
+        assert torch.equal(got, want), (rep, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("B,N", [(512, 128), (300, 128), (1024, 33)])
+def test_forward_is_the_same_bits_with_and_without_the_hidden_chain(dev, B, N):
+    """m360_set_hidden_chain: the bf16 forward with the six hidden NeRF layers as one launch (default) against six launches - 65536 rows (all
+    in the chain), 38400 (32768 in the chain + 5632 layer by layer) and 33792 rows of 33 samples (ragged rows as well): not a bit may differ."""
+    from mipnerf360_amd import _lib
+    from mipnerf360_amd.model import mipNeRF360
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(256, 1024, seed=8).items()}
+    model = mipNeRF360(num_samples=N, hidden_proposal=256, hidden_nerf=1024, mlp_dtype="bf16", device=dev, randomized=False).eval()
+    model.load_state_dict(sd)
+    rays = dev_rays(synthetic.make_rays("garden", B, seed=5), dev)
+    outs = {}
+    for on in (1, 0):
+        was = _lib.lib().m360_set_hidden_chain(on)
+        try:
+            with torch.no_grad():
+                outs[on] = [o.clone() for o in model(rays)]
+        finally:
+            _lib.lib().m360_set_hidden_chain(was)
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.equal(a, b)
+
+
 def test_temporal_stores_flag(dev):
     """M360_STORES_TEMPORAL (what the row blocks use): the same rows as with non-temporal stores; refused without paired output rows."""
     from mipnerf360_amd import _lib, ops

@@ -663,21 +663,25 @@ def test_ring_kernel_store_instructions_match_its_counted_waits(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     text = open(out).read()
     seen = 0
-    # _ZN4m3603w1622linear_bf16_w16_kernelILi<ACT>ELi<ABL>ELb<STAMP>ELb<X3>ELb<ONE_BLOCK>ELi<HEADS>ELb<SPLIT>ELb<LDSEPI>ELb<PAIR>EEE...
-    split_without_x3 = paired = 0
-    for m in re.finditer(r"^(_ZN4m3603w1622linear_bf16_w16_kernelILi(\d)ELi0ELb0ELb([01])ELb([01])ELi(\d)ELb([01])ELb0ELb([01])EEE\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
-        x3, heads, split, pair, body = m.group(3) == "1", int(m.group(5)), m.group(6) == "1", m.group(7) == "1", m.group(8)
+    # _ZN4m3603w1622linear_bf16_w16_kernelILi<ACT>ELi<ABL>ELb<STAMP>ELb<X3>ELb<ONE_BLOCK>ELi<HEADS>ELb<SPLIT>ELb<LDSEPI>ELb<PAIR>ELb<CHAIN>EEE...
+    # (ABL: 0, or 128 = the same kernel with temporal stores: the row blocks' and the layer chain's instantiations)
+    split_without_x3 = paired = chains = 0
+    for m in re.finditer(r"^(_ZN4m3603w1622linear_bf16_w16_kernelILi(\d)ELi(?:0|128)ELb0ELb([01])ELb([01])ELi(\d)ELb([01])ELb0ELb([01])ELb([01])EEE\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        x3, heads, split, pair, chain, body = m.group(3) == "1", int(m.group(5)), m.group(6) == "1", m.group(7) == "1", m.group(8) == "1", m.group(9)
+        chains += int(chain)
+        # the layer chain (m360_mlp_chain_bf16): one counter add per tile, activation pieces that bypass the CU's L1
+        assert (body.count("global_atomic_add") > 0) == chain and (not chain or body.count(" sc1") >= 128), f"{m.group(1)}: the chain's hand-over instructions"
         want = 8 if heads else (64 if split else 32)
         split_without_x3 += int(split and not x3)
         paired += int(pair)
         # paired rows (include/m360.h): the lanes' own pieces are whole lines - no exchange between lanes in that epilogue
         assert (body.count("v_cndmask_b32_dpp") == 0) == (pair or heads > 0), f"{m.group(1)}: lane exchange in a paired-rows / fused-heads epilogue, or none in a plain one"
-        got = len(re.findall(r"\bglobal_store_", body))
+        got = len(re.findall(r"\bglobal_store_dwordx4" if chain else r"\bglobal_store_", body))  # (the chain also stores its error word where a wait gives up)
         assert got == want, f"{m.group(1)}: {got} store instructions, the counted waits assume {want}"
         assert "scratch_" not in body, f"{m.group(1)} spills"
         seen += 1
-    assert seen >= 17 and paired >= 5, f"only {seen} ring-kernel instantiations found ({paired} with paired rows out)"
-    assert split_without_x3 == 3, "the x6 first layer of the bf16x3 mode (plain K loop, [hi | lo] output; none / ReLU / ReLU with paired rows out) is missing"
+    assert seen >= 22 and paired >= 10 and chains == 1, f"only {seen} ring-kernel instantiations found ({paired} with paired rows out, {chains} layer chain)"
+    assert split_without_x3 == 4, "the x6 first layer of the bf16x3 mode (plain K loop, [hi | lo] output; none / ReLU / ReLU with paired rows out, with non-temporal or temporal stores) is missing"
 
 
 def test_design_md_numbers_are_generated_from_profiles():

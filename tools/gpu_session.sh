@@ -136,6 +136,17 @@ for cfg in ("0_1", "49152_1", "24576_2"):
 PYEOF
              ;;
     xcc)     /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 tools/xcc_probe.hip -o /tmp/xcc_probe.bin 2> $out/xcc_probe.err && timeout 120 /tmp/xcc_probe.bin > $out/xcc_probe.txt 2>> $out/xcc_probe.err; cat $out/xcc_probe.txt ;;
+    chaintest) timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "hidden_layer_chain or hidden_chain" > $out/pytest_chain.log 2>&1; echo "pytest rc=$?" >> $out/pytest_chain.log; tail -25 $out/pytest_chain.log | cut -c1-300 ;;
+    chainbench) timeout 600 python tools/diag/chain_bench.py > $out/chain_bench.jsonl 2> $out/chain_bench.err; cat $out/chain_bench.jsonl; tail -3 $out/chain_bench.err
+             timeout 600 python tools/diag/chain_bench.py --c5 --rounds 5 >> $out/chain_bench.jsonl 2>> $out/chain_bench.err; tail -2 $out/chain_bench.jsonl ;;
+    chainab) for r in 1 2; do for f in "" "--no-chain"; do timeout 600 python bench.py --mlp-dtype bf16 --cpu-rays 0 --frame-steps 0 $f >> $out/hidden_chain_ab.jsonl 2>> $out/hidden_chain_ab.err; done; done
+             timeout 600 python bench.py --config c5 --cpu-rays 0 --frame-steps 0 >> $out/hidden_chain_ab.jsonl 2>> $out/hidden_chain_ab.err; timeout 600 python bench.py --config c5 --cpu-rays 0 --frame-steps 0 --no-chain >> $out/hidden_chain_ab.jsonl 2>> $out/hidden_chain_ab.err
+             python3 - <<PYEOF
+import json
+for l in open("$out/hidden_chain_ab.jsonl"):
+    d = json.loads(l); c = d["config"]; r = d["roofline"] or {}; print(c.get("name"), "six launches" if c.get("no_chain") else "chain", d["ms_per_step"], d["ms_per_step_median"], r.get("avg_launch_ms"), r.get("frac"), d.get("parity", {}).get("max_abs_rgb") if isinstance(d.get("parity"), dict) else "")
+PYEOF
+             ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac

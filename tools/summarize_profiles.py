@@ -219,8 +219,12 @@ def bf16_ring_counters(src):
         acc = collections.defaultdict(dict)
         for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
             # the ReLU hidden layers: <ACT = 1, ABL = 0, no stamps, no X3, not ONE_BLOCK, no heads, no split, no LDS epilogue[, paired rows or not]>
-            if any(k in r["Kernel_Name"] for k in ("w16_kernel<1, 0, false, false, false, 0, false, false, true>", "w16_kernel<1, 0, false, false, false, 0, false, false, false>",
+            # ... or, since round 4's last step, the six hidden layers in ONE launch (CHAIN: <1, 128, ..., paired rows, chain>)
+            if any(k in r["Kernel_Name"] for k in ("w16_kernel<1, 128, false, false, false, 0, false, false, true, true>",
+                                                   "w16_kernel<1, 0, false, false, false, 0, false, false, true, false>", "w16_kernel<1, 0, false, false, false, 0, false, false, false, false>",
+                                                   "w16_kernel<1, 0, false, false, false, 0, false, false, true>", "w16_kernel<1, 0, false, false, false, 0, false, false, false>",
                                                    "w16_kernel<1, 0, false, false, false, 0, false, false>", "w16_kernel<1, 0, false, false, false, 0, false>", "w16_kernel<1, 0, false, false, false, 0>")):
+                acc[r["Dispatch_Id"]]["_chain"] = 1.0 if "true, true>" in r["Kernel_Name"] and "<1, 128," in r["Kernel_Name"] else 0.0
                 acc[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
                 acc[r["Dispatch_Id"]]["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         return [x for x in acc.values() if x["_ns"] > 600000]   # the NeRF layers (the 256-wide proposal layers are 7 x shorter)
@@ -228,11 +232,16 @@ def bf16_ring_counters(src):
     if not S or not F or not W:
         return None
     mean = lambda xs, k: sum(x[k] for x in xs) / len(xs)  # noqa: E731
+    chain = any(x.get("_chain") for x in S)
+    if chain:  # the chain launches only (ragged rows, if any, run layer by layer in shorter launches)
+        S, F, W = [x for x in S if x.get("_chain")], [x for x in F if x.get("_chain")], [x for x in W if x.get("_chain")]
     fetch_b, write_b = mean(F, "FETCH_SIZE") * 1024 * 2, mean(W, "WRITE_SIZE") * 1024
     g = mean(S, "GRBM_GUI_ACTIVE") / 8
     from bench import TRAFFIC_SOURCES_BF16
-    return {"kernel": "w16::linear_bf16_w16_kernel<ReLU> 1024x1024, M=524288", "bytes_per_launch": round(fetch_b + write_b),
-            "fetch_bytes": round(fetch_b), "write_bytes": round(write_b), "algorithmic_bytes": 2 * M_BENCH * N_BENCH * 2 + N_BENCH * N_BENCH * 2,
+    return {"kernel": "w16::linear_bf16_w16_kernel<ReLU, CHAIN>: six 1024x1024 layers in one launch, M=524288" if chain else "w16::linear_bf16_w16_kernel<ReLU> 1024x1024, M=524288",
+            "bytes_per_launch": round(fetch_b + write_b), "fetch_bytes": round(fetch_b), "write_bytes": round(write_b),
+            # the chain: input rows in, output rows out, six weight matrices (the five hidden activations in between never have to leave the die)
+            "algorithmic_bytes": 2 * M_BENCH * N_BENCH * 2 + (6 if chain else 1) * N_BENCH * N_BENCH * 2, "layers_per_launch": 6 if chain else 1,
             "launch_ms_under_pmc": round(mean(S, "_ns") / 1e6, 4), "launches_averaged": len(S), "effective_clock_ghz": round(g / mean(S, "_ns"), 3),
             "mfma_busy_fraction": round(mean(S, "SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / g, 4),
             "lds_bank_conflict_cycles": mean(S, "SQ_LDS_BANK_CONFLICT"), "lds_instructions": mean(S, "SQ_INSTS_LDS"),
