@@ -712,6 +712,10 @@ def worker(args):
         comm.fence()
         elapsed = time.perf_counter() - t0
         model.set_prof(None)
+        # bf16 mode: the hidden-layer chain's bounded waits (m360_mlp_chain_bf16) - did any workgroup give up in the last timed step?
+        chain_error = bool(model.chain_error()) if hasattr(model, "chain_error") else False
+        if chain_error:
+            raise SystemExit("bench.py: the hidden-layer chain reported a timed-out wait (m360_forward_chain_error): the run is invalid")
         compute_ms = [e[0].elapsed_time(e[1]) for e in ev]
         gather_ms = [e[1].elapsed_time(e[2]) for e in ev]
         step_ms = [e[0].elapsed_time(e[2]) for e in ev]

@@ -578,6 +578,10 @@ typedef struct {
 } m360_outputs_t;
 
 size_t m360_forward_workspace_bytes(int B, int N, const m360_model_t *model_host);
+/* Layer chain of the bf16 mode (m360_set_hidden_chain) - after a forward (same workspace, B, N = the workspace's samples per ray, model; nerf_rows = B x the NeRF stage's samples per ray):
+ * 1 when a workgroup of its layer chain gave up waiting (bounded spin: never a hang) - the outputs of that forward are not to be trusted;
+ * 0 otherwise, or when the configuration runs no chain.  Synchronises with the device; bench.py asks once after its timed region. */
+int m360_forward_chain_error(const void *workspace, int B, int N, const m360_model_t *model_host, long nerf_rows);
 
 /* prop_net.forward, model.py:80-94 -> out->t_hat, out->w_hat (both required).
  * t_rand: optional uniforms [B,N+1] for randomized=True. */

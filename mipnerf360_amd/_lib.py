@@ -98,6 +98,7 @@ SIGNATURES = {
     "m360_linear_bf16_rows_pairable": (_i, [_i, _i, _i]),
     "m360_set_paired_rows": (_i, [_i]),
     "m360_set_hidden_chain": (_i, [_i]),
+    "m360_forward_chain_error": (_i, [_vp, _i, _i, _vp, _l]),
     "m360_set_row_blocks": (_l, [_l]),
     "m360_set_row_block_streams": (_i, [_i]),
     "m360_pack_linear_bf16x6": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

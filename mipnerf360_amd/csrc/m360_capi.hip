@@ -539,6 +539,19 @@ int m360_prof_read(m360_prof_t *p, int i, float *ms, int *kind, long *M, int *n_
     return M360_OK;
 }
 
+// 1 when a workgroup of the last forward's layer chain (bf16 mode) gave up waiting for its XCD (the bounded spin of m360_mlp_chain_bf16):
+// that forward's outputs are not to be trusted.  Synchronises with the device.  0: no error, or no chain in this configuration.
+int m360_forward_chain_error(const void *workspace, int B, int N, const m360_model_t *model_host, long nerf_rows) {
+    if (!workspace || !model_host || B < 1 || N < 1 || model_host->mlp_bf16 != 1) return 0;
+    const long Mc = (nerf_rows / 32768) * 32768;
+    if (Mc <= 0 || !g_hidden_chain || !m360_mlp_chain_bf16_supported(Mc, model_host->hn_pad, 6)) return 0;
+    const FwdLayout L = layout_for(B, N, model_host);
+    unsigned word = 0;
+    const char *p = static_cast<const char *>(workspace) + L.chain + (size_t)(Mc / 256) * 6 * sizeof(unsigned);
+    if (hipMemcpy(&word, p, sizeof(word), hipMemcpyDeviceToHost) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_forward_chain_error: hipMemcpy failed: %s", hipGetErrorString(hipGetLastError()));
+    return word != 0 ? 1 : 0;
+}
+
 size_t m360_forward_workspace_bytes(int B, int N, const m360_model_t *model_host) {
     if (!model_host || B < 0 || N < 1) return 0;
     return layout_for(B, N, model_host).total;

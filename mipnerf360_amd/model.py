@@ -575,9 +575,22 @@ class mipNeRF360(nn.Module):
         ws = _ws_for(B, max(N, Nf), mstruct, dev)
         ops.call("m360_forward", C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, C.byref(ostruct), ws,
                  ws.numel(), ops.STREAM, device=dev)
+        self._last_fused = (ws, B, max(N, Nf), mstruct, B * Nf)
         if stash:
             self.nerf_net._stash(outs)
         return outs["rgb"], outs["distance"], outs["acc"]
+
+    def chain_error(self) -> bool:
+        """m360_forward_chain_error for the last fused forward (bf16 mode: did a workgroup of the hidden-layer chain give up waiting?
+        Synchronises; False when that forward ran no chain)."""
+        last = getattr(self, "_last_fused", None)
+        if last is None:
+            return False
+        ws, B, N, mstruct, rows = last
+        rc = _lib.lib().m360_forward_chain_error(ws.data_ptr(), B, N, C.byref(mstruct), rows)
+        if rc < 0:
+            raise RuntimeError(_lib.last_error())
+        return rc == 1
 
     def forward(self, rays):
         """model.py:247-252 -> (rgb[B,3], distance[B], acc[B])."""

@@ -678,6 +678,7 @@ def test_forward_is_the_same_bits_with_and_without_the_hidden_chain(dev, B, N):
         try:
             with torch.no_grad():
                 outs[on] = [o.clone() for o in model(rays)]
+            assert model.chain_error() is False  # no workgroup of the chain gave up waiting (m360_forward_chain_error)
         finally:
             _lib.lib().m360_set_hidden_chain(was)
     for a, b in zip(outs[1], outs[0]):
