@@ -236,7 +236,8 @@ int m360_linear_bf16x3(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M,
 /* `layers` (1..8) equally shaped hidden layers (model.py:134-146: Linear(width, width) + ReLU; bf16 weights of m360_pack_linear_bf16, PAIRED
  * rows in and out) in ONE launch: layer j reads act[j & 1] and writes act[(j + 1) & 1] (the result is in act[layers & 1]), the activations
  * handed over through the L2 of the XCD whose four CUs own a row block (a counter per row block and layer in `workspace`, zeroed by the
- * call) instead of a kernel boundary - same bits as `layers` calls of m360_linear_bf16.  Shapes: width 1024, M a multiple of 32768; a
+ * call) instead of a kernel boundary - same bits as `layers` calls of m360_linear_bf16.  Shapes: width 1024 with M a multiple of 32768,
+ * or width 256 (a workgroup then owns whole rows: its own previous tile is all its next layer needs) with M a multiple of 131072; a
  * 256-CU device whose workgroup b runs on XCD b % 8 (checked once per device): m360_mlp_chain_bf16_supported answers. */
 int m360_mlp_chain_bf16_supported(long M, int width, int layers);
 size_t m360_mlp_chain_bf16_workspace(long M, int layers);
@@ -254,7 +255,8 @@ int m360_set_paired_rows(int on);
  * 1024 bf16, when the batch has at least two blocks), > 0 = this many rows per block (a multiple of 256).  Returns the old setting.
  * Measured (profiles/r04): the layers run 7 % faster per row and the additional launches take it back - a switch for experiments. */
 /* m360_forward / m360_nerf_forward, bf16 mode: the six hidden NeRF layers as ONE launch (m360_mlp_chain_bf16) for the rows it takes
- * (multiples of 32768; width 1024; paired rows), 1 = on (default), 0 = six launches.  Same bits.  Returns the old setting. */
+ * (multiples of 32768; width 1024; paired rows), 1 = on (default), 0 = six launches.  Same bits.  Returns the old setting.  (The proposal
+ * MLP's two 256-wide hidden layers stay two launches: the chain is slower there.) */
 int m360_set_hidden_chain(int on);
 long m360_set_row_blocks(long rows);
 /* With row blocks on - 2 (default): odd row blocks run on a second, library-owned stream (forked from and joined to the caller's stream with events; their
@@ -578,7 +580,8 @@ typedef struct {
 } m360_outputs_t;
 
 size_t m360_forward_workspace_bytes(int B, int N, const m360_model_t *model_host);
-/* Layer chain of the bf16 mode (m360_set_hidden_chain) - after a forward (same workspace, B, N = the workspace's samples per ray, model; nerf_rows = B x the NeRF stage's samples per ray):
+/* Layer chain of the bf16 mode (m360_set_hidden_chain) - after a forward (same workspace, B, N = the workspace's samples per ray, model;
+ * nerf_rows = B x the NeRF stage's samples per ray):
  * 1 when a workgroup of its layer chain gave up waiting (bounded spin: never a hang) - the outputs of that forward are not to be trusted;
  * 0 otherwise, or when the configuration runs no chain.  Synchronises with the device; bench.py asks once after its timed region. */
 int m360_forward_chain_error(const void *workspace, int B, int N, const m360_model_t *model_host, long nerf_rows);

@@ -352,6 +352,8 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         if (!ext_norm) M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(mode), h->norm_group_rays, nullptr, parts, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
         const int pair = mlp_rows_pairable(mode, hp, m->in_pad) ? 1 : 0;  // paired rows between the layers (m360.h)
         M360_TRY(p_linear_first(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, a, pair, st));
+        // (the proposal MLP's two hidden layers stay two launches: at width 256 the chain - a workgroup owns whole rows there - measured
+        // 0.245 against 0.201 ms, profiles/r04/chain_bench_w256_SLOWER.jsonl: its tiles are too short for the hand-over's fixed costs)
         M360_TRY(p_linear_bf16(h, mode, a, S, m->prop_w[1], m->prop_b[1], hp, hp, M360_ACT_RELU, b, pair, st));
         M360_TRY(p_linear_bf16(h, mode, b, S, m->prop_w[2], m->prop_b[2], hp, hp, M360_ACT_RELU, a, pair, st));
         // last hidden layer + head on the matrix pipe (full 256-row tiles; tail rows through y): ld of y = hp (bf16) / 2 hp ([hi | lo])
@@ -542,9 +544,9 @@ int m360_prof_read(m360_prof_t *p, int i, float *ms, int *kind, long *M, int *n_
 // 1 when a workgroup of the last forward's layer chain (bf16 mode) gave up waiting for its XCD (the bounded spin of m360_mlp_chain_bf16):
 // that forward's outputs are not to be trusted.  Synchronises with the device.  0: no error, or no chain in this configuration.
 int m360_forward_chain_error(const void *workspace, int B, int N, const m360_model_t *model_host, long nerf_rows) {
-    if (!workspace || !model_host || B < 1 || N < 1 || model_host->mlp_bf16 != 1) return 0;
+    if (!workspace || !model_host || B < 1 || N < 1 || model_host->mlp_bf16 != 1 || !g_hidden_chain) return 0;
     const long Mc = (nerf_rows / 32768) * 32768;
-    if (Mc <= 0 || !g_hidden_chain || !m360_mlp_chain_bf16_supported(Mc, model_host->hn_pad, 6)) return 0;
+    if (Mc <= 0 || !m360_mlp_chain_bf16_supported(Mc, model_host->hn_pad, 6)) return 0;
     const FwdLayout L = layout_for(B, N, model_host);
     unsigned word = 0;
     const char *p = static_cast<const char *>(workspace) + L.chain + (size_t)(Mc / 256) * 6 * sizeof(unsigned);

@@ -735,7 +735,8 @@ static bool chain_xcd_map_ok() {
 }
 
 int m360_mlp_chain_bf16_supported(long M, int width, int layers) {
-    if (M <= 0 || M % (128l * w16::BM) != 0 || width != 4 * w16::BN || layers < 1 || layers > 8) return 0;
+    if (M <= 0 || layers < 1 || layers > 8 || (width != 4 * w16::BN && width != w16::BN)) return 0;
+    if (M % ((width == w16::BN ? 512l : 128l) * w16::BM) != 0) return 0;  // an even number of row blocks per group of workgroups
     return cu_count() == 256 && chain_xcd_map_ok();
 }
 
@@ -747,7 +748,7 @@ int m360_mlp_chain_bf16(void *act0, void *act1, long M, int ld, const void *cons
     if (ld < width || ld % 8 != 0 || (((uintptr_t)act0 | (uintptr_t)act1 | (uintptr_t)workspace) & 15))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: ld=%d >= width=%d, a multiple of 8; 16-byte aligned pointers", ld, width);
     if (!m360_mlp_chain_bf16_supported(M, width, layers))
-        return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: M=%ld (a multiple of %ld), width=%d (%d), layers=%d (1..8), a 256-CU device whose workgroup b runs on XCD b %% 8 (m360_mlp_chain_bf16_supported)", M, 128l * w16::BM, width, 4 * w16::BN, layers);
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: M=%ld (a multiple of 32768 at width 1024, of 131072 at width 256), width=%d, layers=%d (1..8), a 256-CU device whose workgroup b runs on XCD b %% 8 (m360_mlp_chain_bf16_supported)", M, width, layers);
     w16::chain_t ch;
     for (int l = 0; l < 8; ++l) {
         ch.w[l] = static_cast<const __bf16 *>(w_packed[l < layers ? l : layers - 1]);
@@ -762,7 +763,7 @@ int m360_mlp_chain_bf16(void *act0, void *act1, long M, int ld, const void *cons
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (hipMemsetAsync(workspace, 0, m360_mlp_chain_bf16_workspace(M, layers), st) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_mlp_chain_bf16: hipMemsetAsync failed");
     hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 128, false, false, false, 0, false, false, true, true>), dim3(256), dim3(w16::kThreads), 0, st,
-                       ch.act[0], M, ld, ch.w[0], ch.b[0], width, width, ch.act[1], ld, 4, ch.row_blocks * 4, nullptr, nullptr, 1, 0, ch);
+                       ch.act[0], M, ld, ch.w[0], ch.b[0], width, width, ch.act[1], ld, width / w16::BN, ch.row_blocks * (width / w16::BN), nullptr, nullptr, 1, 0, ch);
     return check_launch("mlp_chain_bf16");
 }
 

@@ -85,7 +85,7 @@ struct chain_t {
     __bf16 *act[2];
     unsigned *done;   // [8 XCDs][tiles of a workgroup's sequence] (<= row blocks x layers words) + 1 error word at [row blocks x layers], zeroed by the host
     int layers;
-    int row_blocks;   // a multiple of 128: every quartet owns an even number
+    int row_blocks;   // a multiple of 128 (width 1024) / 512 (width 256): every group of workgroups owns an even number
 };
 
 #ifdef M360_DIAG
@@ -166,12 +166,15 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     int tile_id = blockIdx.x;
     if (tile_id >= ntiles) return;
     // CHAIN: this workgroup's column tile and quartet; its sequence of tiles t -> (row block, layer)
-    const int ch_col = (blockIdx.x >> 3) & 3, ch_q = 8 * (blockIdx.x & 7) + (blockIdx.x >> 5);
-    const int ch_T = CHAIN ? (ch.row_blocks / 64) * ch.layers : 0;
+    // (tiles_n = 4: quartets as above; tiles_n = 1 - a 256-wide layer: every workgroup is its own "quartet" and owns the row blocks b + 256 i)
+    const int ch_nq = 256 / tiles_n;  // groups of tiles_n workgroups
+    const int ch_col = tiles_n == 4 ? (blockIdx.x >> 3) & 3 : 0;
+    const int ch_q = tiles_n == 4 ? 8 * (blockIdx.x & 7) + (blockIdx.x >> 5) : 32 * (blockIdx.x & 7) + (blockIdx.x >> 3);
+    const int ch_T = CHAIN ? (ch.row_blocks / ch_nq) * ch.layers : 0;
     auto chain_seq = [&](int t, int &R, int &j) __attribute__((always_inline)) {
         const int two_l = 2 * ch.layers, p_ = t / two_l, rem = t - p_ * two_l;
         j = rem >> 1;
-        R = ch_q + 64 * (2 * p_ + (rem & 1));
+        R = ch_q + ch_nq * (2 * p_ + (rem & 1));
     };
     if (CHAIN) tile_id = 0;
 #ifdef M360_DIAG

@@ -637,23 +637,25 @@ def test_forward_is_the_same_bits_with_and_without_row_blocks(dev, mode):
             ops.set_row_blocks(was)
 
 
-@pytest.mark.parametrize("M,layers", [(32768, 6), (65536, 3), (32768, 1)])
-def test_hidden_layer_chain_in_one_launch(dev, M, layers):
-    """m360_mlp_chain_bf16: `layers` 1024 x 1024 ReLU layers in ONE launch, a row block's next layer waiting for the quartet of workgroups
-    that owns it instead of a kernel boundary - bit for bit what `layers` calls of m360_linear_bf16 on paired rows give, repeatedly (the
-    hand-over through the L2 has no second chance to be wrong quietly: three runs, fresh inputs each)."""
+@pytest.mark.parametrize("M,width,layers", [(32768, 1024, 6), (65536, 1024, 3), (32768, 1024, 1), (131072, 256, 2), (262144, 256, 5)])
+def test_hidden_layer_chain_in_one_launch(dev, M, width, layers):
+    """m360_mlp_chain_bf16: `layers` equally shaped ReLU layers (1024 wide: the NeRF MLP's; 256 wide: the proposal MLP's) in ONE launch, a
+    row block's next layer waiting for the workgroups of its XCD instead of a kernel boundary - bit for bit what `layers` calls of
+    m360_linear_bf16 on paired rows give, repeatedly (the hand-over through the L2 has no second chance to be wrong quietly: three runs,
+    fresh inputs each)."""
     from mipnerf360_amd import _lib, ops
-    if not ops.mlp_chain_bf16_supported(M, 1024, layers):
+    if not ops.mlp_chain_bf16_supported(M, width, layers):
         pytest.skip("needs a 256-CU device whose workgroup b runs on XCD b % 8")
+    assert not ops.mlp_chain_bf16_supported(M + 256, width, layers) and not ops.mlp_chain_bf16_supported(M, 512, layers)
     g = torch.Generator().manual_seed(M + layers)
     packs = []
     for _ in range(layers):
-        w = (torch.randn(1024, 1024, generator=g) * (2.0 / 1024) ** 0.5).to(dev)
-        b = (torch.randn(1024, generator=g) * 0.1).to(dev)
-        packs.append(ops.pack_linear_bf16(w, b, 1024, 1024))
+        w = (torch.randn(width, width, generator=g) * (2.0 / width) ** 0.5).to(dev)
+        b = (torch.randn(width, generator=g) * 0.1).to(dev)
+        packs.append(ops.pack_linear_bf16(w, b, width, width))
     flags = _lib.ACT_RELU | _lib.ROWS_PAIRED_IN | _lib.ROWS_PAIRED_OUT
     for rep in range(3):
-        x = ops.pair_rows(torch.randn(M, 1024, generator=g).to(dev).bfloat16())
+        x = ops.pair_rows(torch.randn(M, width, generator=g).to(dev).bfloat16())
         want = x
         for wp, bp in packs:
             want = ops.linear_bf16(want, wp, bp, flags)
@@ -662,9 +664,9 @@ def test_hidden_layer_chain_in_one_launch(dev, M, layers):
         assert torch.equal(got, want), (rep, int((got != want).sum()))
 
 
-@pytest.mark.parametrize("B,N", [(512, 128), (300, 128), (1024, 33)])
+@pytest.mark.parametrize("B,N", [(1024, 128), (300, 128), (1024, 33)])
 def test_forward_is_the_same_bits_with_and_without_the_hidden_chain(dev, B, N):
-    """m360_set_hidden_chain: the bf16 forward with the six hidden NeRF layers as one launch (default) against six launches - 65536 rows (all
+    """m360_set_hidden_chain: the bf16 forward with the six hidden NeRF layers as one launch (default) against six launches - 131072 rows (all
     in the chain), 38400 (32768 in the chain + 5632 layer by layer) and 33792 rows of 33 samples (ragged rows as well): not a bit may differ."""
     from mipnerf360_amd import _lib
     from mipnerf360_amd.model import mipNeRF360

@@ -15,6 +15,7 @@ from mipnerf360_amd import _lib, ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--c5", action="store_true")
 ap.add_argument("--layers", type=int, default=6)
+ap.add_argument("--width", type=int, default=1024)
 ap.add_argument("--rounds", type=int, default=9)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -22,10 +23,10 @@ M = 8192 * 256 if a.c5 else 4096 * 128
 g = torch.Generator(device=dev).manual_seed(0)
 packs = []
 for _ in range(a.layers):
-    w = (torch.rand(1024, 1024, device=dev, generator=g) * 2 - 1) * (6.0 / 1024) ** 0.5
-    b = torch.rand(1024, device=dev, generator=g) * 0.2 - 0.1
-    packs.append(ops.pack_linear_bf16(w, b, 1024, 1024))
-x = ops.pair_rows((torch.rand(M, 1024, device=dev, generator=g) * 2 - 1).bfloat16())
+    w = (torch.rand(a.width, a.width, device=dev, generator=g) * 2 - 1) * (6.0 / a.width) ** 0.5
+    b = torch.rand(a.width, device=dev, generator=g) * 0.2 - 0.1
+    packs.append(ops.pack_linear_bf16(w, b, a.width, a.width))
+x = ops.pair_rows((torch.rand(M, a.width, device=dev, generator=g) * 2 - 1).bfloat16())
 flags = _lib.ACT_RELU | _lib.ROWS_PAIRED_IN | _lib.ROWS_PAIRED_OUT
 p0, p1 = torch.empty_like(x), torch.empty_like(x)
 
@@ -75,5 +76,5 @@ for rep in range(2):
     m1, b1 = timed(layer_by_layer)
     m2, b2 = timed(chain_only, pre=lambda: c0.copy_(x))
     print(json.dumps({"M": M, "layers": a.layers, "layer_by_layer_ms": round(m1, 4), "chain_ms": round(m2, 4), "best": [round(b1, 4), round(b2, 4)],
-                      "per_layer_ms": [round(m1 / a.layers, 4), round(m2 / a.layers, 4)], "tflops": [round(2.0 * M * 1024 * 1024 * a.layers / m1 / 1e9, 1), round(2.0 * M * 1024 * 1024 * a.layers / m2 / 1e9, 1)],
+                      "per_layer_ms": [round(m1 / a.layers, 4), round(m2 / a.layers, 4)], "width": a.width, "tflops": [round(2.0 * M * a.width * a.width * a.layers / m1 / 1e9, 1), round(2.0 * M * a.width * a.width * a.layers / m2 / 1e9, 1)],
                       "same_bits": same}), flush=True)

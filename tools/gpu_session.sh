@@ -147,6 +147,7 @@ for l in open("$out/hidden_chain_ab.jsonl"):
     d = json.loads(l); c = d["config"]; r = d["roofline"] or {}; print(c.get("name"), "six launches" if c.get("no_chain") else "chain", d["ms_per_step"], d["ms_per_step_median"], r.get("avg_launch_ms"), r.get("frac"), d.get("parity", {}).get("max_abs_rgb") if isinstance(d.get("parity"), dict) else "")
 PYEOF
              ;;
+    chainbench256) timeout 600 python tools/diag/chain_bench.py --width 256 --layers 2 > $out/chain_bench_w256.jsonl 2> $out/chain_bench_w256.err; cat $out/chain_bench_w256.jsonl; tail -2 $out/chain_bench_w256.err ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
