@@ -37,6 +37,8 @@
 //     (1260 against 1136 cycles per 32 deep); starting the workgroups of an XCD up to 30 k cycles apart, so that the 256 epilogues
 //     do not store in the same microseconds, changes nothing (profiles/r03/bf16_w16_start_stagger_REJECTED.jsonl), and the stores
 //     retire within ~270 cycles (ABL 64): what costs is their lines in L2 - the stores are non-temporal (+2 %, see W16_SWAP_STORE).
+// (Round 4 added: paired rows between layers - PAIR, no lane exchange before the stores; 96 of the 256 accumulators in ArchVGPRs; and
+// CHAIN - several equally shaped layers in one launch, see chain_t below.)
 // Takes full 256 x 256 tiles of layers with K a multiple of 128 (>= 256) or K = 64 (ONE_BLOCK: the first layers - all epilogue,
 // 1.07 GB of whole-line stores), bias + {none, ReLU}; in its X3 form every K that is a multiple of 64; with HEADS the sigmoid /
 // fused-heads last layers of the rendering forward.  Everything else (K = 128 / 192, sigmoid without heads, fused heads that also
@@ -228,12 +230,20 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     // CHAIN: wait (bounded) until all 128 waves of this XCD have stored their tile number t of the sequence: the quartet's own (whose rows
     // tile t + 2 fetches) and the seven others' - the 32 workgroups of an XCD stay on the same layer, i.e. on the same 2 MB of weights in
     // their L2 (without this the quartets drift apart over a long sequence: 8192 x 256 rows ran no faster than layer by layer)
+    // A wait that runs out (~0.1 s: a tile takes 26 us; only workgroups that are NOT all resident - a GPU shared with another process -
+    // can get there) sets the error word and ends all further waiting of this wave: one bounded delay per launch, wrong rows, a loud flag.
+    bool ch_gave_up = false;
     auto chain_wait = [&](int t) __attribute__((always_inline)) {
+        if (ch_gave_up) return;
         unsigned *flag = ch.done + (long)(blockIdx.x & 7) * ch_T + t;
         int spins = 0;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 128u) {
-            if (++spins > (1 << 20)) { __hip_atomic_store(ch.done + (long)ch.row_blocks * ch.layers, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 16)) {
+                __hip_atomic_store(ch.done + (long)ch.row_blocks * ch.layers, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ch_gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
         }
     };
 #define W16_CUR_ADV(C, IS_X)                                                                                                 \
