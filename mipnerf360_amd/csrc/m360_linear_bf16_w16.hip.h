@@ -418,6 +418,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     unsigned long long mt0 = 0, rt0 = 0, mt1 = 0, rt1 = 0, e0 = 0, e1 = 0, te = 0, nsl = 0;
     (void)mt1; (void)rt1; (void)e0; (void)e1; (void)te; (void)nsl;
     if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt0), "=s"(rt0)::"memory");
+    bool ch_pending = false;  // CHAIN: the previous tile of the sequence is stored but not yet counted
     int nbias = 0, ch_R = 0, ch_j = 0;  // where the tile's bias starts in the LDS (n0; CHAIN: 256 x layer), CHAIN: the tile's row block and layer
     __bf16 *Yt = Y;
     for (; tile_id < (CHAIN ? ch_T : ntiles); tile_id += (CHAIN ? 1 : G)) {
@@ -454,6 +455,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         } else {
             W16_STAGE0Z();
             W16_STAGE1();
+            // CHAIN: the previous tile's stores are complete by now - this stage's counted waits let only its own pieces stay in flight
+            // (vmcnt retires in order) - so the tile is counted here, not behind a drain at the end of its epilogue
+            if (CHAIN && ch_pending) {
+                if (lane == 0) __hip_atomic_fetch_add(ch.done + (long)(blockIdx.x & 7) * ch_T + (tile_id - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ch_pending = false;
+            }
             for (int s = 2; s < nstages - 2; s += 2) {
                 W16_STAGE0();
                 W16_STAGE1();
@@ -691,9 +698,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                 W16_SB();  // one pair of column pieces at a time
             }
         }
-        if (CHAIN) {  // this wave's rows of tile (R, j) are in the L2: count it
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(ch.done + (long)(blockIdx.x & 7) * ch_T + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (CHAIN) {  // this wave's rows of tile (R, j): counted once its stores are in the L2 - during the next tile's second stage (above),
+            ch_pending = true;  // the sequence's last tile behind a drain
+            if (tile_id + 1 >= ch_T) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(ch.done + (long)(blockIdx.x & 7) * ch_T + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         if (ABL & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostics: drain the stores (and everything else) inside the stamped epilogue
         if (STAMP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e1)::"memory"); te += e1 - e0; nsl += nstages; }
