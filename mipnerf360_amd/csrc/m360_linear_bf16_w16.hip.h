@@ -78,8 +78,9 @@ struct cursor_t { __amdgpu_buffer_rsrc_t rsrc; int k; int tile; };  // an LDS-DM
 // the host checks it once) and own the row blocks Q + 64 i, which they walk in pairs - (Ra, 0), (Rb, 0), (Ra, 1), (Rb, 1), ... - so that the
 // tile whose activation pieces a last stage prefetches never depends on the running one.  Layer j reads act[j & 1], writes act[(j + 1) & 1];
 // tile number t of the sequence - (R, j) - may fetch its activations once all 128 waves of the XCD have stored their tile t - 2, which for
-// its own quartet is (R, j - 1): done[8-entry-per-XCD][t - 2] == 128 (a wave adds 1 after `s_waitcnt vmcnt(0)`: its stores are in the L2
-// both sides share; the readers' pieces carry sc1 and bypass the CU's L1).  That wait also covers the write-after-read on act[(j + 1) & 1].  The spin is bounded: a lost wake-up ends as done[last] = ~0u
+// its own quartet is (R, j - 1): done[XCD][t - 2] == 128 (a wave adds 1 once its tile's stores have retired - behind the counted waits of the
+// NEXT tile's second stage, the last tile behind a drain: the stores are then in the L2 both sides share; the readers' pieces carry sc1 and
+// bypass the CU's L1).  That wait also covers the write-after-read on act[(j + 1) & 1].  The spin is bounded: a lost wake-up ends as done[last] = ~0u
 // (the host's error), not as a hang.
 struct chain_t {
     const __bf16 *w[8];
