@@ -644,6 +644,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         else if (ABL & 4096) W16_STORE2_(S1, S2, ROW, IMM, " sc1 nt");                                                          \
         else if ((ABL & 8192) && (ABL & 128)) W16_STORE2_(S1, S2, ROW, IMM, " sc0 sc1");                                        \
         else if (ABL & 8192) W16_STORE2_(S1, S2, ROW, IMM, " sc0 sc1 nt");                                                      \
+        else if (CHAIN && ch_j + 1 == ch.layers) W16_STORE2_(S1, S2, ROW, IMM, " nt"); /* the chain's result leaves the die */   \
         else if ((ABL & 128) || M360_W16_PLAIN_STORES) W16_STORE2_(S1, S2, ROW, IMM, "");                                       \
         else W16_STORE2_(S1, S2, ROW, IMM, " nt");                                                                              \
     } while (0)
