@@ -672,6 +672,8 @@ def test_ring_kernel_store_instructions_match_its_counted_waits(tmp_path):
         # the layer chain (m360_mlp_chain_bf16): one counter add per tile, activation pieces that bypass the CU's L1
         assert (body.count("global_atomic_add") > 0) == chain and (not chain or body.count(" sc1") >= 128), f"{m.group(1)}: the chain's hand-over instructions"
         want = 8 if heads else (64 if split else 32)
+        if chain:
+            want *= 2  # one of two store policies per tile (temporal inside the chain, non-temporal for its last layer): a wave-uniform branch
         split_without_x3 += int(split and not x3)
         paired += int(pair)
         # paired rows (include/m360.h): the lanes' own pieces are whole lines - no exchange between lanes in that epilogue
