@@ -149,6 +149,8 @@ PYEOF
              ;;
     chainbench256) timeout 600 python tools/diag/chain_bench.py --width 256 --layers 2 > $out/chain_bench_w256.jsonl 2> $out/chain_bench_w256.err; cat $out/chain_bench_w256.jsonl; tail -2 $out/chain_bench_w256.err ;;
     twotenants) timeout 1200 python tools/diag/chain_two_processes.py > $out/chain_two_processes.txt 2>&1; cat $out/chain_two_processes.txt | cut -c1-300 ;;
+    chainsoak) timeout 900 python tools/diag/chain_soak.py --reps 300 > $out/chain_soak.log 2>&1; tail -3 $out/chain_soak.log
+             timeout 900 python tools/diag/chain_soak.py --reps 60 --rows 2097152 >> $out/chain_soak.log 2>&1; tail -2 $out/chain_soak.log ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
