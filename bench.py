@@ -330,7 +330,11 @@ def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     kname = ("linear_bf16_w16_kernel<X3> (bf16x3: 3 MFMA passes per product)" if x3 else "linear_bf16_w16_kernel") if bf16 else "linear_f32_hd_kernel"
     shape = "six 1024x1024 layers in one launch (m360_mlp_chain_bf16)" if nlay == 6 else "1024x1024 layer"
+    # algorithmic bytes of the dominant launch: rows in + rows out + the weight matrices (bf16x3: [hi | lo] rows, three weight blocks)
+    el = 2 if bf16 else 4
+    algorithmic = rows * HN * el * (2 if x3 else 1) * 2 + nlay * HN * kk * el
     roofline = {"bound": "mfma", "kernel": f"{kname} ({shape}, M={rows}" + (f" of the {S} rows" if rows != S else "") + ")", "achieved": round(achieved, 2),
+                "algorithmic_bytes": algorithmic,
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "launches": len(durs), "avg_launch_ms": round(avg_ms, 4),
                 "median_launch_ms": round(statistics.median(durs), 4), "flops_per_launch": flops}
@@ -379,6 +383,20 @@ def hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib, x3=False):
                          "frac_of_8TBps": round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 3), "launches": len(d)}
             assert out[name]["frac_of_8TBps"] <= 1.0, f"{name}: {out[name]} is above the HBM peak - the byte count is wrong"
     return out
+
+
+def chain_delta(model, before=None):
+    """Counters of the bf16 mode's layer chain (model.chain_status(): launches, launches repaired by the gated re-run, waits that ran
+    out, workgroups off their XCD) accumulated since `before`; None outside the bf16 mode.  Informational: outputs are right either way,
+    but a run with recoveries > 0 measured the repaired path."""
+    if getattr(model, "mlp_dtype", "fp32") != "bf16":
+        return None
+    now = model.chain_status()
+    if before is None:
+        return now
+    d = {k: now[k] - before.get(k, 0) for k in ("launches", "recoveries", "timeouts", "xcc_mismatch")}
+    d["chain_error"] = d["recoveries"] > 0
+    return d
 
 
 MLP_NAMES = {"fp32": "fp32", "bf16": "bf16 (fp32 accumulate)",
@@ -505,6 +523,7 @@ def named_workloads(sd_np, dev, _lib):
         m.eval()
         r = synthetic.make_rays("garden", n_rays, seed=1)
         rays = Rays(*[torch.from_numpy(r[k]).to(dev) for k in synthetic.RAY_FIELDS])
+        chain0 = chain_delta(m)
         ms, recs = timed_forward(m, rays, steps, warm, _lib, torch)
         with torch.no_grad():
             rgb, d, a = m(rays)
@@ -515,7 +534,9 @@ def named_workloads(sd_np, dev, _lib):
                      "metric": metric, "rays_per_s": round(n_rays / ms * 1e3, 1), "ms_per_step": round(ms, 3), "steps": steps,
                      "warmup": warm, "finite": finite,
                      "whole_path_tflops": round(n_rays / ms * 1e3 * FLOPS_PER_SAMPLE * samples / 1e12, 1),
-                     "roofline": None if roof is None else {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")}}
+                     "roofline": None if roof is None else {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "traffic", "algorithmic_bytes", "traffic_note") if k in roof}}
+        if chain0 is not None:
+            out[name]["chain"] = chain_delta(m, chain0)
         del m, rays
         torch.cuda.empty_cache()
 
@@ -644,6 +665,7 @@ def worker(args):
         from mipnerf360_amd.distributed import check_replicas
         check_replicas(model)  # one 32-byte all-reduce at setup: every rank holds the same weights / sample counts
 
+    chain0 = chain_delta(model)
     line = {"metric": metric, "value": None, "unit": "rays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if frame_cfg else "weak",
             "vs_baseline": None, "dtype": mlp_dtype if bf16 else "f32", "data": "synthetic"}
@@ -712,10 +734,6 @@ def worker(args):
         comm.fence()
         elapsed = time.perf_counter() - t0
         model.set_prof(None)
-        # bf16 mode: the hidden-layer chain's bounded waits (m360_mlp_chain_bf16) - did any workgroup give up in the last timed step?
-        chain_error = bool(model.chain_error()) if hasattr(model, "chain_error") else False
-        if chain_error:
-            raise SystemExit("bench.py: the hidden-layer chain reported a timed-out wait (m360_forward_chain_error): the run is invalid")
         compute_ms = [e[0].elapsed_time(e[1]) for e in ev]
         gather_ms = [e[1].elapsed_time(e[2]) for e in ev]
         step_ms = [e[0].elapsed_time(e[2]) for e in ev]
@@ -751,6 +769,8 @@ def worker(args):
     # ---- per-kernel numbers from the event records (HIP events on the launch stream, inside the timed region)
     prof.close()
     line["roofline"] = roofline_from_records(recs, S, bf16, args.config, _lib, x3)
+    if chain0 is not None:  # bf16 mode: what the layer chain's self-checks saw over warm-up + timed region (this rank)
+        line["chain"] = chain_delta(model, chain0)
     line["hbm_kernels"] = hbm_kernels_from_records(recs, n_rays, samples, bf16, _lib, x3)
     line["rccl"] = comm.info
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define M360_VERSION 100 /* 0.1.0 */
+#define M360_VERSION 101 /* 0.1.1: status block at the start of the forward workspace; packed-model layout 2 (see checkpoint tooling) */
 
 typedef void *m360_stream_t;
 
@@ -238,11 +238,37 @@ int m360_linear_bf16x3(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M,
  * handed over through the L2 of the XCD whose four CUs own a row block (a counter per row block and layer in `workspace`, zeroed by the
  * call) instead of a kernel boundary - same bits as `layers` calls of m360_linear_bf16.  Shapes: width 1024 with M a multiple of 32768,
  * or width 256 (a workgroup then owns whole rows: its own previous tile is all its next layer needs) with M a multiple of 131072; a
- * 256-CU device whose workgroup b runs on XCD b % 8 (checked once per device): m360_mlp_chain_bf16_supported answers. */
+ * 256-CU device: m360_mlp_chain_bf16_supported answers.
+ * The hand-over relies on two things no API promises, and the kernel checks both itself (round 5): (1) all workgroups b with the same b % 8 run
+ * on ONE XCD - every workgroup reads HW_REG_XCC_ID and compares it with its slot's; (2) all 256 workgroups are resident at the same time - a
+ * kernel on another stream that holds CUs breaks that while it runs; every wait is bounded by wall-clock time (0.1 s), so a launch always
+ * ends.  A launch that found either violated sets the `error` word of the status block at the start of `workspace`
+ * (m360_workspace_status).  m360_mlp_chain_bf16 leaves it at that (its rows are then not to be trusted: the caller must check);
+ * m360_mlp_chain_bf16_safe - what m360_forward / m360_nerf_forward use - reads layer 0's input from a third buffer `x_in` that no layer
+ * writes and queues `layers` GATED launches of m360_linear_bf16's own kernel behind the chain: their workgroups return at once while the
+ * error word is 0 and redo every row layer by layer when it is not (same bits, no host round trip, nothing to check before using the result;
+ * the status block's sticky counters say how often it happened).  workspace: m360_mlp_chain_bf16_workspace(M, layers) bytes,
+ * 16-byte aligned = [status block, 128 bytes | counters]. */
 int m360_mlp_chain_bf16_supported(long M, int width, int layers);
 size_t m360_mlp_chain_bf16_workspace(long M, int layers);
 int m360_mlp_chain_bf16(void *act0_bf16, void *act1_bf16, long M, int ld, const void *const *w_packed_bf16 /*[layers]*/, const float *const *b_packed /*[layers]*/,
                         int layers, int width, void *workspace, m360_stream_t stream);
+int m360_mlp_chain_bf16_safe(const void *x_in_bf16, void *act0_bf16, void *act1_bf16, long M, int ld, const void *const *w_packed_bf16 /*[layers]*/,
+                             const float *const *b_packed /*[layers]*/, int layers, int width, void *workspace, m360_stream_t stream);
+/* The status block: the first 128 bytes of a chain workspace AND of every forward workspace (m360_forward_workspace_bytes).
+ * m360_workspace_init zeroes its sticky counters (once, after allocating the workspace; m360_mlp_chain_bf16 does it per call);
+ * m360_workspace_status copies it out and waits for the stream: out5 = {chain launches that ran, launches repaired by the gated re-run,
+ * waves whose wait ran out, workgroups off their slot's XCD, error word of the LAST launch}.  Counters of a workspace that was never
+ * initialised are meaningless; no result ever depends on them. */
+int m360_workspace_init(void *workspace, m360_stream_t stream);
+int m360_workspace_status(const void *workspace, unsigned *out5_host, m360_stream_t stream);
+/* Test hooks and A/B switches of the chain, process-wide like m360_set_paired_rows.  m360_set_chain_debug: wait_ticks = bound of one wait in
+ * 100 MHz ticks (<= 0: the default, 0.1 s), fault = 0 none, 1 = one workgroup reports a foreign XCD, 2 = every wave treats its first wait
+ * as run out and stops waiting (wrong rows, error set: what the gated re-run must repair), -1 = m360_forward queues NO gated launches
+ * (A/B of their cost only: results are then unchecked).  m360_set_chain_cooperative(1): launch the chain
+ * with hipLaunchCooperativeKernel (co-residency asked of the runtime); returns the old setting. */
+int m360_set_chain_debug(long wait_ticks, int fault);
+int m360_set_chain_cooperative(int on);
 /* 1 when the call `kind` (M360_PAIRABLE_*) with these pads runs its full tiles on the one-wave ring kernel, i.e. takes paired rows */
 int m360_linear_bf16_rows_pairable(int kind, int n_pad, int k_pad);
 /* m360_forward / m360_prop_forward / m360_nerf_forward (bf16 modes) use paired rows between the layers of an MLP whose layers are all
@@ -580,11 +606,9 @@ typedef struct {
 } m360_outputs_t;
 
 size_t m360_forward_workspace_bytes(int B, int N, const m360_model_t *model_host);
-/* Layer chain of the bf16 mode (m360_set_hidden_chain) - after a forward (same workspace, B, N = the workspace's samples per ray, model;
- * nerf_rows = B x the NeRF stage's samples per ray):
- * 1 when a workgroup of its layer chain gave up waiting (bounded spin: never a hang) - the outputs of that forward are not to be trusted;
- * 0 otherwise, or when the configuration runs no chain.  Synchronises with the device; bench.py asks once after its timed region. */
-int m360_forward_chain_error(const void *workspace, int B, int N, const m360_model_t *model_host, long nerf_rows);
+/* Every forward workspace starts with the 128-byte status block of the bf16 mode's layer chain (see m360_mlp_chain_bf16_safe above):
+ * m360_workspace_init(workspace, stream) once after allocating it, m360_workspace_status(workspace, out5, stream) to read the counters.
+ * A forward's OUTPUTS never need checking: a chain launch that reports an error is repaired on the device by the gated launches behind it. */
 
 /* prop_net.forward, model.py:80-94 -> out->t_hat, out->w_hat (both required).
  * t_rand: optional uniforms [B,N+1] for randomized=True. */

@@ -98,7 +98,11 @@ SIGNATURES = {
     "m360_linear_bf16_rows_pairable": (_i, [_i, _i, _i]),
     "m360_set_paired_rows": (_i, [_i]),
     "m360_set_hidden_chain": (_i, [_i]),
-    "m360_forward_chain_error": (_i, [_vp, _i, _i, _vp, _l]),
+    "m360_mlp_chain_bf16_safe": (_i, [_vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "m360_workspace_init": (_i, [_vp, _vp]),
+    "m360_workspace_status": (_i, [_vp, _P(C.c_uint), _vp]),
+    "m360_set_chain_debug": (_i, [_l, _i]),
+    "m360_set_chain_cooperative": (_i, [_i]),
     "m360_set_row_blocks": (_l, [_l]),
     "m360_set_row_block_streams": (_i, [_i]),
     "m360_pack_linear_bf16x6": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -59,6 +59,12 @@ int nerf_finish_stage(const void *act, int act_bf16, int ld, const float *head_p
                       float *distance, float *acc, float *weights, float *t_vals_out, float *s_vals_out, const unsigned char *nanflag,
                       m360_stream_t stream);
 
+// m360_linear.hip: the hidden-layer chain of the bf16 mode (one launch) and its gated layer-by-layer re-run
+int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
+                          int layers, int width, void *ws, m360_stream_t stream);
+int mlp_chain_bf16_rerun(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
+                         int layers, int width, void *ws, m360_stream_t stream);
+
 // brackets the launches of ONE public entry point with two HIP events on the launch stream
 struct ProfScope {
     m360_prof *p;
@@ -117,6 +123,9 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     const size_t wmax = (size_t)(m->hp_pad > m->hn_pad ? m->hp_pad : m->hn_pad);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    // offset 0 of EVERY forward workspace: the 128-byte status block (m360_workspace_init / m360_workspace_status), in bf16 mode followed
+    // by the counters of the hidden-layer chain (m360_mlp_chain_bf16_workspace = status + counters)
+    L.chain = take(m->mlp_bf16 == 1 && S >= 32768 ? m360_mlp_chain_bf16_workspace((long)(S / 32768) * 32768, 6) : 128);
     L.norm = take(m360_contract_workspace_bytes());
     L.vdenc = take((size_t)B * (vd_ch > 0 ? vd_ch : 1) * sizeof(float));
     L.t1 = take((size_t)B * (N + 1) * sizeof(float));
@@ -135,8 +144,6 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     L.queues = take((size_t)2 * kQueueSlots * kQueueStride * sizeof(unsigned));  // one set per stage
     // bf16 modes: one byte per sample, "a feature of this sample is NaN" (the bf16 pipe's ReLU drops NaN: the finishers restore it)
     L.nanflag = take(m->mlp_bf16 ? S : 0);
-    // bf16 mode: the counters of the hidden-layer chain (m360_mlp_chain_bf16)
-    L.chain = take(m->mlp_bf16 == 1 ? m360_mlp_chain_bf16_workspace((long)S, 6) : 0);
     L.total = off;
     return L;
 }
@@ -442,24 +449,33 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
             if (rc_blocks != M360_OK) return rc_blocks;
             src = a; dst = b;
         } else {
-        M360_TRY(p_linear_first(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, a, pair, st));
         // the six hidden layers: ONE launch for the rows the chain takes (bf16 mode, paired rows, width 1024, multiples of 32768 rows:
         // m360_mlp_chain_bf16 - the activations handed over through the XCDs' L2s instead of six kernel boundaries), layer by layer the rest
         const long Mc = (mode == 1 && pair && g_hidden_chain) ? (S / 32768) * 32768 : 0;
         const bool chain = Mc > 0 && m360_mlp_chain_bf16_supported(Mc, hn, 6);
+        // With the chain the first layer writes to a THIRD buffer - the upper half of `a`, which is sized for fp32 rows and holds bf16 ones
+        // here - that no hidden layer writes: what the chain read stays intact, so the launch can be repeated layer by layer when it reports
+        // that one of its assumptions did not hold (gated launches queued behind it: empty unless its error word is set).
+        float *first = chain ? reinterpret_cast<float *>(reinterpret_cast<char *>(a) + (size_t)S * ldl * 2) : a;
+        M360_TRY(p_linear_first(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, first, pair, st));
         if (chain) {
             const void *cw[6];
             const float *cb[6];
             for (int layer = 1; layer < 7; ++layer) { cw[layer - 1] = m->nerf_w[layer]; cb[layer - 1] = m->nerf_b[layer]; }
-            ProfScope ps(h, st, M360_K_LINEAR_BF16, Mc, hn, 6 * hn);  // k_pad = 6 hn: six layers in one record
-            M360_TRY(ps.done(m360_mlp_chain_bf16(a, b, Mc, hn, cw, cb, 6, hn, ws + L.chain, st)));
+            {
+                ProfScope ps(h, st, M360_K_LINEAR_BF16, Mc, hn, 6 * hn);  // k_pad = 6 hn: six layers in one record (the chain kernel alone)
+                M360_TRY(ps.done(mlp_chain_bf16_launch(first, a, b, Mc, hn, cw, cb, 6, hn, ws + L.chain, st)));
+            }
+            M360_TRY(mlp_chain_bf16_rerun(first, a, b, Mc, hn, cw, cb, 6, hn, ws + L.chain, st));
         }
-        const long r0 = chain ? Mc : 0;  // rows [r0, S) layer by layer (both parts end in `a`: six swaps)
+        const long r0 = chain ? Mc : 0;  // rows [r0, S) layer by layer; both parts end in `a`: first -> b -> a -> b -> a -> b -> a
         if (r0 < S) {
-            float *ts = reinterpret_cast<float *>(reinterpret_cast<char *>(a) + (size_t)r0 * ldl * 2), *td = reinterpret_cast<float *>(reinterpret_cast<char *>(b) + (size_t)r0 * ldl * 2);
+            const size_t ro = (size_t)r0 * ldl * 2;
+            float *ts = reinterpret_cast<float *>(reinterpret_cast<char *>(first) + ro);
             for (int layer = 1; layer < 7; ++layer) {
+                float *td = reinterpret_cast<float *>(reinterpret_cast<char *>((layer & 1) ? b : a) + ro);
                 M360_TRY(p_linear_bf16(h, mode, ts, S - r0, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, td, pair, st));
-                float *tmp = ts; ts = td; td = tmp;
+                ts = td;
             }
         }
         M360_TRY(p_linear_heads(h, mode, src, S, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, dst, ldl, 0, m->nerf_head_w, 4, hpart, st, pair));
@@ -541,19 +557,6 @@ int m360_prof_read(m360_prof_t *p, int i, float *ms, int *kind, long *M, int *n_
     return M360_OK;
 }
 
-// 1 when a workgroup of the last forward's layer chain (bf16 mode) gave up waiting for its XCD (the bounded spin of m360_mlp_chain_bf16):
-// that forward's outputs are not to be trusted.  Synchronises with the device.  0: no error, or no chain in this configuration.
-int m360_forward_chain_error(const void *workspace, int B, int N, const m360_model_t *model_host, long nerf_rows) {
-    if (!workspace || !model_host || B < 1 || N < 1 || model_host->mlp_bf16 != 1 || !g_hidden_chain) return 0;
-    const long Mc = (nerf_rows / 32768) * 32768;
-    if (Mc <= 0 || !m360_mlp_chain_bf16_supported(Mc, model_host->hn_pad, 6)) return 0;
-    const FwdLayout L = layout_for(B, N, model_host);
-    unsigned word = 0;
-    const char *p = static_cast<const char *>(workspace) + L.chain + (size_t)(Mc / 256) * 6 * sizeof(unsigned);
-    if (hipMemcpy(&word, p, sizeof(word), hipMemcpyDeviceToHost) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_forward_chain_error: hipMemcpy failed: %s", hipGetErrorString(hipGetLastError()));
-    return word != 0 ? 1 : 0;
-}
-
 size_t m360_forward_workspace_bytes(int B, int N, const m360_model_t *model_host) {
     if (!model_host || B < 0 || N < 1) return 0;
     return layout_for(B, N, model_host).total;
@@ -618,6 +621,7 @@ static BwdLayout bwd_layout_for(int B, int N, const m360_model_t *m, int stage) 
     const int kmax = width > m->in_pad ? width : m->in_pad;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    (void)take(128);  // a caller may hand in the buffer it uses as forward workspace: its status block (offset 0) is left alone
     L.dz_a = take(S * width * sizeof(float));
     L.dz_b = take(S * width * sizeof(float));
     L.gemm = take(m360_linear_wgrad_workspace_bytes((long)S, width, kmax));

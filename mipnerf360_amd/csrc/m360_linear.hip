@@ -709,62 +709,145 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
 }
 
 // ---- the chain of equally shaped bf16 ReLU layers in one launch (w16::chain_t, m360_linear_bf16_w16.hip.h)
-__global__ void xcc_probe_kernel(int *xcc) {
-    unsigned x;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
-    if (threadIdx.x == 0) xcc[blockIdx.x] = (int)x;
+// Process-wide switches like m360_set_paired_rows (tests and A/B runs): the bound of one wait, a fault to inject, cooperative launch.
+static unsigned g_chain_wait_ticks = w16::kChainWaitTicks;
+static int g_chain_fault = 0;
+static int g_chain_cooperative = 0;
+int m360_set_chain_debug(long wait_ticks, int fault) {
+    g_chain_wait_ticks = wait_ticks > 0 ? (unsigned)wait_ticks : w16::kChainWaitTicks;
+    g_chain_fault = fault;
+    return M360_OK;
 }
-// does workgroup b of a 256-workgroup launch run on XCD b % 8 on this device (what lets a quartet hand its rows over through ONE L2)?
-static bool chain_xcd_map_ok() {
-    static int cached[64];  // 0 unknown, 1 yes, 2 no
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
-    if (cached[dev]) return cached[dev] == 1;
-    int *d = nullptr, h[256];
-    bool ok = hipMalloc(&d, sizeof(h)) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(xcc_probe_kernel, dim3(256), dim3(64), 0, 0, d);
-        ok = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess;
-        (void)hipFree(d);
-        for (int b = 8; ok && b < 256; ++b) ok = h[b] == h[b & 7];
-        for (int b = 0; ok && b < 8; ++b) for (int c = 0; c < b; ++c) ok = ok && h[b] != h[c];
-    }
-    if (!ok) (void)hipGetLastError();
-    cached[dev] = ok ? 1 : 2;
-    return ok;
-}
+int m360_set_chain_cooperative(int on) { const int was = g_chain_cooperative; g_chain_cooperative = on ? 1 : 0; return was; }
 
+// Shapes and device the chain takes.  Nothing is probed: the placement the hand-over relies on (workgroup b on the XCD of slot b % 8) is
+// checked by every launch itself, inside the kernel, and a launch that finds it violated is re-run layer by layer (mlp_chain_bf16_rerun).
 int m360_mlp_chain_bf16_supported(long M, int width, int layers) {
     if (M <= 0 || layers < 1 || layers > 8 || (width != 4 * w16::BN && width != w16::BN)) return 0;
     if (M % ((width == w16::BN ? 512l : 128l) * w16::BM) != 0) return 0;  // an even number of row blocks per group of workgroups
-    return cu_count() == 256 && chain_xcd_map_ok();
+    return cu_count() == 256;
 }
 
-size_t m360_mlp_chain_bf16_workspace(long M, int layers) { return ((size_t)(M / w16::BM) * (size_t)layers + 1) * sizeof(unsigned); }
+// [chain_status_t (128 bytes) | one counter per row block and layer]
+size_t m360_mlp_chain_bf16_workspace(long M, int layers) { return sizeof(w16::chain_status_t) + (size_t)(M / w16::BM) * (size_t)layers * sizeof(unsigned); }
 
-int m360_mlp_chain_bf16(void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed, int layers,
-                        int width, void *workspace, m360_stream_t stream) {
-    if (!act0 || !act1 || !w_packed || !b_packed || !workspace) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: null pointer");
-    if (ld < width || ld % 8 != 0 || (((uintptr_t)act0 | (uintptr_t)act1 | (uintptr_t)workspace) & 15))
-        return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: ld=%d >= width=%d, a multiple of 8; 16-byte aligned pointers", ld, width);
-    if (!m360_mlp_chain_bf16_supported(M, width, layers))
-        return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: M=%ld (a multiple of 32768 at width 1024, of 131072 at width 256), width=%d, layers=%d (1..8), a 256-CU device whose workgroup b runs on XCD b %% 8 (m360_mlp_chain_bf16_supported)", M, width, layers);
+int m360_workspace_init(void *workspace, m360_stream_t stream) {
+    if (!workspace || ((uintptr_t)workspace & 15)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_workspace_init: null or unaligned workspace");
+    if (hipMemsetAsync(workspace, 0, sizeof(w16::chain_status_t), reinterpret_cast<hipStream_t>(stream)) != hipSuccess)
+        return fail(M360_ERR_LAUNCH, "m360_workspace_init: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+    return M360_OK;
+}
+
+int m360_workspace_status(const void *workspace, unsigned *out5, m360_stream_t stream) {
+    if (!workspace || !out5) return fail(M360_ERR_INVALID_ARGUMENT, "m360_workspace_status: null pointer");
+    w16::chain_status_t h;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(&h, workspace, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return fail(M360_ERR_LAUNCH, "m360_workspace_status: copy failed: %s", hipGetErrorString(hipGetLastError()));
+    out5[0] = h.launches; out5[1] = h.recoveries; out5[2] = h.timeouts; out5[3] = h.xcc_mismatch; out5[4] = h.error;
+    return M360_OK;
+}
+
+}  // extern "C"
+
+namespace m360 {
+
+// One chain launch.  ws = [chain_status_t | counters]; the launch part of the status and the counters are zeroed here (one memset), the
+// sticky counters are left alone.  x_in (may be NULL: act0) is what layer 0 reads.
+int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
+                          int layers, int width, void *ws, m360_stream_t stream) {
     w16::chain_t ch;
     for (int l = 0; l < 8; ++l) {
         ch.w[l] = static_cast<const __bf16 *>(w_packed[l < layers ? l : layers - 1]);
         ch.b[l] = b_packed[l < layers ? l : layers - 1];
         if (!ch.w[l] || !ch.b[l] || (((uintptr_t)ch.w[l] | (uintptr_t)ch.b[l]) & 15)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16: layer %d: null or unaligned weights / bias", l);
     }
+    ch.x_in = static_cast<const __bf16 *>(x_in);
     ch.act[0] = static_cast<__bf16 *>(act0);
     ch.act[1] = static_cast<__bf16 *>(act1);
-    ch.done = static_cast<unsigned *>(workspace);
+    ch.status = static_cast<w16::chain_status_t *>(ws);
+    ch.done = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + sizeof(w16::chain_status_t));
     ch.layers = layers;
     ch.row_blocks = (int)(M / w16::BM);
+    ch.wait_ticks = g_chain_wait_ticks;
+    ch.fault = g_chain_fault;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(workspace, 0, m360_mlp_chain_bf16_workspace(M, layers), st) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_mlp_chain_bf16: hipMemsetAsync failed");
-    hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 128, false, false, false, 0, false, false, true, true>), dim3(256), dim3(w16::kThreads), 0, st,
-                       ch.act[0], M, ld, ch.w[0], ch.b[0], width, width, ch.act[1], ld, width / w16::BN, ch.row_blocks * (width / w16::BN), nullptr, nullptr, 1, 0, ch);
+    if (hipMemsetAsync(static_cast<char *>(ws) + w16::kChainStatusLaunchOffset, 0, m360_mlp_chain_bf16_workspace(M, layers) - w16::kChainStatusLaunchOffset, st) != hipSuccess)
+        return fail(M360_ERR_LAUNCH, "m360_mlp_chain_bf16: hipMemsetAsync failed");
+    auto kern = w16::linear_bf16_w16_kernel<M360_ACT_RELU, 128, false, false, false, 0, false, false, true, true>;
+    const __bf16 *X = ch.x_in ? ch.x_in : ch.act[0], *W0 = ch.w[0];
+    const float *B0 = ch.b[0], *hw = nullptr;
+    __bf16 *Y = ch.act[1];
+    float *hp = nullptr;
+    int tiles_n = width / w16::BN, ntiles = ch.row_blocks * tiles_n, xpair = 1, stagger = 0, gate_first = 0;
+    unsigned *gate = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool coop = g_chain_cooperative && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    if (coop) {  // co-residency of the 256 workgroups asked of the runtime (A/B: m360_set_chain_cooperative)
+        void *args[] = {&X, &M, &ld, &W0, &B0, &width, &width, &Y, &ld, &tiles_n, &ntiles, &hw, &hp, &xpair, &stagger, &ch, &gate, &gate_first};
+        if (hipLaunchCooperativeKernel(reinterpret_cast<void *>(kern), dim3(256), dim3(w16::kThreads), args, 0, st) != hipSuccess)
+            return fail(M360_ERR_LAUNCH, "m360_mlp_chain_bf16: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
+    } else {
+        hipLaunchKernelGGL(kern, dim3(256), dim3(w16::kThreads), 0, st, X, M, ld, W0, B0, width, width, Y, ld, tiles_n, ntiles, hw, hp, xpair, stagger, ch, gate, gate_first);
+    }
     return check_launch("mlp_chain_bf16");
+}
+
+// The same layers, layer by layer, as GATED launches behind a chain launch: every workgroup first reads the launch's error word and returns
+// at once when it is 0 (the normal case: `layers` empty launches); when the chain kernel reported a wait that ran out or a workgroup off
+// its XCD, these launches redo all of its rows from x_in (which the chain never writes) - the very kernel m360_linear_bf16 runs for a
+// hidden layer on paired rows, hence the same bits.  No host round trip, nothing for a caller to check before using the result.
+int mlp_chain_bf16_rerun(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
+                         int layers, int width, void *ws, m360_stream_t stream) {
+    if (g_chain_fault == -1) return M360_OK;  // A/B of the gated launches' cost (m360_set_chain_debug): the chain alone, unchecked
+    const int cus = cu_count();
+    if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_mlp_chain_bf16: no HIP device");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    unsigned *gate = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + w16::kChainStatusLaunchOffset);
+    const long nt = (M / w16::BM) * (width / w16::BN);
+    dim3 grid((unsigned)(nt < cus ? nt : cus)), block(w16::kThreads);
+    __bf16 *act[2] = {static_cast<__bf16 *>(act0), static_cast<__bf16 *>(act1)};
+    for (int j = 0; j < layers; ++j) {
+        const __bf16 *src = j == 0 ? static_cast<const __bf16 *>(x_in) : act[j & 1];
+        hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, false, false, 0, false, false, true>), grid, block, 0, st, src, M, ld,
+                           static_cast<const __bf16 *>(w_packed[j]), b_packed[j], width, width, act[(j + 1) & 1], ld, width / w16::BN, (int)nt, nullptr, nullptr, 1, 0,
+                           w16::chain_t(), gate, j == 0 ? 1 : 0);
+    }
+    return check_launch("mlp_chain_bf16 (gated re-run)");
+}
+
+static int chain_args_ok(const char *who, const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
+                         int layers, int width, void *workspace) {
+    if (!act0 || !act1 || !w_packed || !b_packed || !workspace) return fail(M360_ERR_INVALID_ARGUMENT, "%s: null pointer", who);
+    if (ld < width || ld % 8 != 0 || (((uintptr_t)x_in | (uintptr_t)act0 | (uintptr_t)act1 | (uintptr_t)workspace) & 15))
+        return fail(M360_ERR_INVALID_ARGUMENT, "%s: ld=%d >= width=%d, a multiple of 8; 16-byte aligned pointers", who, ld, width);
+    if (!m360_mlp_chain_bf16_supported(M, width, layers))
+        return fail(M360_ERR_INVALID_ARGUMENT, "%s: M=%ld (a multiple of 32768 at width 1024, of 131072 at width 256), width=%d, layers=%d (1..8), a 256-CU device (m360_mlp_chain_bf16_supported)", who, M, width, layers);
+    return M360_OK;
+}
+
+}  // namespace m360
+
+extern "C" {
+
+int m360_mlp_chain_bf16(void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed, int layers,
+                        int width, void *workspace, m360_stream_t stream) {
+    const int rc = chain_args_ok("m360_mlp_chain_bf16", nullptr, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace);
+    if (rc != M360_OK) return rc;
+    const int rc2 = m360_workspace_init(workspace, stream);  // a standalone call's status is its own
+    if (rc2 != M360_OK) return rc2;
+    return mlp_chain_bf16_launch(nullptr, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream);
+}
+
+int m360_mlp_chain_bf16_safe(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
+                             int layers, int width, void *workspace, m360_stream_t stream) {
+    if (!x_in || x_in == act0 || x_in == act1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16_safe: x_in must be a third buffer (the re-run reads it again)");
+    const int rc = chain_args_ok("m360_mlp_chain_bf16_safe", x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace);
+    if (rc != M360_OK) return rc;
+    if (width != 4 * w16::BN) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16_safe: width=%d (1024: the NeRF MLP's hidden layers)", width);
+    const int rc2 = mlp_chain_bf16_launch(x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream);
+    if (rc2 != M360_OK) return rc2;
+    return mlp_chain_bf16_rerun(x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream);
 }
 
 int m360_pack_linear_bf16x6(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed6,

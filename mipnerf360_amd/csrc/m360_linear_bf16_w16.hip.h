@@ -72,23 +72,55 @@ constexpr int kAccVBlocks = M360_W16_ACC_V_BLOCKS;  // activation blocks (of 8) 
 
 struct cursor_t { __amdgpu_buffer_rsrc_t rsrc; int k; int tile; };  // an LDS-DMA cursor: descriptor of its tile, byte offset in a row
 
-// CHAIN (round 4): up to 8 equally shaped ReLU layers (width x width, paired rows) in ONE launch of exactly 256 workgroups, the hidden
-// activations handed from layer to layer through the XCD's L2 instead of a kernel boundary.  Workgroup b is column tile c = (b / 8) & 3 of
-// quartet Q = 8 (b % 8) + (b / 8) / 4: the four workgroups of a quartet run on four CUs of XCD b % 8 (profiles/r04/xcc_of_workgroups.txt;
-// the host checks it once) and own the row blocks Q + 64 i, which they walk in pairs - (Ra, 0), (Rb, 0), (Ra, 1), (Rb, 1), ... - so that the
-// tile whose activation pieces a last stage prefetches never depends on the running one.  Layer j reads act[j & 1], writes act[(j + 1) & 1];
-// tile number t of the sequence - (R, j) - may fetch its activations once all 128 waves of the XCD have stored their tile t - 2, which for
-// its own quartet is (R, j - 1): done[XCD][t - 2] == 128 (a wave adds 1 once its tile's stores have retired - behind the counted waits of the
-// NEXT tile's second stage, the last tile behind a drain: the stores are then in the L2 both sides share; the readers' pieces carry sc1 and
-// bypass the CU's L1).  That wait also covers the write-after-read on act[(j + 1) & 1].  The spin is bounded: a lost wake-up ends as done[last] = ~0u
-// (the host's error), not as a hang.
+// CHAIN (round 4; hardened in round 5): up to 8 equally shaped ReLU layers (width x width, paired rows) in ONE launch of exactly 256 workgroups,
+// the hidden activations handed from layer to layer through the XCD's L2 instead of a kernel boundary.  Workgroup b is column tile c = (b / 8) & 3 of
+// quartet Q = 8 (b % 8) + (b / 8) / 4: the four workgroups of a quartet run on four CUs of the XCD that serves slot b % 8 and own the row blocks
+// Q + 64 i, which they walk in pairs - (Ra, 0), (Rb, 0), (Ra, 1), (Rb, 1), ... - so that the tile whose activation pieces a last stage prefetches
+// never depends on the running one.  Layer 0 reads x_in (never written: the launch can be repeated), layer j >= 1 reads act[j & 1]; layer j
+// writes act[(j + 1) & 1]; tile number t of the sequence - (R, j) - may fetch its activations once all 128 waves of the XCD have stored their
+// tile t - 2, which for its own quartet is (R, j - 1): done[slot][t - 2] == 128 (a wave adds 1 once its tile's stores have retired - behind the
+// counted waits of the NEXT tile's second stage, the last tile behind a drain: the stores are then in the L2 both sides share; the readers'
+// pieces carry sc1 and bypass the CU's L1).  That wait also covers the write-after-read on act[(j + 1) & 1].
+// The two things the hand-over RELIES on are checked by the kernel itself and reported in chain_status_t::error, which gates a layer-by-layer
+// re-run queued behind every launch (m360_linear.hip: mlp_chain_bf16_safe) - a launch whose assumptions did not hold costs time, never rows:
+//   * placement: all workgroups of slot s = b % 8 run on ONE XCD (one L2).  Every workgroup reads HW_REG_XCC_ID and compares it with what the
+//     first workgroup of its slot published (xcc_slot[s]); a difference sets kChainErrXcc.  (The dispatcher's round-robin over the XCDs is a
+//     hardware habit, not a contract: MI355X_MICROARCH.md uses it for speed only.)
+//   * residency: all 256 workgroups run at the same time (one per CU: 144 KiB of LDS).  A kernel on another stream that holds CUs - an RCCL
+//     all-gather waiting for its peers, a second renderer - breaks that for as long as it runs.  Waits are bounded by wall-clock time
+//     (wait_ticks of s_memrealtime, 0.1 s): a wait that runs out sets kChainErrTimeout and ends all further waiting of its wave, so the launch
+//     always ends, with wrong rows that the gated re-run then overwrites.
+// Status block of a chain launch (device memory, 128 bytes; the chain's counters follow it directly, so ONE memset prepares a launch).
+// First line: sticky counters, only ever incremented (m360_workspace_init zeroes them once): what a caller reads to learn that launches were
+// repaired, and why.  Second line: zeroed by the host before EVERY launch - `error` is also the gate of the layer-by-layer re-run the host
+// queues behind the launch (gated launches: a workgroup that reads 0 there returns at once), `xcc_slot[s]` the XCD id + 1 the first
+// workgroup of slot s = blockIdx.x & 7 found itself on.
+struct chain_status_t {
+    unsigned launches;      // chain launches that ran (workgroup 0 counts)
+    unsigned timeouts;      // waves that gave up waiting
+    unsigned xcc_mismatch;  // workgroups that were not on the XCD of their slot
+    unsigned recoveries;    // launches re-run layer by layer (counted by the first gated launch that found `error` set)
+    unsigned pad0[12];
+    unsigned error;         // != 0: this launch's rows are not to be trusted (bit 0: a wait ran out, bit 1: a workgroup off its slot's XCD)
+    unsigned xcc_slot[8];
+    unsigned pad1[7];
+};
+static_assert(sizeof(chain_status_t) == 128, "two 64-byte lines");
+constexpr int kChainStatusLaunchOffset = 64;  // offsetof(chain_status_t, error): what the per-launch memset starts at
+constexpr unsigned kChainErrTimeout = 1u, kChainErrXcc = 2u;
+constexpr unsigned kChainWaitTicks = 10u * 1000u * 1000u;  // bound of one wait in s_memrealtime ticks (100 MHz): 0.1 s where a tile takes 26 us
+
 struct chain_t {
     const __bf16 *w[8];
     const float *b[8];
-    __bf16 *act[2];
-    unsigned *done;   // [8 XCDs][tiles of a workgroup's sequence] (<= row blocks x layers words) + 1 error word at [row blocks x layers], zeroed by the host
+    const __bf16 *x_in;  // layer 0 reads this (paired rows); it is never written, so the layers can be re-run (NULL: act[0])
+    __bf16 *act[2];      // layer j writes act[(j + 1) & 1]; layer j >= 1 reads act[j & 1]
+    unsigned *done;      // [8 XCDs][tiles of a workgroup's sequence] (<= row blocks x layers words), zeroed by the host
+    chain_status_t *status;
     int layers;
-    int row_blocks;   // a multiple of 128 (width 1024) / 512 (width 256): every group of workgroups owns an even number
+    int row_blocks;      // a multiple of 128 (width 1024) / 512 (width 256): every group of workgroups owns an even number
+    unsigned wait_ticks; // bound of one wait (kChainWaitTicks; tests shrink it to force the give-up path)
+    int fault;           // test hook: 1 = workgroup 9 reports a foreign XCD, 2 = every wave treats its first wait as run out
 };
 
 #ifdef M360_DIAG
@@ -133,7 +165,7 @@ template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BL
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, const float *__restrict__ head_w = nullptr,
-    float *__restrict__ head_part = nullptr, int xpair = 0, int stagger = 0, chain_t ch = chain_t()) {
+    float *__restrict__ head_part = nullptr, int xpair = 0, int stagger = 0, chain_t ch = chain_t(), unsigned *gate = nullptr, int gate_first = 0) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0) + (LDSEPI ? 4 * 4096 : 0)];  // 144 (160) KiB
     static_assert(!LDSEPI || (HEADS == 0 && !SPLIT && !X3 && !PAIR), "the LDS epilogue: plain bf16 output (its 16 KiB sit where the head rows would)");
     static_assert(!PAIR || HEADS == 0, "paired rows are a layout of the layer's own output");
@@ -148,6 +180,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     constexpr int W16_STORES = STORE_Y ? (SPLIT ? 64 : 32) : 8;
     static_assert(ACT == M360_ACT_NONE || ACT == M360_ACT_RELU || (ACT == M360_ACT_SIGMOID && (ABL != 0 || HEADS > 0)), "bias + {none, ReLU}; sigmoid with fused heads");
 
+    // gated launch (the layer-by-layer re-run behind a chain launch): nothing to do unless the chain reported an error; the first gated
+    // launch that finds one counts the recovery (gate = &chain_status_t::error: the sticky counters are the 64 bytes in front of it)
+    if (gate != nullptr) {
+        if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+        if (gate_first && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(&reinterpret_cast<chain_status_t *>(reinterpret_cast<char *>(gate) - kChainStatusLaunchOffset)->recoveries, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,6 +218,21 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         R = ch_q + ch_nq * (2 * p_ + (rem & 1));
     };
     if (CHAIN) tile_id = 0;
+    auto chain_src = [&](int j) __attribute__((always_inline)) -> const __bf16 * { return (j == 0 && ch.x_in) ? ch.x_in : ch.act[j & 1]; };
+    if (CHAIN) {  // placement check: is this workgroup on the XCD the first workgroup of its slot ran on?
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        if (ch.fault == 1 && blockIdx.x == 9) xcc ^= 1u;
+        if (threadIdx.x == 0) {
+            unsigned seen = 0u;
+            __hip_atomic_compare_exchange_strong(&ch.status->xcc_slot[blockIdx.x & 7], &seen, xcc + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen != 0u && seen != xcc + 1u) {
+                __hip_atomic_fetch_or(&ch.status->error, kChainErrXcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&ch.status->xcc_mismatch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (blockIdx.x == 0) __hip_atomic_fetch_add(&ch.status->launches, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #ifdef M360_DIAG
     // diagnostics (round 4): start the eight row blocks an XCD works on at once `stagger` x ~1 k cycles apart (the four column tiles of a
     // row block stay together: they share its activation rows through the L2), so that the 256 CUs do not store their tiles in the same
@@ -220,7 +273,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
         if (CHAIN) {
             int R_, j_;
             chain_seq(0, R_, j_);
-            x0 = ch.act[0] + (long)R_ * BM * ldx;
+            x0 = chain_src(0) + (long)R_ * BM * ldx;
             w0 = ch.w[0] + (long)(ch_col * BN) * Kp;
         }
         cx.rsrc = cx2.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(x0), 0, 0x7fffffff, 0x00020000);
@@ -231,21 +284,24 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     // CHAIN: wait (bounded) until all 128 waves of this XCD have stored their tile number t of the sequence: the quartet's own (whose rows
     // tile t + 2 fetches) and the seven others' - the 32 workgroups of an XCD stay on the same layer, i.e. on the same 2 MB of weights in
     // their L2 (without this the quartets drift apart over a long sequence: 8192 x 256 rows ran no faster than layer by layer)
-    // A wait that runs out (~0.1 s: a tile takes 26 us; only workgroups that are NOT all resident - a GPU shared with another process -
-    // can get there) sets the error word and ends all further waiting of this wave: one bounded delay per launch, wrong rows, a loud flag.
+    // A wait that runs out (wait_ticks of the 100 MHz clock: 0.1 s where a tile takes 26 us; only workgroups that are NOT all resident can get
+    // there) sets the error bit and ends all further waiting of this wave: one bounded delay per launch, wrong rows, and the gated re-run behind
+    // the launch puts them right.
     bool ch_gave_up = false;
     auto chain_wait = [&](int t) __attribute__((always_inline)) {
         if (ch_gave_up) return;
         unsigned *flag = ch.done + (long)(blockIdx.x & 7) * ch_T + t;
-        int spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 128u) {
-            if (++spins > (1 << 16)) {
-                __hip_atomic_store(ch.done + (long)ch.row_blocks * ch.layers, ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ch_gave_up = true;
-                break;
+        bool lost = ch.fault == 2;
+        if (!lost && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 128u) {
+            unsigned long long t0, t1;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 128u) {
+                __builtin_amdgcn_s_sleep(8);
+                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+                if (t1 - t0 > (unsigned long long)ch.wait_ticks) { lost = true; break; }
             }
-            __builtin_amdgcn_s_sleep(8);
         }
+        if (lost) ch_gave_up = true;  // scalar state only: the wave reports it once, behind its tile loop (nothing divergent in the K loop)
     };
 #define W16_CUR_ADV(C, IS_X)                                                                                                 \
     do {                                                                                                                     \
@@ -259,7 +315,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                     chain_seq(C.tile, R_, j_);                                                                               \
                     if (IS_X) {                                                                                              \
                         if (C.tile >= 2) chain_wait(C.tile - 2);                                                             \
-                        C.rsrc = __builtin_amdgcn_make_buffer_rsrc(ch.act[j_ & 1] + (long)R_ * BM * ldx, 0, 0x7fffffff, 0x00020000); \
+                        C.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(chain_src(j_)) + (long)R_ * BM * ldx, 0, 0x7fffffff, 0x00020000); \
                     } else {                                                                                                 \
                         C.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16 *>(ch.w[j_]) + (long)(ch_col * BN) * Kp, 0, 0x7fffffff, 0x00020000); \
                     }                                                                                                        \
@@ -713,6 +769,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     }
     if (STAMP) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(mt1), "=s"(rt1)::"memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of this wave may land after the workgroup is gone
+    if (CHAIN && ch_gave_up && lane == 0) {  // a wait of this wave ran out: the launch's rows are not to be trusted (the gated re-run redoes them)
+        __hip_atomic_fetch_or(&ch.status->error, kChainErrTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&ch.status->timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef M360_DIAG
     if (STAMP && tid == 0 && blockIdx.x < 256) {
         g_w16_stamps[blockIdx.x * 4 + 0] = mt1 - mt0;

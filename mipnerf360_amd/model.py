@@ -60,6 +60,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
         ws = None
         with torch.cuda.device(device):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            ops.workspace_init(ws)  # the status block at its start (counters of the bf16 mode's layer chain)
         _WORKSPACES[key] = ws
         mine = [k for k in _WORKSPACES if k[0] == device]
         for k in mine[:max(0, len(mine) - _MAX_WORKSPACES_PER_DEVICE)]:
@@ -117,7 +118,7 @@ class _PackedMLP:
             # The bf16 matrix pipe answers a NaN operand with the default NaN 0xFFC00000 (sign bit set), which its packed integer-max
             # ReLU reads as a negative number: no NaN survives a ReLU layer.  NaN FEATURES are carried around the MLP by per-sample
             # flags (the finishers poison those samples, as nn.ReLU would have); a NaN PARAMETER cannot be - refuse it loudly.
-            if any(bool(torch.isnan(p.detach()).any()) for p in params):
+            if bool(torch.stack([torch.isnan(p.detach()).any() for p in params]).any()):  # ONE device-to-host sync
                 raise RuntimeError("mlp_dtype='bf16' / 'bf16x3': the parameters hold NaN values; the bf16 matrix pipe cannot propagate them "
                                    "the way nn.ReLU does (the reference renders NaN) - use mlp_dtype='fp32' for this checkpoint")
         for i, lin in enumerate(hidden_layers):
@@ -575,22 +576,27 @@ class mipNeRF360(nn.Module):
         ws = _ws_for(B, max(N, Nf), mstruct, dev)
         ops.call("m360_forward", C.byref(rstruct), C.byref(mstruct), C.byref(hyper), B, C.byref(ostruct), ws,
                  ws.numel(), ops.STREAM, device=dev)
-        self._last_fused = (ws, B, max(N, Nf), mstruct, B * Nf)
         if stash:
             self.nerf_net._stash(outs)
         return outs["rgb"], outs["distance"], outs["acc"]
 
+    def chain_status(self) -> dict:
+        """Counters of the bf16 mode's hidden-layer chain on this model's device and the CURRENT stream's scratch buffer since it was
+        allocated (ops.workspace_status; waits for the stream): `launches`, `recoveries` (launches whose self-check failed and that the
+        gated layer-by-layer re-run repaired on the device), `timeouts`, `xcc_mismatch`, `last_error`.  Purely informational - outputs are
+        right either way; `recoveries > 0` means the chain's launches were not alone on the GPU (or the device places workgroups
+        differently) and cost time.  All zero when no forward has run the chain here."""
+        dev = torch.device(self.device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        ws = _WORKSPACES.get((dev, torch.cuda.current_stream(dev).cuda_stream))
+        if ws is None:
+            return dict.fromkeys(ops.CHAIN_STATUS_FIELDS, 0)
+        return ops.workspace_status(ws)
+
     def chain_error(self) -> bool:
-        """m360_forward_chain_error for the last fused forward (bf16 mode: did a workgroup of the hidden-layer chain give up waiting?
-        Synchronises; False when that forward ran no chain)."""
-        last = getattr(self, "_last_fused", None)
-        if last is None:
-            return False
-        ws, B, N, mstruct, rows = last
-        rc = _lib.lib().m360_forward_chain_error(ws.data_ptr(), B, N, C.byref(mstruct), rows)
-        if rc < 0:
-            raise RuntimeError(_lib.last_error())
-        return rc == 1
+        """True when a chain launch of the last forward on this stream reported an error (and was repaired by the gated re-run)."""
+        return self.chain_status()["last_error"] != 0
 
     def forward(self, rays):
         """model.py:247-252 -> (rgb[B,3], distance[B], acc[B])."""

@@ -556,9 +556,35 @@ def mlp_chain_bf16_supported(M: int, width: int, layers: int) -> bool:
     return bool(_lib.lib().m360_mlp_chain_bf16_supported(int(M), int(width), int(layers)))
 
 
-def mlp_chain_bf16(act0, act1, packs):
-    """m360_mlp_chain_bf16: the equally shaped ReLU layers `packs` = [(w_packed, b_packed), ...] in one launch on PAIRED rows: layer j reads
-    act[j & 1], writes act[(j + 1) & 1]; returns the buffer that holds the result."""
+CHAIN_STATUS_FIELDS = ("launches", "recoveries", "timeouts", "xcc_mismatch", "last_error")
+
+
+def workspace_init(ws: torch.Tensor) -> None:
+    """m360_workspace_init: zero the sticky counters of the status block at the start of a forward / chain workspace."""
+    _call("m360_workspace_init", ws, STREAM)
+
+
+def workspace_status(ws: torch.Tensor) -> dict:
+    """m360_workspace_status (waits for the current stream): the counters of the bf16 mode's layer chain since workspace_init -
+    launches that ran, launches the gated layer-by-layer re-run repaired, waves whose wait ran out, workgroups found off their slot's XCD,
+    and the error word of the last launch (0 = its assumptions held)."""
+    import ctypes as C
+    out = (C.c_uint * 5)()
+    _call("m360_workspace_status", ws, out, STREAM)
+    return dict(zip(CHAIN_STATUS_FIELDS, (int(v) for v in out)))
+
+
+def set_chain_debug(wait_ticks: int = 0, fault: int = 0) -> None:
+    """m360_set_chain_debug (tests): bound of one wait in 100 MHz ticks (0 = default 0.1 s), fault to inject (0 none, 1 = a workgroup
+    reports a foreign XCD, 2 = every wave gives up at its first wait)."""
+    _lib.check(_lib.lib().m360_set_chain_debug(int(wait_ticks), int(fault)), "m360_set_chain_debug")
+
+
+def set_chain_cooperative(on: bool) -> bool:
+    return bool(_lib.lib().m360_set_chain_cooperative(int(bool(on))))
+
+
+def _chain_args(act0, act1, packs):
     import ctypes as C
     act0, act1 = dev_bf16(act0, "act0"), dev_bf16(act1, "act1")
     M, ld = act0.shape
@@ -567,10 +593,29 @@ def mlp_chain_bf16(act0, act1, packs):
     ws = torch.empty(int(_lib.lib().m360_mlp_chain_bf16_workspace(M, L)) // 4 + 4, device=act0.device, dtype=torch.int32)
     wl = (C.c_void_p * L)(*[dev_bf16(w, "w").data_ptr() for w, _ in packs])
     bl = (C.c_void_p * L)(*[dev(b, "b").data_ptr() for _, b in packs])
-    _call("m360_mlp_chain_bf16", act0, act1, M, ld, C.cast(wl, C.c_void_p), C.cast(bl, C.c_void_p), L, width, ws, STREAM)
-    if int(ws[(M // 256) * L].item()) != 0:
-        raise RuntimeError("m360_mlp_chain_bf16: a workgroup gave up waiting for its quartet (error word set)")
+    return act0, act1, M, ld, L, width, ws, C.cast(wl, C.c_void_p), C.cast(bl, C.c_void_p)
+
+
+def mlp_chain_bf16(act0, act1, packs):
+    """m360_mlp_chain_bf16: the equally shaped ReLU layers `packs` = [(w_packed, b_packed), ...] in one launch on PAIRED rows: layer j reads
+    act[j & 1], writes act[(j + 1) & 1]; returns the buffer that holds the result.  Raises when the launch reported that one of its
+    assumptions did not hold (this entry point has no re-run: its input is overwritten)."""
+    act0, act1, M, ld, L, width, ws, wl, bl = _chain_args(act0, act1, packs)
+    _call("m360_mlp_chain_bf16", act0, act1, M, ld, wl, bl, L, width, ws, STREAM)
+    st = workspace_status(ws)
+    if st["last_error"] != 0:
+        raise RuntimeError(f"m360_mlp_chain_bf16: the launch reported an error (status {st}): a wait ran out or a workgroup was off its XCD")
     return act0 if L % 2 == 0 else act1
+
+
+def mlp_chain_bf16_safe(x_in, act0, act1, packs):
+    """m360_mlp_chain_bf16_safe: layer 0 reads x_in (never written), layer j writes act[(j + 1) & 1]; a launch that reports an error is redone
+    layer by layer by the gated launches queued behind it -> (result buffer, status dict of this call)."""
+    x_in = dev_bf16(x_in, "x_in")
+    act0, act1, M, ld, L, width, ws, wl, bl = _chain_args(act0, act1, packs)
+    workspace_init(ws)
+    _call("m360_mlp_chain_bf16_safe", x_in, act0, act1, M, ld, wl, bl, L, width, ws, STREAM)
+    return (act0 if L % 2 == 0 else act1), workspace_status(ws)
 
 
 def set_row_blocks(rows: int) -> int:

@@ -31,7 +31,7 @@ def test_header_symbols_are_exported_and_bound(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/m360.h but not exported by libm360.so"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.m360_version() == 100
+    assert lib.m360_version() == 101
     assert lib.m360_contract_workspace_bytes() >= 8192
 
 
@@ -666,11 +666,14 @@ def test_ring_kernel_store_instructions_match_its_counted_waits(tmp_path):
     # _ZN4m3603w1622linear_bf16_w16_kernelILi<ACT>ELi<ABL>ELb<STAMP>ELb<X3>ELb<ONE_BLOCK>ELi<HEADS>ELb<SPLIT>ELb<LDSEPI>ELb<PAIR>ELb<CHAIN>EEE...
     # (ABL: 0, or 128 = the same kernel with temporal stores: the row blocks' and the layer chain's instantiations)
     split_without_x3 = paired = chains = 0
-    for m in re.finditer(r"^(_ZN4m3603w1622linear_bf16_w16_kernelILi(\d)ELi(?:0|128)ELb0ELb([01])ELb([01])ELi(\d)ELb([01])ELb0ELb([01])ELb([01])EEE\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN4m3603w1622linear_bf16_w16_kernelILi(\d)ELi(?:0|128)ELb0ELb([01])ELb([01])ELi(\d)ELb([01])ELb0ELb([01])ELb([01])EEE\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):  # (not up to the first s_endpgm: the gate's early return has one)
         x3, heads, split, pair, chain, body = m.group(3) == "1", int(m.group(5)), m.group(6) == "1", m.group(7) == "1", m.group(8) == "1", m.group(9)
         chains += int(chain)
-        # the layer chain (m360_mlp_chain_bf16): one counter add per tile, activation pieces that bypass the CU's L1
-        assert (body.count("global_atomic_add") > 0) == chain and (not chain or body.count(" sc1") >= 128), f"{m.group(1)}: the chain's hand-over instructions"
+        # every instantiation: the gate at the kernel's entry (one atomic add: the recovery counter of a gated re-run launch).  The layer
+        # chain (m360_mlp_chain_bf16) on top of that: counter adds per tile, its self-checks (XCC_ID read, a compare-and-swap on its slot
+        # word, the error bit), activation pieces that bypass the CU's L1
+        assert (body.count("global_atomic_add") > 1) == chain and body.count("global_atomic_add") >= 1, f"{m.group(1)}: the gate / the chain's hand-over instructions"
+        assert not chain or (len(re.findall(r"buffer_load_dword[^\n]* lds[^\n]* sc1|buffer_load_dword[^\n]* sc1[^\n]* lds", body)) == 64 and "HW_REG_XCC_ID" in body and "global_atomic_cmpswap" in body and "global_atomic_or" in body and "s_memrealtime" in body), f"{m.group(1)}: the chain's self-checks"
         want = 8 if heads else (64 if split else 32)
         if chain:
             want *= 2  # one of two store policies per tile (temporal inside the chain, non-temporal for its last layer): a wave-uniform branch
