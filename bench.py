@@ -472,12 +472,14 @@ def frame_pipeline(model, comm, frames, warmup, overlap, width=FRAME_W, height=F
     per_rank = comm.gather_floats([statistics.median(compute), statistics.median(gather), float(pg.span[1] - pg.span[0])])
     last = outs[(total - 1) % 2]
     finite = bool(torch.isfinite(last[0]).all() and torch.isfinite(last[1]).all() and torch.isfinite(last[2]).all())
+    # the assembled last frame as one number (sum of the pixels' bit patterns): overlapped == serial == one rank, bit for bit
+    bits_sum = int(sum(int(t.contiguous().view(torch.int32).to(torch.int64).sum()) for t in last))
     n_chunks = (n + chunks - 1) // chunks
     return {"frames": frames, "rays_per_frame": n, "seconds": round(elapsed, 4), "seconds_per_frame": round(elapsed / max(frames, 1), 4),
             "rays_per_s": round(n * frames / elapsed, 1), "n_chunks": n_chunks,
             "chunks_per_rank": (n_chunks + world - 1) // world,
             "partition_efficiency_bound": round(partition_efficiency(n, chunks, world), 4),
-            "overlap": bool(side is not None), "finite": finite,
+            "overlap": bool(side is not None), "finite": finite, "frame_bits_sum": bits_sum,
             "per_rank": [{"rank": r, "rays": int(v[2]), "compute_ms_median": round(v[0], 2),
                           "all_gather_ms_median": round(v[1], 3)} for r, v in enumerate(per_rank)]}
 

@@ -84,7 +84,7 @@ int main(int argc, char **argv) {
     add(hn, in_ch); for (int i = 0; i < 7; ++i) add(hn, hn); add(1, hn); add(3, hn);        // nerf_net.model.*, final_density, final_color
 
     m360_model_t model = {};
-    model.in_ch = in_ch; model.in_pad = in_pad; model.hp_pad = hp_pad; model.hn_pad = hn_pad; model.mlp_bf16 = 0;
+    model.in_ch = in_ch; model.in_pad = in_pad; model.hp_pad = hp_pad; model.hn_pad = hn_pad; model.mlp_bf16 = 0; model.packed_layout = M360_PACKED_LAYOUT;
     auto pack = [&](const Layer &l, int n_pad, int k_pad, float **wp, float **bp) -> int {
         float *w = to_device(l.w), *b = to_device(l.b);
         if (!w || !b) return 1;

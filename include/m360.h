@@ -73,6 +73,14 @@ int m360_device_count(void);
 int m360_sample_t(const float *near /*[B]*/, const float *far /*[B]*/, const float *t_rand,
                   int B, int N, float *t_vals, m360_stream_t stream);
 
+/* The same with the jitter's uniforms drawn inside the kernel (randomized=True, intern/ray.py:103-108, without a [B,N+1] tensor of
+ * torch.rand): element e = b (N + 1) + i uses the Philox4x32-10 uniform of (seed, offset, stream 0, e) - see m360_hyper_t.rng_seed. */
+int m360_sample_t_philox(const float *near, const float *far, int B, int N, unsigned long long seed, unsigned long long offset,
+                         float *t_vals, m360_stream_t stream);
+/* out[e] = the uniform the kernels draw for element e of stream `stream_id` (0 = t_rand, 1 = u_rand) under (seed, offset): what a
+ * launch used, written out - tests hand these to the CPU oracle as its t_rand / u_rand (replaces torch.rand at intern/ray.py:31,104). */
+int m360_philox_uniform(unsigned long long seed, unsigned long long offset, int stream_id, long n, float *out, m360_stream_t stream);
+
 /* y = g(x) = 1/(x + 1e-6), elementwise, x untouched.  Replaces intern/parameterization.py:15-21. */
 int m360_g(const float *x, long n, float *y, m360_stream_t stream);
 
@@ -337,6 +345,13 @@ int m360_resample_t_n(const float *t_vals, const float *weights, const float *u_
                       int num_out, float resample_padding, float *t_new /*[B,num_out]*/,
                       m360_stream_t stream);
 
+/* m360_sorted_pdf / m360_resample_t_n in the randomized branch (intern/ray.py:30-35) with the uniforms drawn inside the kernel: element
+ * e = b num_samples + j uses the Philox uniform of (seed, offset, stream 1, e). */
+int m360_sorted_pdf_philox(const float *bins, const float *weights, int B, int nb, int num_samples, unsigned long long seed,
+                           unsigned long long offset, float *samples, m360_stream_t stream);
+int m360_resample_t_philox(const float *t_vals, const float *weights, int B, int N, int num_out, float resample_padding,
+                           unsigned long long seed, unsigned long long offset, float *t_new, m360_stream_t stream);
+
 /* intern/ray.py:155-191; rgb[B,N,3], density[B,N]; weights may be NULL. */
 int m360_volumetric_rendering(const float *rgb, const float *density, const float *t_vals,
                               const float *dirs, int B, int N, int white_bkgd, float *comp_rgb,
@@ -572,7 +587,12 @@ typedef struct {
                      above): mode 1: weights from m360_pack_linear_bf16x3, features as [hi | lo] pairs (4 in_pad bytes per sample,
                      m360_linear_bf16x3_bf16out); mode 2: weights from m360_pack_linear_bf16x6, features as x6 rows (three bf16
                      terms per value, 12 in_pad bytes per sample, m360_linear_bf16_split) */
+    int packed_layout; /* which packing prop_w / nerf_w follow: must be M360_PACKED_LAYOUT when mlp_bf16 != 0 (fp32: 0 is accepted too).
+                     The first-layer packings of the bf16 modes changed in 0.1.0 (layout 2: [n_pad, 3 in_pad] / [n_pad, 6 in_pad] instead of
+                     [n_pad, in_pad] / [n_pad, 3 in_pad]) and the kernels cannot see a buffer's size: a caller (or a packed file,
+                     checkpoint.load_packed) of the older layout is refused instead of being read past its end */
 } m360_model_t; /* packed form of the state_dict of model.py:43-53,131-158 */
+#define M360_PACKED_LAYOUT 2
 
 typedef struct {
     int num_samples;
@@ -591,6 +611,16 @@ typedef struct {
                              (intern/parameterization.py:15-21: +1e-6 each after the proposal stage, so the NeRF stage's
                              t_to_s starts from the values it is handed); used by the mirrors'
                              mutate_like_reference mode to reproduce train.py's drift over its three pairs */
+    int randomized;       /* `randomized=True` (model.py:27,112; the reference's CLI default, config.py:15) with the uniforms drawn INSIDE the
+                             kernels (round 5): bit 0 = stratified jitter of the proposal samples (intern/ray.py:103-108), bit 1 = randomized
+                             inverse CDF incl. its `u + u` (intern/ray.py:30-35).  A bit applies wherever the entry point's own t_rand /
+                             u_rand tensor is NULL (m360_forward has none: a randomized model runs the fused forward); a tensor, when
+                             given, wins.  0 = deterministic. */
+    unsigned long long rng_seed;   /* Philox4x32-10 key: the torch device generator's seed */
+    unsigned long long rng_offset; /* first 64 counter bits: the generator's offset / 4 at this call (the caller advances the generator by 4
+                                      per call); element e of stream s (0 = t_rand, 1 = u_rand, [B, N + 1] row-major) draws
+                                      philox(key, counter = (rng_offset, e, s)).x >> 8 as a 24-bit uniform in [0, 1) - m360_philox_uniform
+                                      writes out exactly these numbers (tests replay them through the oracle) */
 } m360_hyper_t; /* ctor arguments of model.py:203-215 */
 
 typedef struct {

@@ -34,14 +34,18 @@ class ModelStruct(C.Structure):  # m360_model_t
     _fields_ = [("in_ch", C.c_int), ("in_pad", C.c_int), ("hp_pad", C.c_int), ("hn_pad", C.c_int),
                 ("prop_w", _vp * 4), ("prop_b", _vp * 4), ("prop_head_w", _vp), ("prop_head_b", _vp),
                 ("nerf_w", _vp * 8), ("nerf_b", _vp * 8), ("nerf_head_w", _vp), ("nerf_head_b", _vp),
-                ("mlp_bf16", C.c_int)]
+                ("mlp_bf16", C.c_int), ("packed_layout", C.c_int)]
+
+
+PACKED_LAYOUT = 2  # include/m360.h: M360_PACKED_LAYOUT
 
 
 class HyperStruct(C.Structure):  # m360_hyper_t
     _fields_ = [("num_samples", C.c_int), ("viewdir_min_deg", C.c_int), ("viewdir_max_deg", C.c_int),
                 ("white_bkgd", C.c_int), ("density_bias", C.c_float), ("rgb_padding", C.c_float),
                 ("resample_padding", C.c_float), ("num_samples_fine", C.c_int), ("norm_group_rays", C.c_int),
-                ("prof", C.c_void_p), ("rays_mutated", C.c_int)]
+                ("prof", C.c_void_p), ("rays_mutated", C.c_int), ("randomized", C.c_int), ("rng_seed", C.c_ulonglong),
+                ("rng_offset", C.c_ulonglong)]
 
 
 class OutputsStruct(C.Structure):  # m360_outputs_t
@@ -65,6 +69,10 @@ SIGNATURES = {
     "m360_last_error": (C.c_char_p, []),
     "m360_device_count": (_i, []),
     "m360_sample_t": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "m360_sample_t_philox": (_i, [_vp, _vp, _i, _i, C.c_ulonglong, C.c_ulonglong, _vp, _vp]),
+    "m360_philox_uniform": (_i, [C.c_ulonglong, C.c_ulonglong, _i, _l, _vp, _vp]),
+    "m360_sorted_pdf_philox": (_i, [_vp, _vp, _i, _i, _i, C.c_ulonglong, C.c_ulonglong, _vp, _vp]),
+    "m360_resample_t_philox": (_i, [_vp, _vp, _i, _i, _i, _fl, C.c_ulonglong, C.c_ulonglong, _vp, _vp]),
     "m360_g": (_i, [_vp, _l, _vp, _vp]),
     "m360_s_to_t": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "m360_contract": (_i, [_vp, _l, _vp, _vp, _sz, _vp]),

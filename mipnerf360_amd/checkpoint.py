@@ -54,16 +54,22 @@ def to_reference_state_dict(model) -> "OrderedDict[str, torch.Tensor]":
     return OrderedDict((k, v.detach().float().cpu().clone()) for k, v in model.state_dict().items())
 
 
+PACKED_LAYOUT = 2  # include/m360.h: M360_PACKED_LAYOUT (meta[5] of a packed file)
+
+
 def export_packed(model) -> Dict[str, np.ndarray]:
     """Packed weights exactly as the kernels read them (include/m360.h, m360_model_t): per layer a zero-padded
-    [n_pad, k_pad] matrix (k contiguous; float32, or bf16 bit patterns as uint16 for mlp_dtype='bf16'; for
-    mlp_dtype='bf16x3' the [n_pad, 3 k_pad] = [Wh | Wh | Wl] layout of m360_pack_linear_bf16x3; in both bf16 modes layer 0 is
-    the [n_pad, 6 in_pad] "x6" layout of m360_pack_linear_bf16x6) and a [n_pad] fp32 bias;
-    heads as fp32 [H, h_pad] + [H]; meta[4] = m360_model_t.mlp_bf16 (0 / 1 / 2).  Needs a HIP device (packing runs in
-    m360_pack_linear*)."""
+    [n_pad, k_pad] matrix (k contiguous; float32, or bf16 bit patterns as uint16 in the bf16 modes) and a [n_pad] fp32 bias; heads as
+    fp32 [H, h_pad] + [H].  Layouts by mode (meta[4] = m360_model_t.mlp_bf16):
+      0 fp32:    every layer [n_pad, k_pad] float32;
+      1 bf16:    hidden layers [n_pad, k_pad] (m360_pack_linear_bf16); layer 0 [n_pad, 3 in_pad] = [Wh | Wh | Wl] (m360_pack_linear_bf16x3);
+      2 bf16x3:  hidden layers [n_pad, 3 k_pad] = [Wh | Wh | Wl]; layer 0 [n_pad, 6 in_pad] = "x6" (m360_pack_linear_bf16x6).
+    meta = [in_ch, in_pad, hp_pad, hn_pad, mlp_bf16, packed layout (= m360_model_t.packed_layout), M360_VERSION of the writer].
+    Needs a HIP device (packing runs in m360_pack_linear*)."""
+    from . import _lib
     prop, nerf = model.prop_net._pack(), model.nerf_net._pack()
     out: Dict[str, np.ndarray] = {"meta": np.array([model.prop_net.input_size, prop.in_pad, prop.h_pad, nerf.h_pad,
-                                                    int(prop.bf16)], dtype=np.int32)}
+                                                    int(prop.bf16), PACKED_LAYOUT, int(_lib.lib().m360_version())], dtype=np.int32)}
 
     def host(t: torch.Tensor) -> np.ndarray:
         return (t.view(torch.int16) if t.dtype == torch.bfloat16 else t).detach().cpu().numpy().copy()
@@ -73,7 +79,34 @@ def export_packed(model) -> Dict[str, np.ndarray]:
             out[f"{name}.w{i}"] = host(w).view(np.uint16) if w.dtype == torch.bfloat16 else host(w)
             out[f"{name}.b{i}"] = host(b)
         out[f"{name}.head_w"], out[f"{name}.head_b"] = host(p.head_w), host(p.head_b)
+    validate_packed(out)
     return out
+
+
+def validate_packed(packed: Mapping[str, np.ndarray]) -> None:
+    """Refuse a packed model whose layout this library does not read (the first-layer packings of the bf16 modes changed and
+    the kernels cannot see a buffer's size): the layout entry must be there and current, and every matrix must have the shape its
+    mode says."""
+    meta = np.asarray(packed["meta"]).astype(np.int64).ravel()
+    if meta.size < 6:
+        raise ValueError("packed model without a layout entry (meta has %d < 6 values): written before layout %d - its first-layer "
+                         "packings are not what the bf16 kernels read today; export it again" % (meta.size, PACKED_LAYOUT))
+    in_ch, in_pad, hp, hn, mode, layout = (int(v) for v in meta[:6])
+    if layout != PACKED_LAYOUT:
+        raise ValueError(f"packed model of layout {layout}; this library reads layout {PACKED_LAYOUT}: export it again")
+    if mode not in (0, 1, 2):
+        raise ValueError(f"packed model: unknown mlp_bf16 mode {mode}")
+    first = {0: 1, 1: 3, 2: 6}[mode] * in_pad
+    hid = 3 if mode == 2 else 1
+    want_dtype = np.float32 if mode == 0 else np.uint16
+    for name, width, layers in (("prop", hp, 4), ("nerf", hn, 8)):
+        for i in range(layers):
+            w = packed[f"{name}.w{i}"]
+            shape = (width, first if i == 0 else hid * width)
+            if tuple(w.shape) != shape or w.dtype != want_dtype:
+                raise ValueError(f"packed model: {name}.w{i} is {w.dtype}{tuple(w.shape)}, mode {mode} needs {np.dtype(want_dtype)}{shape}")
+            if tuple(packed[f"{name}.b{i}"].shape) != (width,):
+                raise ValueError(f"packed model: {name}.b{i} has shape {tuple(packed[f'{name}.b{i}'].shape)}, expected ({width},)")
 
 
 def save_packed(model, path: str) -> None:
@@ -81,5 +114,8 @@ def save_packed(model, path: str) -> None:
 
 
 def load_packed(path: str) -> Dict[str, np.ndarray]:
+    """-> the arrays of a `save_packed` file; raises ValueError for a file of another layout (validate_packed)."""
     with np.load(path) as z:
-        return {k: z[k] for k in z.files}
+        packed = {k: z[k] for k in z.files}
+    validate_packed(packed)
+    return packed

@@ -44,7 +44,11 @@ namespace m360 {
 
 // m360_sample_encode.hip (stage drivers only, not part of the C-ABI)
 int stage_prologue(const m360_rays_t *r, int B, int N, int min_deg, int max_deg, float *t_vals, float *vdenc,
-                   unsigned *queue_words, int n_queue_words, int ld_feat, void *norm_ws, m360_stream_t stream);
+                   unsigned *queue_words, int n_queue_words, int ld_feat, void *norm_ws, m360_stream_t stream, const rng_t &rng);
+int sample_t_any(const float *near, const float *far, const float *t_rand, int B, int N, float *t_vals, const rng_t &rng, m360_stream_t stream);
+// m360_ray.hip
+int resample_t_any(const float *t_vals, const float *weights, const float *u_rand, int B, int N, int num_out, float resample_padding, float *t_new,
+                   const rng_t &rng, m360_stream_t stream);
 int encode_stage(const float *t_vals, const float *origins, const float *directions, const float *radii, const float *vdenc,
                  int vd_ch, int B, int N, void *feat, int ld_feat, int row_format, int group_rays, const float *ext_norm,
                  int prepared_parts, unsigned char *nanflag, void *workspace, size_t workspace_bytes, m360_stream_t stream);
@@ -52,7 +56,7 @@ int encode_stage(const float *t_vals, const float *origins, const float *directi
 int prop_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
                       const float *head_b, int k_pad, float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                       int B, int N, int num_out, float resample_padding, float *weights, float *t_new, const unsigned char *nanflag,
-                      m360_stream_t stream);
+                      m360_stream_t stream, const rng_t &rng);
 int nerf_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
                       const float *head_b, int k_pad, float density_bias, float rgb_padding, const float *t_vals, const float *dirs,
                       const float *near, const float *far, int near_far_calls, int B, int N, int white_bkgd, float *comp_rgb,
@@ -149,6 +153,11 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
 }
 
 static inline int n_fine(const m360_hyper_t *h) { return h->num_samples_fine > 0 ? h->num_samples_fine : h->num_samples; }
+// m360_hyper_t.randomized: bit 0 = the proposal samples' stratified jitter (intern/ray.py:103-108), bit 1 = the randomized inverse CDF
+// (intern/ray.py:30-35), both drawn inside the kernels from the Philox stream (rng_seed, rng_offset) whenever the entry point's own
+// t_rand / u_rand tensor is NULL
+static inline rng_t rng_jitter(const m360_hyper_t *h, const float *t_rand) { return rng_t{h->rng_seed, h->rng_offset, (!t_rand && (h->randomized & 1)) ? 1 : 0}; }
+static inline rng_t rng_cdf(const m360_hyper_t *h, const float *u_rand) { return rng_t{h->rng_seed, h->rng_offset, (!u_rand && (h->randomized & 2)) ? 1 : 0}; }
 static inline int n_max(const m360_hyper_t *h) { return n_fine(h) > h->num_samples ? n_fine(h) : h->num_samples; }
 
 static int validate(const m360_rays_t *r, const m360_model_t *m, const m360_hyper_t *h, int B,
@@ -161,6 +170,8 @@ static int validate(const m360_rays_t *r, const m360_model_t *m, const m360_hype
     const int vd_ch = 4 * (h->viewdir_max_deg - h->viewdir_min_deg);
     if (vd_ch < 0 || m->in_ch != kIpeCh + vd_ch || m->in_pad < m->in_ch || m->in_pad % 32 || m->hp_pad % 32 || m->hn_pad % 32 || m->hp_pad < 32 || m->hn_pad < 32)
         return fail(M360_ERR_INVALID_ARGUMENT, "%s: model dims inconsistent (in_ch=%d in_pad=%d hp_pad=%d hn_pad=%d vd_ch=%d)", who, m->in_ch, m->in_pad, m->hp_pad, m->hn_pad, vd_ch);
+    if (m->mlp_bf16 < 0 || m->mlp_bf16 > 2 || (m->mlp_bf16 ? m->packed_layout != M360_PACKED_LAYOUT : (m->packed_layout != 0 && m->packed_layout != M360_PACKED_LAYOUT)))
+        return fail(M360_ERR_INVALID_ARGUMENT, "%s: m360_model_t.mlp_bf16=%d with packed_layout=%d: this library reads layout %d (first layers of the bf16 modes as [n_pad, 3 in_pad] / [n_pad, 6 in_pad]: re-pack with m360_pack_linear_bf16x3 / _bf16x6)", who, m->mlp_bf16, m->packed_layout, M360_PACKED_LAYOUT);
     if (m->mlp_bf16 && (m->in_pad % 64 || m->hp_pad % 64 || m->hn_pad % 64))
         return fail(M360_ERR_INVALID_ARGUMENT, "%s: the bf16 MLP needs in_pad/hp_pad/hn_pad multiples of 64", who);
     const FwdLayout L = layout_for(B, n_max(h), m);
@@ -274,7 +285,8 @@ static int p_linear_heads(const m360_hyper_t *h, int bf16, const void *x, long M
 }
 static int p_prop_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, float *w_hat, float *t_new, m360_stream_t st, const unsigned char *flags = nullptr) {
     ProfScope ps(h, st, M360_K_PROP_FINISH, (long)B * N, k_pad, bf16);
-    return ps.done(prop_finish_stage(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, flags, st));
+    // the fused resample (t_new != NULL: m360_forward / the sharded batch) draws its uniforms itself when the model is randomized
+    return ps.done(prop_finish_stage(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, flags, st, rng_cdf(h, nullptr)));
 }
 // heads + composite, and in the same launch the t_vals + 1e-6 and s_vals nerf_net.forward returns (model.py:194-196; until round 3
 // an add_eps and a t_to_s launch).  near / far went through g() once in sample_along_rays (numerically, or physically when
@@ -323,7 +335,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     // queue words) instead of five; the encoder's workgroups finish the norm themselves
     int parts = 0;
     if (!tape && !ext_norm && !t_rand && h->norm_group_rays == 0) {
-        parts = stage_prologue(r, B, N, h->viewdir_min_deg, h->viewdir_max_deg, t_hat, vdenc, reinterpret_cast<unsigned *>(ws + L.queues), 2 * kQueueWords, m->in_pad, ws + L.norm, st);
+        parts = stage_prologue(r, B, N, h->viewdir_min_deg, h->viewdir_max_deg, t_hat, vdenc, reinterpret_cast<unsigned *>(ws + L.queues), 2 * kQueueWords, m->in_pad, ws + L.norm, st, rng_jitter(h, t_rand));
         if (parts < 0) return M360_ERR_LAUNCH;
     }
     if (fused) *fused = parts > 0;
@@ -334,7 +346,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         float *tt = reinterpret_cast<float *>(tape + T.t), *tf = reinterpret_cast<float *>(tape + T.feat);
         float *act[4];
         for (int l = 0; l < 4; ++l) act[l] = reinterpret_cast<float *>(tape + T.act[l]);
-        M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, tt, st));
+        M360_TRY(sample_t_any(r->near, r->far, t_rand, B, N, tt, rng_jitter(h, t_rand), st));
         if (hipMemcpyAsync(t_hat, tt, (size_t)B * (N + 1) * sizeof(float), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(st)) != hipSuccess)
             return fail(M360_ERR_LAUNCH, "m360_prop_forward_train: copy of t_hat failed");
         M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
@@ -347,7 +359,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         return p_prop_finish_fused(h, act[3], 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp, 0), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st);
     }
     if (parts == 0) {
-        if (!ext_norm) M360_TRY(m360_sample_t(r->near, r->far, t_rand, B, N, t_hat, st));  // sharded batch: t_hat is given
+        if (!ext_norm) M360_TRY(sample_t_any(r->near, r->far, t_rand, B, N, t_hat, rng_jitter(h, t_rand), st));  // sharded batch: t_hat is given
         M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
     }
     const int hp = m->hp_pad;
@@ -583,7 +595,7 @@ int m360_nerf_forward(const m360_rays_t *rays, const m360_model_t *model, const 
     char *ws = static_cast<char *>(workspace);
     const FwdLayout L = layout_for(B, n_max(hyper), model);
     float *t1 = reinterpret_cast<float *>(ws + L.t1);
-    M360_TRY(m360_resample_t_n(t_hat, w_hat, u_rand, B, hyper->num_samples, n_fine(hyper) + 1, hyper->resample_padding, t1, stream));
+    M360_TRY(resample_t_any(t_hat, w_hat, u_rand, B, hyper->num_samples, n_fine(hyper) + 1, hyper->resample_padding, t1, rng_cdf(hyper, u_rand), stream));
     return nerf_stage(rays, model, hyper, B, t1, out, ws, stream);
 }
 
@@ -662,7 +674,7 @@ int m360_nerf_forward_train(const m360_rays_t *rays, const m360_model_t *model, 
     const TapeLayout T = tape_for(B, n_fine(hyper), model, 1);
     M360_TRY(validate_train(model, tape, tape_bytes, T.total, "m360_nerf_forward_train"));
     float *t1 = reinterpret_cast<float *>(static_cast<char *>(tape) + T.t);
-    M360_TRY(m360_resample_t_n(t_hat, w_hat, u_rand, B, hyper->num_samples, n_fine(hyper) + 1, hyper->resample_padding, t1, stream));
+    M360_TRY(resample_t_any(t_hat, w_hat, u_rand, B, hyper->num_samples, n_fine(hyper) + 1, hyper->resample_padding, t1, rng_cdf(hyper, u_rand), stream));
     return nerf_stage(rays, model, hyper, B, t1, out, static_cast<char *>(workspace), stream, static_cast<char *>(tape));
 }
 

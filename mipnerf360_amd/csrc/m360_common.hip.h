@@ -82,6 +82,39 @@ __device__ __forceinline__ float linspacef_(float start, float end, int steps, i
     return (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - 1 - i);
 }
 
+// ---- counter-based random numbers (round 5): randomized=True without materialised uniform tensors ------------------------
+// The reference draws `torch.rand(batch, num_samples + 1)` twice per forward (intern/ray.py:104 stratified jitter, :31 randomized
+// inverse CDF).  The kernels draw the same KIND of numbers themselves: Philox4x32-10 (Salmon et al., SC'11 - the generator behind
+// torch's own device RNG), key = the torch generator's seed, counter = (generator offset / 4 as 64 bits, element index, stream id), so
+// a value is a pure function of (seed, offset, stream, element): the prologue can draw a ray's jitter once for t and again for the
+// norm's partial sums, a test can dump exactly the uniforms a launch used (m360_philox_uniform) and replay them through the oracle,
+// and the same seed gives the same bits.  The host advances the generator's offset by 4 per call, so no later torch kernel (whose
+// counters start at its own offset / 4) ever reuses a counter.  Stream ids: 0 = t_rand (jitter), 1 = u_rand (inverse CDF).
+struct rng_t {
+    unsigned long long seed, offset;
+    int on;  // draw in the kernel (the matching t_rand / u_rand pointer is NULL and m360_hyper_t.randomized asks for it)
+};
+__device__ __forceinline__ unsigned philox4x32_10_x(unsigned long long seed, unsigned long long offset, unsigned stream, unsigned long long idx) {
+    unsigned c0 = (unsigned)offset, c1 = (unsigned)(offset >> 32), c2 = (unsigned)idx, c3 = (stream << 28) | (unsigned)((idx >> 32) & 0x0FFFFFFFu);
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+// uniform in [0, 1) with 24 bits, like torch.rand's float32
+__device__ __forceinline__ float philox_uniform(const rng_t &g, unsigned stream, unsigned long long idx) {
+    return (float)(philox4x32_10_x(g.seed, g.offset, stream, idx) >> 8) * 5.9604644775390625e-08f;
+}
+
 // ---- wave-level reductions / scans (64 lanes) ---------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

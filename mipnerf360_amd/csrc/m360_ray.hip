@@ -53,9 +53,11 @@ __device__ __forceinline__ void wave_blur(const float *w, int N, float padding, 
 }
 
 // intern/ray.py:12-57.  bins[nb] and w[nb-1] in LDS (w is overwritten), cdf[nb] LDS scratch.
+// u_rand_row: the ray's uniforms (randomized=True with a materialised tensor), or NULL and rng.on: drawn here from the Philox stream
+// (stream id 1, element rng_base + j), or NULL and !rng.on: the deterministic linspace
 __device__ __forceinline__ void wave_sorted_pdf(const float *bins, float *w, float *cdf, int nb, int ns,
                                                 const float *__restrict__ u_rand_row,
-                                                float *__restrict__ out_row) {
+                                                float *__restrict__ out_row, const rng_t &rng = rng_t{0, 0, 0}, long rng_base = 0) {
     const int l = lane_id();
     const int nw = nb - 1;
     float part = 0.0f;
@@ -92,12 +94,13 @@ __device__ __forceinline__ void wave_sorted_pdf(const float *bins, float *w, flo
     const float umax = 1.0f - f32eps;
     for (int j = l; j < ns; j += kWave) {
         float u;
-        if (u_rand_row == nullptr) {
+        if (u_rand_row == nullptr && !rng.on) {
             u = linspacef_(0.0f, umax, ns, j);
         } else {  // intern/ray.py:30-35, including the `u + u` doubling
             const float s = 1.0f / (float)ns;
             const float base = (float)j * s;
-            u = fminf(base + base + u_rand_row[j] * (s - f32eps), umax);
+            const float ur = u_rand_row != nullptr ? u_rand_row[j] : philox_uniform(rng, 1u, (unsigned long long)(rng_base + j));
+            u = fminf(base + base + ur * (s - f32eps), umax);
         }
         float c0, c1, b0, b1;
         if (!bad) {
@@ -181,7 +184,7 @@ template <bool BLUR>
 __global__ __launch_bounds__(kRayWaves *kWave) void resample_kernel(
     const float *__restrict__ bins_g, const float *__restrict__ weights_g,
     const float *__restrict__ u_rand, int B, int nb, int ns, float padding,
-    float *__restrict__ samples) {
+    float *__restrict__ samples, rng_t rng = rng_t{0, 0, 0}) {
     extern __shared__ float smem[];
     const int wave = threadIdx.x >> 6, l = lane_id();
     const int b = blockIdx.x * kRayWaves + wave;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(kRayWaves *kWave) void resample_kernel(
         wsrc = w2;
     }
     wave_sorted_pdf(bins, wsrc, cdf, nb, ns, u_rand ? u_rand + (long)b * ns : nullptr,
-                    samples + (long)b * ns);
+                    samples + (long)b * ns, rng, (long)b * ns);
 }
 
 __global__ __launch_bounds__(kRayWaves *kWave) void volumetric_rendering_kernel(
@@ -533,7 +536,8 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     const float *__restrict__ head_w, const float *__restrict__ head_b, int k_pad, float density_bias,
     const float *__restrict__ t_vals, const float *__restrict__ dirs, const float *__restrict__ u_rand, int B, int N, int ns,
     float padding, float *__restrict__ weights, float *__restrict__ t_new, int rpb /* rays per workgroup: kFinishRays, or 1 when four rays' buffers exceed the LDS */,
-    const unsigned char *__restrict__ nanflag /* bf16 modes: 1 = the sample had a NaN feature (encode_features_wave_kernel), or NULL */) {
+    const unsigned char *__restrict__ nanflag /* bf16 modes: 1 = the sample had a NaN feature (encode_features_wave_kernel), or NULL */,
+    rng_t rng /* randomized inverse CDF drawn here (u_rand == NULL and rng.on) */) {
     extern __shared__ float smem[];
     const int l = lane_id(), wave = threadIdx.x >> 6;
     const int nb = N + 1;
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
         if (t_new == nullptr) return;
         wave_blur(w, N, padding, w2);
         wave_sync();
-        wave_sorted_pdf(t, w2, cdf, nb, ns, u_rand ? u_rand + (long)b * ns : nullptr, t_new + (long)b * ns);
+        wave_sorted_pdf(t, w2, cdf, nb, ns, u_rand ? u_rand + (long)b * ns : nullptr, t_new + (long)b * ns, rng, (long)b * ns);
     };
     if (fused_rows >= (long)b_end * N) {  // workgroup-uniform: one wave per ray, no workgroup barrier
         const int b = b0 + wave;
@@ -812,6 +816,11 @@ __global__ __launch_bounds__(kFinishThreads) void finish_backward_kernel(
 }  // namespace m360
 
 // =========================================================================================
+namespace m360 {
+int resample_t_any(const float *t_vals, const float *weights, const float *u_rand, int B, int N, int num_out, float resample_padding, float *t_new,
+                   const rng_t &rng, m360_stream_t stream);
+static int sorted_pdf_any(const float *bins, const float *weights, const float *u_rand, int B, int nb, int num_samples, float *samples, const rng_t &rng, m360_stream_t stream);
+}  // namespace m360
 using namespace m360;
 
 static inline hipStream_t S_(m360_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
@@ -836,12 +845,12 @@ int m360_density_to_weight(const float *t_vals, const float *density, const floa
 
 int m360_sorted_pdf(const float *bins, const float *weights, const float *u_rand, int B, int nb,
                     int num_samples, float *samples, m360_stream_t stream) {
-    if (!bins || !weights || !samples || B < 0 || nb < 2 || num_samples < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_sorted_pdf: bad argument");
-    if (B == 0) return M360_OK;
-    const size_t lds = (size_t)kRayWaves * 4 * nb * sizeof(float);
-    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_sorted_pdf: nb=%d too large for LDS", nb);
-    hipLaunchKernelGGL(resample_kernel<false>, dim3((B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * kWave), lds, S_(stream), bins, weights, u_rand, B, nb, num_samples, 0.0f, samples);
-    return check_launch("sorted_pdf");
+    return sorted_pdf_any(bins, weights, u_rand, B, nb, num_samples, samples, rng_t{0, 0, 0}, stream);
+}
+
+int m360_sorted_pdf_philox(const float *bins, const float *weights, int B, int nb, int num_samples, unsigned long long seed,
+                           unsigned long long offset, float *samples, m360_stream_t stream) {
+    return sorted_pdf_any(bins, weights, nullptr, B, nb, num_samples, samples, rng_t{seed, offset, 1}, stream);
 }
 
 int m360_resample_t(const float *t_vals, const float *weights, const float *u_rand, int B, int N,
@@ -851,13 +860,12 @@ int m360_resample_t(const float *t_vals, const float *weights, const float *u_ra
 
 int m360_resample_t_n(const float *t_vals, const float *weights, const float *u_rand, int B, int N, int num_out,
                       float resample_padding, float *t_new, m360_stream_t stream) {
-    if (!t_vals || !weights || !t_new || B < 0 || N < 1 || num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_resample_t: bad argument");
-    if (B == 0) return M360_OK;
-    const int nb = N + 1;
-    const size_t lds = (size_t)kRayWaves * 4 * nb * sizeof(float);
-    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_resample_t: N=%d too large for LDS", N);
-    hipLaunchKernelGGL(resample_kernel<true>, dim3((B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * kWave), lds, S_(stream), t_vals, weights, u_rand, B, nb, num_out, resample_padding, t_new);
-    return check_launch("resample_t");
+    return resample_t_any(t_vals, weights, u_rand, B, N, num_out, resample_padding, t_new, rng_t{0, 0, 0}, stream);
+}
+
+int m360_resample_t_philox(const float *t_vals, const float *weights, int B, int N, int num_out, float resample_padding,
+                           unsigned long long seed, unsigned long long offset, float *t_new, m360_stream_t stream) {
+    return resample_t_any(t_vals, weights, nullptr, B, N, num_out, resample_padding, t_new, rng_t{seed, offset, 1}, stream);
 }
 
 int m360_volumetric_rendering(const float *rgb, const float *density, const float *t_vals,
@@ -917,7 +925,8 @@ int m360_prop_finish_fused(const void *act, int act_bf16, int ld, const float *h
 static int prop_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                            int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
-                           m360_stream_t stream, const float *head_part, long fused_rows, int slots, const unsigned char *nanflag) {
+                           m360_stream_t stream, const float *head_part, long fused_rows, int slots, const unsigned char *nanflag,
+                           const rng_t &rng = rng_t{0, 0, 0}) {
     if (num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: num_out=%d", num_out);
     const int align = bf16 ? 8 : 4;
     if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < (bf16 == 2 ? 2 * k_pad : k_pad) || ld % align != 0)
@@ -929,9 +938,9 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
     const size_t lds = rpb == 1 ? lds_wg : (lds_wg > lds_wave ? lds_wg : lds_wave);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
     const dim3 grid((unsigned)((B + rpb - 1) / rpb));
-    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag);
-    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag);
-    else hipLaunchKernelGGL(prop_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag);
+    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag, rng);
+    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag, rng);
+    else hipLaunchKernelGGL(prop_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag, rng);
     return check_launch("prop_finish");
 }
 
@@ -1067,9 +1076,28 @@ namespace m360 {
 int prop_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
                       const float *head_b, int k_pad, float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                       int B, int N, int num_out, float resample_padding, float *weights, float *t_new, const unsigned char *nanflag,
-                      m360_stream_t stream) {
+                      m360_stream_t stream, const rng_t &rng) {
     if (fused_rows < 0 || (fused_rows > 0 && (!head_part || slots < 1))) return fail(M360_ERR_INVALID_ARGUMENT, "prop_finish_stage: fused_rows=%ld slots=%d", fused_rows, slots);
-    return prop_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, stream, head_part, fused_rows, slots, nanflag);
+    return prop_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, stream, head_part, fused_rows, slots, nanflag, rng);
+}
+// m360_resample_t_n with the inverse CDF's uniforms from a tensor (u_rand), from the Philox stream (rng.on) or deterministic
+int resample_t_any(const float *t_vals, const float *weights, const float *u_rand, int B, int N, int num_out, float resample_padding, float *t_new,
+                   const rng_t &rng, m360_stream_t stream) {
+    if (!t_vals || !weights || !t_new || B < 0 || N < 1 || num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_resample_t: bad argument");
+    if (B == 0) return M360_OK;
+    const int nb = N + 1;
+    const size_t lds = (size_t)kRayWaves * 4 * nb * sizeof(float);
+    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_resample_t: N=%d too large for LDS", N);
+    hipLaunchKernelGGL(resample_kernel<true>, dim3((B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * kWave), lds, S_(stream), t_vals, weights, u_rand, B, nb, num_out, resample_padding, t_new, rng);
+    return check_launch("resample_t");
+}
+static int sorted_pdf_any(const float *bins, const float *weights, const float *u_rand, int B, int nb, int num_samples, float *samples, const rng_t &rng, m360_stream_t stream) {
+    if (!bins || !weights || !samples || B < 0 || nb < 2 || num_samples < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_sorted_pdf: bad argument");
+    if (B == 0) return M360_OK;
+    const size_t lds = (size_t)kRayWaves * 4 * nb * sizeof(float);
+    if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_sorted_pdf: nb=%d too large for LDS", nb);
+    hipLaunchKernelGGL(resample_kernel<false>, dim3((B + kRayWaves - 1) / kRayWaves), dim3(kRayWaves * kWave), lds, S_(stream), bins, weights, u_rand, B, nb, num_samples, 0.0f, samples, rng);
+    return check_launch("sorted_pdf");
 }
 int nerf_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
                       const float *head_b, int k_pad, float density_bias, float rgb_padding, const float *t_vals, const float *dirs,

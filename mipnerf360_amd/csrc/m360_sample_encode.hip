@@ -22,7 +22,7 @@ struct NormScratch {  // layout of the contraction workspace
 // intern/ray.py:99-110
 __global__ void sample_t_kernel(const float *__restrict__ near, const float *__restrict__ far,
                                 const float *__restrict__ t_rand, int B, int N,
-                                float *__restrict__ t_vals) {
+                                float *__restrict__ t_vals, rng_t rng = rng_t{0, 0, 0}) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int M = N + 1;
     if (idx >= (long)B * M) return;
@@ -34,10 +34,10 @@ __global__ void sample_t_kernel(const float *__restrict__ near, const float *__r
         return 1.0f / (mix + kEpsG);
     };
     float t = t_at(i);
-    if (t_rand != nullptr) {  // intern/ray.py:103-108
+    if (t_rand != nullptr || rng.on) {  // intern/ray.py:103-108
         const float lower = (i == 0) ? t : 0.5f * (t + t_at(i - 1));
         const float upper = (i == N) ? t : 0.5f * (t_at(i + 1) + t);
-        t = lower + (upper - lower) * t_rand[idx];
+        t = lower + (upper - lower) * (t_rand != nullptr ? t_rand[idx] : philox_uniform(rng, 0u, (unsigned long long)idx));
     }
     t_vals[idx] = t;
 }
@@ -272,19 +272,28 @@ __global__ __launch_bounds__(256) void stage_prologue_kernel(
     const float *__restrict__ near, const float *__restrict__ far, const float *__restrict__ viewdirs,
     const float *__restrict__ directions, const float *__restrict__ radii, int B, int N, int min_deg, int L,
     float *__restrict__ t_vals, float *__restrict__ vdenc, unsigned *__restrict__ queue_words, int n_queue_words,
-    NormScratch *__restrict__ ws) {
+    NormScratch *__restrict__ ws, rng_t rng) {
     const int M = N + 1;
     const long stride = (long)gridDim.x * blockDim.x, first = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    auto t_at = [&](float gn, float gf, int j) {
+    auto t_lin = [&](float gn, float gf, int j) {
         const float sl = linspacef_(0.0f, 1.0f, M, j);
         const float mix = sl * gf + (1.0f - sl) * gn;
         return 1.0f / (mix + kEpsG);
+    };
+    // randomized=True (intern/ray.py:103-108): sample j of ray b jittered inside its half-intervals by the Philox uniform of element
+    // b M + j - a pure function of the element, so the norm's loop below redraws what the t loop drew (sample_t_kernel's arithmetic)
+    auto t_at = [&](float gn, float gf, int j, long b = 0) {
+        const float t = t_lin(gn, gf, j);
+        if (!rng.on) return t;
+        const float lower = (j == 0) ? t : 0.5f * (t + t_lin(gn, gf, j - 1));
+        const float upper = (j == N) ? t : 0.5f * (t_lin(gn, gf, j + 1) + t);
+        return lower + (upper - lower) * philox_uniform(rng, 0u, (unsigned long long)(b * M + j));
     };
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < n_queue_words; i += blockDim.x) queue_words[i] = 0u;
     for (long idx = first; idx < (long)B * M; idx += stride) {
         const int b = (int)(idx / M), i = (int)(idx % M);
-        t_vals[idx] = t_at(1.0f / (near[b] + kEpsG), 1.0f / (far[b] + kEpsG), i);
+        t_vals[idx] = t_at(1.0f / (near[b] + kEpsG), 1.0f / (far[b] + kEpsG), i, b);
     }
     if (L > 0)
         for (long b = first; b < B; b += stride) {
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256) void stage_prologue_kernel(
     for (long idx = first; idx < S; idx += stride) {
         const int b = (int)(idx / N), n = (int)(idx % N);
         const float gn = 1.0f / (near[b] + kEpsG), gf = 1.0f / (far[b] + kEpsG);
-        const float t0 = t_at(gn, gf, n), t1 = t_at(gn, gf, n + 1);
+        const float t0 = t_at(gn, gf, n, b), t1 = t_at(gn, gf, n + 1, b);
         float tm, tv, rv;
         frustum_moments(t0, t1, radii[b], tm, tv, rv);
 #pragma unroll
@@ -642,12 +651,24 @@ namespace m360 {
 // the norm's partial sums and the tile-queue words; returns the number of partial sums (> 0) to hand to encode_prepared, 0 when
 // the chunk is not of the shape the fused prologue takes (the caller then runs the separate entry points), < 0 on a launch error.
 int stage_prologue(const m360_rays_t *r, int B, int N, int min_deg, int max_deg, float *t_vals, float *vdenc,
-                   unsigned *queue_words, int n_queue_words, int ld_feat, void *norm_ws, m360_stream_t stream) {
+                   unsigned *queue_words, int n_queue_words, int ld_feat, void *norm_ws, m360_stream_t stream, const rng_t &rng) {
     if ((long)B * N <= kSmallGroup || !(ld_feat == 64 || ld_feat == 96)) return 0;
     const int parts = norm_parts((long)B * N);
     hipLaunchKernelGGL(stage_prologue_kernel, dim3(parts), dim3(256), 0, S_(stream), r->near, r->far, r->viewdirs, r->directions, r->radii,
-                       B, N, min_deg, max_deg - min_deg, t_vals, vdenc, queue_words, n_queue_words, static_cast<NormScratch *>(norm_ws));
+                       B, N, min_deg, max_deg - min_deg, t_vals, vdenc, queue_words, n_queue_words, static_cast<NormScratch *>(norm_ws), rng);
     return check_launch("stage_prologue") == M360_OK ? parts : -1;
+}
+// m360_sample_t with the jitter's uniforms from a tensor (t_rand), from the Philox stream (rng.on) or not at all
+int sample_t_any(const float *near, const float *far, const float *t_rand, int B, int N, float *t_vals, const rng_t &rng, m360_stream_t stream) {
+    if (!near || !far || !t_vals || B < 0 || N < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_sample_t: bad argument (B=%d N=%d)", B, N);
+    if (B == 0) return M360_OK;
+    const long n = (long)B * (N + 1);
+    hipLaunchKernelGGL(sample_t_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_(stream), near, far, t_rand, B, N, t_vals, rng);
+    return check_launch("sample_t");
+}
+__global__ void philox_uniform_kernel(rng_t rng, unsigned stream_id, long n, float *__restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) out[idx] = philox_uniform(rng, stream_id, (unsigned long long)idx);
 }
 // the encode step of a stage: per-chunk norms (group_rays > 0), a norm given by the caller (ext_norm), partial sums left by
 // stage_prologue (prepared_parts > 0), or computed here; nanflag: one byte per sample for the bf16 modes' finishers (or NULL)
@@ -665,11 +686,19 @@ extern "C" {
 
 int m360_sample_t(const float *near, const float *far, const float *t_rand, int B, int N,
                   float *t_vals, m360_stream_t stream) {
-    if (!near || !far || !t_vals || B < 0 || N < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_sample_t: bad argument (B=%d N=%d)", B, N);
-    if (B == 0) return M360_OK;
-    const long n = (long)B * (N + 1);
-    hipLaunchKernelGGL(sample_t_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_(stream), near, far, t_rand, B, N, t_vals);
-    return check_launch("sample_t");
+    return sample_t_any(near, far, t_rand, B, N, t_vals, rng_t{0, 0, 0}, stream);
+}
+
+int m360_sample_t_philox(const float *near, const float *far, int B, int N, unsigned long long seed, unsigned long long offset,
+                         float *t_vals, m360_stream_t stream) {
+    return sample_t_any(near, far, nullptr, B, N, t_vals, rng_t{seed, offset, 1}, stream);
+}
+
+int m360_philox_uniform(unsigned long long seed, unsigned long long offset, int stream_id, long n, float *out, m360_stream_t stream) {
+    if (!out || n < 0 || stream_id < 0 || stream_id > 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_philox_uniform: bad argument (n=%ld stream_id=%d)", n, stream_id);
+    if (n == 0) return M360_OK;
+    hipLaunchKernelGGL(philox_uniform_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, S_(stream), rng_t{seed, offset, 1}, (unsigned)stream_id, n, out);
+    return check_launch("philox_uniform");
 }
 
 int m360_t_to_s(const float *t_vals, const float *near, const float *far, int B, int M,

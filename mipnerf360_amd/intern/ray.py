@@ -17,8 +17,8 @@ def namedtuple_map(fn, tup):
 
 def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized=True):
     """intern/ray.py:12-57 (default randomized=True as in the reference; `weights` is not modified)."""
-    u = torch.rand(bins.shape[0], num_samples, device=bins.device) if randomized else None
-    return ops.sorted_pdf(bins, weights, num_samples, u)
+    # randomized: the kernel draws its uniforms itself from torch's generator state (ops.philox_state) - no torch.rand tensor
+    return ops.sorted_pdf(bins, weights, num_samples, philox=ops.philox_state(bins.device) if randomized else None)
 
 
 def convert_to_ndc(origins, directions, focal, w, h, near=1.0):
@@ -44,15 +44,13 @@ def generate_rays(cam_to_world, h, w, focal, near, far, ndc=False, span=None):
 
 def sample_along_rays(origins, directions, radii, num_samples, near, far, randomized):
     """intern/ray.py:81-116 -> (t_vals[B,N+1], (means[B,N,3], covs[B,N,3,3]))."""
-    t_rand = torch.rand(origins.shape[0], num_samples + 1, device=origins.device) if randomized else None
-    t_vals = ops.sample_t(near, far, num_samples, t_rand)
+    t_vals = ops.sample_t(near, far, num_samples, philox=ops.philox_state(near.device) if randomized else None)
     return t_vals, ops.para_rays(t_vals, origins, directions, radii)
 
 
 def resample_along_rays(origins, directions, radii, t_vals, weights, randomized, resample_padding):
     """intern/ray.py:118-153."""
-    u = torch.rand(t_vals.shape, device=t_vals.device) if randomized else None
-    new_t = ops.resample_t(t_vals, weights, resample_padding, u)
+    new_t = ops.resample_t(t_vals, weights, resample_padding, philox=ops.philox_state(t_vals.device) if randomized else None)
     return new_t, ops.para_rays(new_t, origins, directions, radii)
 
 

@@ -161,6 +161,7 @@ def _model_struct(in_ch, prop: Optional[_PackedMLP], nerf: Optional[_PackedMLP],
     m.hp_pad = (prop or nerf).h_pad
     m.hn_pad = (nerf or prop).h_pad
     m.mlp_bf16 = int(getattr(ref, "bf16", 0))
+    m.packed_layout = _lib.PACKED_LAYOUT
     if prop is not None and nerf is not None and getattr(prop, "bf16", False) != getattr(nerf, "bf16", False):
         raise RuntimeError("proposal and NeRF networks must use the same MLP precision")
     if prop is not None:
@@ -180,6 +181,17 @@ def _hyper_struct(num_samples, min_deg, max_deg, white_bkgd=False, density_bias=
                          float(rgb_padding), float(resample_padding))
     h.prof = prof.handle if prof is not None else None  # optional _lib.Prof event recorder (bench.py, tools/)
     return h
+
+
+def _set_randomized(hyper, device, jitter: bool, cdf: bool):
+    """randomized=True: the kernels draw their uniforms themselves (m360_hyper_t.randomized / rng_seed / rng_offset) from torch's
+    device generator state - no [B, N+1] torch.rand tensors (the reference's intern/ray.py:31,104).  Returns (seed, offset) or None."""
+    bits = (1 if jitter else 0) | (2 if cdf else 0)
+    hyper.randomized = bits
+    if not bits:
+        return None
+    hyper.rng_seed, hyper.rng_offset = ops.philox_state(device)
+    return hyper.rng_seed, hyper.rng_offset
 
 
 def _mutable_field(rays, name):
@@ -361,7 +373,8 @@ class prop_net(nn.Module):
                               prof=getattr(self, "prof", None))
         t_hat = torch.empty(B, N + 1, device=dev)
         w_hat = torch.empty(B, N, device=dev)
-        t_rand = torch.rand(B, N + 1, device=dev) if self.randomized else None
+        t_rand = None  # randomized: drawn inside the kernels (stage_prologue_kernel / sample_t_kernel)
+        self.last_rng = _set_randomized(hyper, dev, bool(self.randomized), False)
         ws = _ws_for(B, N, mstruct, dev)
         if train:
             tc = _TrainCtx(self, 0, keep, rstruct, B, N, hyper, packed, mstruct)
@@ -459,7 +472,8 @@ class nerf_net(nn.Module):
         hyper = self._hyper(N, Nf)
         outs = _alloc_outputs(B, Nf, dev, with_prop=False)
         ostruct = _outputs_struct(outs)
-        u_rand = torch.rand(B, Nf + 1, device=dev) if self.randomized else None
+        u_rand = None  # randomized: drawn inside the resample kernel
+        self.last_rng = _set_randomized(hyper, dev, False, bool(self.randomized))
         ws = _ws_for(B, max(N, Nf), mstruct, dev)
         if train:
             tc = _TrainCtx(self, 1, keep, rstruct, B, Nf, hyper, self._packed, mstruct)
@@ -566,6 +580,7 @@ class mipNeRF360(nn.Module):
         mstruct = _model_struct(self.prop_net.input_size, self.prop_net._pack(), self.nerf_net._pack(), dev)
         hyper = self.nerf_net._hyper(N, Nf)
         hyper.norm_group_rays = int(norm_group_rays)
+        self.last_rng = _set_randomized(hyper, dev, bool(self.prop_net.randomized), bool(self.nerf_net.randomized))
         if stash:
             outs = _alloc_outputs(B, Nf, dev, with_prop=False, rgb=rgb, distance=distance, acc=acc)
         else:
@@ -601,7 +616,7 @@ class mipNeRF360(nn.Module):
     def forward(self, rays):
         """model.py:247-252 -> (rgb[B,3], distance[B], acc[B])."""
         staged = self.prop_net.mutate_like_reference or self.nerf_net.mutate_like_reference
-        if not self.prop_net.randomized and not self.nerf_net.randomized and not _wants_grad(self) and not staged:
+        if not _wants_grad(self) and not staged:  # randomized or not: the kernels draw their own uniforms (round 5)
             return self._forward_fused(rays)
         t_hat, w_hat = self.prop_net.forward(rays)
         rgb, dist, acc, _, _, _ = self.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
@@ -665,7 +680,7 @@ class mipNeRF360(nn.Module):
             rgb = torch.empty(length, 3, device=dev)
             dist = torch.empty(length, device=dev)
             acc = torch.empty(length, device=dev)
-        fused = not self.prop_net.randomized and not self.nerf_net.randomized and not self.mutate_like_reference
+        fused = not self.mutate_like_reference
         # Small chunks (the reference's default is 128 rays, config.py:49) are launched many at a time: the chunk
         # partition only matters through the per-chunk contraction norm, which the kernels keep per group of `chunks`
         # rays (m360_hyper_t.norm_group_rays) - bit-identical to one launch per chunk, at large-batch efficiency.

@@ -96,14 +96,39 @@ def _ws(device) -> torch.Tensor:
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
+# ----------------------------------------------------------------------------- random numbers
+def philox_state(device) -> Tuple[int, int]:
+    """(seed, offset) for one randomized libm360 call, taken from torch's device generator - and the generator advanced by 4, so
+    that no later torch kernel (nor a later call of ours) reuses the counters (include/m360.h: m360_hyper_t.rng_offset).  Same
+    `torch.manual_seed` -> same numbers, like torch.rand.  The kernels draw their uniforms themselves (Philox4x32-10): no
+    [B, N + 1] tensor of torch.rand is materialised (the reference's intern/ray.py:31,104)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+    seed, off = int(gen.initial_seed()), int(gen.get_offset())
+    gen.set_offset(off + 4)
+    return seed & 0xFFFFFFFFFFFFFFFF, off // 4
+
+
+def philox_uniform(seed: int, offset: int, stream_id: int, n: int, device) -> torch.Tensor:
+    """m360_philox_uniform: the uniforms a kernel draws for elements 0..n-1 of stream `stream_id` (0 = t_rand, 1 = u_rand)."""
+    out = torch.empty(n, device=device)
+    _call("m360_philox_uniform", C.c_ulonglong(seed), C.c_ulonglong(offset), int(stream_id), int(n), out, STREAM)
+    return out
+
+
 # ----------------------------------------------------------------------------- sampling
-def sample_t(near, far, num_samples: int, t_rand=None) -> torch.Tensor:
+def sample_t(near, far, num_samples: int, t_rand=None, philox: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """t_rand: uniforms [B, N+1] for the stratified jitter (a tensor wins); philox = (seed, offset): drawn in the kernel."""
     near, far = dev(near, "near"), dev(far, "far")
     B = near.shape[0]
     t = torch.empty(B, num_samples + 1, device=near.device)
     if t_rand is not None:
         t_rand = dev(t_rand, "t_rand")
-    _call("m360_sample_t", near, far, t_rand, B, num_samples, t, STREAM)
+    if t_rand is None and philox is not None:
+        _call("m360_sample_t_philox", near, far, B, num_samples, C.c_ulonglong(philox[0]), C.c_ulonglong(philox[1]), t, STREAM)
+    else:
+        _call("m360_sample_t", near, far, t_rand, B, num_samples, t, STREAM)
     return t
 
 
@@ -443,26 +468,35 @@ def density_to_weight(t_vals, density, dirs) -> torch.Tensor:
     return w
 
 
-def sorted_pdf(bins, weights, num_samples: int, u_rand=None) -> torch.Tensor:
+def sorted_pdf(bins, weights, num_samples: int, u_rand=None, philox: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """u_rand: uniforms [B, num_samples] of the randomized branch (a tensor wins); philox = (seed, offset): drawn in the kernel."""
     bins, weights = dev(bins, "bins"), dev(weights, "weights")
     B, nb = bins.shape
     if weights.shape[-1] != nb - 1:
         raise RuntimeError(f"sorted_pdf: weights must have {nb - 1} entries per ray, got {weights.shape[-1]}")
     out = torch.empty(B, num_samples, device=bins.device)
     u = None if u_rand is None else dev(u_rand, "u_rand")
-    _call("m360_sorted_pdf", bins, weights, u, B, nb, num_samples, out, STREAM)
+    if u is None and philox is not None:
+        _call("m360_sorted_pdf_philox", bins, weights, B, nb, num_samples, C.c_ulonglong(philox[0]), C.c_ulonglong(philox[1]), out, STREAM)
+    else:
+        _call("m360_sorted_pdf", bins, weights, u, B, nb, num_samples, out, STREAM)
     return out
 
 
-def resample_t(t_vals, weights, resample_padding: float, u_rand=None, num_out: Optional[int] = None) -> torch.Tensor:
-    """num_out (extension): number of resampled values per ray; None = t_vals.shape[-1] as in the reference."""
+def resample_t(t_vals, weights, resample_padding: float, u_rand=None, num_out: Optional[int] = None,
+               philox: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """num_out (extension): number of resampled values per ray; None = t_vals.shape[-1] as in the reference.
+    u_rand / philox: as for sorted_pdf."""
     t_vals, weights = dev(t_vals, "t_vals"), dev(weights, "weights")
     B, M = t_vals.shape
     n_out = M if num_out is None else int(num_out)
     out = torch.empty(B, n_out, device=t_vals.device)
     u = None if u_rand is None else dev(u_rand, "u_rand")
-    _call("m360_resample_t_n", t_vals, weights, u, B, M - 1, n_out, float(resample_padding), out,
-          STREAM)
+    if u is None and philox is not None:
+        _call("m360_resample_t_philox", t_vals, weights, B, M - 1, n_out, float(resample_padding), C.c_ulonglong(philox[0]),
+              C.c_ulonglong(philox[1]), out, STREAM)
+    else:
+        _call("m360_resample_t_n", t_vals, weights, u, B, M - 1, n_out, float(resample_padding), out, STREAM)
     return out
 
 

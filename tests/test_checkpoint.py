@@ -37,7 +37,8 @@ def test_packed_export_matches_padded_weights(tmp_path, dtype):
     m = checkpoint.load_reference_checkpoint(path, device=dev, num_samples=16, mlp_dtype=dtype)
     packed = checkpoint.export_packed(m)
     pad = 64 if dtype == "bf16" else 32
-    in_ch, in_pad, hp_pad, hn_pad, is_bf16 = (int(x) for x in packed["meta"])
+    in_ch, in_pad, hp_pad, hn_pad, is_bf16, layout, version = (int(x) for x in packed["meta"])
+    assert layout == checkpoint.PACKED_LAYOUT == 2 and version >= 101
     assert (in_ch, in_pad, is_bf16) == (58, 64, int(dtype == "bf16"))
     assert hp_pad == -(-100 // pad) * pad and hn_pad == -(-200 // pad) * pad
     w0 = packed["nerf.w0"]
@@ -63,6 +64,16 @@ def test_packed_export_matches_padded_weights(tmp_path, dtype):
     checkpoint.save_packed(m, str(tmp_path / "packed.npz"))
     again = checkpoint.load_packed(str(tmp_path / "packed.npz"))
     assert all(np.array_equal(again[k], packed[k]) for k in packed)
+    # a file of another layout is refused, never read past the end of its first-layer matrices
+    old = dict(packed, meta=packed["meta"][:5])
+    np.savez(str(tmp_path / "old.npz"), **old)
+    with pytest.raises(ValueError, match="layout"):
+        checkpoint.load_packed(str(tmp_path / "old.npz"))
+    if dtype == "bf16":  # round 3's first layer: [n_pad, in_pad]
+        bad = dict(packed)
+        bad["nerf.w0"] = packed["nerf.w0"][:, :in_pad].copy()
+        with pytest.raises(ValueError, match="nerf.w0"):
+            checkpoint.validate_packed(bad)
     # the loaded model renders (padding path: 100 -> 128, 200 -> 224/256 columns)
     from mipnerf360_amd.intern.ray import Rays
     from oracle import ref_path as O
@@ -95,3 +106,29 @@ def test_render_checkpoint_tool_writes_frames(tmp_path):
     for n in names:
         raw = open(out / n, "rb").read()
         assert raw[:8] == b"\x89PNG\r\n\x1a\n" and b"IHDR" in raw[:32] and len(raw) > 100
+
+
+def test_validate_packed_on_cpu():
+    """checkpoint.validate_packed needs no device: shapes by mode, layout entry required."""
+    def fake(mode, layout=checkpoint.PACKED_LAYOUT, in_pad=64, hp=64, hn=128):
+        first = {0: 1, 1: 3, 2: 6}[mode] * in_pad
+        hid = 3 if mode == 2 else 1
+        dt = np.float32 if mode == 0 else np.uint16
+        p = {"meta": np.array([58, in_pad, hp, hn, mode, layout, 101], np.int32)}
+        for name, w, layers in (("prop", hp, 4), ("nerf", hn, 8)):
+            for i in range(layers):
+                p[f"{name}.w{i}"] = np.zeros((w, first if i == 0 else hid * w), dt)
+                p[f"{name}.b{i}"] = np.zeros(w, np.float32)
+        return p
+    for mode in (0, 1, 2):
+        checkpoint.validate_packed(fake(mode))
+    with pytest.raises(ValueError, match="layout 1"):
+        checkpoint.validate_packed(fake(1, layout=1))
+    p = fake(2)
+    p["prop.w0"] = p["prop.w0"][:, :3 * 64]  # the bf16x3 first layer of round 3
+    with pytest.raises(ValueError, match="prop.w0"):
+        checkpoint.validate_packed(p)
+    p = fake(1)
+    p["meta"] = p["meta"][:5]
+    with pytest.raises(ValueError, match="without a layout entry"):
+        checkpoint.validate_packed(p)

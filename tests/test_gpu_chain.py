@@ -6,10 +6,17 @@ kernel checks both itself, reports in a status block, and the host queues a GATE
 tests break each assumption on purpose (injected faults, a shrunk wait bound, kernels on a second stream that hold CUs) and require the
 SAME BITS as six plain launches every time, plus honest counters.
 """
+import json
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
 from mipnerf360_amd import synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -272,3 +279,30 @@ def test_cooperative_launch_same_bits(dev):
     got, st = ops.mlp_chain_bf16_safe(x, a, b, packs)
     ops.set_chain_cooperative(False)
     assert torch.equal(got, want) and st["last_error"] == 0 and st["launches"] == 1, st
+
+
+def _run_bench(*argv, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bf16_frames_over_two_ranks_with_the_overlapped_gather(dev):
+    """`bench.py --config c4 --mlp-dtype bf16 --gpus 2 --backend gloo` - two rank processes render bf16 frames
+    (every chunk's NeRF MLP through the chain) while the pixel gather of the previous frame runs on a side stream.  The assembled frame
+    must be the SAME BITS overlapped, serial, and rendered by one rank alone; the line carries the chain's counters."""
+    size = "300x205"  # 61500 rays: 16 chunks of 4096 (the last one partial)
+    res2, two = _run_bench("--gpus", "2", "--backend", "gloo", "--config", "c4", "--mlp-dtype", "bf16", "--steps", "3", "--warmup", "1", "--frame-size", size)
+    assert res2.returncode == 0 and two is not None, (res2.stdout[-1500:], res2.stderr[-3000:])
+    res1, one = _run_bench("--config", "c4", "--mlp-dtype", "bf16", "--steps", "1", "--warmup", "1", "--frame-size", size)
+    assert res1.returncode == 0 and one is not None, (res1.stdout[-1500:], res1.stderr[-3000:])
+    assert two["dtype"] == "bf16" and two["frame"]["overlapped"]["overlap"] and not two["frame"]["serial"]["overlap"]
+    sums = {two["frame"]["overlapped"]["frame_bits_sum"], two["frame"]["serial"]["frame_bits_sum"], one["frame"]["overlapped"]["frame_bits_sum"]}
+    assert len(sums) == 1, sums
+    for line in (one, two):
+        ch = line["chain"]
+        assert ch["launches"] > 0 and ch["recoveries"] <= ch["launches"] and ch["chain_error"] == (ch["recoveries"] > 0), ch
+    assert one["chain"]["recoveries"] == 0, one["chain"]  # alone on the GPU nothing needs repairing

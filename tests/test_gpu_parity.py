@@ -1203,40 +1203,7 @@ def test_randomized_mode_is_statistically_sane(dev):
     assert torch.isfinite(b).all()
 
 
-@pytest.mark.parametrize("kind,B,n,wb", [("lego", 96, 32, True), ("garden", 64, 48, False)])
-def test_randomized_mode_with_replayed_uniforms_vs_oracle(dev, kind, B, n, wb, mlp_dtype="fp32"):
-    """randomized=True beyond statistics: the mirrors draw their uniforms with torch.rand on the device (t_rand [B, N+1] in
-    prop_net.forward, then u_rand [B, N+1] in nerf_net.forward), so re-seeding torch's device generator and drawing the same
-    two tensors gives the oracle the SAME uniforms - stratified jitter (intern/ray.py:103-108) and the randomized inverse-CDF
-    branch with its `u + u` doubling (:30-35) are then held to the fp32 tolerance like the deterministic path."""
-    from mipnerf360_amd.model import mipNeRF360
-    from oracle import ref_path as O
-    sd = synthetic.make_state_dict(64, 128, seed=8)
-    m = mipNeRF360(randomized=True, num_samples=n, hidden_proposal=64, hidden_nerf=128, white_bkgd=wb, device=dev, mlp_dtype=mlp_dtype)
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    r = synthetic.make_rays(kind, B, seed=9)
-    rays = dev_rays(r, dev)
-    torch.manual_seed(1234)
-    with torch.no_grad():
-        t_hat, w_hat = m.prop_net.forward(rays)
-        out = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
-    torch.manual_seed(1234)
-    t_rand = torch.rand(B, n + 1, device=dev).cpu()
-    u_rand = torch.rand(B, n + 1, device=dev).cpu()
-    sdt, hp = O.to_torch_state_dict(sd), O.Hyper(num_samples=n, white_bkgd=wb)
-    with torch.no_grad():
-        o_t, o_w = O.prop_forward(O.rays_from_numpy(r), sdt, hp, t_rand=t_rand)
-        o = O.nerf_forward(O.rays_from_numpy(r), o_t, o_w, sdt, hp, u_rand=u_rand)
-    close(t_hat, o_t, atol=2e-6, rtol=1e-5), close(w_hat, o_w, atol=5e-6 if mlp_dtype == "fp32" else 2e-5)
-    close_render(out[0], out[1], out[2], o[0], o[1], o[2])
-    close(out[3], o[3], atol=1e-5 if mlp_dtype == "fp32" else 1e-4, rtol=1e-4), close(out[4], o[4], atol=2e-5 if mlp_dtype == "fp32" else 1e-4, rtol=1e-4)
-    # the jitter really happened: the same rays without it sample elsewhere
-    assert float((t_hat.cpu() - O.prop_forward(O.rays_from_numpy(r), sdt, hp)[0]).abs().max()) > 1e-3 * float(o_t.max())
-
-
-def test_randomized_mode_with_replayed_uniforms_bf16x3(dev):
-    """The same in the bf16x3 mode (the jittered samples take the separate prologue kernels: t_rand rules out the one-launch form)."""
-    test_randomized_mode_with_replayed_uniforms_vs_oracle(dev, "lego", 40, 24, True, mlp_dtype="bf16x3")
+# (randomized=True against the oracle on the uniforms the kernels drew themselves: tests/test_gpu_random.py)
 
 
 # =============================================================================== BASELINE.json full size

@@ -1,0 +1,169 @@
+"""GPU tests (`-m gpu`) of randomized=True with the uniforms drawn INSIDE the kernels (round 5; the reference's CLI default,
+config.py:15; intern/ray.py:30-35 randomized inverse CDF with its `u + u`, :103-108 stratified jitter).
+
+The kernels use Philox4x32-10 keyed by torch's device generator (seed, offset); `m360_philox_uniform` writes out exactly the uniforms a
+launch drew, so the CPU oracle can be run on THE SAME uniforms and the randomized path is held to the fp32 tolerance like the
+deterministic one - not just to statistics.
+"""
+import numpy as np
+import pytest
+import torch
+
+from mipnerf360_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+RGB_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test needs a HIP device")
+    return torch.device("cuda:0")
+
+
+def H(t):
+    return t.detach().cpu().numpy()
+
+
+def close(a, b, atol=1e-6, rtol=1e-5):
+    np.testing.assert_allclose(H(a) if isinstance(a, torch.Tensor) else a, H(b) if isinstance(b, torch.Tensor) else b, atol=atol, rtol=rtol)
+
+
+def dev_rays(d, dev):
+    from mipnerf360_amd.intern.ray import Rays
+    return Rays(*[torch.from_numpy(np.ascontiguousarray(d[k])).float().to(dev) for k in synthetic.RAY_FIELDS])
+
+
+def test_dumped_uniforms_are_philox4x32_10(dev):
+    """m360_philox_uniform == the numpy restatement (oracle/philox.py, pinned by Random123's known answers on the CPU), bit for bit,
+    for several (seed, offset, stream): element e of stream s is philox(key = seed, counter = (offset, e, s << 28)).x >> 8."""
+    from mipnerf360_amd import ops
+    from oracle import philox as P
+    assert float(ops.philox_uniform(0, 0, 0, 1, dev)[0]) == float(np.float32(0x6627e8d5 >> 8) * np.float32(2.0 ** -24))  # Random123 KAT, word 0
+    for seed, off, stream, n in ((0, 0, 0, 1000), (1234, 0, 1, 4097), (2 ** 63 + 12345, 2 ** 40 + 3, 0, 777), (987654321987, 5, 1, 100000)):
+        got = ops.philox_uniform(seed, off, stream, n, dev).cpu().numpy()
+        want = P.uniform(seed, off, stream, n)
+        assert np.array_equal(got, want), (seed, off, stream)
+        assert got.min() >= 0.0 and got.max() < 1.0
+    big = ops.philox_uniform(7, 1, 0, 1 << 20, dev)
+    assert abs(float(big.mean()) - 0.5) < 2e-3 and abs(float(big.var()) - 1.0 / 12.0) < 1e-3
+    assert not torch.equal(ops.philox_uniform(7, 1, 0, 4096, dev), ops.philox_uniform(7, 1, 1, 4096, dev))   # streams differ
+    assert not torch.equal(ops.philox_uniform(7, 1, 0, 4096, dev), ops.philox_uniform(7, 2, 0, 4096, dev))   # offsets differ
+
+
+def _model(dev, n, wb, mlp_dtype="fp32", seed=8):
+    from mipnerf360_amd.model import mipNeRF360
+    sd = synthetic.make_state_dict(64, 128, seed=seed)
+    m = mipNeRF360(randomized=True, num_samples=n, hidden_proposal=64, hidden_nerf=128, white_bkgd=wb, device=dev, mlp_dtype=mlp_dtype)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m, sd
+
+
+@pytest.mark.parametrize("kind,B,n,wb,mlp_dtype", [("lego", 96, 32, True, "fp32"), ("garden", 64, 48, False, "fp32"), ("lego", 40, 24, True, "bf16x3")])
+def test_staged_randomized_forwards_vs_oracle_on_the_dumped_uniforms(dev, kind, B, n, wb, mlp_dtype):
+    """prop_net.forward then nerf_net.forward of a randomized model: each draws its uniforms in its kernels from the generator state it
+    took (module.last_rng); the oracle, handed the dumped uniforms as t_rand / u_rand, must agree within the fp32 tolerance."""
+    from mipnerf360_amd import ops
+    from oracle import ref_path as O
+    m, sd = _model(dev, n, wb, mlp_dtype)
+    r = synthetic.make_rays(kind, B, seed=9)
+    rays = dev_rays(r, dev)
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+        out = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    (s0, o0), (s1, o1) = m.prop_net.last_rng, m.nerf_net.last_rng
+    assert s0 == s1 == 1234 and o1 == o0 + 1  # the generator moved on by 4 (one counter block) per call
+    t_rand = ops.philox_uniform(s0, o0, 0, B * (n + 1), dev).reshape(B, n + 1).cpu()
+    u_rand = ops.philox_uniform(s1, o1, 1, B * (n + 1), dev).reshape(B, n + 1).cpu()
+    sdt, hp = O.to_torch_state_dict(sd), O.Hyper(num_samples=n, white_bkgd=wb)
+    with torch.no_grad():
+        o_t, o_w = O.prop_forward(O.rays_from_numpy(r), sdt, hp, t_rand=t_rand)
+        o = O.nerf_forward(O.rays_from_numpy(r), o_t, o_w, sdt, hp, u_rand=u_rand)
+    f32 = mlp_dtype == "fp32"
+    close(t_hat, o_t, atol=2e-6, rtol=1e-5), close(w_hat, o_w, atol=5e-6 if f32 else 2e-5)
+    close(out[0], o[0], atol=RGB_TOL, rtol=0), close(out[2], o[2], atol=RGB_TOL, rtol=0)
+    assert np.all(np.abs(H(out[1]) - H(o[1])) <= 1e-4 * np.maximum(1.0, np.abs(H(o[1]))))
+    close(out[3], o[3], atol=1e-5 if f32 else 1e-4, rtol=1e-4), close(out[4], o[4], atol=2e-5 if f32 else 1e-4, rtol=1e-4)
+    # the jitter really happened: the same rays without it sample elsewhere
+    assert float((t_hat.cpu() - O.prop_forward(O.rays_from_numpy(r), sdt, hp)[0]).abs().max()) > 1e-3 * float(o_t.max())
+
+
+@pytest.mark.parametrize("B,n", [(2304, 64), (200, 32)])
+def test_fused_randomized_forward_vs_oracle_on_the_dumped_uniforms(dev, B, n):
+    """a randomized model takes the fused m360_forward - jitter in the one-launch prologue (2304 x 64 = 147456
+    samples: the prologue's own norm loop redraws the same uniforms) or in sample_t_kernel (small batch), randomized inverse CDF in the
+    proposal finisher.  Against the oracle on the dumped uniforms; same seed -> same bits; another seed -> other samples."""
+    from mipnerf360_amd import ops
+    from oracle import ref_path as O
+    m, sd = _model(dev, n, False)
+    m.eval()  # reference quirk: the sub-nets stay randomized (model.py:276-283)
+    r = synthetic.make_rays("garden", B, seed=3)
+    rays = dev_rays(r, dev)
+    torch.manual_seed(77)
+    with torch.no_grad():
+        got = [o.clone() for o in m(rays)]
+    seed, off = m.last_rng
+    assert seed == 77 and off == 0
+    t_rand = ops.philox_uniform(seed, off, 0, B * (n + 1), dev).reshape(B, n + 1).cpu()
+    u_rand = ops.philox_uniform(seed, off, 1, B * (n + 1), dev).reshape(B, n + 1).cpu()
+    sdt, hp = O.to_torch_state_dict(sd), O.Hyper(num_samples=n, white_bkgd=False)
+    with torch.no_grad():
+        o_t, o_w = O.prop_forward(O.rays_from_numpy(r), sdt, hp, t_rand=t_rand)
+        o = O.nerf_forward(O.rays_from_numpy(r), o_t, o_w, sdt, hp, u_rand=u_rand)
+    close(got[0], o[0], atol=RGB_TOL, rtol=0), close(got[2], o[2], atol=RGB_TOL, rtol=0)
+    assert np.all(np.abs(H(got[1]) - H(o[1])) <= 1e-4 * np.maximum(1.0, np.abs(H(o[1]))))
+    close(m.nerf_net.t_vals, o[3], atol=1e-5, rtol=1e-4)
+    torch.manual_seed(77)
+    with torch.no_grad():
+        again = m(rays)
+    assert all(torch.equal(a, b) for a, b in zip(got, again))
+    with torch.no_grad():
+        other = m(rays)  # the generator has moved on
+    assert m.last_rng == (77, 1) and not torch.equal(other[0], got[0])
+    # and the deterministic render of the same rays is close but not equal (statistics)
+    det, _ = _model(dev, n, False)
+    det.prop_net.randomized = det.nerf_net.randomized = False
+    with torch.no_grad():
+        d = det(rays)
+    assert float((d[0] - got[0]).abs().mean()) < 0.05 and not torch.equal(d[0], got[0])
+
+
+def test_randomized_free_functions_vs_oracle(dev):
+    """The mirrors of intern/ray.py with randomized=True: sample_along_rays, resample_along_rays, sorted_piecewise_constant_pdf draw in
+    their kernels too (no torch.rand tensor); replayed through the oracle's jitter_t / resample_t / sorted_piecewise_constant_pdf."""
+    from mipnerf360_amd import ops
+    from mipnerf360_amd.intern import ray as R
+    from oracle import ref_path as O
+    B, n = 50, 40
+    r = synthetic.make_rays("lego", B, seed=2)
+    rays = dev_rays(r, dev)
+    g = torch.Generator().manual_seed(0)
+    w = torch.rand(B, n, generator=g)
+    torch.manual_seed(5)
+    t_vals, _ = R.sample_along_rays(rays.origins, rays.directions, rays.radii, n, rays.near, rays.far, True)
+    t_new, _ = R.resample_along_rays(rays.origins, rays.directions, rays.radii, t_vals, w.to(dev), True, 0.01)
+    pdf = R.sorted_piecewise_constant_pdf(t_vals, w.to(dev) + 0.01, 17, randomized=True)
+    tr = ops.philox_uniform(5, 0, 0, B * (n + 1), dev).reshape(B, n + 1).cpu()
+    ur = ops.philox_uniform(5, 1, 1, B * (n + 1), dev).reshape(B, n + 1).cpu()
+    ur2 = ops.philox_uniform(5, 2, 1, B * 17, dev).reshape(B, 17).cpu()
+    o_t = O.jitter_t(O.sample_t(torch.from_numpy(r["near"]), torch.from_numpy(r["far"]), n), tr)
+    close(t_vals, o_t, atol=2e-6, rtol=1e-5)
+    close(t_new, O.resample_t(t_vals.cpu(), w, 0.01, u_rand=ur), atol=4e-6, rtol=1e-5)
+    close(pdf, O.sorted_piecewise_constant_pdf(t_vals.cpu(), w + 0.01, 17, u_rand=ur2), atol=4e-6, rtol=1e-5)
+
+
+def test_randomized_frame_renders_through_the_fused_path(dev):
+    """render_image of a randomized model (what the reference's test.py does by default, config.py:15): grouped small chunks and whole
+    chunks both go through m360_forward now; finite, reproducible under a seed, close to the deterministic frame."""
+    m, _ = _model(dev, 32, True)
+    m.eval()
+    r = synthetic.make_rays("lego", 24 * 16, seed=4)
+    rays = dev_rays(r, dev)
+    for chunks in (128, 4096):
+        torch.manual_seed(3)
+        a = m.render_image(rays, 16, 24, chunks)
+        torch.manual_seed(3)
+        b = m.render_image(rays, 16, 24, chunks)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)) and np.isfinite(a[1]).all() and a[0].dtype == np.uint8

@@ -587,3 +587,21 @@ def test_g21_oracle_gradients_on_structured_weights(golden, kind):
     np.testing.assert_allclose(float(ld), float(g[kind + "_loss_dist"]), rtol=1e-4)
     for name, gr in grads.items():
         assert_grad_within_reference_error(gr.numpy(), g[f"{kind}_nerfstep.{name}"], g[f"{kind}_nerfstep64.{name}"], what=f"nerf step {name}")
+
+
+def test_philox_known_answers():
+    """oracle/philox.py (the generator behind randomized=True, restated in numpy) against Random123's published known-answer vectors for
+    Philox4x32-10 (kat_vectors: philox4x32 10), and the uniform mapping: top 24 bits of word 0, in [0, 1)."""
+    from oracle import philox as P
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(v) for v in P.philox4x32_10(ctr, key)) == want
+    u = P.uniform(0, 0, 0, 3)
+    assert u.dtype == np.float32 and float(u[0]) == (0x6627e8d5 >> 8) / 2.0 ** 24
+    # element 1 of stream 0 = counter (0, 0, 1, 0); stream 1 element 0 = counter (0, 0, 0, 1 << 28)
+    assert float(u[1]) == (int(P.philox4x32_10((0, 0, 1, 0), (0, 0))[0]) >> 8) / 2.0 ** 24
+    assert float(P.uniform(0, 0, 1, 1)[0]) == (int(P.philox4x32_10((0, 0, 0, 1 << 28), (0, 0))[0]) >> 8) / 2.0 ** 24
+    big = P.uniform(99, 3, 1, 200000)
+    assert big.min() >= 0.0 and big.max() < 1.0 and abs(float(big.mean()) - 0.5) < 3e-3
