@@ -546,35 +546,8 @@ def named_workloads(sd_np, dev, _lib):
     forward_entry("c2_bf16", "c2", "bf16", 20, 3)       # configs[1]'s shape with the opt-in bf16 MLP
     forward_entry("c2_bf16x3", "c2", "bf16x3", 10, 2)   # ... and with two bf16 terms per value (inside the fp32 tolerance)
 
-    # ---- one iteration of the reference's training loop body (train.py:53-82: two proposal updates, one NeRF update, AdamW)
-    n_rays, samples = CONFIGS["c2"][0], CONFIGS["c2"][1]
-    model = mipNeRF360(randomized=False, num_samples=samples, hidden_proposal=HP, hidden_nerf=HN, device=dev)
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
-    model.train()
-    r = synthetic.make_rays("garden", n_rays, seed=1)
-    rays = Rays(*[torch.from_numpy(r[k]).to(dev) for k in synthetic.RAY_FIELDS])
-    pixels = torch.rand(n_rays, 3, device=dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
-
-    def prop_step():
-        t_hat, w_hat = model.prop_net.forward(rays)
-        with torch.no_grad():
-            _, _, _, t, w_, _ = model.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
-        loss = Loss_prop(t=t, w=w_, t_hat=t_hat, w_hat=w_hat)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-
-    def nerf_step():
-        with torch.no_grad():
-            t_hat, w_hat = model.prop_net.forward(rays)
-        rgb, _, _, _, fw, sv = model.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
-        ln, _ = Loss_nerf(input=rgb, target=pixels)
-        ld = Loss_dist(s_vals=sv, weights=fw)
-        opt.zero_grad()
-        (ln + 0.01 * ld).backward()
-        opt.step()
-
+    # ---- one iteration of the reference's training loop body (train.py:53-82: two proposal updates, one NeRF update, AdamW), in fp32 and
+    # (round 5) with the student in bf16: bf16 tape and gradients in flight, fp32 accumulation, fp32 master weights + AdamW
     def timed(fn, iters):
         fn()
         torch.cuda.synchronize()
@@ -584,34 +557,78 @@ def named_workloads(sd_np, dev, _lib):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters * 1e3
 
-    prop_ms, nerf_ms = timed(prop_step, 1), timed(nerf_step, 2)
-    it_ms = 2 * prop_ms + nerf_ms
-    del model, opt
-    torch.cuda.empty_cache()
-    M = n_rays * samples
-    dz = torch.randn(M, HN, device=dev)
-    x = torch.relu(torch.randn(M, HN, device=dev))
-    wt = ops.pack_linear_transposed(torch.randn(HN, HN, device=dev) / 32)
-    dx = torch.empty(M, HN, device=dev)
-    flops = 2.0 * M * HN * HN
-    wgrad_ms = timed(lambda: ops.linear_wgrad(dz, x), 3)
-    dgrad_ms = timed(lambda: ops.linear_dgrad(dz, wt, x, out=dx), 3)
-    del dz, x, dx, wt
-    torch.cuda.empty_cache()
-    out["c2_training_iteration"] = {
-        "config": "c2", "dtype": "f32",
-        "workload": "one iteration of the reference's training loop body (train.py:53-82) at 4096 rays x 128 samples, full width, fp32: "
-                    "two proposal updates (forward both nets, Loss_prop, backward of the proposal net, AdamW) + one NeRF update "
-                    "(forward both nets, Loss_nerf + 0.01 Loss_dist, backward of the NeRF net, AdamW); tape-keeping forwards, "
-                    "hand-written backward (m360_prop_backward / m360_nerf_backward), torch.optim.AdamW",
-        "iteration_ms": round(it_ms, 2), "prop_update_ms": round(prop_ms, 2), "nerf_update_ms": round(nerf_ms, 2),
-        "train_rays_per_s": round(n_rays / it_ms * 1e3, 1),
-        "nerf_update_tflops": round(M * (423424 + 3 * 14807040) / nerf_ms / 1e9, 1),
-        "wgrad_1024x1024": {"ms": round(wgrad_ms, 3), "tflops": round(flops / wgrad_ms / 1e9, 1), "frac": round(flops / wgrad_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
-                            "kernel": "linear_tn_kernel + tn_reduce_kernel (dW = dZ^T X, bias gradient fused)"},
-        "dgrad_1024x1024": {"ms": round(dgrad_ms, 3), "tflops": round(flops / dgrad_ms / 1e9, 1), "frac": round(flops / dgrad_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
-                            "kernel": "linear_f32_mfma_persist_kernel<RELU_MASK> (dX = (dZ W) * [a > 0])"},
-        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+    def training_entry(name, mlp_dtype):
+        n_rays, samples = CONFIGS["c2"][0], CONFIGS["c2"][1]
+        b16 = mlp_dtype == "bf16"
+        torch.cuda.reset_peak_memory_stats()
+        model = mipNeRF360(randomized=False, num_samples=samples, hidden_proposal=HP, hidden_nerf=HN, device=dev, mlp_dtype=mlp_dtype)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        model.train()
+        r = synthetic.make_rays("garden", n_rays, seed=1)
+        rays = Rays(*[torch.from_numpy(r[k]).to(dev) for k in synthetic.RAY_FIELDS])
+        pixels = torch.rand(n_rays, 3, device=dev)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
+
+        def prop_step():
+            t_hat, w_hat = model.prop_net.forward(rays)
+            with torch.no_grad():
+                _, _, _, t, w_, _ = model.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+            loss = Loss_prop(t=t, w=w_, t_hat=t_hat, w_hat=w_hat)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+        def nerf_step():
+            with torch.no_grad():
+                t_hat, w_hat = model.prop_net.forward(rays)
+            rgb, _, _, _, fw, sv = model.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+            ln, _ = Loss_nerf(input=rgb, target=pixels)
+            ld = Loss_dist(s_vals=sv, weights=fw)
+            opt.zero_grad()
+            (ln + 0.01 * ld).backward()
+            opt.step()
+
+        prop_ms, nerf_ms = timed(prop_step, 2 if b16 else 1), timed(nerf_step, 3 if b16 else 2)
+        it_ms = 2 * prop_ms + nerf_ms
+        finite = all(bool(torch.isfinite(p).all()) for p in model.parameters())
+        del model, opt
+        torch.cuda.empty_cache()
+        M = n_rays * samples
+        flops = 2.0 * M * HN * HN
+        if b16:
+            dz = torch.randn(M, HN, device=dev).bfloat16()
+            x = torch.relu(torch.randn(M, HN, device=dev)).bfloat16()
+            wt = ops.pack_linear_bf16_transposed(torch.randn(HN, HN, device=dev) / 32)
+            dx = torch.empty(M, HN, device=dev, dtype=torch.bfloat16)
+            wgrad_ms = timed(lambda: ops.linear_wgrad_bf16(dz, x), 5)
+            dgrad_ms = timed(lambda: ops.linear_dgrad_bf16(dz, wt, x, out=dx), 5)
+            peak, wk, dk = PEAK_BF16_MFMA_TFLOPS, "linear_tn_bf16_kernel + tn16_reduce_kernel (dW = dZ^T X on v_mfma_f32_16x16x32_bf16, operands transposed by ds_read_b64_tr_b16; bias gradient on the matrix pipe)", \
+                "linear_bf16_w16_kernel on the transposed bf16 packing + relu_mask_bf16_kernel (dX = (dZ W) * [a > 0])"
+        else:
+            dz = torch.randn(M, HN, device=dev)
+            x = torch.relu(torch.randn(M, HN, device=dev))
+            wt = ops.pack_linear_transposed(torch.randn(HN, HN, device=dev) / 32)
+            dx = torch.empty(M, HN, device=dev)
+            wgrad_ms = timed(lambda: ops.linear_wgrad(dz, x), 3)
+            dgrad_ms = timed(lambda: ops.linear_dgrad(dz, wt, x, out=dx), 3)
+            peak, wk, dk = PEAK_F32_MFMA_TFLOPS, "linear_tn_kernel + tn_reduce_kernel (dW = dZ^T X, bias gradient fused)", "linear_f32_mfma_persist_kernel<RELU_MASK> (dX = (dZ W) * [a > 0])"
+        del dz, x, dx, wt
+        torch.cuda.empty_cache()
+        out[name] = {
+            "config": "c2", "dtype": "bf16" if b16 else "f32", "finite": finite,
+            "workload": f"one iteration of the reference's training loop body (train.py:53-82) at 4096 rays x 128 samples, full width, {MLP_NAMES[mlp_dtype]}: "
+                        "two proposal updates (forward both nets, Loss_prop, backward of the proposal net, AdamW) + one NeRF update "
+                        "(forward both nets, Loss_nerf + 0.01 Loss_dist, backward of the NeRF net, AdamW); tape-keeping forwards, "
+                        "hand-written backward (m360_prop_backward / m360_nerf_backward), torch.optim.AdamW on fp32 master weights",
+            "iteration_ms": round(it_ms, 2), "prop_update_ms": round(prop_ms, 2), "nerf_update_ms": round(nerf_ms, 2),
+            "train_rays_per_s": round(n_rays / it_ms * 1e3, 1),
+            "nerf_update_tflops": round(M * (423424 + 3 * 14807040) / nerf_ms / 1e9, 1),
+            "wgrad_1024x1024": {"ms": round(wgrad_ms, 3), "tflops": round(flops / wgrad_ms / 1e9, 1), "frac": round(flops / wgrad_ms / 1e9 / peak, 4), "kernel": wk},
+            "dgrad_1024x1024": {"ms": round(dgrad_ms, 3), "tflops": round(flops / dgrad_ms / 1e9, 1), "frac": round(flops / dgrad_ms / 1e9 / peak, 4), "kernel": dk},
+            "peak": peak, "unit": "TFLOP/s", "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+
+    training_entry("c2_training_iteration", "fp32")
+    training_entry("c2_training_iteration_bf16", "bf16")
     out["seconds"] = round(time.perf_counter() - t_all, 2)
     return out
 

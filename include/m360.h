@@ -210,6 +210,23 @@ int m360_pack_linear_bf16(const float *w, const float *b, int n_out, int k_in, i
                           void *w_packed_bf16, float *b_packed, m360_stream_t stream);
 int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_bf16, const float *b_packed,
                      int n_pad, int k_pad, int act, void *y_bf16, int ldy, m360_stream_t stream);
+/* ---- bf16 training path (round 5; SURVEY.md §8 row f3 in the precision BASELINE configs[4] runs at): what autograd computes for
+ * nn.Linear under train.py:62,80 (model.py:43-53,131-158) with activations and their gradients carried in bf16 - fp32 accumulation,
+ * fp32 gradients out, fp32 master weights / AdamW untouched.
+ *   m360_pack_linear_bf16_transposed: fp32 [n_out, k_in] -> bf16 transpose [k_pad, n_pad] (n_pad a multiple of 64), the operand of the
+ *     input gradient;
+ *   m360_linear_dgrad_bf16: dX[M, k_pad] = dZ[M, n_pad] * W as the forward layer kernel on that packing (bf16 in, bf16 out); relu_out (the
+ *     forward OUTPUT of the layer below, bf16, leading dimension ldx; NULL = no mask) clears dX where it is <= 0 (ReLU');
+ *   m360_linear_wgrad_bf16: dW[n_pad, k_pad] = dZ^T X and db[n_pad] = column sums of dZ (NULL to skip) in fp32 from bf16 rows.  n_pad, k_pad
+ *     multiples of 256 run on v_mfma_f32_16x16x32_bf16 (both operands transposed on their way out of the LDS by ds_read_b64_tr_b16; row splits
+ *     reduced in a fixed order: deterministic); other pads (multiples of 32: reduced-width models) are widened to fp32 for m360_linear_wgrad. */
+int m360_pack_linear_bf16_transposed(const float *w, int n_out, int k_in, int n_pad, int k_pad, void *wt_packed_bf16 /*[k_pad, n_pad]*/,
+                                     m360_stream_t stream);
+int m360_linear_dgrad_bf16(const void *dz_bf16, long M, int ldz, const void *wt_packed_bf16, int k_pad, int n_pad, const void *relu_out_bf16,
+                           void *dx_bf16, int ldx, m360_stream_t stream);
+size_t m360_linear_wgrad_bf16_workspace_bytes(long M, int n_pad, int k_pad);
+int m360_linear_wgrad_bf16(const void *dz_bf16, int ldz, const void *x_bf16, int ldx, long M, int n_pad, int k_pad, float *grad_w,
+                           float *grad_b, void *workspace, size_t workspace_bytes, m360_stream_t stream);
 /* ---- opt-in "bf16x3" MLP: near-fp32 accuracy on the bf16 matrix pipe.  Every activation and weight is carried as TWO bf16
  * terms (hi = bf16(v), lo = bf16(v - hi): 16 significant bits) and a product x w is formed as xh wh + xl wh + xh wl with
  * fp32 accumulation (the xl wl term, 2^-16 of the product, is dropped): three bf16 MFMA passes per 64-deep block, in the order
@@ -661,7 +678,10 @@ int m360_forward(const m360_rays_t *rays_host, const m360_model_t *model_host,
  * Backward of the two stages with respect to the network parameters - what `loss.backward()` computes in
  * train.py:62,80.  As in the reference, the sample positions carry no gradient (resampling runs under
  * torch.no_grad(), intern/ray.py:136; train.py:70-71 detaches t_hat / w_hat), so the gradient stops at the MLP
- * inputs.  fp32 only.  Gradients use the packed layouts of the model struct, zero in the padding. */
+ * inputs.  mlp_bf16 = 0 (fp32) or 1 (bf16, round 5: the tape holds bf16 layer outputs and the [hi | lo] feature rows, dz travels in bf16,
+ * products accumulate in fp32; m360_mlp_transposed_t then carries m360_pack_linear_bf16_transposed packings); the bf16x3 mode is
+ * forward-only.  Gradients are fp32 in the packed [n_pad, k_pad] layouts of the fp32 model struct (layer 0: [n_pad, in_pad] in every mode),
+ * zero in the padding. */
 
 typedef struct m360_mlp_transposed {
     const float *w_t[8]; /* layer l >= 1: m360_pack_linear_transposed of that layer's weight; [0] unused */

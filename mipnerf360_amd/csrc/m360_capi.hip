@@ -63,6 +63,13 @@ int nerf_finish_stage(const void *act, int act_bf16, int ld, const float *head_p
                       float *distance, float *acc, float *weights, float *t_vals_out, float *s_vals_out, const unsigned char *nanflag,
                       m360_stream_t stream);
 
+int prop_finish_backward_bf16(const void *act, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, const float *t_vals,
+                              const float *dirs, int B, int N, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b,
+                              void *workspace, size_t workspace_bytes, m360_stream_t stream);
+int nerf_finish_backward_bf16(const void *act, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, float rgb_padding,
+                              const float *t_vals, const float *dirs, int B, int N, int white_bkgd, const float *grad_rgb, const float *grad_distance,
+                              const float *grad_acc, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b, void *workspace,
+                              size_t workspace_bytes, m360_stream_t stream);
 // m360_linear.hip: the hidden-layer chain of the bf16 mode (one launch) and its gated layer-by-layer re-run
 int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
                           int layers, int width, void *ws, m360_stream_t stream);
@@ -309,8 +316,9 @@ static TapeLayout tape_for(int B, int N, const m360_model_t *m, int stage) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     T.t = take((size_t)B * (N + 1) * sizeof(float));
-    T.feat = take(S * m->in_pad * sizeof(float));
-    for (int l = 0; l < 8; ++l) T.act[l] = l < T.layers ? take(S * width * sizeof(float)) : 0;
+    T.feat = take(S * m->in_pad * sizeof(float));  // bf16 mode: [hi | lo] pairs of in_pad bf16 each - the same 4 bytes per value
+    const size_t el = m->mlp_bf16 == 1 ? sizeof(unsigned short) : sizeof(float);  // bf16 mode: every layer's output as bf16 rows
+    for (int l = 0; l < 8; ++l) T.act[l] = l < T.layers ? take(S * width * el) : 0;
     T.total = off;
     return T;
 }
@@ -340,7 +348,25 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     }
     if (fused) *fused = parts > 0;
     M360_TRY(queues_begin(&tq, ws, L.queues, 0, parts > 0, st));
-    if (tape) {  // training: fp32 only, every layer output kept
+    if (tape && m->mlp_bf16 == 1) {  // bf16 training (round 5): plain rows, every layer's bf16 output kept; the encoder's [hi | lo] feature rows too
+        const TapeLayout T = tape_for(B, N, m, 0);
+        const int hp = m->hp_pad;
+        float *tt = reinterpret_cast<float *>(tape + T.t);
+        void *tf = tape + T.feat;
+        void *act[4];
+        for (int l = 0; l < 4; ++l) act[l] = tape + T.act[l];
+        M360_TRY(sample_t_any(r->near, r->far, t_rand, B, N, tt, rng_jitter(h, t_rand), st));
+        if (hipMemcpyAsync(t_hat, tt, (size_t)B * (N + 1) * sizeof(float), hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(st)) != hipSuccess)
+            return fail(M360_ERR_LAUNCH, "m360_prop_forward_train: copy of t_hat failed");
+        M360_TRY(m360_viewdir_enc(r->viewdirs, B, h->viewdir_min_deg, h->viewdir_max_deg, vdenc, st));
+        M360_TRY(p_encode(h, tt, r, vdenc, vd_ch, B, N, tf, m->in_pad, first_row_format(1), h->norm_group_rays, nullptr, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_linear_first(h, 1, tf, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, act[0], 0, st));
+        for (int l = 1; l < 3; ++l)
+            M360_TRY(p_linear_bf16(h, 1, act[l - 1], S, m->prop_w[l], m->prop_b[l], hp, hp, M360_ACT_RELU, act[l], 0, st));
+        M360_TRY(p_linear_heads(h, 1, act[2], S, hp, m->prop_w[3], m->prop_b[3], hp, hp, act[3], hp, 1, m->prop_head_w, 1, hpart, st));
+        return p_prop_finish_fused(h, act[3], 1, hp, hpart, m360_linear_heads_fused_rows(S, hp, 1), m360_linear_heads_slots_bf16(hp, hp, 1, 1), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st, flags);
+    }
+    if (tape) {  // training, fp32: every layer output kept
         const TapeLayout T = tape_for(B, N, m, 0);
         const int hp = m->hp_pad;
         float *tt = reinterpret_cast<float *>(tape + T.t), *tf = reinterpret_cast<float *>(tape + T.feat);
@@ -410,7 +436,18 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     const int hn = m->hn_pad;
     const int slots = m360_linear_heads_slots(hn, m->mlp_bf16);
     float *src = a, *dst = b;
-    if (tape) {  // training: fp32 only, every layer output kept (t1 already lives in the tape)
+    if (tape && m->mlp_bf16 == 1) {  // bf16 training (round 5): plain rows, every layer's bf16 output kept (t1 already lives in the tape)
+        const TapeLayout T = tape_for(B, N, m, 1);
+        void *tf = tape + T.feat;
+        void *act[8];
+        for (int l = 0; l < 8; ++l) act[l] = tape + T.act[l];
+        M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, tf, m->in_pad, first_row_format(1), h->norm_group_rays, nullptr, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
+        M360_TRY(p_linear_first(h, 1, tf, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, act[0], 0, st));
+        for (int l = 1; l < 7; ++l)
+            M360_TRY(p_linear_bf16(h, 1, act[l - 1], S, m->nerf_w[l], m->nerf_b[l], hn, hn, M360_ACT_RELU, act[l], 0, st));
+        M360_TRY(p_linear_heads(h, 1, act[6], S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, act[7], hn, 1, m->nerf_head_w, 4, hpart, st));
+        M360_TRY(p_nerf_finish_fused(h, act[7], 1, hn, hpart, m360_linear_heads_fused_rows(S, hn, 1), m360_linear_heads_slots_bf16(hn, hn, 1, 1), m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st, flags));
+    } else if (tape) {  // training, fp32: every layer output kept (t1 already lives in the tape)
         const TapeLayout T = tape_for(B, N, m, 1);
         float *tf = reinterpret_cast<float *>(tape + T.feat);
         float *act[8];
@@ -624,20 +661,34 @@ size_t m360_train_tape_bytes(int B, int N, const m360_model_t *model_host, int s
 }
 
 struct BwdLayout {
-    size_t dz_a, dz_b, gemm, finish, total;
+    size_t dz_a, dz_b, gemm, finish, feat_wide, first, total;
+    int first_k;  // bf16 mode: columns of the first layer's operand as the weight-gradient kernel sees it (see mlp_backward_bf16)
 };
+// bf16 mode, first layer: the features are [hi | lo] pair rows of 2 in_pad columns.  The MFMA weight-gradient kernel takes contractions over
+// 256-column tiles, so the rows are copied into a zero-padded [S, 256] operand for it (widths it does not take go through the fp32 kernel as
+// they are); either way the result [n_pad, first_k] is folded into grad_w[0][n][k] = r[n][k] + r[n][in_pad + k]
+static int bf16_first_k(const m360_model_t *m, int width) { return (width % 256 == 0 && 2 * m->in_pad <= 256) ? 256 : 2 * m->in_pad; }
 static BwdLayout bwd_layout_for(int B, int N, const m360_model_t *m, int stage) {
     BwdLayout L;
     const size_t S = (size_t)B * N;
     const int width = stage == 0 ? m->hp_pad : m->hn_pad;
     const int kmax = width > m->in_pad ? width : m->in_pad;
+    const bool b16 = m->mlp_bf16 == 1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     (void)take(128);  // a caller may hand in the buffer it uses as forward workspace: its status block (offset 0) is left alone
-    L.dz_a = take(S * width * sizeof(float));
-    L.dz_b = take(S * width * sizeof(float));
-    L.gemm = take(m360_linear_wgrad_workspace_bytes((long)S, width, kmax));
+    L.first_k = b16 ? bf16_first_k(m, width) : 0;
+    L.dz_a = take(S * width * (b16 ? 2 : sizeof(float)));
+    L.dz_b = take(S * width * (b16 ? 2 : sizeof(float)));
+    if (b16) {
+        const size_t g1 = m360_linear_wgrad_bf16_workspace_bytes((long)S, width, width), g0 = m360_linear_wgrad_bf16_workspace_bytes((long)S, width, L.first_k);
+        L.gemm = take(g1 > g0 ? g1 : g0);
+    } else {
+        L.gemm = take(m360_linear_wgrad_workspace_bytes((long)S, width, kmax));
+    }
     L.finish = take(m360_finish_backward_workspace_bytes(B, stage == 0 ? 1 : 4, width));
+    L.feat_wide = take(b16 && L.first_k != 2 * m->in_pad ? S * (size_t)L.first_k * 2 : 0);
+    L.first = take(b16 ? (size_t)width * L.first_k * sizeof(float) : 0);
     L.total = off;
     return L;
 }
@@ -648,7 +699,7 @@ size_t m360_backward_workspace_bytes(int B, int N, const m360_model_t *model_hos
 }
 
 static int validate_train(const m360_model_t *m, const void *tape, size_t tape_bytes, size_t need, const char *who) {
-    if (m->mlp_bf16) return fail(M360_ERR_INVALID_ARGUMENT, "%s: the training path is fp32 only (mlp_bf16 must be 0)", who);
+    if (m->mlp_bf16 == 2) return fail(M360_ERR_INVALID_ARGUMENT, "%s: the training path takes mlp_bf16 = 0 (fp32) or 1 (bf16); the bf16x3 mode is forward-only", who);
     if (!tape || tape_bytes < need || ((uintptr_t)tape & 255)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "%s: tape %zu < required %zu bytes (or not 256-byte aligned)", who, tape_bytes, need);
     return M360_OK;
 }
@@ -696,6 +747,48 @@ static int mlp_backward(const m360_hyper_t *h, int layers, const float *const *w
     return M360_OK;
 }
 
+// bf16 mode: grad_w[0] = fold of dZ^T [feat_hi | feat_lo]
+__global__ void fold_first_layer_kernel(const float *__restrict__ r, int n_pad, int ld, int in_pad, float *__restrict__ gw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_pad * in_pad) return;
+    const int n = idx / in_pad, k = idx % in_pad;
+    gw[idx] = r[(long)n * ld + k] + r[(long)n * ld + in_pad + k];
+}
+// The same chain in the bf16 mode (round 5): dz, the stored activations and the transposed weights are bf16, every product accumulates in
+// fp32 on the bf16 matrix pipe, the gradients come out in fp32 in the packed [n_pad, k_pad] layouts of the fp32 path (layer 0: [n_pad, in_pad]).
+static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *const *w_t, float *const *grad_w, float *const *grad_b, const void *feat,
+                             int in_pad, void *const *act, int width, long S, void *dz, void *dz_other, char *ws, const BwdLayout &L,
+                             m360_stream_t st, const char *who) {
+    void *gemm_ws = ws + L.gemm;
+    const size_t gemm_bytes = L.finish - L.gemm;
+    for (int l = layers - 1; l >= 0; --l) {
+        if (!grad_w[l] || !grad_b[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: gradient buffer of layer %d is null", who, l);
+        if (l > 0) {
+            M360_PROF(h, st, M360_K_WGRAD, S, width, -width, m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], grad_b[l], gemm_ws, gemm_bytes, st));
+            if (!w_t[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: transposed weight of layer %d is null", who, l);
+            M360_PROF(h, st, M360_K_DGRAD, S, width, -width, m360_linear_dgrad_bf16(dz, S, width, w_t[l], width, width, act[l - 1], dz_other, width, st));
+            void *tmp = dz; dz = dz_other; dz_other = tmp;
+        } else {
+            const void *x0 = feat;
+            int ld0 = 2 * in_pad;
+            hipStream_t hs = reinterpret_cast<hipStream_t>(st);
+            if (L.first_k != 2 * in_pad) {  // zero-padded [S, first_k] copy of the [hi | lo] rows for the 256-column tiles of the MFMA kernel
+                void *wide = ws + L.feat_wide;
+                if (hipMemsetAsync(wide, 0, (size_t)S * L.first_k * 2, hs) != hipSuccess ||
+                    hipMemcpy2DAsync(wide, (size_t)L.first_k * 2, feat, (size_t)2 * in_pad * 2, (size_t)2 * in_pad * 2, (size_t)S, hipMemcpyDeviceToDevice, hs) != hipSuccess)
+                    return fail(M360_ERR_LAUNCH, "%s: widening the feature rows failed: %s", who, hipGetErrorString(hipGetLastError()));
+                x0 = wide;
+                ld0 = L.first_k;
+            }
+            float *r = reinterpret_cast<float *>(ws + L.first);
+            M360_PROF(h, st, M360_K_WGRAD, S, width, -L.first_k, m360_linear_wgrad_bf16(dz, width, x0, ld0, S, width, L.first_k, r, grad_b[0], gemm_ws, gemm_bytes, st));
+            hipLaunchKernelGGL(fold_first_layer_kernel, dim3((unsigned)((width * in_pad + 255) / 256)), dim3(256), 0, hs, r, width, L.first_k, in_pad, grad_w[0]);
+            M360_TRY(check_launch(who));
+        }
+    }
+    return M360_OK;
+}
+
 int m360_prop_backward(const m360_rays_t *rays, const m360_model_t *model, const m360_mlp_transposed_t *wt,
                        const m360_hyper_t *hyper, int B, const void *tape, size_t tape_bytes,
                        const float *grad_w_hat, const m360_mlp_grads_t *grads, void *workspace,
@@ -713,6 +806,12 @@ int m360_prop_backward(const m360_rays_t *rays, const m360_model_t *model, const
     float *act[4];
     for (int l = 0; l < 4; ++l) act[l] = reinterpret_cast<float *>(tp + T.act[l]);
     float *dz = reinterpret_cast<float *>(ws + L.dz_a), *dz2 = reinterpret_cast<float *>(ws + L.dz_b);
+    if (model->mlp_bf16 == 1) {
+        void *actb[4];
+        for (int l = 0; l < 4; ++l) actb[l] = tp + T.act[l];
+        M360_TRY(prop_finish_backward_bf16(actb[3], hp, model->prop_head_w, model->prop_head_b, hp, hyper->density_bias, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, grad_w_hat, dz, grads->head_w, grads->head_b, ws + L.finish, L.feat_wide - L.finish, stream));
+        return mlp_backward_bf16(hyper, 4, wt->w_t, grads->w, grads->b, tp + T.feat, model->in_pad, actb, hp, (long)B * N, dz, dz2, ws, L, stream, "m360_prop_backward");
+    }
     M360_TRY(m360_prop_finish_backward(act[3], hp, model->prop_head_w, model->prop_head_b, hp, hyper->density_bias, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, grad_w_hat, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, stream));
     return mlp_backward(hyper, 4, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hp, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_prop_backward");
 }
@@ -735,6 +834,12 @@ int m360_nerf_backward(const m360_rays_t *rays, const m360_model_t *model, const
     float *act[8];
     for (int l = 0; l < 8; ++l) act[l] = reinterpret_cast<float *>(tp + T.act[l]);
     float *dz = reinterpret_cast<float *>(ws + L.dz_a), *dz2 = reinterpret_cast<float *>(ws + L.dz_b);
+    if (model->mlp_bf16 == 1) {
+        void *actb[8];
+        for (int l = 0; l < 8; ++l) actb[l] = tp + T.act[l];
+        M360_TRY(nerf_finish_backward_bf16(actb[7], hn, model->nerf_head_w, model->nerf_head_b, hn, hyper->density_bias, hyper->rgb_padding, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, hyper->white_bkgd, grad_rgb, grad_distance, grad_acc, grad_weights, dz, grads->head_w, grads->head_b, ws + L.finish, L.feat_wide - L.finish, stream));
+        return mlp_backward_bf16(hyper, 8, wt->w_t, grads->w, grads->b, tp + T.feat, model->in_pad, actb, hn, (long)B * N, dz, dz2, ws, L, stream, "m360_nerf_backward");
+    }
     M360_TRY(m360_nerf_finish_backward(act[7], hn, model->nerf_head_w, model->nerf_head_b, hn, hyper->density_bias, hyper->rgb_padding, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, hyper->white_bkgd, grad_rgb, grad_distance, grad_acc, grad_weights, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, stream));
     return mlp_backward(hyper, 8, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hn, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_nerf_backward");
 }

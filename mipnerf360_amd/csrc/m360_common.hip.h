@@ -87,7 +87,7 @@ __device__ __forceinline__ float linspacef_(float start, float end, int steps, i
 // inverse CDF).  The kernels draw the same KIND of numbers themselves: Philox4x32-10 (Salmon et al., SC'11 - the generator behind
 // torch's own device RNG), key = the torch generator's seed, counter = (generator offset / 4 as 64 bits, element index, stream id), so
 // a value is a pure function of (seed, offset, stream, element): the prologue can draw a ray's jitter once for t and again for the
-// norm's partial sums, a test can dump exactly the uniforms a launch used (m360_philox_uniform) and replay them through the oracle,
+// norm's partial sums, a test can dump exactly the uniforms a launch used (m360_philox_uniform) and replay them through the CPU restatement of the path,
 // and the same seed gives the same bits.  The host advances the generator's offset by 4 per call, so no later torch kernel (whose
 // counters start at its own offset / 4) ever reuses a counter.  Stream ids: 0 = t_rand (jitter), 1 = u_rand (inverse CDF).
 struct rng_t {

@@ -32,6 +32,7 @@
 #define M360_W16_MIN_K 256  // narrowest contraction the bf16 hidden layers hand to the one-wave ring kernel
 #endif
 #include "m360_linear_tn.hip.h"
+#include "m360_linear_tn_bf16.hip.h"
 #ifdef M360_DIAG  // diagnostics build only: stamped twins of the product kernels + the two bf16 structures that lost the A/B
 #include "diag/m360_diag.h"
 #include "diag/m360_linear_bf16_sp.hip.h"
@@ -899,6 +900,93 @@ int m360_linear_bf16_split(const void *x, long M, int ldx, const void *w_packed,
         else hipLaunchKernelGGL((pbf16::linear_bf16_mfma_simple_kernel<M360_ACT_NONE, false, true>), grid, block, 0, st, xt, Mt, ldx, wb, b_packed, n_pad, k_pad, yt, ldy);
     }
     return check_launch("linear_bf16_split");
+}
+
+// ---- bf16 training path (round 5): transposed bf16 packing, input gradient, weight gradient
+int m360_pack_linear_bf16_transposed(const float *w, int n_out, int k_in, int n_pad, int k_pad, void *wt_packed_bf16, m360_stream_t stream) {
+    if (!w || !wt_packed_bf16 || n_out < 1 || k_in < 1 || n_pad < n_out || k_pad < k_in || n_pad % 64 != 0)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_pack_linear_bf16_transposed: bad argument (n_out=%d k_in=%d n_pad=%d k_pad=%d; n_pad - the contraction of the input gradient - must be a multiple of 64)", n_out, k_in, n_pad, k_pad);
+    const long n = (long)n_pad * k_pad;
+    hipLaunchKernelGGL(tn16::pack_linear_bf16_t_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, n_out, k_in, n_pad, k_pad, static_cast<__bf16 *>(wt_packed_bf16));
+    return check_launch("pack_linear_bf16_transposed");
+}
+
+int m360_linear_dgrad_bf16(const void *dz, long M, int ldz, const void *wt_packed_bf16, int k_pad, int n_pad, const void *relu_out,
+                           void *dx, int ldx, m360_stream_t stream) {
+    // dX[M, k_pad] = dZ[M, n_pad] * W[n_pad, k_pad] in bf16 with fp32 accumulation: the forward layer kernel (m360_linear_bf16, act none,
+    // zero bias) on the transposed packing wt[k_pad][n_pad]; then, where relu_out (the forward OUTPUT of the layer below, bf16, leading
+    // dimension ldx) is <= 0, the row's entry is cleared (ReLU').  The mask is a pass of its own here: the forward kernels' epilogues
+    // are counted-wait schedules that a load in the epilogue would stall
+    if (!dz || !wt_packed_bf16 || !dx || M < 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_dgrad_bf16: null pointer or negative M");
+    if (k_pad > kZeroBias || k_pad % 8 != 0 || ldx < k_pad || ldx % 8 != 0) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_dgrad_bf16: k_pad=%d (<= %d, a multiple of 8), ldx=%d", k_pad, kZeroBias, ldx);
+    float *zero_bias = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void **>(&zero_bias), HIP_SYMBOL(g_zero_bias)) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_linear_dgrad_bf16: zero bias symbol not found");
+    const int rc = m360_linear_bf16(dz, M, ldz, wt_packed_bf16, zero_bias, k_pad, n_pad, M360_ACT_NONE, dx, ldx, stream);
+    if (rc != M360_OK || !relu_out || M == 0) return rc;
+    if (((uintptr_t)relu_out | (uintptr_t)dx) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_dgrad_bf16: relu_out / dx must be 16-byte aligned");
+    const long n = M * (k_pad / 8);
+    hipLaunchKernelGGL(tn16::relu_mask_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<__bf16 *>(dx), static_cast<const __bf16 *>(relu_out), M, k_pad, ldx);
+    return check_launch("linear_dgrad_bf16 (ReLU mask)");
+}
+
+static bool wgrad_bf16_on_mfma(long M, int n_pad, int k_pad, int ldz, int ldx) {
+    return n_pad % tn16::BT == 0 && k_pad % tn16::BT == 0 && ldz % 8 == 0 && ldx % 8 == 0 && M >= tn16::BKM;
+}
+static void wgrad_bf16_plan(long M, int n_pad, int k_pad, int *ntiles, int *nsplit, long *total_steps, long *steps_per_split) {
+    *ntiles = (n_pad / tn16::BT) * (k_pad / tn16::BT);
+    *total_steps = M / tn16::BKM;
+    long ns = tn16::kMaxWorkgroups / *ntiles;
+    if (ns < 1) ns = 1;
+    if (ns > *total_steps) ns = *total_steps;
+    *nsplit = (int)ns;
+    *steps_per_split = ns > 0 ? (*total_steps + ns - 1) / ns : 0;
+}
+
+size_t m360_linear_wgrad_bf16_workspace_bytes(long M, int n_pad, int k_pad) {
+    if (M < 0 || n_pad < 1 || k_pad < 1) return 0;
+    if (wgrad_bf16_on_mfma(M, n_pad, k_pad, 8, 8)) {
+        int ntiles, nsplit;
+        long total, per;
+        wgrad_bf16_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
+        return up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)) + up256_((size_t)tn16::kMaxWorkgroups * n_pad * sizeof(float));
+    }
+    // other shapes: both operands widened to fp32 for the fp32 kernel
+    return up256_((size_t)M * n_pad * sizeof(float)) + up256_((size_t)M * k_pad * sizeof(float)) + m360_linear_wgrad_workspace_bytes(M, n_pad, k_pad);
+}
+
+int m360_linear_wgrad_bf16(const void *dz, int ldz, const void *x, int ldx, long M, int n_pad, int k_pad, float *grad_w, float *grad_b,
+                           void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    if (!dz || !x || !grad_w || M < 0 || n_pad < 32 || k_pad < 32 || n_pad % 32 || k_pad % 32 || ldz < n_pad || ldx < k_pad)
+        return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_wgrad_bf16: bad argument (M=%ld n_pad=%d k_pad=%d ldz=%d ldx=%d)", M, n_pad, k_pad, ldz, ldx);
+    const size_t need = m360_linear_wgrad_bf16_workspace_bytes(M, n_pad, k_pad);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_linear_wgrad_bf16: workspace %zu < %zu bytes (or not 256-byte aligned)", workspace_bytes, need);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const __bf16 *dzb = static_cast<const __bf16 *>(dz), *xb = static_cast<const __bf16 *>(x);
+    if (wgrad_bf16_on_mfma(M, n_pad, k_pad, ldz, ldx) && !(((uintptr_t)dz | (uintptr_t)x | (uintptr_t)grad_w) & 15)) {
+        int ntiles, nsplit;
+        long total, per;
+        wgrad_bf16_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
+        float *partial = static_cast<float *>(workspace);
+        float *bias_part = reinterpret_cast<float *>(static_cast<char *>(workspace) + up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)));
+        hipLaunchKernelGGL(tn16::linear_tn_bf16_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn16::kThreads), 0, st, dzb, ldz, xb, ldx, n_pad, k_pad, partial, k_pad / tn16::BT, ntiles, nsplit, total, per, grad_b ? bias_part : nullptr);
+        const long count4 = (long)n_pad * k_pad / 4;
+        hipLaunchKernelGGL(tn16::tn16_reduce_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, partial, nsplit, n_pad, k_pad, dzb, ldz, xb, ldx, total * tn16::BKM, M, grad_w);
+        if (grad_b) hipLaunchKernelGGL(tn16::tn16_bias_reduce_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, bias_part, nsplit, n_pad, dzb, ldz, total * tn16::BKM, M, grad_b);
+        return check_launch("linear_wgrad_bf16");
+    }
+    if (M == 0) {
+        if (hipMemsetAsync(grad_w, 0, (size_t)n_pad * k_pad * sizeof(float), st) != hipSuccess || (grad_b && hipMemsetAsync(grad_b, 0, (size_t)n_pad * sizeof(float), st) != hipSuccess))
+            return fail(M360_ERR_LAUNCH, "m360_linear_wgrad_bf16: memset failed");
+        return M360_OK;
+    }
+    float *dzf = static_cast<float *>(workspace);
+    float *xf = reinterpret_cast<float *>(static_cast<char *>(workspace) + up256_((size_t)M * n_pad * sizeof(float)));
+    char *rest = reinterpret_cast<char *>(xf) + up256_((size_t)M * k_pad * sizeof(float));
+    hipLaunchKernelGGL(tn16::widen_bf16_kernel, dim3((unsigned)((M * n_pad + 255) / 256)), dim3(256), 0, st, dzb, M, n_pad, ldz, dzf);
+    hipLaunchKernelGGL(tn16::widen_bf16_kernel, dim3((unsigned)((M * k_pad + 255) / 256)), dim3(256), 0, st, xb, M, k_pad, ldx, xf);
+    const int rc = check_launch("linear_wgrad_bf16 (widen)");
+    if (rc != M360_OK) return rc;
+    return m360_linear_wgrad(dzf, n_pad, xf, k_pad, M, n_pad, k_pad, grad_w, grad_b, rest, workspace_bytes - (size_t)(rest - static_cast<char *>(workspace)), stream);
 }
 
 int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed3,

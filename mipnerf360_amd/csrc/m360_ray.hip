@@ -657,13 +657,30 @@ __global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
 //            and the chain through softplus / sigmoid / rgb padding -> d raw[N][H]
 //   phase 3  dz[s,:] = (sum_h d raw[s,h] head_w[h,:]) * a(1 - a)  (a = sigmoid output of the last hidden layer),
 //            per-ray partial sums of d head_w[h,:] = sum_s d raw[s,h] a[s,:] and d head_b (reduced later, fixed order)
-template <int H>
+// T = float, or __bf16 (the bf16 training path, round 5): the stored activations are read and dz is written in T, everything in between is fp32
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+    static __device__ __forceinline__ float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void store(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct Quad<__bf16> {
+    typedef __bf16 bf16x4_q __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ float4 load(const __bf16 *p) {
+        const bf16x4_q v = *reinterpret_cast<const bf16x4_q *>(p);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+    static __device__ __forceinline__ void store(__bf16 *p, float4 v) {
+        const bf16x4_q o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<bf16x4_q *>(p) = o;
+    }
+};
+template <int H, typename T = float>
 __global__ __launch_bounds__(kFinishThreads) void finish_backward_kernel(
-    const float *__restrict__ act, int ld, const float *__restrict__ head_w, const float *__restrict__ head_b,
+    const T *__restrict__ act, int ld, const float *__restrict__ head_w, const float *__restrict__ head_b,
     int k_pad, float density_bias, float rgb_padding, const float *__restrict__ t_vals,
     const float *__restrict__ dirs, int N, int white_bkgd, const float *__restrict__ g_rgb,
     const float *__restrict__ g_dist, const float *__restrict__ g_acc, const float *__restrict__ g_w,
-    float *__restrict__ dz, float *__restrict__ part_hw /*[B*groups][H*k_pad]*/,
+    T *__restrict__ dz, float *__restrict__ part_hw /*[B*groups][H*k_pad]*/,
     float *__restrict__ part_hb /*[B][H]*/, int groups) {
     extern __shared__ float smem[];
     const int b = blockIdx.x, l = lane_id();
@@ -673,8 +690,8 @@ __global__ __launch_bounds__(kFinishThreads) void finish_backward_kernel(
     for (int i = threadIdx.x; i < H * k_pad; i += blockDim.x) hw[i] = head_w[i];
     for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
     __syncthreads();
-    const float *act_ray = act + (long)b * N * ld;
-    head_dots<H, float>(act_ray, ld, hw, head_b, k_pad, N, raw);
+    const T *act_ray = act + (long)b * N * ld;
+    head_dots<H, T>(act_ray, ld, hw, head_b, k_pad, N, raw);
     __syncthreads();
     if (threadIdx.x < kWave) {
         const float dnorm = dir_norm(dirs, b);
@@ -778,7 +795,7 @@ __global__ __launch_bounds__(kFinishThreads) void finish_backward_kernel(
     const int per = kc < (int)blockDim.x ? kc : (int)blockDim.x;  // threads per group
     const int group = threadIdx.x / per, tc = threadIdx.x % per;
     if (group >= groups) return;
-    float *__restrict__ dz_ray = dz + (long)b * N * ld;
+    T *__restrict__ dz_ray = dz + (long)b * N * ld;
     for (int c = tc; c < kc; c += per) {
         float4 hwc[H], accw[H];
 #pragma unroll
@@ -787,7 +804,7 @@ __global__ __launch_bounds__(kFinishThreads) void finish_backward_kernel(
             accw[hh] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         for (int n = group; n < N; n += groups) {
-            const float4 a = *reinterpret_cast<const float4 *>(act_ray + (long)n * ld + 4 * c);
+            const float4 a = Quad<T>::load(act_ray + (long)n * ld + 4 * c);
             float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
             for (int hh = 0; hh < H; ++hh) {
@@ -805,7 +822,7 @@ __global__ __launch_bounds__(kFinishThreads) void finish_backward_kernel(
             d.y *= a.y * (1.0f - a.y);
             d.z *= a.z * (1.0f - a.z);
             d.w *= a.w * (1.0f - a.w);
-            *reinterpret_cast<float4 *>(dz_ray + (long)n * ld + 4 * c) = d;
+            Quad<T>::store(dz_ray + (long)n * ld + 4 * c, d);
         }
 #pragma unroll
         for (int hh = 0; hh < H; ++hh)
@@ -898,7 +915,7 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
                            float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                            int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
                            m360_stream_t stream, const float *head_part = nullptr, long fused_rows = 0, int slots = 0,
-                           const unsigned char *nanflag = nullptr);
+                           const unsigned char *nanflag = nullptr, const rng_t &rng = rng_t{0, 0, 0});
 
 int m360_prop_finish_n(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
                        float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
@@ -926,7 +943,7 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
                            float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                            int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
                            m360_stream_t stream, const float *head_part, long fused_rows, int slots, const unsigned char *nanflag,
-                           const rng_t &rng = rng_t{0, 0, 0}) {
+                           const rng_t &rng) {
     if (num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: num_out=%d", num_out);
     const int align = bf16 ? 8 : 4;
     if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < (bf16 == 2 ? 2 * k_pad : k_pad) || ld % align != 0)
@@ -1026,13 +1043,14 @@ size_t m360_finish_backward_workspace_bytes(int B, int heads, int k_pad) {
 }
 
 extern "C++" {
-template <int H>
-static int finish_backward_any(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
+template <int H, typename T = float>
+static int finish_backward_any(const T *act, int ld, const float *head_w, const float *head_b, int k_pad,
                                float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
                                int N, int white_bkgd, const float *g_rgb, const float *g_dist, const float *g_acc,
-                               const float *g_w, float *dz, float *grad_head_w, float *grad_head_b, void *workspace,
+                               const float *g_w, T *dz, float *grad_head_w, float *grad_head_b, void *workspace,
                                size_t workspace_bytes, m360_stream_t stream, const char *who) {
-    if (!act || !head_w || !head_b || !t_vals || !dirs || !dz || !grad_head_w || !grad_head_b || B < 0 || N < 1 || k_pad < 4 || k_pad % 4 || ld < k_pad || ld % 4)
+    constexpr int kAlign = sizeof(T) == 2 ? 8 : 4;  // bf16 rows are read in 16-byte chunks by head_dots
+    if (!act || !head_w || !head_b || !t_vals || !dirs || !dz || !grad_head_w || !grad_head_b || B < 0 || N < 1 || k_pad < kAlign || k_pad % kAlign || ld < k_pad || ld % kAlign)
         return fail(M360_ERR_INVALID_ARGUMENT, "%s: bad argument", who);
     if (B == 0) return M360_OK;
     const size_t need = m360_finish_backward_workspace_bytes(B, H, k_pad);
@@ -1044,7 +1062,7 @@ static int finish_backward_any(const float *act, int ld, const float *head_w, co
     float *part_hw = reinterpret_cast<float *>(ws);
     float *part_hb = reinterpret_cast<float *>(ws + fb_up((size_t)B * groups * C * sizeof(float)));
     float *slices = reinterpret_cast<float *>(reinterpret_cast<char *>(part_hb) + fb_up((size_t)B * H * sizeof(float)));
-    hipLaunchKernelGGL(finish_backward_kernel<H>, dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, g_rgb, g_dist, g_acc, g_w, dz, part_hw, part_hb, groups);
+    hipLaunchKernelGGL((finish_backward_kernel<H, T>), dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, g_rgb, g_dist, g_acc, g_w, dz, part_hw, part_hb, groups);
     const int rc = check_launch(who);
     if (rc != M360_OK) return rc;
     M360_RAY_TRY(launch_colsum(part_hw, (long)B * groups, C, C, slices, kFinishSlices, grad_head_w, S_(stream)));
@@ -1071,6 +1089,21 @@ int m360_nerf_finish_backward(const float *act, int ld, const float *head_w, con
 }  // extern "C"
 
 namespace m360 {
+// bf16 training path (m360_capi.hip): the finishers' backward on bf16 activations, dz written in bf16
+int prop_finish_backward_bf16(const void *act, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, const float *t_vals,
+                              const float *dirs, int B, int N, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b,
+                              void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+    if (!grad_weights) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_backward: grad_w_hat is required");
+    return finish_backward_any<1, __bf16>(static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, 0.0f, t_vals, dirs, B, N, 0, nullptr, nullptr, nullptr, grad_weights,
+                                          static_cast<__bf16 *>(dz), grad_head_w, grad_head_b, workspace, workspace_bytes, stream, "m360_prop_backward (bf16 finisher)");
+}
+int nerf_finish_backward_bf16(const void *act, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, float rgb_padding,
+                              const float *t_vals, const float *dirs, int B, int N, int white_bkgd, const float *grad_rgb, const float *grad_distance,
+                              const float *grad_acc, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b, void *workspace,
+                              size_t workspace_bytes, m360_stream_t stream) {
+    return finish_backward_any<4, __bf16>(static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, grad_rgb, grad_distance,
+                                          grad_acc, grad_weights, static_cast<__bf16 *>(dz), grad_head_w, grad_head_b, workspace, workspace_bytes, stream, "m360_nerf_backward (bf16 finisher)");
+}
 // Stage drivers only (m360_capi.hip; not part of the C-ABI): the fused finishers with the encoder's per-sample NaN flags (bf16 / bf16x3
 // modes; NULL = none) - and, for the NeRF stage, the t_vals + 1e-6 / s_vals outputs of m360_nerf_finish_outputs.
 int prop_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,

@@ -204,9 +204,10 @@ def _mutable_field(rays, name):
 
 
 def _wants_grad(module: nn.Module) -> bool:
-    """Tape-keeping differentiable forward?  Only the fp32 MLP is trainable: a model built with mlp_dtype='bf16' is
-    forward-only (its outputs never carry a graph)."""
-    if getattr(module, "mlp_bf16", 0) or getattr(module, "mlp_dtype", "fp32") != "fp32":
+    """Tape-keeping differentiable forward?  The fp32 and (round 5) the bf16 MLP are trainable - in bf16 the tape holds bf16 layer
+    outputs, dz travels in bf16, products accumulate in fp32 and the parameter gradients come out in fp32 (fp32 master weights, the
+    optimizer is untouched); a model built with mlp_dtype='bf16x3' is forward-only (its outputs never carry a graph)."""
+    if getattr(module, "mlp_bf16", 0) == 2 or getattr(module, "mlp_dtype", "fp32") == "bf16x3":
         return False
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
@@ -227,8 +228,11 @@ class _TrainCtx:
                                 device=dev)
         layers, _ = module._layers()
         # transposed packings for the input-gradient GEMMs (layer 0 needs none), made from the same parameter
-        # versions as the forward packing
-        self.w_t = [None] + [ops.pack_linear_transposed(lin.weight, packed.h_pad, packed.h_pad) for lin in layers[1:]]
+        # versions as the forward packing (bf16 mode: bf16 transposes for m360_linear_dgrad_bf16)
+        self.bf16 = int(getattr(packed, "bf16", 0))
+        pack_t = ops.pack_linear_bf16_transposed if self.bf16 else ops.pack_linear_transposed
+        self.w_t = [None] + [pack_t(lin.weight, packed.h_pad, packed.h_pad) for lin in layers[1:]]
+        self.in_pad = packed.in_pad
         self.versions = [p._version for p in module.parameters()]
 
     def backward(self, grad_args):
@@ -244,8 +248,9 @@ class _TrainCtx:
         lib = _lib.lib()
         layers, heads = module._layers()
         L, H = len(layers), sum(h.out_features for h in heads)
-        gw = [torch.empty_like(w) for w in self.packed_keep[0]]
-        gb = [torch.empty_like(b) for b in self.packed_keep[1]]
+        # fp32 gradients in the packed [n_pad, k_pad] layouts of the fp32 path, whatever the forward's precision (layer 0: [n_pad, in_pad])
+        gw = [torch.empty(self.h_pad, self.in_pad if i == 0 else self.h_pad, device=dev) for i in range(L)]
+        gb = [torch.empty(self.h_pad, device=dev) for _ in range(L)]
         ghw, ghb = torch.empty(H, self.h_pad, device=dev), torch.empty(H, device=dev)
         gstruct, tstruct = _lib.MlpGradsStruct(), _lib.MlpTransposedStruct()
         for i in range(L):

@@ -335,6 +335,46 @@ def linear_wgrad(dz, x, want_bias: bool = True):
     return gw, gb
 
 
+def pack_linear_bf16_transposed(weight, n_pad: Optional[int] = None, k_pad: Optional[int] = None) -> torch.Tensor:
+    """[n_out,k_in] fp32 weight -> zero-padded bf16 transpose [k_pad,n_pad] (the operand of linear_dgrad_bf16)."""
+    weight = dev(weight.detach(), "weight")
+    n_out, k_in = weight.shape
+    n_pad, k_pad = n_pad or round_up(n_out, 64), k_pad or round_up(k_in, 64)
+    wt = torch.empty(k_pad, n_pad, device=weight.device, dtype=torch.bfloat16)
+    _call("m360_pack_linear_bf16_transposed", weight, n_out, k_in, n_pad, k_pad, wt, STREAM)
+    return wt
+
+
+def linear_dgrad_bf16(dz, wt_packed, relu_out=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 dx = dz @ W (cleared where relu_out <= 0), W given as its packed bf16 transpose [k_pad,n_pad] (m360_linear_dgrad_bf16)."""
+    dz, wt_packed = dev_bf16(dz, "dz"), dev_bf16(wt_packed, "wt_packed")
+    M, n_pad = dz.shape
+    k_pad = wt_packed.shape[0]
+    if wt_packed.shape[1] != n_pad:
+        raise RuntimeError(f"linear_dgrad_bf16: dz has {n_pad} columns, packed transpose expects {wt_packed.shape[1]}")
+    dx = out if out is not None else torch.empty(M, k_pad, device=dz.device, dtype=torch.bfloat16)
+    if relu_out is not None:
+        relu_out = dev_bf16(relu_out, "relu_out")
+        if tuple(relu_out.shape) != (M, dx.shape[1]):
+            raise RuntimeError("linear_dgrad_bf16: relu_out must have the shape of dx")
+    _call("m360_linear_dgrad_bf16", dz, M, n_pad, wt_packed, k_pad, n_pad, relu_out, dx, dx.shape[1], STREAM)
+    return dx
+
+
+def linear_wgrad_bf16(dz, x, want_bias: bool = True):
+    """bf16 rows -> fp32 (grad_w[n_pad,k_pad] = dz^T @ x, grad_b[n_pad] = dz.sum(0) or None) (m360_linear_wgrad_bf16)"""
+    dz, x = dev_bf16(dz, "dz"), dev_bf16(x, "x")
+    M, n_pad = dz.shape
+    if x.shape[0] != M:
+        raise RuntimeError("linear_wgrad_bf16: dz and x need the same number of rows")
+    k_pad = x.shape[1]
+    gw = torch.empty(n_pad, k_pad, device=dz.device)
+    gb = torch.empty(n_pad, device=dz.device) if want_bias else None
+    ws = torch.empty(max(int(_lib.lib().m360_linear_wgrad_bf16_workspace_bytes(M, n_pad, k_pad)), 256), dtype=torch.uint8, device=dz.device)
+    _call("m360_linear_wgrad_bf16", dz, n_pad, x, k_pad, M, n_pad, k_pad, gw, gb, ws, ws.numel(), STREAM)
+    return gw, gb
+
+
 def dev_bf16(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
     _require_device(t, name)
     if t.dtype != torch.bfloat16:

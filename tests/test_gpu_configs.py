@@ -427,7 +427,7 @@ def test_bench_default_line_carries_every_single_gpu_config(dev):
     fr = line["strong_scaling_frame"]
     assert fr["finite"] and "64 proposal + 128 NeRF" in fr["samples_per_ray"] and fr["flops_per_ray"] == 423424 * 64 + 14807040 * 128
     nw = line["named_workloads"]
-    assert set(nw) >= {"c5_bf16", "c2_bf16", "c2_bf16x3", "c2_training_iteration", "c3_frame_64+128", "seconds"}
+    assert set(nw) >= {"c5_bf16", "c2_bf16", "c2_bf16x3", "c2_training_iteration", "c2_training_iteration_bf16", "c3_frame_64+128", "seconds"}
     assert nw["c5_bf16"]["dtype"] == "bf16" and nw["c5_bf16"]["config"] == "c5" and "8192 rays x 256 samples" in nw["c5_bf16"]["workload"]
     assert nw["c2_bf16"]["dtype"] == "bf16" and nw["c2_bf16x3"]["dtype"] == "bf16x3"
     for k in ("c5_bf16", "c2_bf16", "c2_bf16x3"):
@@ -435,4 +435,8 @@ def test_bench_default_line_carries_every_single_gpu_config(dev):
     assert nw["c2_bf16"]["rays_per_s"] > 3 * line["value"] and nw["c2_bf16x3"]["rays_per_s"] > 2 * line["value"]
     tr = nw["c2_training_iteration"]
     assert tr["dtype"] == "f32" and 100 < tr["iteration_ms"] < 1000 and tr["wgrad_1024x1024"]["frac"] > 0.7 and tr["dgrad_1024x1024"]["frac"] > 0.7
-    assert nw["seconds"] < 30
+    tb = nw["c2_training_iteration_bf16"]   # round 5: row f3 in the precision configs[4] runs at
+    assert tb["dtype"] == "bf16" and tb["finite"] and tb["iteration_ms"] < 0.5 * tr["iteration_ms"] and tb["wgrad_1024x1024"]["frac"] > 0.15
+    for k in ("c5_bf16", "c2_bf16"):        # the layer chain's self-checks, in the record
+        assert nw[k]["chain"]["launches"] > 0 and nw[k]["chain"]["chain_error"] is False
+    assert nw["seconds"] < 40

@@ -1896,9 +1896,9 @@ def test_training_bf16_is_forward_only_and_inplace_update_is_caught(golden, dev)
     w2.sum().backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second time"):
         w2.sum().backward()
-    m16 = mipNeRF360(num_samples=16, hidden_proposal=64, hidden_nerf=64, device=dev, mlp_dtype="bf16").train()
-    t16, w16 = m16.prop_net.forward(rays)      # the bf16 MLP is forward-only: no graph, so backward is an error
-    assert not w16.requires_grad
+    m16 = mipNeRF360(num_samples=16, hidden_proposal=64, hidden_nerf=64, device=dev, mlp_dtype="bf16x3").train()
+    t16, w16 = m16.prop_net.forward(rays)      # the bf16x3 MLP is forward-only: no graph, so backward is an error
+    assert not w16.requires_grad               # (bf16 trains since round 5: tests/test_gpu_train_bf16.py)
     with pytest.raises(RuntimeError):
         w16.sum().backward()
 

@@ -1,0 +1,223 @@
+"""GPU tests (`-m gpu`) of TRAINING in the bf16 mode (round 5; SURVEY.md §8 row f3 in the precision BASELINE configs[4] runs at): the
+reference's loop body (train.py:53-82) on the mirrors with mlp_dtype="bf16" - tape-keeping bf16 forwards, dz in bf16, the input gradient
+through the forward layer kernel on a transposed bf16 packing, the weight gradient on v_mfma_f32_16x16x32_bf16 with both operands
+transposed out of the LDS (ds_read_b64_tr_b16), fp32 accumulation, fp32 gradients and master weights.
+
+Gradients are held against the REFERENCE's own gradients (fixtures G13 / G21: its autograd in fp32 and fp64).  bf16 carries 8
+significant bits, so the bound is relative to each tensor's scale and stated where it is used; what it is derived from - the error of
+the bf16 FORWARD on the same weights - is printed beside it.
+"""
+import numpy as np
+import pytest
+import torch
+from conftest import g21_case
+
+from mipnerf360_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test needs a HIP device")
+    return torch.device("cuda:0")
+
+
+def H(t):
+    return t.detach().float().cpu().numpy()
+
+
+def D(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).float().to(dev)
+
+
+def dev_rays(d, dev):
+    from mipnerf360_amd.intern.ray import Rays
+    return Rays(*[D(d[k], dev) for k in synthetic.RAY_FIELDS])
+
+
+@pytest.mark.parametrize("M,n,k", [(4096 + 37, 256, 256), (65536, 1024, 256), (32768 + 64, 256, 1024), (700, 64, 128), (64, 256, 256), (50, 256, 256)])
+def test_linear_wgrad_bf16_against_fp64(dev, M, n, k):
+    """dW = dZ^T X, db = column sums of dZ from bf16 rows: the MFMA kernel (pads of 256; ragged tail rows, a single stage, fewer rows than a
+    stage) and the widening fall-back (other pads) against fp64 products of the SAME bf16 values - only the fp32 summation order differs;
+    twice the same bits (row splits are reduced in a fixed order)."""
+    from mipnerf360_amd import ops
+    g = torch.Generator().manual_seed(M + n + k)
+    dz = (torch.randn(M, n, generator=g) * torch.rand(M, 1, generator=g)).to(dev).bfloat16()
+    x = torch.relu(torch.randn(M, k, generator=g)).to(dev).bfloat16()
+    gw, gb = ops.linear_wgrad_bf16(dz, x)
+    ref_w = dz.double().t() @ x.double()
+    ref_b = dz.double().sum(0)
+    scale_w, scale_b = float(ref_w.abs().max()), float(ref_b.abs().max())
+    assert float((gw.double() - ref_w).abs().max()) <= 2e-5 * scale_w, (float((gw.double() - ref_w).abs().max()), scale_w)
+    assert float((gb.double() - ref_b).abs().max()) <= 2e-5 * scale_b
+    gw2, gb2 = ops.linear_wgrad_bf16(dz, x)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    gw3, none = ops.linear_wgrad_bf16(dz, x, want_bias=False)
+    assert none is None and torch.equal(gw3, gw)
+
+
+@pytest.mark.parametrize("M,n,k,mask", [(512, 256, 256, True), (300, 64, 128, True), (256 * 3 + 5, 1024, 256, True), (131072, 1024, 1024, True),
+                                        (512, 256, 256, False)])
+def test_linear_dgrad_bf16_against_fp64(dev, M, n, k, mask):
+    """dx = (dz W) * [relu_out > 0] in bf16: the forward layer kernels on the transposed bf16 packing, then the mask - against fp64 on the
+    bf16-rounded operands, within one bf16 rounding of the result."""
+    from mipnerf360_amd import ops
+    g = torch.Generator().manual_seed(M * 3 + n + k)
+    n_out, k_in = n - 3, k - 5
+    w = (torch.randn(n_out, k_in, generator=g) / np.sqrt(n_out)).to(dev)
+    dz = torch.randn(M, n, generator=g).to(dev)
+    dz[:, n_out:] = 0
+    dz = dz.bfloat16()
+    relu_out = torch.relu(torch.randn(M, k, generator=g)).to(dev).bfloat16() if mask else None
+    wt = ops.pack_linear_bf16_transposed(w, n_pad=n, k_pad=k)
+    assert torch.equal(wt[:k_in, :n_out], w.t().bfloat16()) and float(wt[k_in:].float().abs().sum()) == 0 and float(wt[:, n_out:].float().abs().sum()) == 0
+    dx = ops.linear_dgrad_bf16(dz, wt, relu_out)
+    ref = dz.double() @ wt.double().t()
+    if mask:
+        ref = ref * (relu_out > 0)
+    err = (dx.double() - ref).abs()
+    assert float((err - (2.0 ** -8) * ref.abs()).max()) <= 1e-3 * float(ref.abs().max()), float(err.max())
+    if mask:
+        assert float(dx.float()[relu_out <= 0].abs().sum()) == 0.0
+
+
+def _rel(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    return float(np.abs(H(got).astype(np.float64) - want).max()) / max(float(np.abs(want).max()), 1e-30)
+
+
+def _cos(pairs):
+    a = np.concatenate([H(g).ravel().astype(np.float64) for g, _ in pairs])
+    b = np.concatenate([np.asarray(w, dtype=np.float64).ravel() for _, w in pairs])
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+
+
+def _bf16_model(sd, dev, n, hp_, hn_, wb):
+    from mipnerf360_amd.model import mipNeRF360
+    m = mipNeRF360(randomized=False, num_samples=n, hidden_proposal=hp_, hidden_nerf=hn_, white_bkgd=wb, device=dev, mlp_dtype="bf16")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.train()
+
+
+# bounds on a gradient tensor's max |error| relative to the tensor's max |value|, and on the direction of the whole gradient:
+# the bf16 forward of these models is 2-6e-3 from the fp32 one on its outputs (printed below); a gradient is a sum of products of two
+# such quantities per sample (activation x dz, each with 2^-9 relative rounding) - NeRF step: 3e-2; the proposal loss divides by weights
+# down to 1e-6 (test_g13_train_step_gradients: 2.5 x the tolerance already in fp32): 8e-2
+NERF_REL, PROP_REL, COS_MIN = 3e-2, 8e-2, 0.999
+
+
+@pytest.mark.parametrize("kind", ["lego", "garden"])
+def test_g13_train_step_gradients_bf16(golden, dev, kind):
+    """Fixture G13 (every parameter gradient of the reference's loop body, reduced width 32 / 64 -> the widening weight-gradient path):
+    the bf16 mirrors against the reference's fp32 autograd."""
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
+    g = golden("g13_train_gradients")
+    B, n, wb = (int(v) for v in g[f"{kind}_cfg"])
+    sd = {k[3:]: g[k] for k in g if k.startswith("sd.")}
+    model = _bf16_model(sd, dev, n, 32, 64, bool(wb))
+    rays = dev_rays({f: g[f"{kind}_rays_{f}"] for f in synthetic.RAY_FIELDS}, dev)
+    t_hat, w_hat = model.prop_net.forward(rays)
+    assert w_hat.requires_grad
+    _, _, _, t, w, _ = model.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    loss_prop = Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
+    model.zero_grad()
+    loss_prop.backward()
+    pairs = [(p.grad, g[f"{kind}_propstep.{name}"]) for name, p in model.named_parameters() if name.startswith("prop_net")]
+    rel_p = max(_rel(a, b) for a, b in pairs)
+    cos_p = _cos(pairs)
+    t_hat, w_hat = model.prop_net.forward(rays)
+    rgb, _, _, _, fine_w, s_vals = model.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+    loss_nerf, _ = Loss_nerf(input=rgb, target=D(g[f"{kind}_pixels"], dev))
+    loss_dist = Loss_dist(s_vals=s_vals, weights=fine_w)
+    model.zero_grad()
+    (loss_nerf + 0.01 * loss_dist).backward()
+    pairs = [(p.grad, g[f"{kind}_nerfstep.{name}"]) for name, p in model.named_parameters() if name.startswith("nerf_net")]
+    rel_n = max(_rel(a, b) for a, b in pairs)
+    cos_n = _cos(pairs)
+    print(f"G13 bf16 {kind}: proposal step max rel {rel_p:.2e} cos {cos_p:.6f} | NeRF step max rel {rel_n:.2e} cos {cos_n:.6f} | loss_nerf {float(loss_nerf):.5f} vs {float(g[kind + '_loss_nerf']):.5f}")
+    assert rel_n <= NERF_REL and cos_n >= COS_MIN, (rel_n, cos_n)
+    assert rel_p <= PROP_REL and cos_p >= COS_MIN, (rel_p, cos_p)
+    assert abs(float(loss_nerf) - float(g[f"{kind}_loss_nerf"])) <= 2e-2 * abs(float(g[f"{kind}_loss_nerf"]))
+
+
+@pytest.mark.parametrize("kind", ["lego", "mixed"])
+def test_g21_structured_gradients_bf16(golden, dev, kind):
+    """Fixture G21 (trained-like weights: density shells, spread colours): the bf16 gradients against the reference's fp64 gradients.
+    The reference's own fp32 run is up to 1 % of a tensor's scale from its fp64 run on the proposal step here (ill-conditioned loss);
+    bf16 gets the bounds above, and its direction - what the optimiser uses - must agree to 0.999."""
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
+    g = golden("g21_structured_gradients")
+    (B, n, wb, hp_, hn_), r, sd, pixels = g21_case(g, kind)
+    model = _bf16_model(sd, dev, n, hp_, hn_, wb)
+    rays = dev_rays(r, dev)
+    t_hat, w_hat = model.prop_net.forward(rays)
+    _, _, _, t, w, _ = model.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    loss_prop = Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
+    model.zero_grad()
+    loss_prop.backward()
+    pairs = [(p.grad, g[f"{kind}_propstep64.{name}"]) for name, p in model.named_parameters() if name.startswith("prop_net")]
+    rel_p, cos_p = max(_rel(a, b) for a, b in pairs), _cos(pairs)
+    model.zero_grad()
+    t_hat, w_hat = model.prop_net.forward(rays)
+    rgb, _, _, _, fine_w, s_vals = model.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+    loss_nerf, _ = Loss_nerf(rgb, D(pixels, dev))
+    (loss_nerf + 0.01 * Loss_dist(s_vals, fine_w)).backward()
+    pairs = [(p.grad, g[f"{kind}_nerfstep64.{name}"]) for name, p in model.named_parameters() if name.startswith("nerf_net")]
+    rel_n, cos_n = max(_rel(a, b) for a, b in pairs), _cos(pairs)
+    print(f"G21 bf16 {kind}: proposal step max rel {rel_p:.2e} cos {cos_p:.6f} | NeRF step max rel {rel_n:.2e} cos {cos_n:.6f}")
+    assert rel_n <= 2 * NERF_REL and cos_n >= COS_MIN, (rel_n, cos_n)
+    assert rel_p <= 2 * PROP_REL and cos_p >= 0.99, (rel_p, cos_p)
+
+
+def test_full_width_gradients_bf16_vs_fp32_mirrors(dev):
+    """Full width (256 / 1024: the MFMA weight-gradient kernel, the zero-padded first-layer operand, the ring kernel as input-gradient
+    kernel) at 512 rays x 64 samples: the bf16 gradients of one NeRF update and one proposal update against the fp32 mirrors' (which
+    G13 / G21 pin to the reference), tensor by tensor."""
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
+    from mipnerf360_amd.model import mipNeRF360
+    sd = synthetic.make_state_dict(256, 1024, seed=4)
+    r = synthetic.make_rays("garden", 512, seed=6)
+    rays = dev_rays(r, dev)
+    pixels = torch.rand(512, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    grads = {}
+    for dtype in ("fp32", "bf16"):
+        m = mipNeRF360(randomized=False, num_samples=64, hidden_proposal=256, hidden_nerf=1024, device=dev, mlp_dtype=dtype).train()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        t_hat, w_hat = m.prop_net.forward(rays)
+        with torch.no_grad():
+            _, _, _, t, w, _ = m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+        m.zero_grad()
+        Loss_prop(t=t, w=w, t_hat=t_hat, w_hat=w_hat).backward()
+        gp = {n: p.grad.clone() for n, p in m.named_parameters() if n.startswith("prop_net")}
+        rgb, _, _, _, fw, sv = m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+        ln, _ = Loss_nerf(input=rgb, target=pixels)
+        m.zero_grad()
+        (ln + 0.01 * Loss_dist(s_vals=sv, weights=fw)).backward()
+        gn = {n: p.grad.clone() for n, p in m.named_parameters() if n.startswith("nerf_net")}
+        grads[dtype] = (gp, gn)
+        del m
+    for which, bound in ((1, NERF_REL), (0, PROP_REL)):
+        pairs = [(grads["bf16"][which][n], H(grads["fp32"][which][n])) for n in grads["fp32"][which]]
+        rel, cos = max(_rel(a, b) for a, b in pairs), _cos(pairs)
+        print(f"full width bf16 vs fp32 mirrors, {'NeRF' if which else 'proposal'} step: max rel {rel:.2e} cos {cos:.6f}")
+        assert rel <= bound and cos >= COS_MIN, (which, rel, cos)
+        assert all(torch.isfinite(a).all() for a, _ in pairs)
+
+
+def test_training_descends_end_to_end_bf16(dev):
+    """tools/train_demo.py --mlp-dtype bf16: the reference's loop body with the student in bf16 fits the teacher's pixels like the fp32
+    student does (PSNR up by > 3 dB in 40 steps, within 1.5 dB of the fp32 run's end point), deterministic and randomized."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import train_demo
+    kw = dict(steps=40, rays_n=512, samples=16, hp=32, hn=64, lr=3e-3, log_every=39)
+    f32 = train_demo.run(**kw)
+    b16 = train_demo.run(**kw, mlp_dtype="bf16")
+    first, last = b16["trajectory"][0]["psnr"], b16["trajectory"][-1]["psnr"]
+    print("train_demo fp32:", f32["trajectory"], "bf16:", b16["trajectory"])
+    assert np.isfinite(last) and last > first + 3.0 and last > f32["trajectory"][-1]["psnr"] - 1.5, (f32, b16)
+    rnd = train_demo.run(**kw, mlp_dtype="bf16", randomized=True)
+    assert rnd["trajectory"][-1]["psnr"] > rnd["trajectory"][0]["psnr"] + 3.0, rnd

@@ -25,7 +25,7 @@ from mipnerf360_amd.model import mipNeRF360  # noqa: E402
 
 
 def run(steps=150, rays_n=1024, samples=32, hp=64, hn=128, lr=2e-3, dist_weight=0.01, seed=0, device="cuda:0", log_every=25,
-        randomized=False, kind="garden", teacher_kind="kaiming", save=None, white_bkgd=False):
+        randomized=False, kind="garden", teacher_kind="kaiming", save=None, white_bkgd=False, mlp_dtype="fp32"):
     """teacher_kind="structured": the teacher carries the trained-like weights of fixture G19 (high-contrast colours, density
     shells), so the student is fitted to an image with signal.  save: write the trained student's state_dict in the reference's
     checkpoint layout (train.py:98-103) - fixture G20 is such a file, rendered by the reference itself."""
@@ -33,7 +33,9 @@ def run(steps=150, rays_n=1024, samples=32, hp=64, hn=128, lr=2e-3, dist_weight=
     torch.manual_seed(seed)
     kw = dict(randomized=False, num_samples=samples, hidden_proposal=hp, hidden_nerf=hn, white_bkgd=white_bkgd, device=dev)
     teacher = mipNeRF360(**kw)
-    student = mipNeRF360(**dict(kw, randomized=randomized))   # train.py's default is randomized=True (config.py:14)
+    # train.py's default is randomized=True (config.py:14); mlp_dtype="bf16": the student trains on the bf16 matrix pipe (bf16 tape and
+    # gradients in flight, fp32 accumulation, fp32 master weights + AdamW) - the teacher's pixels stay fp32
+    student = mipNeRF360(**dict(kw, randomized=randomized, mlp_dtype=mlp_dtype))
     r = synthetic.make_rays(kind, rays_n, seed=300 + seed)
     t_sd = (synthetic.make_structured_state_dict(hp, hn, 100 + seed, r, samples) if teacher_kind == "structured"
             else synthetic.make_state_dict(hp, hn, seed=100 + seed))
@@ -68,7 +70,7 @@ def run(steps=150, rays_n=1024, samples=32, hp=64, hn=128, lr=2e-3, dist_weight=
                          "loss_dist": round(float(loss_dist.detach()), 5)})
     torch.cuda.synchronize()
     out = {"steps": steps, "rays": rays_n, "samples": samples, "hidden": [hp, hn], "seconds": round(time.perf_counter() - t0, 2),
-           "kind": kind, "teacher": teacher_kind, "rays_seed": 300 + seed, "white_bkgd": bool(white_bkgd),
+           "kind": kind, "teacher": teacher_kind, "rays_seed": 300 + seed, "white_bkgd": bool(white_bkgd), "mlp_dtype": mlp_dtype,
            "target_rgb_std_over_rays": [round(float(v), 4) for v in pixels.std(0)], "trajectory": traj}
     if save:
         from mipnerf360_amd import checkpoint
@@ -95,9 +97,10 @@ def main():
     ap.add_argument("--teacher", default="kaiming", choices=("kaiming", "structured"))
     ap.add_argument("--white-bkgd", action="store_true")
     ap.add_argument("--save", default=None, help="write the trained student's state_dict (reference checkpoint layout) here")
+    ap.add_argument("--mlp-dtype", default="fp32", choices=("fp32", "bf16"), help="precision the student trains in")
     a = ap.parse_args()
     print(json.dumps(run(a.steps, a.rays, a.samples, a.hidden[0], a.hidden[1], a.lr, randomized=a.randomized, kind=a.kind,
-                         teacher_kind=a.teacher, save=a.save, white_bkgd=a.white_bkgd)))
+                         teacher_kind=a.teacher, save=a.save, white_bkgd=a.white_bkgd, mlp_dtype=a.mlp_dtype)))
 
 
 if __name__ == "__main__":
