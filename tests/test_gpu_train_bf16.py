@@ -101,74 +101,96 @@ def _bf16_model(sd, dev, n, hp_, hn_, wb):
     return m.train()
 
 
-# bounds on a gradient tensor's max |error| relative to the tensor's max |value|, and on the direction of the whole gradient:
-# the bf16 forward of these models is 2-6e-3 from the fp32 one on its outputs (printed below); a gradient is a sum of products of two
-# such quantities per sample (activation x dz, each with 2^-9 relative rounding) - NeRF step: 3e-2; the proposal loss divides by weights
-# down to 1e-6 (test_g13_train_step_gradients: 2.5 x the tolerance already in fp32): 8e-2
-NERF_REL, PROP_REL, COS_MIN = 3e-2, 8e-2, 0.999
+# How the bounds are derived.  A gradient error is quoted per tensor as max |error| / max |value|.  Training in bf16 changes the gradient
+# twice: (1) the bf16 FORWARD is another function than the fp32 one (activations rounded to 8 bits: ReLU units near zero switch, every
+# layer's input carries 2^-9 relative noise) - inherent to the mode, measured here by the oracle's bf16-emulating forward differentiated
+# by torch autograd in fp32 (O.*_step_gradients with Hyper(mlp_bf16=1): exact backward of the rounded forward) against the reference's
+# gradients; it grows towards the first layers (G13 lego: 0.4 % at the last hidden layer, ~10 % at the first, on 32 / 64-wide Kaiming
+# nets whose units are nearly constant over the batch); (2) the bf16 BACKWARD rounds dz to bf16 after every layer and reads bf16
+# weights - what the HIP path adds on top: held to BACKWARD_REL against the oracle's bf16 gradients.  Against the reference itself the
+# HIP gradients may then be off by the inherent part + that; their DIRECTION - what AdamW consumes - must agree to COS_MIN.
+BACKWARD_REL, COS_MIN = 4e-2, 0.999
+
+
+def _step_errors(hip, oracle16, ref, what):
+    names = list(ref)
+    inherent = max(_rel(torch.from_numpy(np.asarray(oracle16[n])), ref[n]) for n in names)
+    added = max(_rel(hip[n], oracle16[n].numpy()) for n in names)
+    total = max(_rel(hip[n], ref[n]) for n in names)
+    cos = _cos([(hip[n], ref[n]) for n in names])
+    print(f"{what}: bf16 forward alone (oracle, fp32 backward) {inherent:.2e} | HIP bf16 backward on top {added:.2e} | HIP vs reference {total:.2e}, cos {cos:.6f}")
+    return inherent, added, total, cos
 
 
 @pytest.mark.parametrize("kind", ["lego", "garden"])
 def test_g13_train_step_gradients_bf16(golden, dev, kind):
     """Fixture G13 (every parameter gradient of the reference's loop body, reduced width 32 / 64 -> the widening weight-gradient path):
-    the bf16 mirrors against the reference's fp32 autograd."""
+    the bf16 mirrors against the reference's fp32 autograd, with the share of the bf16 forward taken from the oracle."""
     from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
+    from oracle import ref_path as O
     g = golden("g13_train_gradients")
     B, n, wb = (int(v) for v in g[f"{kind}_cfg"])
     sd = {k[3:]: g[k] for k in g if k.startswith("sd.")}
     model = _bf16_model(sd, dev, n, 32, 64, bool(wb))
-    rays = dev_rays({f: g[f"{kind}_rays_{f}"] for f in synthetic.RAY_FIELDS}, dev)
+    r = {f: g[f"{kind}_rays_{f}"] for f in synthetic.RAY_FIELDS}
+    rays = dev_rays(r, dev)
+    sdt, hp16 = O.to_torch_state_dict(sd), O.Hyper(num_samples=n, white_bkgd=bool(wb), mlp_bf16=1)
     t_hat, w_hat = model.prop_net.forward(rays)
     assert w_hat.requires_grad
     _, _, _, t, w, _ = model.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
     loss_prop = Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
     model.zero_grad()
     loss_prop.backward()
-    pairs = [(p.grad, g[f"{kind}_propstep.{name}"]) for name, p in model.named_parameters() if name.startswith("prop_net")]
-    rel_p = max(_rel(a, b) for a, b in pairs)
-    cos_p = _cos(pairs)
+    hip = {name: p.grad.clone() for name, p in model.named_parameters() if name.startswith("prop_net")}
+    _, og = O.prop_step_gradients(O.rays_from_numpy(r), sdt, hp16)
+    inh_p, add_p, tot_p, cos_p = _step_errors(hip, og, {nm: g[f"{kind}_propstep.{nm}"] for nm in hip}, f"G13 bf16 {kind} proposal step")
     t_hat, w_hat = model.prop_net.forward(rays)
     rgb, _, _, _, fine_w, s_vals = model.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
     loss_nerf, _ = Loss_nerf(input=rgb, target=D(g[f"{kind}_pixels"], dev))
     loss_dist = Loss_dist(s_vals=s_vals, weights=fine_w)
     model.zero_grad()
     (loss_nerf + 0.01 * loss_dist).backward()
-    pairs = [(p.grad, g[f"{kind}_nerfstep.{name}"]) for name, p in model.named_parameters() if name.startswith("nerf_net")]
-    rel_n = max(_rel(a, b) for a, b in pairs)
-    cos_n = _cos(pairs)
-    print(f"G13 bf16 {kind}: proposal step max rel {rel_p:.2e} cos {cos_p:.6f} | NeRF step max rel {rel_n:.2e} cos {cos_n:.6f} | loss_nerf {float(loss_nerf):.5f} vs {float(g[kind + '_loss_nerf']):.5f}")
-    assert rel_n <= NERF_REL and cos_n >= COS_MIN, (rel_n, cos_n)
-    assert rel_p <= PROP_REL and cos_p >= COS_MIN, (rel_p, cos_p)
+    hip = {name: p.grad.clone() for name, p in model.named_parameters() if name.startswith("nerf_net")}
+    _, _, og = O.nerf_step_gradients(O.rays_from_numpy(r), sdt, hp16, torch.from_numpy(g[f"{kind}_pixels"]))
+    inh_n, add_n, tot_n, cos_n = _step_errors(hip, og, {nm: g[f"{kind}_nerfstep.{nm}"] for nm in hip}, f"G13 bf16 {kind} NeRF step")
+    for inh, add, tot, cos in ((inh_p, add_p, tot_p, cos_p), (inh_n, add_n, tot_n, cos_n)):
+        assert add <= BACKWARD_REL and tot <= inh + BACKWARD_REL and cos >= COS_MIN, (inh, add, tot, cos)
     assert abs(float(loss_nerf) - float(g[f"{kind}_loss_nerf"])) <= 2e-2 * abs(float(g[f"{kind}_loss_nerf"]))
 
 
 @pytest.mark.parametrize("kind", ["lego", "mixed"])
 def test_g21_structured_gradients_bf16(golden, dev, kind):
-    """Fixture G21 (trained-like weights: density shells, spread colours): the bf16 gradients against the reference's fp64 gradients.
-    The reference's own fp32 run is up to 1 % of a tensor's scale from its fp64 run on the proposal step here (ill-conditioned loss);
-    bf16 gets the bounds above, and its direction - what the optimiser uses - must agree to 0.999."""
+    """Fixture G21 (trained-like weights: density shells, spread colours): the bf16 gradients against the reference's fp64 gradients,
+    same decomposition.  (The reference's own fp32 run is up to 1 % of a tensor's scale from its fp64 run on the proposal step here.)"""
     from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
+    from oracle import ref_path as O
     g = golden("g21_structured_gradients")
     (B, n, wb, hp_, hn_), r, sd, pixels = g21_case(g, kind)
     model = _bf16_model(sd, dev, n, hp_, hn_, wb)
     rays = dev_rays(r, dev)
+    sdt, hp16 = O.to_torch_state_dict(sd), O.Hyper(num_samples=n, white_bkgd=bool(wb), mlp_bf16=1)
     t_hat, w_hat = model.prop_net.forward(rays)
     _, _, _, t, w, _ = model.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
     loss_prop = Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
     model.zero_grad()
     loss_prop.backward()
-    pairs = [(p.grad, g[f"{kind}_propstep64.{name}"]) for name, p in model.named_parameters() if name.startswith("prop_net")]
-    rel_p, cos_p = max(_rel(a, b) for a, b in pairs), _cos(pairs)
+    hip = {name: p.grad.clone() for name, p in model.named_parameters() if name.startswith("prop_net")}
+    _, og = O.prop_step_gradients(O.rays_from_numpy(r), sdt, hp16)
+    inh_p, add_p, tot_p, cos_p = _step_errors(hip, og, {nm: g[f"{kind}_propstep64.{nm}"] for nm in hip}, f"G21 bf16 {kind} proposal step")
     model.zero_grad()
     t_hat, w_hat = model.prop_net.forward(rays)
     rgb, _, _, _, fine_w, s_vals = model.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
     loss_nerf, _ = Loss_nerf(rgb, D(pixels, dev))
     (loss_nerf + 0.01 * Loss_dist(s_vals, fine_w)).backward()
-    pairs = [(p.grad, g[f"{kind}_nerfstep64.{name}"]) for name, p in model.named_parameters() if name.startswith("nerf_net")]
-    rel_n, cos_n = max(_rel(a, b) for a, b in pairs), _cos(pairs)
-    print(f"G21 bf16 {kind}: proposal step max rel {rel_p:.2e} cos {cos_p:.6f} | NeRF step max rel {rel_n:.2e} cos {cos_n:.6f}")
-    assert rel_n <= 2 * NERF_REL and cos_n >= COS_MIN, (rel_n, cos_n)
-    assert rel_p <= 2 * PROP_REL and cos_p >= 0.99, (rel_p, cos_p)
+    hip = {name: p.grad.clone() for name, p in model.named_parameters() if name.startswith("nerf_net")}
+    _, _, og = O.nerf_step_gradients(O.rays_from_numpy(r), sdt, hp16, torch.from_numpy(np.ascontiguousarray(pixels)).float())
+    inh_n, add_n, tot_n, cos_n = _step_errors(hip, og, {nm: g[f"{kind}_nerfstep64.{nm}"] for nm in hip}, f"G21 bf16 {kind} NeRF step")
+    # the proposal loss through a density shell is ill-conditioned (DESIGN.md §2, G21): twice the bound there, direction to 0.99
+    assert add_n <= BACKWARD_REL and tot_n <= inh_n + BACKWARD_REL and cos_n >= COS_MIN, (inh_n, add_n, tot_n, cos_n)
+    assert add_p <= 2 * BACKWARD_REL and tot_p <= inh_p + 2 * BACKWARD_REL and cos_p >= 0.99, (inh_p, add_p, tot_p, cos_p)
+
+
+NERF_REL, PROP_REL = 3e-2, 8e-2  # full width against the fp32 mirrors (measured 1.2e-2 / 1.8e-2: wide layers average the rounding noise)
 
 
 def test_full_width_gradients_bf16_vs_fp32_mirrors(dev):
