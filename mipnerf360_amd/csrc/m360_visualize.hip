@@ -5,7 +5,6 @@
 // deterministic two-level fp64 reduction (fixed partition), like the contraction norm.
 #include <string.h>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "m360_common.hip.h"
 #include "m360_turbo_lut.h"
@@ -196,6 +195,78 @@ __global__ void vis_prepare_sort_kernel(const float *__restrict__ depth, const f
     vals[idx] = isnan(d) ? 0.0f : (acc ? acc[idx] : 1.0f);
 }
 
+// The sort itself (round 5: hand-written - until then rocPRIM's radix_sort_pairs, the build's last vendor-library call).  A frame is at
+// most a few million (depth, acc) pairs, sorted once per visualised frame, off the render path: a plain LSD radix sort, four passes of
+// 8 bits over the order-preserving integer image of the float keys (sign bit flipped for positives, all bits for negatives: -x < -0 < +0 <
+// +x < +Inf < +NaN, the order rocPRIM's float sort gave and numpy's argsort gives up to ties).  Per pass: per-tile digit counts, one
+// workgroup turns them into global offsets ([digit][tile], digit-major), then every tile - ONE wave walking its 1024 elements in index
+// order, 64 at a time - places its elements: lanes with the same digit find each other with eight ballots, their rank among
+// themselves is a popcount below the lane: STABLE, hence deterministic, no atomics on the data path.
+constexpr int kSortTile = 1024;
+__device__ __forceinline__ unsigned sort_key_bits(float f) {
+    const unsigned b = __builtin_bit_cast(unsigned, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ __launch_bounds__(64) void vis_sort_count_kernel(const float *__restrict__ keys, long n, int shift, int ntiles, unsigned *__restrict__ counts /*[256][ntiles]*/) {
+    __shared__ unsigned hist[256];
+    const int l = threadIdx.x;
+    for (int d = l; d < 256; d += 64) hist[d] = 0u;
+    __syncthreads();
+    const long base = (long)blockIdx.x * kSortTile;
+    for (int c = 0; c < kSortTile; c += 64) {
+        const long i = base + c + l;
+        if (i < n) atomicAdd(&hist[(sort_key_bits(keys[i]) >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int d = l; d < 256; d += 64) counts[(long)d * ntiles + blockIdx.x] = hist[d];
+}
+__global__ __launch_bounds__(256) void vis_sort_offsets_kernel(unsigned *__restrict__ counts, int ntiles) {
+    // exclusive prefix over the digit-major array [256][ntiles]: thread d walks its digit's tiles, then the digits' totals are chained
+    __shared__ unsigned total[256];
+    const int d = threadIdx.x;
+    unsigned run = 0u;
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned c = counts[(long)d * ntiles + t];
+        counts[(long)d * ntiles + t] = run;
+        run += c;
+    }
+    total[d] = run;
+    __syncthreads();
+    unsigned before = 0u;
+    for (int e = 0; e < d; ++e) before += total[e];
+    for (int t = 0; t < ntiles; ++t) counts[(long)d * ntiles + t] += before;
+}
+__global__ __launch_bounds__(64) void vis_sort_scatter_kernel(const float *__restrict__ keys, const float *__restrict__ vals, long n, int shift, int ntiles,
+                                                               const unsigned *__restrict__ offsets, float *__restrict__ keys_out, float *__restrict__ vals_out) {
+    __shared__ unsigned next[256];  // where the tile's next element of each digit goes
+    const int l = threadIdx.x;
+    for (int d = l; d < 256; d += 64) next[d] = offsets[(long)d * ntiles + blockIdx.x];
+    __syncthreads();
+    const long base = (long)blockIdx.x * kSortTile;
+    const unsigned long long below = (1ull << l) - 1ull;
+    for (int c = 0; c < kSortTile; c += 64) {
+        const long i = base + c + l;
+        const bool live = i < n;
+        const float k = live ? keys[i] : 0.0f, v = live ? vals[i] : 0.0f;
+        const unsigned digit = (sort_key_bits(k) >> shift) & 255u;
+        unsigned long long same = __ballot(live);  // lanes holding an element with MY digit
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long set = __ballot(live && ((digit >> b) & 1u));
+            same &= ((digit >> b) & 1u) ? set : ~set;
+        }
+        unsigned pos = 0u;
+        if (live) pos = next[digit] + (unsigned)__popcll(same & below);
+        __syncthreads();  // every lane has read next[] before the group leaders advance it
+        if (live && (same & below) == 0ull) next[digit] += (unsigned)__popcll(same);
+        __syncthreads();
+        if (live) {
+            keys_out[pos] = k;
+            vals_out[pos] = v;
+        }
+    }
+}
+
 __global__ void vis_cumsum_seq_kernel(const float *__restrict__ vals, long n, float *__restrict__ cum, int *__restrict__ range) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     float run = 0.0f;
@@ -307,17 +378,14 @@ int m360_visualize_depth(const float *depth, const float *acc, int h, int w, flo
     return check_launch("visualize_depth");
 }
 
-static size_t sort_temp_bytes(long n) {
-    size_t bytes = 0;
-    float *nul = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, (size_t)n, 0, 32, (hipStream_t)0);
-    return bytes;
+static size_t sort_temp_bytes(long n) {  // digit counts / offsets of one pass: [256][tiles]
+    return (size_t)256 * (size_t)((n + kSortTile - 1) / kSortTile) * sizeof(unsigned);
 }
 
 size_t m360_visualize_depth_ex_workspace_bytes(int h, int w) {
     if (h < 1 || w < 1) return 0;
     const long n = (long)h * w;
-    // VisScratch | planes[2] + range[2] | keys, vals, keys sorted, vals sorted, cum | rocPRIM temporary storage
+    // VisScratch | planes[2] + range[2] | keys, vals, keys / vals of the other pass, cum | the sort's digit offsets
     return vis_up(sizeof(VisScratch)) + 256 + 5 * vis_up((size_t)n * sizeof(float)) + vis_up(sort_temp_bytes(n));
 }
 
@@ -347,12 +415,20 @@ int m360_visualize_depth_ex(const float *depth, const float *acc, int h, int w, 
     if (near_auto || far_auto) {
         if (ignore_frac > 0.0f) {
             hipLaunchKernelGGL(vis_prepare_sort_kernel, dim3(blocks), dim3(256), 0, st, depth, acc, n, keys, vals);
-            size_t temp_bytes = sort_temp_bytes(n);
-            if (rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_s, vals, vals_s, (size_t)n, 0, 32, st) != hipSuccess)
-                return fail(M360_ERR_LAUNCH, "m360_visualize_depth_ex: radix sort failed");
-            hipLaunchKernelGGL(vis_cumsum_seq_kernel, dim3(1), dim3(64), 0, st, vals_s, n, cum, range);
+            // four stable 8-bit passes, ping-pong between (keys, vals) and (keys_s, vals_s): the sorted pairs end up in (keys, vals)
+            const int ntiles = (int)((n + kSortTile - 1) / kSortTile);
+            unsigned *offsets = static_cast<unsigned *>(temp);
+            float *ki = keys, *vi = vals, *ko = keys_s, *vo = vals_s;
+            for (int shift = 0; shift < 32; shift += 8) {
+                hipLaunchKernelGGL(vis_sort_count_kernel, dim3((unsigned)ntiles), dim3(64), 0, st, ki, n, shift, ntiles, offsets);
+                hipLaunchKernelGGL(vis_sort_offsets_kernel, dim3(1), dim3(256), 0, st, offsets, ntiles);
+                hipLaunchKernelGGL(vis_sort_scatter_kernel, dim3((unsigned)ntiles), dim3(64), 0, st, ki, vi, n, shift, ntiles, offsets, ko, vo);
+                float *t = ki; ki = ko; ko = t;
+                t = vi; vi = vo; vo = t;
+            }
+            hipLaunchKernelGGL(vis_cumsum_seq_kernel, dim3(1), dim3(64), 0, st, vi, n, cum, range);
             hipLaunchKernelGGL(vis_band_kernel, dim3(blocks), dim3(256), 0, st, cum, n, ignore_frac, range);
-            hipLaunchKernelGGL(vis_planes_kernel, dim3(1), dim3(64), 0, st, keys_s, range, planes);
+            hipLaunchKernelGGL(vis_planes_kernel, dim3(1), dim3(64), 0, st, ki, range, planes);
         } else {
             const int rc = launch_stats(depth, h, w, ws, st);
             if (rc != M360_OK) return rc;

@@ -1445,6 +1445,23 @@ def test_g11_visualisation(golden, dev):
     close(P.visualize_normals(big, bacc), O.visualize_normals(big, bacc), atol=2e-5)
     lut_close(P.visualize_depth(big, bacc, None, None), O.visualize_depth(big, bacc, None, None))
     lut_close(P.visualize_depth(big, bacc, ignore_frac=0.03), O.visualize_depth(big, bacc, ignore_frac=0.03))  # 155 617-pixel sort
+    # round 5: the sort behind ignore_frac is the build's own (stable LSD radix sort on the keys' order-preserving integer image) - a
+    # full-frame-sized map with heavy ties (quantised depths), negative values, -0 / +0, +Inf and NaNs: the chosen planes against numpy's
+    # stable argsort + sequential float32 cumsum, exactly
+    from mipnerf360_amd import ops
+    gen = np.random.Generator(np.random.PCG64(11))
+    frame = np.round(gen.normal(3.0, 2.0, size=(822, 1237)) * 16.0).astype(np.float32) / 16.0
+    frame[gen.uniform(size=frame.shape) < 0.01] = np.nan
+    frame[5, :7] = [0.0, -0.0, np.inf, -3.5, 0.0, -0.0, 1e-30]
+    facc = gen.uniform(0, 1, size=frame.shape).astype(np.float32)
+    for frac in (0.02, 0.3):
+        planes = ops.visualize_depth_ex(D(frame, dev), D(facc, dev), ignore_frac=frac, want="planes").cpu().numpy()
+        a = np.where(np.isnan(frame), 0.0, facc).astype(np.float32).reshape(-1)
+        order = np.argsort(frame.reshape(-1), kind="stable")
+        cum = np.cumsum(a[order], dtype=np.float32)
+        keep = frame.reshape(-1)[order][(cum >= cum[-1] * np.float32(frac)) & (cum <= cum[-1] * np.float32(1 - frac))]
+        eps = np.finfo(np.float32).eps
+        assert planes[0] == np.float32(keep[0] - eps) and planes[1] == np.float32(keep[-1] + eps), (frac, planes, keep[0], keep[-1])
     # end to end: render -> device visualisation -> uint8, as test.py:52-56 does with numpy + to8b
     from mipnerf360_amd.intern.utils import to8b
     img = to8b(P.visualize_depth(big, bacc, 1.0, 20.0))

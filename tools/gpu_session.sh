@@ -39,6 +39,18 @@ for s in $steps; do
              python3 -c "import bench, json; print(json.dumps({'fp32': bench.kernel_source_sha(), 'bf16': bench.kernel_source_sha(bench.TRAFFIC_SOURCES_BF16)}))" > $O/kernel_source_sha256_at_measurement.json
              # raw traces are large: keep the csv files the summariser needs, drop the rest
              find $O -name "*.db" -delete 2>/dev/null; du -sh $O; tail -2 $O/bench_under_rocprof.log | cut -c1-300 ;;
+    finpmc)  # round 5: what the HBM-bound kernels' microseconds are made of - SQ counters of the finishers / the encoder / the prologue, fp32 and bf16 steps
+             R=$PWD; O=$R/$out; PMC="--kernel-trace --output-format csv"
+             ( cd /tmp && export TMPDIR=/tmp
+               timeout 600 rocprofv3 $PMC --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE -d $O/pmc_fin_a -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rays 0 --frame-steps 0 --no-named > $O/pmc_fin_a.log 2>&1
+               timeout 600 rocprofv3 $PMC --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT -d $O/pmc_fin_b -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rays 0 --frame-steps 0 --no-named > $O/pmc_fin_b.log 2>&1
+               timeout 600 rocprofv3 $PMC --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE -d $O/pmc_fin_a16 -- python3 $R/bench.py --mlp-dtype bf16 --steps 3 --warmup 1 --cpu-rays 0 --frame-steps 0 > $O/pmc_fin_a16.log 2>&1 )
+             find $O -name "*.db" -delete 2>/dev/null
+             python3 tools/summarize_profiles.py --hbm-kernels $tag | cut -c1-400 ;;
+    train16) # round 5: the bf16 training iteration - timings, then its kernels under rocprofv3 (per-kernel time of the iteration alone)
+             timeout 600 python tools/train_step_bench.py --mlp-dtype bf16 --iters 5 > $out/train_step_bf16.json 2> $out/train_step_bf16.err; cat $out/train_step_bf16.json
+             timeout 600 python tools/train_step_bench.py --iters 2 > $out/train_step_fp32.json 2> $out/train_step_fp32.err; cat $out/train_step_fp32.json
+             R=$PWD; O=$R/$out; ( cd /tmp && export TMPDIR=/tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train16 -- python3 $R/tools/train_step_bench.py --mlp-dtype bf16 --iters 5 --no-gemms > $O/train_step_bf16_under_rocprof.log 2>&1 ); find $O/stats_train16 -name "*.db" -delete 2>/dev/null; cp $O/stats_train16/*/*_kernel_stats.csv $O/rocprofv3_kernel_stats_train_bf16.csv 2>/dev/null; head -24 $O/rocprofv3_kernel_stats_train_bf16.csv | cut -c1-200 ;;
     r3new)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -k "span or one_chunk or bench_ or two_ranks or c2_full or rccl or g18 or nan_rows" > $out/pytest_r3new.log 2>&1; echo "pytest rc=$?" >> $out/pytest_r3new.log; tail -25 $out/pytest_r3new.log ;;
     nccl2)   # two RCCL ranks on a 1-GPU box: must fail with RCCL's own error (not a SystemExit of bench.py), and must not hang
              timeout 300 python bench.py --gpus 2 --steps 2 --warmup 1 --frame-steps 0 > $out/nccl2.out 2> $out/nccl2.err; echo "rc=$?" >> $out/nccl2.out; tail -3 $out/nccl2.out; grep -i "nccl\|rccl\|duplicate\|error" $out/nccl2.err | head -12 ;;

@@ -251,9 +251,57 @@ def bf16_ring_counters(src):
             "kernel_source_sha256": sha_at_measurement(src, "bf16", "kernel_source_sha256_at_measurement_b16.json")}
 
 
+def hbm_kernel_counters(tag):
+    """SQ counters of the path's HBM- / latency-bound kernels (tools/gpu_session.sh finpmc: separate --pmc passes over bench.py): per kernel
+    the mean launch duration under the counters, waves, and per WAVE: resident cycles, cycles waiting on an instruction's operands, cycles
+    issuing, instruction counts by kind -> profiles/<tag>/hbm_kernels_sq_counters.json (what are the 16 / 31 / 40 us made
+    of?).  SQ_* cycle counters are summed over the waves of all XCDs; per-wave = / SQ_WAVES."""
+    src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles", tag)
+    os.makedirs(dst, exist_ok=True)
+    names = ("stage_prologue_kernel", "encode_features_wave_kernel", "prop_finish_kernel", "nerf_finish_kernel", "norm_partial_from_t_kernel")
+    out = {}
+    for mode, dirs in (("fp32", ("pmc_fin_a", "pmc_fin_b")), ("bf16", ("pmc_fin_a16",))):
+        per = {}
+        for d in dirs:
+            fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
+            if not fs:
+                continue
+            acc = collections.defaultdict(lambda: collections.defaultdict(list))
+            for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
+                for nm in names:
+                    if nm in r["Kernel_Name"]:
+                        # full 4096-ray chunks only: the grid of a 4096 x 128 launch
+                        acc[nm][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                        acc[nm]["_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                        acc[nm]["_grid"].append(int(r.get("Grid_Size", 0) or 0))
+            for nm, c in acc.items():
+                e = per.setdefault(nm, {})
+                for k, v in c.items():
+                    if k == "_grid":
+                        continue
+                    # a counter row per (dispatch, counter): _ns repeats per counter - the mean is unaffected
+                    e[k if k != "_ns" else f"launch_us_under_pmc[{d}]"] = round((sum(v) / len(v)) / (1e3 if k == "_ns" else 1.0), 3)
+                e.setdefault("dispatches", {})[d] = len(c["_ns"]) // max(1, len([k for k in c if not k.startswith("_")]))
+        for nm, e in per.items():
+            w = e.get("SQ_WAVES")
+            if w:
+                e["per_wave"] = {k: round(e[k] / w, 1) for k in ("SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
+                                                             "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU") if k in e}
+                if "SQ_WAVE_CYCLES" in e and "SQ_WAIT_INST_ANY" in e:
+                    e["waiting_fraction_of_wave_cycles"] = round(e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"], 3)
+        out[mode] = per
+    out["method"] = ("separate rocprofv3 --kernel-trace --pmc passes over `bench.py --steps 3 --warmup 1 --cpu-rays 0 --frame-steps 0` (fp32: two passes of 8 "
+                     "counters; bf16: one), mean over the launches of each kernel; SQ cycle / instruction counters are sums over all waves")
+    json.dump(out, open(f"{dst}/hbm_kernels_sq_counters.json", "w"), indent=1)
+    return out
+
+
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--markdown":
         sys.stdout.write(markdown(sys.argv[2]))
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--hbm-kernels":
+        print(json.dumps(hbm_kernel_counters(sys.argv[2])))
         return
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles", tag)

@@ -39,30 +39,38 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--gemm-only", action="store_true")
+    ap.add_argument("--mlp-dtype", default="fp32", choices=("fp32", "bf16"), help="precision the model trains in (round 5: bf16)")
+    ap.add_argument("--no-gemms", action="store_true", help="skip the stand-alone gradient GEMMs (kernel profiles of the iteration alone)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    out = {"rays": a.rays, "samples": a.samples}
+    out = {"rays": a.rays, "samples": a.samples, "mlp_dtype": a.mlp_dtype}
+    b16 = a.mlp_dtype == "bf16"
 
     # --- the two gradient GEMMs of one 1024 x 1024 layer
     M = a.rays * a.samples
-    dz = torch.randn(M, 1024, device=dev)
-    x = torch.relu(torch.randn(M, 1024, device=dev))
-    w = torch.randn(1024, 1024, device=dev) / 32
-    wt = ops.pack_linear_transposed(w)
-    dx = torch.empty(M, 1024, device=dev)
-    flops = 2.0 * M * 1024 * 1024
-    ms = timed(lambda: ops.linear_wgrad(dz, x), a.iters)
-    out["wgrad_ms"], out["wgrad_tflops"] = round(ms, 3), round(flops / ms / 1e9, 1)
-    ms = timed(lambda: ops.linear_wgrad(dz, x, want_bias=False), a.iters)
-    out["wgrad_nobias_ms"] = round(ms, 3)
-    ms = timed(lambda: ops.linear_dgrad(dz, wt, x, out=dx), a.iters)
-    out["dgrad_ms"], out["dgrad_tflops"] = round(ms, 3), round(flops / ms / 1e9, 1)
-    del dz, x, dx
+    if not a.no_gemms:
+        dt = torch.bfloat16 if b16 else torch.float32
+        dz = torch.randn(M, 1024, device=dev).to(dt)
+        x = torch.relu(torch.randn(M, 1024, device=dev)).to(dt)
+        w = torch.randn(1024, 1024, device=dev) / 32
+        wt = (ops.pack_linear_bf16_transposed if b16 else ops.pack_linear_transposed)(w)
+        dx = torch.empty(M, 1024, device=dev, dtype=dt)
+        wgrad, dgrad = (ops.linear_wgrad_bf16, ops.linear_dgrad_bf16) if b16 else (ops.linear_wgrad, ops.linear_dgrad)
+        flops = 2.0 * M * 1024 * 1024
+        ms = timed(lambda: wgrad(dz, x), a.iters)
+        out["wgrad_ms"], out["wgrad_tflops"] = round(ms, 3), round(flops / ms / 1e9, 1)
+        ms = timed(lambda: wgrad(dz, x, want_bias=False), a.iters)
+        out["wgrad_nobias_ms"] = round(ms, 3)
+        ms = timed(lambda: dgrad(dz, wt, x, out=dx), a.iters)
+        out["dgrad_ms"], out["dgrad_tflops"] = round(ms, 3), round(flops / ms / 1e9, 1)
+        ms = timed(lambda: dgrad(dz, wt, None, out=dx), a.iters)
+        out["dgrad_nomask_ms"] = round(ms, 3)
+        del dz, x, dx
     if a.gemm_only:
         print(json.dumps(out))
         return
 
-    model = mipNeRF360(randomized=False, num_samples=a.samples, device=dev)
+    model = mipNeRF360(randomized=False, num_samples=a.samples, device=dev, mlp_dtype=a.mlp_dtype)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(256, 1024, seed=0).items()})
     model.train()
     r = synthetic.make_rays("garden", a.rays, seed=1)
