@@ -629,6 +629,32 @@ def named_workloads(sd_np, dev, _lib):
 
     training_entry("c2_training_iteration", "fp32")
     training_entry("c2_training_iteration_bf16", "bf16")
+
+    # ---- a frame at the reference's CLI default chunk size (config.py:49: chunks = 128; configs[0]'s scene: lego 400 x 400, 64 samples per ray,
+    # white background): 1250 chunks, each contracted by ITS OWN norm, launched 32 at a time (m360_hyper_t.norm_group_rays) - bit-identical to one
+    # launch sequence per chunk (tests), here with a number
+    from mipnerf360_amd.intern.ray import generate_rays
+    fm = mipNeRF360(randomized=False, num_samples=64, hidden_proposal=HP, hidden_nerf=HN, white_bkgd=True, device=dev)
+    fm.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    fm.eval()
+    pose = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 4.0]], device=dev)
+    frays = generate_rays(pose, 400, 400, 555.6, 2.0, 6.0, False)
+    fm.render_rays(Rays(*[f[:8192] for f in frays]), chunks=128)  # warm-up: packing, workspace
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rgb, dist, acc = fm.render_rays(frays, chunks=128)
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    flops_ray = FLOPS_PER_SAMPLE * 64
+    out["c1_frame_chunks128"] = {
+        "config": "c1", "dtype": "f32", "workload": "nerf_synthetic/lego-like 400 x 400 frame (160 000 rays, synthetic pinhole pose, near 2 / far 6, white background), 64 samples per ray, "
+                                                    "rendered in the reference's default chunks of 128 rays (config.py:49) = 1250 chunks of their own contraction norm, 32 chunks per launch "
+                                                    "sequence; proposal 4x256 + NeRF 8x1024 MLPs in fp32 on MFMA, random-init Kaiming weights (BASELINE.json configs[0]'s scene on the GPU)",
+        "rays_per_s": round(160000 / sec, 1), "ms_per_step": round(sec * 1e3, 1), "steps": 1, "chunks": 128, "n_chunks": 1250,
+        "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(dist).all() and torch.isfinite(acc).all()),
+        "whole_path_tflops": round(160000 / sec * flops_ray / 1e12, 1), "frac_of_fp32_mfma_peak": round(160000 / sec * flops_ray / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+    del fm, frays, rgb, dist, acc
+    torch.cuda.empty_cache()
     out["seconds"] = round(time.perf_counter() - t_all, 2)
     return out
 

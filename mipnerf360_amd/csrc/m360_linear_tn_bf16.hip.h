@@ -16,8 +16,8 @@
 //     16-column block) then fall into 8 different bank octets - conflict-free (MI355X_MICROARCH.md §LDS: banks count per 32-lane half).
 //   * 512 threads = 8 waves, wave tile 128 (n) x 64 (k) = 8 x 4 blocks, 128 accumulator registers; operands swapped (A := X columns,
 //     B := dZ columns) so that a lane's 4 accumulator registers are 4 consecutive k of one n: 16-byte stores of the partial tile.
-//   * bias gradient db[n] = sum_m dZ[m, n] on the matrix pipe as well: one MFMA per dZ block and k-step against a fragment of ones, in the
-//     waves of the first k quarter of the first tile column only (exact: bf16 values added in fp32).
+//   * bias gradient db[n] = sum_m dZ[m, n] on the matrix pipe as well: one MFMA per dZ block and k-step against a fragment of ones (exact:
+//     bf16 values added in fp32), the 16 blocks of a tile row spread over its workgroups and waves (below).
 //   * ids are XCD-aware: the 16 tiles of one split (same rows) run on one XCD, so a row of dZ / X comes from HBM once per XCD and from its L2
 //     for the other tiles of the split.
 #pragma once
@@ -71,15 +71,20 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
     const long s_begin = (long)split * steps_per_split;
     long s_end = s_begin + steps_per_split;
     if (s_end > total_steps) s_end = total_steps;
-    const bool do_bias = bias_partial != nullptr && k0 == 0 && wk == 0;  // wave-uniform
-
-    f32x4 acc[8][4], bacc[8];
+    // bias gradient: the column sums of the dZ tile's 2 x 8 blocks of 16 columns are spread over the tile row's workgroups and waves - slot
+    // 4 kt + wk of k tile kt, wave (wn, wk) adds up `bias_n` blocks of its n half from `bias_first` on (one block per slot with 4 k tiles: ONE
+    // extra MFMA and fragment read per k-step in the waves of the first two k tiles; two blocks per wave when the layer has a single k tile).
+    // When all of it sat in the first k tile's wk = 0 waves - 8 extra MFMAs per 32 - those workgroups finished 12 % after the rest
+    // (1.31 -> 1.55 ms per 1024^2 layer).
+    const int nslots = 4 * tiles_k < 8 ? 4 * tiles_k : 8, per = 8 / nslots, slot = 4 * (tile % tiles_k) + wk;
+    const int bias_n = (bias_partial != nullptr && slot < nslots) ? per : 0, bias_first = slot * per;  // wave-uniform
+    f32x4 acc[8][4], bacc[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        bacc[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bacc[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     if (s_begin < s_end) {
         // ---- LDS-DMA: wave w stages pieces 4w .. 4w+3 (rows 8w .. 8w+7) of the dZ tile and of the X tile; lane L of a piece lands at byte
@@ -114,6 +119,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
         for (int i = 0; i < 8; ++i) a_off[i] = lds0 + lane_off + (unsigned)((i ^ f) + 8 * wn) * 32u;                                   // dZ block 8 wn + i
 #pragma unroll
         for (int j = 0; j < 4; ++j) b_off[j] = lds0 + kOperandBytes + lane_off + (unsigned)(((4 * (wk & 1) + j) ^ f) + 8 * (wk >> 1)) * 32u;  // X block 4 wk + j
+        unsigned bias_off[2];  // the blocks this wave sums for the bias gradient (read once more: no dynamic choice among the fragments in registers)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) bias_off[e] = lds0 + lane_off + (unsigned)((((bias_first + e) & 7) ^ f) + 8 * wn) * 32u;
         auto frag = [&](unsigned addr) __attribute__((always_inline)) -> bf16x8 {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)addr);
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(addr + 4 * kRowBytes));
@@ -121,18 +129,17 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
         };
         const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
 
+        // ONE barrier per stage: behind it every wave has its pieces of stage s in the LDS and has finished reading the other buffer (stage
+        // s - 1), so the pieces of stage s + 1 go out right there and have the whole stage's matrix work to land
         issue(0, 0u, 0u);
         int buf = 0;
         for (long s = s_begin; s < s_end; ++s) {
-            const bool more = s + 1 < s_end;
-            if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (s + 1 < s_end) {
                 const unsigned rows = (unsigned)(s + 1 - s_begin) * BKM;
                 issue(buf ^ 1, rows * (unsigned)ldz * 2u, rows * (unsigned)ldx * 2u);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // this wave's pieces of stage s have landed (the 8 of stage s + 1 may fly)
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __syncthreads();  // ... and every other wave's
             const unsigned boff = buf ? (unsigned)kStageBytes : 0u;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -145,12 +152,14 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
                 for (int i = 0; i < 8; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                if (do_bias) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], bacc[i], 0, 0, 0);
+                if (bias_n > 0) {
+                    bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, frag(bias_off[0] + boff + ks * 32 * kRowBytes), bacc[0], 0, 0, 0);
+                    if (bias_n > 1) bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, frag(bias_off[1] + boff + ks * 32 * kRowBytes), bacc[1], 0, 0, 0);
                 }
+                // one k-step's 12 fragments at a time: with both k-steps' reads hoisted to the top of the stage the kernel needs 300+ registers
+                // (256 per wave with two waves per SIMD) and spilled 62 of them into the loop
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();  // everyone is done with `buf` before the next iteration's pieces overwrite it
             buf ^= 1;
         }
     }
@@ -162,9 +171,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(P + (long)(nrow + 16 * i) * Kp + kcol + 16 * j) = acc[i][j];
-    if (do_bias && g == 0) {  // every row of the ones product holds the column sums: take row 0 (lanes 0 .. 15, register 0)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) bias_partial[(long)split * Np + nrow + 16 * i] = bacc[i][0];
+    if (bias_n > 0 && g == 0) {  // every row of the ones product holds the column sums: take row 0 (lanes 0 .. 15, register 0)
+        bias_partial[(long)split * Np + nrow + 16 * bias_first] = bacc[0][0];
+        if (bias_n > 1) bias_partial[(long)split * Np + nrow + 16 * (bias_first + 1)] = bacc[1][0];
     }
 }
 
@@ -177,12 +186,22 @@ __global__ __launch_bounds__(256) void tn16_reduce_kernel(const float *__restric
     if (idx4 * 4 >= count) return;
     const int n = (int)((idx4 * 4) / Kp), k = (int)((idx4 * 4) % Kp);
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int sp = 0; sp < nsplit; ++sp) {
-        const float4 v = *reinterpret_cast<const float4 *>(partial + (long)sp * count + idx4 * 4);
-        s.x += v.x;
-        s.y += v.y;
-        s.z += v.z;
-        s.w += v.w;
+    // 16 loads in flight, then added in ascending order (a thread that loads and adds one split at a time waits out 16 memory latencies:
+    // 38-77 us per 1024 x 1024 gradient)
+    for (int s0 = 0; s0 < nsplit; s0 += 16) {
+        float4 v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            v[e] = s0 + e < nsplit ? *reinterpret_cast<const float4 *>(partial + (long)(s0 + e) * count + idx4 * 4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (s0 + e < nsplit) {
+                s.x += v[e].x;
+                s.y += v[e].y;
+                s.z += v[e].z;
+                s.w += v[e].w;
+            }
+        }
     }
     for (long m = m_begin; m < M; ++m) {
         const float gz = (float)dZ[m * ldz + n];
@@ -201,7 +220,14 @@ __global__ __launch_bounds__(256) void tn16_bias_reduce_kernel(const float *__re
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= Np) return;
     float s = 0.0f;
-    for (int sp = 0; sp < nsplit; ++sp) s += bias_partial[(long)sp * Np + n];
+    for (int s0 = 0; s0 < nsplit; s0 += 16) {  // 16 loads in flight, added in ascending order
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = s0 + e < nsplit ? bias_partial[(long)(s0 + e) * Np + n] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (s0 + e < nsplit) s += v[e];
+    }
     for (long m = m_begin; m < M; ++m) s += (float)dZ[m * ldz + n];
     grad_b[n] = s;
 }

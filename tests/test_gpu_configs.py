@@ -439,4 +439,6 @@ def test_bench_default_line_carries_every_single_gpu_config(dev):
     assert tb["dtype"] == "bf16" and tb["finite"] and tb["iteration_ms"] < 0.5 * tr["iteration_ms"] and tb["wgrad_1024x1024"]["frac"] > 0.15
     for k in ("c5_bf16", "c2_bf16"):        # the layer chain's self-checks, in the record
         assert nw[k]["chain"]["launches"] > 0 and nw[k]["chain"]["chain_error"] is False
-    assert nw["seconds"] < 40
+    fr128 = nw["c1_frame_chunks128"]        # the reference's CLI default chunk size, through the grouped-chunk path
+    assert fr128["finite"] and fr128["chunks"] == 128 and fr128["rays_per_s"] > 5e4
+    assert nw["seconds"] < 45
