@@ -130,7 +130,11 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
         const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
 
         // ONE barrier per stage: behind it every wave has its pieces of stage s in the LDS and has finished reading the other buffer (stage
-        // s - 1), so the pieces of stage s + 1 go out right there and have the whole stage's matrix work to land
+        // s - 1), so the pieces of stage s + 1 go out right there and have the whole stage's matrix work to land.
+        // (Measured and rejected, profiles/r05/bf16_wgrad_pipelined_halves_SLOWER.jsonl: the loop over 32-row halves in four LDS quarters with
+        // the fragments of half i + 1 read into a second register set "under" the MFMAs of half i and one barrier per half - 1.41 instead of
+        // 1.27 ms per 1024^2 layer: lgkmcnt counts at most 15 LDS operations, so the 24 reads in front of the MFMAs are waited for anyway,
+        // and the barrier count doubles.)
         issue(0, 0u, 0u);
         int buf = 0;
         for (long s = s_begin; s < s_end; ++s) {

@@ -113,14 +113,31 @@ class _PackedMLP:
         self.in_pad = ops.round_up(first.in_features, pad)
         self.h_pad = ops.round_up(first.out_features, pad)
         pack = {0: ops.pack_linear, 1: ops.pack_linear_bf16, 2: ops.pack_linear_bf16x3}[bf16]
-        self.w, self.b = [], []
         if bf16:
+            self.key = None  # a refused packing must not look current to the next call
             # The bf16 matrix pipe answers a NaN operand with the default NaN 0xFFC00000 (sign bit set), which its packed integer-max
             # ReLU reads as a negative number: no NaN survives a ReLU layer.  NaN FEATURES are carried around the MLP by per-sample
             # flags (the finishers poison those samples, as nn.ReLU would have); a NaN PARAMETER cannot be - refuse it loudly.
-            if bool(torch.stack([torch.isnan(p.detach()).any() for p in params]).any()):  # ONE device-to-host sync
-                raise RuntimeError("mlp_dtype='bf16' / 'bf16x3': the parameters hold NaN values; the bf16 matrix pipe cannot propagate them "
-                                   "the way nn.ReLU does (the reference renders NaN) - use mlp_dtype='fp32' for this checkpoint")
+            # ONE reduction on the device.  Rendering (the key decides: a re-pack is rare) waits for it here.  Training re-packs on every
+            # forward (`always`): the flag travels to pinned memory behind an event and is looked at by the NEXT re-pack - by then it has long
+            # arrived, so a training step never stalls on it and a NaN parameter is still refused, one forward late.
+            flag = torch.stack([torch.isnan(p.detach()).any() for p in params]).any()
+            msg = ("mlp_dtype='bf16' / 'bf16x3': the parameters hold NaN values; the bf16 matrix pipe cannot propagate them "
+                   "the way nn.ReLU does (the reference renders NaN) - use mlp_dtype='fp32' for this checkpoint")
+            if always:
+                pending = getattr(self, "_nan_pending", None)
+                host = torch.empty(1, dtype=torch.bool, pin_memory=True)
+                host.copy_(flag.reshape(1), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(first.weight.device))
+                self._nan_pending = (host, ev)
+                if pending is not None:
+                    pending[1].synchronize()
+                    if bool(pending[0][0]):
+                        raise RuntimeError(msg)
+            elif bool(flag):
+                raise RuntimeError(msg)
+        self.w, self.b = [], []
         for i, lin in enumerate(hidden_layers):
             if i == 0 and bf16 == 2:  # bf16x3: the first layer multiplies all 24 bits of features and weights ("x6")
                 wp, bp = ops.pack_linear_bf16x6(lin.weight, lin.bias, self.h_pad, self.in_pad)

@@ -243,3 +243,22 @@ def test_training_descends_end_to_end_bf16(dev):
     assert np.isfinite(last) and last > first + 3.0 and last > f32["trajectory"][-1]["psnr"] - 1.5, (f32, b16)
     rnd = train_demo.run(**kw, mlp_dtype="bf16", randomized=True)
     assert rnd["trajectory"][-1]["psnr"] > rnd["trajectory"][0]["psnr"] + 3.0, rnd
+
+
+def test_nan_parameter_is_refused_in_training_mode_one_forward_late(dev):
+    """the NaN-parameter guard of the bf16 modes used to cost ~30 host syncs per forward in training mode (one per
+    tensor, every forward re-packs).  Now: one reduction on the device, its flag copied to pinned memory behind an event and read by the
+    NEXT re-pack - no stall in a training step, and a NaN parameter is still refused (the bf16 pipe's ReLU would drop it silently)."""
+    sd = synthetic.make_state_dict(64, 128, seed=3)
+    m = _bf16_model(sd, dev, 16, 64, 128, False)
+    rays = dev_rays(synthetic.make_rays("lego", 32, seed=4), dev)
+    m.prop_net.forward(rays)
+    with torch.no_grad():
+        m.prop_net.model[2].weight[1, 1] = float("nan")
+    m.prop_net.forward(rays)  # this packing's flag is looked at by the next one
+    with pytest.raises(RuntimeError, match="parameters hold NaN"):
+        m.prop_net.forward(rays)
+    m.eval()
+    with pytest.raises(RuntimeError, match="parameters hold NaN"):
+        with torch.no_grad():
+            m(rays)
