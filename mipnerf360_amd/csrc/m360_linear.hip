@@ -968,7 +968,12 @@ int m360_linear_wgrad_bf16(const void *dz, int ldz, const void *x, int ldx, long
         wgrad_bf16_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
         float *partial = static_cast<float *>(workspace);
         float *bias_part = reinterpret_cast<float *>(static_cast<char *>(workspace) + up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)));
-        hipLaunchKernelGGL(tn16::linear_tn_bf16_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn16::kThreads), 0, st, dzb, ldz, xb, ldx, n_pad, k_pad, partial, k_pad / tn16::BT, ntiles, nsplit, total, per, grad_b ? bias_part : nullptr);
+#ifdef M360_DIAG  // diagnostics build only (make diag; tools/diag/wgrad_bf16_probe.py with M360_LIB=libm360_diag.so): ablations, wrong results when != 0
+        static const int abl = getenv("M360_TN16_ABL") ? atoi(getenv("M360_TN16_ABL")) : 0;
+#else
+        const int abl = 0;
+#endif
+        hipLaunchKernelGGL(tn16::linear_tn_bf16_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn16::kThreads), 0, st, dzb, ldz, xb, ldx, n_pad, k_pad, partial, k_pad / tn16::BT, ntiles, nsplit, total, per, grad_b ? bias_part : nullptr, abl);
         const long count4 = (long)n_pad * k_pad / 4;
         hipLaunchKernelGGL(tn16::tn16_reduce_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, partial, nsplit, n_pad, k_pad, dzb, ldz, xb, ldx, total * tn16::BKM, M, grad_w);
         if (grad_b) hipLaunchKernelGGL(tn16::tn16_bias_reduce_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, bias_part, nsplit, n_pad, dzb, ldz, total * tn16::BKM, M, grad_b);

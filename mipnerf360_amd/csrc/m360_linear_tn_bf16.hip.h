@@ -47,7 +47,8 @@ __device__ __forceinline__ int swz(int r) { return (r & 3) | (((r >> 3) & 1) << 
 __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
     const __bf16 *__restrict__ dZ, int ldz, const __bf16 *__restrict__ X, int ldx, int Np, int Kp,
     float *__restrict__ partial /*[nsplit][Np][Kp]*/, int tiles_k, int ntiles, int nsplit, long total_steps,
-    long steps_per_split, float *__restrict__ bias_partial /*[nsplit][Np] or nullptr*/) {
+    long steps_per_split, float *__restrict__ bias_partial /*[nsplit][Np] or nullptr*/,
+    int abl = 0 /* diagnostics (M360_TN16_ABL, wrong results): 1 = no MFMAs, 2 = no fragment reads, 4 = no LDS-DMA, 8 = no barrier */) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes];  // 128 KiB
 
     const int tid = threadIdx.x;
@@ -122,6 +123,14 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
         unsigned bias_off[2];  // the blocks this wave sums for the bias gradient (read once more: no dynamic choice among the fragments in registers)
 #pragma unroll
         for (int e = 0; e < 2; ++e) bias_off[e] = lds0 + lane_off + (unsigned)((((bias_first + e) & 7) ^ f) + 8 * wn) * 32u;
+        // one piece pair (dZ + X piece i) of the next stage: issued BETWEEN the MFMAs of the stage's first k-step (an LDS-DMA issue - M0 write +
+        // buffer_load .. lds - costs a wave 100-185 cycles when it stands alone and nothing in an MFMA gap; the eight of a stage in one burst
+        // behind the barrier: 1.28 instead of 1.15 ms per 1024^2 layer) and still most of a stage ahead of their use
+        auto issue_pair = [&](int buf, int i, unsigned soff_a, unsigned soff_b) __attribute__((always_inline)) {
+            char *dst = dma_dst + buf * kStageBytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(dst + i * 1024), 16, va[i], soff_a, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(dst + kOperandBytes + i * 1024), 16, vb[i], soff_b, 0, 0);
+        };
         auto frag = [&](unsigned addr) __attribute__((always_inline)) -> bf16x8 {
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)addr);
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(addr + 4 * kRowBytes));
@@ -130,7 +139,14 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
         const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
 
         // ONE barrier per stage: behind it every wave has its pieces of stage s in the LDS and has finished reading the other buffer (stage
-        // s - 1), so the pieces of stage s + 1 go out right there and have the whole stage's matrix work to land.
+        // s - 1), so the pieces of stage s + 1 may go out (issue_pair, in the first k-step's MFMA gaps) and have most of the stage to land.
+        // What the 1.15 ms of a 1024^2 layer are made of (M360_TN16_ABL ablations, profiles/r05/wgrad_bf16_ablation*.txt): LDS-DMA +
+        // barriers alone 0.76 ms (one stage = 64 KB per CU in flight against ~1.5 us of L2 -> LDS latency: 44 GB/s per CU), MFMAs + barriers
+        // alone 0.65 (the matrix work itself: 0.45), fragment reads + barriers alone 0.35; SQ_LDS_BANK_CONFLICT = 0; MFMA pipe busy 37 -> 41 %.
+        // The three overlap only partly in an 8-wave, barrier-per-stage loop scheduled by the compiler; the remedy is the ring kernel's
+        // structure (one wave per SIMD, 128 x 128 wave tiles, a generated schedule) - not built for this operand layout yet.
+        // Also measured: the transposed reads as inline assembly with counted lgkmcnt waits (the compiler puts s_waitcnt vmcnt(0) in front of
+        // LDS reads that follow an LDS-DMA issue): 1.17 ms, no gain - kept as builtins.
         // (Measured and rejected, profiles/r05/bf16_wgrad_pipelined_halves_SLOWER.jsonl: the loop over 32-row halves in four LDS quarters with
         // the fragments of half i + 1 read into a second register set "under" the MFMAs of half i and one barrier per half - 1.41 instead of
         // 1.27 ms per 1024^2 layer: lgkmcnt counts at most 15 LDS operations, so the 24 reads in front of the MFMAs are waited for anyway,
@@ -139,26 +155,49 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
         int buf = 0;
         for (long s = s_begin; s < s_end; ++s) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (s + 1 < s_end) {
-                const unsigned rows = (unsigned)(s + 1 - s_begin) * BKM;
-                issue(buf ^ 1, rows * (unsigned)ldz * 2u, rows * (unsigned)ldx * 2u);
-            }
+            if (!(abl & 8)) __syncthreads();
+            const bool more = s + 1 < s_end && !(abl & 4);  // wave-uniform
+            const unsigned nrows = (unsigned)(s + 1 - s_begin) * BKM;
+            const unsigned soff_a = nrows * (unsigned)ldz * 2u, soff_b = nrows * (unsigned)ldx * 2u;
             const unsigned boff = buf ? (unsigned)kStageBytes : 0u;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 fa[8], fb[4];
+                bf16x8 fbias[2] = {ones, ones};  // read WITH the other fragments: a read right in front of its MFMA exposes the LDS latency twice per stage
+                if (bias_n > 0) fbias[0] = frag(bias_off[0] + boff + ks * 32 * kRowBytes);
+                if (bias_n > 1) fbias[1] = frag(bias_off[1] + boff + ks * 32 * kRowBytes);
+                if (!(abl & 2)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = frag(b_off[j] + boff + ks * 32 * kRowBytes);
+                    for (int j = 0; j < 4; ++j) fb[j] = frag(b_off[j] + boff + ks * 32 * kRowBytes);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) fa[i] = frag(a_off[i] + boff + ks * 32 * kRowBytes);
+                    for (int i = 0; i < 8; ++i) fa[i] = frag(a_off[i] + boff + ks * 32 * kRowBytes);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                    for (int j = 0; j < 4; ++j) fb[j] = ones;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 8; ++i) fa[i] = ones;
+                }
+                if (abl & 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fb[j]));
+                    if (more && ks == 0) issue(buf ^ 1, soff_a, soff_b);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                        if (ks == 0 && (i & 1)) {  // the next stage's four piece pairs, each behind 8 MFMAs of the first k-step
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) issue_pair(buf ^ 1, i >> 1, soff_a, soff_b);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
                 if (bias_n > 0) {
-                    bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, frag(bias_off[0] + boff + ks * 32 * kRowBytes), bacc[0], 0, 0, 0);
-                    if (bias_n > 1) bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, frag(bias_off[1] + boff + ks * 32 * kRowBytes), bacc[1], 0, 0, 0);
+                    bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fbias[0], bacc[0], 0, 0, 0);
+                    if (bias_n > 1) bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fbias[1], bacc[1], 0, 0, 0);
                 }
                 // one k-step's 12 fragments at a time: with both k-steps' reads hoisted to the top of the stage the kernel needs 300+ registers
                 // (256 per wave with two waves per SIMD) and spilled 62 of them into the loop

@@ -193,6 +193,35 @@ def test_g21_structured_gradients_bf16(golden, dev, kind):
 NERF_REL, PROP_REL = 3e-2, 8e-2  # full width against the fp32 mirrors (measured 1.2e-2 / 1.8e-2: wide layers average the rounding noise)
 
 
+@pytest.mark.parametrize("B,N,Nf", [(77, 37, None), (130, 32, 48)])
+def test_ragged_full_width_gradients_bf16_vs_fp32_mirrors(dev, B, N, Nf):
+    """Row counts that are no multiple of anything (77 x 37 = 2849 rows: 11 full 256-row tiles + 33 ragged rows; the weight-gradient
+    kernel's 64-row stages + a tail added by its reduce kernel) and a NeRF stage with its own sample count (`num_samples_fine`): the bf16
+    gradients against the fp32 mirrors', full width."""
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf
+    from mipnerf360_amd.model import mipNeRF360
+    sd = synthetic.make_state_dict(256, 1024, seed=14)
+    rays = dev_rays(synthetic.make_rays("lego", B, seed=16), dev)
+    pixels = torch.rand(B, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    grads = {}
+    for dtype in ("fp32", "bf16"):
+        m = mipNeRF360(randomized=False, num_samples=N, num_samples_fine=Nf, hidden_proposal=256, hidden_nerf=1024, white_bkgd=True, device=dev, mlp_dtype=dtype).train()
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        with torch.no_grad():
+            t_hat, w_hat = m.prop_net.forward(rays)
+        rgb, dist, acc, _, fw, sv = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        assert fw.shape == (B, Nf or N)
+        ln, _ = Loss_nerf(input=rgb, target=pixels)
+        m.zero_grad()
+        (ln + 0.01 * Loss_dist(s_vals=sv, weights=fw) + 0.1 * acc.sum() + 0.05 * dist.sum()).backward()
+        grads[dtype] = {n: p.grad.clone() for n, p in m.named_parameters() if n.startswith("nerf_net")}
+        del m
+    pairs = [(grads["bf16"][n], H(grads["fp32"][n])) for n in grads["fp32"]]
+    rel, cos = max(_rel(a, b) for a, b in pairs), _cos(pairs)
+    print(f"ragged {B} x {N} (+{Nf}) full width, NeRF step incl. acc / distance gradients: max rel {rel:.2e} cos {cos:.6f}")
+    assert rel <= 2 * NERF_REL and cos >= COS_MIN and all(torch.isfinite(a).all() for a, _ in pairs), (rel, cos)
+
+
 def test_full_width_gradients_bf16_vs_fp32_mirrors(dev):
     """Full width (256 / 1024: the MFMA weight-gradient kernel, the zero-padded first-layer operand, the ring kernel as input-gradient
     kernel) at 512 rays x 64 samples: the bf16 gradients of one NeRF update and one proposal update against the fp32 mirrors' (which
