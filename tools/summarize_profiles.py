@@ -131,15 +131,24 @@ def markdown(tag):
                 if not isinstance(v, dict):
                     continue
                 if "iteration_ms" in v:
-                    out.append(f"* `{k}` (train.py:53-82 at 4096 x 128, fp32): **{v['iteration_ms']:.1f} ms per iteration = {v['train_rays_per_s']:.0f} rays/s** "
+                    out.append(f"* `{k}` (train.py:53-82 at 4096 x 128, {v.get('dtype', 'f32')}): **{v['iteration_ms']:.1f} ms per iteration = {v['train_rays_per_s']:.0f} rays/s** "
                                f"(proposal update {v['prop_update_ms']:.1f} ms x 2, NeRF update {v['nerf_update_ms']:.1f} ms = {v['nerf_update_tflops']:.1f} TF sustained); "
                                f"wgrad 1024x1024 {v['wgrad_1024x1024']['ms']:.3f} ms = {v['wgrad_1024x1024']['tflops']:.1f} TF = {v['wgrad_1024x1024']['frac']:.3f}, "
                                f"dgrad {v['dgrad_1024x1024']['ms']:.3f} ms = {v['dgrad_1024x1024']['tflops']:.1f} TF = {v['dgrad_1024x1024']['frac']:.3f} of {v['peak']:.1f}; "
                                f"peak memory {v['peak_mem_gb']:.1f} GB")
                 else:
                     r_ = v.get("roofline") or {}
-                    out.append(f"* `{k}` (dtype {v['dtype']}): **{v['rays_per_s']:.0f} rays/s, {v['ms_per_step']:.3f} ms/step**, dominant kernel "
-                               f"{r_.get('achieved', 0):.0f} TF = {r_.get('frac', 0):.3f} of {r_.get('peak', 0):.0f}")
+                    line = f"* `{k}` (dtype {v['dtype']}): **{v['rays_per_s']:.0f} rays/s, {v['ms_per_step']:.3f} ms/step**"
+                    if r_:
+                        line += f", dominant kernel {r_.get('achieved', 0):.0f} TF = {r_.get('frac', 0):.3f} of {r_.get('peak', 0):.0f}"
+                        if r_.get("traffic"):
+                            line += f", counter traffic {r_['traffic'] / 1e9:.2f} GB per launch against {r_.get('algorithmic_bytes', 0) / 1e9:.2f} GB algorithmic"
+                    elif "frac_of_fp32_mfma_peak" in v:
+                        line += f" ({v.get('n_chunks', '?')} chunks of {v.get('chunks', '?')} rays), whole path {v['whole_path_tflops']:.1f} TF = {v['frac_of_fp32_mfma_peak']:.3f} of the fp32-MFMA roofline"
+                    ch = v.get("chain")
+                    if ch:
+                        line += f"; layer chain: {ch['launches']} launches, {ch['recoveries']} repaired, {ch['timeouts']} waits ran out, {ch['xcc_mismatch']} workgroups off their XCD"
+                    out.append(line)
             out.append("")
     dom = os.path.join(d, "dominant_kernel_launches.csv")
     if os.path.exists(dom):
@@ -196,6 +205,27 @@ def markdown(tag):
                 extra += f"; {r['layer_algorithmic_tflops']:.1f} TF in units of the fp32 layer's FLOPs"
             out.append(f"* {label}: **{x['value']:.0f} rays/s, {x['ms_per_step']:.3f} ms/step**, dtype {x['dtype']}, dominant kernel "
                        f"{r.get('achieved', 0):.0f} TF = {r.get('frac', 0):.3f} of {r.get('peak', 0):.0f}{extra} (`profiles/{tag}/{name}`)")
+    hk = os.path.join(d, "hbm_kernels_sq_counters.json")
+    if os.path.exists(hk):
+        h = json.load(open(hk)).get("fp32", {})
+        parts = []
+        for nm in ("stage_prologue_kernel", "encode_features_wave_kernel", "prop_finish_kernel", "nerf_finish_kernel"):
+            e = h.get(nm)
+            if e and e.get("per_wave"):
+                pw = e["per_wave"]
+                us = [v for k, v in e.items() if k.startswith("launch_us_under_pmc")]
+                parts.append(f"`{nm}` {sum(us) / len(us):.1f} us, {e['SQ_WAVES']:.0f} waves: per wave {4 * pw['SQ_WAVE_CYCLES']:.0f} cycles resident, {pw['SQ_INSTS_VALU']:.0f} vector + "
+                             f"{pw['SQ_INSTS_SALU']:.0f} scalar + {pw.get('SQ_INSTS_LDS', 0):.0f} LDS + {pw.get('SQ_INSTS_VMEM_RD', 0) + pw.get('SQ_INSTS_VMEM_WR', 0):.0f} memory instructions, "
+                             f"waiting on an operand {100 * e['waiting_fraction_of_wave_cycles']:.0f} %")
+        if parts:
+            out += ["", "SQ counters of the path's small kernels (`hbm_kernels_sq_counters.json`, separate `--pmc` passes; SQ cycle counters are quad-cycles, x 4 here): " + "; ".join(parts) + ".", ""]
+    ts = os.path.join(d, "train_step_bf16.json")
+    if os.path.exists(ts):
+        t = _bench_line(ts)
+        if t:
+            out += [f"bf16 training iteration alone (`train_step_bf16.json`, `tools/train_step_bench.py --mlp-dtype bf16`): {t['iteration_ms']} ms (proposal update {t['prop_step_ms']} ms, NeRF update "
+                    f"{t['nerf_step_ms']} ms = {t['nerf_step_tflops']} TF); dW of a 1024^2 layer {t['wgrad_ms']} ms ({t['wgrad_nobias_ms']} without the bias gradient), dX {t['dgrad_ms']} ms "
+                    f"({t['dgrad_nomask_ms']} without the ReLU mask pass); peak memory {t['peak_mem_gb']} GB; kernel times of the iteration: `rocprofv3_kernel_stats_train_bf16.csv`.", ""]
     return "\n".join(out) + "\n"
 
 
@@ -308,7 +338,8 @@ def main():
     os.makedirs(dst, exist_ok=True)
     shutil.copy(one(f"{src}/stats/*/*_kernel_stats.csv"), f"{dst}/rocprofv3_kernel_stats_bench.csv")
     for extra in ("bench.json", "bench_under_rocprof.log", "bench_bf16.json", "bench_c5.json", "bench_bf16x3.json", "bench_c5_bf16x3.json", "rocprofv3_kernel_stats_bench_bf16x3.csv", "rocprofv3_kernel_stats_bench_bf16.csv", "bench_c4.json", "bench_c4_bf16.json", "bench_c4_bf16x3.json",
-                  "bench_gloo2.json", "pytest_gpu.log", "smoke.log", "nccl2.err", "nccl2.out"):
+                  "bench_gloo2.json", "pytest_gpu.log", "smoke.log", "nccl2.err", "nccl2.out", "train_step_bf16.json", "train_step_fp32.json", "rocprofv3_kernel_stats_train_bf16.csv",
+                  "g20_recipe_in_bf16.json", "g20_recipe_in_fp32.json"):
         if os.path.exists(f"{src}/{extra}"):
             shutil.copy(f"{src}/{extra}", f"{dst}/{extra}")
     for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
