@@ -306,3 +306,37 @@ def test_bf16_frames_over_two_ranks_with_the_overlapped_gather(dev):
         ch = line["chain"]
         assert ch["launches"] > 0 and ch["recoveries"] <= ch["launches"] and ch["chain_error"] == (ch["recoveries"] > 0), ch
     assert one["chain"]["recoveries"] == 0, one["chain"]  # alone on the GPU nothing needs repairing
+
+
+@pytest.mark.parametrize("fault", [0, 2])
+def test_bf16_forward_in_a_captured_hip_graph(dev, fault):
+    """the chain used to probe the device from inside the first bf16 forward (hipMalloc, a kernel on the null stream, a
+    blocking copy) - impossible under stream capture.  Nothing is probed any more: the whole bf16 forward - chain launch, its memset,
+    the six gated launches - is captured into ONE HIP graph and replayed; replays equal the eager bits, the status block counts every
+    replay, and a fault baked into the captured launch (every wave gives up at its first wait) is repaired on every replay."""
+    from mipnerf360_amd import ops
+    _skip_unless_chain()
+    model, rays = _bf16_model(dev), _rays(dev, 512)
+    with torch.no_grad():
+        want = [o.clone() for o in model(rays)]
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.no_grad(), torch.cuda.stream(side):
+        for _ in range(2):
+            model(rays)  # this stream's scratch buffer and the packing, outside the capture
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        before = model.chain_status()
+    ops.set_chain_debug(0, fault)
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g, stream=side):
+        res = model(rays)
+    ops.set_chain_debug(0, 0)
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(res, want):
+            assert torch.equal(a, b)
+    with torch.cuda.stream(side):
+        after = model.chain_status()
+    assert after["launches"] - before["launches"] == 3 and after["recoveries"] - before["recoveries"] == (3 if fault else 0), (before, after)
