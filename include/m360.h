@@ -220,6 +220,9 @@ int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_b
  *   m360_linear_wgrad_bf16: dW[n_pad, k_pad] = dZ^T X and db[n_pad] = column sums of dZ (NULL to skip) in fp32 from bf16 rows.  n_pad, k_pad
  *     multiples of 256 run on v_mfma_f32_16x16x32_bf16 (both operands transposed on their way out of the LDS by ds_read_b64_tr_b16; row splits
  *     reduced in a fixed order: deterministic); other pads (multiples of 32: reduced-width models) are widened to fp32 for m360_linear_wgrad. */
+/* A/B switch of m360_linear_wgrad_bf16's MFMA form, process-wide like m360_set_paired_rows: 1 (default) = one wave per SIMD with 128 x 128 wave tiles
+ * and the LDS filled four k-steps ahead, 0 = the 8-wave kernel; both deterministic, results equal up to fp32 summation order.  Returns the old setting. */
+int m360_set_wgrad_bf16_form(int form);
 int m360_pack_linear_bf16_transposed(const float *w, int n_out, int k_in, int n_pad, int k_pad, void *wt_packed_bf16 /*[k_pad, n_pad]*/,
                                      m360_stream_t stream);
 int m360_linear_dgrad_bf16(const void *dz_bf16, long M, int ldz, const void *wt_packed_bf16, int k_pad, int n_pad, const void *relu_out_bf16,

@@ -33,6 +33,7 @@
 #endif
 #include "m360_linear_tn.hip.h"
 #include "m360_linear_tn_bf16.hip.h"
+#include "m360_linear_tn_bf16_w.hip.h"
 #ifdef M360_DIAG  // diagnostics build only: stamped twins of the product kernels + the two bf16 structures that lost the A/B
 #include "diag/m360_diag.h"
 #include "diag/m360_linear_bf16_sp.hip.h"
@@ -929,6 +930,11 @@ int m360_linear_dgrad_bf16(const void *dz, long M, int ldz, const void *wt_packe
     return check_launch("linear_dgrad_bf16 (ReLU mask)");
 }
 
+// which MFMA form m360_linear_wgrad_bf16 runs (A/B switch, process-wide like m360_set_paired_rows): 1 = one wave per SIMD, 128 x 128 wave tiles,
+// five LDS quarters (m360_linear_tn_bf16_w.hip.h), 0 = the 8-wave kernel of m360_linear_tn_bf16.hip.h.  Both deterministic; their row splits differ, so
+// their results agree to fp32 summation order, not bit for bit.
+static int g_wgrad_bf16_form = 1;
+int m360_set_wgrad_bf16_form(int form) { const int was = g_wgrad_bf16_form; g_wgrad_bf16_form = form ? 1 : 0; return was; }
 static bool wgrad_bf16_on_mfma(long M, int n_pad, int k_pad, int ldz, int ldx) {
     return n_pad % tn16::BT == 0 && k_pad % tn16::BT == 0 && ldz % 8 == 0 && ldx % 8 == 0 && M >= tn16::BKM;
 }
@@ -968,6 +974,14 @@ int m360_linear_wgrad_bf16(const void *dz, int ldz, const void *x, int ldx, long
         wgrad_bf16_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
         float *partial = static_cast<float *>(workspace);
         float *bias_part = reinterpret_cast<float *>(static_cast<char *>(workspace) + up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)));
+        if (g_wgrad_bf16_form == 1 && k_pad >= 4 * tn16w::BT) {  // one wave per SIMD: k-steps of 32 rows, the same number of splits (>= 4 k tiles: its bias sums)
+            const long total32 = M / tn16w::KS, per32 = (total32 + nsplit - 1) / nsplit;
+            hipLaunchKernelGGL(tn16w::linear_tn_bf16_w_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn16w::kThreads), 0, st, dzb, ldz, xb, ldx, n_pad, k_pad, partial, k_pad / tn16w::BT, ntiles, nsplit, total32, per32, grad_b ? bias_part : nullptr);
+            const long count4w = (long)n_pad * k_pad / 4;
+            hipLaunchKernelGGL(tn16::tn16_reduce_kernel, dim3((unsigned)((count4w + 255) / 256)), dim3(256), 0, st, partial, nsplit, n_pad, k_pad, dzb, ldz, xb, ldx, total32 * tn16w::KS, M, grad_w);
+            if (grad_b) hipLaunchKernelGGL(tn16::tn16_bias_reduce_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, bias_part, nsplit, n_pad, dzb, ldz, total32 * tn16w::KS, M, grad_b);
+            return check_launch("linear_wgrad_bf16 (one-wave form)");
+        }
 #ifdef M360_DIAG  // diagnostics build only (make diag; tools/diag/wgrad_bf16_probe.py with M360_LIB=libm360_diag.so): ablations, wrong results when != 0
         static const int abl = getenv("M360_TN16_ABL") ? atoi(getenv("M360_TN16_ABL")) : 0;
 #else

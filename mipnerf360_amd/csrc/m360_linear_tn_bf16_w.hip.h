@@ -1,0 +1,209 @@
+// Weight-gradient GEMM of the bf16 training path, second form (round 5): ONE wave per SIMD with 128 x 128 wave tiles - the structure of the
+// forward ring kernel (m360_linear_bf16_w16.hip.h) for the "row = contraction index" operand layout of dW = dZ^T X.
+//
+// Why a second form: the 8-wave kernel (m360_linear_tn_bf16.hip.h) reads 24 fragments per 32 MFMAs and wave, meets at one barrier per 64-row
+// stage and prefetches ONE stage ahead; its ablations (profiles/r05/wgrad_bf16_ablation*.txt) show LDS-DMA, fragment reads and matrix work
+// overlapping only partly (0.76 / 0.35 / 0.65 ms alone, 1.15 ms together per 1024^2 layer; MFMA pipe busy 41 %).  Here:
+//   * 4 waves, wave tile 128 (n) x 128 (k) = 8 x 8 blocks of v_mfma_f32_16x16x32_bf16: 256 accumulators in AccVGPRs (MFMAs as inline assembly with
+//     "+a" operands, as in the ring kernel), 16 fragments = 32 ds_read_b64_tr_b16 per 64 MFMAs: two thirds of the LDS read traffic per flop;
+//   * the unit of the loop is a k-step of 32 rows; the LDS holds FIVE such "quarters" (5 x 32 KiB = all 160 KiB), filled four k-steps ahead of the
+//     matrix work by LDS-DMA (8 pieces per wave and k-step, one per 8 MFMAs) - the lead the L2 -> LDS latency needs (~1.5 us under load against
+//     ~0.45 us of matrix work per k-step);
+//   * the fragments of k-step i + 1 are read BETWEEN the MFMAs of k-step i (two per 8 MFMAs: the X fragment a group has just finished with is
+//     overwritten in place, the dZ fragments alternate between two register sets), behind the one barrier of the k-step that makes quarter i + 1
+//     complete for every wave;
+//   * the LDS-DMA instructions are inline assembly (M0 write + buffer_load_dwordx4 .. lds): the compiler must not know that they write the LDS, or
+//     it puts s_waitcnt vmcnt(0) in front of every LDS read behind one (which waits for pieces issued four k-steps ahead); the transposed reads are
+//     the ds_read_tr16_b64 builtin (register pairs assembled without copies, lgkmcnt waits placed by the compiler per fragment).  The orderings
+//     that matter are kept by hand: vmcnt(16) + s_barrier in front of the first read of a quarter, and a quarter is refilled only behind the
+//     barrier after its last read.
+// Same LDS image (512-byte rows, 32-byte units XOR-swizzled by f(r): conflict-free transposed reads), same (tile, split) decomposition, same
+// deterministic split reduction and the same bits in the partial sums' layout as the 8-wave kernel.
+#pragma once
+#include "m360_linear_tn_bf16.hip.h"
+
+namespace m360 {
+namespace tn16w {
+
+using tn16::bf16x8;
+using tn16::f32x4;
+using tn16::lds_s16x4_p;
+using tn16::s16x4;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BT = 256;                 // output tile edge
+constexpr int KS = 32;                  // rows (contraction) per k-step = per LDS quarter
+constexpr int kThreads = 256;
+constexpr int kRowBytes = BT * 2;       // 512
+constexpr int kOpBytes = KS * kRowBytes;  // 16 KiB: one operand of one k-step
+constexpr int kQuarterBytes = 2 * kOpBytes;  // dZ rows | X rows
+constexpr int kQuarters = 5;
+
+__global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
+    const __bf16 *__restrict__ dZ, int ldz, const __bf16 *__restrict__ X, int ldx, int Np, int Kp,
+    float *__restrict__ partial /*[nsplit][Np][Kp]*/, int tiles_k, int ntiles, int nsplit, long total_steps /* k-steps of 32 rows */,
+    long steps_per_split, float *__restrict__ bias_partial /*[nsplit][Np] or nullptr*/) {
+    __shared__ __attribute__((aligned(1024))) char smem[kQuarters * kQuarterBytes];  // 160 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int g = lane >> 4, l15 = lane & 15, q = l15 >> 2, p = l15 & 3;
+
+    const int total = ntiles * nsplit;
+    int split, tile;
+    if (total % 8 == 0 && (total / 8) % ntiles == 0) {  // all tiles of a split on ONE XCD (speed only)
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = j % ntiles;
+        split = x * ((total / 8) / ntiles) + j / ntiles;
+    } else {
+        split = blockIdx.x / ntiles;
+        tile = blockIdx.x % ntiles;
+    }
+    const int kt = tile % tiles_k;
+    const int n0 = (tile / tiles_k) * BT, k0 = kt * BT;
+    const long s_begin = (long)split * steps_per_split;
+    long s_end = s_begin + steps_per_split;
+    if (s_end > total_steps) s_end = total_steps;
+    const long nk = s_end > s_begin ? s_end - s_begin : 0;  // k-steps of this workgroup
+    // bias gradient (the host sends layers with fewer than 4 k tiles to the 8-wave kernel): k tile kt < 4, waves wk == 0 add up dZ blocks 2 kt, 2 kt + 1
+    // of their n half against a fragment of ones - 2 extra MFMAs per 64
+    const bool bias_wave = bias_partial != nullptr && wk == 0 && kt < 4;
+    f32x4 acc[8][8], bacc[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[a][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    if (nk > 0) {
+        // ---- LDS-DMA: wave w stages pieces 4w .. 4w+3 of each operand of a quarter (rows 8w .. 8w+7 of its 32); lane L of a piece lands at byte 16 L =
+        // row 2 pi + (L >> 5), 16-byte slot L & 31, and fetches the chunk whose 32-byte unit the swizzle puts there
+        unsigned va[4], vb[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 2 * (4 * wave + e) + (lane >> 5), s = lane & 31;
+            const int c = 2 * ((s >> 1) ^ tn16::swz(r)) + (s & 1);
+            va[e] = (unsigned)(r * ldz + 8 * c) * 2u;
+            vb[e] = (unsigned)(r * ldx + 8 * c) * 2u;
+        }
+        const unsigned long long pa = (unsigned long long)(dZ + s_begin * KS * ldz + n0), pb = (unsigned long long)(X + s_begin * KS * ldx + k0);
+        i32x4 ra, rb;
+        ra[0] = __builtin_amdgcn_readfirstlane((int)pa); ra[1] = __builtin_amdgcn_readfirstlane((int)(pa >> 32)); ra[2] = 0x7fffffff; ra[3] = 0x00020000;
+        rb[0] = __builtin_amdgcn_readfirstlane((int)pb); rb[1] = __builtin_amdgcn_readfirstlane((int)(pb >> 32)); rb[2] = 0x7fffffff; rb[3] = 0x00020000;
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+        const unsigned dma0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 4u * 1024u);
+        const unsigned step_a = (unsigned)KS * (unsigned)ldz * 2u, step_b = (unsigned)KS * (unsigned)ldx * 2u;  // bytes per k-step
+        // one piece of k-step `ks` (clamped to the last one: the pipeline's tail re-loads rows nobody reads) into quarter `qd`; e = 0..3: dZ, 4..7: X
+#define TNW_DMA(E, QD_OFF, SOFF_A, SOFF_B)                                                                                                   \
+    do {                                                                                                                                     \
+        if ((E) < 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dma0 + (QD_OFF) + (unsigned)((E) & 3) * 1024u), "v"(va[(E) & 3]), "s"(ra), "s"(SOFF_A) : "memory"); \
+        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dma0 + (QD_OFF) + (unsigned)kOpBytes + (unsigned)((E) & 3) * 1024u), "v"(vb[(E) & 3]), "s"(rb), "s"(SOFF_B) : "memory"); \
+    } while (0)
+
+        // ---- transposed fragment reads (tn16): lane (g, q, p) supplies row 8g + q (+ 4) of block c, bytes 8p of its 32-byte unit in slot (c & 7) ^ f;
+        // block a of this wave's operand = base ^ (a << 5) (the slot bits 5 - 7 are nobody else's)
+        const int f = q | ((g & 1) << 2);
+        const unsigned lane_off = (unsigned)((8 * g + q) * kRowBytes + 8 * p);
+        const unsigned a_base = lds0 + lane_off + (unsigned)(f + 8 * wn) * 32u;
+        const unsigned b_base = lds0 + (unsigned)kOpBytes + lane_off + (unsigned)(f + 8 * wk) * 32u;
+        auto frag = [&](unsigned addr) __attribute__((always_inline)) -> bf16x8 {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)addr);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)(addr + 4 * kRowBytes));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
+        const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
+#define TNW_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+// the bias sums: ArchVGPRs (the 256 AccVGPRs are the tile's).  Their operands are VALU results (the selected dZ fragment, the ones): an MFMA must not
+// read a VGPR within 2 wait states of the VALU write, and behind inline assembly the hazard recogniser cannot insert them - hence the s_nop
+#define TNW_MFMA_V(ACC, A, B) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define TNW_SB() __builtin_amdgcn_sched_barrier(0)
+
+        // ---- prologue: k-steps 0 .. 3 on their way (8 pieces each), quarter 0 awaited and read
+        const long last = nk - 1;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const unsigned ks = (unsigned)(k4 < last ? k4 : last);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) TNW_DMA(e, (unsigned)k4 * (unsigned)kQuarterBytes, ks * step_a, ks * step_b);
+        }
+        asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        __syncthreads();
+        // X fragment j is dead behind its group of 8 MFMAs: the next k-step's is read into the SAME registers right there (an MFMA reads its
+        // sources when it issues; the LDS returns data hundreds of cycles later); the dZ fragments are used by all 8 groups: two sets
+        bf16x8 fa[2][8], fb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fb[j] = frag(b_base ^ (unsigned)(j << 5));
+#pragma unroll
+        for (int a = 0; a < 8; ++a) fa[0][a] = frag(a_base ^ (unsigned)(a << 5));
+
+        unsigned qn = 1;  // quarter of k-step i + 1
+        for (long i = 0; i < nk; i += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {  // the two dZ fragment sets alternate: unrolled so that both are static
+                const long ii = i + par;
+                if (ii < nk) {
+                    // quarter ii + 1 complete (this wave's pieces: all but the 16 youngest of the 24 in flight; everyone's: the barrier), quarter ii - 1 free
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    __syncthreads();
+                    const unsigned qoff = qn * (unsigned)kQuarterBytes;                       // where k-step ii + 1 lies
+                    const unsigned qd = (qn + 3 >= (unsigned)kQuarters ? qn + 3 - kQuarters : qn + 3) * (unsigned)kQuarterBytes;  // quarter of k-step ii + 4 (= of ii - 1)
+                    const unsigned ksn = (unsigned)(ii + 4 < last ? ii + 4 : last);
+                    const unsigned soff_a = ksn * step_a, soff_b = ksn * step_b;
+                    const unsigned aq = a_base + qoff, bq = b_base + qoff;
+                    const bool more = ii + 1 < nk;  // wave-uniform: the last k-step has nothing to read ahead
+                    // the bias sums FIRST: their accumulators live in ArchVGPRs, where the compiler may copy them at the loop's edges - and an MFMA
+                    // result read too early is a software hazard the hazard recogniser cannot see behind inline assembly (a first form that ran
+                    // these two MFMAs at the END of the k-step returned NaNs in the bias gradient): 64 MFMAs later they are long written
+                    if (bias_wave) {
+                        bf16x8 fbias0 = ones, fbias1 = ones;
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr)
+                            if (pr == kt) {
+                                fbias0 = fa[par][2 * pr];
+                                fbias1 = fa[par][2 * pr + 1];
+                            }
+                        TNW_MFMA_V(bacc[0], ones, fbias0);
+                        TNW_MFMA_V(bacc[1], ones, fbias1);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                        for (int a = 0; a < 8; ++a) TNW_MFMA(acc[a][j], fb[j], fa[par][a]);
+                        TNW_SB();  // behind every 8 MFMAs: the next k-step's X fragment j and dZ fragment j, and one LDS-DMA piece
+                        if (more) {
+                            fb[j] = frag(bq ^ (unsigned)(j << 5));
+                            fa[par ^ 1][j] = frag(aq ^ (unsigned)(j << 5));
+                        }
+                        TNW_DMA(j, qd, soff_a, soff_b);
+                        TNW_SB();
+                    }
+                    TNW_SB();
+                    qn = qn + 1 == (unsigned)kQuarters ? 0u : qn + 1;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of this wave may land after the workgroup is gone
+        // the last MFMAs (inline assembly: the hazard recogniser does not see them) have written their accumulators before anything reads them
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#undef TNW_DMA
+#undef TNW_MFMA
+#undef TNW_MFMA_V
+#undef TNW_SB
+    }
+
+    // ---- epilogue: acc[a][j][r] of lane (l15, g) = dW[n0 + 128 wn + 16 a + l15][k0 + 128 wk + 16 j + 4 g + r]
+    float *__restrict__ P = partial + (long)split * Np * Kp;
+    const int nrow = n0 + wn * 128 + l15, kcol = k0 + wk * 128 + 4 * g;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4 *>(P + (long)(nrow + 16 * a) * Kp + kcol + 16 * j) = acc[a][j];
+    if (bias_wave && g == 0) {  // every row of the ones product holds the column sums: row 0 = lanes 0 .. 15, register 0
+        bias_partial[(long)split * Np + nrow + 16 * (2 * kt)] = bacc[0][0];
+        bias_partial[(long)split * Np + nrow + 16 * (2 * kt + 1)] = bacc[1][0];
+    }
+}
+
+}  // namespace tn16w
+}  // namespace m360
