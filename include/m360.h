@@ -200,6 +200,12 @@ int m360_linear_wgrad(const float *dz, int ldz, const float *x, int ldx, long M,
                       float *grad_w, float *grad_b, void *workspace, size_t workspace_bytes,
                       m360_stream_t stream);
 
+/* flag[0] = 1 if any of the n_tensors fp32 tensors (host arrays of device pointers / element counts) holds a NaN, else 0 - ONE launch per
+ * 32 tensors.  The host side of the bf16 modes uses it to refuse NaN parameters (the bf16 matrix pipe's NaN has its sign bit set, and the
+ * packed integer-max ReLU of those modes reads it as a negative number: model.py:43-53,131-148 render NaN through nn.ReLU, these modes
+ * could not). */
+int m360_params_nan_flag(const float *const *tensors, const long *counts, int n_tensors, unsigned *flag, m360_stream_t stream);
+
 /* ---- opt-in bf16 MLP (BASELINE configs[4]): bf16 inputs, fp32 accumulate on v_mfma_f32_16x16x32_bf16.
  * bf16 tensors are passed as raw 16-bit storage (void*).  k_pad multiple of 64, ldx/ldy multiples of 8.  Which kernel takes the
  * full 256 x 256 tiles depends on the call's shape alone: bias + {none, ReLU} with k_pad a multiple of 128 (>= 256) or k_pad = 64

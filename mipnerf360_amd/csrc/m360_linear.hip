@@ -630,6 +630,40 @@ int m360_pack_linear_transposed(const float *w, int n_out, int k_in, int n_pad, 
     return check_launch("pack_linear_transposed");
 }
 
+// ---- NaN scan of a parameter set in ONE launch (the bf16 modes refuse NaN parameters: m360.h) - block (x, t) strides over tensor t
+}  // extern "C"
+namespace m360 {
+constexpr int kNanScanMax = 32, kNanScanBlocks = 16;
+struct nan_scan_t {
+    const float *p[kNanScanMax];
+    long n[kNanScanMax];
+};
+__global__ __launch_bounds__(256) void nan_scan_kernel(nan_scan_t a, unsigned *flag) {
+    const float *__restrict__ p = a.p[blockIdx.y];
+    const long n = a.n[blockIdx.y];
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)kNanScanBlocks * 256) bad |= p[i] != p[i];
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+}  // namespace m360
+extern "C" {
+int m360_params_nan_flag(const float *const *tensors, const long *counts, int n_tensors, unsigned *flag, m360_stream_t stream) {
+    if (!flag || n_tensors < 0 || (n_tensors > 0 && (!tensors || !counts))) return fail(M360_ERR_INVALID_ARGUMENT, "m360_params_nan_flag: null pointer or negative count");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(flag, 0, sizeof(unsigned), st) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_params_nan_flag: memset failed");
+    for (int t0 = 0; t0 < n_tensors; t0 += kNanScanMax) {
+        nan_scan_t a{};
+        const int nt = n_tensors - t0 < kNanScanMax ? n_tensors - t0 : kNanScanMax;
+        for (int t = 0; t < nt; ++t) {
+            if (counts[t0 + t] < 0 || (counts[t0 + t] > 0 && !tensors[t0 + t])) return fail(M360_ERR_INVALID_ARGUMENT, "m360_params_nan_flag: tensor %d: null pointer or negative count", t0 + t);
+            a.p[t] = tensors[t0 + t];
+            a.n[t] = counts[t0 + t];
+        }
+        hipLaunchKernelGGL(nan_scan_kernel, dim3(kNanScanBlocks, (unsigned)nt), dim3(256), 0, st, a, flag);
+    }
+    return check_launch("params_nan_flag");
+}
+
 // ---- opt-in bf16 MLP (fp32 accumulate): weights and activations as raw 16-bit bf16
 int m360_pack_linear_bf16(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                           void *w_packed_bf16, float *b_packed, m360_stream_t stream) {

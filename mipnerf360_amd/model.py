@@ -94,7 +94,7 @@ class _PackedMLP:
     def invalidate(self) -> None:
         self.key = None
 
-    def refresh(self, hidden_layers, heads, bf16: int = 0, always: bool = False) -> "_PackedMLP":
+    def refresh(self, hidden_layers, heads, bf16: int = 0, always: bool = False, defer_nan: bool = False) -> "_PackedMLP":
         """`always`: re-pack even when the (data_ptr, version) key is unchanged.  Writes through `.data`
         (`p.data.mul_()`, EMA swaps, weight clamping) do not bump a tensor's version counter, so in training mode
         - where parameters are expected to change between forwards - the packing is rebuilt on every forward
@@ -118,24 +118,25 @@ class _PackedMLP:
             # The bf16 matrix pipe answers a NaN operand with the default NaN 0xFFC00000 (sign bit set), which its packed integer-max
             # ReLU reads as a negative number: no NaN survives a ReLU layer.  NaN FEATURES are carried around the MLP by per-sample
             # flags (the finishers poison those samples, as nn.ReLU would have); a NaN PARAMETER cannot be - refuse it loudly.
-            # ONE reduction on the device.  Rendering (the key decides: a re-pack is rare) waits for it here.  Training re-packs on every
-            # forward (`always`): the flag travels to pinned memory behind an event and is looked at by the NEXT re-pack - by then it has long
-            # arrived, so a training step never stalls on it and a NaN parameter is still refused, one forward late.
-            flag = torch.stack([torch.isnan(p.detach()).any() for p in params]).any()
+            # ONE launch over all tensors.  Rendering (the key decides: a re-pack is rare; any forward without a tape counts) waits for it
+            # here.  A training step (`defer_nan`: the tape-keeping forward in training mode) re-packs on every forward: the flag travels to
+            # pinned memory behind an event and is looked at by the NEXT re-pack - by then it has long arrived, so a training step never stalls on it and a NaN
+            # parameter is still refused, one forward late.
+            flag = ops.params_nan_flag(params)  # one launch over all tensors
             msg = ("mlp_dtype='bf16' / 'bf16x3': the parameters hold NaN values; the bf16 matrix pipe cannot propagate them "
                    "the way nn.ReLU does (the reference renders NaN) - use mlp_dtype='fp32' for this checkpoint")
-            if always:
+            if always and defer_nan:
                 pending = getattr(self, "_nan_pending", None)
-                host = torch.empty(1, dtype=torch.bool, pin_memory=True)
-                host.copy_(flag.reshape(1), non_blocking=True)
+                host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                host.copy_(flag, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(first.weight.device))
                 self._nan_pending = (host, ev)
                 if pending is not None:
                     pending[1].synchronize()
-                    if bool(pending[0][0]):
+                    if int(pending[0][0]) != 0:
                         raise RuntimeError(msg)
-            elif bool(flag):
+            elif int(flag.item()) != 0:
                 raise RuntimeError(msg)
         self.w, self.b = [], []
         for i, lin in enumerate(hidden_layers):
@@ -358,9 +359,9 @@ class prop_net(nn.Module):
         self._packed = _PackedMLP()
         self.mutate_like_reference = MUTATE_LIKE_REFERENCE
 
-    def _pack(self) -> _PackedMLP:
+    def _pack(self, defer_nan: bool = False) -> _PackedMLP:
         return self._packed.refresh([self.model[i] for i in (0, 2, 4, 6)], [self.model[8]],
-                                    getattr(self, "mlp_bf16", False), always=self.training)
+                                    getattr(self, "mlp_bf16", False), always=self.training, defer_nan=defer_nan)
 
     def invalidate_packed(self) -> None:
         """Forget the packed copy of the weights: call after changing parameters through `.data` in eval mode."""
@@ -389,7 +390,7 @@ class prop_net(nn.Module):
         rstruct, keep, B = _rays_struct(rays)
         dev = keep[0].device
         N = self.num_samples
-        packed = self._pack()
+        packed = self._pack(defer_nan=train)
         mstruct = _model_struct(self.input_size, packed, None, dev)
         hyper = _hyper_struct(N, self.viewdir_min_deg, self.viewdir_max_deg, density_bias=self.density_bias,
                               prof=getattr(self, "prof", None))
@@ -442,10 +443,10 @@ class nerf_net(nn.Module):
         self._packed = _PackedMLP()
         self.mutate_like_reference = MUTATE_LIKE_REFERENCE
 
-    def _pack(self) -> _PackedMLP:
+    def _pack(self, defer_nan: bool = False) -> _PackedMLP:
         return self._packed.refresh([self.model[i] for i in range(0, 16, 2)],
                                     [self.final_density[0], self.final_color[0]], getattr(self, "mlp_bf16", False),
-                                    always=self.training)
+                                    always=self.training, defer_nan=defer_nan)
 
     def invalidate_packed(self) -> None:
         """Forget the packed copy of the weights: call after changing parameters through `.data` in eval mode."""
@@ -490,7 +491,7 @@ class nerf_net(nn.Module):
         t_vals, coarse_weights = ops.dev(t_vals, "t_vals"), ops.dev(coarse_weights, "coarse_weights")
         N = t_vals.shape[-1] - 1
         Nf = getattr(self, "num_samples_fine", None) or N  # extension; None = the reference's behaviour
-        mstruct = _model_struct(self.input_size, None, self._pack(), dev)
+        mstruct = _model_struct(self.input_size, None, self._pack(defer_nan=train), dev)
         hyper = self._hyper(N, Nf)
         outs = _alloc_outputs(B, Nf, dev, with_prop=False)
         ostruct = _outputs_struct(outs)

@@ -382,6 +382,19 @@ def dev_bf16(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
     return t.contiguous()
 
 
+def params_nan_flag(tensors) -> torch.Tensor:
+    """int32[1] on the device: 1 if any of the fp32 device tensors holds a NaN, else 0 - one launch for the whole parameter set
+    (no host synchronisation: read the flag when it is needed)."""
+    import ctypes
+    ts = [dev(t.detach(), "parameter") for t in tensors]
+    flag = torch.empty(1, dtype=torch.int32, device=ts[0].device)
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    counts = (ctypes.c_long * len(ts))(*[t.numel() for t in ts])
+    _call("m360_params_nan_flag", ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(counts, ctypes.c_void_p), len(ts), flag, STREAM)
+    del ts  # (kept alive until the launch is queued)
+    return flag
+
+
 def pack_linear_bf16(weight, bias=None, n_pad: Optional[int] = None, k_pad: Optional[int] = None):
     """fp32 Linear -> zero-padded bf16 weight [n_pad,k_pad] (k_pad multiple of 64) + fp32 bias [n_pad]."""
     weight = dev(weight.detach(), "weight")
