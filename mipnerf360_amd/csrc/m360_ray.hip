@@ -463,17 +463,18 @@ __device__ __forceinline__ void ray_heads_fused_wave(const float *__restrict__ h
         // fp32 NeRF stage at width 1024: a sample's 8 slots x 4 heads are 128 contiguous bytes.  Lane (sample l >> 3, slot l & 7)
         // loads one float4 - a wave instruction reads 8 whole lines - and the slots are added in order 0, 1, ... 7 by a chain of
         // row_shl DPP adds that ends in the group's first lane: ((((0 + x0) + x1) + x2) ... + x7) + bias, the order of ray_heads.
-        // Four independent loads in flight per lane (the kernel is latency-bound).
+        // Independent loads in flight per lane (the kernel is latency-bound).
         const int q = l & 7;
-        for (int n0 = l >> 3; n0 < N; n0 += 4 * (kWave >> 3)) {
-            float4 v[4];
+        constexpr int U = 8;  // round 5: 8 (N = 128: two rounds of loads; 16: 133 VGPRs, three waves per SIMD where the launch has four), round 4: 4
+        for (int n0 = l >> 3; n0 < N; n0 += U * (kWave >> 3)) {
+            float4 v[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int n = n0 + u * (kWave >> 3);
                 v[u] = n < N ? *reinterpret_cast<const float4 *>(head_part + ((s0 + n) * 8 + q) * 4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int n = n0 + u * (kWave >> 3);
                 float a[4] = {0.0f + v[u].x, 0.0f + v[u].y, 0.0f + v[u].z, 0.0f + v[u].w};
                 const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -495,6 +496,8 @@ __device__ __forceinline__ void ray_heads_fused_wave(const float *__restrict__ h
             raw[n] = ((0.0f + v.x) + v.y) + head_b[0];
         }
     } else if (sizeof(T) == 2 && H == 4 && slots % 8 == 0) {
+        // (round 5: the loads of four of these sample groups issued before the first add - 16 float4 per lane in flight - measured no gain,
+        // 29.8 against 29.9 us: the kernel's time is its ~1900 vector instructions per ray, profiles/r05/hbm_kernels_sq_counters.json)
         const int per = slots / 8, lane8 = l & 7;
         for (int n = l >> 3; n < N; n += kWave >> 3) {
             const float4 *p = reinterpret_cast<const float4 *>(head_part + ((s0 + n) * slots + lane8 * per) * 4);
@@ -580,8 +583,10 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
 }
 
 // model.py:150-158,180-186 + intern/ray.py:155-191
+// (4 waves per SIMD asked of the compiler - at most 128 VGPRs: the launch is B / 4 workgroups of one wave per SIMD each, 4 per CU at 4096
+// rays; the fp32 form had 132 and ran its last quarter of workgroups in a second round)
 template <typename T, bool SPLIT = false>
-__global__ __launch_bounds__(kFinishThreads) void nerf_finish_kernel(
+__global__ __launch_bounds__(kFinishThreads, 4) void nerf_finish_kernel(
     const T *__restrict__ act, int ld, const float *__restrict__ head_part, long fused_rows, int slots,
     const float *__restrict__ head_w, const float *__restrict__ head_b, int k_pad, float density_bias,
     float rgb_padding, const float *__restrict__ t_vals, const float *__restrict__ dirs, int B, int N, int white_bkgd,
