@@ -229,6 +229,10 @@ int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_b
 /* A/B switch of m360_linear_wgrad_bf16's MFMA form, process-wide like m360_set_paired_rows: 1 (default) = one wave per SIMD with 128 x 128 wave tiles
  * and the LDS filled four k-steps ahead, 0 = the 8-wave kernel; both deterministic, results equal up to fp32 summation order.  Returns the old setting. */
 int m360_set_wgrad_bf16_form(int form);
+/* A/B switch of m360_prop_backward / m360_nerf_backward in the bf16 mode, process-wide: 1 (default) = the ReLU mask of a layer's input gradient
+ * runs on a second stream of the library beside that layer's weight gradient (forked from and joined to the caller's stream inside the call: the
+ * caller sees one stream), 0 = everything on the caller's stream.  Same bits either way.  Returns the old setting. */
+int m360_set_backward_overlap(int on);
 int m360_pack_linear_bf16_transposed(const float *w, int n_out, int k_in, int n_pad, int k_pad, void *wt_packed_bf16 /*[k_pad, n_pad]*/,
                                      m360_stream_t stream);
 int m360_linear_dgrad_bf16(const void *dz_bf16, long M, int ldz, const void *wt_packed_bf16, int k_pad, int n_pad, const void *relu_out_bf16,

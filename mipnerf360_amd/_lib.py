@@ -96,6 +96,7 @@ SIGNATURES = {
     "m360_linear_wgrad_workspace_bytes": (_sz, [_l, _i, _i]),
     "m360_linear_wgrad": (_i, [_vp, _i, _vp, _i, _l, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "m360_set_wgrad_bf16_form": (_i, [_i]),
+    "m360_set_backward_overlap": (_i, [_i]),
     "m360_params_nan_flag": (_i, [_vp, _vp, _i, _vp, _vp]),
     "m360_pack_linear_bf16_transposed": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "m360_linear_dgrad_bf16": (_i, [_vp, _l, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),

@@ -75,6 +75,8 @@ int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int 
                           int layers, int width, void *ws, m360_stream_t stream);
 int mlp_chain_bf16_rerun(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
                          int layers, int width, void *ws, m360_stream_t stream);
+// m360_linear.hip: the ReLU mask of m360_linear_dgrad_bf16 on its own (mlp_backward_bf16 overlaps it with the weight gradient)
+int relu_mask_bf16(void *dx, const void *relu_out, long M, int k_pad, int ldx, m360_stream_t stream, int blocks /* > 0: that many striding workgroups */);
 
 // brackets the launches of ONE public entry point with two HIP events on the launch stream
 struct ProfScope {
@@ -756,14 +758,40 @@ __global__ void fold_first_layer_kernel(const float *__restrict__ r, int n_pad, 
 }
 // The same chain in the bf16 mode (round 5): dz, the stored activations and the transposed weights are bf16, every product accumulates in
 // fp32 on the bf16 matrix pipe, the gradients come out in fp32 in the packed [n_pad, k_pad] layouts of the fp32 path (layer 0: [n_pad, in_pad]).
+// Round 5: the ReLU mask of a layer's input gradient (an HBM pass over [S, width] bf16: 0.52 ms at 524 288 x 1024) runs on a SECOND stream
+// beside the layer's weight gradient (MFMA-bound, 1.0 ms, reads dz and the stored activations - not dx): input-gradient GEMM, then fork -
+// {mask | weight gradient} - join.  m360_set_backward_overlap(0): one stream, the mask behind its GEMM (same bits either way).
+// The mask runs THROTTLED there - one striding workgroup per CU, two 16-byte pieces per thread in flight: at full rate (6 TB/s) it stretched the
+// weight gradient beside it from 1.04 to 1.45 ms and the pair gained 0.1 ms; 4096 x 128, NeRF backward + forward, same box, ms:
+//   one stream 26.5 | mask workgroups: all 25.4, 4096 25.7, 1024 25.6, 512 24.5, 384 26.3, 320 26.1, 256 23.7-23.9, 192 24.9, 128 27.5, 64 36.9
+// (four pieces in flight: no better; profiles/r05/backward_overlap_ab.jsonl)
+static int g_backward_overlap = 1;
+static int g_backward_mask_blocks = 256;
+extern "C" int m360_set_backward_overlap(int on) {  // > 1 (A/B runs): that many workgroups of the mask kernel
+    const int was = g_backward_overlap;
+    g_backward_overlap = on ? 1 : 0;
+    if (on > 1) g_backward_mask_blocks = on;
+    return was;
+}
 static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *const *w_t, float *const *grad_w, float *const *grad_b, const void *feat,
                              int in_pad, void *const *act, int width, long S, void *dz, void *dz_other, char *ws, const BwdLayout &L,
                              m360_stream_t st, const char *who) {
     void *gemm_ws = ws + L.gemm;
     const size_t gemm_bytes = L.finish - L.gemm;
+    SideStream *ss = (g_backward_overlap && S >= 32768 && !(h && h->prof)) ? side_stream() : nullptr;  // (a recorder brackets launches of ONE stream)
     for (int l = layers - 1; l >= 0; --l) {
         if (!grad_w[l] || !grad_b[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: gradient buffer of layer %d is null", who, l);
-        if (l > 0) {
+        if (l > 0 && ss) {
+            if (!w_t[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: transposed weight of layer %d is null", who, l);
+            hipStream_t hs = reinterpret_cast<hipStream_t>(st);
+            M360_TRY(m360_linear_dgrad_bf16(dz, S, width, w_t[l], width, width, nullptr, dz_other, width, st));
+            if (hipEventRecord(ss->fork, hs) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return fail(M360_ERR_LAUNCH, "%s: fork to the second stream failed: %s", who, hipGetErrorString(hipGetLastError()));
+            M360_TRY(relu_mask_bf16(dz_other, act[l - 1], S, width, width, reinterpret_cast<m360_stream_t>(ss->s), g_backward_mask_blocks));
+            if (hipEventRecord(ss->join, ss->s) != hipSuccess) return fail(M360_ERR_LAUNCH, "%s: join event failed: %s", who, hipGetErrorString(hipGetLastError()));
+            M360_TRY(m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], grad_b[l], gemm_ws, gemm_bytes, st));
+            if (hipStreamWaitEvent(hs, ss->join, 0) != hipSuccess) return fail(M360_ERR_LAUNCH, "%s: join of the second stream failed: %s", who, hipGetErrorString(hipGetLastError()));
+            void *tmp = dz; dz = dz_other; dz_other = tmp;
+        } else if (l > 0) {
             M360_PROF(h, st, M360_K_WGRAD, S, width, -width, m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], grad_b[l], gemm_ws, gemm_bytes, st));
             if (!w_t[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: transposed weight of layer %d is null", who, l);
             M360_PROF(h, st, M360_K_DGRAD, S, width, -width, m360_linear_dgrad_bf16(dz, S, width, w_t[l], width, width, act[l - 1], dz_other, width, st));

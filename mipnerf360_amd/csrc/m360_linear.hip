@@ -938,6 +938,23 @@ int m360_linear_bf16_split(const void *x, long M, int ldx, const void *w_packed,
 }
 
 // ---- bf16 training path (round 5): transposed bf16 packing, input gradient, weight gradient
+}  // extern "C"
+namespace m360 {
+// dx[m, k] = relu_out[m, k] > 0 ? dx[m, k] : 0 in place (the second half of m360_linear_dgrad_bf16; m360_capi.hip runs it on a second stream
+// beside the layer's weight gradient, which does not read dx)
+int relu_mask_bf16(void *dx, const void *relu_out, long M, int k_pad, int ldx, m360_stream_t stream, int blocks) {
+    if (!dx || !relu_out || M < 0 || k_pad < 8 || k_pad % 8 || ldx < k_pad || ldx % 8) return fail(M360_ERR_INVALID_ARGUMENT, "relu_mask_bf16: bad argument (M=%ld k_pad=%d ldx=%d)", M, k_pad, ldx);
+    if (((uintptr_t)relu_out | (uintptr_t)dx) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_dgrad_bf16: relu_out / dx must be 16-byte aligned");
+    if (M == 0) return M360_OK;
+    const long n = M * (k_pad / 8);
+    if (blocks > 0 && (n + 255) / 256 > blocks)  // beside another kernel: a fixed number of workgroups (m360_capi.hip: mlp_backward_bf16)
+        hipLaunchKernelGGL(tn16::relu_mask_bf16_stride_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<__bf16 *>(dx), static_cast<const __bf16 *>(relu_out), M, k_pad, ldx);
+    else
+        hipLaunchKernelGGL(tn16::relu_mask_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<__bf16 *>(dx), static_cast<const __bf16 *>(relu_out), M, k_pad, ldx);
+    return check_launch("linear_dgrad_bf16 (ReLU mask)");
+}
+}  // namespace m360
+extern "C" {
 int m360_pack_linear_bf16_transposed(const float *w, int n_out, int k_in, int n_pad, int k_pad, void *wt_packed_bf16, m360_stream_t stream) {
     if (!w || !wt_packed_bf16 || n_out < 1 || k_in < 1 || n_pad < n_out || k_pad < k_in || n_pad % 64 != 0)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_pack_linear_bf16_transposed: bad argument (n_out=%d k_in=%d n_pad=%d k_pad=%d; n_pad - the contraction of the input gradient - must be a multiple of 64)", n_out, k_in, n_pad, k_pad);
@@ -958,10 +975,7 @@ int m360_linear_dgrad_bf16(const void *dz, long M, int ldz, const void *wt_packe
     if (hipGetSymbolAddress(reinterpret_cast<void **>(&zero_bias), HIP_SYMBOL(g_zero_bias)) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_linear_dgrad_bf16: zero bias symbol not found");
     const int rc = m360_linear_bf16(dz, M, ldz, wt_packed_bf16, zero_bias, k_pad, n_pad, M360_ACT_NONE, dx, ldx, stream);
     if (rc != M360_OK || !relu_out || M == 0) return rc;
-    if (((uintptr_t)relu_out | (uintptr_t)dx) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_dgrad_bf16: relu_out / dx must be 16-byte aligned");
-    const long n = M * (k_pad / 8);
-    hipLaunchKernelGGL(tn16::relu_mask_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<__bf16 *>(dx), static_cast<const __bf16 *>(relu_out), M, k_pad, ldx);
-    return check_launch("linear_dgrad_bf16 (ReLU mask)");
+    return m360::relu_mask_bf16(dx, relu_out, M, k_pad, ldx, stream, 0);
 }
 
 // which MFMA form m360_linear_wgrad_bf16 runs (A/B switch, process-wide like m360_set_paired_rows): 1 = one wave per SIMD, 128 x 128 wave tiles,

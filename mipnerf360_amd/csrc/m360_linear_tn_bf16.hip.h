@@ -298,6 +298,33 @@ __global__ __launch_bounds__(256) void relu_mask_bf16_kernel(__bf16 *__restrict_
     *reinterpret_cast<s16x8 *>(dx + r * ld + c) = v;
 }
 
+// The same mask by a FIXED number of workgroups striding over the rows (U pieces per thread in flight): the form m360_capi.hip runs on a second
+// stream beside the layer's weight gradient - throttled so that it takes about as long as that kernel instead of saturating the HBM for half of it
+template <int U>
+__global__ __launch_bounds__(256) void relu_mask_bf16_stride_kernel(__bf16 *__restrict__ dx, const __bf16 *__restrict__ relu_out, long M, int cols, int ld) {
+    const int c8 = cols / 8;
+    const long total = M * c8, stride = (long)gridDim.x * blockDim.x;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += U * stride) {
+        long o[U];
+        s16x8 v[U], a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long i = idx + u * stride < total ? idx + u * stride : idx;
+            o[u] = (i / c8) * ld + (i % c8) * 8;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const s16x8 *>(dx + o[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const s16x8 *>(relu_out + o[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[u][i] = a[u][i] > 0 ? v[u][i] : (short)0;
+            if (u == 0 || idx + u * stride < total) *reinterpret_cast<s16x8 *>(dx + o[u]) = v[u];
+        }
+    }
+}
+
 __global__ void pack_linear_bf16_t_kernel(const float *__restrict__ w, int n_out, int k_in, int n_pad, int k_pad, __bf16 *__restrict__ wt) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)n_pad * k_pad) return;

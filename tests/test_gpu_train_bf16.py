@@ -307,3 +307,38 @@ def test_params_nan_flag_one_launch(dev):
         ts[which].reshape(-1)[where] = keep
     ts[2][5] = float("inf")  # an infinity is not a NaN
     assert int(ops.params_nan_flag(ts).item()) == 0
+
+
+def test_backward_overlap_same_bits(dev):
+    """m360_set_backward_overlap: the ReLU mask of a layer's input gradient on the library's second stream beside the weight gradient (the
+    default; one striding workgroup per CU) against everything on the caller's stream - the same gradients bit for bit, NeRF and proposal
+    update, at a size where the overlapped form runs (>= 32768 rows: 300 rays x 128 samples, ragged)."""
+    from mipnerf360_amd import _lib
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
+    sd = synthetic.make_state_dict(64, 256, seed=21)
+    rays = dev_rays(synthetic.make_rays("garden", 300, seed=22), dev)
+    pixels = torch.rand(300, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    out = {}
+    was = _lib.lib().m360_set_backward_overlap(1)
+    try:
+        for mode in (1, 0, 1):
+            _lib.lib().m360_set_backward_overlap(mode)
+            m = _bf16_model(sd, dev, 128, 64, 256, True)
+            t_hat, w_hat = m.prop_net.forward(rays)
+            rgb, dist, acc, t, fw, sv = m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+            ln, _ = Loss_nerf(input=rgb, target=pixels)
+            m.zero_grad()
+            (ln + 0.01 * Loss_dist(s_vals=sv, weights=fw)).backward()
+            Loss_prop(t=t.detach(), w=fw.detach(), t_hat=t_hat, w_hat=w_hat).backward()
+            torch.cuda.synchronize()
+            g = {n: p.grad.clone() for n, p in m.named_parameters()}
+            assert all(torch.isfinite(v).all() for v in g.values())
+            if mode in out:
+                assert all(torch.equal(g[n], out[mode][n]) for n in g), "the overlapped backward is not deterministic"
+            out[mode] = g
+            del m
+    finally:
+        _lib.lib().m360_set_backward_overlap(was)
+    diff = [n for n in out[0] if not torch.equal(out[0][n], out[1][n])]
+    assert not diff, diff
+    assert float(max(v.abs().max() for v in out[1].values())) > 0
