@@ -633,7 +633,7 @@ int m360_pack_linear_transposed(const float *w, int n_out, int k_in, int n_pad, 
 // ---- NaN scan of a parameter set in ONE launch (the bf16 modes refuse NaN parameters: m360.h) - block (x, t) strides over tensor t
 }  // extern "C"
 namespace m360 {
-constexpr int kNanScanMax = 32, kNanScanBlocks = 16;
+constexpr int kNanScanMax = 32, kNanScanBlocks = 256;  // (16 workgroups per tensor: 56 us for the set of a 1024-wide model - a 1024 x 1024 matrix was 256 serial loads per thread; 256: 16)
 struct nan_scan_t {
     const float *p[kNanScanMax];
     long n[kNanScanMax];
@@ -642,6 +642,7 @@ __global__ __launch_bounds__(256) void nan_scan_kernel(nan_scan_t a, unsigned *f
     const float *__restrict__ p = a.p[blockIdx.y];
     const long n = a.n[blockIdx.y];
     bool bad = false;
+#pragma unroll 4
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)kNanScanBlocks * 256) bad |= p[i] != p[i];
     if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }

@@ -460,34 +460,23 @@ __device__ __forceinline__ void ray_heads_fused_wave(const float *__restrict__ h
                                                      long s0, int N, float *raw /*LDS [N][H], this wave's*/) {
     const int l = lane_id();
     if (sizeof(T) == 4 && H == 4 && slots == 8) {
-        // fp32 NeRF stage at width 1024: a sample's 8 slots x 4 heads are 128 contiguous bytes.  Lane (sample l >> 3, slot l & 7)
-        // loads one float4 - a wave instruction reads 8 whole lines - and the slots are added in order 0, 1, ... 7 by a chain of
-        // row_shl DPP adds that ends in the group's first lane: ((((0 + x0) + x1) + x2) ... + x7) + bias, the order of ray_heads.
-        // Independent loads in flight per lane (the kernel is latency-bound).
-        const int q = l & 7;
-        constexpr int U = 8;  // round 5: 8 (N = 128: two rounds of loads; 16: 133 VGPRs, three waves per SIMD where the launch has four), round 4: 4
-        for (int n0 = l >> 3; n0 < N; n0 += U * (kWave >> 3)) {
-            float4 v[U];
+        // fp32 NeRF stage at width 1024: a sample's 8 slots x 4 heads are 128 contiguous bytes = one line.  Round 5: ONE LANE PER SAMPLE adds
+        // its line's eight float4 in order - ((((0 + x0) + x1) + x2) ... + x7) + bias, the order of ray_heads - 36 adds per 64 samples where
+        // rounds 3-4 spread a sample over 8 lanes (whole lines per load instruction) and paid 7 DPP adds x 4 heads per 8 samples: the kernel
+        // is bound by its vector instructions, not by how its 64 KB per ray arrive; all of a lane's loads are in flight at once.
+#pragma unroll 1
+        for (int n = l; n < N; n += kWave) {
+            const float4 *p = reinterpret_cast<const float4 *>(head_part + (s0 + n) * 32);
+            float4 v[8];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int n = n0 + u * (kWave >> 3);
-                v[u] = n < N ? *reinterpret_cast<const float4 *>(head_part + ((s0 + n) * 8 + q) * 4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
+            for (int q = 0; q < 8; ++q) v[q] = p[q];
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int n = n0 + u * (kWave >> 3);
-                float a[4] = {0.0f + v[u].x, 0.0f + v[u].y, 0.0f + v[u].z, 0.0f + v[u].w};
-                const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#define M360_SHL_ADD(K)                                                                                                                  \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                                        \
-        a[c] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x[c]), 0x100 + (K), 0xF, 0xF, true));
-                M360_SHL_ADD(1) M360_SHL_ADD(2) M360_SHL_ADD(3) M360_SHL_ADD(4) M360_SHL_ADD(5) M360_SHL_ADD(6) M360_SHL_ADD(7)
-#undef M360_SHL_ADD
-                if (q == 0 && n < N) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) raw[n * 4 + c] = a[c] + head_b[c];
-                }
-            }
+            for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+            raw[n * 4 + 0] = a.x + head_b[0];  // (raw is 4-byte aligned only: t[N + 1] lies before it)
+            raw[n * 4 + 1] = a.y + head_b[1];
+            raw[n * 4 + 2] = a.z + head_b[2];
+            raw[n * 4 + 3] = a.w + head_b[3];
         }
     } else if (H == 1 && slots == 2) {
         // proposal stage at width 256 (fp32 kernel and the bf16 ring kernel alike): two partial sums per sample, one float2 per lane
