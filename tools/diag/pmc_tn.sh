@@ -4,8 +4,8 @@ python3 - <<'PY'
 import csv, glob, collections
 fs = glob.glob("gpurun_out/r05/pmc_tn/*/*_counter_collection.csv")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(fs[-1])):
-    if "linear_tn_bf16_kernel" in r["Kernel_Name"]:
+for r in csv.DictReader(open(max(fs, key=__import__("os").path.getmtime))):
+    if "linear_tn_bf16" in r["Kernel_Name"]:
         acc[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
         acc[r["Dispatch_Id"]]["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 big = [v for v in acc.values() if v["_ns"] > 900000]
