@@ -37,7 +37,9 @@ def dev_rays(d, dev):
     return Rays(*[D(d[k], dev) for k in synthetic.RAY_FIELDS])
 
 
-@pytest.mark.parametrize("M,n,k", [(4096 + 37, 256, 256), (65536, 1024, 256), (32768 + 64, 256, 1024), (700, 64, 128), (64, 256, 256), (50, 256, 256)])
+@pytest.mark.parametrize("M,n,k", [(4096 + 37, 256, 256), (65536, 1024, 256), (32768 + 64, 256, 1024), (700, 64, 128), (64, 256, 256), (50, 256, 256),
+                                   # the one-wave form (k >= 1024): fewer k-steps than its four-deep prologue, one split, ragged tails, many splits
+                                   (64, 256, 1024), (100, 256, 1024), (96, 1024, 1024), (577, 256, 1024), (8192 + 31, 1024, 1024), (262144, 256, 1024)])
 def test_linear_wgrad_bf16_against_fp64(dev, M, n, k):
     """dW = dZ^T X, db = column sums of dZ from bf16 rows: the MFMA kernel (pads of 256; ragged tail rows, a single stage, fewer rows than a
     stage) and the widening fall-back (other pads) against fp64 products of the SAME bf16 values - only the fp32 summation order differs;
