@@ -233,8 +233,7 @@ int m360_set_wgrad_bf16_form(int form);
  * runs on a second stream of the library beside that layer's weight gradient (forked from and joined to the caller's stream inside the call: the
  * caller sees one stream), 0 = everything on the caller's stream.  Same bits either way.  Returns the old setting.
  * The second stream and its two events are the library's, one set per process, created on first use for the device current then (other devices:
- * everything on the caller's stream): backward calls of ONE host thread at a time, as torch's autograd engine issues them; capturable in a HIP
- * graph (a fork / join inside the capture). */
+ * everything on the caller's stream): backward calls of ONE host thread at a time, as torch's autograd engine issues them. */
 int m360_set_backward_overlap(int on);
 int m360_pack_linear_bf16_transposed(const float *w, int n_out, int k_in, int n_pad, int k_pad, void *wt_packed_bf16 /*[k_pad, n_pad]*/,
                                      m360_stream_t stream);
