@@ -1021,10 +1021,15 @@ int m360_linear_wgrad_bf16(const void *dz, int ldz, const void *x, int ldx, long
         int ntiles, nsplit;
         long total, per;
         wgrad_bf16_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
+        // a split's rows are addressed by 32-bit offsets inside a 2 GB buffer descriptor (M x ld beyond ~16 G elements: split the batch)
+        if ((per + 1) * tn16::BKM * (long)(ldz > ldx ? ldz : ldx) * 2 >= (1l << 31))
+            return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_wgrad_bf16: M=%ld rows of %d elements exceed the 2 GB a row split addresses (%d splits); call it on blocks of rows", M, ldz > ldx ? ldz : ldx, nsplit);
         float *partial = static_cast<float *>(workspace);
         float *bias_part = reinterpret_cast<float *>(static_cast<char *>(workspace) + up256_((size_t)(nsplit > 0 ? nsplit : 1) * n_pad * k_pad * sizeof(float)));
-        if (g_wgrad_bf16_form == 1 && k_pad >= 4 * tn16w::BT) {  // one wave per SIMD: k-steps of 32 rows, the same number of splits (>= 4 k tiles: its bias sums)
-            const long total32 = M / tn16w::KS, per32 = (total32 + nsplit - 1) / nsplit;
+        const long total32 = M / tn16w::KS, per32 = (total32 + nsplit - 1) / nsplit;
+        // one wave per SIMD: k-steps of 32 rows, the same number of splits (>= 4 k tiles: its bias sums; a split's rows within the 2 GB its
+        // buffer descriptors address: 32-bit offsets)
+        if (g_wgrad_bf16_form == 1 && k_pad >= 4 * tn16w::BT && (per32 + 1) * tn16w::KS * (long)(ldz > ldx ? ldz : ldx) * 2 < (1l << 31)) {
             hipLaunchKernelGGL(tn16w::linear_tn_bf16_w_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn16w::kThreads), 0, st, dzb, ldz, xb, ldx, n_pad, k_pad, partial, k_pad / tn16w::BT, ntiles, nsplit, total32, per32, grad_b ? bias_part : nullptr);
             const long count4w = (long)n_pad * k_pad / 4;
             hipLaunchKernelGGL(tn16::tn16_reduce_kernel, dim3((unsigned)((count4w + 255) / 256)), dim3(256), 0, st, partial, nsplit, n_pad, k_pad, dzb, ldz, xb, ldx, total32 * tn16w::KS, M, grad_w);
