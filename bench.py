@@ -602,7 +602,7 @@ def named_workloads(sd_np, dev, _lib):
             dx = torch.empty(M, HN, device=dev, dtype=torch.bfloat16)
             wgrad_ms = timed(lambda: ops.linear_wgrad_bf16(dz, x), 5)
             dgrad_ms = timed(lambda: ops.linear_dgrad_bf16(dz, wt, x, out=dx), 5)
-            peak, wk, dk = PEAK_BF16_MFMA_TFLOPS, "linear_tn_bf16_kernel + tn16_reduce_kernel (dW = dZ^T X on v_mfma_f32_16x16x32_bf16, operands transposed by ds_read_b64_tr_b16; bias gradient on the matrix pipe)", \
+            peak, wk, dk = PEAK_BF16_MFMA_TFLOPS, "tn16w::linear_tn_bf16_w_kernel (one wave per SIMD, 128 x 128 wave tiles) + tn16_reduce_kernel (dW = dZ^T X on v_mfma_f32_16x16x32_bf16, operands transposed by ds_read_b64_tr_b16; bias gradient on the matrix pipe)", \
                 "linear_bf16_w16_kernel on the transposed bf16 packing + relu_mask_bf16_kernel (dX = (dZ W) * [a > 0])"
         else:
             dz = torch.randn(M, HN, device=dev)
