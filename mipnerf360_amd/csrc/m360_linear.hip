@@ -423,7 +423,8 @@ int m360_linear_heads_slots(int n_pad, int bf16) {  // partial sums per row: fp3
 // which kernel forms the fused heads of a bf16 / bf16x3 last layer: the one-wave ring kernel (rendering forward: the layer's own
 // output is not kept) when the contraction has its shape, else the ping-pong kernel
 static bool heads_on_ring(int k_pad, int x3, int store_y) {
-    return M360_W16_HEADS_ON && !store_y && (x3 ? (k_pad % w16::BKS == 0 && k_pad >= 2 * w16::BKS) : (k_pad % (2 * w16::BKS) == 0 && k_pad >= 4 * w16::BKS));
+    // (store_y - the tape-keeping forward of the bf16 training path - since round 5 in the plain bf16 form: KEEP_Y; bf16x3 is forward-only)
+    return M360_W16_HEADS_ON && !(store_y && x3) && (x3 ? (k_pad % w16::BKS == 0 && k_pad >= 2 * w16::BKS) : (k_pad % (2 * w16::BKS) == 0 && k_pad >= 4 * w16::BKS));
 }
 
 // paired rows (m360.h: M360_ROWS_PAIRED_IN / _OUT): the layout only the one-wave ring kernel reads and writes - does the call `kind`
@@ -521,9 +522,14 @@ static int linear_heads_bf16_any(const void *x, long M, int ldx, const void *w_p
 #define M360_PP_HEADS(X3M, H, SY) hipLaunchKernelGGL((pp16::linear_bf16_pp_kernel<M360_ACT_SIGMOID, false, X3M, H, SY>), grid, block, 0, st, xb, M_fused, ldx, wb, b_packed, n_pad, kk, yb, ldy, tn, (int)nt, head_w, head_part)
 #define M360_W16_HEADS(X3B, H) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 0, false, X3B, false, H>), grid, dim3(w16::kThreads), 0, st, xb, M_fused, ldx, wb, b_packed, n_pad, kk, yb, ldy, tn, (int)nt, head_w, head_part, xin)
         // the rendering forward (the layer's own output is not kept): the one-wave ring kernel - its exposed sigmoid epilogue costs
-        // less than its K loop wins (0.85 against 1.08-1.12 ms for the 1024^2 NeRF layer)
+        // less than its K loop wins (0.85 against 1.08-1.12 ms for the 1024^2 NeRF layer); with store_y (the tape-keeping forward of the bf16
+        // training path) its KEEP_Y form: 32 row stores + 8 partial-sum stores per tile (the ping-pong kernel's store_y forms spill 44-75
+        // registers: 1.7 ms for that layer, 0.27 ms for the proposal net's)
         const bool ring = heads_on_ring(k_pad, x3, store_y);
-        if (ring) {
+#define M360_W16_HEADS_KEEP(H) hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 0, false, false, false, H, false, false, false, false, true>), grid, dim3(w16::kThreads), 0, st, xb, M_fused, ldx, wb, b_packed, n_pad, kk, yb, ldy, tn, (int)nt, head_w, head_part, xin)
+        if (ring && store_y) {
+            if (heads == 1) M360_W16_HEADS_KEEP(1); else M360_W16_HEADS_KEEP(4);
+        } else if (ring) {
             if (x3) { if (heads == 1) M360_W16_HEADS(true, 1); else M360_W16_HEADS(true, 4); }
             else { if (heads == 1) M360_W16_HEADS(false, 1); else M360_W16_HEADS(false, 4); }
         } else if (x3) {
@@ -535,6 +541,7 @@ static int linear_heads_bf16_any(const void *x, long M, int ldx, const void *w_p
         }
 #undef M360_PP_HEADS
 #undef M360_W16_HEADS
+#undef M360_W16_HEADS_KEEP
         const int rc = check_launch(who);
         if (rc != M360_OK) return rc;
     }

@@ -161,7 +161,7 @@ constexpr int kHeadMaxN = 1024;  // widest layer the fused heads take (their hi 
 // exchange.  The reader is this kernel's LDS-DMA, whose lanes carry their own source addresses: xpair != 0 fetches chunk c of row r
 // from line 2 (r >> 1) + (c >> 2), bytes 64 (r & 1) + 16 (c & 3) - the same eight whole lines per piece, a different lane order.
 // Rows beyond the last full 256-row tile are other kernels' rows and stay plain in both layouts.
-template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0, bool SPLIT = X3, bool LDSEPI = false, bool PAIR = false, bool CHAIN = false>
+template <int ACT, int ABL = 0, bool STAMP = false, bool X3 = false, bool ONE_BLOCK = false, int HEADS = 0, bool SPLIT = X3, bool LDSEPI = false, bool PAIR = false, bool CHAIN = false, bool KEEP_Y = false>
 __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     const __bf16 *__restrict__ X, long M, int ldx, const __bf16 *__restrict__ W, const float *__restrict__ bias, int Np,
     int Kp, __bf16 *__restrict__ Y, int ldy, int tiles_n, int ntiles, const float *__restrict__ head_w = nullptr,
@@ -173,11 +173,13 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     static_assert(HEADS == 0 || HEADS == 1 || HEADS == 4, "1 (proposal) or 4 (NeRF) heads");
     // X3 loop + plain bf16 output: the first layer of the bf16 mode (two-term features and weights in, one bf16 term out)
     static_assert(SPLIT == X3 || HEADS == 0, "X3 loop and split output go together wherever the heads are fused");
-    constexpr bool STORE_Y = HEADS == 0;
+    // KEEP_Y (round 5): fused heads AND the layer's own output (plain rows) - the last hidden layer of the tape-keeping bf16 forward (training)
+    static_assert(!KEEP_Y || (HEADS > 0 && !X3 && !SPLIT && !PAIR && !LDSEPI && !CHAIN && !ONE_BLOCK), "KEEP_Y: the plain bf16 fused-heads layer");
+    constexpr bool STORE_Y = HEADS == 0 || KEEP_Y;
     // accumulators in ArchVGPRs (W16_ACC_V): not in the plain 64-deep form, whose single stage keeps more fragments live (256 ArchVGPRs + spills)
     constexpr int kAccV = (ONE_BLOCK && !X3) ? 0 : kAccVBlocks;
     // vector-memory operations of a tile's epilogue: 32 whole-line stores (64 as [hi | lo]) or, with fused heads, 8 partial-sum stores
-    constexpr int W16_STORES = STORE_Y ? (SPLIT ? 64 : 32) : 8;
+    constexpr int W16_STORES = (STORE_Y ? (SPLIT ? 64 : 32) : 0) + (HEADS ? 8 : 0);
     static_assert(ACT == M360_ACT_NONE || ACT == M360_ACT_RELU || (ACT == M360_ACT_SIGMOID && (ABL != 0 || HEADS > 0)), "bias + {none, ReLU}; sigmoid with fused heads");
 
     // gated launch (the layer-by-layer re-run behind a chain launch): nothing to do unless the chain reported an error; the first gated

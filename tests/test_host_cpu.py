@@ -663,29 +663,33 @@ def test_ring_kernel_store_instructions_match_its_counted_waits(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     text = open(out).read()
     seen = 0
-    # _ZN4m3603w1622linear_bf16_w16_kernelILi<ACT>ELi<ABL>ELb<STAMP>ELb<X3>ELb<ONE_BLOCK>ELi<HEADS>ELb<SPLIT>ELb<LDSEPI>ELb<PAIR>ELb<CHAIN>EEE...
+    # _ZN4m3603w1622linear_bf16_w16_kernelILi<ACT>ELi<ABL>ELb<STAMP>ELb<X3>ELb<ONE_BLOCK>ELi<HEADS>ELb<SPLIT>ELb<LDSEPI>ELb<PAIR>ELb<CHAIN>ELb<KEEP_Y>EEE...
     # (ABL: 0, or 128 = the same kernel with temporal stores: the row blocks' and the layer chain's instantiations)
     split_without_x3 = paired = chains = 0
-    for m in re.finditer(r"^(_ZN4m3603w1622linear_bf16_w16_kernelILi(\d)ELi(?:0|128)ELb0ELb([01])ELb([01])ELi(\d)ELb([01])ELb0ELb([01])ELb([01])EEE\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):  # (not up to the first s_endpgm: the gate's early return has one)
-        x3, heads, split, pair, chain, body = m.group(3) == "1", int(m.group(5)), m.group(6) == "1", m.group(7) == "1", m.group(8) == "1", m.group(9)
+    keeps = 0
+    for m in re.finditer(r"^(_ZN4m3603w1622linear_bf16_w16_kernelILi(\d)ELi(?:0|128)ELb0ELb([01])ELb([01])ELi(\d)ELb([01])ELb0ELb([01])ELb([01])ELb([01])EEE\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, re.S | re.M):  # (not up to the first s_endpgm: the gate's early return has one)
+        x3, heads, split, pair, chain, keep, body = m.group(3) == "1", int(m.group(5)), m.group(6) == "1", m.group(7) == "1", m.group(8) == "1", m.group(9) == "1", m.group(10)
         chains += int(chain)
+        keeps += int(keep)
         # every instantiation: the gate at the kernel's entry (one atomic add: the recovery counter of a gated re-run launch).  The layer
         # chain (m360_mlp_chain_bf16) on top of that: counter adds per tile, its self-checks (XCC_ID read, a compare-and-swap on its slot
         # word, the error bit), activation pieces that bypass the CU's L1
         assert (body.count("global_atomic_add") > 1) == chain and body.count("global_atomic_add") >= 1, f"{m.group(1)}: the gate / the chain's hand-over instructions"
         assert not chain or (len(re.findall(r"buffer_load_dword[^\n]* lds[^\n]* sc1|buffer_load_dword[^\n]* sc1[^\n]* lds", body)) == 64 and "HW_REG_XCC_ID" in body and "global_atomic_cmpswap" in body and "global_atomic_or" in body and "s_memrealtime" in body), f"{m.group(1)}: the chain's self-checks"
         want = 8 if heads else (64 if split else 32)
+        if keep:
+            want = 32 + 8  # KEEP_Y (the tape-keeping last layer of the bf16 training path): the layer's own rows AND the partial head sums
         if chain:
             want *= 2  # one of two store policies per tile (temporal inside the chain, non-temporal for its last layer): a wave-uniform branch
         split_without_x3 += int(split and not x3)
         paired += int(pair)
         # paired rows (include/m360.h): the lanes' own pieces are whole lines - no exchange between lanes in that epilogue
-        assert (body.count("v_cndmask_b32_dpp") == 0) == (pair or heads > 0), f"{m.group(1)}: lane exchange in a paired-rows / fused-heads epilogue, or none in a plain one"
+        assert (body.count("v_cndmask_b32_dpp") == 0) == (pair or (heads > 0 and not keep)), f"{m.group(1)}: lane exchange in a paired-rows / fused-heads epilogue, or none in a plain one"
         got = len(re.findall(r"\bglobal_store_dwordx4" if chain else r"\bglobal_store_", body))  # (the chain also stores its error word where a wait gives up)
         assert got == want, f"{m.group(1)}: {got} store instructions, the counted waits assume {want}"
         assert "scratch_" not in body, f"{m.group(1)} spills"
         seen += 1
-    assert seen >= 22 and paired >= 10 and chains == 1, f"only {seen} ring-kernel instantiations found ({paired} with paired rows out, {chains} layer chain)"
+    assert seen >= 24 and paired >= 10 and chains == 1 and keeps == 2, f"only {seen} ring-kernel instantiations found ({paired} with paired rows out, {chains} layer chain, {keeps} keeping y beside the heads)"
     assert split_without_x3 == 4, "the x6 first layer of the bf16x3 mode (plain K loop, [hi | lo] output; none / ReLU / ReLU with paired rows out, with non-temporal or temporal stores) is missing"
 
 
