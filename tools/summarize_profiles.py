@@ -250,11 +250,13 @@ def bf16_ring_counters(src):
         for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
             # the ReLU hidden layers: <ACT = 1, ABL = 0, no stamps, no X3, not ONE_BLOCK, no heads, no split, no LDS epilogue[, paired rows or not]>
             # ... or, since round 4's last step, the six hidden layers in ONE launch (CHAIN: <1, 128, ..., paired rows, chain>)
-            if any(k in r["Kernel_Name"] for k in ("w16_kernel<1, 128, false, false, false, 0, false, false, true, true>",
+            if any(k in r["Kernel_Name"] for k in ("w16_kernel<1, 128, false, false, false, 0, false, false, true, true, false>",  # (round 5: an 11th parameter, KEEP_Y)
+                                                   "w16_kernel<1, 0, false, false, false, 0, false, false, true, false, false>", "w16_kernel<1, 0, false, false, false, 0, false, false, false, false, false>",
+                                                   "w16_kernel<1, 128, false, false, false, 0, false, false, true, true>",
                                                    "w16_kernel<1, 0, false, false, false, 0, false, false, true, false>", "w16_kernel<1, 0, false, false, false, 0, false, false, false, false>",
                                                    "w16_kernel<1, 0, false, false, false, 0, false, false, true>", "w16_kernel<1, 0, false, false, false, 0, false, false, false>",
                                                    "w16_kernel<1, 0, false, false, false, 0, false, false>", "w16_kernel<1, 0, false, false, false, 0, false>", "w16_kernel<1, 0, false, false, false, 0>")):
-                acc[r["Dispatch_Id"]]["_chain"] = 1.0 if "true, true>" in r["Kernel_Name"] and "<1, 128," in r["Kernel_Name"] else 0.0
+                acc[r["Dispatch_Id"]]["_chain"] = 1.0 if ("true, true>" in r["Kernel_Name"] or "true, true, false>" in r["Kernel_Name"]) and "<1, 128," in r["Kernel_Name"] else 0.0
                 acc[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
                 acc[r["Dispatch_Id"]]["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         return [x for x in acc.values() if x["_ns"] > 600000]   # the NeRF layers (the 256-wide proposal layers are 7 x shorter)
