@@ -140,11 +140,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_kernel(
 
         // ONE barrier per stage: behind it every wave has its pieces of stage s in the LDS and has finished reading the other buffer (stage
         // s - 1), so the pieces of stage s + 1 may go out (issue_pair, in the first k-step's MFMA gaps) and have most of the stage to land.
-        // What the 1.15 ms of a 1024^2 layer are made of (M360_TN16_ABL ablations, profiles/r05/wgrad_bf16_ablation*.txt): LDS-DMA +
-        // barriers alone 0.76 ms (one stage = 64 KB per CU in flight against ~1.5 us of L2 -> LDS latency: 44 GB/s per CU), MFMAs + barriers
-        // alone 0.65 (the matrix work itself: 0.45), fragment reads + barriers alone 0.35; SQ_LDS_BANK_CONFLICT = 0; MFMA pipe busy 37 -> 41 %.
+        // What the 1.15-1.19 ms of a 1024^2 layer are made of (M360_TN16_ABL ablations of the diagnostics build, tools/diag/wgrad_ablations.sh,
+        // profiles/r05/wgrad_bf16_ablation_8wave_form.txt; times include the 0.02 ms reduce kernel): LDS-DMA + barriers alone 0.84 ms (8.6 GB of
+        // operand tiles: the L2s deliver ~10.5 TB/s into the LDSs), MFMAs + barriers alone 0.72 (without the barrier 0.69 = 1.59 PF: the matrix
+        // pipe's own ceiling at the clock the chip holds), fragment reads + barriers alone 0.39; SQ_LDS_BANK_CONFLICT = 0; MFMA pipe busy 37 -> 41 %.
         // The three overlap only partly in an 8-wave, barrier-per-stage loop scheduled by the compiler; the remedy is the ring kernel's
-        // structure (one wave per SIMD, 128 x 128 wave tiles, a generated schedule) - not built for this operand layout yet.
+        // structure (one wave per SIMD, 128 x 128 wave tiles: m360_linear_tn_bf16_w.hip.h, round 5 - 1.04-1.12 ms; a generated schedule: not built).
         // Also measured: the transposed reads as inline assembly with counted lgkmcnt waits (the compiler puts s_waitcnt vmcnt(0) in front of
         // LDS reads that follow an LDS-DMA issue): 1.17 ms, no gain - kept as builtins.
         // (Measured and rejected, profiles/r05/bf16_wgrad_pipelined_halves_SLOWER.jsonl: the loop over 32-row halves in four LDS quarters with

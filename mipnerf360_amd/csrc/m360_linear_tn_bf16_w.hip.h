@@ -2,8 +2,8 @@
 // forward ring kernel (m360_linear_bf16_w16.hip.h) for the "row = contraction index" operand layout of dW = dZ^T X.
 //
 // Why a second form: the 8-wave kernel (m360_linear_tn_bf16.hip.h) reads 24 fragments per 32 MFMAs and wave, meets at one barrier per 64-row
-// stage and prefetches ONE stage ahead; its ablations (profiles/r05/wgrad_bf16_ablation*.txt) show LDS-DMA, fragment reads and matrix work
-// overlapping only partly (0.76 / 0.35 / 0.65 ms alone, 1.15 ms together per 1024^2 layer; MFMA pipe busy 41 %).  Here:
+// stage and prefetches ONE stage ahead; its ablations (profiles/r05/wgrad_bf16_ablation_8wave_form.txt) show LDS-DMA, fragment reads and matrix
+// work overlapping only partly (0.84 / 0.39 / 0.72 ms alone, 1.15-1.19 ms together per 1024^2 layer; MFMA pipe busy 41 %).  Here:
 //   * 4 waves, wave tile 128 (n) x 128 (k) = 8 x 8 blocks of v_mfma_f32_16x16x32_bf16: 256 accumulators in AccVGPRs (MFMAs as inline assembly with
 //     "+a" operands, as in the ring kernel), 16 fragments = 32 ds_read_b64_tr_b16 per 64 MFMAs: two thirds of the LDS read traffic per flop;
 //   * the unit of the loop is a k-step of 32 rows; the LDS holds FIVE such "quarters" (5 x 32 KiB = all 160 KiB), filled four k-steps ahead of the
