@@ -17,6 +17,9 @@
 //     the ds_read_tr16_b64 builtin (register pairs assembled without copies, lgkmcnt waits placed by the compiler per fragment).  The orderings
 //     that matter are kept by hand: vmcnt(16) + s_barrier in front of the first read of a quarter, and a quarter is refilled only behind the
 //     barrier after its last read.
+// (Measured, no gain: FOUR quarters in flight instead of three - k-step i + 5 into the quarter whose fragments k-step i - 1 already took into
+// registers, vmcnt(24) - 1.10 against 1.06-1.09 ms on a box whose other kernels ran 2-3 % slow: the L2 -> LDS delivery rate bounds the loop, not the
+// bytes in flight.)
 // Same LDS image (512-byte rows, 32-byte units XOR-swizzled by f(r): conflict-free transposed reads), same (tile, split) decomposition, same
 // deterministic split reduction and the same bits in the partial sums' layout as the 8-wave kernel.
 #pragma once
