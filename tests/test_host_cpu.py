@@ -71,6 +71,14 @@ def test_argument_validation_without_gpu(lib):
     assert lib.m360_linear(None, 4, 64, None, None, 32, 64, 0, None, 32, None) == -1
     assert lib.m360_resample_t(None, None, None, 1, 0, 0.01, None, None) == -1
     assert lib.m360_forward(None, None, None, 1, None, None, 0, None) == -1
+    # round 5's entries: the NaN scan, the bf16 gradient GEMMs, the switches (which only return the previous setting)
+    assert lib.m360_params_nan_flag(None, None, 3, None, None) == -1 and "m360_params_nan_flag" in _lib.last_error()
+    assert lib.m360_linear_wgrad_bf16(None, 1024, None, 1024, 4096, 1024, 1024, None, None, None, 0, None) == -1
+    assert lib.m360_linear_dgrad_bf16(None, 4096, 1024, None, 1024, 1024, None, None, 1024, None) == -1
+    assert lib.m360_linear_wgrad_bf16_workspace_bytes(524288, 1024, 1024) >= 16 * 1024 * 1024 * 4
+    for switch in (lib.m360_set_backward_overlap, lib.m360_set_wgrad_bf16_form):
+        was = switch(0)
+        assert switch(was) == 0 and switch(was) == was
     with pytest.raises(RuntimeError, match="m360_ipe"):
         _lib.check(lib.m360_ipe(None, None, 5, None, None), "m360_ipe")
     m = _lib.ModelStruct()
