@@ -519,6 +519,16 @@ def named_workloads(sd_np, dev, _lib):
     out = {}
     t_all = time.perf_counter()
 
+    def guarded(name, fn, *a):
+        """An entry that fails (an out-of-memory on a shared box, ...) reports its error instead of costing the run its headline line."""
+        try:
+            fn(name, *a)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:500]}
+            torch.cuda.empty_cache()
+
     def forward_entry(name, cfg, mlp_dtype, steps, warm):
         n_rays, samples, _, metric, workload = CONFIGS[cfg]
         m = mipNeRF360(randomized=False, num_samples=samples, hidden_proposal=HP, hidden_nerf=HN, white_bkgd=False, device=dev,
@@ -544,9 +554,9 @@ def named_workloads(sd_np, dev, _lib):
         del m, rays
         torch.cuda.empty_cache()
 
-    forward_entry("c5_bf16", "c5", "bf16", 8, 2)        # BASELINE configs[4]'s per-GPU shape: 8192 x 256, bf16 MLP
-    forward_entry("c2_bf16", "c2", "bf16", 20, 3)       # configs[1]'s shape with the opt-in bf16 MLP
-    forward_entry("c2_bf16x3", "c2", "bf16x3", 10, 2)   # ... and with two bf16 terms per value (inside the fp32 tolerance)
+    guarded("c5_bf16", forward_entry, "c5", "bf16", 8, 2)        # BASELINE configs[4]'s per-GPU shape: 8192 x 256, bf16 MLP
+    guarded("c2_bf16", forward_entry, "c2", "bf16", 20, 3)       # configs[1]'s shape with the opt-in bf16 MLP
+    guarded("c2_bf16x3", forward_entry, "c2", "bf16x3", 10, 2)   # ... and with two bf16 terms per value (inside the fp32 tolerance)
 
     # ---- one iteration of the reference's training loop body (train.py:53-82: two proposal updates, one NeRF update, AdamW), in fp32 and
     # (round 5) with the student in bf16: bf16 tape and gradients in flight, fp32 accumulation, fp32 master weights + AdamW
@@ -629,34 +639,37 @@ def named_workloads(sd_np, dev, _lib):
             "dgrad_1024x1024": {"ms": round(dgrad_ms, 3), "tflops": round(flops / dgrad_ms / 1e9, 1), "frac": round(flops / dgrad_ms / 1e9 / peak, 4), "kernel": dk},
             "peak": peak, "unit": "TFLOP/s", "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
 
-    training_entry("c2_training_iteration", "fp32")
-    training_entry("c2_training_iteration_bf16", "bf16")
+    guarded("c2_training_iteration", training_entry, "fp32")
+    guarded("c2_training_iteration_bf16", training_entry, "bf16")
 
     # ---- a frame at the reference's CLI default chunk size (config.py:49: chunks = 128; configs[0]'s scene: lego 400 x 400, 64 samples per ray,
     # white background): 1250 chunks, each contracted by ITS OWN norm, launched 32 at a time (m360_hyper_t.norm_group_rays) - bit-identical to one
     # launch sequence per chunk (tests), here with a number
-    from mipnerf360_amd.intern.ray import generate_rays
-    fm = mipNeRF360(randomized=False, num_samples=64, hidden_proposal=HP, hidden_nerf=HN, white_bkgd=True, device=dev)
-    fm.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
-    fm.eval()
-    pose = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 4.0]], device=dev)
-    frays = generate_rays(pose, 400, 400, 555.6, 2.0, 6.0, False)
-    fm.render_rays(Rays(*[f[:8192] for f in frays]), chunks=128)  # warm-up: packing, workspace
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rgb, dist, acc = fm.render_rays(frays, chunks=128)
-    torch.cuda.synchronize()
-    sec = time.perf_counter() - t0
-    flops_ray = FLOPS_PER_SAMPLE * 64
-    out["c1_frame_chunks128"] = {
-        "config": "c1", "dtype": "f32", "workload": "nerf_synthetic/lego-like 400 x 400 frame (160 000 rays, synthetic pinhole pose, near 2 / far 6, white background), 64 samples per ray, "
-                                                    "rendered in the reference's default chunks of 128 rays (config.py:49) = 1250 chunks of their own contraction norm, 32 chunks per launch "
-                                                    "sequence; proposal 4x256 + NeRF 8x1024 MLPs in fp32 on MFMA, random-init Kaiming weights (BASELINE.json configs[0]'s scene on the GPU)",
-        "rays_per_s": round(160000 / sec, 1), "ms_per_step": round(sec * 1e3, 1), "steps": 1, "chunks": 128, "n_chunks": 1250,
-        "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(dist).all() and torch.isfinite(acc).all()),
-        "whole_path_tflops": round(160000 / sec * flops_ray / 1e12, 1), "frac_of_fp32_mfma_peak": round(160000 / sec * flops_ray / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
-    del fm, frays, rgb, dist, acc
-    torch.cuda.empty_cache()
+    def chunks128_entry(name):
+        from mipnerf360_amd.intern.ray import generate_rays
+        fm = mipNeRF360(randomized=False, num_samples=64, hidden_proposal=HP, hidden_nerf=HN, white_bkgd=True, device=dev)
+        fm.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+        fm.eval()
+        pose = torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 4.0]], device=dev)
+        frays = generate_rays(pose, 400, 400, 555.6, 2.0, 6.0, False)
+        fm.render_rays(Rays(*[f[:8192] for f in frays]), chunks=128)  # warm-up: packing, workspace
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rgb, dist, acc = fm.render_rays(frays, chunks=128)
+        torch.cuda.synchronize()
+        sec = time.perf_counter() - t0
+        flops_ray = FLOPS_PER_SAMPLE * 64
+        out[name] = {
+            "config": "c1", "dtype": "f32", "workload": "nerf_synthetic/lego-like 400 x 400 frame (160 000 rays, synthetic pinhole pose, near 2 / far 6, white background), 64 samples per ray, "
+                                                        "rendered in the reference's default chunks of 128 rays (config.py:49) = 1250 chunks of their own contraction norm, 32 chunks per launch "
+                                                        "sequence; proposal 4x256 + NeRF 8x1024 MLPs in fp32 on MFMA, random-init Kaiming weights (BASELINE.json configs[0]'s scene on the GPU)",
+            "rays_per_s": round(160000 / sec, 1), "ms_per_step": round(sec * 1e3, 1), "steps": 1, "chunks": 128, "n_chunks": 1250,
+            "finite": bool(torch.isfinite(rgb).all() and torch.isfinite(dist).all() and torch.isfinite(acc).all()),
+            "whole_path_tflops": round(160000 / sec * flops_ray / 1e12, 1), "frac_of_fp32_mfma_peak": round(160000 / sec * flops_ray / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        del fm, frays, rgb, dist, acc
+        torch.cuda.empty_cache()
+
+    guarded("c1_frame_chunks128", chunks128_entry)
     out["seconds"] = round(time.perf_counter() - t_all, 2)
     return out
 
@@ -825,27 +838,34 @@ def worker(args):
         # BASELINE configs[2] as written ("hierarchical 64+128 samples") beside the headline, and configs[3] for N > 1: the
         # same processes render one frame together (strong scaling).  64 proposal + 128 NeRF samples per ray is the build's
         # `num_samples_fine` extension (the reference draws as many NeRF as proposal samples, intern/ray.py:147).
-        fw, fh = frame_size(args)
-        fmodel = mipNeRF360(randomized=False, num_samples=64, num_samples_fine=128, hidden_proposal=HP, hidden_nerf=HN,
-                            white_bkgd=False, device=dev, mlp_dtype=mlp_dtype)
-        fmodel.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
-        fmodel.eval()
-        fprof = _lib.Prof(40 * ((fw * fh + FRAME_CHUNKS - 1) // FRAME_CHUNKS // world + 2) * args.frame_steps + 64)
-        fmodel.set_prof(fprof)
-        fr = frame_pipeline(fmodel, comm, args.frame_steps, 0, overlap=False, width=fw, height=fh)
-        fmodel.set_prof(None)
-        frecs = fprof.records()
-        fprof.close()
-        fr["samples_per_ray"] = "64 proposal + 128 NeRF (BASELINE configs[2]: 'hierarchical 64+128 samples')"
-        fr["flops_per_ray"] = 423424 * 64 + 14807040 * 128
-        fr["whole_path_tflops"] = round(fr["rays_per_s"] * fr["flops_per_ray"] / 1e12, 2)
-        froof = roofline_from_records(frecs, FRAME_CHUNKS * 128, bf16, "c2", _lib, x3)
-        fr["roofline"] = None if froof is None else {k: froof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")}
-        fr["workload"] = (f"DIAGNOSTIC frame size {fw}x{fh} instead of 1237x822; " if args.frame_size else "") + \
-            CONFIGS["c4"][4].format(mlp=MLP_NAMES[mlp_dtype]).replace("x 128 samples/ray", "x (64 proposal + 128 NeRF) samples/ray")
-        line["strong_scaling_frame"] = fr
-        del fmodel
-        torch.cuda.empty_cache()
+        # (an extra leg: the headline above is complete - an error here, e.g. in the first RCCL all-gather a multi-GPU node ever runs for
+        # this build, is reported in the line instead of costing the run its result)
+        try:
+            fw, fh = frame_size(args)
+            fmodel = mipNeRF360(randomized=False, num_samples=64, num_samples_fine=128, hidden_proposal=HP, hidden_nerf=HN,
+                                white_bkgd=False, device=dev, mlp_dtype=mlp_dtype)
+            fmodel.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+            fmodel.eval()
+            fprof = _lib.Prof(40 * ((fw * fh + FRAME_CHUNKS - 1) // FRAME_CHUNKS // world + 2) * args.frame_steps + 64)
+            fmodel.set_prof(fprof)
+            fr = frame_pipeline(fmodel, comm, args.frame_steps, 0, overlap=False, width=fw, height=fh)
+            fmodel.set_prof(None)
+            frecs = fprof.records()
+            fprof.close()
+            fr["samples_per_ray"] = "64 proposal + 128 NeRF (BASELINE configs[2]: 'hierarchical 64+128 samples')"
+            fr["flops_per_ray"] = 423424 * 64 + 14807040 * 128
+            fr["whole_path_tflops"] = round(fr["rays_per_s"] * fr["flops_per_ray"] / 1e12, 2)
+            froof = roofline_from_records(frecs, FRAME_CHUNKS * 128, bf16, "c2", _lib, x3)
+            fr["roofline"] = None if froof is None else {k: froof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")}
+            fr["workload"] = (f"DIAGNOSTIC frame size {fw}x{fh} instead of 1237x822; " if args.frame_size else "") + \
+                CONFIGS["c4"][4].format(mlp=MLP_NAMES[mlp_dtype]).replace("x 128 samples/ray", "x (64 proposal + 128 NeRF) samples/ray")
+            line["strong_scaling_frame"] = fr
+            del fmodel
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            line["strong_scaling_frame"] = {"error": f"{type(e).__name__}: {e}"[:500]}
 
     if rank != 0:
         comm.close()
@@ -853,7 +873,7 @@ def worker(args):
 
     if args.config == "c2" and mlp_dtype == "fp32" and world == 1 and not args.no_named:
         line["named_workloads"] = named_workloads(sd_np, dev, _lib)
-        if "strong_scaling_frame" in line:  # BASELINE configs[2] is the frame leg above: listed with the others
+        if "strong_scaling_frame" in line and "error" not in line["strong_scaling_frame"]:  # BASELINE configs[2] is the frame leg above: listed with the others
             fr = line["strong_scaling_frame"]
             line["named_workloads"]["c3_frame_64+128"] = {
                 "config": "c3", "dtype": "f32", "workload": fr["workload"], "rays_per_s": fr["rays_per_s"],
