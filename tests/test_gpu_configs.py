@@ -424,7 +424,9 @@ def test_bench_default_line_carries_every_single_gpu_config(dev):
     assert line["roofline"]["bound"] == "mfma" and 0.9 < line["roofline"]["frac"] < 1.0 and line["value"] > 6e4
     for k in ("encode_features", "prop_finish", "nerf_finish"):
         assert 0 < line["hbm_kernels"][k]["frac_of_8TBps"] <= 1.0
+        assert abs(line["hbm_kernels"][k]["frac_of_measured_copy_6p29TBps"] - line["hbm_kernels"][k]["frac_of_8TBps"] * 8000 / 6290) < 2e-3
     fr = line["strong_scaling_frame"]
+    assert "error" not in fr and not any("error" in v for v in line["named_workloads"].values() if isinstance(v, dict))  # (the extra legs are fail-soft)
     assert fr["finite"] and "64 proposal + 128 NeRF" in fr["samples_per_ray"] and fr["flops_per_ray"] == 423424 * 64 + 14807040 * 128
     nw = line["named_workloads"]
     assert set(nw) >= {"c5_bf16", "c2_bf16", "c2_bf16x3", "c2_training_iteration", "c2_training_iteration_bf16", "c3_frame_64+128", "seconds"}
