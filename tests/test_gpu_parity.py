@@ -1409,6 +1409,7 @@ def test_forward_bf16_mode(dev, kind, B, n, hp, hn, wb):
     emu = O.forward(O.rays_from_numpy(r), sdt, O.Hyper(num_samples=n, white_bkgd=wb, mlp_bf16=True))
     ref = O.forward(O.rays_from_numpy(r), sdt, O.Hyper(num_samples=n, white_bkgd=wb))
     assert float((rgb.detach().cpu() - emu[0]).abs().max()) <= 6e-3 and float((acc.detach().cpu() - emu[2]).abs().max()) <= 6e-3
+    rgb, acc = rgb.detach(), acc.detach()
     assert float((rgb.cpu() - ref[0]).abs().max()) <= 2e-2 and float((acc.cpu() - ref[2]).abs().max()) <= 2e-2
     mse = float(((rgb.cpu() - ref[0]) ** 2).mean())
     assert -10 * np.log10(max(mse, 1e-20)) > 45.0  # PSNR of the bf16 render against the fp32 render
