@@ -70,10 +70,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
     long s_end = s_begin + steps_per_split;
     if (s_end > total_steps) s_end = total_steps;
     const long nk = s_end > s_begin ? s_end - s_begin : 0;  // k-steps of this workgroup
-    // bias gradient (the host sends layers with fewer than 4 k tiles to the 8-wave kernel): k tile kt < 4, waves wk == 0 add up dZ blocks 2 kt, 2 kt + 1
-    // of their n half against a fragment of ones - 2 extra MFMAs per 64
-    const bool bias_wave = bias_partial != nullptr && wk == 0 && kt < 4;
-    f32x4 acc[8][8], bacc[2] = {(f32x4){0.0f, 0.0f, 0.0f, 0.0f}, (f32x4){0.0f, 0.0f, 0.0f, 0.0f}};
+    // bias gradient (the host sends layers with fewer than 4 k tiles to the 8-wave kernel): in the workgroups of k tiles kt < 4 wave (wn, wk) adds up dZ
+    // block 2 kt + wk of its n half against a fragment of ones - 1 extra MFMA per 64 and wave.  (Measured: the bias gradient costs the kernel ~0.1 ms of
+    // 1.0 whichever way its two MFMAs per k-step are issued - selected by v_cndmask on two waves, by a wave-uniform switch, or one per wave as here.)
+    const bool bias_wave = bias_partial != nullptr && kt < 4;
+    const int bias_blk = 2 * kt + wk;  // wave-uniform: the dZ block (of this wave's n half) whose column sums this wave forms - ONE extra MFMA per k-step and wave
+    f32x4 acc[8][8], bacc = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -117,9 +119,10 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
         };
         const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
 #define TNW_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
-// the bias sums: ArchVGPRs (the 256 AccVGPRs are the tile's).  Their operands are VALU results (the selected dZ fragment, the ones): an MFMA must not
-// read a VGPR within 2 wait states of the VALU write, and behind inline assembly the hazard recogniser cannot insert them - hence the s_nop
-#define TNW_MFMA_V(ACC, A, B) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+// the bias sum's MFMA: accumulator in ArchVGPRs; s_nop 1 in front: one operand is a VALU result (the ones), and an MFMA must not read a VGPR within 2
+// wait states of the VALU write - behind inline assembly the hazard recogniser cannot insert them; 2 x s_nop 15 behind: the MFMA's own latency (above)
+#define TNW_MFMA_V1(ACC, A, B)                                                                                                          \
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15" : "+v"(ACC) : "v"(A), "v"(B))
 #define TNW_SB() __builtin_amdgcn_sched_barrier(0)
 
         // ---- prologue: k-steps 0 .. 3 on their way (8 pieces each), quarter 0 awaited and read
@@ -155,19 +158,21 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
                     const unsigned soff_a = ksn * step_a, soff_b = ksn * step_b;
                     const unsigned aq = a_base + qoff, bq = b_base + qoff;
                     const bool more = ii + 1 < nk;  // wave-uniform: the last k-step has nothing to read ahead
-                    // the bias sums FIRST: their accumulators live in ArchVGPRs, where the compiler may copy them at the loop's edges - and an MFMA
-                    // result read too early is a software hazard the hazard recogniser cannot see behind inline assembly (a first form that ran
-                    // these two MFMAs at the END of the k-step returned NaNs in the bias gradient): 64 MFMAs later they are long written
+                    // the bias sum: its accumulator lives in ArchVGPRs (the 256 AccVGPRs are the tile's), where the compiler copies it at branch
+                    // and loop edges - and an MFMA result read too early is a software hazard the hazard recogniser cannot see behind inline
+                    // assembly (forms without the wait inside the statement returned NaNs / garbage in the bias gradient).  Which dZ fragment: a
+                    // wave-uniform switch (no vector selects in the K loop).
                     if (bias_wave) {
-                        bf16x8 fbias0 = ones, fbias1 = ones;
-#pragma unroll
-                        for (int pr = 0; pr < 4; ++pr)
-                            if (pr == kt) {
-                                fbias0 = fa[par][2 * pr];
-                                fbias1 = fa[par][2 * pr + 1];
-                            }
-                        TNW_MFMA_V(bacc[0], ones, fbias0);
-                        TNW_MFMA_V(bacc[1], ones, fbias1);
+                        switch (bias_blk) {
+                            case 0: TNW_MFMA_V1(bacc, ones, fa[par][0]); break;
+                            case 1: TNW_MFMA_V1(bacc, ones, fa[par][1]); break;
+                            case 2: TNW_MFMA_V1(bacc, ones, fa[par][2]); break;
+                            case 3: TNW_MFMA_V1(bacc, ones, fa[par][3]); break;
+                            case 4: TNW_MFMA_V1(bacc, ones, fa[par][4]); break;
+                            case 5: TNW_MFMA_V1(bacc, ones, fa[par][5]); break;
+                            case 6: TNW_MFMA_V1(bacc, ones, fa[par][6]); break;
+                            default: TNW_MFMA_V1(bacc, ones, fa[par][7]); break;
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
 #undef TNW_DMA
 #undef TNW_MFMA
 #undef TNW_MFMA_V
+#undef TNW_MFMA_V1
 #undef TNW_SB
     }
 
@@ -202,10 +208,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4 *>(P + (long)(nrow + 16 * a) * Kp + kcol + 16 * j) = acc[a][j];
-    if (bias_wave && g == 0) {  // every row of the ones product holds the column sums: row 0 = lanes 0 .. 15, register 0
-        bias_partial[(long)split * Np + nrow + 16 * (2 * kt)] = bacc[0][0];
-        bias_partial[(long)split * Np + nrow + 16 * (2 * kt + 1)] = bacc[1][0];
-    }
+    if (bias_wave && g == 0)  // every row of the ones product holds the column sums: row 0 = lanes 0 .. 15, register 0
+        bias_partial[(long)split * Np + nrow + 16 * bias_blk] = bacc[0];
 }
 
 }  // namespace tn16w
