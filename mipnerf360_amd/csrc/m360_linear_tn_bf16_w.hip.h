@@ -196,7 +196,6 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #undef TNW_DMA
 #undef TNW_MFMA
-#undef TNW_MFMA_V
 #undef TNW_MFMA_V1
 #undef TNW_SB
     }
