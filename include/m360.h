@@ -232,7 +232,9 @@ int m360_set_wgrad_bf16_form(int form);
 /* A/B switch of m360_prop_backward / m360_nerf_backward in the bf16 mode, process-wide: 1 (default) = the ReLU mask of a layer's input gradient
  * runs on a second stream of the library beside that layer's weight gradient (forked from and joined to the caller's stream inside the call: the
  * caller sees one stream), 0 = everything on the caller's stream (values > 1, A/B runs only: on, with that many workgroups of the throttled mask
- * kernel instead of one per CU).  Same bits either way.  Returns the old setting (0 / 1).
+ * kernel instead of one per CU).  Weight gradients: the same bits either way; the bias gradients of the layers below the top one are, in the
+ * overlapped form, the column sums the mask kernel forms on its way (its rows are the next layer's dz), on one stream the weight-gradient kernel's
+ * ones-product: the same fp32 sums in another order, both deterministic.  Returns the old setting (0 / 1).
  * The second stream and its two events are the library's, one set per process, created on first use for the device current then (other devices:
  * everything on the caller's stream): backward calls of ONE host thread at a time, as torch's autograd engine issues them. */
 int m360_set_backward_overlap(int on);

@@ -76,7 +76,11 @@ int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int 
 int mlp_chain_bf16_rerun(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
                          int layers, int width, void *ws, m360_stream_t stream);
 // m360_linear.hip: the ReLU mask of m360_linear_dgrad_bf16 on its own (mlp_backward_bf16 overlaps it with the weight gradient)
-int relu_mask_bf16(void *dx, const void *relu_out, long M, int k_pad, int ldx, m360_stream_t stream, int blocks /* > 0: that many striding workgroups */);
+int relu_mask_bf16(void *dx, const void *relu_out, long M, int k_pad, int ldx, m360_stream_t stream, int blocks /* > 0: that many striding workgroups */,
+                   float *sums_part /* != NULL: [blocks][k_pad] column sums of the masked rows per workgroup */);
+bool relu_mask_bf16_sums_ok(long M, int k_pad, int blocks);
+int relu_mask_bf16_sums_reduce(const float *part, int blocks, int k_pad, float *grad_b, m360_stream_t stream);
+size_t relu_mask_bf16_sums_bytes(int blocks);
 
 // brackets the launches of ONE public entry point with two HIP events on the launch stream
 struct ProfScope {
@@ -779,20 +783,33 @@ static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *con
     void *gemm_ws = ws + L.gemm;
     const size_t gemm_bytes = L.finish - L.gemm;
     SideStream *ss = (g_backward_overlap && S >= 32768 && !(h && h->prof)) ? side_stream() : nullptr;  // (a recorder brackets launches of ONE stream)
+    // The masked rows the second stream writes ARE the next layer's dz: their column sums - that layer's bias gradient - come out of the mask kernel
+    // (it meets every element anyway and runs beside, not in front of, the matrix work), where the weight-gradient kernel pays ~0.1 ms of its 1.0 for
+    // them.  Its partial sums (2 MB) live in the finishers' backward scratch (read for the last time before this function runs).
+    float *mask_part = reinterpret_cast<float *>(ws + L.finish);
+    const bool mask_sums = ss && relu_mask_bf16_sums_ok(S, width, g_backward_mask_blocks) && relu_mask_bf16_sums_bytes(g_backward_mask_blocks) <= L.feat_wide - L.finish;
+    bool have_bias = false;  // grad_b[l] already written (by the mask that produced this layer's dz)
     for (int l = layers - 1; l >= 0; --l) {
         if (!grad_w[l] || !grad_b[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: gradient buffer of layer %d is null", who, l);
+        float *gb = have_bias ? nullptr : grad_b[l];
+        have_bias = false;
         if (l > 0 && ss) {
             if (!w_t[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: transposed weight of layer %d is null", who, l);
             hipStream_t hs = reinterpret_cast<hipStream_t>(st);
+            m360_stream_t s2 = reinterpret_cast<m360_stream_t>(ss->s);
             M360_TRY(m360_linear_dgrad_bf16(dz, S, width, w_t[l], width, width, nullptr, dz_other, width, st));
             if (hipEventRecord(ss->fork, hs) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return fail(M360_ERR_LAUNCH, "%s: fork to the second stream failed: %s", who, hipGetErrorString(hipGetLastError()));
-            M360_TRY(relu_mask_bf16(dz_other, act[l - 1], S, width, width, reinterpret_cast<m360_stream_t>(ss->s), g_backward_mask_blocks));
+            M360_TRY(relu_mask_bf16(dz_other, act[l - 1], S, width, width, s2, g_backward_mask_blocks, mask_sums ? mask_part : nullptr));
+            if (mask_sums) {
+                M360_TRY(relu_mask_bf16_sums_reduce(mask_part, g_backward_mask_blocks, width, grad_b[l - 1], s2));
+                have_bias = true;
+            }
             if (hipEventRecord(ss->join, ss->s) != hipSuccess) return fail(M360_ERR_LAUNCH, "%s: join event failed: %s", who, hipGetErrorString(hipGetLastError()));
-            M360_TRY(m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], grad_b[l], gemm_ws, gemm_bytes, st));
+            M360_TRY(m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], gb, gemm_ws, gemm_bytes, st));
             if (hipStreamWaitEvent(hs, ss->join, 0) != hipSuccess) return fail(M360_ERR_LAUNCH, "%s: join of the second stream failed: %s", who, hipGetErrorString(hipGetLastError()));
             void *tmp = dz; dz = dz_other; dz_other = tmp;
         } else if (l > 0) {
-            M360_PROF(h, st, M360_K_WGRAD, S, width, -width, m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], grad_b[l], gemm_ws, gemm_bytes, st));
+            M360_PROF(h, st, M360_K_WGRAD, S, width, -width, m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], gb, gemm_ws, gemm_bytes, st));
             if (!w_t[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: transposed weight of layer %d is null", who, l);
             M360_PROF(h, st, M360_K_DGRAD, S, width, -width, m360_linear_dgrad_bf16(dz, S, width, w_t[l], width, width, act[l - 1], dz_other, width, st));
             void *tmp = dz; dz = dz_other; dz_other = tmp;
@@ -809,7 +826,7 @@ static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *con
                 ld0 = L.first_k;
             }
             float *r = reinterpret_cast<float *>(ws + L.first);
-            M360_PROF(h, st, M360_K_WGRAD, S, width, -L.first_k, m360_linear_wgrad_bf16(dz, width, x0, ld0, S, width, L.first_k, r, grad_b[0], gemm_ws, gemm_bytes, st));
+            M360_PROF(h, st, M360_K_WGRAD, S, width, -L.first_k, m360_linear_wgrad_bf16(dz, width, x0, ld0, S, width, L.first_k, r, gb, gemm_ws, gemm_bytes, st));
             hipLaunchKernelGGL(fold_first_layer_kernel, dim3((unsigned)((width * in_pad + 255) / 256)), dim3(256), 0, hs, r, width, L.first_k, in_pad, grad_w[0]);
             M360_TRY(check_launch(who));
         }

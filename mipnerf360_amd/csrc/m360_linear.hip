@@ -950,13 +950,29 @@ int m360_linear_bf16_split(const void *x, long M, int ldx, const void *w_packed,
 namespace m360 {
 // dx[m, k] = relu_out[m, k] > 0 ? dx[m, k] : 0 in place (the second half of m360_linear_dgrad_bf16; m360_capi.hip runs it on a second stream
 // beside the layer's weight gradient, which does not read dx)
-int relu_mask_bf16(void *dx, const void *relu_out, long M, int k_pad, int ldx, m360_stream_t stream, int blocks) {
+// can the throttled form with `blocks` workgroups also form the column sums of the masked rows (mlp_backward_bf16: the next layer's bias gradient)?
+bool relu_mask_bf16_sums_ok(long M, int k_pad, int blocks) {
+    const int c8 = k_pad / 8;
+    return k_pad % 8 == 0 && c8 >= 1 && c8 <= 256 && 256 % c8 == 0 && blocks > 0 && (M * c8 + 255) / 256 > blocks;
+}
+// bytes of its part[blocks * 256 / (k_pad / 8)][k_pad] (one row of sums per thread group: 8 floats per thread)
+size_t relu_mask_bf16_sums_bytes(int blocks) { return (size_t)blocks * 256 * 8 * sizeof(float); }
+// ... and the reduction of those rows into grad_b[k_pad] (ascending)
+int relu_mask_bf16_sums_reduce(const float *part, int blocks, int k_pad, float *grad_b, m360_stream_t stream) {
+    if (!part || !grad_b || blocks < 1 || k_pad < 8) return fail(M360_ERR_INVALID_ARGUMENT, "relu_mask_bf16_sums_reduce: bad argument");
+    hipLaunchKernelGGL(tn16::tn16_bias_reduce_kernel, dim3((unsigned)((k_pad + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, blocks * (256 / (k_pad / 8)), k_pad, static_cast<const __bf16 *>(nullptr), 0, 0l, 0l, grad_b);
+    return check_launch("linear_dgrad_bf16 (column sums of the masked rows)");
+}
+int relu_mask_bf16(void *dx, const void *relu_out, long M, int k_pad, int ldx, m360_stream_t stream, int blocks, float *sums_part) {
     if (!dx || !relu_out || M < 0 || k_pad < 8 || k_pad % 8 || ldx < k_pad || ldx % 8) return fail(M360_ERR_INVALID_ARGUMENT, "relu_mask_bf16: bad argument (M=%ld k_pad=%d ldx=%d)", M, k_pad, ldx);
     if (((uintptr_t)relu_out | (uintptr_t)dx) & 15) return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_dgrad_bf16: relu_out / dx must be 16-byte aligned");
     if (M == 0) return M360_OK;
     const long n = M * (k_pad / 8);
-    if (blocks > 0 && (n + 255) / 256 > blocks)  // beside another kernel: a fixed number of workgroups (m360_capi.hip: mlp_backward_bf16)
-        hipLaunchKernelGGL(tn16::relu_mask_bf16_stride_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<__bf16 *>(dx), static_cast<const __bf16 *>(relu_out), M, k_pad, ldx);
+    if (sums_part && !relu_mask_bf16_sums_ok(M, k_pad, blocks)) return fail(M360_ERR_INVALID_ARGUMENT, "relu_mask_bf16: column sums need the throttled form on a width whose eighth divides 256 (M=%ld k_pad=%d blocks=%d)", M, k_pad, blocks);
+    if (sums_part)
+        hipLaunchKernelGGL((tn16::relu_mask_bf16_stride_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<__bf16 *>(dx), static_cast<const __bf16 *>(relu_out), M, k_pad, ldx, sums_part);
+    else if (blocks > 0 && (n + 255) / 256 > blocks)  // beside another kernel: a fixed number of workgroups (m360_capi.hip: mlp_backward_bf16)
+        hipLaunchKernelGGL((tn16::relu_mask_bf16_stride_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<__bf16 *>(dx), static_cast<const __bf16 *>(relu_out), M, k_pad, ldx, static_cast<float *>(nullptr));
     else
         hipLaunchKernelGGL(tn16::relu_mask_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), static_cast<__bf16 *>(dx), static_cast<const __bf16 *>(relu_out), M, k_pad, ldx);
     return check_launch("linear_dgrad_bf16 (ReLU mask)");
@@ -983,7 +999,7 @@ int m360_linear_dgrad_bf16(const void *dz, long M, int ldz, const void *wt_packe
     if (hipGetSymbolAddress(reinterpret_cast<void **>(&zero_bias), HIP_SYMBOL(g_zero_bias)) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_linear_dgrad_bf16: zero bias symbol not found");
     const int rc = m360_linear_bf16(dz, M, ldz, wt_packed_bf16, zero_bias, k_pad, n_pad, M360_ACT_NONE, dx, ldx, stream);
     if (rc != M360_OK || !relu_out || M == 0) return rc;
-    return m360::relu_mask_bf16(dx, relu_out, M, k_pad, ldx, stream, 0);
+    return m360::relu_mask_bf16(dx, relu_out, M, k_pad, ldx, stream, 0, nullptr);
 }
 
 // which MFMA form m360_linear_wgrad_bf16 runs (A/B switch, process-wide like m360_set_paired_rows): 1 = one wave per SIMD, 128 x 128 wave tiles,

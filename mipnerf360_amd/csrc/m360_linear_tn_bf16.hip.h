@@ -300,11 +300,16 @@ __global__ __launch_bounds__(256) void relu_mask_bf16_kernel(__bf16 *__restrict_
 }
 
 // The same mask by a FIXED number of workgroups striding over the rows (U pieces per thread in flight): the form m360_capi.hip runs on a second
-// stream beside the layer's weight gradient - throttled so that it takes about as long as that kernel instead of saturating the HBM for half of it
-template <int U>
-__global__ __launch_bounds__(256) void relu_mask_bf16_stride_kernel(__bf16 *__restrict__ dx, const __bf16 *__restrict__ relu_out, long M, int cols, int ld) {
+// stream beside the layer's weight gradient - throttled so that it takes about as long as that kernel instead of saturating the HBM for half of it.
+// SUMS: the masked rows ARE the next layer's dz, whose column sums are that layer's bias gradient - a thread always meets the same 8 columns
+// (the stride is a multiple of cols / 8: the host checks), so it adds them up in registers on the way and writes them to part[workgroups x 256 /
+// (cols / 8)][cols]; tn16_bias_reduce_kernel adds those rows in ascending order: deterministic.
+template <int U, bool SUMS>
+__global__ __launch_bounds__(256) void relu_mask_bf16_stride_kernel(__bf16 *__restrict__ dx, const __bf16 *__restrict__ relu_out, long M, int cols, int ld,
+                                                                    float *__restrict__ part) {
     const int c8 = cols / 8;
     const long total = M * c8, stride = (long)gridDim.x * blockDim.x;
+    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += U * stride) {
         long o[U];
         s16x8 v[U], a[U];
@@ -321,8 +326,21 @@ __global__ __launch_bounds__(256) void relu_mask_bf16_stride_kernel(__bf16 *__re
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[u][i] = a[u][i] > 0 ? v[u][i] : (short)0;
-            if (u == 0 || idx + u * stride < total) *reinterpret_cast<s16x8 *>(dx + o[u]) = v[u];
+            if (u == 0 || idx + u * stride < total) {
+                *reinterpret_cast<s16x8 *>(dx + o[u]) = v[u];
+                if (SUMS) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += __builtin_bit_cast(float, (unsigned)(unsigned short)v[u][i] << 16);  // bf16 -> fp32: exact
+                }
+            }
         }
+    }
+    if (SUMS) {  // (256 % c8 == 0 and c8 <= 256: thread t's column group is t % c8 in every workgroup.)  No LDS: the kernel runs beside one that
+        // owns all 160 KB of every CU - with a shared array its workgroups wait for that kernel to END (measured: +1.9 ms per layer).  Every
+        // thread writes its own sums: part[(workgroup * 256 / c8 + t / c8)][cols]
+        float *row = part + ((long)blockIdx.x * (256 / c8) + threadIdx.x / c8) * cols + 8 * (threadIdx.x % c8);
+        *reinterpret_cast<float4 *>(row) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4 *>(row + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
 }
 
