@@ -212,6 +212,20 @@ def _set_randomized(hyper, device, jitter: bool, cdf: bool):
     return hyper.rng_seed, hyper.rng_offset
 
 
+def _replay_uniforms(module, shape, device):
+    """`module.replay_uniforms` (default None): unit uniforms in [0, 1) a randomized stage uses INSTEAD of drawing its own - the
+    jitter's `torch.rand` of intern/ray.py:104 ([B, N + 1]) for prop_net, the draw behind `uniform_(to=s - eps)` of intern/ray.py:33 for
+    nerf_net.  This is how recorded draws of the reference are replayed through the kernels (fixture G22); ignored unless the module is
+    randomized, like the reference ignores its generator then."""
+    u = getattr(module, "replay_uniforms", None)
+    if u is None or not module.randomized:
+        return None
+    u = ops.dev(u, "replay_uniforms")
+    if tuple(u.shape) != tuple(shape):
+        raise RuntimeError(f"replay_uniforms has shape {tuple(u.shape)}, this forward draws {tuple(shape)}")
+    return u
+
+
 def _mutable_field(rays, name):
     """The caller's own tensor of a ray field, for the in-place bumps of mutate_like_reference mode."""
     t = getattr(rays, name)
@@ -358,6 +372,7 @@ class prop_net(nn.Module):
         self.to(device)
         self._packed = _PackedMLP()
         self.mutate_like_reference = MUTATE_LIKE_REFERENCE
+        self.replay_uniforms = None  # unit uniforms to use instead of drawing (see _replay_uniforms)
 
     def _pack(self, defer_nan: bool = False) -> _PackedMLP:
         return self._packed.refresh([self.model[i] for i in (0, 2, 4, 6)], [self.model[8]],
@@ -396,8 +411,9 @@ class prop_net(nn.Module):
                               prof=getattr(self, "prof", None))
         t_hat = torch.empty(B, N + 1, device=dev)
         w_hat = torch.empty(B, N, device=dev)
-        t_rand = None  # randomized: drawn inside the kernels (stage_prologue_kernel / sample_t_kernel)
-        self.last_rng = _set_randomized(hyper, dev, bool(self.randomized), False)
+        # randomized: drawn inside the kernels (stage_prologue_kernel / sample_t_kernel) unless uniforms are handed in for replay
+        t_rand = _replay_uniforms(self, (B, N + 1), dev)
+        self.last_rng = _set_randomized(hyper, dev, bool(self.randomized) and t_rand is None, False)
         ws = _ws_for(B, N, mstruct, dev)
         if train:
             tc = _TrainCtx(self, 0, keep, rstruct, B, N, hyper, packed, mstruct)
@@ -442,6 +458,7 @@ class nerf_net(nn.Module):
         self.to(device)
         self._packed = _PackedMLP()
         self.mutate_like_reference = MUTATE_LIKE_REFERENCE
+        self.replay_uniforms = None  # unit uniforms to use instead of drawing (see _replay_uniforms)
 
     def _pack(self, defer_nan: bool = False) -> _PackedMLP:
         return self._packed.refresh([self.model[i] for i in range(0, 16, 2)],
@@ -495,8 +512,9 @@ class nerf_net(nn.Module):
         hyper = self._hyper(N, Nf)
         outs = _alloc_outputs(B, Nf, dev, with_prop=False)
         ostruct = _outputs_struct(outs)
-        u_rand = None  # randomized: drawn inside the resample kernel
-        self.last_rng = _set_randomized(hyper, dev, False, bool(self.randomized))
+        # randomized: drawn inside the resample kernel unless uniforms are handed in for replay
+        u_rand = _replay_uniforms(self, (B, Nf + 1), dev)
+        self.last_rng = _set_randomized(hyper, dev, False, bool(self.randomized) and u_rand is None)
         ws = _ws_for(B, max(N, Nf), mstruct, dev)
         if train:
             tc = _TrainCtx(self, 1, keep, rstruct, B, Nf, hyper, self._packed, mstruct)
@@ -639,6 +657,8 @@ class mipNeRF360(nn.Module):
     def forward(self, rays):
         """model.py:247-252 -> (rgb[B,3], distance[B], acc[B])."""
         staged = self.prop_net.mutate_like_reference or self.nerf_net.mutate_like_reference
+        # recorded draws to replay (fixture G22): the staged entry points take them as t_rand / u_rand, m360_forward has no such argument
+        staged = staged or getattr(self.prop_net, "replay_uniforms", None) is not None or getattr(self.nerf_net, "replay_uniforms", None) is not None
         if not _wants_grad(self) and not staged:  # randomized or not: the kernels draw their own uniforms (round 5)
             return self._forward_fused(rays)
         t_hat, w_hat = self.prop_net.forward(rays)

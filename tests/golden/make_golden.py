@@ -919,10 +919,142 @@ def g21():
     save("g21_structured_gradients", **out)
 
 
+# ----------------------------------------------------------------------------- G22: the randomized branches, draws RECORDED
+class record_draws:
+    """Record - not replace - what the reference draws in its randomized branches: `torch.rand` (the stratified jitter,
+    intern/ray.py:104) and `Tensor.uniform_(to=s - eps)` (the inverse CDF, intern/ray.py:33).  The reference runs unmodified on
+    torch's own CPU generator; every tensor those two calls return is kept.  For `uniform_` the UNIT uniform behind the scaled value
+    is recovered too: torch's CPU kernel computes x * (to - from) + from with x = (random & (2^24 - 1)) * 2^-24 from the same
+    generator stream `torch.rand` reads, so replaying the generator state it started from through `torch.rand` gives x - checked
+    bit for bit against the scaled tensor the reference received (x * float32(to) == scaled), then the generator is put back where the
+    reference left it."""
+
+    def __enter__(self):
+        self.rand, self.uniform_scaled, self.uniform_unit, self.uniform_to = [], [], [], []
+        self._rand, self._uniform = torch.rand, torch.Tensor.uniform_
+        rec = self
+
+        def rand(*a, **k):
+            out = rec._rand(*a, **k)
+            rec.rand.append(out.clone())
+            return out
+
+        def uniform_(t, *a, **k):
+            assert not a and set(k) == {"to"}, (a, k)   # the reference's only form: uniform_(to=...)
+            before = torch.get_rng_state()
+            out = rec._uniform(t, **k)
+            after = torch.get_rng_state()
+            torch.set_rng_state(before)
+            unit = rec._rand(t.shape, dtype=t.dtype)
+            torch.set_rng_state(after)
+            to = torch.tensor(k["to"], dtype=t.dtype)
+            assert torch.equal(unit * to, out), "uniform_(to=) is not rand * to on this torch build"
+            rec.uniform_scaled.append(out.clone())
+            rec.uniform_unit.append(unit)
+            rec.uniform_to.append(float(k["to"]))
+            return out
+
+        torch.rand, torch.Tensor.uniform_ = rand, uniform_
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.Tensor.uniform_ = self._rand, self._uniform
+
+
+def g22():
+    """Fixture G22: intern/ray.py:103-108 (jitter) and :30-35 (randomized inverse CDF: `u + u`, the scaled
+    uniform, the 1 - eps clamp) - the reference's CLI default (config.py:15) - run with randomized=True, draws recorded."""
+    out = {}
+    torch.manual_seed(2222)
+    # (1) sample_along_rays: jittered t, and the Gaussians built from them
+    for kind in ("lego", "garden"):
+        for n in (8, 64, 128):
+            r = synthetic.make_rays(kind, 5, seed=22)
+            with record_draws() as rec:
+                t_vals, (means, covs) = ref_ray.sample_along_rays(
+                    T(r["origins"]), T(r["directions"]), T(r["radii"]), n, T(r["near"]), T(r["far"]), True)
+            assert len(rec.rand) == 1 and not rec.uniform_scaled
+            key = f"sample_{kind}_{n}"
+            out[key + "_t_rand"], out[key + "_t"] = N(rec.rand[0]), N(t_vals)
+            out[key + "_means"], out[key + "_covs"] = N(means), N(covs)
+        for k in synthetic.RAY_FIELDS:
+            out[f"sample_{kind}_rays_{k}"] = synthetic.make_rays(kind, 5, seed=22)[k]
+    # (2) the bare sampler: uniform, peaked, all-zero (padding branch), near-empty (sum < 1e-5: padding branch with a remainder), and
+    # an output count that differs from the bin count
+    g = np.random.Generator(np.random.PCG64(2266))
+    B, n = 7, 48
+    t = np.sort(g.uniform(2, 6, size=(B, n + 1)), axis=1).astype(np.float32)
+    w = g.uniform(0, 1, size=(B, n)).astype(np.float32)
+    w[0] = 1.0 / n
+    w[1] = 0.0
+    w[1, 17] = 1.0
+    w[2] = 0.0
+    w[3] = np.exp(-0.5 * ((np.arange(n) - 30) / 2.0) ** 2)
+    w[4] = 1e-8 * g.uniform(0, 1, size=n)            # sums to ~2.4e-7 < 1e-5: the pad is added to unequal weights
+    out["pdf_t"], out["pdf_w"] = t, w
+    for ns in (n + 1, 16, 128):
+        with record_draws() as rec:
+            smp = ref_ray.sorted_piecewise_constant_pdf(T(t), T(w), ns, randomized=True)
+        assert len(rec.uniform_unit) == 1 and not rec.rand
+        out[f"pdf_{ns}_u_unit"], out[f"pdf_{ns}_u_scaled"] = N(rec.uniform_unit[0]), N(rec.uniform_scaled[0])
+        out[f"pdf_{ns}_to"] = np.array(rec.uniform_to[0], dtype=np.float64)
+        out[f"pdf_{ns}_samples"] = N(smp)
+    # (3) resample_along_rays (blur + padding + randomized sampler + Gaussians), N in {8, 64, 128}
+    for n2 in (8, 64, 128):
+        r = synthetic.make_rays("lego" if n2 != 64 else "garden", 4, seed=220 + n2)
+        lo, hi = float(r["near"][0, 0]), float(r["far"][0, 0])
+        t2 = np.sort(g.uniform(lo + 1e-3, hi, size=(4, n2 + 1)), axis=1).astype(np.float32)
+        w2 = (g.uniform(0, 1, size=(4, n2)) ** 4).astype(np.float32)
+        w2[1] = 0.0                                   # all-zero ray: only the padding remains
+        w2[2] = 0.0
+        w2[2, n2 // 3] = 0.9                          # a single surface
+        for pad in (0.01, 0.0):
+            with record_draws() as rec:
+                new_t, (means, covs) = ref_ray.resample_along_rays(T(r["origins"]), T(r["directions"]), T(r["radii"]), T(t2), T(w2), True, pad)
+            key = f"resample_{n2}_pad{pad}"
+            out[key + "_u_unit"], out[key + "_u_scaled"] = N(rec.uniform_unit[0]), N(rec.uniform_scaled[0])
+            out[key + "_t"] = N(new_t)
+            if pad == 0.01:
+                out[key + "_means"], out[key + "_covs"] = N(means), N(covs)
+        out[f"resample_{n2}_t_in"], out[f"resample_{n2}_w_in"] = t2, w2
+        for k in synthetic.RAY_FIELDS:
+            out[f"resample_{n2}_rays_{k}"] = r[k]
+    # (4) both stage forwards of a randomized model (reduced width; model.py:80-94,163-200), and eval() leaving the sub-nets
+    # randomized (model.py:281-283 switches only the outer flag)
+    hp_, hn_ = 32, 64
+    sd = synthetic.make_state_dict(hp_, hn_, seed=22)
+    for k, v in sd.items():
+        out["sd." + k] = v
+    for kind, Bm, nm, wb in (("lego", 10, 16, True), ("garden", 8, 64, False), ("lego", 3, 128, False)):
+        r = synthetic.make_rays(kind, Bm, seed=2200 + nm)
+        m = ref_model.mipNeRF360(randomized=True, num_samples=nm, hidden_proposal=hp_, hidden_nerf=hn_, white_bkgd=wb, device=CPU)
+        m.load_state_dict({k: T(v) for k, v in sd.items()})
+        m.eval()
+        assert m.prop_net.randomized and m.nerf_net.randomized   # eval() leaves the sub-nets' flags alone
+        out[f"stage_{kind}_{nm}_outer_randomized_after_eval"] = np.array(int(bool(m.randomized)))  # nn.Module.eval() -> the overridden train(False)
+        t0 = time.time()
+        with torch.no_grad(), record_draws() as rec:
+            rays = ref_rays(r)
+            t_hat, w_hat = m.prop_net.forward(rays)
+            t_hat_np, w_hat_np = N(t_hat), N(w_hat)
+            o = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        assert len(rec.rand) == 1 and len(rec.uniform_unit) == 1
+        tag = f"stage_{kind}_{nm}"
+        for k in synthetic.RAY_FIELDS:
+            out[f"{tag}_rays_{k}"] = r[k]
+        out[tag + "_cfg"] = np.array([Bm, nm, int(wb)])
+        out[tag + "_t_rand"], out[tag + "_u_unit"], out[tag + "_u_scaled"] = N(rec.rand[0]), N(rec.uniform_unit[0]), N(rec.uniform_scaled[0])
+        out[tag + "_t_hat"], out[tag + "_w_hat"] = t_hat_np, w_hat_np
+        for nm_, v in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), o):
+            out[f"{tag}_{nm_}"] = N(v)
+        print(f"  G22 {tag}: {time.time() - t0:.1f}s")
+    save("g22_randomized", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19", "g20", "g21", "g22"]
     table = dict(g1=g1_g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12, g13=g13, g14=g14,
-                 g15=g15, g16=g16, g17=g17, g18=g18, g19=g19, g20=g20, g21=g21)
+                 g15=g15, g16=g16, g17=g17, g18=g18, g19=g19, g20=g20, g21=g21, g22=g22)
     for k in which:
         print(k)
         table[k]()

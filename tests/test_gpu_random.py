@@ -167,3 +167,97 @@ def test_randomized_frame_renders_through_the_fused_path(dev):
         torch.manual_seed(3)
         b = m.render_image(rays, 16, 24, chunks)
         assert all(np.array_equal(x, y) for x, y in zip(a, b)) and np.isfinite(a[1]).all() and a[0].dtype == np.uint8
+
+
+# ----------------------------------------------------------------------------- fixture G22: the REFERENCE's own randomized run
+# (tests/golden/make_golden.py g22: randomized=True with torch.rand / Tensor.uniform_ recorded, not replaced).  The kernels are handed
+# the recorded UNIT uniforms through the staged entry points' t_rand / u_rand arguments and must reproduce what the reference computed.
+def _g22():
+    from conftest import load_golden
+    return load_golden("g22_randomized")
+
+
+def D(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).float().to(dev)
+
+
+@pytest.mark.parametrize("kind", ["lego", "garden"])
+@pytest.mark.parametrize("n", [8, 64, 128])
+def test_g22_jitter_kernel_vs_reference(dev, kind, n):
+    """m360_sample_t with t_rand = the reference's own torch.rand draw (intern/ray.py:103-108), then the Gaussians (para_rays)."""
+    from conftest import assert_cov_within_reference_error  # noqa: F401  (same derivation as G1; here only the fp32 run exists)
+    from mipnerf360_amd import ops
+    g = _g22()
+    pre = f"sample_{kind}_"
+    t = ops.sample_t(D(g[pre + "rays_near"], dev), D(g[pre + "rays_far"], dev), n, t_rand=D(g[f"{pre}{n}_t_rand"], dev))
+    close(t, g[f"{pre}{n}_t"], atol=0, rtol=2e-6)
+    m, c = ops.para_rays(t, D(g[pre + "rays_origins"], dev), D(g[pre + "rays_directions"], dev), D(g[pre + "rays_radii"], dev))
+    close(m, g[f"{pre}{n}_means"], atol=2e-6)
+    scale = np.abs(g[f"{pre}{n}_covs"]).max(axis=(-1, -2), keepdims=True)
+    assert (np.abs(H(c) - g[f"{pre}{n}_covs"]) <= 2e-4 * scale + 1e-12).all()
+
+
+@pytest.mark.parametrize("ns", [49, 16, 128])
+def test_g22_randomized_inverse_cdf_kernel_vs_reference(dev, ns):
+    """m360_sorted_pdf with u_rand = the unit uniforms behind the reference's uniform_(to=s - eps) (intern/ray.py:30-35): `u + u`, the
+    scaling by s - eps, the 1 - eps clamp; padding branch rows (all-zero, sum 2.4e-7) included."""
+    from mipnerf360_amd import ops
+    g = _g22()
+    got = ops.sorted_pdf(D(g["pdf_t"], dev), D(g["pdf_w"], dev), ns, u_rand=D(g[f"pdf_{ns}_u_unit"], dev))
+    close(got, g[f"pdf_{ns}_samples"], atol=4e-6, rtol=2e-6)
+
+
+@pytest.mark.parametrize("n", [8, 64, 128])
+def test_g22_resample_kernel_vs_reference(dev, n):
+    """m360_resample_t_n (blur + padding + randomized inverse CDF, intern/ray.py:136-149) and the prop finisher's fused form of it."""
+    from mipnerf360_amd import ops
+    g = _g22()
+    pre = f"resample_{n}_"
+    t, w = D(g[pre + "t_in"], dev), D(g[pre + "w_in"], dev)
+    for pad in (0.01, 0.0):
+        got = ops.resample_t(t, w, pad, u_rand=D(g[f"{pre}pad{pad}_u_unit"], dev))
+        close(got, g[f"{pre}pad{pad}_t"], atol=4e-6, rtol=2e-6)
+    new_t = ops.resample_t(t, w, 0.01, u_rand=D(g[pre + "pad0.01_u_unit"], dev))
+    m, _ = ops.para_rays(new_t, D(g[pre + "rays_origins"], dev), D(g[pre + "rays_directions"], dev), D(g[pre + "rays_radii"], dev))
+    close(m, g[pre + "pad0.01_means"], atol=4e-6)
+
+
+@pytest.mark.parametrize("tag", ["lego_16", "garden_64", "lego_128"])
+@pytest.mark.parametrize("train", [False, True])
+def test_g22_randomized_stage_forwards_vs_reference(dev, tag, train):
+    """prop_net.forward / nerf_net.forward of a randomized model replaying the reference's draws (`replay_uniforms`): all six stage
+    outputs against the reference's own randomized run, through the rendering forwards and through the tape-keeping (training) ones;
+    then the outer forward (which goes staged when draws are replayed)."""
+    from mipnerf360_amd.model import mipNeRF360
+    g = _g22()
+    pre = f"stage_{tag}_"
+    B, n, wb = (int(x) for x in g[pre + "cfg"])
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd.")}
+    m = mipNeRF360(randomized=True, num_samples=n, hidden_proposal=32, hidden_nerf=64, white_bkgd=bool(wb), device=dev)
+    m.load_state_dict(sd)
+    m.eval()
+    assert m.prop_net.randomized and m.nerf_net.randomized and bool(m.randomized) == bool(int(g[pre + "outer_randomized_after_eval"]))
+    m.prop_net.replay_uniforms, m.nerf_net.replay_uniforms = D(g[pre + "t_rand"], dev), D(g[pre + "u_unit"], dev)
+    rays = dev_rays({k: g[f"{pre}rays_{k}"] for k in synthetic.RAY_FIELDS}, dev)
+    with torch.set_grad_enabled(train):
+        t_hat, w_hat = m.prop_net.forward(rays)
+        out = m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+    assert w_hat.requires_grad == train and m.prop_net.last_rng is None and m.nerf_net.last_rng is None
+    close(t_hat, g[pre + "t_hat"], atol=0, rtol=2e-6)
+    close(w_hat, g[pre + "w_hat"], atol=5e-6)
+    close(out[0], g[pre + "rgb"], atol=RGB_TOL, rtol=0), close(out[2], g[pre + "acc"], atol=RGB_TOL, rtol=0)
+    assert np.all(np.abs(H(out[1]) - g[pre + "dist"]) <= 1e-4 * np.maximum(1.0, np.abs(g[pre + "dist"])))
+    close(out[3], g[pre + "t_vals"], atol=1e-5, rtol=1e-5), close(out[4], g[pre + "fine_w"], atol=2e-5, rtol=1e-4)
+    close(out[5], g[pre + "s_vals"], atol=2e-5, rtol=1e-4)
+    with torch.no_grad():
+        rgb, dist, acc = m(rays)
+    close(rgb, g[pre + "rgb"], atol=RGB_TOL, rtol=0), close(acc, g[pre + "acc"], atol=RGB_TOL, rtol=0)
+    # a wrong shape is refused, and without replay the model draws for itself again
+    m.nerf_net.replay_uniforms = m.nerf_net.replay_uniforms[:, :-1]
+    with pytest.raises(RuntimeError, match="replay_uniforms"), torch.no_grad():
+        m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+    m.prop_net.replay_uniforms = m.nerf_net.replay_uniforms = None
+    torch.manual_seed(1)
+    with torch.no_grad():
+        m(rays)
+    assert m.last_rng == (1, 0)

@@ -605,3 +605,79 @@ def test_philox_known_answers():
     assert float(P.uniform(0, 0, 1, 1)[0]) == (int(P.philox4x32_10((0, 0, 0, 1 << 28), (0, 0))[0]) >> 8) / 2.0 ** 24
     big = P.uniform(99, 3, 1, 200000)
     assert big.min() >= 0.0 and big.max() < 1.0 and abs(float(big.mean()) - 0.5) < 3e-3
+
+
+# ----------------------------------------------------------------------------- G22: the randomized branches (the reference's CLI default)
+def test_g22_recorded_draws_are_what_the_reference_used(golden):
+    """The fixture's own consistency: the scaled uniforms the reference's `uniform_(to=s - eps)` returned (intern/ray.py:33) are the
+    recorded unit uniforms times float32(to), bit for bit, `to` is 1 / num_samples - eps_f32, and every unit uniform lies in [0, 1)."""
+    g = golden("g22_randomized")
+    eps = float(np.finfo(np.float32).eps)
+    for ns in (49, 16, 128):
+        unit, scaled, to = g[f"pdf_{ns}_u_unit"], g[f"pdf_{ns}_u_scaled"], float(g[f"pdf_{ns}_to"])
+        assert to == 1 / ns - eps
+        assert unit.dtype == np.float32 and unit.shape == (7, ns) and unit.min() >= 0.0 and unit.max() < 1.0
+        assert np.array_equal(unit * np.float32(to), scaled)
+    for key in [k for k in g if k.endswith("_t_rand")]:
+        assert g[key].min() >= 0.0 and g[key].max() < 1.0
+
+
+@pytest.mark.parametrize("kind", ["lego", "garden"])
+@pytest.mark.parametrize("n", [8, 64, 128])
+def test_g22_jitter(golden, kind, n):
+    """intern/ray.py:103-108: t = lower + (upper - lower) * torch.rand, on the uniforms the reference itself drew."""
+    g = golden("g22_randomized")
+    pre = f"sample_{kind}_"
+    near, far = T(g[pre + "rays_near"]), T(g[pre + "rays_far"])
+    t = O.jitter_t(O.sample_t(near, far, n), T(g[f"{pre}{n}_t_rand"]))
+    close(t, g[f"{pre}{n}_t"], atol=0, rtol=2e-6)
+    assert np.abs(g[f"{pre}{n}_t"] - O.sample_t(near, far, n).numpy()).max() > 1e-3   # the jitter is in the fixture
+    m, c = O.para_rays(t, T(g[pre + "rays_origins"]), T(g[pre + "rays_directions"]), T(g[pre + "rays_radii"]))
+    close(m, g[f"{pre}{n}_means"], atol=2e-6)
+    scale = np.abs(g[f"{pre}{n}_covs"]).max(axis=(-1, -2), keepdims=True)
+    assert (np.abs(c.numpy() - g[f"{pre}{n}_covs"]) <= 2e-4 * scale + 1e-12).all()   # t_var cancels at near = 0 (G1 derives this bound)
+
+
+@pytest.mark.parametrize("ns", [49, 16, 128])
+def test_g22_randomized_inverse_cdf(golden, ns):
+    """intern/ray.py:30-35: u = arange * s; u = u + u + uniform_(to = s - eps); min(u, 1 - eps) - the doubling included - on the unit
+    uniforms behind the reference's own draws; rows: uniform, one peak, all-zero and near-empty (padding branch), a bump, random."""
+    g = golden("g22_randomized")
+    t, w = T(g["pdf_t"]), T(g["pdf_w"])
+    got = O.sorted_piecewise_constant_pdf(t, w.clone(), ns, u_rand=T(g[f"pdf_{ns}_u_unit"]))
+    close(got, g[f"pdf_{ns}_samples"], atol=2e-6, rtol=2e-6)
+    # the doubling is real: from arange * s = 1/2 on every u is clamped to 1 - eps, so the upper half of a row is ONE value
+    smp = g[f"pdf_{ns}_samples"]
+    assert (smp[:, (ns + 1) // 2 + 1:] == smp[:, -1:]).all() and (smp[:, 1] < smp[:, -1]).all()
+
+
+@pytest.mark.parametrize("n", [8, 64, 128])
+def test_g22_resample_along_rays(golden, n):
+    g = golden("g22_randomized")
+    pre = f"resample_{n}_"
+    t, w = T(g[pre + "t_in"]), T(g[pre + "w_in"])
+    for pad in (0.01, 0.0):
+        got = O.resample_t(t, w, pad, u_rand=T(g[f"{pre}pad{pad}_u_unit"]))
+        close(got, g[f"{pre}pad{pad}_t"], atol=2e-6, rtol=2e-6)
+    new_t = O.resample_t(t, w, 0.01, u_rand=T(g[pre + "pad0.01_u_unit"]))
+    m, c = O.para_rays(new_t, T(g[pre + "rays_origins"]), T(g[pre + "rays_directions"]), T(g[pre + "rays_radii"]))
+    close(m, g[pre + "pad0.01_means"], atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["lego_16", "garden_64", "lego_128"])
+def test_g22_randomized_stage_forwards(golden, tag):
+    """prop_net.forward / nerf_net.forward of a randomized reference model (model.py:80-94,163-200) after eval() - which leaves the
+    sub-nets randomized (model.py:281-283) - replayed through the oracle on the recorded draws: all six stage outputs."""
+    g = golden("g22_randomized")
+    sd = _sd(g)
+    pre = f"stage_{tag}_"
+    B, n, wb = (int(x) for x in g[pre + "cfg"])
+    rays = O.rays_from_numpy({k: g[f"{pre}rays_{k}"] for k in synthetic.RAY_FIELDS})
+    hp = O.Hyper(num_samples=n, white_bkgd=bool(wb))
+    with torch.no_grad():
+        t_hat, w_hat = O.prop_forward(rays, sd, hp, t_rand=T(g[pre + "t_rand"]))
+        out = O.nerf_forward(rays, t_hat, w_hat, sd, hp, u_rand=T(g[pre + "u_unit"]))
+    close(t_hat, g[pre + "t_hat"], atol=0, rtol=2e-6)
+    close(w_hat, g[pre + "w_hat"], atol=2e-6)
+    for nm, v in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), out):
+        close(v, g[f"{pre}{nm}"], atol=2e-6, rtol=2e-5)
