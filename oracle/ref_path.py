@@ -229,15 +229,21 @@ def blur_weights(weights, resample_padding):
     return 0.5 * (wm[..., :-1] + wm[..., 1:]) + resample_padding
 
 
-def sorted_piecewise_constant_pdf(bins, weights, num_samples, u_rand: Optional[torch.Tensor] = None):
+def sorted_piecewise_constant_pdf(bins, weights, num_samples, u_rand: Optional[torch.Tensor] = None, wsum_ulps: int = 0):
     """intern/ray.py:12-57. Deterministic u unless `u_rand` ([B,num_samples]
     uniforms in [0,1)) is given, in which case the randomized branch (:30-35,
     including its `u + u` doubling) is followed with those uniforms.
     The O(N^2) mask is replaced by a sorted search (same bracket: the last
-    cdf_i <= u)."""
+    cdf_i <= u).
+    wsum_ulps (conditioning probe for tests, 0 = the reference): the weight sum moved by that many fp32 ulps before it is
+    used - what another summation order of torch.sum could return.  Where a flat stretch of the cdf sits within an ulp of a
+    u (the randomized branch clamps HALF of its u to 1 - eps, so a cdf that saturates at ~1 is such a stretch) the bracket,
+    and with it the sample, depends on that ulp: such samples are not defined by the reference beyond this set of answers."""
     eps = 1e-5
     f32eps = float(torch.finfo(torch.float32).eps)
     wsum = torch.sum(weights, dim=-1, keepdim=True)
+    for _ in range(abs(int(wsum_ulps))):
+        wsum = torch.nextafter(wsum, torch.full_like(wsum, float("inf") if wsum_ulps > 0 else float("-inf")))
     pad = torch.maximum(torch.zeros_like(wsum), eps - wsum)  # NaN-propagating, like the reference's torch.maximum
     weights = weights + pad / weights.shape[-1]
     wsum = wsum + pad

@@ -999,6 +999,11 @@ def g22():
         out[f"pdf_{ns}_u_unit"], out[f"pdf_{ns}_u_scaled"] = N(rec.uniform_unit[0]), N(rec.uniform_scaled[0])
         out[f"pdf_{ns}_to"] = np.array(rec.uniform_to[0], dtype=np.float64)
         out[f"pdf_{ns}_samples"] = N(smp)
+    # the same rows the way the path hands them over (+ resample_padding, intern/ray.py:142): no flat stretch of the cdf near u = 1 - eps
+    for ns in (n + 1, 16, 128):
+        with record_draws() as rec:
+            smp = ref_ray.sorted_piecewise_constant_pdf(T(t), T(w) + 0.01, ns, randomized=True)
+        out[f"pdfpad_{ns}_u_unit"], out[f"pdfpad_{ns}_samples"] = N(rec.uniform_unit[0]), N(smp)
     # (3) resample_along_rays (blur + padding + randomized sampler + Gaussians), N in {8, 64, 128}
     for n2 in (8, 64, 128):
         r = synthetic.make_rays("lego" if n2 != 64 else "garden", 4, seed=220 + n2)

@@ -646,6 +646,7 @@ def test_g22_randomized_inverse_cdf(golden, ns):
     t, w = T(g["pdf_t"]), T(g["pdf_w"])
     got = O.sorted_piecewise_constant_pdf(t, w.clone(), ns, u_rand=T(g[f"pdf_{ns}_u_unit"]))
     close(got, g[f"pdf_{ns}_samples"], atol=2e-6, rtol=2e-6)
+    close(O.sorted_piecewise_constant_pdf(t, w + 0.01, ns, u_rand=T(g[f"pdfpad_{ns}_u_unit"])), g[f"pdfpad_{ns}_samples"], atol=2e-6, rtol=2e-6)
     # the doubling is real: from arange * s = 1/2 on every u is clamped to 1 - eps, so the upper half of a row is ONE value
     smp = g[f"pdf_{ns}_samples"]
     assert (smp[:, (ns + 1) // 2 + 1:] == smp[:, -1:]).all() and (smp[:, 1] < smp[:, -1]).all()
