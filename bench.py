@@ -111,13 +111,9 @@ def parse_args(argv=None):
                          "then says so in config.workload")
     ap.add_argument("--no-named", action="store_true",
                     help="c2 / fp32 / 1 GPU only: skip the `named_workloads` block (the other single-GPU configs, a few steps each)")
-    ap.add_argument("--row-blocks", type=int, default=None, metavar="ROWS",
-                    help="(diagnostics, bf16 modes) m360_set_row_blocks: 0 = layer by layer, -1 = automatic (default), > 0 rows per block; "
-                         "the line then carries config.row_blocks")
-    ap.add_argument("--row-block-streams", type=int, default=None, choices=(1, 2), help="(diagnostics) m360_set_row_block_streams")
-    ap.add_argument("--no-chain", action="store_true", help="(diagnostics, bf16 mode) m360_set_hidden_chain(0): six launches for the six hidden NeRF layers")
+    ap.add_argument("--no-chain", action="store_true", help="(diagnostics, bf16 mode) M360_TUNE_NO_HIDDEN_CHAIN per call: six launches for the six hidden NeRF layers")
     ap.add_argument("--plain-rows", action="store_true",
-                    help="(diagnostics, bf16 modes) m360_set_paired_rows(0): plain instead of paired rows between the layers - same bits; "
+                    help="(diagnostics, bf16 modes) M360_TUNE_PLAIN_ROWS per call: plain instead of paired rows between the layers - same bits; "
                          "the line then carries config.plain_rows")
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the child command as JSON and exit")
@@ -290,8 +286,7 @@ class Comm:
 def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
     lin_kind = _lib.K_LINEAR_BF16 if bf16 else _lib.K_LINEAR
     kk = 3 * HN if x3 else HN  # bf16x3: one contraction of length 3K (xh wh + xl wh + xh wl)
-    # the 1024 x 1024 layers: one launch over all S rows, or (bf16 modes, m360_set_row_blocks) one per block of rows - all of one size but a
-    # shorter last one, which is left out
+    # the 1024 x 1024 layers: one launch over all S rows
     hits = [r for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == kk]
     chained = [r for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == 6 * HN] if bf16 and not x3 else []
     nlay = 1
@@ -699,14 +694,12 @@ def worker(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
-    if args.plain_rows:
-        _lib.lib().m360_set_paired_rows(0)
-    if args.no_chain:
-        _lib.lib().m360_set_hidden_chain(0)
-    if args.row_blocks is not None:
-        _lib.lib().m360_set_row_blocks(args.row_blocks)
-    if args.row_block_streams is not None:
-        _lib.lib().m360_set_row_block_streams(args.row_block_streams)
+    if args.plain_rows or args.no_chain:  # per-call bits of m360_hyper_t.tuning; the host mirror keeps them for this thread
+        from mipnerf360_amd import ops as _ops
+        if args.plain_rows:
+            _ops.set_paired_rows(False)
+        if args.no_chain:
+            _ops.set_hidden_chain(False)
     ndev = torch.cuda.device_count()
     # one GPU per rank.  With fewer devices than ranks the ranks wrap around: RCCL then refuses the duplicate device
     # with its own error (the gloo diagnostics backend lets ranks share a GPU).
@@ -784,7 +777,7 @@ def worker(args):
 
         for _ in range(warmup):
             step()
-        prof = _lib.Prof((800 if args.row_blocks else 48) * max(steps, 1))  # caller-owned HIP-event recorder: every kernel of the stage drivers
+        prof = _lib.Prof(48 * max(steps, 1))  # caller-owned HIP-event recorder: every kernel of the stage drivers
         model.set_prof(prof)
         comm.fence()
         t0 = time.perf_counter()
@@ -819,10 +812,6 @@ def worker(args):
             line["config"]["plain_rows"] = True
         if args.no_chain:
             line["config"]["no_chain"] = True
-        if args.row_blocks is not None:
-            line["config"]["row_blocks"] = args.row_blocks
-        if args.row_block_streams is not None:
-            line["config"]["row_block_streams"] = args.row_block_streams
         if per_rank:
             line["per_rank"] = per_rank
 

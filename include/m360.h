@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define M360_VERSION 101 /* 0.1.1: status block at the start of the forward workspace; packed-model layout 2 (see checkpoint tooling) */
+#define M360_VERSION 200 /* 0.2.0: no process-wide switches any more (m360_set_* gone): per-call m360_hyper_t.tuning, caller-owned m360_side_t; test hooks in the diagnostics build only */
 
 typedef void *m360_stream_t;
 
@@ -226,25 +226,16 @@ int m360_linear_bf16(const void *x_bf16, long M, int ldx, const void *w_packed_b
  *   m360_linear_wgrad_bf16: dW[n_pad, k_pad] = dZ^T X and db[n_pad] = column sums of dZ (NULL to skip) in fp32 from bf16 rows.  n_pad, k_pad
  *     multiples of 256 run on v_mfma_f32_16x16x32_bf16 (both operands transposed on their way out of the LDS by ds_read_b64_tr_b16; row splits
  *     reduced in a fixed order: deterministic); other pads (multiples of 32: reduced-width models) are widened to fp32 for m360_linear_wgrad. */
-/* A/B switch of m360_linear_wgrad_bf16's MFMA form, process-wide like m360_set_paired_rows: 1 (default) = one wave per SIMD with 128 x 128 wave tiles
- * and the LDS filled four k-steps ahead, 0 = the 8-wave kernel; both deterministic, results equal up to fp32 summation order.  Returns the old setting. */
-int m360_set_wgrad_bf16_form(int form);
-/* A/B switch of m360_prop_backward / m360_nerf_backward in the bf16 mode, process-wide: 1 (default) = the ReLU mask of a layer's input gradient
- * runs on a second stream of the library beside that layer's weight gradient (forked from and joined to the caller's stream inside the call: the
- * caller sees one stream), 0 = everything on the caller's stream (values > 1, A/B runs only: on, with that many workgroups of the throttled mask
- * kernel instead of one per CU).  Weight gradients: the same bits either way; the bias gradients of the layers below the top one are, in the
- * overlapped form, the column sums the mask kernel forms on its way (its rows are the next layer's dz), on one stream the weight-gradient kernel's
- * ones-product: the same fp32 sums in another order, both deterministic.  Returns the old setting (0 / 1).
- * The second stream and its two events are the library's, one set per process, created on first use for the device current then (other devices:
- * everything on the caller's stream): backward calls of ONE host thread at a time, as torch's autograd engine issues them. */
-int m360_set_backward_overlap(int on);
+/* Which MFMA form m360_linear_wgrad_bf16 takes is a per-call choice (`tuning`, M360_TUNE_* below): 0 (default) = one wave per SIMD with
+ * 128 x 128 wave tiles and the LDS filled four k-steps ahead, M360_TUNE_WGRAD_FORM0 = the 8-wave kernel; both deterministic, results equal up to
+ * fp32 summation order.  m360_prop_backward / m360_nerf_backward read the same bit from m360_hyper_t.tuning. */
 int m360_pack_linear_bf16_transposed(const float *w, int n_out, int k_in, int n_pad, int k_pad, void *wt_packed_bf16 /*[k_pad, n_pad]*/,
                                      m360_stream_t stream);
 int m360_linear_dgrad_bf16(const void *dz_bf16, long M, int ldz, const void *wt_packed_bf16, int k_pad, int n_pad, const void *relu_out_bf16,
                            void *dx_bf16, int ldx, m360_stream_t stream);
 size_t m360_linear_wgrad_bf16_workspace_bytes(long M, int n_pad, int k_pad);
 int m360_linear_wgrad_bf16(const void *dz_bf16, int ldz, const void *x_bf16, int ldx, long M, int n_pad, int k_pad, float *grad_w,
-                           float *grad_b, void *workspace, size_t workspace_bytes, m360_stream_t stream);
+                           float *grad_b, void *workspace, size_t workspace_bytes, unsigned tuning, m360_stream_t stream);
 /* ---- opt-in "bf16x3" MLP: near-fp32 accuracy on the bf16 matrix pipe.  Every activation and weight is carried as TWO bf16
  * terms (hi = bf16(v), lo = bf16(v - hi): 16 significant bits) and a product x w is formed as xh wh + xl wh + xh wl with
  * fp32 accumulation (the xl wl term, 2^-16 of the product, is dropped): three bf16 MFMA passes per 64-deep block, in the order
@@ -294,10 +285,14 @@ int m360_linear_bf16x3(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M,
  * 16-byte aligned = [status block, 128 bytes | counters]. */
 int m360_mlp_chain_bf16_supported(long M, int width, int layers);
 size_t m360_mlp_chain_bf16_workspace(long M, int layers);
+/* opts (may be NULL = defaults): only its per-call switches are read - m360_hyper_t.tuning (M360_TUNE_CHAIN_COOPERATIVE) and, in the diagnostics
+ * build, the chain_debug_* test hooks. */
+struct m360_hyper;
 int m360_mlp_chain_bf16(void *act0_bf16, void *act1_bf16, long M, int ld, const void *const *w_packed_bf16 /*[layers]*/, const float *const *b_packed /*[layers]*/,
-                        int layers, int width, void *workspace, m360_stream_t stream);
+                        int layers, int width, void *workspace, const struct m360_hyper *opts, m360_stream_t stream);
 int m360_mlp_chain_bf16_safe(const void *x_in_bf16, void *act0_bf16, void *act1_bf16, long M, int ld, const void *const *w_packed_bf16 /*[layers]*/,
-                             const float *const *b_packed /*[layers]*/, int layers, int width, void *workspace, m360_stream_t stream);
+                             const float *const *b_packed /*[layers]*/, int layers, int width, void *workspace, const struct m360_hyper *opts,
+                             m360_stream_t stream);
 /* The status block: the first 128 bytes of a chain workspace AND of every forward workspace (m360_forward_workspace_bytes).
  * m360_workspace_init zeroes its sticky counters (once, after allocating the workspace; m360_mlp_chain_bf16 does it per call);
  * m360_workspace_status copies it out and waits for the stream: out5 = {chain launches that ran, launches repaired by the gated re-run,
@@ -305,33 +300,14 @@ int m360_mlp_chain_bf16_safe(const void *x_in_bf16, void *act0_bf16, void *act1_
  * initialised are meaningless; no result ever depends on them. */
 int m360_workspace_init(void *workspace, m360_stream_t stream);
 int m360_workspace_status(const void *workspace, unsigned *out5_host, m360_stream_t stream);
-/* Test hooks and A/B switches of the chain, process-wide like m360_set_paired_rows.  m360_set_chain_debug: wait_ticks = bound of one wait in
- * 100 MHz ticks (<= 0: the default, 0.1 s), fault = 0 none, 1 = one workgroup reports a foreign XCD, 2 = every wave treats its first wait
- * as run out and stops waiting (wrong rows, error set: what the gated re-run must repair), -1 = m360_forward queues NO gated launches
- * (A/B of their cost only: results are then unchecked).  m360_set_chain_cooperative(1): launch the chain
- * with hipLaunchCooperativeKernel (co-residency asked of the runtime); returns the old setting. */
-int m360_set_chain_debug(long wait_ticks, int fault);
-int m360_set_chain_cooperative(int on);
 /* 1 when the call `kind` (M360_PAIRABLE_*) with these pads runs its full tiles on the one-wave ring kernel, i.e. takes paired rows */
 int m360_linear_bf16_rows_pairable(int kind, int n_pad, int k_pad);
 /* m360_forward / m360_prop_forward / m360_nerf_forward (bf16 modes) use paired rows between the layers of an MLP whose layers are all
- * pairable; 0 switches that off process-wide (diagnostics: A/B on one box - the outputs are the same bits), returns the old setting */
-int m360_set_paired_rows(int on);
-/* Row blocks of the NeRF MLP in the bf16 modes (paired rows only): m360_forward / m360_nerf_forward run blocks of rows through all eight
- * layers, block after block, on the SAME ping / pong rows with temporal stores (M360_STORES_TEMPORAL): the hidden activations then live in
- * the Infinity Cache instead of making a round trip through HBM per layer (model.py:131-158: the layers are row-independent; same bits).
- * rows: 0 = off (default: one launch per layer over all rows), -1 = automatic (bf16 mode: pairs of 192 MiB in all, e.g. 49152 rows of
- * 1024 bf16, when the batch has at least two blocks), > 0 = this many rows per block (a multiple of 256).  Returns the old setting.
- * Measured (profiles/r04): the layers run 7 % faster per row and the additional launches take it back - a switch for experiments. */
-/* m360_forward / m360_nerf_forward, bf16 mode: the six hidden NeRF layers as ONE launch (m360_mlp_chain_bf16) for the rows it takes
- * (multiples of 32768; width 1024; paired rows), 1 = on (default), 0 = six launches.  Same bits.  Returns the old setting.  (The proposal
- * MLP's two 256-wide hidden layers stay two launches: the chain is slower there.) */
-int m360_set_hidden_chain(int on);
-long m360_set_row_blocks(long rows);
-/* With row blocks on - 2 (default): odd row blocks run on a second, library-owned stream (forked from and joined to the caller's stream with events; their
- * own ping / pong rows), so that one block's kernels fill the ~7 us between two dependent kernels of the other; 1: all blocks on the
- * caller's stream.  The automatic block size halves with 2 (the two pairs together stay 192 MiB).  Returns the old setting. */
-int m360_set_row_block_streams(int n);
+ * pairable, and run the six hidden NeRF layers as ONE launch (m360_mlp_chain_bf16_safe) for the rows it takes (multiples of 32768; width 1024;
+ * paired rows; the proposal MLP's 256-wide layers stay launches: the chain is slower there).  Both can be switched off PER CALL through
+ * m360_hyper_t.tuning (M360_TUNE_PLAIN_ROWS, M360_TUNE_NO_HIDDEN_CHAIN): A/B runs on one box - the outputs are the same bits.
+ * (Until 0.2.0 these were process-wide m360_set_* switches; the library now holds no mutable state at all.  The row-block form of the NeRF
+ * MLP is gone with its switch: measured in round 4, superseded by the chain, profiles/HISTORY.md.) */
 int m360_linear_bf16x3_bf16out(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/, long M, int ldx, const void *w_packed3_bf16,
                                const float *b_packed, int n_pad, int k_pad, int act, void *y_bf16 /*[M, ldy >= n_pad]*/, int ldy,
                                m360_stream_t stream);
@@ -629,7 +605,25 @@ typedef struct {
 } m360_model_t; /* packed form of the state_dict of model.py:43-53,131-158 */
 #define M360_PACKED_LAYOUT 2
 
-typedef struct {
+/* Per-call switches (m360_hyper_t.tuning; 0 = the defaults).  Every one leaves the results bit-identical (M360_TUNE_WGRAD_FORM0: up to fp32
+ * summation order): they exist for A/B measurements on one box and for tests, and they are per CALL so that two threads, streams or models of
+ * one process never see each other's choice. */
+#define M360_TUNE_NO_HIDDEN_CHAIN 1u   /* bf16 mode: six launches instead of the one-launch chain for the hidden NeRF layers */
+#define M360_TUNE_PLAIN_ROWS 2u        /* bf16 modes: plain instead of paired rows between the layers (which also means no chain) */
+#define M360_TUNE_WGRAD_FORM0 4u       /* bf16 backward: the 8-wave weight-gradient kernel instead of the one-wave form */
+#define M360_TUNE_CHAIN_COOPERATIVE 8u /* the chain through hipLaunchCooperativeKernel (co-residency asked of the runtime) */
+#define M360_TUNE_CHAIN_UNGATED 16u    /* diagnostics build only (refused otherwise): no gated re-run behind the chain - A/B of its cost, results unchecked */
+
+/* A caller-owned second stream with its fork / join events (bf16 backward: the ReLU mask of a layer's input gradient runs there beside that
+ * layer's weight gradient, forked from and joined to the caller's stream inside the call - the caller still sees one stream).  Created for the
+ * device that is current at m360_side_create; put into m360_hyper_t.side of the backward calls that may use it (NULL = everything on the
+ * caller's stream: same weight gradients bit for bit, the lower layers' bias gradients the same sums in another fixed order).  One call at a
+ * time per handle - use one per (device, stream) or per thread, like a workspace.  The library keeps no stream, event or handle of its own. */
+typedef struct m360_side m360_side_t;
+int m360_side_create(m360_side_t **out);
+void m360_side_destroy(m360_side_t *side);
+
+typedef struct m360_hyper {
     int num_samples;
     int viewdir_min_deg, viewdir_max_deg;
     int white_bkgd;
@@ -656,6 +650,12 @@ typedef struct {
                                       per call); element e of stream s (0 = t_rand, 1 = u_rand, [B, N + 1] row-major) draws
                                       philox(key, counter = (rng_offset, e, s)).x >> 8 as a 24-bit uniform in [0, 1) - m360_philox_uniform
                                       writes out exactly these numbers (tests replay them through the oracle) */
+    unsigned tuning;      /* M360_TUNE_* bits, 0 = defaults: per-call A/B switches with bit-identical results */
+    void *side;           /* optional m360_side_t* (see above): m360_prop_backward / m360_nerf_backward in the bf16 mode; NULL = one stream */
+    long chain_debug_wait_ticks; /* test hooks of the layer chain, honoured by the DIAGNOSTICS build only (libm360_diag.so; the product library */
+    int chain_debug_fault;       /* refuses non-zero values): bound of one wait in 100 MHz ticks (0 = the default 0.1 s); fault 1 = one workgroup
+                                    reports a foreign XCD, 2 = every wave treats its first wait as run out (wrong rows, error set: what the gated
+                                    re-run must repair) */
 } m360_hyper_t; /* ctor arguments of model.py:203-215 */
 
 typedef struct {

@@ -40,12 +40,17 @@ class ModelStruct(C.Structure):  # m360_model_t
 PACKED_LAYOUT = 2  # include/m360.h: M360_PACKED_LAYOUT
 
 
+# m360_hyper_t.tuning: per-call A/B switches (include/m360.h, M360_TUNE_*)
+TUNE_NO_HIDDEN_CHAIN, TUNE_PLAIN_ROWS, TUNE_WGRAD_FORM0, TUNE_CHAIN_COOPERATIVE, TUNE_CHAIN_UNGATED = 1, 2, 4, 8, 16
+
+
 class HyperStruct(C.Structure):  # m360_hyper_t
     _fields_ = [("num_samples", C.c_int), ("viewdir_min_deg", C.c_int), ("viewdir_max_deg", C.c_int),
                 ("white_bkgd", C.c_int), ("density_bias", C.c_float), ("rgb_padding", C.c_float),
                 ("resample_padding", C.c_float), ("num_samples_fine", C.c_int), ("norm_group_rays", C.c_int),
                 ("prof", C.c_void_p), ("rays_mutated", C.c_int), ("randomized", C.c_int), ("rng_seed", C.c_ulonglong),
-                ("rng_offset", C.c_ulonglong)]
+                ("rng_offset", C.c_ulonglong), ("tuning", C.c_uint), ("side", C.c_void_p),
+                ("chain_debug_wait_ticks", C.c_long), ("chain_debug_fault", C.c_int)]
 
 
 class OutputsStruct(C.Structure):  # m360_outputs_t
@@ -95,13 +100,13 @@ SIGNATURES = {
     "m360_linear_dgrad": (_i, [_vp, _l, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "m360_linear_wgrad_workspace_bytes": (_sz, [_l, _i, _i]),
     "m360_linear_wgrad": (_i, [_vp, _i, _vp, _i, _l, _i, _i, _vp, _vp, _vp, _sz, _vp]),
-    "m360_set_wgrad_bf16_form": (_i, [_i]),
-    "m360_set_backward_overlap": (_i, [_i]),
+    "m360_side_create": (_i, [_P(_vp)]),
+    "m360_side_destroy": (None, [_vp]),
     "m360_params_nan_flag": (_i, [_vp, _vp, _i, _vp, _vp]),
     "m360_pack_linear_bf16_transposed": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "m360_linear_dgrad_bf16": (_i, [_vp, _l, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "m360_linear_wgrad_bf16_workspace_bytes": (_sz, [_l, _i, _i]),
-    "m360_linear_wgrad_bf16": (_i, [_vp, _i, _vp, _i, _l, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "m360_linear_wgrad_bf16": (_i, [_vp, _i, _vp, _i, _l, _i, _i, _vp, _vp, _vp, _sz, C.c_uint, _vp]),
     "m360_pack_linear_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear_bf16": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_pack_linear_bf16x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -109,17 +114,11 @@ SIGNATURES = {
     "m360_linear_bf16x3_bf16out": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_mlp_chain_bf16_supported": (_i, [_l, _i, _i]),
     "m360_mlp_chain_bf16_workspace": (C.c_size_t, [_l, _i]),
-    "m360_mlp_chain_bf16": (_i, [_vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "m360_mlp_chain_bf16": (_i, [_vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _P(HyperStruct), _vp]),
     "m360_linear_bf16_rows_pairable": (_i, [_i, _i, _i]),
-    "m360_set_paired_rows": (_i, [_i]),
-    "m360_set_hidden_chain": (_i, [_i]),
-    "m360_mlp_chain_bf16_safe": (_i, [_vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    "m360_mlp_chain_bf16_safe": (_i, [_vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _P(HyperStruct), _vp]),
     "m360_workspace_init": (_i, [_vp, _vp]),
     "m360_workspace_status": (_i, [_vp, _P(C.c_uint), _vp]),
-    "m360_set_chain_debug": (_i, [_l, _i]),
-    "m360_set_chain_cooperative": (_i, [_i]),
-    "m360_set_row_blocks": (_l, [_l]),
-    "m360_set_row_block_streams": (_i, [_i]),
     "m360_pack_linear_bf16x6": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m360_linear_bf16_split": (_i, [_vp, _l, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "m360_encode_features_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
@@ -192,6 +191,8 @@ SIGNATURES = {
 }
 
 _lib = None
+_loaded = {}  # path -> bound CDLL
+DIAG_LIB_PATH = os.path.join(_HERE, "libm360_diag.so")  # make -C mipnerf360_amd/csrc diag: the same sources with -DM360_DIAG (test hooks, stamped kernels)
 
 
 def build(verbose: bool = False) -> str:
@@ -215,14 +216,42 @@ def lib() -> C.CDLL:
                 "Build it with `make -C mipnerf360_amd/csrc` (needs hipcc, gfx950).")
         # libm360 and PyTorch must share ONE HIP runtime (torch owns the device memory and the
         # streams we launch on): load torch's bundled libamdhip64 first so the loader reuses it.
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+def _load(path: str) -> C.CDLL:
+    if path not in _loaded:
         import torch  # noqa: F401
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        _lib = handle
-    return _lib
+        handle.m360_path = path
+        _loaded[path] = handle
+    return _loaded[path]
+
+
+class use_library:
+    """Tests / diagnostics: route every call of this process through another build of the library for the duration of the block -
+    `with _lib.use_library(_lib.DIAG_LIB_PATH): ...` runs the diagnostics build, the only one that honours the layer chain's fault-injection
+    hooks (m360_hyper_t.chain_debug_*).  Handles made by one build (event recorders, second streams) must not be handed to the other."""
+
+    def __init__(self, path: str):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        if not os.path.exists(self.path):
+            raise RuntimeError(f"{self.path} not found (make -C mipnerf360_amd/csrc diag)")
+        self.prev = lib()
+        _lib = _load(self.path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.prev
 
 
 class Prof:

@@ -40,6 +40,13 @@ struct m360_prof {
     size_t used = 0;
 };
 
+// Caller-owned second stream + fork / join events (include/m360.h, m360_side_t): no stream, event or handle lives in the library.
+struct m360_side {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int device = -1;
+};
+
 namespace m360 {
 
 // m360_sample_encode.hip (stage drivers only, not part of the C-ABI)
@@ -72,9 +79,9 @@ int nerf_finish_backward_bf16(const void *act, int ld, const float *head_w, cons
                               size_t workspace_bytes, m360_stream_t stream);
 // m360_linear.hip: the hidden-layer chain of the bf16 mode (one launch) and its gated layer-by-layer re-run
 int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
-                          int layers, int width, void *ws, m360_stream_t stream);
+                          int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts);
 int mlp_chain_bf16_rerun(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
-                         int layers, int width, void *ws, m360_stream_t stream);
+                         int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts);
 // m360_linear.hip: the ReLU mask of m360_linear_dgrad_bf16 on its own (mlp_backward_bf16 overlaps it with the weight gradient)
 int relu_mask_bf16(void *dx, const void *relu_out, long M, int k_pad, int ldx, m360_stream_t stream, int blocks /* > 0: that many striding workgroups */,
                    float *sums_part /* != NULL: [blocks][k_pad] column sums of the masked rows per workgroup */);
@@ -190,6 +197,10 @@ static int validate(const m360_rays_t *r, const m360_model_t *m, const m360_hype
     const FwdLayout L = layout_for(B, n_max(h), m);
     if (B > 0 && (!ws || ws_bytes < L.total)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "%s: workspace %zu < required %zu bytes", who, ws_bytes, L.total);
     if ((uintptr_t)ws & 255) return fail(M360_ERR_INVALID_ARGUMENT, "%s: workspace must be 256-byte aligned", who);
+#ifndef M360_DIAG
+    if (h->chain_debug_wait_ticks != 0 || h->chain_debug_fault != 0 || (h->tuning & M360_TUNE_CHAIN_UNGATED))
+        return fail(M360_ERR_INVALID_ARGUMENT, "%s: m360_hyper_t.chain_debug_* / M360_TUNE_CHAIN_UNGATED are test hooks of the diagnostics build (libm360_diag.so); this library has none", who);
+#endif
     return M360_OK;
 }
 
@@ -218,51 +229,11 @@ static int p_linear(const m360_hyper_t *h, TileQueues *q, const float *x, long M
 static inline int first_row_format(int mode) { return mode == 2 ? 3 : (mode == 1 ? 2 : 0); }  // encoder row format of the MLP input
 // Paired rows (m360.h) between the layers of one bf16 / bf16x3 MLP: only when EVERY layer of it runs its full tiles on the one-wave ring
 // kernel - first layer out, hidden layers in and out, fused-heads last layer in (rendering forward: the tape-keeping one keeps plain rows)
-static int g_hidden_chain = 1;  // m360_set_hidden_chain
-extern "C" int m360_set_hidden_chain(int on) { const int was = g_hidden_chain; g_hidden_chain = on ? 1 : 0; return was; }
-static long g_row_blocks = 0;  // m360_set_row_blocks: 0 off (default: no gain in the step, see nerf_row_block), -1 automatic, > 0 rows per block
-static int g_row_block_streams = 2;  // m360_set_row_block_streams
-extern "C" int m360_set_row_block_streams(int n) { const int was = g_row_block_streams; g_row_block_streams = n >= 2 ? 2 : 1; return was; }
-// The second stream of the row blocks (odd blocks): its own launches depend on each other, not on the other stream's, so one block's
-// kernels run in the ~7 us that lie between two dependent kernels of the other block.  Created on first use, for the device current then.
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; int device = -1; bool ok = false, tried = false; };
-static SideStream g_side;
-static SideStream *side_stream() {
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    if (!g_side.tried) {
-        g_side.tried = true;
-        g_side.device = dev;
-        g_side.ok = hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) == hipSuccess &&
-                    hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) == hipSuccess;
-        if (!g_side.ok) (void)hipGetLastError();
-    }
-    return (g_side.ok && g_side.device == dev) ? &g_side : nullptr;
-}
-extern "C" long m360_set_row_blocks(long rows) {
-    const long was = g_row_blocks;
-    g_row_blocks = rows < 0 ? -1 : (rows / 256) * 256;
-    return was;
-}
-// rows per block of the NeRF MLP in the bf16 modes (0: layer by layer): a ping / pong pair of 192 MiB - 49152 rows of 1024 bf16 measured
-// best in a chain of six hidden layers (tools/mlp_chain_bench.py --reuse, profiles/r04/mlp_chain_plain_vs_nt_blocks.log: 0.80 against
-// 0.85-0.89 ms per layer with 8 times the launches; 256 MiB pairs 0.80-0.81, 128 MiB 0.82; with non-temporal stores no gain) - and only when
-// the batch has at least two blocks.  In the rendering forward the kernels do run 7 % faster per row (1394 against 1300 TF), and the 80-160
-// additional launches take it all back (6.66-6.71 against 6.67 ms per forward at 4096 x 128, 26.35-26.7 against 26.45-26.48 at 8192 x 256,
-// one or two streams: profiles/r04/row_blocks_ab_no_recorder*.jsonl): OFF by default, kept as a switch (same bits, tested).
-static long nerf_row_block(long S, long row_bytes, int mode) {
-    long rows = g_row_blocks;
-    // automatic: the bf16 mode only - the bf16x3 layers do three times the matrix work per byte of activations and lose more to the
-    // shorter launches than they win (17.2 -> 19.6 ms per step with blocks of 24576 rows, profiles/r04)
-    if (rows < 0 && mode != 1) return 0;
-    if (rows < 0) rows = ((96l << 20) / (g_row_block_streams >= 2 ? 2 : 1) / row_bytes / 256) * 256;
-    return (rows >= 256 && S >= 2 * rows) ? rows : 0;
-}
-static int g_paired_rows = 1;  // m360_set_paired_rows: A/B of the two layouts (same bits either way)
-extern "C" int m360_set_paired_rows(int on) { const int was = g_paired_rows; g_paired_rows = on ? 1 : 0; return was; }
-static bool mlp_rows_pairable(int mode, int width, int in_pad) {
-    if (!g_paired_rows) return false;
+// (Round 6: the process-wide switches that lived here - hidden chain, paired rows, row blocks, backward overlap - are per-call bits
+// of m360_hyper_t.tuning now, the library-owned second stream a caller-owned handle; the row-block form of the NeRF MLP is gone with its switch:
+// profiles/HISTORY.md.)
+static bool mlp_rows_pairable(const m360_hyper_t *h, int mode, int width, int in_pad) {
+    if (h->tuning & M360_TUNE_PLAIN_ROWS) return false;  // A/B of the two layouts (same bits either way)
     if (mode == 2) return m360_linear_bf16_rows_pairable(M360_PAIRABLE_SPLIT, width, 6 * in_pad) && m360_linear_bf16_rows_pairable(M360_PAIRABLE_X3, width, width) && m360_linear_bf16_rows_pairable(M360_PAIRABLE_HEADS_X3, width, width);
     return m360_linear_bf16_rows_pairable(M360_PAIRABLE_X3_BF16OUT, width, in_pad) && m360_linear_bf16_rows_pairable(M360_PAIRABLE_LINEAR, width, width) && m360_linear_bf16_rows_pairable(M360_PAIRABLE_HEADS, width, width);
 }
@@ -401,7 +372,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     if (m->mlp_bf16) {  // opt-in: bf16 features / weights / activations, fp32 accumulation (same buffers; mode 2 = bf16x3: [hi | lo] pairs)
         const int mode = m->mlp_bf16;
         if (!ext_norm) M360_TRY(p_encode(h, t_hat, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(mode), h->norm_group_rays, nullptr, parts, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
-        const int pair = mlp_rows_pairable(mode, hp, m->in_pad) ? 1 : 0;  // paired rows between the layers (m360.h)
+        const int pair = mlp_rows_pairable(h, mode, hp, m->in_pad) ? 1 : 0;  // paired rows between the layers (m360.h)
         M360_TRY(p_linear_first(h, mode, feat, S, m->prop_w[0], m->prop_b[0], hp, m->in_pad, a, pair, st));
         // (the proposal MLP's two hidden layers stay two launches: at width 256 the chain - a workgroup owns whole rows there - measured
         // 0.245 against 0.201 ms, profiles/r04/chain_bench_w256_SLOWER.jsonl: its tiles are too short for the hand-over's fixed costs)
@@ -467,46 +438,12 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
     } else if (m->mlp_bf16) {
         const int mode = m->mlp_bf16;
         M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(mode), ext_norm ? 0 : h->norm_group_rays, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
-        const int pair = mlp_rows_pairable(mode, hn, m->in_pad) ? 1 : 0;  // paired rows between the layers (m360.h)
+        const int pair = mlp_rows_pairable(h, mode, hn, m->in_pad) ? 1 : 0;  // paired rows between the layers (m360.h)
         const int ldl = mode == 2 ? 2 * hn : hn;
-        const long rb = pair ? nerf_row_block(S, (long)ldl * 2, mode) : 0;
-        if (rb > 0) {
-            // Row blocks (m360_set_row_blocks): all eight layers on rows [r0, r0 + rb) before the next block, every block on the SAME rows
-            // [0, rb) of the ping / pong buffers, temporal stores: the hidden activations stay in the Infinity Cache.  The features are read
-            // and the heads' partial sums written at the block's own rows; y of the fused-heads layer holds ragged rows only (last block).
-            const size_t feat_row = (size_t)m->in_pad * (mode == 2 ? 12 : 4);
-            const int slots = m360_linear_heads_slots_bf16(hn, hn, mode, 0);
-            // odd blocks on a second stream with their own ping / pong rows [rb, 2 rb) (m360_set_row_block_streams)
-            SideStream *side = g_row_block_streams >= 2 ? side_stream() : nullptr;
-            hipStream_t main_st = reinterpret_cast<hipStream_t>(st);
-            if (side && (hipEventRecord(side->fork, main_st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)) { (void)hipGetLastError(); side = nullptr; }
-            int rc_blocks = M360_OK;
-            long blk = 0;
-            for (long r0 = 0; r0 < S && rc_blocks == M360_OK; r0 += rb, ++blk) {
-                const long rows = S - r0 < rb ? S - r0 : rb;
-                const bool odd = side && (blk & 1);
-                m360_stream_t bst = odd ? reinterpret_cast<m360_stream_t>(side->s) : st;
-                float *ba = odd ? reinterpret_cast<float *>(reinterpret_cast<char *>(a) + (size_t)rb * ldl * 2) : a;
-                float *bb = odd ? reinterpret_cast<float *>(reinterpret_cast<char *>(b) + (size_t)rb * ldl * 2) : b;
-                rc_blocks = p_linear_first(h, mode, reinterpret_cast<const char *>(feat) + (size_t)r0 * feat_row, rows, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, ba, pair, bst, 1);
-                float *bs = ba, *bd = bb;
-                for (int layer = 1; layer < 7 && rc_blocks == M360_OK; ++layer) {
-                    rc_blocks = p_linear_bf16(h, mode, bs, rows, m->nerf_w[layer], m->nerf_b[layer], hn, hn, M360_ACT_RELU, bd, pair, bst, 1);
-                    float *tmp = bs; bs = bd; bd = tmp;
-                }
-                char *yb = reinterpret_cast<char *>(b) + (size_t)r0 * ldl * 2;  // ragged rows of the batch at their own place in b
-                if (rc_blocks == M360_OK)
-                    rc_blocks = p_linear_heads(h, mode, bs, rows, ldl, m->nerf_w[7], m->nerf_b[7], hn, hn, yb, ldl, 0, m->nerf_head_w, 4, hpart + (size_t)r0 * slots * 4, bst, pair);
-            }
-            // the join is issued whatever happened: the caller's stream must not run ahead of work already queued on the second one
-            if (side && (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(main_st, side->join, 0) != hipSuccess))
-                return fail(M360_ERR_LAUNCH, "m360_nerf_forward: joining the row blocks' second stream failed: %s", hipGetErrorString(hipGetLastError()));
-            if (rc_blocks != M360_OK) return rc_blocks;
-            src = a; dst = b;
-        } else {
+        {
         // the six hidden layers: ONE launch for the rows the chain takes (bf16 mode, paired rows, width 1024, multiples of 32768 rows:
         // m360_mlp_chain_bf16 - the activations handed over through the XCDs' L2s instead of six kernel boundaries), layer by layer the rest
-        const long Mc = (mode == 1 && pair && g_hidden_chain) ? (S / 32768) * 32768 : 0;
+        const long Mc = (mode == 1 && pair && !(h->tuning & M360_TUNE_NO_HIDDEN_CHAIN)) ? (S / 32768) * 32768 : 0;
         const bool chain = Mc > 0 && m360_mlp_chain_bf16_supported(Mc, hn, 6);
         // With the chain the first layer writes to a THIRD buffer - the upper half of `a`, which is sized for fp32 rows and holds bf16 ones
         // here - that no hidden layer writes: what the chain read stays intact, so the launch can be repeated layer by layer when it reports
@@ -519,9 +456,9 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
             for (int layer = 1; layer < 7; ++layer) { cw[layer - 1] = m->nerf_w[layer]; cb[layer - 1] = m->nerf_b[layer]; }
             {
                 ProfScope ps(h, st, M360_K_LINEAR_BF16, Mc, hn, 6 * hn);  // k_pad = 6 hn: six layers in one record (the chain kernel alone)
-                M360_TRY(ps.done(mlp_chain_bf16_launch(first, a, b, Mc, hn, cw, cb, 6, hn, ws + L.chain, st)));
+                M360_TRY(ps.done(mlp_chain_bf16_launch(first, a, b, Mc, hn, cw, cb, 6, hn, ws + L.chain, st, h)));
             }
-            M360_TRY(mlp_chain_bf16_rerun(first, a, b, Mc, hn, cw, cb, 6, hn, ws + L.chain, st));
+            M360_TRY(mlp_chain_bf16_rerun(first, a, b, Mc, hn, cw, cb, 6, hn, ws + L.chain, st, h));
         }
         const long r0 = chain ? Mc : 0;  // rows [r0, S) layer by layer; both parts end in `a`: first -> b -> a -> b -> a -> b -> a
         if (r0 < S) {
@@ -566,6 +503,28 @@ int m360_device_count(void) {
         return 0;
     }
     return n;
+}
+
+int m360_side_create(m360_side_t **out) {
+    if (!out) return fail(M360_ERR_INVALID_ARGUMENT, "m360_side_create: null out pointer");
+    *out = nullptr;
+    m360_side *sd = new m360_side();
+    if (hipGetDevice(&sd->device) != hipSuccess || hipStreamCreateWithFlags(&sd->s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) != hipSuccess) {
+        const int rc = fail(M360_ERR_LAUNCH, "m360_side_create: %s", hipGetErrorString(hipGetLastError()));
+        m360_side_destroy(sd);
+        return rc;
+    }
+    *out = sd;
+    return M360_OK;
+}
+
+void m360_side_destroy(m360_side_t *sd) {
+    if (!sd) return;
+    if (sd->s) { (void)hipStreamSynchronize(sd->s); (void)hipStreamDestroy(sd->s); }
+    if (sd->fork) (void)hipEventDestroy(sd->fork);
+    if (sd->join) (void)hipEventDestroy(sd->join);
+    delete sd;
 }
 
 m360_prof_t *m360_prof_create(int capacity) {
@@ -764,30 +723,30 @@ __global__ void fold_first_layer_kernel(const float *__restrict__ r, int n_pad, 
 // fp32 on the bf16 matrix pipe, the gradients come out in fp32 in the packed [n_pad, k_pad] layouts of the fp32 path (layer 0: [n_pad, in_pad]).
 // Round 5: the ReLU mask of a layer's input gradient (an HBM pass over [S, width] bf16: 0.52 ms at 524 288 x 1024) runs on a SECOND stream
 // beside the layer's weight gradient (MFMA-bound, 1.0 ms, reads dz and the stored activations - not dx): input-gradient GEMM, then fork -
-// {mask | weight gradient} - join.  m360_set_backward_overlap(0): one stream, the mask behind its GEMM (same bits either way).
+// {mask | weight gradient} - join.  The second stream is the CALLER's (m360_hyper_t.side, a m360_side_t); without one: one stream, the mask behind
+// its GEMM (same weight gradients bit for bit).
 // The mask runs THROTTLED there - one striding workgroup per CU, two 16-byte pieces per thread in flight: at full rate (6 TB/s) it stretched the
 // weight gradient beside it from 1.04 to 1.45 ms and the pair gained 0.1 ms; 4096 x 128, NeRF backward + forward, same box, ms:
 //   one stream 26.5 | mask workgroups: all 25.4, 4096 25.7, 1024 25.6, 512 24.5, 384 26.3, 320 26.1, 256 23.7-23.9, 192 24.9, 128 27.5, 64 36.9
 // (four pieces in flight: no better; profiles/r05/backward_overlap_ab.jsonl)
-static int g_backward_overlap = 1;
-static int g_backward_mask_blocks = 256;
-extern "C" int m360_set_backward_overlap(int on) {  // > 1 (A/B runs): that many workgroups of the mask kernel
-    const int was = g_backward_overlap;
-    g_backward_overlap = on ? 1 : 0;
-    if (on > 1) g_backward_mask_blocks = on;
-    return was;
-}
+constexpr int kBackwardMaskBlocks = 256;  // one striding workgroup of the throttled mask kernel per CU (the A/B above)
 static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *const *w_t, float *const *grad_w, float *const *grad_b, const void *feat,
                              int in_pad, void *const *act, int width, long S, void *dz, void *dz_other, char *ws, const BwdLayout &L,
                              m360_stream_t st, const char *who) {
     void *gemm_ws = ws + L.gemm;
     const size_t gemm_bytes = L.finish - L.gemm;
-    SideStream *ss = (g_backward_overlap && S >= 32768 && !(h && h->prof)) ? side_stream() : nullptr;  // (a recorder brackets launches of ONE stream)
+    m360_side *ss = (h && h->side && S >= 32768 && !h->prof) ? static_cast<m360_side *>(h->side) : nullptr;  // (a recorder brackets launches of ONE stream)
+    if (ss) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev != ss->device)
+            return fail(M360_ERR_INVALID_ARGUMENT, "%s: m360_hyper_t.side was created for device %d, the call runs on device %d", who, ss->device, dev);
+    }
     // The masked rows the second stream writes ARE the next layer's dz: their column sums - that layer's bias gradient - come out of the mask kernel
     // (it meets every element anyway and runs beside, not in front of, the matrix work), where the weight-gradient kernel pays ~0.1 ms of its 1.0 for
     // them.  Its partial sums (2 MB) live in the finishers' backward scratch (read for the last time before this function runs).
     float *mask_part = reinterpret_cast<float *>(ws + L.finish);
-    const bool mask_sums = ss && relu_mask_bf16_sums_ok(S, width, g_backward_mask_blocks) && relu_mask_bf16_sums_bytes(g_backward_mask_blocks) <= L.feat_wide - L.finish;
+    const bool mask_sums = ss && relu_mask_bf16_sums_ok(S, width, kBackwardMaskBlocks) && relu_mask_bf16_sums_bytes(kBackwardMaskBlocks) <= L.feat_wide - L.finish;
+    const unsigned tuning = h ? h->tuning : 0u;
     bool have_bias = false;  // grad_b[l] already written (by the mask that produced this layer's dz)
     for (int l = layers - 1; l >= 0; --l) {
         if (!grad_w[l] || !grad_b[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: gradient buffer of layer %d is null", who, l);
@@ -799,17 +758,23 @@ static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *con
             m360_stream_t s2 = reinterpret_cast<m360_stream_t>(ss->s);
             M360_TRY(m360_linear_dgrad_bf16(dz, S, width, w_t[l], width, width, nullptr, dz_other, width, st));
             if (hipEventRecord(ss->fork, hs) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) return fail(M360_ERR_LAUNCH, "%s: fork to the second stream failed: %s", who, hipGetErrorString(hipGetLastError()));
-            M360_TRY(relu_mask_bf16(dz_other, act[l - 1], S, width, width, s2, g_backward_mask_blocks, mask_sums ? mask_part : nullptr));
-            if (mask_sums) {
-                M360_TRY(relu_mask_bf16_sums_reduce(mask_part, g_backward_mask_blocks, width, grad_b[l - 1], s2));
+            // From here to the join the second stream may hold work that writes dz_other / mask_part / grad_b[l - 1]: WHATEVER fails in between, the
+            // caller's stream is ordered behind that work before this call returns (an early return used to leave it unordered, and the
+            // caller free to recycle those buffers under it).
+            int rc = relu_mask_bf16(dz_other, act[l - 1], S, width, width, s2, kBackwardMaskBlocks, mask_sums ? mask_part : nullptr);
+            if (rc == M360_OK && mask_sums) {
+                rc = relu_mask_bf16_sums_reduce(mask_part, kBackwardMaskBlocks, width, grad_b[l - 1], s2);
                 have_bias = true;
             }
-            if (hipEventRecord(ss->join, ss->s) != hipSuccess) return fail(M360_ERR_LAUNCH, "%s: join event failed: %s", who, hipGetErrorString(hipGetLastError()));
-            M360_TRY(m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], gb, gemm_ws, gemm_bytes, st));
-            if (hipStreamWaitEvent(hs, ss->join, 0) != hipSuccess) return fail(M360_ERR_LAUNCH, "%s: join of the second stream failed: %s", who, hipGetErrorString(hipGetLastError()));
+            if (rc == M360_OK) rc = m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], gb, gemm_ws, gemm_bytes, tuning, st);
+            if (hipEventRecord(ss->join, ss->s) != hipSuccess || hipStreamWaitEvent(hs, ss->join, 0) != hipSuccess) {
+                (void)hipStreamSynchronize(ss->s);  // no event to order the streams by: wait the second one out on the host
+                if (rc == M360_OK) rc = fail(M360_ERR_LAUNCH, "%s: join of the second stream failed: %s", who, hipGetErrorString(hipGetLastError()));
+            }
+            if (rc != M360_OK) return rc;
             void *tmp = dz; dz = dz_other; dz_other = tmp;
         } else if (l > 0) {
-            M360_PROF(h, st, M360_K_WGRAD, S, width, -width, m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], gb, gemm_ws, gemm_bytes, st));
+            M360_PROF(h, st, M360_K_WGRAD, S, width, -width, m360_linear_wgrad_bf16(dz, width, act[l - 1], width, S, width, width, grad_w[l], gb, gemm_ws, gemm_bytes, tuning, st));
             if (!w_t[l]) return fail(M360_ERR_INVALID_ARGUMENT, "%s: transposed weight of layer %d is null", who, l);
             M360_PROF(h, st, M360_K_DGRAD, S, width, -width, m360_linear_dgrad_bf16(dz, S, width, w_t[l], width, width, act[l - 1], dz_other, width, st));
             void *tmp = dz; dz = dz_other; dz_other = tmp;
@@ -826,7 +791,7 @@ static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *con
                 ld0 = L.first_k;
             }
             float *r = reinterpret_cast<float *>(ws + L.first);
-            M360_PROF(h, st, M360_K_WGRAD, S, width, -L.first_k, m360_linear_wgrad_bf16(dz, width, x0, ld0, S, width, L.first_k, r, gb, gemm_ws, gemm_bytes, st));
+            M360_PROF(h, st, M360_K_WGRAD, S, width, -L.first_k, m360_linear_wgrad_bf16(dz, width, x0, ld0, S, width, L.first_k, r, gb, gemm_ws, gemm_bytes, tuning, st));
             hipLaunchKernelGGL(fold_first_layer_kernel, dim3((unsigned)((width * in_pad + 255) / 256)), dim3(256), 0, hs, r, width, L.first_k, in_pad, grad_w[0]);
             M360_TRY(check_launch(who));
         }

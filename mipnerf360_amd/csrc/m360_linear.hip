@@ -14,6 +14,8 @@
 //   step s) so one ds_read_b128 feeds four consecutive MFMAs for A and for B alike.
 //   Workgroup ids are remapped so the 4 N-tiles of one M-tile run on the same XCD (shared L2).
 #include <stdlib.h>
+#include <atomic>
+
 #include "m360_common.hip.h"
 #include "m360_linear_persist.hip.h"
 #include "m360_linear_bf16.hip.h"
@@ -264,18 +266,22 @@ using namespace m360;
 
 // CU count of the CURRENT device (the persistent kernels launch one workgroup per CU); cached per device
 static int cu_count() {
-    static int cached[64];  // zero-initialised; a benign race at worst queries twice
+    // a memo of an immutable hardware property, not state: zero-initialised, relaxed atomics (two threads at worst both query and store the same number)
+    static std::atomic<int> cached[64];
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
-    if (dev >= 0 && dev < 64 && cached[dev] > 0) return cached[dev];
+    if (dev >= 0 && dev < 64) {
+        const int c = cached[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
-    if (dev >= 0 && dev < 64) cached[dev] = n;
+    if (dev >= 0 && dev < 64) cached[dev].store(n, std::memory_order_relaxed);
     return n;
 }
 
@@ -753,17 +759,8 @@ int m360_linear_bf16(const void *x, long M, int ldx, const void *w_packed, const
 }
 
 // ---- the chain of equally shaped bf16 ReLU layers in one launch (w16::chain_t, m360_linear_bf16_w16.hip.h)
-// Process-wide switches like m360_set_paired_rows (tests and A/B runs): the bound of one wait, a fault to inject, cooperative launch.
-static unsigned g_chain_wait_ticks = w16::kChainWaitTicks;
-static int g_chain_fault = 0;
-static int g_chain_cooperative = 0;
-int m360_set_chain_debug(long wait_ticks, int fault) {
-    g_chain_wait_ticks = wait_ticks > 0 ? (unsigned)wait_ticks : w16::kChainWaitTicks;
-    g_chain_fault = fault;
-    return M360_OK;
-}
-int m360_set_chain_cooperative(int on) { const int was = g_chain_cooperative; g_chain_cooperative = on ? 1 : 0; return was; }
-
+// Per-call options (m360_hyper_t: tuning bit M360_TUNE_CHAIN_COOPERATIVE; diagnostics build only: the bound of one wait and a fault to inject -
+// the product library refuses those hooks, it never injects a fault).  The library holds no switch of its own.
 // Shapes and device the chain takes.  Nothing is probed: the placement the hand-over relies on (workgroup b on the XCD of slot b % 8) is
 // checked by every launch itself, inside the kernel, and a launch that finds it violated is re-run layer by layer (mlp_chain_bf16_rerun).
 int m360_mlp_chain_bf16_supported(long M, int width, int layers) {
@@ -798,8 +795,19 @@ namespace m360 {
 
 // One chain launch.  ws = [chain_status_t | counters]; the launch part of the status and the counters are zeroed here (one memset), the
 // sticky counters are left alone.  x_in (may be NULL: act0) is what layer 0 reads.
+int chain_opts_ok(const m360_hyper_t *opts, const char *who) {
+#ifndef M360_DIAG
+    if (opts && (opts->chain_debug_wait_ticks != 0 || opts->chain_debug_fault != 0 || (opts->tuning & M360_TUNE_CHAIN_UNGATED)))
+        return fail(M360_ERR_INVALID_ARGUMENT, "%s: chain_debug_* / M360_TUNE_CHAIN_UNGATED are test hooks of the diagnostics build (libm360_diag.so); this library has none", who);
+#endif
+    (void)opts; (void)who;
+    return M360_OK;
+}
+
 int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
-                          int layers, int width, void *ws, m360_stream_t stream) {
+                          int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts) {
+    const int rc_opts = chain_opts_ok(opts, "m360_mlp_chain_bf16");
+    if (rc_opts != M360_OK) return rc_opts;
     w16::chain_t ch;
     for (int l = 0; l < 8; ++l) {
         ch.w[l] = static_cast<const __bf16 *>(w_packed[l < layers ? l : layers - 1]);
@@ -813,8 +821,12 @@ int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int 
     ch.done = reinterpret_cast<unsigned *>(static_cast<char *>(ws) + sizeof(w16::chain_status_t));
     ch.layers = layers;
     ch.row_blocks = (int)(M / w16::BM);
-    ch.wait_ticks = g_chain_wait_ticks;
-    ch.fault = g_chain_fault;
+    ch.wait_ticks = w16::kChainWaitTicks;
+    ch.fault = 0;
+#ifdef M360_DIAG
+    if (opts && opts->chain_debug_wait_ticks > 0) ch.wait_ticks = (unsigned)opts->chain_debug_wait_ticks;
+    if (opts) ch.fault = opts->chain_debug_fault;
+#endif
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (hipMemsetAsync(static_cast<char *>(ws) + w16::kChainStatusLaunchOffset, 0, m360_mlp_chain_bf16_workspace(M, layers) - w16::kChainStatusLaunchOffset, st) != hipSuccess)
         return fail(M360_ERR_LAUNCH, "m360_mlp_chain_bf16: hipMemsetAsync failed");
@@ -826,8 +838,8 @@ int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int 
     int tiles_n = width / w16::BN, ntiles = ch.row_blocks * tiles_n, xpair = 1, stagger = 0, gate_first = 0;
     unsigned *gate = nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool coop = g_chain_cooperative && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
-    if (coop) {  // co-residency of the 256 workgroups asked of the runtime (A/B: m360_set_chain_cooperative)
+    const bool coop = opts && (opts->tuning & M360_TUNE_CHAIN_COOPERATIVE) && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    if (coop) {  // co-residency of the 256 workgroups asked of the runtime (A/B: M360_TUNE_CHAIN_COOPERATIVE)
         void *args[] = {&X, &M, &ld, &W0, &B0, &width, &width, &Y, &ld, &tiles_n, &ntiles, &hw, &hp, &xpair, &stagger, &ch, &gate, &gate_first};
         if (hipLaunchCooperativeKernel(reinterpret_cast<void *>(kern), dim3(256), dim3(w16::kThreads), args, 0, st) != hipSuccess)
             return fail(M360_ERR_LAUNCH, "m360_mlp_chain_bf16: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -842,8 +854,11 @@ int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int 
 // its XCD, these launches redo all of its rows from x_in (which the chain never writes) - the very kernel m360_linear_bf16 runs for a
 // hidden layer on paired rows, hence the same bits.  No host round trip, nothing for a caller to check before using the result.
 int mlp_chain_bf16_rerun(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
-                         int layers, int width, void *ws, m360_stream_t stream) {
-    if (g_chain_fault == -1) return M360_OK;  // A/B of the gated launches' cost (m360_set_chain_debug): the chain alone, unchecked
+                         int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts) {
+#ifdef M360_DIAG
+    if (opts && (opts->tuning & M360_TUNE_CHAIN_UNGATED)) return M360_OK;  // A/B of the gated launches' cost: the chain alone, unchecked
+#endif
+    (void)opts;
     const int cus = cu_count();
     if (cus <= 0) return fail(M360_ERR_NO_DEVICE, "m360_mlp_chain_bf16: no HIP device");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -875,23 +890,23 @@ static int chain_args_ok(const char *who, const void *x_in, void *act0, void *ac
 extern "C" {
 
 int m360_mlp_chain_bf16(void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed, int layers,
-                        int width, void *workspace, m360_stream_t stream) {
+                        int width, void *workspace, const m360_hyper_t *opts, m360_stream_t stream) {
     const int rc = chain_args_ok("m360_mlp_chain_bf16", nullptr, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace);
     if (rc != M360_OK) return rc;
     const int rc2 = m360_workspace_init(workspace, stream);  // a standalone call's status is its own
     if (rc2 != M360_OK) return rc2;
-    return mlp_chain_bf16_launch(nullptr, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream);
+    return mlp_chain_bf16_launch(nullptr, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream, opts);
 }
 
 int m360_mlp_chain_bf16_safe(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
-                             int layers, int width, void *workspace, m360_stream_t stream) {
+                             int layers, int width, void *workspace, const m360_hyper_t *opts, m360_stream_t stream) {
     if (!x_in || x_in == act0 || x_in == act1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16_safe: x_in must be a third buffer (the re-run reads it again)");
     const int rc = chain_args_ok("m360_mlp_chain_bf16_safe", x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace);
     if (rc != M360_OK) return rc;
     if (width != 4 * w16::BN) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16_safe: width=%d (1024: the NeRF MLP's hidden layers)", width);
-    const int rc2 = mlp_chain_bf16_launch(x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream);
+    const int rc2 = mlp_chain_bf16_launch(x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream, opts);
     if (rc2 != M360_OK) return rc2;
-    return mlp_chain_bf16_rerun(x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream);
+    return mlp_chain_bf16_rerun(x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream, opts);
 }
 
 int m360_pack_linear_bf16x6(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed6,
@@ -1002,13 +1017,14 @@ int m360_linear_dgrad_bf16(const void *dz, long M, int ldz, const void *wt_packe
     return m360::relu_mask_bf16(dx, relu_out, M, k_pad, ldx, stream, 0, nullptr);
 }
 
-// which MFMA form m360_linear_wgrad_bf16 runs (A/B switch, process-wide like m360_set_paired_rows): 1 = one wave per SIMD, 128 x 128 wave tiles,
-// five LDS quarters (m360_linear_tn_bf16_w.hip.h), 0 = the 8-wave kernel of m360_linear_tn_bf16.hip.h.  Both deterministic; their row splits differ, so
-// their results agree to fp32 summation order, not bit for bit.
-static int g_wgrad_bf16_form = 1;
-int m360_set_wgrad_bf16_form(int form) { const int was = g_wgrad_bf16_form; g_wgrad_bf16_form = form ? 1 : 0; return was; }
-static bool wgrad_bf16_on_mfma(long M, int n_pad, int k_pad, int ldz, int ldx) {
-    return n_pad % tn16::BT == 0 && k_pad % tn16::BT == 0 && ldz % 8 == 0 && ldx % 8 == 0 && M >= tn16::BKM;
+// which MFMA form m360_linear_wgrad_bf16 runs is the caller's per-call choice (`tuning`): default = one wave per SIMD, 128 x 128 wave tiles,
+// five LDS quarters (m360_linear_tn_bf16_w.hip.h), M360_TUNE_WGRAD_FORM0 = the 8-wave kernel of m360_linear_tn_bf16.hip.h.  Both deterministic; their row
+// splits differ, so their results agree to fp32 summation order, not bit for bit.
+// The path is a function of (M, n_pad, k_pad) ALONE - it sizes the workspace (m360_linear_wgrad_bf16_workspace_bytes has nothing else) and it
+// picks the kernel; what the MFMA kernels additionally need of a call (leading dimensions that are multiples of 8, 16-byte aligned pointers) is
+// REQUIRED of a call with such pads, not a reason to take the other path with a workspace sized for this one.
+static bool wgrad_bf16_on_mfma(long M, int n_pad, int k_pad) {
+    return n_pad % tn16::BT == 0 && k_pad % tn16::BT == 0 && M >= tn16::BKM;
 }
 static void wgrad_bf16_plan(long M, int n_pad, int k_pad, int *ntiles, int *nsplit, long *total_steps, long *steps_per_split) {
     *ntiles = (n_pad / tn16::BT) * (k_pad / tn16::BT);
@@ -1022,7 +1038,7 @@ static void wgrad_bf16_plan(long M, int n_pad, int k_pad, int *ntiles, int *nspl
 
 size_t m360_linear_wgrad_bf16_workspace_bytes(long M, int n_pad, int k_pad) {
     if (M < 0 || n_pad < 1 || k_pad < 1) return 0;
-    if (wgrad_bf16_on_mfma(M, n_pad, k_pad, 8, 8)) {
+    if (wgrad_bf16_on_mfma(M, n_pad, k_pad)) {
         int ntiles, nsplit;
         long total, per;
         wgrad_bf16_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
@@ -1033,14 +1049,16 @@ size_t m360_linear_wgrad_bf16_workspace_bytes(long M, int n_pad, int k_pad) {
 }
 
 int m360_linear_wgrad_bf16(const void *dz, int ldz, const void *x, int ldx, long M, int n_pad, int k_pad, float *grad_w, float *grad_b,
-                           void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+                           void *workspace, size_t workspace_bytes, unsigned tuning, m360_stream_t stream) {
     if (!dz || !x || !grad_w || M < 0 || n_pad < 32 || k_pad < 32 || n_pad % 32 || k_pad % 32 || ldz < n_pad || ldx < k_pad)
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_wgrad_bf16: bad argument (M=%ld n_pad=%d k_pad=%d ldz=%d ldx=%d)", M, n_pad, k_pad, ldz, ldx);
     const size_t need = m360_linear_wgrad_bf16_workspace_bytes(M, n_pad, k_pad);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_linear_wgrad_bf16: workspace %zu < %zu bytes (or not 256-byte aligned)", workspace_bytes, need);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const __bf16 *dzb = static_cast<const __bf16 *>(dz), *xb = static_cast<const __bf16 *>(x);
-    if (wgrad_bf16_on_mfma(M, n_pad, k_pad, ldz, ldx) && !(((uintptr_t)dz | (uintptr_t)x | (uintptr_t)grad_w) & 15)) {
+    if (wgrad_bf16_on_mfma(M, n_pad, k_pad)) {
+        if (ldz % 8 != 0 || ldx % 8 != 0 || (((uintptr_t)dz | (uintptr_t)x | (uintptr_t)grad_w) & 15))
+            return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_wgrad_bf16: n_pad=%d, k_pad=%d (multiples of %d) run on the MFMA kernels: ldz=%d and ldx=%d must be multiples of 8 and dz, x, grad_w 16-byte aligned", n_pad, k_pad, tn16::BT, ldz, ldx);
         int ntiles, nsplit;
         long total, per;
         wgrad_bf16_plan(M, n_pad, k_pad, &ntiles, &nsplit, &total, &per);
@@ -1052,7 +1070,7 @@ int m360_linear_wgrad_bf16(const void *dz, int ldz, const void *x, int ldx, long
         const long total32 = M / tn16w::KS, per32 = (total32 + nsplit - 1) / nsplit;
         // one wave per SIMD: k-steps of 32 rows, the same number of splits (>= 4 k tiles: its bias sums; a split's rows within the 2 GB its
         // buffer descriptors address: 32-bit offsets)
-        if (g_wgrad_bf16_form == 1 && k_pad >= 4 * tn16w::BT && (per32 + 1) * tn16w::KS * (long)(ldz > ldx ? ldz : ldx) * 2 < (1l << 31)) {
+        if (!(tuning & M360_TUNE_WGRAD_FORM0) && k_pad >= 4 * tn16w::BT && (per32 + 1) * tn16w::KS * (long)(ldz > ldx ? ldz : ldx) * 2 < (1l << 31)) {
             hipLaunchKernelGGL(tn16w::linear_tn_bf16_w_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn16w::kThreads), 0, st, dzb, ldz, xb, ldx, n_pad, k_pad, partial, k_pad / tn16w::BT, ntiles, nsplit, total32, per32, grad_b ? bias_part : nullptr);
             const long count4w = (long)n_pad * k_pad / 4;
             hipLaunchKernelGGL(tn16::tn16_reduce_kernel, dim3((unsigned)((count4w + 255) / 256)), dim3(256), 0, st, partial, nsplit, n_pad, k_pad, dzb, ldz, xb, ldx, total32 * tn16w::KS, M, grad_w);
@@ -1078,11 +1096,13 @@ int m360_linear_wgrad_bf16(const void *dz, int ldz, const void *x, int ldx, long
     float *dzf = static_cast<float *>(workspace);
     float *xf = reinterpret_cast<float *>(static_cast<char *>(workspace) + up256_((size_t)M * n_pad * sizeof(float)));
     char *rest = reinterpret_cast<char *>(xf) + up256_((size_t)M * k_pad * sizeof(float));
+    const size_t used = (size_t)(rest - static_cast<char *>(workspace));
+    if (used > workspace_bytes) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_linear_wgrad_bf16: workspace %zu < %zu bytes for the widened operands", workspace_bytes, used);
     hipLaunchKernelGGL(tn16::widen_bf16_kernel, dim3((unsigned)((M * n_pad + 255) / 256)), dim3(256), 0, st, dzb, M, n_pad, ldz, dzf);
     hipLaunchKernelGGL(tn16::widen_bf16_kernel, dim3((unsigned)((M * k_pad + 255) / 256)), dim3(256), 0, st, xb, M, k_pad, ldx, xf);
     const int rc = check_launch("linear_wgrad_bf16 (widen)");
     if (rc != M360_OK) return rc;
-    return m360_linear_wgrad(dzf, n_pad, xf, k_pad, M, n_pad, k_pad, grad_w, grad_b, rest, workspace_bytes - (size_t)(rest - static_cast<char *>(workspace)), stream);
+    return m360_linear_wgrad(dzf, n_pad, xf, k_pad, M, n_pad, k_pad, grad_w, grad_b, rest, workspace_bytes - used, stream);
 }
 
 int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed3,

@@ -120,7 +120,7 @@ struct chain_t {
     int layers;
     int row_blocks;      // a multiple of 128 (width 1024) / 512 (width 256): every group of workgroups owns an even number
     unsigned wait_ticks; // bound of one wait (kChainWaitTicks; tests shrink it to force the give-up path)
-    int fault;           // test hook: 1 = workgroup 9 reports a foreign XCD, 2 = every wave treats its first wait as run out
+    int fault;           // test hook, read by the DIAGNOSTICS build only: 1 = workgroup 9 reports a foreign XCD, 2 = every wave treats its first wait as run out
 };
 
 #ifdef M360_DIAG
@@ -224,7 +224,9 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     if (CHAIN) {  // placement check: is this workgroup on the XCD the first workgroup of its slot ran on?
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+#ifdef M360_DIAG  // test hook (diagnostics build only): one workgroup reports a foreign XCD
         if (ch.fault == 1 && blockIdx.x == 9) xcc ^= 1u;
+#endif
         if (threadIdx.x == 0) {
             unsigned seen = 0u;
             __hip_atomic_compare_exchange_strong(&ch.status->xcc_slot[blockIdx.x & 7], &seen, xcc + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -293,7 +295,11 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     auto chain_wait = [&](int t) __attribute__((always_inline)) {
         if (ch_gave_up) return;
         unsigned *flag = ch.done + (long)(blockIdx.x & 7) * ch_T + t;
+#ifdef M360_DIAG  // test hook (diagnostics build only): every wave treats its first wait as run out
         bool lost = ch.fault == 2;
+#else
+        bool lost = false;
+#endif
         if (!lost && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 128u) {
             unsigned long long t0, t1;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");

@@ -198,6 +198,7 @@ def _hyper_struct(num_samples, min_deg, max_deg, white_bkgd=False, density_bias=
     h = _lib.HyperStruct(int(num_samples), int(min_deg), int(max_deg), int(bool(white_bkgd)), float(density_bias),
                          float(rgb_padding), float(resample_padding))
     h.prof = prof.handle if prof is not None else None  # optional _lib.Prof event recorder (bench.py, tools/)
+    ops.apply_tuning(h)  # this thread's per-call A/B switches (libm360 holds none of its own)
     return h
 
 
@@ -265,6 +266,7 @@ class _TrainCtx:
         pack_t = ops.pack_linear_bf16_transposed if self.bf16 else ops.pack_linear_transposed
         self.w_t = [None] + [pack_t(lin.weight, packed.h_pad, packed.h_pad) for lin in layers[1:]]
         self.in_pad = packed.in_pad
+        self.overlap = ops.backward_overlap_wanted()  # decided on the forward's thread, like hyper.tuning
         self.versions = [p._version for p in module.parameters()]
 
     def backward(self, grad_args):
@@ -275,6 +277,9 @@ class _TrainCtx:
         # the event recorder of the FORWARD may have been detached / closed since: use what is attached now, or none
         prof = getattr(module, "prof", None)
         self.hyper.prof = prof.handle if (prof is not None and getattr(prof, "handle", None)) else None
+        # (self.hyper carries the per-call switches of the thread that ran the FORWARD: autograd runs this on its own engine thread)
+        # bf16 mode: a second stream of our own for the ReLU mask beside the weight gradient (m360_side_t; the library owns none)
+        self.hyper.side = ops.side_handle(dev) if (self.bf16 and self.overlap) else None
         if [p._version for p in module.parameters()] != self.versions:
             raise RuntimeError("a parameter was modified in place between the forward and its backward")
         lib = _lib.lib()

@@ -91,6 +91,125 @@ def call(name: str, *args, device=None):
 _call = call
 
 
+# ----------------------------------------------------------------------------- per-call tuning (include/m360.h: m360_hyper_t.tuning, .side, .chain_debug_*)
+# libm360 holds NO switch of its own (0.2.0): what used to be process-wide m360_set_* calls are fields of every call's m360_hyper_t.  The host
+# mirror keeps the CURRENT THREAD's choice here - thread-local, so two threads driving two models never see each other's setting - and
+# writes it into each hyper struct it builds (apply_tuning).  Defaults: chain on, paired rows, one-wave weight gradient, overlapped backward.
+import threading  # noqa: E402
+
+_TUNE_DEFAULTS = dict(hidden_chain=True, paired_rows=True, wgrad_form=1, backward_overlap=True, chain_cooperative=False, chain_ungated=False,
+                      chain_wait_ticks=0, chain_fault=0)
+
+
+class _Tuning(threading.local):
+    def __init__(self):
+        self.__dict__.update(_TUNE_DEFAULTS)
+
+
+_tuning = _Tuning()
+
+
+def _swap(name, value):
+    old = getattr(_tuning, name)
+    setattr(_tuning, name, value)
+    return old
+
+
+def set_paired_rows(on: bool) -> bool:
+    """Paired rows between the layers of the bf16 / bf16x3 MLPs on / off for this thread's calls (M360_TUNE_PLAIN_ROWS; same bits either
+    way); returns the old setting"""
+    return _swap("paired_rows", bool(on))
+
+
+def set_hidden_chain(on: bool) -> bool:
+    """bf16 mode: the six hidden NeRF layers as one launch (default) or six (M360_TUNE_NO_HIDDEN_CHAIN; same bits); returns the old setting"""
+    return _swap("hidden_chain", bool(on))
+
+
+def set_wgrad_bf16_form(form: int) -> int:
+    """m360_linear_wgrad_bf16: 1 = one wave per SIMD (default), 0 = the 8-wave kernel (M360_TUNE_WGRAD_FORM0); returns the old setting"""
+    return _swap("wgrad_form", 1 if form else 0)
+
+
+def set_backward_overlap(on: bool) -> bool:
+    """bf16 backward: hand the calls a second stream (m360_side_t) for the ReLU mask beside the weight gradient (default) or none"""
+    return _swap("backward_overlap", bool(on))
+
+
+def set_chain_cooperative(on: bool) -> bool:
+    return _swap("chain_cooperative", bool(on))
+
+
+def set_chain_debug(wait_ticks: int = 0, fault: int = 0) -> None:
+    """Test hooks of the layer chain, honoured by the DIAGNOSTICS build only (`with _lib.use_library(_lib.DIAG_LIB_PATH)`; the product
+    library refuses a call that carries them): bound of one wait in 100 MHz ticks (0 = default 0.1 s), fault to inject (0 none, 1 = a
+    workgroup reports a foreign XCD, 2 = every wave gives up at its first wait, -1 = no gated re-run behind the chain: A/B of its cost)."""
+    _tuning.chain_wait_ticks = max(int(wait_ticks), 0)
+    _tuning.chain_fault = int(fault) if int(fault) > 0 else 0
+    _tuning.chain_ungated = int(fault) == -1
+
+
+def tuning_bits() -> int:
+    t = _tuning
+    return ((0 if t.hidden_chain else _lib.TUNE_NO_HIDDEN_CHAIN) | (0 if t.paired_rows else _lib.TUNE_PLAIN_ROWS) |
+            (0 if t.wgrad_form else _lib.TUNE_WGRAD_FORM0) | (_lib.TUNE_CHAIN_COOPERATIVE if t.chain_cooperative else 0) |
+            (_lib.TUNE_CHAIN_UNGATED if t.chain_ungated else 0))
+
+
+def apply_tuning(hyper) -> None:
+    """Write this thread's choices into a _lib.HyperStruct (every call of the stage drivers carries its own)."""
+    hyper.tuning = tuning_bits()
+    hyper.chain_debug_wait_ticks = _tuning.chain_wait_ticks
+    hyper.chain_debug_fault = _tuning.chain_fault
+
+
+def _opts_struct():
+    h = _lib.HyperStruct()
+    apply_tuning(h)
+    return h
+
+
+class _Side:
+    """A caller-owned second stream of libm360 (m360_side_t) for one (library build, device, stream)."""
+
+    def __init__(self, device):
+        import ctypes as C
+        self.lib = _lib.lib()
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self.lib.m360_side_create(C.byref(h)), "m360_side_create")
+        self.handle = h.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.m360_side_destroy(self.handle)
+        except Exception:
+            pass
+
+
+_SIDES = {}
+_SIDES_LOCK = threading.Lock()
+
+
+def backward_overlap_wanted() -> bool:
+    return bool(_tuning.backward_overlap)
+
+
+def side_handle(device):
+    """The m360_side_t to put into m360_hyper_t.side of a bf16 backward on torch's current stream of `device`.  One per (build of the
+    library, device, stream): calls on one stream are issued one after the other."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (getattr(_lib.lib(), "m360_path", ""), device.index, torch.cuda.current_stream(device).cuda_stream)
+    with _SIDES_LOCK:
+        side = _SIDES.get(key)
+        if side is None:
+            side = _SIDES[key] = _Side(device)
+    return side.handle
+
+
 def _ws(device) -> torch.Tensor:
     n = _lib.lib().m360_contract_workspace_bytes()
     return torch.empty(n, dtype=torch.uint8, device=device)
@@ -371,7 +490,7 @@ def linear_wgrad_bf16(dz, x, want_bias: bool = True):
     gw = torch.empty(n_pad, k_pad, device=dz.device)
     gb = torch.empty(n_pad, device=dz.device) if want_bias else None
     ws = torch.empty(max(int(_lib.lib().m360_linear_wgrad_bf16_workspace_bytes(M, n_pad, k_pad)), 256), dtype=torch.uint8, device=dz.device)
-    _call("m360_linear_wgrad_bf16", dz, n_pad, x, k_pad, M, n_pad, k_pad, gw, gb, ws, ws.numel(), STREAM)
+    _call("m360_linear_wgrad_bf16", dz, n_pad, x, k_pad, M, n_pad, k_pad, gw, gb, ws, ws.numel(), tuning_bits(), STREAM)
     return gw, gb
 
 
@@ -634,11 +753,6 @@ def rows_pairable(kind: int, n_pad: int, k_pad: int) -> bool:
     return bool(_lib.lib().m360_linear_bf16_rows_pairable(int(kind), int(n_pad), int(k_pad)))
 
 
-def set_paired_rows(on: bool) -> bool:
-    """m360_set_paired_rows (diagnostics): paired rows between the layers of the bf16 / bf16x3 MLPs on / off; returns the old setting"""
-    return bool(_lib.lib().m360_set_paired_rows(int(bool(on))))
-
-
 def mlp_chain_bf16_supported(M: int, width: int, layers: int) -> bool:
     return bool(_lib.lib().m360_mlp_chain_bf16_supported(int(M), int(width), int(layers)))
 
@@ -661,16 +775,6 @@ def workspace_status(ws: torch.Tensor) -> dict:
     return dict(zip(CHAIN_STATUS_FIELDS, (int(v) for v in out)))
 
 
-def set_chain_debug(wait_ticks: int = 0, fault: int = 0) -> None:
-    """m360_set_chain_debug (tests): bound of one wait in 100 MHz ticks (0 = default 0.1 s), fault to inject (0 none, 1 = a workgroup
-    reports a foreign XCD, 2 = every wave gives up at its first wait)."""
-    _lib.check(_lib.lib().m360_set_chain_debug(int(wait_ticks), int(fault)), "m360_set_chain_debug")
-
-
-def set_chain_cooperative(on: bool) -> bool:
-    return bool(_lib.lib().m360_set_chain_cooperative(int(bool(on))))
-
-
 def _chain_args(act0, act1, packs):
     import ctypes as C
     act0, act1 = dev_bf16(act0, "act0"), dev_bf16(act1, "act1")
@@ -688,7 +792,9 @@ def mlp_chain_bf16(act0, act1, packs):
     act[j & 1], writes act[(j + 1) & 1]; returns the buffer that holds the result.  Raises when the launch reported that one of its
     assumptions did not hold (this entry point has no re-run: its input is overwritten)."""
     act0, act1, M, ld, L, width, ws, wl, bl = _chain_args(act0, act1, packs)
-    _call("m360_mlp_chain_bf16", act0, act1, M, ld, wl, bl, L, width, ws, STREAM)
+    import ctypes as C
+    opts = _opts_struct()
+    _call("m360_mlp_chain_bf16", act0, act1, M, ld, wl, bl, L, width, ws, C.byref(opts), STREAM)
     st = workspace_status(ws)
     if st["last_error"] != 0:
         raise RuntimeError(f"m360_mlp_chain_bf16: the launch reported an error (status {st}): a wait ran out or a workgroup was off its XCD")
@@ -701,13 +807,10 @@ def mlp_chain_bf16_safe(x_in, act0, act1, packs):
     x_in = dev_bf16(x_in, "x_in")
     act0, act1, M, ld, L, width, ws, wl, bl = _chain_args(act0, act1, packs)
     workspace_init(ws)
-    _call("m360_mlp_chain_bf16_safe", x_in, act0, act1, M, ld, wl, bl, L, width, ws, STREAM)
+    import ctypes as C
+    opts = _opts_struct()
+    _call("m360_mlp_chain_bf16_safe", x_in, act0, act1, M, ld, wl, bl, L, width, ws, C.byref(opts), STREAM)
     return (act0 if L % 2 == 0 else act1), workspace_status(ws)
-
-
-def set_row_blocks(rows: int) -> int:
-    """m360_set_row_blocks: rows per block of the NeRF MLP in the bf16 modes (0 off, -1 automatic, > 0 explicit); returns the old setting"""
-    return int(_lib.lib().m360_set_row_blocks(int(rows)))
 
 
 def linear_heads_bf16(x, w_packed, b_packed, head_w, store_y: bool = True, x3: bool = False, paired_in: bool = False):

@@ -34,6 +34,20 @@ def _restore_chain_switches():
     yield
     ops.set_chain_debug(0, 0)
     ops.set_chain_cooperative(False)
+    ops.set_hidden_chain(True)
+    ops.set_paired_rows(True)
+
+
+@pytest.fixture
+def diag():
+    """The fault-injection hooks (m360_hyper_t.chain_debug_*) exist in the DIAGNOSTICS build only - the same sources with -DM360_DIAG
+    (make -C mipnerf360_amd/csrc diag); the product library refuses a call that carries them (test_product_library_has_no_test_hooks).
+    Tests that break the chain's assumptions on purpose run every call of theirs through that build."""
+    from mipnerf360_amd import _lib
+    if not os.path.exists(_lib.DIAG_LIB_PATH):
+        pytest.skip("libm360_diag.so not built (make -C mipnerf360_amd/csrc diag)")
+    with _lib.use_library(_lib.DIAG_LIB_PATH) as lib:
+        yield lib
 
 
 def _packs(width, layers, dev, seed):
@@ -78,7 +92,7 @@ def test_safe_chain_clean_launch(dev, M, layers):
 
 
 @pytest.mark.parametrize("fault", [1, 2])
-def test_safe_chain_repairs_an_injected_fault(dev, fault):
+def test_safe_chain_repairs_an_injected_fault(dev, diag, fault):
     """fault 1: one workgroup reports a foreign XCD (placement check); fault 2: every wave treats its first wait as run out and stops
     waiting - it then reads rows its neighbours have not written yet.  Either way the launch flags itself, the gated re-run redoes all
     rows from x_in, and the result is the layer-by-layer bits; the sticky counters record what happened."""
@@ -97,7 +111,7 @@ def test_safe_chain_repairs_an_injected_fault(dev, fault):
         assert torch.equal(got, want), (fault, rep, int((got != want).sum()))
 
 
-def test_unsafe_entry_point_reports_the_fault(dev):
+def test_unsafe_entry_point_reports_the_fault(dev, diag):
     """m360_mlp_chain_bf16 (no third buffer, no re-run) must at least say so: ops.mlp_chain_bf16 raises."""
     from mipnerf360_amd import ops
     _skip_unless_chain()
@@ -108,6 +122,29 @@ def test_unsafe_entry_point_reports_the_fault(dev):
         ops.mlp_chain_bf16(x.clone(), torch.empty_like(x), packs)
     ops.set_chain_debug(0, 0)
     assert torch.equal(ops.mlp_chain_bf16(x.clone(), torch.empty_like(x), packs), _layer_by_layer(x, packs))
+
+
+def test_product_library_has_no_test_hooks(dev):
+    """the fault-injection hooks live in libm360_diag.so only.  The product library refuses a call whose m360_hyper_t
+    carries them - through the op and through the whole forward - and renders normally again once they are cleared."""
+    from mipnerf360_amd import _lib, ops
+    _skip_unless_chain()
+    assert getattr(_lib.lib(), "m360_path", "").endswith("libm360.so")
+    packs, g = _packs(1024, 2, dev, 5)
+    x = ops.pair_rows(torch.randn(32768, 1024, generator=g).to(dev).bfloat16())
+    for hook in ((0, 2), (5000, 0), (0, -1)):
+        ops.set_chain_debug(*hook)
+        with pytest.raises(RuntimeError, match="diagnostics build"):
+            ops.mlp_chain_bf16_safe(x, torch.empty_like(x), torch.empty_like(x), packs)
+    model, rays = _bf16_model(dev), _rays(dev, 300)
+    ops.set_chain_debug(0, 1)
+    with pytest.raises(RuntimeError, match="diagnostics build"), torch.no_grad():
+        model(rays)
+    ops.set_chain_debug(0, 0)
+    with torch.no_grad():
+        assert all(bool(torch.isfinite(o).all()) for o in model(rays))
+    got, st = ops.mlp_chain_bf16_safe(x, torch.empty_like(x), torch.empty_like(x), packs)
+    assert torch.equal(got, _layer_by_layer(x, packs)) and st["last_error"] == 0
 
 
 def _blocker(dev, stream, launches=40):
@@ -127,7 +164,7 @@ def _blocker(dev, stream, launches=40):
     return go, (xb, wp, bp, yb)
 
 
-def test_safe_chain_next_to_a_kernel_that_holds_cus(dev):
+def test_safe_chain_next_to_a_kernel_that_holds_cus(dev, diag):
     """The advisor's case: a kernel on ANOTHER stream of the same process holds CUs while the chain runs - what an RCCL
     all-gather waiting for a late peer does under the next frame's compute.  With the wait bound shrunk to 50 us the chain's resident
     workgroups give up on the ones that cannot start; whatever happens, the rows must be the layer-by-layer bits."""
@@ -168,18 +205,18 @@ def _rays(dev, B, seed=5):
 
 
 @pytest.mark.parametrize("fault", [1, 2])
-def test_forward_repairs_a_faulty_chain_launch(dev, fault):
+def test_forward_repairs_a_faulty_chain_launch(dev, diag, fault):
     """The whole bf16 forward (m360_forward) with a fault injected into its chain launch: same bits as with six launches, and
     model.chain_status() counts the repair.  300 rays x 128 samples: 32768 rows in the chain + 5632 layer by layer."""
     from mipnerf360_amd import _lib, ops
     _skip_unless_chain()
     model, rays = _bf16_model(dev), _rays(dev, 300)
-    was = _lib.lib().m360_set_hidden_chain(0)
+    was = ops.set_hidden_chain(False)
     try:
         with torch.no_grad():
             want = [o.clone() for o in model(rays)]
     finally:
-        _lib.lib().m360_set_hidden_chain(was)
+        ops.set_hidden_chain(was)
     before = model.chain_status()
     ops.set_chain_debug(0, fault)
     with torch.no_grad():
@@ -198,7 +235,7 @@ def test_forward_repairs_a_faulty_chain_launch(dev, fault):
 
 
 def test_chain_status_when_no_chain_runs(dev):
-    """the status must be defined when the configuration runs no chain - plain rows, row blocks, the chain switched
+    """the status must be defined when the configuration runs no chain - plain rows, the chain switched
     off, a batch below 32768 rows, fp32: `launches` does not move and last_error is the last chain launch's, never uninitialised memory."""
     from mipnerf360_amd import _lib, ops
     _skip_unless_chain()
@@ -219,16 +256,11 @@ def test_chain_status_when_no_chain_runs(dev):
         same_after(lambda: model(rays))
     finally:
         ops.set_paired_rows(was)
-    was = ops.set_row_blocks(16384)
+    was = ops.set_hidden_chain(False)
     try:
         same_after(lambda: model(rays))
     finally:
-        ops.set_row_blocks(was)
-    was = _lib.lib().m360_set_hidden_chain(0)
-    try:
-        same_after(lambda: model(rays))
-    finally:
-        _lib.lib().m360_set_hidden_chain(was)
+        ops.set_hidden_chain(was)
     same_after(lambda: model(_rays(dev, 200)))  # 25600 rows: below one chain block
 
 
@@ -268,7 +300,7 @@ def test_two_streams_of_one_process(dev):
 
 
 def test_cooperative_launch_same_bits(dev):
-    """m360_set_chain_cooperative(1): the chain through hipLaunchCooperativeKernel - same bits, clean status."""
+    """M360_TUNE_CHAIN_COOPERATIVE (ops.set_chain_cooperative): the chain through hipLaunchCooperativeKernel - same bits, clean status."""
     from mipnerf360_amd import ops
     _skip_unless_chain()
     packs, g = _packs(1024, 6, dev, 33)
@@ -309,7 +341,7 @@ def test_bf16_frames_over_two_ranks_with_the_overlapped_gather(dev):
 
 
 @pytest.mark.parametrize("fault", [0, 2])
-def test_bf16_forward_in_a_captured_hip_graph(dev, fault):
+def test_bf16_forward_in_a_captured_hip_graph(dev, diag, fault):
     """the chain used to probe the device from inside the first bf16 forward (hipMalloc, a kernel on the null stream, a
     blocking copy) - impossible under stream capture.  Nothing is probed any more: the whole bf16 forward - chain launch, its memset,
     the six gated launches - is captured into ONE HIP graph and replayed; replays equal the eager bits, the status block counts every

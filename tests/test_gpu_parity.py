@@ -584,7 +584,7 @@ def test_paired_rows_are_refused_where_no_kernel_takes_them(dev):
 @pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
 def test_forward_is_the_same_bits_with_and_without_paired_rows(dev, mode):
     """m360_forward in the reduced-precision modes uses paired rows between the layers of both MLPs (full width: every layer on the
-    ring kernel); m360_set_paired_rows(0) keeps plain rows: the six outputs must not differ in a bit - 1000 rays x 32 samples, i.e.
+    ring kernel); M360_TUNE_PLAIN_ROWS (ops.set_paired_rows(False)) keeps plain rows: the six outputs must not differ in a bit - 1000 rays x 32 samples, i.e.
     125 full tiles + 0 ragged rows for the NeRF stage, and 999 x 33 with ragged rows in every layer."""
     from mipnerf360_amd import ops
     from mipnerf360_amd.model import mipNeRF360
@@ -603,38 +603,6 @@ def test_forward_is_the_same_bits_with_and_without_paired_rows(dev, mode):
                 ops.set_paired_rows(was)
         for a, b in zip(outs[True], outs[False]):
             assert torch.equal(a, b)
-
-
-@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
-def test_forward_is_the_same_bits_with_and_without_row_blocks(dev, mode):
-    """m360_set_row_blocks: the NeRF MLP of the reduced-precision modes run block of rows after block of rows (all eight layers on
-    the same ping / pong rows, temporal stores) against layer by layer: the six outputs must not differ in a bit.  Blocks of 1024 and
-    2304 rows on 200 rays x 33 samples (6600 rows: ragged rows in the last block, which is shorter than the others) and the
-    automatic block size on 1024 rays x 128 samples (131072 rows: two blocks of 49152 + one of 32768 in bf16)."""
-    from mipnerf360_amd import _lib, ops
-    from mipnerf360_amd.model import mipNeRF360
-    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(256, 1024, seed=6).items()}
-    for B, N, settings in ((200, 33, (1024, 2304)), (1024, 128, (-1,))):
-        model = mipNeRF360(num_samples=N, hidden_proposal=256, hidden_nerf=1024, mlp_dtype=mode, device=dev, randomized=False).eval()
-        model.load_state_dict(sd)
-        rays = dev_rays(synthetic.make_rays("garden", B, seed=4), dev)
-        was = ops.set_row_blocks(0)
-        try:
-            with torch.no_grad():
-                want = [o.clone() for o in model(rays)]
-            for rows in settings:
-                for streams in (2, 1):  # odd blocks on the library's second stream, or all on the caller's
-                    ops.set_row_blocks(rows)
-                    was_streams = _lib.lib().m360_set_row_block_streams(streams)
-                    try:
-                        with torch.no_grad():
-                            got = model(rays)
-                    finally:
-                        _lib.lib().m360_set_row_block_streams(was_streams)
-                    for a, b in zip(got, want):
-                        assert torch.equal(a, b), (rows, streams)
-        finally:
-            ops.set_row_blocks(was)
 
 
 @pytest.mark.parametrize("M,width,layers", [(32768, 1024, 6), (65536, 1024, 3), (32768, 1024, 1), (131072, 256, 2), (262144, 256, 5)])
@@ -666,9 +634,9 @@ def test_hidden_layer_chain_in_one_launch(dev, M, width, layers):
 
 @pytest.mark.parametrize("B,N", [(1024, 128), (300, 128), (1024, 33)])
 def test_forward_is_the_same_bits_with_and_without_the_hidden_chain(dev, B, N):
-    """m360_set_hidden_chain: the bf16 forward with the six hidden NeRF layers as one launch (default) against six launches - 131072 rows (all
+    """M360_TUNE_NO_HIDDEN_CHAIN (ops.set_hidden_chain): the bf16 forward with the six hidden NeRF layers as one launch (default) against six launches - 131072 rows (all
     in the chain), 38400 (32768 in the chain + 5632 layer by layer) and 33792 rows of 33 samples (ragged rows as well): not a bit may differ."""
-    from mipnerf360_amd import _lib
+    from mipnerf360_amd import ops
     from mipnerf360_amd.model import mipNeRF360
     sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(256, 1024, seed=8).items()}
     model = mipNeRF360(num_samples=N, hidden_proposal=256, hidden_nerf=1024, mlp_dtype="bf16", device=dev, randomized=False).eval()
@@ -676,13 +644,13 @@ def test_forward_is_the_same_bits_with_and_without_the_hidden_chain(dev, B, N):
     rays = dev_rays(synthetic.make_rays("garden", B, seed=5), dev)
     outs = {}
     for on in (1, 0):
-        was = _lib.lib().m360_set_hidden_chain(on)
+        was = ops.set_hidden_chain(bool(on))
         try:
             with torch.no_grad():
                 outs[on] = [o.clone() for o in model(rays)]
             assert model.chain_error() is False  # no workgroup of the chain gave up waiting (m360_forward_chain_error)
         finally:
-            _lib.lib().m360_set_hidden_chain(was)
+            ops.set_hidden_chain(was)
     for a, b in zip(outs[1], outs[0]):
         assert torch.equal(a, b)
 

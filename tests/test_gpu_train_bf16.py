@@ -312,19 +312,19 @@ def test_params_nan_flag_one_launch(dev):
 
 
 def test_backward_overlap_same_bits(dev):
-    """m360_set_backward_overlap: the ReLU mask of a layer's input gradient on the library's second stream beside the weight gradient (the
+    """m360_hyper_t.side (ops.set_backward_overlap): the ReLU mask of a layer's input gradient on a CALLER-OWNED second stream (m360_side_t) beside the weight gradient (the
     default; one striding workgroup per CU) against everything on the caller's stream - the same weight gradients bit for bit (bias gradients: the
     same sums in another order), NeRF and proposal update, at a size where the overlapped form runs (>= 32768 rows: 300 rays x 128 samples, ragged)."""
-    from mipnerf360_amd import _lib
+    from mipnerf360_amd import ops
     from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
     sd = synthetic.make_state_dict(64, 256, seed=21)
     rays = dev_rays(synthetic.make_rays("garden", 300, seed=22), dev)
     pixels = torch.rand(300, 3, generator=torch.Generator().manual_seed(3)).to(dev)
     out = {}
-    was = _lib.lib().m360_set_backward_overlap(1)
+    was = ops.set_backward_overlap(True)
     try:
         for mode in (1, 0, 1):
-            _lib.lib().m360_set_backward_overlap(mode)
+            ops.set_backward_overlap(bool(mode))
             m = _bf16_model(sd, dev, 128, 64, 256, True)
             t_hat, w_hat = m.prop_net.forward(rays)
             rgb, dist, acc, t, fw, sv = m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
@@ -340,7 +340,7 @@ def test_backward_overlap_same_bits(dev):
             out[mode] = g
             del m
     finally:
-        _lib.lib().m360_set_backward_overlap(was)
+        ops.set_backward_overlap(was)
     # weights: the same bits.  Bias gradients of the layers whose dz came out of a mask pass: in the overlapped form they are the column sums the
     # (throttled) mask kernel forms on its way, on one stream the weight-gradient kernel's ones-product - the same fp32 sums in another order
     diff = [n for n in out[0] if not n.endswith(".bias") and not torch.equal(out[0][n], out[1][n])]
@@ -351,3 +351,61 @@ def test_backward_overlap_same_bits(dev):
             assert float((out[0][n] - out[1][n]).abs().max()) <= 2e-5 * scale + 1e-30, (n, float((out[0][n] - out[1][n]).abs().max()), scale)
     assert sum(int(not torch.equal(out[0][n], out[1][n])) for n in out[0] if n.endswith(".bias")) > 0, "the mask kernel's column sums were not used"
     assert float(max(v.abs().max() for v in out[1].values())) > 0
+
+
+def test_two_threads_train_two_models_on_two_streams(dev):
+    """libm360 keeps no state of its own - no switch, no stream, no event (0.2.0).  Two host threads each train their own
+    bf16 model on their own stream (own workspace, own m360_side_t for the overlapped backward), one of them with per-call switches flipped
+    (plain rows, no chain, 8-wave weight gradient) that the other must never see: every thread's gradients are the bits a serial run of
+    the same thread's configuration gives, step after step."""
+    import threading
+
+    from mipnerf360_amd import ops
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf
+    sds = [synthetic.make_state_dict(64, 256, seed=31), synthetic.make_state_dict(64, 256, seed=32)]
+    rays = [dev_rays(synthetic.make_rays("garden", 300, seed=40 + i), dev) for i in range(2)]
+    pixels = [torch.rand(300, 3, generator=torch.Generator().manual_seed(50 + i)).to(dev) for i in range(2)]
+
+    def configure(i):
+        if i == 1:  # thread-local: the other thread keeps the defaults
+            ops.set_paired_rows(False), ops.set_hidden_chain(False), ops.set_wgrad_bf16_form(0)
+
+    def steps(i, stream, n, out):
+        try:
+            configure(i)
+            with torch.cuda.stream(stream):
+                for _ in range(n):
+                    m = _bf16_model(sds[i], dev, 128, 64, 256, True)
+                    t_hat, w_hat = m.prop_net.forward(rays[i])
+                    rgb, dist, acc, t, fw, sv = m.nerf_net.forward(rays[i], t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+                    ln, _ = Loss_nerf(input=rgb, target=pixels[i])
+                    (ln + 0.01 * Loss_dist(s_vals=sv, weights=fw)).backward()
+                    stream.synchronize()
+                    out.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        except BaseException as e:  # noqa: BLE001  (reported by the main thread)
+            out.append(e)
+
+    def run_thread(i, stream, n):
+        out = []
+        th = threading.Thread(target=steps, args=(i, stream, n, out))
+        return th, out
+
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    serial = []
+    for i in range(2):  # each configuration alone, in a thread of its own (thread-local switches start from the defaults)
+        th, out = run_thread(i, streams[i], 1)
+        th.start(), th.join()
+        assert out and not isinstance(out[0], BaseException), out
+        serial.append(out[0])
+    assert ops.tuning_bits() == 0  # nothing leaked into this thread
+    pairs = [run_thread(i, streams[i], 4) for i in range(2)]
+    for th, _ in pairs:
+        th.start()
+    for th, _ in pairs:
+        th.join()
+    for i, (_, out) in enumerate(pairs):
+        assert len(out) == 4 and not any(isinstance(o, BaseException) for o in out), out
+        for step in out:
+            assert step.keys() == serial[i].keys()
+            for k in step:
+                assert torch.equal(step[k], serial[i][k]), (i, k)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What the safety of the bf16 mode's layer chain costs (round 5): ms per forward at 4096 x 128 (and 8192 x 256 with --c5), alternating,
- (a) chain + six gated re-run launches behind it (the product), (b) chain alone, unchecked (m360_set_chain_debug(fault = -1): A/B only),
+ (a) chain + six gated re-run launches behind it (the product), (b) chain alone, unchecked (M360_TUNE_CHAIN_UNGATED, diagnostics build: run with M360_LIB=mipnerf360_amd/libm360_diag.so; A/B only),
  (c) chain through hipLaunchCooperativeKernel + gated launches, (d) no chain: six launches.  No event recorder attached."""
 import argparse
 import json
@@ -33,7 +33,7 @@ def run(cfg):
     fault, coop, chain = cfg
     ops.set_chain_debug(0, fault)
     ops.set_chain_cooperative(bool(coop))
-    was = _lib.lib().m360_set_hidden_chain(chain)
+    was = ops.set_hidden_chain(bool(chain))
     try:
         with torch.no_grad():
             for _ in range(3):
@@ -45,7 +45,7 @@ def run(cfg):
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / a.iters * 1e3
     finally:
-        _lib.lib().m360_set_hidden_chain(was)
+        ops.set_hidden_chain(was)
         ops.set_chain_debug(0, 0)
         ops.set_chain_cooperative(False)
     return ms, [o.clone() for o in out]

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 from mipnerf360_amd import _lib, ops  # noqa: E402
 
 if os.environ.get("M360_WGRAD_FORM"):  # 0: the 8-wave kernel (the one the M360_TN16_ABL ablations of the diagnostics build act on), 1: the one-wave form
-    _lib.lib().m360_set_wgrad_bf16_form(int(os.environ["M360_WGRAD_FORM"]))
+    ops.set_wgrad_bf16_form(int(os.environ["M360_WGRAD_FORM"]))
 
 dev = torch.device("cuda:0")
 for M in ((524288,) if os.environ.get("M360_TN16_ABL") else (16384, 32768, 65536, 131072, 524288)):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""m360_linear_wgrad_bf16: the one-wave form (m360_set_wgrad_bf16_form(1)) against the 8-wave form (0) and fp64, where they differ."""
+"""m360_linear_wgrad_bf16: the one-wave form (default) against the 8-wave form (0) and fp64, where they differ."""
 import os
 import sys
 
@@ -16,7 +16,7 @@ for M, n, k in ((32832, 256, 1024), (4096, 1024, 1024), (524288, 1024, 1024), (3
     ref = dz.double().t() @ x.double() if M <= 65536 else None
     out = {}
     for form in (0, 1):
-        _lib.lib().m360_set_wgrad_bf16_form(form)
+        ops.set_wgrad_bf16_form(form)
         gw, gb = ops.linear_wgrad_bf16(dz, x)
         gw2, gb2 = ops.linear_wgrad_bf16(dz, x)
         out[form] = (gw, gb)
@@ -29,4 +29,4 @@ for M, n, k in ((32832, 256, 1024), (4096, 1024, 1024), (524288, 1024, 1024), (3
     if bad.shape[0]:
         rows, cols = bad[:, 0], bad[:, 1]
         print("   bad rows: min", int(rows.min()), "max", int(rows.max()), "distinct", len(set(rows.tolist())), "| cols: min", int(cols.min()), "max", int(cols.max()), "distinct", len(set(cols.tolist())))
-_lib.lib().m360_set_wgrad_bf16_form(1)
+ops.set_wgrad_bf16_form(1)

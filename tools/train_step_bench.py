@@ -41,11 +41,11 @@ def main():
     ap.add_argument("--gemm-only", action="store_true")
     ap.add_argument("--mlp-dtype", default="fp32", choices=("fp32", "bf16"), help="precision the model trains in (round 5: bf16)")
     ap.add_argument("--no-gemms", action="store_true", help="skip the stand-alone gradient GEMMs (kernel profiles of the iteration alone)")
-    ap.add_argument("--overlap", type=int, default=None, help="m360_set_backward_overlap (bf16: ReLU mask beside the weight gradient); default: the library's")
+    ap.add_argument("--overlap", type=int, default=None, help="bf16: 1 = the ReLU mask on a second stream (m360_side_t) beside the weight gradient (default), 0 = one stream")
     a = ap.parse_args()
     if a.overlap is not None:
-        from mipnerf360_amd import _lib
-        _lib.lib().m360_set_backward_overlap(a.overlap)
+        from mipnerf360_amd import ops as _ops
+        _ops.set_backward_overlap(bool(a.overlap))
     dev = torch.device("cuda:0")
     out = {"rays": a.rays, "samples": a.samples, "mlp_dtype": a.mlp_dtype}
     if a.overlap is not None:
