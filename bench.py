@@ -225,6 +225,36 @@ def cpu_baseline(sd_np, rays_np, n_rays, samples):
 
 
 # ------------------------------------------------------------------------------------------------- rank process
+def rccl_log_summary(path):
+    """What RCCL itself logged while it built this rank's communicator (NCCL_DEBUG=INFO, subsystems INIT + GRAPH): the rank count it
+    printed, its channel count and how many peer connections went over which transport ("via P2P/IPC" = xGMI / PCIe peer access,
+    "via SHM", "via NET/...").  Informational, never fatal: {} when there is no log of ours or nothing in it parses."""
+    import re
+    out = {}
+    try:
+        if not path or not os.path.exists(path):
+            return out
+        text = open(path, errors="replace").read()
+        via = {}
+        for m in re.finditer(r"\bvia ([A-Za-z0-9_/]+)", text):
+            via[m.group(1)] = via.get(m.group(1), 0) + 1
+        if via:
+            out["transports"] = via
+        m = re.search(r"nranks (\d+)", text)
+        if m:
+            out["log_nranks"] = int(m.group(1))
+        ch = re.findall(r"(\d+) coll channels", text)
+        if ch:
+            out["coll_channels"] = int(ch[-1])
+        m = re.search(r"(RCCL version[^\n]*|NCCL version[^\n]*)", text)
+        if m:
+            out["log_version"] = m.group(1).strip()[:120]
+        out["log_lines"] = text.count("\n")
+    except Exception as e:  # noqa: BLE001
+        out = {"log_error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
 class Comm:
     """The few collectives bench.py itself needs (barrier, max / gather of timings), on RCCL or - diagnostics - gloo."""
 
@@ -235,7 +265,13 @@ class Comm:
         self.info = None
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            log = None
             if backend == "nccl":
+                # RCCL's own account of what it set up (ranks, channels, the transport of every peer connection) goes into the line: its
+                # INIT-level log is written to a file of ours unless the caller already directs NCCL_DEBUG somewhere
+                if "NCCL_DEBUG" not in os.environ and "NCCL_DEBUG_FILE" not in os.environ:
+                    log = f"/tmp/m360_rccl_rank{rank}_{os.getpid()}.log"
+                    os.environ["NCCL_DEBUG"], os.environ["NCCL_DEBUG_SUBSYS"], os.environ["NCCL_DEBUG_FILE"] = "INFO", "INIT,GRAPH", log
                 dist.init_process_group("nccl", device_id=dev)
             else:
                 dist.init_process_group("gloo")
@@ -244,6 +280,8 @@ class Comm:
             self.info = {"backend": backend, "ranks": int(ones.item())}
             if backend == "nccl":
                 self.info["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                torch.cuda.synchronize()
+                self.info.update(rccl_log_summary(log))
             else:
                 self.info["note"] = "diagnostics backend: collectives staged through the host, NOT a scaling measurement"
 
@@ -267,6 +305,13 @@ class Comm:
             return v
         t = self.torch.tensor([v], dtype=self.torch.float64, device=self.cdev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def min(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return float(t.item())
 
     def gather_floats(self, vals):
@@ -391,7 +436,8 @@ def chain_delta(model, before=None):
     now = model.chain_status()
     if before is None:
         return now
-    d = {k: now[k] - before.get(k, 0) for k in ("launches", "recoveries", "timeouts", "xcc_mismatch")}
+    # (the counters live in the stream's scratch buffer and restart at 0 when a larger one replaces it: a delta is never negative)
+    d = {k: (now[k] - before.get(k, 0) if now[k] >= before.get(k, 0) else now[k]) for k in ("launches", "recoveries", "timeouts", "xcc_mismatch")}
     d["chain_error"] = d["recoveries"] > 0
     return d
 
@@ -827,8 +873,12 @@ def worker(args):
         # BASELINE configs[2] as written ("hierarchical 64+128 samples") beside the headline, and configs[3] for N > 1: the
         # same processes render one frame together (strong scaling).  64 proposal + 128 NeRF samples per ray is the build's
         # `num_samples_fine` extension (the reference draws as many NeRF as proposal samples, intern/ray.py:147).
-        # (an extra leg: the headline above is complete - an error here, e.g. in the first RCCL all-gather a multi-GPU node ever runs for
-        # this build, is reported in the line instead of costing the run its result)
+        # An extra leg: the headline above is complete.  What CAN fail on one rank alone - building the frame model, its buffers, the event
+        # recorder (out of memory) - is tried first, and the ranks AGREE on the outcome (one MIN all-reduce that every rank takes part in,
+        # whatever happened to it): all render or none does, nobody is left waiting in a collective for a rank that gave up.
+        # From there on an exception with N > 1 is not caught: it ends this process, the launcher ends the others, the run exits non-zero.
+        fmodel = fprof = None
+        setup_error = None
         try:
             fw, fh = frame_size(args)
             fmodel = mipNeRF360(randomized=False, num_samples=64, num_samples_fine=128, hidden_proposal=HP, hidden_nerf=HN,
@@ -836,6 +886,13 @@ def worker(args):
             fmodel.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
             fmodel.eval()
             fprof = _lib.Prof(40 * ((fw * fh + FRAME_CHUNKS - 1) // FRAME_CHUNKS // world + 2) * args.frame_steps + 64)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            setup_error = f"{type(e).__name__}: {e}"[:500]
+        all_ok = comm.min(0.0 if setup_error else 1.0) > 0.5
+
+        def frame_leg():
             fmodel.set_prof(fprof)
             fr = frame_pipeline(fmodel, comm, args.frame_steps, 0, overlap=False, width=fw, height=fh)
             fmodel.set_prof(None)
@@ -848,13 +905,21 @@ def worker(args):
             fr["roofline"] = None if froof is None else {k: froof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches")}
             fr["workload"] = (f"DIAGNOSTIC frame size {fw}x{fh} instead of 1237x822; " if args.frame_size else "") + \
                 CONFIGS["c4"][4].format(mlp=MLP_NAMES[mlp_dtype]).replace("x 128 samples/ray", "x (64 proposal + 128 NeRF) samples/ray")
-            line["strong_scaling_frame"] = fr
-            del fmodel
-            torch.cuda.empty_cache()
-        except Exception as e:  # noqa: BLE001
-            import traceback
-            traceback.print_exc()
-            line["strong_scaling_frame"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+            return fr
+
+        if not all_ok:
+            line["strong_scaling_frame"] = {"error": setup_error or "another rank could not set the frame leg up (see its stderr)"}
+        elif world > 1:
+            line["strong_scaling_frame"] = frame_leg()  # collectives inside: a failure ends the run (non-zero exit), it is not papered over
+        else:
+            try:
+                line["strong_scaling_frame"] = frame_leg()
+            except Exception as e:  # noqa: BLE001  (one rank: nobody waits for us)
+                import traceback
+                traceback.print_exc()
+                line["strong_scaling_frame"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        del fmodel, fprof
+        torch.cuda.empty_cache()
 
     if rank != 0:
         comm.close()

@@ -94,6 +94,19 @@ class _PackedMLP:
     def invalidate(self) -> None:
         self.key = None
 
+    def check_nan_pending(self) -> None:
+        """Training mode: look at the NaN-parameter flag the last re-pack sent to pinned memory (bf16 modes).  Called by the next re-pack,
+        by the backward of the forward that packed (before its gradients are handed out: no update is ever made from a NaN-parameter
+        forward) and by `flush_nan_check()`.  The copy was queued before the forward's kernels, so waiting for it stalls nothing."""
+        pending = getattr(self, "_nan_pending", None)
+        if pending is None:
+            return
+        self._nan_pending = None
+        pending[1].synchronize()
+        if int(pending[0][0]) != 0:
+            self.key = None
+            raise RuntimeError(pending[2])
+
     def refresh(self, hidden_layers, heads, bf16: int = 0, always: bool = False, defer_nan: bool = False) -> "_PackedMLP":
         """`always`: re-pack even when the (data_ptr, version) key is unchanged.  Writes through `.data`
         (`p.data.mul_()`, EMA swaps, weight clamping) do not bump a tensor's version counter, so in training mode
@@ -125,17 +138,13 @@ class _PackedMLP:
             flag = ops.params_nan_flag(params)  # one launch over all tensors
             msg = ("mlp_dtype='bf16' / 'bf16x3': the parameters hold NaN values; the bf16 matrix pipe cannot propagate them "
                    "the way nn.ReLU does (the reference renders NaN) - use mlp_dtype='fp32' for this checkpoint")
-            if always and defer_nan:
-                pending = getattr(self, "_nan_pending", None)
+            if always:  # training mode (defer_nan or not: the no-grad forwards of a training step must not stall it either)
+                self.check_nan_pending()  # the previous re-pack's flag: arrived long ago
                 host = torch.empty(1, dtype=torch.int32, pin_memory=True)
                 host.copy_(flag, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(first.weight.device))
-                self._nan_pending = (host, ev)
-                if pending is not None:
-                    pending[1].synchronize()
-                    if int(pending[0][0]) != 0:
-                        raise RuntimeError(msg)
+                self._nan_pending = (host, ev, msg)
             elif int(flag.item()) != 0:
                 raise RuntimeError(msg)
         self.w, self.b = [], []
@@ -202,14 +211,16 @@ def _hyper_struct(num_samples, min_deg, max_deg, white_bkgd=False, density_bias=
     return h
 
 
-def _set_randomized(hyper, device, jitter: bool, cdf: bool):
+def _set_randomized(hyper, device, jitter: bool, cdf: bool, state=None):
     """randomized=True: the kernels draw their uniforms themselves (m360_hyper_t.randomized / rng_seed / rng_offset) from torch's
-    device generator state - no [B, N+1] torch.rand tensors (the reference's intern/ray.py:31,104).  Returns (seed, offset) or None."""
+    device generator state - no [B, N+1] torch.rand tensors (the reference's intern/ray.py:31,104).  `state`: a (seed, offset) already
+    drawn for this forward (the outer forward hands ONE to both stages, so that the staged and the fused path draw the same samples).
+    Returns (seed, offset) or None."""
     bits = (1 if jitter else 0) | (2 if cdf else 0)
     hyper.randomized = bits
     if not bits:
         return None
-    hyper.rng_seed, hyper.rng_offset = ops.philox_state(device)
+    hyper.rng_seed, hyper.rng_offset = state if state is not None else ops.philox_state(device)
     return hyper.rng_seed, hyper.rng_offset
 
 
@@ -317,6 +328,7 @@ class _TrainCtx:
             grads += [ghw[row:row + h.out_features, :h.in_features], ghb[row:row + h.out_features]]
             row += h.out_features
         self.tape = self.packed_keep = None  # one backward per forward, like autograd's freed buffers
+        packed.check_nan_pending()  # bf16 modes: this forward's parameters held a NaN -> raise instead of handing gradients to the optimizer
         return [g.contiguous() for g in grads]
 
 
@@ -418,7 +430,7 @@ class prop_net(nn.Module):
         w_hat = torch.empty(B, N, device=dev)
         # randomized: drawn inside the kernels (stage_prologue_kernel / sample_t_kernel) unless uniforms are handed in for replay
         t_rand = _replay_uniforms(self, (B, N + 1), dev)
-        self.last_rng = _set_randomized(hyper, dev, bool(self.randomized) and t_rand is None, False)
+        self.last_rng = _set_randomized(hyper, dev, bool(self.randomized) and t_rand is None, False, getattr(self, "_rng_state", None))
         ws = _ws_for(B, N, mstruct, dev)
         if train:
             tc = _TrainCtx(self, 0, keep, rstruct, B, N, hyper, packed, mstruct)
@@ -519,7 +531,7 @@ class nerf_net(nn.Module):
         ostruct = _outputs_struct(outs)
         # randomized: drawn inside the resample kernel unless uniforms are handed in for replay
         u_rand = _replay_uniforms(self, (B, Nf + 1), dev)
-        self.last_rng = _set_randomized(hyper, dev, False, bool(self.randomized) and u_rand is None)
+        self.last_rng = _set_randomized(hyper, dev, False, bool(self.randomized) and u_rand is None, getattr(self, "_rng_state", None))
         ws = _ws_for(B, max(N, Nf), mstruct, dev)
         if train:
             tc = _TrainCtx(self, 1, keep, rstruct, B, Nf, hyper, self._packed, mstruct)
@@ -617,6 +629,13 @@ class mipNeRF360(nn.Module):
         self.prop_net.invalidate_packed()
         self.nerf_net.invalidate_packed()
 
+    def flush_nan_check(self) -> None:
+        """bf16 modes, training: raise now if the parameters of the LAST forward of either sub-net held a NaN (the flag travels to pinned
+        memory beside each training-mode forward and is otherwise looked at by the next forward or by the backward).  For the end of a
+        training loop, or before a checkpoint is written."""
+        self.prop_net._packed.check_nan_pending()
+        self.nerf_net._packed.check_nan_pending()
+
     # ------------------------------------------------------------------ fused two-stage forward
     def _forward_fused(self, rays, rgb=None, distance=None, acc=None, stash=True, norm_group_rays=0):
         rstruct, keep, B = _rays_struct(rays)
@@ -666,8 +685,17 @@ class mipNeRF360(nn.Module):
         staged = staged or getattr(self.prop_net, "replay_uniforms", None) is not None or getattr(self.nerf_net, "replay_uniforms", None) is not None
         if not _wants_grad(self) and not staged:  # randomized or not: the kernels draw their own uniforms (round 5)
             return self._forward_fused(rays)
-        t_hat, w_hat = self.prop_net.forward(rays)
-        rgb, dist, acc, _, _, _ = self.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        # ONE generator state for both stages, like the fused path (streams 0 / 1 of the same counter block): the same seed gives the same
+        # samples whichever path a forward takes
+        draws = (bool(self.prop_net.randomized) and self.prop_net.replay_uniforms is None) or (bool(self.nerf_net.randomized) and self.nerf_net.replay_uniforms is None)
+        state = ops.philox_state(_rays_struct(rays)[1][0].device) if draws else None
+        self.prop_net._rng_state = self.nerf_net._rng_state = state
+        try:
+            t_hat, w_hat = self.prop_net.forward(rays)
+            rgb, dist, acc, _, _, _ = self.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        finally:
+            self.prop_net._rng_state = self.nerf_net._rng_state = None
+        self.last_rng = state
         return rgb, dist, acc
 
     # ------------------------------------------------------------------ one batch sharded over ranks

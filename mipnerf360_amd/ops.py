@@ -220,9 +220,18 @@ def philox_state(device) -> Tuple[int, int]:
     """(seed, offset) for one randomized libm360 call, taken from torch's device generator - and the generator advanced by 4, so
     that no later torch kernel (nor a later call of ours) reuses the counters (include/m360.h: m360_hyper_t.rng_offset).  Same
     `torch.manual_seed` -> same numbers, like torch.rand.  The kernels draw their uniforms themselves (Philox4x32-10): no
-    [B, N + 1] tensor of torch.rand is materialised (the reference's intern/ray.py:31,104)."""
+    [B, N + 1] tensor of torch.rand is materialised (the reference's intern/ray.py:31,104).
+    Which counters a call uses depends on how many randomized calls came before it: `mipNeRF360.forward` draws ONE state for both of its
+    stages (fused or staged: the same samples for the same seed), `prop_net.forward` and `nerf_net.forward` called on their own (train.py)
+    draw one each.  Always torch's DEFAULT generator of the device (what `torch.manual_seed` / `torch.random.fork_rng(devices=[i])`
+    govern); a user-made torch.Generator cannot be handed in - replay recorded uniforms through `module.replay_uniforms` instead.
+    Not under stream capture: (seed, offset) are host values a graph would bake in, every replay would draw the same numbers."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("randomized=True inside a HIP-graph capture: the Philox (seed, offset) of the call would be baked into the graph and every "
+                           "replay would draw the same uniforms - capture a deterministic model, or hand the draws in as tensors "
+                           "(prop_net.replay_uniforms / nerf_net.replay_uniforms, refilled between replays)")
     gen = torch.cuda.default_generators[idx]
     seed, off = int(gen.initial_seed()), int(gen.get_offset())
     gen.set_offset(off + 4)

@@ -283,3 +283,30 @@ def test_g22_randomized_stage_forwards_vs_reference(dev, tag, train):
     with torch.no_grad():
         m(rays)
     assert m.last_rng == (1, 0)
+
+
+def test_same_seed_same_samples_fused_or_staged(dev):
+    """the fused forward (no grad) used one generator offset, the staged one (grad enabled) two, so a seed gave different
+    samples depending on the path.  The outer forward now draws ONE state for both stages either way: same seed -> same bits, and the
+    generator moves on by one counter block per forward.  Under a stream capture a randomized forward refuses (its offset would be baked in)."""
+    m, _ = _model(dev, 24, True)
+    rays = dev_rays(synthetic.make_rays("lego", 96, seed=12), dev)
+    torch.manual_seed(99)
+    with torch.no_grad():
+        fused = [o.clone() for o in m(rays)]
+    assert m.last_rng == (99, 0)
+    torch.manual_seed(99)
+    staged = m(rays)  # grad enabled, trainable parameters: both stages as tape-keeping autograd functions
+    assert staged[0].requires_grad and m.last_rng == (99, 0) and m.prop_net.last_rng == (99, 0) and m.nerf_net.last_rng == (99, 0)
+    for a, b in zip(fused, staged):
+        assert torch.equal(a, b.detach())
+    with torch.no_grad():
+        m(rays)
+    assert m.last_rng == (99, 1)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="baked into the graph"):
+        with torch.no_grad(), torch.cuda.graph(g, stream=side):
+            m(rays)
+    torch.cuda.synchronize()

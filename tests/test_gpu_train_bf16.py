@@ -295,6 +295,31 @@ def test_nan_parameter_is_refused_in_training_mode_one_forward_late(dev):
             m(rays)
 
 
+def test_nan_parameter_never_reaches_the_optimizer(dev):
+    """the FIRST tape-keeping forward on NaN parameters used to hand finite-looking gradients to the optimizer (the bf16
+    ReLU drops the NaN) - the flag was only read by the next forward, and the last step's never.  Now the backward of that very forward
+    raises before returning gradients, `flush_nan_check()` reads the flag of a forward nothing follows, and the no-grad forwards of a
+    training step use the deferred flag too (no host sync in the step)."""
+    sd = synthetic.make_state_dict(64, 128, seed=3)
+    rays = dev_rays(synthetic.make_rays("lego", 32, seed=4), dev)
+    m = _bf16_model(sd, dev, 16, 64, 128, False)
+    with torch.no_grad():
+        m.prop_net.model[2].weight[1, 1] = float("nan")
+    t_hat, w_hat = m.prop_net.forward(rays)       # first forward ever: nothing before it could have looked
+    with pytest.raises(RuntimeError, match="parameters hold NaN"):
+        w_hat.sum().backward()
+    assert all(p.grad is None for p in m.prop_net.parameters())
+    m2 = _bf16_model(sd, dev, 16, 64, 128, False)
+    with torch.no_grad():
+        m2.nerf_net.final_color[0].bias[0] = float("nan")
+        m2.prop_net.forward(rays), m2.flush_nan_check()   # clean sub-net: nothing to report
+        t_hat, w_hat = m2.prop_net.forward(rays)
+        m2.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)   # training mode, no grad: deferred flag, no sync
+    with pytest.raises(RuntimeError, match="parameters hold NaN"):
+        m2.flush_nan_check()
+    m2.flush_nan_check()  # reported once
+
+
 def test_params_nan_flag_one_launch(dev):
     """m360_params_nan_flag: one launch over a parameter set (more than 32 tensors: two), NaNs of either sign, at the first / last element."""
     from mipnerf360_amd import ops

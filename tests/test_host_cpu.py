@@ -355,6 +355,80 @@ def test_sharded_batch_global_norm_world2_gloo(tmp_path):
     assert res.stdout.count("OK") == 2
 
 
+GLOO_C5_SPLIT_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from mipnerf360_amd.distributed import forward_sharded
+from mipnerf360_amd import synthetic
+from oracle import ref_path as O   # checker only (tests/): stands in for the HIP stages, which need a GPU
+
+torch.set_num_threads(1)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+per, N = 1024, 256                      # BASELINE configs[4]: 8192 rays x 256 samples over 8 ranks, bf16 MLP
+sd = O.to_torch_state_dict(synthetic.make_state_dict(32, 32, seed=1))
+hp = O.Hyper(num_samples=N, mlp_bf16=1)
+
+class OracleStages:
+    def sharded_sample(self, rays):
+        return O.sample_t(rays.near, rays.far, hp.num_samples).expand(rays.origins.shape[0], -1).contiguous()
+    def sharded_sumsq(self, rays, t):
+        return O.mean_sumsq(t, rays.directions, rays.radii)
+    def sharded_prop(self, rays, t, norm):
+        return O.prop_forward_from_t(rays, sd, hp, t, norm)
+    def sharded_nerf(self, rays, t_new, norm):
+        return O.nerf_forward_from_t(rays, sd, hp, t_new, norm)
+
+r = synthetic.make_rays("garden", per * world, seed=2)
+r["origins"] = r["origins"] * 3.0
+whole = O.rays_from_numpy(r)
+mine = O.Rays(*[f[rank * per:(rank + 1) * per] for f in whole])
+with torch.no_grad():
+    got = forward_sharded(OracleStages(), mine)
+    # the whole 8192-ray batch on ONE rank (what a single device renders), handed to the others
+    ref = [torch.empty(per * world, 3), torch.empty(per * world), torch.empty(per * world)]
+    if rank == 0:
+        torch.set_num_threads(8)
+        ref = [t.contiguous() for t in O.forward(whole, sd, hp)]
+        torch.set_num_threads(1)
+    for t in ref:
+        dist.broadcast(t, src=0)
+    alone = O.forward(mine, sd, hp) if rank == world - 1 else None
+    # (and in fp32 arithmetic, where what the norm is worth can be told from rounding noise)
+    hp32 = O.Hyper(num_samples=N)
+    alone32 = O.forward(mine, sd, hp32) if rank == world - 1 else None
+sl = slice(rank * per, (rank + 1) * per)
+# one 8-byte all-reduce per stage rebuilds the 8192-ray norm up to the summation order of 8 partial sums; the bf16 emulation rounds
+# activations to 8 bits, so an ulp of the norm may flip a rounding somewhere: 5e-4 on colours in [0, 1], far below what the norm is worth
+for g, w, tol in zip(got, ref, (5e-4, 5e-4, 5e-4)):
+    err = float((g - w[sl]).abs().max() / max(1.0, float(w[sl].abs().max())))
+    assert err <= tol, ("sharded batch != whole batch", rank, err)
+if alone is not None:
+    # the shard rendered with its OWN 1024-ray norm is another picture: in fp32 the difference is far above rounding ...
+    with torch.no_grad():
+        whole32 = O.forward(whole, sd, hp32) if rank == world - 1 else None
+    gap32 = float((alone32[0] - whole32[0][sl]).abs().max())
+    assert gap32 > 1e-4, ("the global norm must matter in this test", gap32)
+    print("norm gap fp32", gap32, "bf16", float((alone[0] - ref[0][sl]).abs().max()), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_sharded_batch_c5_split_world8_gloo(tmp_path):
+    """BASELINE configs[4] as it shards - 8192 rays x 256 samples as 8 x 1024 over a world of 8 (gloo, the oracle's
+    bf16-emulating stages standing in for the HIP ones): every rank's rows equal those rows of the single-device 8192-ray forward."""
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_C5_SPLIT_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29583", str(script), ROOT]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert res.stdout.count("OK") == 8
+
+
 GLOO_FRAME_WORKER = r"""
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
