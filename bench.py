@@ -354,19 +354,22 @@ def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
                             "Infinity-Cache hits included, so W re-streamed per tile counts; algorithmic bytes are 4.30 GB")
         else:
             traffic_note = "profiles/traffic.json was measured on different kernel sources (stale): not reported"
-    elif os.path.exists(tpath) and bf16 and not x3 and config_name == "c2":
-        tb = json.load(open(tpath)).get("bf16_ring_kernel")
+    elif os.path.exists(tpath) and bf16 and config_name in ("c2", "c5"):
+        # the reduced-precision workloads, each with its own counter passes (tools/gpu_session.sh pmc16): c2_bf16 (legacy key bf16_ring_kernel),
+        # c5_bf16 (configs[4]'s per-GPU shape), c2_bf16x3
+        tj = json.load(open(tpath))
+        key = f"{config_name}_{'bf16x3' if x3 else 'bf16'}"
+        tb = (tj.get("by_workload") or {}).get(key) or (tj.get("bf16_ring_kernel") if key == "c2_bf16" else None)
         if tb and tb.get("kernel_source_sha256") == kernel_source_sha(TRAFFIC_SOURCES_BF16):
             traffic = tb.get("bytes_per_launch")
-            if tb.get("layers_per_launch", 1) != nlay:
+            if tb.get("layers_per_launch", 1) != nlay or tb.get("rows", rows) != rows:
                 traffic = None
             traffic_note = ("fabric-side counter bytes per launch (FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, gfx950 corrections); "
-                            + ("algorithmic bytes of the six-layer launch are 2.16 GB (rows in, rows out, six weight matrices); the five hidden "
+                            + ("the algorithmic bytes of the six-layer launch are rows in, rows out and six weight matrices; the five hidden "
                                "activations in between are counted here whenever they cross the fabric (Infinity-Cache hits included)" if nlay == 6 else
-                               "algorithmic bytes are 2.15 GB (the activation tile is read by the 4 column tiles of an XCD: L2 hits are not counted, "
-                               "Infinity-Cache hits are)"))
+                               "the activation tile is read by the 4 column tiles of an XCD: L2 hits are not counted, Infinity-Cache hits are"))
         elif tb:
-            traffic_note = "profiles/traffic.json (bf16_ring_kernel) was measured on different kernel sources (stale): not reported"
+            traffic_note = f"profiles/traffic.json ({key}) was measured on different kernel sources (stale): not reported"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     kname = ("linear_bf16_w16_kernel<X3> (bf16x3: 3 MFMA passes per product)" if x3 else "linear_bf16_w16_kernel") if bf16 else "linear_f32_hd_kernel"
     shape = "six 1024x1024 layers in one launch (m360_mlp_chain_bf16)" if nlay == 6 else "1024x1024 layer"
@@ -592,6 +595,7 @@ def named_workloads(sd_np, dev, _lib):
                      "roofline": None if roof is None else {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "traffic", "algorithmic_bytes", "traffic_note") if k in roof}}
         if chain0 is not None:
             out[name]["chain"] = chain_delta(m, chain0)
+        out[name]["hbm_kernels"] = hbm_kernels_from_records(recs, n_rays, samples, mlp_dtype != "fp32", _lib, x3)
         del m, rays
         torch.cuda.empty_cache()
 
@@ -654,9 +658,10 @@ def named_workloads(sd_np, dev, _lib):
             wt = ops.pack_linear_bf16_transposed(torch.randn(HN, HN, device=dev) / 32)
             dx = torch.empty(M, HN, device=dev, dtype=torch.bfloat16)
             wgrad_ms = timed(lambda: ops.linear_wgrad_bf16(dz, x), 5)
-            dgrad_ms = timed(lambda: ops.linear_dgrad_bf16(dz, wt, x, out=dx), 5)
+            dgrad_ms = timed(lambda: ops.linear_dgrad_bf16(dz, wt, None, out=dx), 5)        # the GEMM alone (MFMA-bound)
+            dgrad_serial_ms = timed(lambda: ops.linear_dgrad_bf16(dz, wt, x, out=dx), 5)    # + the ReLU mask pass behind it, one stream, full rate
             peak, wk, dk = PEAK_BF16_MFMA_TFLOPS, "tn16w::linear_tn_bf16_w_kernel (one wave per SIMD, 128 x 128 wave tiles) + tn16_reduce_kernel (dW = dZ^T X on v_mfma_f32_16x16x32_bf16, operands transposed by ds_read_b64_tr_b16; bias gradient on the matrix pipe)", \
-                "linear_bf16_w16_kernel on the transposed bf16 packing + relu_mask_bf16_kernel (dX = (dZ W) * [a > 0])"
+                "linear_bf16_w16_kernel on the transposed bf16 packing (dX = dZ W; the ReLU mask is its own HBM-bound kernel: relu_mask_1024)"
         else:
             dz = torch.randn(M, HN, device=dev)
             x = torch.relu(torch.randn(M, HN, device=dev))
@@ -678,6 +683,15 @@ def named_workloads(sd_np, dev, _lib):
             "nerf_update_tflops": round(M * (423424 + 3 * 14807040) / nerf_ms / 1e9, 1),
             "wgrad_1024x1024": {"ms": round(wgrad_ms, 3), "tflops": round(flops / wgrad_ms / 1e9, 1), "frac": round(flops / wgrad_ms / 1e9 / peak, 4), "kernel": wk},
             "dgrad_1024x1024": {"ms": round(dgrad_ms, 3), "tflops": round(flops / dgrad_ms / 1e9, 1), "frac": round(flops / dgrad_ms / 1e9 / peak, 4), "kernel": dk},
+            **({"relu_mask_1024": {
+                # dX *= [a > 0]: its own kernel with its own bound (HBM: dX in, the stored activation in, dX out = 6 bytes per element).  Timed as
+                # (GEMM + mask on one stream) - (GEMM alone): the mask at full rate.  In the training iteration it runs THROTTLED on a second stream
+                # beside the weight gradient (m360_hyper_t.side), where the pair costs ~0.12 ms more than the weight gradient alone
+                "ms": round(dgrad_serial_ms - dgrad_ms, 3), "bound": "hbm", "algorithmic_bytes": 3 * M * HN * 2,
+                "achieved_GBps": round(3 * M * HN * 2 / max(dgrad_serial_ms - dgrad_ms, 1e-6) / 1e6, 1),
+                "frac_of_8TBps": round(3 * M * HN * 2 / max(dgrad_serial_ms - dgrad_ms, 1e-6) / 1e6 / PEAK_HBM_GBPS, 3),
+                "dgrad_plus_mask_serial_ms": round(dgrad_serial_ms, 3),
+                "kernel": "relu_mask_bf16_kernel (16-byte pieces, whole rows per workgroup)"}} if b16 else {}),
             "peak": peak, "unit": "TFLOP/s", "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
 
     guarded("c2_training_iteration", training_entry, "fp32")

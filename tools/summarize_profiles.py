@@ -134,8 +134,11 @@ def markdown(tag):
                     out.append(f"* `{k}` (train.py:53-82 at 4096 x 128, {v.get('dtype', 'f32')}): **{v['iteration_ms']:.1f} ms per iteration = {v['train_rays_per_s']:.0f} rays/s** "
                                f"(proposal update {v['prop_update_ms']:.1f} ms x 2, NeRF update {v['nerf_update_ms']:.1f} ms = {v['nerf_update_tflops']:.1f} TF sustained); "
                                f"wgrad 1024x1024 {v['wgrad_1024x1024']['ms']:.3f} ms = {v['wgrad_1024x1024']['tflops']:.1f} TF = {v['wgrad_1024x1024']['frac']:.3f}, "
-                               f"dgrad {v['dgrad_1024x1024']['ms']:.3f} ms = {v['dgrad_1024x1024']['tflops']:.1f} TF = {v['dgrad_1024x1024']['frac']:.3f} of {v['peak']:.1f}; "
-                               f"peak memory {v['peak_mem_gb']:.1f} GB")
+                               f"dgrad {v['dgrad_1024x1024']['ms']:.3f} ms = {v['dgrad_1024x1024']['tflops']:.1f} TF = {v['dgrad_1024x1024']['frac']:.3f} of {v['peak']:.1f}"
+                               + (f" (the GEMM; its ReLU mask is a kernel of its own: {v['relu_mask_1024']['ms']:.3f} ms = {v['relu_mask_1024']['achieved_GBps']:.0f} GB/s = "
+                                  f"{v['relu_mask_1024']['frac_of_8TBps']:.3f} of 8 TB/s at full rate, GEMM + mask on one stream {v['relu_mask_1024']['dgrad_plus_mask_serial_ms']:.3f} ms; "
+                                  f"in the iteration it runs throttled beside the weight gradient)" if v.get("relu_mask_1024") else "")
+                               + f"; peak memory {v['peak_mem_gb']:.1f} GB")
                 else:
                     r_ = v.get("roofline") or {}
                     line = f"* `{k}` (dtype {v['dtype']}): **{v['rays_per_s']:.0f} rays/s, {v['ms_per_step']:.3f} ms/step**"
@@ -148,6 +151,9 @@ def markdown(tag):
                     ch = v.get("chain")
                     if ch:
                         line += f"; layer chain: {ch['launches']} launches, {ch['recoveries']} repaired, {ch['timeouts']} waits ran out, {ch['xcc_mismatch']} workgroups off their XCD"
+                    hkn = v.get("hbm_kernels") or {}
+                    if any("frac_of_8TBps" in x for x in hkn.values()):
+                        line += "; HBM-bound kernels: " + ", ".join(f"`{k2}` {x['avg_launch_ms'] * 1e3:.1f} us = {x['frac_of_8TBps']:.3f} of 8 TB/s" for k2, x in hkn.items() if "frac_of_8TBps" in x)
                     out.append(line)
             out.append("")
     dom = os.path.join(d, "dominant_kernel_launches.csv")
@@ -165,9 +171,8 @@ def markdown(tag):
                     f"against {t['algorithmic_bytes'] / 1e9:.2f} GB algorithmic ({t['linear_f32_mfma_1024x1024_bytes_per_launch'] / t['algorithmic_bytes']:.2f}x: "
                     f"fabric-side counters, Infinity-Cache hits included - W is re-streamed per 128-row tile); MFMA pipe busy "
                     f"{100 * t['mfma_busy_fraction']:.1f} % at {t['effective_clock_ghz']:.3f} GHz.", ""]
-            b = t.get("bf16_ring_kernel")
-            if b:
-                out += [f"The same for the dominant kernel of `--mlp-dtype bf16` (`{b['kernel']}`, `rocprofv3_pmc_bf16_ring_kernel_summary.json`): fetch "
+            for key, b in (t.get("by_workload") or ({"c2_bf16": t["bf16_ring_kernel"]} if t.get("bf16_ring_kernel") else {})).items():
+                out += [f"The same for the dominant kernel of `{key}` (`{b['kernel']}`, `rocprofv3_pmc_{key}_summary.json`): fetch "
                         f"{b['fetch_bytes'] / 1e9:.2f} GB + write {b['write_bytes'] / 1e9:.2f} GB = {b['bytes_per_launch'] / 1e9:.2f} GB per launch against "
                         f"{b['algorithmic_bytes'] / 1e9:.2f} GB algorithmic ({b['bytes_per_launch'] / b['algorithmic_bytes']:.2f}x); MFMA pipe busy "
                         f"{100 * b['mfma_busy_fraction']:.1f} % at {b['effective_clock_ghz']:.3f} GHz; LDS bank-conflict cycles "
@@ -238,49 +243,62 @@ def sha_at_measurement(src, key, name="kernel_source_sha256_at_measurement.json"
     return json.load(open(path)).get(key)
 
 
-def bf16_ring_counters(src):
-    """Counters of the 1024 x 1024 ReLU launches of the bf16 ring kernel from three separate --pmc passes over
-    `bench.py --mlp-dtype bf16` (tools/gpu_session.sh b16pmc), or None when those passes were not run."""
+# the reduced-precision workloads of the driver line with counter passes of their own (tools/gpu_session.sh pmc16):
+# key -> (rows of the dominant launch, bf16x3?, what the launch is)
+WORKLOADS_16 = {"c2_bf16": (4096 * 128, False), "c5_bf16": (8192 * 256, False), "c2_bf16x3": (4096 * 128, True)}
+
+
+def workload_counters(src, key):
+    """Counters of the dominant launches of one reduced-precision workload from three separate --pmc passes over its bench.py command
+    (tools/gpu_session.sh pmc16: pmc_<key>_{fetch,write,sq}; round 5's b16pmc directories are read for c2_bf16), or None when those
+    passes were not run.  Dominant = the ReLU launches of the one-wave ring kernel that take at least half as long as the longest one:
+    the six-layer chain launch in the bf16 mode, the 1024 x 1024 hidden layers in the bf16x3 mode."""
     import collections
+    rows, x3 = WORKLOADS_16[key]
+
     def per_dispatch(d):
         fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
         if not fs:
             return None
         acc = collections.defaultdict(dict)
         for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
-            # the ReLU hidden layers: <ACT = 1, ABL = 0, no stamps, no X3, not ONE_BLOCK, no heads, no split, no LDS epilogue[, paired rows or not]>
-            # ... or, since round 4's last step, the six hidden layers in ONE launch (CHAIN: <1, 128, ..., paired rows, chain>)
-            if any(k in r["Kernel_Name"] for k in ("w16_kernel<1, 128, false, false, false, 0, false, false, true, true, false>",  # (round 5: an 11th parameter, KEEP_Y)
-                                                   "w16_kernel<1, 0, false, false, false, 0, false, false, true, false, false>", "w16_kernel<1, 0, false, false, false, 0, false, false, false, false, false>",
-                                                   "w16_kernel<1, 128, false, false, false, 0, false, false, true, true>",
-                                                   "w16_kernel<1, 0, false, false, false, 0, false, false, true, false>", "w16_kernel<1, 0, false, false, false, 0, false, false, false, false>",
-                                                   "w16_kernel<1, 0, false, false, false, 0, false, false, true>", "w16_kernel<1, 0, false, false, false, 0, false, false, false>",
-                                                   "w16_kernel<1, 0, false, false, false, 0, false, false>", "w16_kernel<1, 0, false, false, false, 0, false>", "w16_kernel<1, 0, false, false, false, 0>")):
-                acc[r["Dispatch_Id"]]["_chain"] = 1.0 if ("true, true>" in r["Kernel_Name"] or "true, true, false>" in r["Kernel_Name"]) and "<1, 128," in r["Kernel_Name"] else 0.0
-                acc[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
-                acc[r["Dispatch_Id"]]["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        return [x for x in acc.values() if x["_ns"] > 600000]   # the NeRF layers (the 256-wide proposal layers are 7 x shorter)
-    S, F, W = per_dispatch("pmc_b16_sq"), per_dispatch("pmc_b16_fetch"), per_dispatch("pmc_b16_write")
+            if "linear_bf16_w16_kernel<1," not in r["Kernel_Name"]:   # ACT = ReLU
+                continue
+            acc[r["Dispatch_Id"]]["_chain"] = 1.0 if "<1, 128," in r["Kernel_Name"] else 0.0   # the chain launch carries ABL = 128 (its own instantiation)
+            acc[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+            acc[r["Dispatch_Id"]]["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        xs = list(acc.values())
+        if not xs:
+            return None
+        top = max(x["_ns"] for x in xs)
+        return [x for x in xs if x["_ns"] >= 0.5 * top]
+
+    def dirs(kind):
+        new = f"pmc_{key}_{kind}"
+        return new if glob.glob(f"{src}/{new}/*/*_counter_collection.csv") or key != "c2_bf16" else f"pmc_b16_{kind}"
+    S, F, W = per_dispatch(dirs("sq")), per_dispatch(dirs("fetch")), per_dispatch(dirs("write"))
     if not S or not F or not W:
         return None
     mean = lambda xs, k: sum(x[k] for x in xs) / len(xs)  # noqa: E731
     chain = any(x.get("_chain") for x in S)
-    if chain:  # the chain launches only (ragged rows, if any, run layer by layer in shorter launches)
-        S, F, W = [x for x in S if x.get("_chain")], [x for x in F if x.get("_chain")], [x for x in W if x.get("_chain")]
     fetch_b, write_b = mean(F, "FETCH_SIZE") * 1024 * 2, mean(W, "WRITE_SIZE") * 1024
     g = mean(S, "GRBM_GUI_ACTIVE") / 8
-    from bench import TRAFFIC_SOURCES_BF16
-    return {"kernel": "w16::linear_bf16_w16_kernel<ReLU, CHAIN>: six 1024x1024 layers in one launch, M=524288" if chain else "w16::linear_bf16_w16_kernel<ReLU> 1024x1024, M=524288",
-            "bytes_per_launch": round(fetch_b + write_b), "fetch_bytes": round(fetch_b), "write_bytes": round(write_b),
-            # the chain: input rows in, output rows out, six weight matrices (the five hidden activations in between never have to leave the die)
-            "algorithmic_bytes": 2 * M_BENCH * N_BENCH * 2 + (6 if chain else 1) * N_BENCH * N_BENCH * 2, "layers_per_launch": 6 if chain else 1,
+    nlay = 6 if chain else 1
+    el = 4 if x3 else 2   # bf16x3 rows are [hi | lo] pairs
+    kk = 3 * N_BENCH if x3 else N_BENCH
+    stamp = "kernel_source_sha256_at_measurement_b16.json"
+    return {"kernel": (f"w16::linear_bf16_w16_kernel<ReLU, CHAIN>: six 1024x1024 layers in one launch, M={rows}" if chain else
+                       f"w16::linear_bf16_w16_kernel<ReLU{', X3' if x3 else ''}> 1024x1024, M={rows}"),
+            "rows": rows, "bytes_per_launch": round(fetch_b + write_b), "fetch_bytes": round(fetch_b), "write_bytes": round(write_b),
+            # rows in, rows out, the weight matrices (the chain's five hidden activations in between never HAVE to leave the die)
+            "algorithmic_bytes": 2 * rows * N_BENCH * el + nlay * N_BENCH * kk * 2, "layers_per_launch": nlay,
             "launch_ms_under_pmc": round(mean(S, "_ns") / 1e6, 4), "launches_averaged": len(S), "effective_clock_ghz": round(g / mean(S, "_ns"), 3),
             "mfma_busy_fraction": round(mean(S, "SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / g, 4),
             "lds_bank_conflict_cycles": mean(S, "SQ_LDS_BANK_CONFLICT"), "lds_instructions": mean(S, "SQ_INSTS_LDS"),
             "sq_counters_mean": {k: mean(S, k) for k in S[0] if not k.startswith("_")},
-            "method": "three separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ counters) over `bench.py --mlp-dtype bf16 --steps 3 "
-                      "--warmup 1 --cpu-rays 0 --frame-steps 0`, mean over the 1024x1024 ReLU launches; bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024",
-            "kernel_source_sha256": sha_at_measurement(src, "bf16", "kernel_source_sha256_at_measurement_b16.json")}
+            "method": f"three separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ counters) over the workload's bench.py command "
+                      f"(tools/gpu_session.sh pmc16: {key}), mean over its dominant launches; bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024",
+            "kernel_source_sha256": sha_at_measurement(src, "bf16", stamp)}
 
 
 def hbm_kernel_counters(tag):
@@ -373,10 +391,14 @@ def main():
             "sq_counters_mean": {k: v[0] for k, v in s.items()},
             # bench.py trusts this file only while the kernel sources it was measured on are unchanged (stamped at measurement time)
             "kernel_source_sha256": sha_at_measurement(src, "fp32")}
-    bf = bf16_ring_counters(src)
-    if bf:
-        info["bf16_ring_kernel"] = bf
-        json.dump(bf, open(f"{dst}/rocprofv3_pmc_bf16_ring_kernel_summary.json", "w"), indent=1)
+    info["by_workload"] = {}
+    for key in WORKLOADS_16:
+        wc = workload_counters(src, key)
+        if wc:
+            info["by_workload"][key] = wc
+            json.dump(wc, open(f"{dst}/rocprofv3_pmc_{key}_summary.json", "w"), indent=1)
+    if "c2_bf16" in info["by_workload"]:
+        info["bf16_ring_kernel"] = info["by_workload"]["c2_bf16"]   # (the key rounds 4-5 used)
     json.dump(info, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps({k: info[k] for k in list(info)[:9]}, indent=1))
 
