@@ -811,5 +811,16 @@ def test_design_md_numbers_are_generated_from_profiles():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_profiles.py"), "--markdown", tag],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert res.returncode == 0, res.stderr[-2000:]
-    assert block == res.stdout, "DESIGN.md's profile block is stale: re-run tools/summarize_profiles.py --markdown " + tag
+    assert block == res.stdout, "DESIGN.md's profile block is stale: re-run tools/summarize_profiles.py --sync-docs " + tag
     assert "rays/s" in block and "last_step_kernel_trace.csv" in block
+    # README.md and INTEGRATION.md quote their few numbers from the SAME bench.json, through the same tool (one number per quantity)
+    for name in ("README.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, name)).read()
+        m2 = re.search(r"<!-- state:begin (\w+) -->\n(.*?)<!-- state:end -->", text, re.S)
+        assert m2, f"{name} lost its <!-- state:begin <tag> --> block"
+        assert m2.group(1) == tag, f"{name} quotes profiles/{m2.group(1)}, DESIGN.md profiles/{tag}"
+        res2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_profiles.py"), "--readme", tag],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+        assert res2.returncode == 0 and m2.group(2) == res2.stdout, f"{name}'s state block is stale: re-run tools/summarize_profiles.py --sync-docs " + tag
+        outside = text[:m2.start()] + text[m2.end():]
+        assert not re.search(r"\d[\d.]* ?(k rays/s|ms per (step|iteration)|ms/step)", outside), f"{name} types a measured number outside its generated block"

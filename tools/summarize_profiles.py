@@ -234,6 +234,50 @@ def markdown(tag):
     return "\n".join(out) + "\n"
 
 
+def readme_state(tag):
+    """The few numbers README.md and INTEGRATION.md quote, as ONE generated paragraph (their `<!-- state:begin <tag> -->` blocks): one number
+    per quantity, from profiles/<tag>/bench.json alone - the same file DESIGN.md's block is made from."""
+    b = _bench_line(os.path.join(ROOT, "profiles", tag, "bench.json"))
+    if not b:
+        return f"*(no profiles/{tag}/bench.json)*\n"
+    r, nw, p_ = b["roofline"], b.get("named_workloads", {}), b.get("parity", {})
+    f_ = b.get("strong_scaling_frame", {})
+    parts = [f"*Generated by `python tools/summarize_profiles.py --readme {tag}` from `profiles/{tag}/bench.json` (one default `python bench.py` run on 1 x MI355X; "
+             f"boxes of the pool differ by +-2 %).*", "",
+             f"fp32 headline (BASELINE configs[1], 4096 rays x 128 samples): **{b['value'] / 1e3:.1f} k rays/s**, {b['ms_per_step']:.2f} ms per step = "
+             f"{100 * b['config']['whole_path_tflops'] / r['peak']:.1f} % of the fp32 matrix-core roofline for the whole forward; dominant kernel "
+             f"{r['achieved']:.1f} TFLOP/s = {r['frac']:.3f} of peak; max |error| vs the CPU oracle on all {p_.get('rays', '?')} rays "
+             f"{p_.get('max_abs_rgb', float('nan')):.1e} (rgb); CPU oracle {b['cpu_baseline']['value']:.0f} rays/s on {b['cpu_baseline']['cores']} threads "
+             f"(the unmodified reference: 18-19 rays/s on 8 cores, BASELINE.md)."]
+    if f_ and "rays_per_s" in f_:
+        parts.append(f"A 1237 x 822 frame at 64 + 128 samples (configs[2]): {f_['seconds_per_frame']:.2f} s = {f_['rays_per_s'] / 1e3:.1f} k rays/s.")
+    for k, label in (("c2_bf16", "bf16 MLP, configs[1] shape"), ("c5_bf16", "bf16 MLP, configs[4] per-GPU shape 8192 x 256"), ("c2_bf16x3", "bf16x3 (two bf16 terms per value, inside the fp32 tolerance)")):
+        v = nw.get(k)
+        if isinstance(v, dict) and "rays_per_s" in v:
+            rr = v.get("roofline") or {}
+            parts.append(f"{label}: {v['rays_per_s'] / 1e3:.0f} k rays/s, {v['ms_per_step']:.2f} ms per step, dominant kernel {rr.get('frac', 0):.3f} of {rr.get('peak', 0):.0f} TF.")
+    for k, label in (("c2_training_iteration", "fp32"), ("c2_training_iteration_bf16", "bf16")):
+        v = nw.get(k)
+        if isinstance(v, dict) and "iteration_ms" in v:
+            parts.append(f"One iteration of `train.py:53-82` at 4096 x 128 in {label}: {v['iteration_ms']:.1f} ms ({v['train_rays_per_s'] / 1e3:.1f} k rays/s).")
+    return "\n".join(parts) + "\n"
+
+
+def sync_docs(tag):
+    """Rewrite the generated blocks of DESIGN.md (`profiles:begin`), README.md and INTEGRATION.md (`state:begin`) in place."""
+    import re
+    for name, marker, gen in (("DESIGN.md", "profiles", markdown), ("README.md", "state", readme_state), ("INTEGRATION.md", "state", readme_state)):
+        path = os.path.join(ROOT, name)
+        text = open(path).read()
+        pat = re.compile(r"<!-- " + marker + r":begin \w+ -->\n.*?<!-- " + marker + r":end -->", re.S)
+        if not pat.search(text):
+            print(f"{name}: no {marker} block")
+            continue
+        text = pat.sub(lambda _m: f"<!-- {marker}:begin {tag} -->\n" + gen(tag) + f"<!-- {marker}:end -->", text)
+        open(path, "w").write(text)
+        print(f"{name}: {marker} block regenerated from profiles/{tag}/")
+
+
 def sha_at_measurement(src, key, name="kernel_source_sha256_at_measurement.json"):
     """The SHA-256 of the kernel sources as stamped on the GPU box when the counters were collected (tools/gpu_session.sh prof /
     b16pmc).  Never recomputed here: a summary made after the sources changed must not look current to bench.py."""
@@ -349,6 +393,12 @@ def hbm_kernel_counters(tag):
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--markdown":
         sys.stdout.write(markdown(sys.argv[2]))
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--readme":
+        sys.stdout.write(readme_state(sys.argv[2]))
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "--sync-docs":
+        sync_docs(sys.argv[2])
         return
     if len(sys.argv) > 2 and sys.argv[1] == "--hbm-kernels":
         print(json.dumps(hbm_kernel_counters(sys.argv[2])))
