@@ -672,24 +672,25 @@ def _trainable(sd):
     return {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
 
 
-def prop_step_gradients(rays: Rays, sd, hp: Hyper):
+def prop_step_gradients(rays: Rays, sd, hp: Hyper, t_rand=None, u_rand=None):
     """train.py:55-62: Loss_prop(t, w, t_hat, w_hat).backward() -> (loss, {parameter name: gradient}) by autograd
-    through the restated forward (only prop_net.* receive a gradient: t and w are detached, train.py:57-58)."""
+    through the restated forward (only prop_net.* receive a gradient: t and w are detached, train.py:57-58).
+    t_rand / u_rand: the draws of a randomized model (fixture G22), None = deterministic."""
     p = _trainable(sd)
-    t_hat, w_hat = prop_forward(rays, p, hp)
+    t_hat, w_hat = prop_forward(rays, p, hp, t_rand=t_rand)
     with torch.no_grad():
-        _, _, _, t, w, _ = nerf_forward(rays, t_hat, w_hat, p, hp)
+        _, _, _, t, w, _ = nerf_forward(rays, t_hat, w_hat, p, hp, u_rand=u_rand)
     loss = loss_prop_given(w_hat, prop_bounds(t, w, t_hat.detach()))
     loss.backward()
     return loss.detach(), {k: v.grad for k, v in p.items() if k.startswith("prop_net")}
 
 
-def nerf_step_gradients(rays: Rays, sd, hp: Hyper, pixels: torch.Tensor, dist_weight: float = 0.01):
+def nerf_step_gradients(rays: Rays, sd, hp: Hyper, pixels: torch.Tensor, dist_weight: float = 0.01, t_rand=None, u_rand=None):
     """train.py:69-80: (Loss_nerf + dist_weight * Loss_dist).backward() -> (loss_nerf, loss_dist, gradients of nerf_net.*)."""
     p = _trainable(sd)
     with torch.no_grad():
-        t_hat, w_hat = prop_forward(rays, p, hp)
-    rgb, _, _, _, fine_w, s_vals = nerf_forward(rays, t_hat, w_hat, p, hp)
+        t_hat, w_hat = prop_forward(rays, p, hp, t_rand=t_rand)
+    rgb, _, _, _, fine_w, s_vals = nerf_forward(rays, t_hat, w_hat, p, hp, u_rand=u_rand)
     ln, _ = loss_nerf(rgb, pixels)
     ld = loss_dist(s_vals, fine_w)
     (ln + dist_weight * ld).backward()

@@ -1053,6 +1053,45 @@ def g22():
         for nm_, v in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), o):
             out[f"{tag}_{nm_}"] = N(v)
         print(f"  G22 {tag}: {time.time() - t0:.1f}s")
+    # (5) one iteration's two kinds of update with randomized=True - what `python train.py` runs by default (config.py:15): the proposal
+    # step (train.py:55-62) and the NeRF step (train.py:69-80) on a randomized model in train() mode, every draw recorded
+    from intern import loss as ref_loss
+    gen = np.random.Generator(np.random.PCG64(2213))
+    for kind, Bm, nm, wb in (("lego", 10, 16, True), ("garden", 6, 64, False)):
+        r = synthetic.make_rays(kind, Bm, seed=2300 + nm)
+        pixels = gen.uniform(0, 1, size=(Bm, 3)).astype(np.float32)
+        m = ref_model.mipNeRF360(randomized=True, num_samples=nm, hidden_proposal=hp_, hidden_nerf=hn_, white_bkgd=wb, device=CPU)
+        m.load_state_dict({k: T(v) for k, v in sd.items()})
+        m.train()
+        tag = f"train_{kind}_{nm}"
+        for k in synthetic.RAY_FIELDS:
+            out[f"{tag}_rays_{k}"] = r[k]
+        out[tag + "_cfg"], out[tag + "_pixels"] = np.array([Bm, nm, int(wb)]), pixels
+        m.zero_grad()
+        with record_draws() as rec:
+            rays = ref_rays(r)
+            t_hat, w_hat = m.prop_net.forward(rays)
+            _, _, _, t, w, _ = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        loss_prop = ref_loss.Loss_prop(t=t.detach(), w=w.detach(), t_hat=t_hat, w_hat=w_hat)
+        loss_prop.backward()
+        out[tag + "_prop_t_rand"], out[tag + "_prop_u_unit"], out[tag + "_loss_prop"] = N(rec.rand[0]), N(rec.uniform_unit[0]), N(loss_prop)
+        for name, p in m.named_parameters():
+            if name.startswith("prop_net"):
+                out[f"{tag}_propstep.{name}"] = N(p.grad)
+        m.zero_grad()
+        with record_draws() as rec:
+            rays = ref_rays(r)
+            t_hat, w_hat = m.prop_net.forward(rays)
+            rgb, _, _, _, fine_w, s_vals = m.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+        loss_nerf, _ = ref_loss.Loss_nerf(input=rgb, target=T(pixels))
+        loss_dist = ref_loss.Loss_dist(s_vals=s_vals, weights=fine_w)
+        (loss_nerf + 0.01 * loss_dist).backward()
+        out[tag + "_nerf_t_rand"], out[tag + "_nerf_u_unit"] = N(rec.rand[0]), N(rec.uniform_unit[0])
+        out[tag + "_loss_nerf"], out[tag + "_loss_dist"], out[tag + "_rgb"] = N(loss_nerf), N(loss_dist), N(rgb)
+        for name, p in m.named_parameters():
+            if name.startswith("nerf_net"):
+                out[f"{tag}_nerfstep.{name}"] = N(p.grad)
+        print(f"  G22 {tag}: loss_prop {float(loss_prop):.5g} loss_nerf {float(loss_nerf):.5g} loss_dist {float(loss_dist):.5g}")
     save("g22_randomized", **out)
 
 

@@ -682,3 +682,29 @@ def test_g22_randomized_stage_forwards(golden, tag):
     close(w_hat, g[pre + "w_hat"], atol=2e-6)
     for nm, v in zip(("rgb", "dist", "acc", "t_vals", "fine_w", "s_vals"), out):
         close(v, g[f"{pre}{nm}"], atol=2e-6, rtol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["lego_16", "garden_64"])
+def test_g22_randomized_training_steps(golden, tag):
+    """What `python train.py` runs by default (config.py:15, randomized=True): the proposal step (train.py:55-62) and the NeRF step
+    (train.py:69-80) on a randomized reference model in train() mode, draws recorded - losses and every parameter gradient by autograd
+    through the oracle on the same draws."""
+    g = golden("g22_randomized")
+    sd = _sd(g)
+    pre = f"train_{tag}_"
+    B, n, wb = (int(x) for x in g[pre + "cfg"])
+    rays = O.rays_from_numpy({k: g[f"{pre}rays_{k}"] for k in synthetic.RAY_FIELDS})
+    hp = O.Hyper(num_samples=n, white_bkgd=bool(wb))
+
+    def grad_close(got, want, name, rel):
+        scale = max(float(np.abs(want).max()), 1e-12)
+        assert float(np.abs(got.numpy() - want).max()) <= rel * scale, name
+
+    loss, grads = O.prop_step_gradients(rays, sd, hp, t_rand=T(g[pre + "prop_t_rand"]), u_rand=T(g[pre + "prop_u_unit"]))
+    close(loss, g[pre + "loss_prop"], atol=0, rtol=5e-4)
+    for k, v in grads.items():
+        grad_close(v, g[f"{pre}propstep.{k}"], k, 5e-4)
+    ln, ld, grads = O.nerf_step_gradients(rays, sd, hp, T(g[pre + "pixels"]), t_rand=T(g[pre + "nerf_t_rand"]), u_rand=T(g[pre + "nerf_u_unit"]))
+    close(ln, g[pre + "loss_nerf"], atol=0, rtol=5e-5), close(ld, g[pre + "loss_dist"], atol=0, rtol=2e-4)
+    for k, v in grads.items():
+        grad_close(v, g[f"{pre}nerfstep.{k}"], k, 2e-4)
