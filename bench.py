@@ -115,6 +115,9 @@ def parse_args(argv=None):
     ap.add_argument("--plain-rows", action="store_true",
                     help="(diagnostics, bf16 modes) M360_TUNE_PLAIN_ROWS per call: plain instead of paired rows between the layers - same bits; "
                          "the line then carries config.plain_rows")
+    ap.add_argument("--fail-frame-setup-on-rank", type=int, default=-1, metavar="R",
+                    help="(test hook) rank R raises while setting the frame leg up: every rank must then skip the leg together (no rank is left "
+                         "waiting in a collective) and the run must still end with its headline line and rc 0")
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE: print the child command as JSON and exit")
     return ap.parse_args(argv)
@@ -895,6 +898,8 @@ def worker(args):
         setup_error = None
         try:
             fw, fh = frame_size(args)
+            if rank == args.fail_frame_setup_on_rank:
+                raise MemoryError("injected by --fail-frame-setup-on-rank (test hook)")
             fmodel = mipNeRF360(randomized=False, num_samples=64, num_samples_fine=128, hidden_proposal=HP, hidden_nerf=HN,
                                 white_bkgd=False, device=dev, mlp_dtype=mlp_dtype)
             fmodel.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})

@@ -270,6 +270,21 @@ def test_bench_launches_its_own_ranks_weak_scaling_line(dev):
     assert "cpu_baseline" not in line  # N = 1 only
 
 
+@pytest.mark.parametrize("bad_rank", [0, 1])
+def test_bench_frame_leg_is_skipped_by_all_ranks_when_one_cannot_set_it_up(dev, bad_rank):
+    """the frame leg used to be wrapped in a per-rank try / except - a rank that failed recorded an error and moved on
+    while the others waited for it in the pixel all-gather: a hang instead of a failure.  Now the ranks agree on the set-up's outcome (one
+    MIN all-reduce everybody takes part in) before the leg's first collective: either rank failing makes BOTH skip it, the run ends with
+    its headline line and rc 0, within the timeout."""
+    res, line = _run_bench("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--frame-size", "160x120",
+                           "--fail-frame-setup-on-rank", str(bad_rank), timeout=420)
+    assert res.returncode == 0 and line is not None, (res.stdout[-1500:], res.stderr[-3000:])
+    assert line["value"] > 0 and line["n_gpus"] == 2
+    assert "error" in line["strong_scaling_frame"] and "rays_per_s" not in line["strong_scaling_frame"], line["strong_scaling_frame"]
+    assert ("injected" in line["strong_scaling_frame"]["error"]) == (bad_rank == 0)   # rank 0's line: its own error, or "another rank"
+    assert "injected by --fail-frame-setup-on-rank" in res.stderr
+
+
 def test_bench_c4_frames_sharded_over_two_ranks(dev):
     """bench.py --config c4 (BASELINE configs[3]) through its own launcher: frames sharded by whole chunks, each rank
     generating the rays of its own span, overlapped and serial pixel gathers."""
