@@ -138,7 +138,10 @@ class _PackedMLP:
             flag = ops.params_nan_flag(params)  # one launch over all tensors
             msg = ("mlp_dtype='bf16' / 'bf16x3': the parameters hold NaN values; the bf16 matrix pipe cannot propagate them "
                    "the way nn.ReLU does (the reference renders NaN) - use mlp_dtype='fp32' for this checkpoint")
-            if always:  # training mode (defer_nan or not: the no-grad forwards of a training step must not stall it either)
+            if always and defer_nan:  # the tape-keeping forward of a training step: it must not stall on the flag
+                # (A no-grad forward in training mode - rendering with a model that was never put into eval(), or the other net's forward
+                # inside a training step - reads its flag at once below: it has no backward that could still refuse, and a silent render
+                # from NaN parameters is worse than one host sync.)
                 self.check_nan_pending()  # the previous re-pack's flag: arrived long ago
                 host = torch.empty(1, dtype=torch.int32, pin_memory=True)
                 host.copy_(flag, non_blocking=True)

@@ -298,8 +298,8 @@ def test_nan_parameter_is_refused_in_training_mode_one_forward_late(dev):
 def test_nan_parameter_never_reaches_the_optimizer(dev):
     """the FIRST tape-keeping forward on NaN parameters used to hand finite-looking gradients to the optimizer (the bf16
     ReLU drops the NaN) - the flag was only read by the next forward, and the last step's never.  Now the backward of that very forward
-    raises before returning gradients, `flush_nan_check()` reads the flag of a forward nothing follows, and the no-grad forwards of a
-    training step use the deferred flag too (no host sync in the step)."""
+    raises before returning gradients, and `flush_nan_check()` reads the flag of a tape-keeping forward that nothing follows.  A no-grad
+    forward in training mode (a model never put into eval(), or the other net's forward inside a training step) still refuses at once."""
     sd = synthetic.make_state_dict(64, 128, seed=3)
     rays = dev_rays(synthetic.make_rays("lego", 32, seed=4), dev)
     m = _bf16_model(sd, dev, 16, 64, 128, False)
@@ -312,12 +312,16 @@ def test_nan_parameter_never_reaches_the_optimizer(dev):
     m2 = _bf16_model(sd, dev, 16, 64, 128, False)
     with torch.no_grad():
         m2.nerf_net.final_color[0].bias[0] = float("nan")
-        m2.prop_net.forward(rays), m2.flush_nan_check()   # clean sub-net: nothing to report
+    with torch.no_grad():
         t_hat, w_hat = m2.prop_net.forward(rays)
-        m2.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)   # training mode, no grad: deferred flag, no sync
+    m2.flush_nan_check()                          # the proposal net is clean: nothing to report
+    out = m2.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)   # tape-keeping: the flag is deferred ...
+    assert out[0].requires_grad
     with pytest.raises(RuntimeError, match="parameters hold NaN"):
-        m2.flush_nan_check()
-    m2.flush_nan_check()  # reported once
+        m2.flush_nan_check()                      # ... and read here although no backward and no further forward ever runs
+    m2.flush_nan_check()                          # reported once
+    with pytest.raises(RuntimeError, match="parameters hold NaN"), torch.no_grad():
+        m2.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)     # training mode, no grad: refused at once
 
 
 def test_params_nan_flag_one_launch(dev):
