@@ -9,7 +9,10 @@ module; `mipnerf360_amd/` must never do so.
 Parity status: PINNED. `tests/golden/*.npz` were produced by importing the
 reference itself in the authoring container (`tests/golden/make_golden.py`) and
 `tests/test_oracle_golden.py` checks every function below against them
-(<= 1e-6 abs on O(1) quantities).
+(<= 1e-6 abs on O(1) quantities) - since round 6 including the RANDOMIZED branches
+(`jitter_t`, the `u_rand` branch of `sorted_piecewise_constant_pdf`, the stage forwards and the
+training steps with draws): fixture G22 is the reference's own randomized run with what
+`torch.rand` / `Tensor.uniform_` returned recorded beside its outputs.
 
 Reference behaviours reproduced on purpose:
   * `contract()` uses the Frobenius norm of the WHOLE [B,N,3] tensor
