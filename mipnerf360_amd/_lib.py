@@ -195,14 +195,16 @@ _loaded = {}  # path -> bound CDLL
 DIAG_LIB_PATH = os.path.join(_HERE, "libm360_diag.so")  # make -C mipnerf360_amd/csrc diag: the same sources with -DM360_DIAG (test hooks, stamped kernels)
 
 
-def build(verbose: bool = False) -> str:
-    """Compile libm360.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC_DIR, "-j4"]
-    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if verbose or res.returncode != 0:
-        print(res.stdout)
-    if res.returncode != 0:
-        raise RuntimeError("building libm360.so failed (see output above)")
+def build(verbose: bool = False, diag: bool = False) -> str:
+    """Compile libm360.so for gfx950 with hipcc (cross-compiles without a GPU); diag=True: libm360_diag.so as well (the same sources with
+    -DM360_DIAG: stamped kernels for tools/, the layer chain's fault-injection hooks for tests/test_gpu_chain.py - never loaded by the package)."""
+    for target in ([], ["diag"]) if diag else ([],):
+        cmd = ["make", "-C", CSRC_DIR, "-j4"] + target
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if verbose or res.returncode != 0:
+            print(res.stdout)
+        if res.returncode != 0:
+            raise RuntimeError(f"building {'libm360_diag.so' if target else 'libm360.so'} failed (see output above)")
     return LIB_PATH
 
 
