@@ -192,6 +192,49 @@ def test_g21_structured_gradients_bf16(golden, dev, kind):
     assert add_p <= 2 * BACKWARD_REL and tot_p <= inh_p + 2 * BACKWARD_REL and cos_p >= 0.99, (inh_p, add_p, tot_p, cos_p)
 
 
+@pytest.mark.parametrize("tag", ["lego_16", "garden_64"])
+def test_g22_randomized_training_steps_bf16(golden, dev, tag):
+    """Fixture G22's training steps - randomized=True, what `python train.py` runs by default (config.py:15) - in bf16, on the reference's own
+    recorded draws (module.replay_uniforms), with the same decomposition as G13: what the bf16 forward costs is taken from the oracle's
+    bf16-emulating forward on the same draws, what the HIP bf16 backward adds is held to BACKWARD_REL, the direction to COS_MIN."""
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
+    from oracle import ref_path as O
+    g = golden("g22_randomized")
+    pre = f"train_{tag}_"
+    B, n, wb = (int(v) for v in g[pre + "cfg"])
+    sd = {k[3:]: g[k] for k in g if k.startswith("sd.")}
+    r = {f: g[f"{pre}rays_{f}"] for f in synthetic.RAY_FIELDS}
+    rays = dev_rays(r, dev)
+    model = _bf16_model(sd, dev, n, 32, 64, bool(wb))
+    model.prop_net.randomized = model.nerf_net.randomized = True
+    sdt, hp16 = O.to_torch_state_dict(sd), O.Hyper(num_samples=n, white_bkgd=bool(wb), mlp_bf16=1)
+    T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()  # noqa: E731
+    U = lambda a: T_(a).to(dev)  # noqa: E731
+    model.prop_net.replay_uniforms, model.nerf_net.replay_uniforms = U(g[pre + "prop_t_rand"]), U(g[pre + "prop_u_unit"])
+    t_hat, w_hat = model.prop_net.forward(rays)
+    with torch.no_grad():
+        _, _, _, t, w, _ = model.nerf_net.forward(rays, t_vals=t_hat.detach(), coarse_weights=w_hat.detach())
+    model.zero_grad()
+    Loss_prop(t=t, w=w, t_hat=t_hat, w_hat=w_hat).backward()
+    hip = {name: p.grad.clone() for name, p in model.named_parameters() if name.startswith("prop_net")}
+    _, og = O.prop_step_gradients(O.rays_from_numpy(r), sdt, hp16, t_rand=T_(g[pre + "prop_t_rand"]), u_rand=T_(g[pre + "prop_u_unit"]))
+    inh_p, add_p, tot_p, cos_p = _step_errors(hip, og, {nm: g[f"{pre}propstep.{nm}"] for nm in hip}, f"G22 bf16 {tag} proposal step")
+    model.prop_net.replay_uniforms, model.nerf_net.replay_uniforms = U(g[pre + "nerf_t_rand"]), U(g[pre + "nerf_u_unit"])
+    with torch.no_grad():
+        t_hat, w_hat = model.prop_net.forward(rays)
+    rgb, _, _, _, fine_w, s_vals = model.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    loss_nerf, _ = Loss_nerf(input=rgb, target=U(g[pre + "pixels"]))
+    model.zero_grad()
+    (loss_nerf + 0.01 * Loss_dist(s_vals=s_vals, weights=fine_w)).backward()
+    hip = {name: p.grad.clone() for name, p in model.named_parameters() if name.startswith("nerf_net")}
+    _, _, og = O.nerf_step_gradients(O.rays_from_numpy(r), sdt, hp16, T_(g[pre + "pixels"]), t_rand=T_(g[pre + "nerf_t_rand"]), u_rand=T_(g[pre + "nerf_u_unit"]))
+    inh_n, add_n, tot_n, cos_n = _step_errors(hip, og, {nm: g[f"{pre}nerfstep.{nm}"] for nm in hip}, f"G22 bf16 {tag} NeRF step")
+    # the proposal loss divides by w_hat + 1e-6 (near = 0: weights of 1e-6): twice the bound there, as for G21
+    assert add_n <= BACKWARD_REL and tot_n <= inh_n + BACKWARD_REL and cos_n >= COS_MIN, (inh_n, add_n, tot_n, cos_n)
+    assert add_p <= 2 * BACKWARD_REL and tot_p <= inh_p + 2 * BACKWARD_REL and cos_p >= 0.99, (inh_p, add_p, tot_p, cos_p)
+    assert abs(float(loss_nerf.detach()) - float(g[pre + "loss_nerf"])) <= 2e-2 * abs(float(g[pre + "loss_nerf"]))
+
+
 NERF_REL, PROP_REL = 3e-2, 8e-2  # full width against the fp32 mirrors (measured 1.2e-2 / 1.8e-2: wide layers average the rounding noise)
 
 
