@@ -229,8 +229,12 @@ def test_g22_randomized_training_steps_bf16(golden, dev, tag):
     hip = {name: p.grad.clone() for name, p in model.named_parameters() if name.startswith("nerf_net")}
     _, _, og = O.nerf_step_gradients(O.rays_from_numpy(r), sdt, hp16, T_(g[pre + "pixels"]), t_rand=T_(g[pre + "nerf_t_rand"]), u_rand=T_(g[pre + "nerf_u_unit"]))
     inh_n, add_n, tot_n, cos_n = _step_errors(hip, og, {nm: g[f"{pre}nerfstep.{nm}"] for nm in hip}, f"G22 bf16 {tag} NeRF step")
-    # the proposal loss divides by w_hat + 1e-6 (near = 0: weights of 1e-6): twice the bound there, as for G21
-    assert add_n <= BACKWARD_REL and tot_n <= inh_n + BACKWARD_REL and cos_n >= COS_MIN, (inh_n, add_n, tot_n, cos_n)
+    # the proposal loss divides by w_hat + 1e-6 (near = 0: weights of 1e-6): twice the bound there, as for G21.  Direction: against the
+    # reference to COS_MIN - or, where the bf16 FORWARD alone already turns the gradient further than that (lego_16's 64-wide NeRF net on 10
+    # jittered rays: 38 % of a tensor's scale inherent), no further than the oracle's bf16 gradients are
+    cos_inherent = _cos([(og[nm], g[f"{pre}nerfstep.{nm}"]) for nm in hip])
+    assert add_n <= BACKWARD_REL and tot_n <= inh_n + BACKWARD_REL and cos_n >= min(COS_MIN, cos_inherent - 1e-3), (inh_n, add_n, tot_n, cos_n, cos_inherent)
+    assert _cos([(hip[nm], og[nm].numpy()) for nm in hip]) >= COS_MIN
     assert add_p <= 2 * BACKWARD_REL and tot_p <= inh_p + 2 * BACKWARD_REL and cos_p >= 0.99, (inh_p, add_p, tot_p, cos_p)
     assert abs(float(loss_nerf.detach()) - float(g[pre + "loss_nerf"])) <= 2e-2 * abs(float(g[pre + "loss_nerf"]))
 
