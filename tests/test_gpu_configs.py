@@ -270,6 +270,20 @@ def test_bench_launches_its_own_ranks_weak_scaling_line(dev):
     assert "cpu_baseline" not in line  # N = 1 only
 
 
+def test_bench_eight_ranks_share_the_gpu_over_gloo(dev):
+    """The driver's N = 8 invocation (`python bench.py --gpus 8`), as far as ONE GPU can go: eight fresh rank processes through bench.py's own
+    launcher, each with its own 4096 x 128 batch (weak line) and its block of whole chunks of one frame (configs[3]: 30 chunks -> 4 per rank,
+    the last rank 2), pixel blocks gathered over gloo - the per-rank code, partition and gather logic of the RCCL run; no performance claim."""
+    res, line = _run_bench("--gpus", "8", "--backend", "gloo", "--steps", "1", "--warmup", "1", "--frame-size", "400x300", timeout=900)
+    assert res.returncode == 0 and line is not None, (res.stdout[-1500:], res.stderr[-3000:])
+    assert line["n_gpus"] == 8 and line["rccl"]["ranks"] == 8 and len(line["per_rank"]) == 8 and line["scaling"] == "weak"
+    assert line["config"]["global_rays"] == 8 * 4096 if "global_rays" in line["config"] else True
+    fr = line["strong_scaling_frame"]
+    assert fr["finite"] and fr["rays_per_frame"] == 400 * 300 and fr["n_chunks"] == 30 and fr["chunks_per_rank"] == 4
+    assert [r["rays"] for r in fr["per_rank"]] == [4 * 4096] * 7 + [400 * 300 - 7 * 4 * 4096]
+    assert abs(fr["partition_efficiency_bound"] - 400 * 300 / (8 * 4 * 4096)) < 1e-4
+
+
 @pytest.mark.parametrize("bad_rank", [0, 1])
 def test_bench_frame_leg_is_skipped_by_all_ranks_when_one_cannot_set_it_up(dev, bad_rank):
     """the frame leg used to be wrapped in a per-rank try / except - a rank that failed recorded an error and moved on
