@@ -1285,6 +1285,8 @@ int m360_diag_linear_bf16(const void *x, long M, int ldx, const void *w_packed, 
             case 44: M360_W16_ABL(8192, true); break;        // variant 144: system-scope non-temporal stores (sc0 sc1 nt)
             case 45: M360_W16_ABL(8192 + 128, true); break;  // variant 145: system-scope stores (sc0 sc1)
             case 100: M360_W16_ABL(0, false); break;
+            case 51: M360_W16_ABL(32768, true); break;  // variant 151: + 8 selects per piece on an SGPR-pair mask (a ReLU bit tape APPLIED in the epilogue; results correct)
+            case 52: M360_W16_ABL(65536, true); break;  // variant 152: + 8 v_cmp per piece into SGPR pairs (the tape PRODUCED by the epilogue; results correct)
             case 50: hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_SIGMOID, 16, true>), g4, b4, 0, st, xb, M, ldx, wb, b_packed, n_pad, k_pad, yb, ldy, n_pad / w16::BN, (int)nt); break;  // sigmoid epilogue, no stores: what would a last layer cost here?
             default: return fail(M360_ERR_INVALID_ARGUMENT, "m360_diag_linear_bf16: variant %d", variant);
         }

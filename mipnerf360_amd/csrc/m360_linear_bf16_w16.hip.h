@@ -646,6 +646,26 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                                      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
                                      : "a"(acc[i][2 * p][0]), "a"(acc[i][2 * p][1]), "a"(acc[i][2 * p][2]), "a"(acc[i][2 * p][3]),
                                        "a"(acc[i][2 * p + 1][0]), "a"(acc[i][2 * p + 1][1]), "a"(acc[i][2 * p + 1][2]), "a"(acc[i][2 * p + 1][3]));
+                        // Diagnostics (round 6; VERDICT r5 item 2: a ReLU bit tape applied in / produced by this epilogue instead of the
+                        // backward's mask pass).  ABL 32768: what APPLYING it costs the input gradient - 8 selects per piece on a wave-level
+                        // mask in an SGPR pair (here: exec, i.e. all ones - the results stay right; the real thing fetches 16 SGPRs per piece
+                        // with s_load_dwordx16, scalar memory that the counted vmcnt schedule does not see).  ABL 65536: what PRODUCING it
+                        // costs the tape-keeping forward - 8 v_cmp per piece into SGPR pairs (the 4 s_store_dwordx4 that would carry them to
+                        // memory are scalar instructions and left out).  tools/linear_bench.py --variant 151 / 152 against 100.
+                        if constexpr ((ABL & 32768) != 0) {
+                            unsigned long long mk_;
+                            asm volatile("s_mov_b64 %0, exec" : "=s"(mk_));
+                            asm volatile("v_cndmask_b32 %0, 0, %0, %8\n\tv_cndmask_b32 %1, 0, %1, %8\n\tv_cndmask_b32 %2, 0, %2, %8\n\tv_cndmask_b32 %3, 0, %3, %8\n\t"
+                                         "v_cndmask_b32 %4, 0, %4, %8\n\tv_cndmask_b32 %5, 0, %5, %8\n\tv_cndmask_b32 %6, 0, %6, %8\n\tv_cndmask_b32 %7, 0, %7, %8"
+                                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "s"(mk_));
+                        }
+                        if constexpr ((ABL & 65536) != 0) {
+                            unsigned long long m0_, m1_, m2_, m3_, m4_, m5_, m6_, m7_;
+                            asm volatile("v_cmp_lt_f32 %0, 0, %8\n\tv_cmp_lt_f32 %1, 0, %9\n\tv_cmp_lt_f32 %2, 0, %10\n\tv_cmp_lt_f32 %3, 0, %11\n\t"
+                                         "v_cmp_lt_f32 %4, 0, %12\n\tv_cmp_lt_f32 %5, 0, %13\n\tv_cmp_lt_f32 %6, 0, %14\n\tv_cmp_lt_f32 %7, 0, %15"
+                                         : "=s"(m0_), "=s"(m1_), "=s"(m2_), "=s"(m3_), "=s"(m4_), "=s"(m5_), "=s"(m6_), "=s"(m7_)
+                                         : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
+                        }
 // plain: bias, bf16 conversion, ReLU on the packed pair.  X3: bias, ReLU in fp32, hi = bf16(t), lo = bf16(t - hi)
 #define W16_PACK(e, a0, a1, bb_, be)                                                                           \
     do {                                                                                                       \
