@@ -1,0 +1,169 @@
+"""GPU tests (`-m gpu`): property-based sweeps of the whole path over shapes nobody picked by hand (hypothesis, derandomized: the same
+examples on every run).  Each example builds a small model (widths multiples of 32, like the reference's own reduced configurations), a
+ray batch of an arbitrary size and sample count - B = 1, N = 1, counts that are multiples of nothing - and holds the HIP path to the CPU
+oracle at the stated fp32 tolerance: the fused forward, both staged forwards with recorded-style uniforms (the randomized branches), and
+the parameter gradients of a NeRF step."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from mipnerf360_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+RGB_TOL = 1e-4
+import os
+
+# M360_FUZZ_SCALE=10: ten times the examples (a one-off deeper search: profiles/r06/pytest_gpu_fuzz_x10.log); the default keeps the suite short
+_SCALE = int(os.environ.get("M360_FUZZ_SCALE", "1"))
+SETTINGS = dict(max_examples=40 * _SCALE, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test needs a HIP device")
+    return torch.device("cuda:0")
+
+
+def H(t):
+    return t.detach().cpu().numpy()
+
+
+def _rays(r, dev):
+    from mipnerf360_amd.intern.ray import Rays
+    return Rays(*[torch.from_numpy(np.ascontiguousarray(r[k])).float().to(dev) for k in synthetic.RAY_FIELDS])
+
+
+def _pair(dev, B, n, hp, hn, wb, kind, seed, randomized=False, n_fine=None):
+    from mipnerf360_amd.model import mipNeRF360
+    from oracle import ref_path as O
+    sd = synthetic.make_state_dict(hp, hn, seed=seed)
+    m = mipNeRF360(randomized=randomized, num_samples=n, hidden_proposal=hp, hidden_nerf=hn, white_bkgd=wb, device=dev,
+                   **({"num_samples_fine": n_fine} if n_fine else {}))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    r = synthetic.make_rays(kind, B, seed=seed + 1)
+    return m, sd, r, O.to_torch_state_dict(sd), O.Hyper(num_samples=n, white_bkgd=wb, **({"num_samples_fine": n_fine} if n_fine else {}))
+
+
+def _check_render(got, want):
+    for a, b, what in zip(got[:3], want[:3], ("rgb", "distance", "acc")):
+        a, b = H(a), H(b)
+        tol = RGB_TOL * np.maximum(1.0, np.abs(b)) if what == "distance" else RGB_TOL
+        assert np.isfinite(a).all() and (np.abs(a - b) <= tol).all(), (what, float(np.abs(a - b).max()))
+
+
+@settings(**SETTINGS)
+@given(B=st.integers(1, 300), n=st.integers(1, 160), hp=st.sampled_from([32, 64, 96]), hn=st.sampled_from([32, 64, 128]), wb=st.booleans(),
+       kind=st.sampled_from(["lego", "garden"]), seed=st.integers(0, 10 ** 6))
+def test_fused_forward_any_shape_vs_oracle(dev, B, n, hp, hn, wb, kind, seed):
+    """mipNeRF360.forward (m360_forward) on B x n of anything: B = 1, n = 1 (one interval: an empty cumsum in the inverse CDF), ragged rows in
+    every layer - against the oracle on the same rays as one chunk."""
+    from oracle import ref_path as O
+    m, sd, r, sdt, hp_o = _pair(dev, B, n, hp, hn, wb, kind, seed)
+    m.eval()
+    with torch.no_grad():
+        got = m(_rays(r, dev))
+        want = O.forward(O.rays_from_numpy(r), sdt, hp_o)
+    _check_render(got, want)
+
+
+@settings(**{**SETTINGS, "max_examples": 15 * _SCALE})
+@given(B=st.integers(1, 120), n=st.integers(2, 96), nf=st.integers(2, 96), wb=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_unequal_sample_counts_any_shape_vs_oracle(dev, B, n, nf, wb, seed):
+    """The "64+128" extension (num_samples_fine) at arbitrary pairs of counts, fewer fine samples than proposal samples included."""
+    from oracle import ref_path as O
+    m, sd, r, sdt, hp_o = _pair(dev, B, n, 32, 64, wb, "garden", seed, n_fine=nf)
+    m.eval()
+    with torch.no_grad():
+        got = m(_rays(r, dev))
+        want = O.forward(O.rays_from_numpy(r), sdt, hp_o)
+    _check_render(got, want)
+
+
+@settings(**{**SETTINGS, "max_examples": 15 * _SCALE})
+@given(B=st.integers(1, 150), n=st.integers(1, 130), wb=st.booleans(), kind=st.sampled_from(["lego", "garden"]), seed=st.integers(0, 10 ** 6))
+def test_randomized_stages_any_shape_vs_oracle(dev, B, n, wb, kind, seed):
+    """The randomized branches (intern/ray.py:30-35,103-108; pinned to the reference by fixture G22) at arbitrary shapes: uniforms handed to
+    both stages (replay_uniforms), all six stage outputs against the oracle on the same uniforms."""
+    from oracle import ref_path as O
+    m, sd, r, sdt, hp_o = _pair(dev, B, n, 32, 64, wb, kind, seed, randomized=True)
+    m.eval()
+    g = torch.Generator().manual_seed(seed)
+    t_rand, u_rand = torch.rand(B, n + 1, generator=g), torch.rand(B, n + 1, generator=g)
+    m.prop_net.replay_uniforms, m.nerf_net.replay_uniforms = t_rand.to(dev), u_rand.to(dev)
+    rays = _rays(r, dev)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+        out = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+        o_t, o_w = O.prop_forward(O.rays_from_numpy(r), sdt, hp_o, t_rand=t_rand)
+        o = O.nerf_forward(O.rays_from_numpy(r), o_t, o_w, sdt, hp_o, u_rand=u_rand)
+    np.testing.assert_allclose(H(t_hat), H(o_t), atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(H(w_hat), H(o_w), atol=5e-6, rtol=1e-4)
+    _check_render(out, o)
+    np.testing.assert_allclose(H(out[3]), H(o[3]), atol=2e-5, rtol=1e-4)   # resampled t: a weight error moves a sample by its share of a bin
+
+
+@settings(**{**SETTINGS, "max_examples": 10 * _SCALE})
+@given(B=st.integers(1, 90), n=st.integers(1, 70), hp=st.sampled_from([32, 64]), hn=st.sampled_from([32, 64]), wb=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_nerf_step_gradients_any_shape_vs_oracle(dev, B, n, hp, hn, wb, seed):
+    """The NeRF step of train.py:69-80 (Loss_nerf + 0.01 Loss_dist) at arbitrary shapes: every parameter gradient of libm360's backward
+    against torch autograd through the oracle."""
+    from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf
+    from oracle import ref_path as O
+    m, sd, r, sdt, hp_o = _pair(dev, B, n, hp, hn, wb, "lego", seed)
+    m.train()
+    pixels = torch.rand(B, 3, generator=torch.Generator().manual_seed(seed + 2))
+    rays = _rays(r, dev)
+    with torch.no_grad():
+        t_hat, w_hat = m.prop_net.forward(rays)
+    rgb, _, _, _, fw, sv = m.nerf_net.forward(rays, t_vals=t_hat, coarse_weights=w_hat)
+    ln, _ = Loss_nerf(input=rgb, target=pixels.to(dev))
+    m.zero_grad()
+    (ln + 0.01 * Loss_dist(s_vals=sv, weights=fw)).backward()
+    _, _, og = O.nerf_step_gradients(O.rays_from_numpy(r), sdt, hp_o, pixels)
+    for name, p in m.named_parameters():
+        if name.startswith("nerf_net"):
+            want = og[name].numpy()
+            scale = max(float(np.abs(want).max()), 1e-12)
+            assert float(np.abs(H(p.grad) - want).max()) <= 3e-4 * scale + 1e-9, (name, float(np.abs(H(p.grad) - want).max()) / scale)
+
+
+@settings(**{**SETTINGS, "max_examples": 12 * _SCALE})
+@given(h=st.integers(1, 40), w=st.integers(1, 40), chunks=st.integers(1, 700), n=st.integers(1, 48), wb=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_render_image_any_frame_and_chunk_size_vs_oracle(dev, h, w, chunks, n, wb, seed):
+    """mipNeRF360.render_image (model.py:254-274) on h x w of anything in chunks of anything: the chunk partition decides the contraction
+    norms, so the frame must equal the oracle's chunk loop (grouped small chunks, ragged last chunk, a chunk larger than the frame): uint8
+    colours within one count, distance / acc at the fp32 tolerance, NumPy arrays of the reference's shapes and dtypes."""
+    from oracle import ref_path as O
+    m, sd, r, sdt, hp_o = _pair(dev, h * w, n, 32, 32, wb, "lego", seed)
+    m.eval()
+    rgb8, dist, acc = m.render_image(_rays(r, dev), h, w, chunks)
+    o_rgb8, o_dist, o_acc = O.render_image(O.rays_from_numpy(r), h, w, sdt, hp_o, chunks=chunks)
+    assert rgb8.dtype == np.uint8 and rgb8.shape == (h, w, 3) and dist.dtype == np.float32 and dist.shape == (h, w) and acc.shape == (h, w)
+    assert np.abs(rgb8.astype(int) - o_rgb8.astype(int)).max() <= 1
+    assert (np.abs(dist - o_dist) <= RGB_TOL * np.maximum(1.0, np.abs(o_dist))).all() and np.abs(acc - o_acc).max() <= RGB_TOL
+
+
+@settings(**{**SETTINGS, "max_examples": 12 * _SCALE})
+@given(B=st.integers(1, 200), n=st.integers(1, 100), mode=st.sampled_from(["bf16", "bf16x3"]), hn=st.sampled_from([64, 128, 256]), wb=st.booleans(),
+       seed=st.integers(0, 10 ** 6))
+def test_reduced_precision_modes_any_shape_vs_oracle_emulation(dev, B, n, mode, hn, wb, seed):
+    """mlp_dtype='bf16' / 'bf16x3' (BASELINE configs[4]'s precision and its fp32-accurate sibling) at arbitrary shapes - ragged rows take the
+    generic kernels, full tiles the ring kernel - against the oracle rounding at the same points (bf16: <= 6e-3) resp. the fp32 oracle (bf16x3:
+    the fp32 tolerance)."""
+    from mipnerf360_amd.model import mipNeRF360
+    from oracle import ref_path as O
+    sd = synthetic.make_state_dict(64, hn, seed=seed)
+    m = mipNeRF360(num_samples=n, hidden_proposal=64, hidden_nerf=hn, white_bkgd=wb, device=dev, mlp_dtype=mode).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    r = synthetic.make_rays("garden", B, seed=seed + 1)
+    sdt = O.to_torch_state_dict(sd)
+    with torch.no_grad():
+        got = m(_rays(r, dev))
+        if mode == "bf16":
+            emu = O.forward(O.rays_from_numpy(r), sdt, O.Hyper(num_samples=n, white_bkgd=wb, mlp_bf16=1))
+            assert float((got[0].cpu() - emu[0]).abs().max()) <= 6e-3 and float((got[2].cpu() - emu[2]).abs().max()) <= 6e-3
+        else:
+            _check_render(got, O.forward(O.rays_from_numpy(r), sdt, O.Hyper(num_samples=n, white_bkgd=wb)))
