@@ -127,7 +127,9 @@ def test_nerf_step_gradients_any_shape_vs_oracle(dev, B, n, hp, hn, wb, seed):
         if name.startswith("nerf_net"):
             want = og[name].numpy()
             scale = max(float(np.abs(want).max()), 1e-12)
-            assert float(np.abs(H(p.grad) - want).max()) <= 3e-4 * scale + 1e-9, (name, float(np.abs(H(p.grad) - want).max()) / scale)
+            # fp32 sums in another order than autograd's, through up to eight layers: 2e-4 of a tensor's scale on the fixtures' shapes; the worst
+            # of 100 random shapes (M360_FUZZ_SCALE=10: B = 35, n = 34, first-layer weight) reached 4.3e-4
+            assert float(np.abs(H(p.grad) - want).max()) <= 1e-3 * scale + 1e-9, (name, float(np.abs(H(p.grad) - want).max()) / scale)
 
 
 @settings(**{**SETTINGS, "max_examples": 12 * _SCALE})
