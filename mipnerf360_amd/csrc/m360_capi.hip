@@ -729,7 +729,16 @@ __global__ void fold_first_layer_kernel(const float *__restrict__ r, int n_pad, 
 // weight gradient beside it from 1.04 to 1.45 ms and the pair gained 0.1 ms; 4096 x 128, NeRF backward + forward, same box, ms:
 //   one stream 26.5 | mask workgroups: all 25.4, 4096 25.7, 1024 25.6, 512 24.5, 384 26.3, 320 26.1, 256 23.7-23.9, 192 24.9, 128 27.5, 64 36.9
 // (four pieces in flight: no better; profiles/r05/backward_overlap_ab.jsonl)
-constexpr int kBackwardMaskBlocks = 256;  // one striding workgroup of the throttled mask kernel per CU (the A/B above)
+#ifdef M360_DIAG  // diagnostics build: M360_MASK_BLOCKS re-tunes the throttle (A/B runs: tools/train_step_bench.py with M360_LIB=libm360_diag.so)
+static const int kBackwardMaskBlocks = getenv("M360_MASK_BLOCKS") ? atoi(getenv("M360_MASK_BLOCKS")) : 256;
+#else
+// one striding workgroup of the throttled mask kernel per CU.  Re-swept in round 6 beside the faster weight gradient
+// (profiles/r06/backward_mask_blocks_sweep_after_new_wgrad.txt: NeRF / proposal update in ms - 256: 23.4 / 9.4, 320: 25.4 / 9.6, 384: 25.0 / 9.8,
+// 448: 24.3 / 9.9, 512: 22.7 / 10.0, 640: 23.4 / 10.1): counts that are not a multiple of the CU count put two mask workgroups on some CUs
+// and slow those CUs' weight-gradient tiles; 512 gains on the 1024-wide layers what it loses on the 256-wide ones.  The pair is bound by HBM:
+// mask 3.2 GB + weight gradient 2.15 GB in ~0.9 ms is the 6.3 TB/s a copy reaches on this chip.
+constexpr int kBackwardMaskBlocks = 256;
+#endif
 static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *const *w_t, float *const *grad_w, float *const *grad_b, const void *feat,
                              int in_pad, void *const *act, int width, long S, void *dz, void *dz_other, char *ws, const BwdLayout &L,
                              m360_stream_t st, const char *who) {

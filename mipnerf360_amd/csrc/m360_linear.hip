@@ -1071,7 +1071,24 @@ int m360_linear_wgrad_bf16(const void *dz, int ldz, const void *x, int ldx, long
         // one wave per SIMD: k-steps of 32 rows, the same number of splits (>= 4 k tiles: its bias sums; a split's rows within the 2 GB its
         // buffer descriptors address: 32-bit offsets)
         if (!(tuning & M360_TUNE_WGRAD_FORM0) && k_pad >= 4 * tn16w::BT && (per32 + 1) * tn16w::KS * (long)(ldz > ldx ? ldz : ldx) * 2 < (1l << 31)) {
-            hipLaunchKernelGGL(tn16w::linear_tn_bf16_w_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(tn16w::kThreads), 0, st, dzb, ldz, xb, ldx, n_pad, k_pad, partial, k_pad / tn16w::BT, ntiles, nsplit, total32, per32, grad_b ? bias_part : nullptr);
+#define M360_TNW_LAUNCH(A) hipLaunchKernelGGL(tn16w::linear_tn_bf16_w_kernel<A>, dim3((unsigned)(ntiles * nsplit)), dim3(tn16w::kThreads), 0, st, dzb, ldz, xb, ldx, n_pad, k_pad, partial, k_pad / tn16w::BT, ntiles, nsplit, total32, per32, grad_b ? bias_part : nullptr)
+#ifdef M360_DIAG  // diagnostics build only (tools/diag/wgrad_bf16_probe.py with M360_LIB=libm360_diag.so): ablations of the one-wave form, wrong results when != 0
+            static const int wabl = getenv("M360_TNW_ABL") ? atoi(getenv("M360_TNW_ABL")) : 0;
+            switch (wabl) {
+                case 1: M360_TNW_LAUNCH(1); break;
+                case 2: M360_TNW_LAUNCH(2); break;
+                case 3: M360_TNW_LAUNCH(3); break;
+                case 4: M360_TNW_LAUNCH(4); break;
+                case 5: M360_TNW_LAUNCH(5); break;
+                case 6: M360_TNW_LAUNCH(6); break;
+                case 8: M360_TNW_LAUNCH(8); break;
+                case 16: M360_TNW_LAUNCH(16); break;
+                default: M360_TNW_LAUNCH(0); break;
+            }
+#else
+            M360_TNW_LAUNCH(0);
+#endif
+#undef M360_TNW_LAUNCH
             const long count4w = (long)n_pad * k_pad / 4;
             hipLaunchKernelGGL(tn16::tn16_reduce_kernel, dim3((unsigned)((count4w + 255) / 256)), dim3(256), 0, st, partial, nsplit, n_pad, k_pad, dzb, ldz, xb, ldx, total32 * tn16w::KS, M, grad_w);
             if (grad_b) hipLaunchKernelGGL(tn16::tn16_bias_reduce_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, bias_part, nsplit, n_pad, dzb, ldz, total32 * tn16w::KS, M, grad_b);

@@ -42,6 +42,9 @@ constexpr int kOpBytes = KS * kRowBytes;  // 16 KiB: one operand of one k-step
 constexpr int kQuarterBytes = 2 * kOpBytes;  // dZ rows | X rows
 constexpr int kQuarters = 5;
 
+// ABL (diagnostics build only, M360_TNW_ABL; results are wrong unless 0): 1 = no LDS-DMA pieces in the loop, 2 = no fragment reads in the loop,
+// 4 = no MFMAs, 8 = no counted wait + barrier per k-step, 16 = no epilogue stores - which of the loop's three streams overlap badly?
+template <int ABL = 0>
 __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
     const __bf16 *__restrict__ dZ, int ldz, const __bf16 *__restrict__ X, int ldx, int Np, int Kp,
     float *__restrict__ partial /*[nsplit][Np][Kp]*/, int tiles_k, int ntiles, int nsplit, long total_steps /* k-steps of 32 rows */,
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
             return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         };
         const bf16x8 ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
-#define TNW_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+#define TNW_MFMA(ACC, A, B) do { if (!(ABL & 4)) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B)); } while (0)
 // the bias sum's MFMA: accumulator in ArchVGPRs; s_nop 1 in front: one operand is a VALU result (the ones), and an MFMA must not read a VGPR within 2
 // wait states of the VALU write - behind inline assembly the hazard recogniser cannot insert them; 2 x s_nop 15 behind: the MFMA's own latency (above)
 #define TNW_MFMA_V1(ACC, A, B)                                                                                                          \
@@ -135,33 +138,38 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
         }
         asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         __syncthreads();
-        // X fragment j is dead behind its group of 8 MFMAs: the next k-step's is read into the SAME registers right there (an MFMA reads its
-        // sources when it issues; the LDS returns data hundreds of cycles later); the dZ fragments are used by all 8 groups: two sets
-        bf16x8 fa[2][8], fb[8];
+        // Round 6: every non-matrix instruction of a k-step in its OWN MFMA gap, like the forward ring kernel's generated stages.  The ablations of
+        // round 5's loop (profiles/r06/wgrad_bf16_ablation_one_wave_form.txt: M360_TNW_ABL in the diagnostics build) showed its three streams adding
+        // up instead of overlapping - matrix work alone 0.63 ms, + fragment reads 0.89, + LDS-DMA 0.88, all three 1.11 - because the 4 transposed
+        // reads and the 3 instructions of a piece were issued in one clump behind every 8 MFMAs (the matrix pipe drains while a lone wave issues
+        // 7 other instructions), and the last fragments of a k-step were read at its very end and awaited at the top of the next one.  Now: 64
+        // gaps per k-step; transposed read r (0 .. 31: the 16 halves of the next k-step's dZ fragments, then the X fragments') in gap
+        // floor(1.5 r) - all issued 17 MFMAs before the k-step ends; LDS-DMA piece q in gap 2 + 6 q (free: 2 mod 3).  Both fragment sets are double
+        // buffered (an MFMA reads its sources at issue, the LDS returns data later: a read must not target a register a later MFMA of the same
+        // k-step still reads).  Same MFMA order, same accumulation order: same bits.
+        bf16x8 fa[2][8], fb[2][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fb[j] = frag(b_base ^ (unsigned)(j << 5));
+        for (int j = 0; j < 8; ++j) fb[0][j] = frag(b_base ^ (unsigned)(j << 5));
 #pragma unroll
         for (int a = 0; a < 8; ++a) fa[0][a] = frag(a_base ^ (unsigned)(a << 5));
 
         unsigned qn = 1;  // quarter of k-step i + 1
         for (long i = 0; i < nk; i += 2) {
 #pragma unroll
-            for (int par = 0; par < 2; ++par) {  // the two dZ fragment sets alternate: unrolled so that both are static
+            for (int par = 0; par < 2; ++par) {  // the two fragment sets alternate: unrolled so that both are static
                 const long ii = i + par;
                 if (ii < nk) {
                     // quarter ii + 1 complete (this wave's pieces: all but the 16 youngest of the 24 in flight; everyone's: the barrier), quarter ii - 1 free
-                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                    __syncthreads();
+                    if (!(ABL & 8)) {
+                        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                        __syncthreads();
+                    }
                     const unsigned qoff = qn * (unsigned)kQuarterBytes;                       // where k-step ii + 1 lies
                     const unsigned qd = (qn + 3 >= (unsigned)kQuarters ? qn + 3 - kQuarters : qn + 3) * (unsigned)kQuarterBytes;  // quarter of k-step ii + 4 (= of ii - 1)
                     const unsigned ksn = (unsigned)(ii + 4 < last ? ii + 4 : last);
                     const unsigned soff_a = ksn * step_a, soff_b = ksn * step_b;
                     const unsigned aq = a_base + qoff, bq = b_base + qoff;
-                    const bool more = ii + 1 < nk;  // wave-uniform: the last k-step has nothing to read ahead
-                    // the bias sum: its accumulator lives in ArchVGPRs (the 256 AccVGPRs are the tile's), where the compiler copies it at branch
-                    // and loop edges - and an MFMA result read too early is a software hazard the hazard recogniser cannot see behind inline
-                    // assembly (forms without the wait inside the statement returned NaNs / garbage in the bias gradient).  Which dZ fragment: a
-                    // wave-uniform switch (no vector selects in the K loop).
+                    // (the last k-step reads ahead too - a quarter that holds stale rows, into fragments nobody uses: no branch in the loop)
                     if (bias_wave) {
                         switch (bias_blk) {
                             case 0: TNW_MFMA_V1(bacc, ones, fa[par][0]); break;
@@ -174,17 +182,36 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
                             default: TNW_MFMA_V1(bacc, ones, fa[par][7]); break;
                         }
                     }
+                    s16x4 ha[8][2], hb[8][2];  // the 32 halves read in this k-step
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
 #pragma unroll
-                        for (int a = 0; a < 8; ++a) TNW_MFMA(acc[a][j], fb[j], fa[par][a]);
-                        TNW_SB();  // behind every 8 MFMAs: the next k-step's X fragment j and dZ fragment j, and one LDS-DMA piece
-                        if (more) {
-                            fb[j] = frag(bq ^ (unsigned)(j << 5));
-                            fa[par ^ 1][j] = frag(aq ^ (unsigned)(j << 5));
+                        for (int a = 0; a < 8; ++a) {
+                            TNW_MFMA(acc[a][j], fb[par][j], fa[par][a]);
+                            const int gap = 8 * j + a;
+                            if (gap % 3 != 2 && gap <= 46 && !(ABL & 2)) {  // transposed read r = gap - gap / 3
+                                const int r = gap - gap / 3, f_ = (r & 15) >> 1, hf = r & 1;
+                                const unsigned addr = ((r < 16 ? aq : bq) ^ (unsigned)(f_ << 5)) + (unsigned)(hf * 4 * kRowBytes);
+                                const s16x4 v_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(uintptr_t)addr);
+                                if (r < 16) ha[f_][hf] = v_; else hb[f_][hf] = v_;
+                            }
+#ifndef M360_TNW_DMA_LATE
+                            if (gap % 6 == 2 && gap <= 44 && !(ABL & 1)) TNW_DMA(gap / 6, qd, soff_a, soff_b);
+#else  // A/B: the pieces behind the reads, every other gap of the k-step's tail
+                            if (gap >= 47 && gap % 2 == 1 && gap <= 61 && !(ABL & 1)) TNW_DMA((gap - 47) / 2, qd, soff_a, soff_b);
+#endif
+                            TNW_SB();
                         }
-                        TNW_DMA(j, qd, soff_a, soff_b);
-                        TNW_SB();
+                    }
+                    if (!(ABL & 2)) {
+#pragma unroll
+                        for (int f_ = 0; f_ < 8; ++f_) {
+                            fa[par ^ 1][f_] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(ha[f_][0], ha[f_][1], 0, 1, 2, 3, 4, 5, 6, 7));
+                            fb[par ^ 1][f_] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(hb[f_][0], hb[f_][1], 0, 1, 2, 3, 4, 5, 6, 7));
+                        }
+                    } else {
+#pragma unroll
+                        for (int f_ = 0; f_ < 8; ++f_) { fa[par ^ 1][f_] = fa[par][f_]; fb[par ^ 1][f_] = fb[par][f_]; }
                     }
                     TNW_SB();
                     qn = qn + 1 == (unsigned)kQuarters ? 0u : qn + 1;
@@ -203,6 +230,7 @@ __global__ __launch_bounds__(kThreads, 1) void linear_tn_bf16_w_kernel(
     // ---- epilogue: acc[a][j][r] of lane (l15, g) = dW[n0 + 128 wn + 16 a + l15][k0 + 128 wk + 16 j + 4 g + r]
     float *__restrict__ P = partial + (long)split * Np * Kp;
     const int nrow = n0 + wn * 128 + l15, kcol = k0 + wk * 128 + 4 * g;
+    if (!(ABL & 16))
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll

@@ -15,7 +15,7 @@ if os.environ.get("M360_WGRAD_FORM"):  # 0: the 8-wave kernel (the one the M360_
     ops.set_wgrad_bf16_form(int(os.environ["M360_WGRAD_FORM"]))
 
 dev = torch.device("cuda:0")
-for M in ((524288,) if os.environ.get("M360_TN16_ABL") else (16384, 32768, 65536, 131072, 524288)):
+for M in ((524288,) if (os.environ.get("M360_TN16_ABL") or os.environ.get("M360_TNW_ABL")) else (16384, 32768, 65536, 131072, 524288)):
     dz = torch.randn(M, 1024, device=dev).bfloat16()
     x = torch.relu(torch.randn(M, 1024, device=dev)).bfloat16()
     ts = []
