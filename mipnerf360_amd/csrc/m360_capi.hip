@@ -730,15 +730,18 @@ __global__ void fold_first_layer_kernel(const float *__restrict__ r, int n_pad, 
 //   one stream 26.5 | mask workgroups: all 25.4, 4096 25.7, 1024 25.6, 512 24.5, 384 26.3, 320 26.1, 256 23.7-23.9, 192 24.9, 128 27.5, 64 36.9
 // (four pieces in flight: no better; profiles/r05/backward_overlap_ab.jsonl)
 #ifdef M360_DIAG  // diagnostics build: M360_MASK_BLOCKS re-tunes the throttle (A/B runs: tools/train_step_bench.py with M360_LIB=libm360_diag.so)
-static const int kBackwardMaskBlocks = getenv("M360_MASK_BLOCKS") ? atoi(getenv("M360_MASK_BLOCKS")) : 256;
+static const int kBackwardMaskBlocksWide = getenv("M360_MASK_BLOCKS") ? atoi(getenv("M360_MASK_BLOCKS")) : 512;
 #else
 // one striding workgroup of the throttled mask kernel per CU.  Re-swept in round 6 beside the faster weight gradient
 // (profiles/r06/backward_mask_blocks_sweep_after_new_wgrad.txt: NeRF / proposal update in ms - 256: 23.4 / 9.4, 320: 25.4 / 9.6, 384: 25.0 / 9.8,
 // 448: 24.3 / 9.9, 512: 22.7 / 10.0, 640: 23.4 / 10.1): counts that are not a multiple of the CU count put two mask workgroups on some CUs
 // and slow those CUs' weight-gradient tiles; 512 gains on the 1024-wide layers what it loses on the 256-wide ones.  The pair is bound by HBM:
 // mask 3.2 GB + weight gradient 2.15 GB in ~0.9 ms is the 6.3 TB/s a copy reaches on this chip.
-constexpr int kBackwardMaskBlocks = 256;
+constexpr int kBackwardMaskBlocksWide = 512;
 #endif
+// ... hence by width: two mask workgroups per CU beside the one-wave weight gradient of the 1024-wide layers (whose 0.85 ms the one-per-CU mask
+// outlasted: 1.2 ms), one per CU beside the 8-wave kernel of the narrow ones
+static inline int backward_mask_blocks(int width) { return width >= 1024 ? kBackwardMaskBlocksWide : 256; }
 static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *const *w_t, float *const *grad_w, float *const *grad_b, const void *feat,
                              int in_pad, void *const *act, int width, long S, void *dz, void *dz_other, char *ws, const BwdLayout &L,
                              m360_stream_t st, const char *who) {
@@ -754,6 +757,7 @@ static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *con
     // (it meets every element anyway and runs beside, not in front of, the matrix work), where the weight-gradient kernel pays ~0.1 ms of its 1.0 for
     // them.  Its partial sums (2 MB) live in the finishers' backward scratch (read for the last time before this function runs).
     float *mask_part = reinterpret_cast<float *>(ws + L.finish);
+    const int kBackwardMaskBlocks = backward_mask_blocks(width);
     const bool mask_sums = ss && relu_mask_bf16_sums_ok(S, width, kBackwardMaskBlocks) && relu_mask_bf16_sums_bytes(kBackwardMaskBlocks) <= L.feat_wide - L.finish;
     const unsigned tuning = h ? h->tuning : 0u;
     bool have_bias = false;  // grad_b[l] already written (by the mask that produced this layer's dz)
