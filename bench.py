@@ -660,10 +660,13 @@ def named_workloads(sd_np, dev, _lib):
             x = torch.relu(torch.randn(M, HN, device=dev)).bfloat16()
             wt = ops.pack_linear_bf16_transposed(torch.randn(HN, HN, device=dev) / 32)
             dx = torch.empty(M, HN, device=dev, dtype=torch.bfloat16)
-            wgrad_ms = timed(lambda: ops.linear_wgrad_bf16(dz, x), 5)
+            # dW = dZ^T X with its split reduction - what six of the seven 1024-wide layers run (their bias gradient comes out of the ReLU-mask kernel
+            # beside it); the top layer also forms db on the matrix pipe: wgrad_with_bias_ms
+            wgrad_ms = timed(lambda: ops.linear_wgrad_bf16(dz, x, want_bias=False), 5)
+            wgrad_bias_ms = timed(lambda: ops.linear_wgrad_bf16(dz, x), 5)
             dgrad_ms = timed(lambda: ops.linear_dgrad_bf16(dz, wt, None, out=dx), 5)        # the GEMM alone (MFMA-bound)
             dgrad_serial_ms = timed(lambda: ops.linear_dgrad_bf16(dz, wt, x, out=dx), 5)    # + the ReLU mask pass behind it, one stream, full rate
-            peak, wk, dk = PEAK_BF16_MFMA_TFLOPS, "tn16w::linear_tn_bf16_w_kernel (one wave per SIMD, 128 x 128 wave tiles) + tn16_reduce_kernel (dW = dZ^T X on v_mfma_f32_16x16x32_bf16, operands transposed by ds_read_b64_tr_b16; bias gradient on the matrix pipe)", \
+            peak, wk, dk = PEAK_BF16_MFMA_TFLOPS, "tn16w::linear_tn_bf16_w_kernel (one wave per SIMD, 128 x 128 wave tiles, one read / LDS-DMA piece per MFMA gap) + tn16_reduce_kernel (dW = dZ^T X on v_mfma_f32_16x16x32_bf16, operands transposed by ds_read_b64_tr_b16; with_bias: + db on the matrix pipe and its reduction)", \
                 "linear_bf16_w16_kernel on the transposed bf16 packing (dX = dZ W; the ReLU mask is its own HBM-bound kernel: relu_mask_1024)"
         else:
             dz = torch.randn(M, HN, device=dev)
@@ -684,7 +687,8 @@ def named_workloads(sd_np, dev, _lib):
             "iteration_ms": round(it_ms, 2), "prop_update_ms": round(prop_ms, 2), "nerf_update_ms": round(nerf_ms, 2),
             "train_rays_per_s": round(n_rays / it_ms * 1e3, 1),
             "nerf_update_tflops": round(M * (423424 + 3 * 14807040) / nerf_ms / 1e9, 1),
-            "wgrad_1024x1024": {"ms": round(wgrad_ms, 3), "tflops": round(flops / wgrad_ms / 1e9, 1), "frac": round(flops / wgrad_ms / 1e9 / peak, 4), "kernel": wk},
+            "wgrad_1024x1024": {"ms": round(wgrad_ms, 3), "tflops": round(flops / wgrad_ms / 1e9, 1), "frac": round(flops / wgrad_ms / 1e9 / peak, 4), "kernel": wk,
+                                **({"with_bias_ms": round(wgrad_bias_ms, 3), "with_bias_frac": round(flops / wgrad_bias_ms / 1e9 / peak, 4)} if b16 else {})},
             "dgrad_1024x1024": {"ms": round(dgrad_ms, 3), "tflops": round(flops / dgrad_ms / 1e9, 1), "frac": round(flops / dgrad_ms / 1e9 / peak, 4), "kernel": dk},
             **({"relu_mask_1024": {
                 # dX *= [a > 0]: its own kernel with its own bound (HBM: dX in, the stored activation in, dX out = 6 bytes per element).  Timed as

@@ -133,7 +133,9 @@ def markdown(tag):
                 if "iteration_ms" in v:
                     out.append(f"* `{k}` (train.py:53-82 at 4096 x 128, {v.get('dtype', 'f32')}): **{v['iteration_ms']:.1f} ms per iteration = {v['train_rays_per_s']:.0f} rays/s** "
                                f"(proposal update {v['prop_update_ms']:.1f} ms x 2, NeRF update {v['nerf_update_ms']:.1f} ms = {v['nerf_update_tflops']:.1f} TF sustained); "
-                               f"wgrad 1024x1024 {v['wgrad_1024x1024']['ms']:.3f} ms = {v['wgrad_1024x1024']['tflops']:.1f} TF = {v['wgrad_1024x1024']['frac']:.3f}, "
+                               f"wgrad 1024x1024 {v['wgrad_1024x1024']['ms']:.3f} ms = {v['wgrad_1024x1024']['tflops']:.1f} TF = {v['wgrad_1024x1024']['frac']:.3f}"
+                               + (f" (with the bias gradient, top layer only: {v['wgrad_1024x1024']['with_bias_ms']:.3f} ms = {v['wgrad_1024x1024']['with_bias_frac']:.3f})" if "with_bias_ms" in v["wgrad_1024x1024"] else "") + ", "
+                               
                                f"dgrad {v['dgrad_1024x1024']['ms']:.3f} ms = {v['dgrad_1024x1024']['tflops']:.1f} TF = {v['dgrad_1024x1024']['frac']:.3f} of {v['peak']:.1f}"
                                + (f" (the GEMM; its ReLU mask is a kernel of its own: {v['relu_mask_1024']['ms']:.3f} ms = {v['relu_mask_1024']['achieved_GBps']:.0f} GB/s = "
                                   f"{v['relu_mask_1024']['frac_of_8TBps']:.3f} of 8 TB/s at full rate, GEMM + mask on one stream {v['relu_mask_1024']['dgrad_plus_mask_serial_ms']:.3f} ms; "
