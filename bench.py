@@ -336,10 +336,10 @@ def roofline_from_records(recs, S, bf16, config_name, _lib, x3=False):
     kk = 3 * HN if x3 else HN  # bf16x3: one contraction of length 3K (xh wh + xl wh + xh wl)
     # the 1024 x 1024 layers: one launch over all S rows
     hits = [r for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == kk]
-    chained = [r for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == 6 * HN] if bf16 and not x3 else []
+    chained = [r for r in recs if r["kind"] == lin_kind and r["n_pad"] == HN and r["k_pad"] == 6 * kk] if bf16 else []
     nlay = 1
     if chained and (not hits or max(r["M"] for r in chained) >= max(r["M"] for r in hits)):
-        hits, nlay = chained, 6  # bf16 mode: the six hidden layers in ONE launch (m360_mlp_chain_bf16), recorded as one kernel
+        hits, nlay = chained, 6  # bf16 / bf16x3 modes: the six hidden layers in ONE launch (m360_mlp_chain_bf16[x3]_safe), recorded as one kernel
     if not hits:
         return None
     rows = max(r["M"] for r in hits)

@@ -293,6 +293,12 @@ int m360_mlp_chain_bf16(void *act0_bf16, void *act1_bf16, long M, int ld, const 
 int m360_mlp_chain_bf16_safe(const void *x_in_bf16, void *act0_bf16, void *act1_bf16, long M, int ld, const void *const *w_packed_bf16 /*[layers]*/,
                              const float *const *b_packed /*[layers]*/, int layers, int width, void *workspace, const struct m360_hyper *opts,
                              m360_stream_t stream);
+/* The same for the bf16x3 mode's hidden layers (round 6; model.py:134-146 with every value as two bf16 terms): rows are [hi | lo] pairs
+ * (ld >= 2 width), weights those of m360_pack_linear_bf16x3 ([Wh | Wh | Wl]: 3 width per row), width 1024, M a multiple of 32768 - same bits as
+ * `layers` calls of m360_linear_bf16x3 on paired rows, same self-checks, same gated re-run. */
+int m360_mlp_chain_bf16x3_safe(const void *x_in_hi_lo_bf16, void *act0_hi_lo_bf16, void *act1_hi_lo_bf16, long M, int ld,
+                               const void *const *w_packed3_bf16 /*[layers]*/, const float *const *b_packed /*[layers]*/, int layers, int width,
+                               void *workspace, const struct m360_hyper *opts, m360_stream_t stream);
 /* The status block: the first 128 bytes of a chain workspace AND of every forward workspace (m360_forward_workspace_bytes).
  * m360_workspace_init zeroes its sticky counters (once, after allocating the workspace; m360_mlp_chain_bf16 does it per call);
  * m360_workspace_status copies it out and waits for the stream: out5 = {chain launches that ran, launches repaired by the gated re-run,

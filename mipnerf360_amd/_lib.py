@@ -117,6 +117,7 @@ SIGNATURES = {
     "m360_mlp_chain_bf16": (_i, [_vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _P(HyperStruct), _vp]),
     "m360_linear_bf16_rows_pairable": (_i, [_i, _i, _i]),
     "m360_mlp_chain_bf16_safe": (_i, [_vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _P(HyperStruct), _vp]),
+    "m360_mlp_chain_bf16x3_safe": (_i, [_vp, _vp, _vp, _l, _i, _vp, _vp, _i, _i, _vp, _P(HyperStruct), _vp]),
     "m360_workspace_init": (_i, [_vp, _vp]),
     "m360_workspace_status": (_i, [_vp, _P(C.c_uint), _vp]),
     "m360_pack_linear_bf16x6": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

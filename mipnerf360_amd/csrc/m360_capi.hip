@@ -79,9 +79,9 @@ int nerf_finish_backward_bf16(const void *act, int ld, const float *head_w, cons
                               size_t workspace_bytes, m360_stream_t stream);
 // m360_linear.hip: the hidden-layer chain of the bf16 mode (one launch) and its gated layer-by-layer re-run
 int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
-                          int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts);
+                          int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts, bool x3);
 int mlp_chain_bf16_rerun(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
-                         int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts);
+                         int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts, bool x3);
 // m360_linear.hip: the ReLU mask of m360_linear_dgrad_bf16 on its own (mlp_backward_bf16 overlaps it with the weight gradient)
 int relu_mask_bf16(void *dx, const void *relu_out, long M, int k_pad, int ldx, m360_stream_t stream, int blocks /* > 0: that many striding workgroups */,
                    float *sums_part /* != NULL: [blocks][k_pad] column sums of the masked rows per workgroup */);
@@ -120,7 +120,7 @@ struct ProfScope {
 static inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FwdLayout {
-    size_t norm, vdenc, t1, t0, what, feat, act_a, act_b, hpart, queues, nanflag, chain, total;
+    size_t norm, vdenc, t1, t0, what, feat, act_a, act_b, act_c, hpart, queues, nanflag, chain, total;
 };
 // tile-queue words of the balanced linear launches of one stage (m360_linear_balanced): 16 words, one per 64-byte line
 constexpr int kQueueSlots = 16, kQueueStride = 16;
@@ -159,6 +159,10 @@ static FwdLayout layout_for(int B, int N, const m360_model_t *m) {
     L.feat = take(S * m->in_pad * (m->mlp_bf16 == 2 ? 6 * sizeof(unsigned short) : sizeof(float)));  // bf16: [hi | lo] pairs = 4 bytes per value too
     L.act_a = take(S * wmax * sizeof(float));
     L.act_b = take(S * wmax * sizeof(float));
+    // (bf16x3 mode: m360_mlp_chain_bf16x3_safe exists and is bit-identical, but the forward does not use it - measured in round 6: 16.98 against
+    // 17.01 ms per step with six launches (three matrix passes per byte of activations: the round trip through HBM is not what bounds those
+    // layers), and its [hi | lo] rows fill a and b completely, so the chain's untouched third input buffer would cost 2.1 GB more workspace)
+    L.act_c = 0;
     // partial head sums of the fused last layer: [S][slots][heads] fp32 (67 MB at 4096 x 128, width 1024)
     // sized by the rows the fused epilogue really covers: none in bf16 mode or at widths it does not take
     const size_t hp_slots = (size_t)m360_linear_heads_slots(m->hp_pad, m->mlp_bf16), hn_slots = (size_t)m360_linear_heads_slots(m->hn_pad, m->mlp_bf16);
@@ -448,17 +452,17 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         // With the chain the first layer writes to a THIRD buffer - the upper half of `a`, which is sized for fp32 rows and holds bf16 ones
         // here - that no hidden layer writes: what the chain read stays intact, so the launch can be repeated layer by layer when it reports
         // that one of its assumptions did not hold (gated launches queued behind it: empty unless its error word is set).
-        float *first = chain ? reinterpret_cast<float *>(reinterpret_cast<char *>(a) + (size_t)S * ldl * 2) : a;
+        float *first = !chain ? a : mode == 2 ? reinterpret_cast<float *>(ws + L.act_c) : reinterpret_cast<float *>(reinterpret_cast<char *>(a) + (size_t)S * ldl * 2);
         M360_TRY(p_linear_first(h, mode, feat, S, m->nerf_w[0], m->nerf_b[0], hn, m->in_pad, first, pair, st));
         if (chain) {
             const void *cw[6];
             const float *cb[6];
             for (int layer = 1; layer < 7; ++layer) { cw[layer - 1] = m->nerf_w[layer]; cb[layer - 1] = m->nerf_b[layer]; }
             {
-                ProfScope ps(h, st, M360_K_LINEAR_BF16, Mc, hn, 6 * hn);  // k_pad = 6 hn: six layers in one record (the chain kernel alone)
-                M360_TRY(ps.done(mlp_chain_bf16_launch(first, a, b, Mc, hn, cw, cb, 6, hn, ws + L.chain, st, h)));
+                ProfScope ps(h, st, M360_K_LINEAR_BF16, Mc, hn, (mode == 2 ? 18 : 6) * hn);  // k_pad = 6 hn (bf16x3: 6 x 3 hn): six layers in one record (the chain kernel alone)
+                M360_TRY(ps.done(mlp_chain_bf16_launch(first, a, b, Mc, ldl, cw, cb, 6, hn, ws + L.chain, st, h, mode == 2)));
             }
-            M360_TRY(mlp_chain_bf16_rerun(first, a, b, Mc, hn, cw, cb, 6, hn, ws + L.chain, st, h));
+            M360_TRY(mlp_chain_bf16_rerun(first, a, b, Mc, ldl, cw, cb, 6, hn, ws + L.chain, st, h, mode == 2));
         }
         const long r0 = chain ? Mc : 0;  // rows [r0, S) layer by layer; both parts end in `a`: first -> b -> a -> b -> a -> b -> a
         if (r0 < S) {

@@ -805,7 +805,7 @@ int chain_opts_ok(const m360_hyper_t *opts, const char *who) {
 }
 
 int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
-                          int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts) {
+                          int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts, bool x3) {
     const int rc_opts = chain_opts_ok(opts, "m360_mlp_chain_bf16");
     if (rc_opts != M360_OK) return rc_opts;
     w16::chain_t ch;
@@ -830,7 +830,10 @@ int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (hipMemsetAsync(static_cast<char *>(ws) + w16::kChainStatusLaunchOffset, 0, m360_mlp_chain_bf16_workspace(M, layers) - w16::kChainStatusLaunchOffset, st) != hipSuccess)
         return fail(M360_ERR_LAUNCH, "m360_mlp_chain_bf16: hipMemsetAsync failed");
-    auto kern = w16::linear_bf16_w16_kernel<M360_ACT_RELU, 128, false, false, false, 0, false, false, true, true>;
+    // bf16: rows of `width` bf16, weights [width, width]; bf16x3: [hi | lo] rows of 2 width, weights [Wh | Wh | Wl] of 3 width (m360_linear_bf16x3)
+    auto kern = x3 ? w16::linear_bf16_w16_kernel<M360_ACT_RELU, 128, false, true, false, 0, true, false, true, true>
+                   : w16::linear_bf16_w16_kernel<M360_ACT_RELU, 128, false, false, false, 0, false, false, true, true>;
+    int kp = x3 ? 3 * width : width;
     const __bf16 *X = ch.x_in ? ch.x_in : ch.act[0], *W0 = ch.w[0];
     const float *B0 = ch.b[0], *hw = nullptr;
     __bf16 *Y = ch.act[1];
@@ -840,11 +843,11 @@ int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int 
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool coop = opts && (opts->tuning & M360_TUNE_CHAIN_COOPERATIVE) && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
     if (coop) {  // co-residency of the 256 workgroups asked of the runtime (A/B: M360_TUNE_CHAIN_COOPERATIVE)
-        void *args[] = {&X, &M, &ld, &W0, &B0, &width, &width, &Y, &ld, &tiles_n, &ntiles, &hw, &hp, &xpair, &stagger, &ch, &gate, &gate_first};
+        void *args[] = {&X, &M, &ld, &W0, &B0, &width, &kp, &Y, &ld, &tiles_n, &ntiles, &hw, &hp, &xpair, &stagger, &ch, &gate, &gate_first};
         if (hipLaunchCooperativeKernel(reinterpret_cast<void *>(kern), dim3(256), dim3(w16::kThreads), args, 0, st) != hipSuccess)
             return fail(M360_ERR_LAUNCH, "m360_mlp_chain_bf16: cooperative launch failed: %s", hipGetErrorString(hipGetLastError()));
     } else {
-        hipLaunchKernelGGL(kern, dim3(256), dim3(w16::kThreads), 0, st, X, M, ld, W0, B0, width, width, Y, ld, tiles_n, ntiles, hw, hp, xpair, stagger, ch, gate, gate_first);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(w16::kThreads), 0, st, X, M, ld, W0, B0, width, kp, Y, ld, tiles_n, ntiles, hw, hp, xpair, stagger, ch, gate, gate_first);
     }
     return check_launch("mlp_chain_bf16");
 }
@@ -854,7 +857,7 @@ int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int 
 // its XCD, these launches redo all of its rows from x_in (which the chain never writes) - the very kernel m360_linear_bf16 runs for a
 // hidden layer on paired rows, hence the same bits.  No host round trip, nothing for a caller to check before using the result.
 int mlp_chain_bf16_rerun(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
-                         int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts) {
+                         int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts, bool x3) {
 #ifdef M360_DIAG
     if (opts && (opts->tuning & M360_TUNE_CHAIN_UNGATED)) return M360_OK;  // A/B of the gated launches' cost: the chain alone, unchecked
 #endif
@@ -868,6 +871,11 @@ int mlp_chain_bf16_rerun(const void *x_in, void *act0, void *act1, long M, int l
     __bf16 *act[2] = {static_cast<__bf16 *>(act0), static_cast<__bf16 *>(act1)};
     for (int j = 0; j < layers; ++j) {
         const __bf16 *src = j == 0 ? static_cast<const __bf16 *>(x_in) : act[j & 1];
+        if (x3)
+            hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, true, false, 0, true, false, true>), grid, block, 0, st, src, M, ld,
+                               static_cast<const __bf16 *>(w_packed[j]), b_packed[j], width, 3 * width, act[(j + 1) & 1], ld, width / w16::BN, (int)nt, nullptr, nullptr, 1, 0,
+                               w16::chain_t(), gate, j == 0 ? 1 : 0);
+        else
         hipLaunchKernelGGL((w16::linear_bf16_w16_kernel<M360_ACT_RELU, 0, false, false, false, 0, false, false, true>), grid, block, 0, st, src, M, ld,
                            static_cast<const __bf16 *>(w_packed[j]), b_packed[j], width, width, act[(j + 1) & 1], ld, width / w16::BN, (int)nt, nullptr, nullptr, 1, 0,
                            w16::chain_t(), gate, j == 0 ? 1 : 0);
@@ -876,8 +884,9 @@ int mlp_chain_bf16_rerun(const void *x_in, void *act0, void *act1, long M, int l
 }
 
 static int chain_args_ok(const char *who, const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
-                         int layers, int width, void *workspace) {
+                         int layers, int width, void *workspace, bool x3 = false) {
     if (!act0 || !act1 || !w_packed || !b_packed || !workspace) return fail(M360_ERR_INVALID_ARGUMENT, "%s: null pointer", who);
+    if (x3 && (ld < 2 * width || width != 4 * w16::BN)) return fail(M360_ERR_INVALID_ARGUMENT, "%s: [hi | lo] rows need ld=%d >= 2 width=%d, width 1024", who, ld, width);
     if (ld < width || ld % 8 != 0 || (((uintptr_t)x_in | (uintptr_t)act0 | (uintptr_t)act1 | (uintptr_t)workspace) & 15))
         return fail(M360_ERR_INVALID_ARGUMENT, "%s: ld=%d >= width=%d, a multiple of 8; 16-byte aligned pointers", who, ld, width);
     if (!m360_mlp_chain_bf16_supported(M, width, layers))
@@ -895,7 +904,7 @@ int m360_mlp_chain_bf16(void *act0, void *act1, long M, int ld, const void *cons
     if (rc != M360_OK) return rc;
     const int rc2 = m360_workspace_init(workspace, stream);  // a standalone call's status is its own
     if (rc2 != M360_OK) return rc2;
-    return mlp_chain_bf16_launch(nullptr, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream, opts);
+    return mlp_chain_bf16_launch(nullptr, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream, opts, false);
 }
 
 int m360_mlp_chain_bf16_safe(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
@@ -904,9 +913,19 @@ int m360_mlp_chain_bf16_safe(const void *x_in, void *act0, void *act1, long M, i
     const int rc = chain_args_ok("m360_mlp_chain_bf16_safe", x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace);
     if (rc != M360_OK) return rc;
     if (width != 4 * w16::BN) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16_safe: width=%d (1024: the NeRF MLP's hidden layers)", width);
-    const int rc2 = mlp_chain_bf16_launch(x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream, opts);
+    const int rc2 = mlp_chain_bf16_launch(x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream, opts, false);
     if (rc2 != M360_OK) return rc2;
-    return mlp_chain_bf16_rerun(x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream, opts);
+    return mlp_chain_bf16_rerun(x_in, act0, act1, M, ld, w_packed, b_packed, layers, width, workspace, stream, opts, false);
+}
+
+int m360_mlp_chain_bf16x3_safe(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed3, const float *const *b_packed,
+                               int layers, int width, void *workspace, const m360_hyper_t *opts, m360_stream_t stream) {
+    if (!x_in || x_in == act0 || x_in == act1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_mlp_chain_bf16x3_safe: x_in must be a third buffer (the re-run reads it again)");
+    const int rc = chain_args_ok("m360_mlp_chain_bf16x3_safe", x_in, act0, act1, M, ld, w_packed3, b_packed, layers, width, workspace, true);
+    if (rc != M360_OK) return rc;
+    const int rc2 = mlp_chain_bf16_launch(x_in, act0, act1, M, ld, w_packed3, b_packed, layers, width, workspace, stream, opts, true);
+    if (rc2 != M360_OK) return rc2;
+    return mlp_chain_bf16_rerun(x_in, act0, act1, M, ld, w_packed3, b_packed, layers, width, workspace, stream, opts, true);
 }
 
 int m360_pack_linear_bf16x6(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed6,

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
     __shared__ __attribute__((aligned(1024))) char smem[2 * kStageBytes + kMaxBias * 4 + (HEADS ? 2 * 4 * kHeadMaxN * 2 : 0) + (LDSEPI ? 4 * 4096 : 0)];  // 144 (160) KiB
     static_assert(!LDSEPI || (HEADS == 0 && !SPLIT && !X3 && !PAIR), "the LDS epilogue: plain bf16 output (its 16 KiB sit where the head rows would)");
     static_assert(!PAIR || HEADS == 0, "paired rows are a layout of the layer's own output");
-    static_assert(!CHAIN || (PAIR && !X3 && !ONE_BLOCK && !SPLIT && HEADS == 0 && ACT == M360_ACT_RELU), "the layer chain: plain bf16 ReLU layers on paired rows");
+    // (round 6: the chain takes the bf16x3 hidden layers too - X3 with its [hi | lo] split output)
+    static_assert(!CHAIN || (PAIR && !ONE_BLOCK && SPLIT == X3 && HEADS == 0 && ACT == M360_ACT_RELU), "the layer chain: bf16 / bf16x3 ReLU layers on paired rows");
     static_assert(HEADS == 0 || HEADS == 1 || HEADS == 4, "1 (proposal) or 4 (NeRF) heads");
     // X3 loop + plain bf16 output: the first layer of the bf16 mode (two-term features and weights in, one bf16 term out)
     static_assert(SPLIT == X3 || HEADS == 0, "X3 loop and split output go together wherever the heads are fused");
@@ -504,6 +505,12 @@ __global__ __launch_bounds__(kThreads, 1) void linear_bf16_w16_kernel(
                 W16X_T3L();   // this body behind a run-time branch of the general kernel its 1024^2 layer took 2.42 instead of 2.21 ms)
             } else {
                 W16X_T3();
+                // CHAIN: stages 0 and 1 of a tile are the only ones whose counted waits still let the previous tile's stores stay in flight
+                // (the generator's "@0" / "@1" bodies): behind the first T3 they have retired - the tile is counted here
+                if (CHAIN && ch_pending) {
+                    if (lane == 0) __hip_atomic_fetch_add(ch.done + (long)(blockIdx.x & 7) * ch_T + (tile_id - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ch_pending = false;
+                }
                 for (int b = 1; b < nstages - 1; ++b) {
                     W16X_T1();
                     W16X_T2();

@@ -810,6 +810,23 @@ def mlp_chain_bf16(act0, act1, packs):
     return act0 if L % 2 == 0 else act1
 
 
+def mlp_chain_bf16x3_safe(x_in, act0, act1, packs3):
+    """m360_mlp_chain_bf16x3_safe: the bf16x3 mode's hidden layers in one launch - [hi | lo] rows [M, 2 width] (paired), packs3 =
+    [(w_packed3 [width, 3 width], b_packed), ...] of pack_linear_bf16x3 -> (result buffer, status dict of this call)."""
+    import ctypes as C
+    x_in, act0, act1 = dev_bf16(x_in, "x_in"), dev_bf16(act0, "act0"), dev_bf16(act1, "act1")
+    M, ld = act0.shape
+    L = len(packs3)
+    width = packs3[0][0].shape[0]
+    ws = torch.empty(int(_lib.lib().m360_mlp_chain_bf16_workspace(M, L)) // 4 + 4, device=act0.device, dtype=torch.int32)
+    wl = (C.c_void_p * L)(*[dev_bf16(w, "w").data_ptr() for w, _ in packs3])
+    bl = (C.c_void_p * L)(*[dev(b, "b").data_ptr() for _, b in packs3])
+    workspace_init(ws)
+    opts = _opts_struct()
+    _call("m360_mlp_chain_bf16x3_safe", x_in, act0, act1, M, ld, C.cast(wl, C.c_void_p), C.cast(bl, C.c_void_p), L, width, ws, C.byref(opts), STREAM)
+    return (act0 if L % 2 == 0 else act1), workspace_status(ws)
+
+
 def mlp_chain_bf16_safe(x_in, act0, act1, packs):
     """m360_mlp_chain_bf16_safe: layer 0 reads x_in (never written), layer j writes act[(j + 1) & 1]; a launch that reports an error is redone
     layer by layer by the gated launches queued behind it -> (result buffer, status dict of this call)."""

@@ -372,3 +372,63 @@ def test_bf16_forward_in_a_captured_hip_graph(dev, diag, fault):
     with torch.cuda.stream(side):
         after = model.chain_status()
     assert after["launches"] - before["launches"] == 3 and after["recoveries"] - before["recoveries"] == (3 if fault else 0), (before, after)
+
+
+# ------------------------------------------------------------------------------- round 6: the chain for the bf16x3 hidden layers
+# (m360_mlp_chain_bf16x3_safe: built, bit-identical, self-checking like the bf16 one - and NOT used by the forward: 16.98 against 17.01 ms per
+# step, profiles/r06/bf16x3_chain_NO_GAIN.txt.  The op and its tests stay: the kernel's CHAIN form is one template for both modes.)
+def _packs_x3(width, layers, dev, seed):
+    from mipnerf360_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    packs = []
+    for _ in range(layers):
+        w = (torch.randn(width, width, generator=g) * (2.0 / width) ** 0.5).to(dev)
+        b = (torch.randn(width, generator=g) * 0.1).to(dev)
+        packs.append(ops.pack_linear_bf16x3(w, b, width, width))
+    return packs, g
+
+
+def _hi_lo(v):
+    hi = v.bfloat16()
+    return torch.cat([hi, (v - hi.float()).bfloat16()], dim=1).contiguous()
+
+
+def _layer_by_layer_x3(x, packs):
+    from mipnerf360_amd import _lib, ops
+    flags = _lib.ACT_RELU | _lib.ROWS_PAIRED_IN | _lib.ROWS_PAIRED_OUT
+    for wp, bp in packs:
+        x = ops.linear_bf16x3(x, wp, bp, flags)
+    return x
+
+
+@pytest.mark.parametrize("M,layers", [(32768, 6), (65536, 3), (32768, 1)])
+def test_x3_chain_clean_launch(dev, M, layers):
+    """m360_mlp_chain_bf16x3_safe: the bf16x3 mode's hidden layers ([hi | lo] rows, three products per 64-deep block) in ONE launch -
+    bit for bit what `layers` calls of m360_linear_bf16x3 on paired rows give, x_in untouched, one clean launch in the counters."""
+    from mipnerf360_amd import ops
+    _skip_unless_chain(M, 1024, layers)
+    packs, g = _packs_x3(1024, layers, dev, 200 + layers)
+    x = ops.pair_rows(_hi_lo(torch.randn(M, 1024, generator=g).to(dev)))
+    keep = x.clone()
+    for rep in range(2):
+        a, b = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+        got, st = ops.mlp_chain_bf16x3_safe(x, a, b, packs)
+        assert torch.equal(x, keep)
+        want = _layer_by_layer_x3(keep, packs)
+        assert torch.equal(got, want), (rep, int((got != want).sum()))
+        assert st == dict(launches=1, recoveries=0, timeouts=0, xcc_mismatch=0, last_error=0), st
+
+
+@pytest.mark.parametrize("fault", [1, 2])
+def test_x3_chain_repairs_an_injected_fault(dev, diag, fault):
+    from mipnerf360_amd import ops
+    _skip_unless_chain()
+    packs, g = _packs_x3(1024, 6, dev, 17 + fault)
+    x = ops.pair_rows(_hi_lo(torch.randn(65536, 1024, generator=g).to(dev)))
+    want = _layer_by_layer_x3(x, packs)
+    ops.set_chain_debug(0, fault)
+    a, b = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+    got, st = ops.mlp_chain_bf16x3_safe(x, a, b, packs)
+    ops.set_chain_debug(0, 0)
+    assert st["launches"] == 1 and st["recoveries"] == 1 and st["last_error"] == (2 if fault == 1 else 1), st
+    assert torch.equal(got, want), (fault, int((got != want).sum()))
