@@ -795,7 +795,7 @@ def test_ring_kernel_store_instructions_match_its_counted_waits(tmp_path):
         assert got == want, f"{m.group(1)}: {got} store instructions, the counted waits assume {want}"
         assert "scratch_" not in body, f"{m.group(1)} spills"
         seen += 1
-    assert seen >= 24 and paired >= 10 and chains == 2 and keeps == 2,  # chains: the bf16 one and (round 6) the bf16x3 one f"only {seen} ring-kernel instantiations found ({paired} with paired rows out, {chains} layer chain, {keeps} keeping y beside the heads)"
+    assert seen >= 24 and paired >= 10 and chains == 2 and keeps == 2, f"(chains: the bf16 one and, since round 6, the bf16x3 one) only {seen} ring-kernel instantiations found ({paired} with paired rows out, {chains} layer chain, {keeps} keeping y beside the heads)"
     assert split_without_x3 == 4, "the x6 first layer of the bf16x3 mode (plain K loop, [hi | lo] output; none / ReLU / ReLU with paired rows out, with non-temporal or temporal stores) is missing"
 
 
