@@ -6,7 +6,7 @@
 # (Rounds 1-5 kept ~70 one-off steps here - probes, ablations, A/B runs; their outputs are profiles/r0N/, the recipes are in git history.)
 tag=${1:-r06}; shift
 out=gpurun_out/$tag; mkdir -p $out
-steps=${@:-tests smoke bench prof pmc16 finpmc bf16 c5 x3 x3c5 b16prof train16 c4 c4b16 gloo2}
+steps=${@:-tests smoke prof pmc16 summarize bench finpmc bf16 c5 x3 x3c5 b16prof train16 c4 c4b16 gloo2}
 R=$PWD; O=$R/$out
 PMC="--kernel-trace --output-format csv"
 stamp() { python3 -c "import bench, json; print(json.dumps({'fp32': bench.kernel_source_sha(), 'bf16': bench.kernel_source_sha(bench.TRAFFIC_SOURCES_BF16)}))" > $O/$1; }
@@ -14,6 +14,8 @@ for s in $steps; do
   case $s in
     tests)   timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/pytest_gpu.log; tail -5 $out/pytest_gpu.log ;;
     smoke)   timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -2 $out/smoke.log ;;
+    summarize) # profiles/traffic.json from the counter passes of THIS call, so that the bench lines behind it carry this round's counter traffic
+             cp $out/bench.json $out/bench_before_counters.json 2>/dev/null; python3 tools/summarize_profiles.py $tag > $out/summarize.log 2>&1; tail -3 $out/summarize.log ;;
     bench)   timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; tail -c 3000 $out/bench.json ;;
     bf16)    timeout 900 python bench.py --mlp-dtype bf16 --cpu-rays 0 > $out/bench_bf16.json 2> $out/bench_bf16.err; tail -c 2500 $out/bench_bf16.json ;;
     c5)      timeout 900 python bench.py --config c5 > $out/bench_c5.json 2> $out/bench_c5.err; tail -c 2500 $out/bench_c5.json ;;
