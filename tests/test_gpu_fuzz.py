@@ -129,9 +129,11 @@ def test_nerf_step_gradients_any_shape_vs_oracle(dev, B, n, hp, hn, wb, seed):
         if name.startswith("nerf_net"):
             want = og[name].numpy()
             scale = max(float(np.abs(want).max()), 1e-12)
-            # fp32 sums in another order than autograd's, through up to eight layers: 2e-4 of a tensor's scale on the fixtures' shapes; the worst
-            # of 100 random shapes (M360_FUZZ_SCALE=10: B = 35, n = 34, first-layer weight) reached 4.3e-4
-            assert float(np.abs(H(p.grad) - want).max()) <= 1e-3 * scale + 1e-9, (name, float(np.abs(H(p.grad) - want).max()) / scale)
+            # fp32 sums in another order than autograd's, through up to eight layers: 2e-4 of a tensor's scale on the fixtures' shapes.  On
+            # small random nets a pre-activation within an ulp of zero takes the other side of its ReLU in one of the two implementations and
+            # that sample's whole contribution to the unit's gradient flips: the worst of 2 x 100 random shapes (M360_FUZZ_SCALE=10: B = 14,
+            # n = 62, 32-wide nets - 868 samples) reached 2.8e-3.  This sweep is after indexing / ragged-shape errors, which are orders above.
+            assert float(np.abs(H(p.grad) - want).max()) <= 1e-2 * scale + 1e-9, (name, float(np.abs(H(p.grad) - want).max()) / scale)
 
 
 @settings(**{**SETTINGS, "max_examples": 12 * _SCALE})
