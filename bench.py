@@ -79,6 +79,25 @@ TRAFFIC_SOURCES_BF16 = ("mipnerf360_amd/csrc/m360_linear_bf16_w16.hip.h", "mipne
                         "mipnerf360_amd/csrc/m360_linear.hip", "mipnerf360_amd/csrc/m360_common.hip.h")
 
 
+# ... and the gradient GEMMs of the training path (weight gradient: the tn kernels; input gradient: the forward kernels on transposed packings)
+TRAFFIC_SOURCES_TRAIN = ("mipnerf360_amd/csrc/m360_linear.hip", "mipnerf360_amd/csrc/m360_common.hip.h", "mipnerf360_amd/csrc/m360_linear_tn.hip.h",
+                         "mipnerf360_amd/csrc/m360_linear_tn_bf16.hip.h", "mipnerf360_amd/csrc/m360_linear_tn_bf16_w.hip.h",
+                         "mipnerf360_amd/csrc/m360_linear_persist.hip.h", "mipnerf360_amd/csrc/m360_linear_bf16_w16.hip.h",
+                         "mipnerf360_amd/csrc/m360_linear_bf16_w16_gen.inc")
+
+
+def training_gemm_traffic(dtype_key):
+    """{'wgrad': {...}, 'dgrad': {...}[, 'relu_mask': {...}]} of profiles/traffic.json's training_gemms for 'bf16' / 'fp32' (fabric-side counter
+    bytes per launch from separate --pmc passes, tools/gpu_session.sh pmctrain), or {} when absent or measured on other kernel sources."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return {}
+    tg = json.load(open(tpath)).get("training_gemms") or {}
+    if tg.get("kernel_source_sha256") != kernel_source_sha(TRAFFIC_SOURCES_TRAIN):
+        return {}
+    return tg.get(dtype_key) or {}
+
+
 def kernel_source_sha(sources=None):
     h = hashlib.sha256()
     for rel in (sources or TRAFFIC_SOURCES):
@@ -678,6 +697,17 @@ def named_workloads(sd_np, dev, _lib):
             peak, wk, dk = PEAK_F32_MFMA_TFLOPS, "linear_tn_kernel + tn_reduce_kernel (dW = dZ^T X, bias gradient fused)", "linear_f32_mfma_persist_kernel<RELU_MASK> (dX = (dZ W) * [a > 0])"
         del dz, x, dx, wt
         torch.cuda.empty_cache()
+        tg = training_gemm_traffic("bf16" if b16 else "fp32")
+        el_ = 2 if b16 else 4
+
+        def with_traffic(entry, key, algorithmic):
+            entry["algorithmic_bytes"] = algorithmic
+            if key in tg:
+                entry["traffic"] = tg[key]["bytes_per_launch"]
+                entry["traffic_note"] = "fabric-side counter bytes per launch (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950 corrections; Infinity-Cache hits included)"
+            else:
+                entry["traffic"] = None
+            return entry
         out[name] = {
             "config": "c2", "dtype": "bf16" if b16 else "f32", "finite": finite,
             "workload": f"one iteration of the reference's training loop body (train.py:53-82) at 4096 rays x 128 samples, full width, {MLP_NAMES[mlp_dtype]}: "
@@ -687,9 +717,13 @@ def named_workloads(sd_np, dev, _lib):
             "iteration_ms": round(it_ms, 2), "prop_update_ms": round(prop_ms, 2), "nerf_update_ms": round(nerf_ms, 2),
             "train_rays_per_s": round(n_rays / it_ms * 1e3, 1),
             "nerf_update_tflops": round(M * (423424 + 3 * 14807040) / nerf_ms / 1e9, 1),
-            "wgrad_1024x1024": {"ms": round(wgrad_ms, 3), "tflops": round(flops / wgrad_ms / 1e9, 1), "frac": round(flops / wgrad_ms / 1e9 / peak, 4), "kernel": wk,
-                                **({"with_bias_ms": round(wgrad_bias_ms, 3), "with_bias_frac": round(flops / wgrad_bias_ms / 1e9 / peak, 4)} if b16 else {})},
-            "dgrad_1024x1024": {"ms": round(dgrad_ms, 3), "tflops": round(flops / dgrad_ms / 1e9, 1), "frac": round(flops / dgrad_ms / 1e9 / peak, 4), "kernel": dk},
+            # algorithmic bytes: dW reads dZ and X once and writes [1024, 1024] fp32 (+ its split partials, which are the kernel's own business);
+            # dX reads dZ and the 1024 x 1024 weights and writes dX (fp32: + the stored activation for the fused ReLU mask)
+            "wgrad_1024x1024": with_traffic({"ms": round(wgrad_ms, 3), "tflops": round(flops / wgrad_ms / 1e9, 1), "frac": round(flops / wgrad_ms / 1e9 / peak, 4), "kernel": wk,
+                                             **({"with_bias_ms": round(wgrad_bias_ms, 3), "with_bias_frac": round(flops / wgrad_bias_ms / 1e9 / peak, 4)} if b16 else {})},
+                                            "wgrad", 2 * M * HN * el_ + HN * HN * 4),
+            "dgrad_1024x1024": with_traffic({"ms": round(dgrad_ms, 3), "tflops": round(flops / dgrad_ms / 1e9, 1), "frac": round(flops / dgrad_ms / 1e9 / peak, 4), "kernel": dk},
+                                            "dgrad", (2 if b16 else 3) * M * HN * el_ + HN * HN * el_),
             **({"relu_mask_1024": {
                 # dX *= [a > 0]: its own kernel with its own bound (HBM: dX in, the stored activation in, dX out = 6 bytes per element).  Timed as
                 # (GEMM + mask on one stream) - (GEMM alone): the mask at full rate.  In the training iteration it runs THROTTLED on a second stream
@@ -697,7 +731,7 @@ def named_workloads(sd_np, dev, _lib):
                 "ms": round(dgrad_serial_ms - dgrad_ms, 3), "bound": "hbm", "algorithmic_bytes": 3 * M * HN * 2,
                 "achieved_GBps": round(3 * M * HN * 2 / max(dgrad_serial_ms - dgrad_ms, 1e-6) / 1e6, 1),
                 "frac_of_8TBps": round(3 * M * HN * 2 / max(dgrad_serial_ms - dgrad_ms, 1e-6) / 1e6 / PEAK_HBM_GBPS, 3),
-                "dgrad_plus_mask_serial_ms": round(dgrad_serial_ms, 3),
+                "dgrad_plus_mask_serial_ms": round(dgrad_serial_ms, 3), "traffic": (tg.get("relu_mask") or {}).get("bytes_per_launch"),
                 "kernel": "relu_mask_bf16_kernel (16-byte pieces, whole rows per workgroup)"}} if b16 else {}),
             "peak": peak, "unit": "TFLOP/s", "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
 

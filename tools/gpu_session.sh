@@ -6,7 +6,7 @@
 # (Rounds 1-5 kept ~70 one-off steps here - probes, ablations, A/B runs; their outputs are profiles/r0N/, the recipes are in git history.)
 tag=${1:-r06}; shift
 out=gpurun_out/$tag; mkdir -p $out
-steps=${@:-tests smoke prof pmc16 summarize bench finpmc bf16 c5 x3 x3c5 b16prof train16 c4 c4b16 gloo2}
+steps=${@:-tests smoke prof pmc16 pmctrain summarize bench finpmc bf16 c5 x3 x3c5 b16prof train16 c4 c4b16 gloo2}
 R=$PWD; O=$R/$out
 PMC="--kernel-trace --output-format csv"
 stamp() { python3 -c "import bench, json; print(json.dumps({'fp32': bench.kernel_source_sha(), 'bf16': bench.kernel_source_sha(bench.TRAFFIC_SOURCES_BF16)}))" > $O/$1; }
@@ -45,6 +45,15 @@ for s in $steps; do
              done
              stamp kernel_source_sha256_at_measurement_b16.json
              find $O -name "*.db" -delete 2>/dev/null; ls -d $O/pmc_c*_sq/*/ | head -3 ;;
+    pmctrain) # counter traffic of the training GEMMs (weight gradient, input gradient, ReLU mask) of one 1024 x 1024 layer on 524 288 rows, bf16 and fp32
+             for w in "bf16:--mlp-dtype bf16" "fp32:"; do
+               k=${w%%:*}; B="python3 $R/tools/train_step_bench.py ${w#*:} --gemm-only --iters 3"
+               ( cd /tmp && export TMPDIR=/tmp
+                 timeout 600 rocprofv3 $PMC --pmc FETCH_SIZE -d $O/pmc_train_${k}_fetch -- $B > $O/pmc_train_${k}_fetch.log 2>&1
+                 timeout 600 rocprofv3 $PMC --pmc WRITE_SIZE -d $O/pmc_train_${k}_write -- $B > $O/pmc_train_${k}_write.log 2>&1 )
+             done
+             python3 -c "import bench, json; print(json.dumps({'train': bench.kernel_source_sha(bench.TRAFFIC_SOURCES_TRAIN)}))" > $O/kernel_source_sha256_at_measurement_train.json
+             find $O -name "*.db" -delete 2>/dev/null; ls -d $O/pmc_train_*/*/ | head -4 ;;
     b16prof) ( cd /tmp && export TMPDIR=/tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b16 -- python3 $R/bench.py --mlp-dtype bf16 --steps 5 --warmup 2 --cpu-rays 0 > $O/bench_b16_under_rocprof.log 2>&1
                timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_x3 -- python3 $R/bench.py --mlp-dtype bf16x3 --steps 5 --warmup 2 --cpu-rays 0 > $O/bench_x3_under_rocprof.log 2>&1 )
              find $O/stats_b16 $O/stats_x3 -name "*.db" -delete 2>/dev/null

@@ -140,6 +140,9 @@ def markdown(tag):
                                + (f" (the GEMM; its ReLU mask is a kernel of its own: {v['relu_mask_1024']['ms']:.3f} ms = {v['relu_mask_1024']['achieved_GBps']:.0f} GB/s = "
                                   f"{v['relu_mask_1024']['frac_of_8TBps']:.3f} of 8 TB/s at full rate, GEMM + mask on one stream {v['relu_mask_1024']['dgrad_plus_mask_serial_ms']:.3f} ms; "
                                   f"in the iteration it runs throttled beside the weight gradient)" if v.get("relu_mask_1024") else "")
+                               + (f"; counter traffic: wgrad {v['wgrad_1024x1024']['traffic'] / 1e9:.2f} GB against {v['wgrad_1024x1024']['algorithmic_bytes'] / 1e9:.2f} GB algorithmic, "
+                                  f"dgrad {v['dgrad_1024x1024']['traffic'] / 1e9:.2f} against {v['dgrad_1024x1024']['algorithmic_bytes'] / 1e9:.2f}"
+                                  if v["wgrad_1024x1024"].get("traffic") and v["dgrad_1024x1024"].get("traffic") else "")
                                + f"; peak memory {v['peak_mem_gb']:.1f} GB")
                 else:
                     r_ = v.get("roofline") or {}
@@ -347,6 +350,51 @@ def workload_counters(src, key):
             "kernel_source_sha256": sha_at_measurement(src, "bf16", stamp)}
 
 
+def training_gemm_counters(src):
+    """Counter traffic of the training GEMMs of one 1024 x 1024 layer on 524 288 rows (tools/gpu_session.sh pmctrain: FETCH_SIZE and WRITE_SIZE passes
+    over `tools/train_step_bench.py --gemm-only`, bf16 and fp32) -> traffic.json: training_gemms, or None when those passes were not run."""
+    import collections
+    pick = {"bf16": {"wgrad": ("linear_tn_bf16_w_kernel",), "dgrad": ("linear_bf16_w16_kernel<0, 0, false, false, false, 0, false, false, false, false, false>",),
+                     "relu_mask": ("relu_mask_bf16_kernel",)},
+            "fp32": {"wgrad": ("linear_tn_kernel",), "dgrad": ("linear_f32_mfma_persist_kernel",)}}
+
+    def per_kernel(d, counter, names):
+        fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
+        if not fs:
+            return None
+        vals = collections.defaultdict(list)
+        for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
+            if r["Counter_Name"] != counter:
+                continue
+            for key, pats in names.items():
+                if any(p_ in r["Kernel_Name"] for p_ in pats):
+                    vals[key].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        return vals
+    out = {}
+    for dk, names in pick.items():
+        F, W = per_kernel(f"pmc_train_{dk}_fetch", "FETCH_SIZE", names), per_kernel(f"pmc_train_{dk}_write", "WRITE_SIZE", names)
+        if not F or not W:
+            continue
+        out[dk] = {}
+        for key in names:
+            if not F.get(key) or not W.get(key):
+                continue
+            # the long launches only (the weight gradient's split reduction and other small launches of the same family are left out)
+            top = max(ns for _, ns in F[key])
+            f_ = [v for v, ns in F[key] if ns >= 0.5 * top]
+            topw = max(ns for _, ns in W[key])
+            w_ = [v for v, ns in W[key] if ns >= 0.5 * topw]
+            fetch_b, write_b = sum(f_) / len(f_) * 1024 * 2, sum(w_) / len(w_) * 1024
+            out[dk][key] = {"bytes_per_launch": round(fetch_b + write_b), "fetch_bytes": round(fetch_b), "write_bytes": round(write_b), "launches_averaged": len(f_),
+                            "launch_ms_under_pmc": round(sum(ns for _, ns in F[key] if ns >= 0.5 * top) / len(f_) / 1e6, 4)}
+    if not out:
+        return None
+    out["kernel_source_sha256"] = sha_at_measurement(src, "train", "kernel_source_sha256_at_measurement_train.json")
+    out["method"] = ("two separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE) over `tools/train_step_bench.py [--mlp-dtype bf16] --gemm-only --iters 3` "
+                     "(tools/gpu_session.sh pmctrain), mean over each kernel's long launches; bytes = FETCH_SIZE*1024*2 + WRITE_SIZE*1024")
+    return out
+
+
 def hbm_kernel_counters(tag):
     """SQ counters of the path's HBM- / latency-bound kernels (tools/gpu_session.sh finpmc: separate --pmc passes over bench.py): per kernel
     the mean launch duration under the counters, waves, and per WAVE: resident cycles, cycles waiting on an instruction's operands, cycles
@@ -449,6 +497,10 @@ def main():
         if wc:
             info["by_workload"][key] = wc
             json.dump(wc, open(f"{dst}/rocprofv3_pmc_{key}_summary.json", "w"), indent=1)
+    tg = training_gemm_counters(src)
+    if tg:
+        info["training_gemms"] = tg
+        json.dump(tg, open(f"{dst}/rocprofv3_pmc_training_gemms_summary.json", "w"), indent=1)
     if "c2_bf16" in info["by_workload"]:
         info["bf16_ring_kernel"] = info["by_workload"]["c2_bf16"]   # (the key rounds 4-5 used)
     json.dump(info, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
