@@ -734,7 +734,9 @@ int m360_nerf_finish_backward(const float *act, int ld, const float *head_w, con
                               float *grad_head_b, void *workspace, size_t workspace_bytes, m360_stream_t stream);
 
 /* stage = 0 proposal (N = num_samples), 1 NeRF (N = number of fine intervals).  The tape keeps the sample
- * positions, the encoded features and every layer output of ONE forward for its backward. */
+ * positions, the encoded features, every layer output and the head sums (1 / 4 floats per sample, as the forward's
+ * finisher formed them: the backward starts from those instead of re-reading the last layer's rows) of ONE forward
+ * for its backward.  Opaque: its size and layout belong to the library build that wrote it. */
 size_t m360_train_tape_bytes(int B, int N, const m360_model_t *model_host, int stage);
 size_t m360_backward_workspace_bytes(int B, int N, const m360_model_t *model_host, int stage);
 

@@ -63,20 +63,20 @@ int encode_stage(const float *t_vals, const float *origins, const float *directi
 int prop_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
                       const float *head_b, int k_pad, float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                       int B, int N, int num_out, float resample_padding, float *weights, float *t_new, const unsigned char *nanflag,
-                      m360_stream_t stream, const rng_t &rng);
+                      m360_stream_t stream, const rng_t &rng, float *raw_out);
 int nerf_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
                       const float *head_b, int k_pad, float density_bias, float rgb_padding, const float *t_vals, const float *dirs,
                       const float *near, const float *far, int near_far_calls, int B, int N, int white_bkgd, float *comp_rgb,
                       float *distance, float *acc, float *weights, float *t_vals_out, float *s_vals_out, const unsigned char *nanflag,
-                      m360_stream_t stream);
+                      m360_stream_t stream, float *raw_out);
 
-int prop_finish_backward_bf16(const void *act, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, const float *t_vals,
-                              const float *dirs, int B, int N, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b,
-                              void *workspace, size_t workspace_bytes, m360_stream_t stream);
-int nerf_finish_backward_bf16(const void *act, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, float rgb_padding,
-                              const float *t_vals, const float *dirs, int B, int N, int white_bkgd, const float *grad_rgb, const float *grad_distance,
-                              const float *grad_acc, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b, void *workspace,
-                              size_t workspace_bytes, m360_stream_t stream);
+int prop_finish_backward_stage(const void *act, int act_bf16, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, const float *t_vals,
+                               const float *dirs, int B, int N, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b,
+                               void *workspace, size_t workspace_bytes, const float *raw_in, m360_stream_t stream);
+int nerf_finish_backward_stage(const void *act, int act_bf16, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, float rgb_padding,
+                               const float *t_vals, const float *dirs, int B, int N, int white_bkgd, const float *grad_rgb, const float *grad_distance,
+                               const float *grad_acc, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b, void *workspace,
+                               size_t workspace_bytes, const float *raw_in, m360_stream_t stream);
 // m360_linear.hip: the hidden-layer chain of the bf16 mode (one launch) and its gated layer-by-layer re-run
 int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
                           int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts, bool x3);
@@ -271,23 +271,23 @@ static int p_linear_heads(const m360_hyper_t *h, int bf16, const void *x, long M
     if (bf16) return ps.done(m360_linear_heads_bf16(x, M, ldx, w, b, n_pad, k_pad, sig, y, ldy, store_y, head_w, heads, part, st));
     return ps.done(m360_linear_heads(static_cast<const float *>(x), M, ldx, static_cast<const float *>(w), b, n_pad, k_pad, M360_ACT_SIGMOID, static_cast<float *>(y), ldy, store_y, head_w, heads, part, st));
 }
-static int p_prop_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, float *w_hat, float *t_new, m360_stream_t st, const unsigned char *flags = nullptr) {
+static int p_prop_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const float *dirs, int B, int N, float *w_hat, float *t_new, m360_stream_t st, const unsigned char *flags = nullptr, float *raw_out = nullptr) {
     ProfScope ps(h, st, M360_K_PROP_FINISH, (long)B * N, k_pad, bf16);
     // the fused resample (t_new != NULL: m360_forward / the sharded batch) draws its uniforms itself when the model is randomized
-    return ps.done(prop_finish_stage(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, flags, st, rng_cdf(h, nullptr)));
+    return ps.done(prop_finish_stage(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, t, dirs, nullptr, B, N, n_fine(h) + 1, h->resample_padding, w_hat, t_new, flags, st, rng_cdf(h, nullptr), raw_out));
 }
 // heads + composite, and in the same launch the t_vals + 1e-6 and s_vals nerf_net.forward returns (model.py:194-196; until round 3
 // an add_eps and a t_to_s launch).  near / far went through g() once in sample_along_rays (numerically, or physically when
 // rays_mutated: then t_to_s starts from the values it is handed).
-static int p_nerf_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const m360_rays_t *r, int B, int N, const m360_outputs_t *out, m360_stream_t st, const unsigned char *flags = nullptr) {
+static int p_nerf_finish_fused(const m360_hyper_t *h, const void *act, int bf16, int ld, const float *part, long fused_rows, int slots, const float *hw, const float *hb, int k_pad, const float *t, const m360_rays_t *r, int B, int N, const m360_outputs_t *out, m360_stream_t st, const unsigned char *flags = nullptr, float *raw_out = nullptr) {
     ProfScope ps(h, st, M360_K_NERF_FINISH, (long)B * N, k_pad, bf16);
-    return ps.done(nerf_finish_stage(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, r->directions, r->near, r->far, h->rays_mutated ? 0 : 1, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, out->t_vals, out->s_vals, flags, st));
+    return ps.done(nerf_finish_stage(act, bf16, ld, part, fused_rows, slots, hw, hb, k_pad, h->density_bias, h->rgb_padding, t, r->directions, r->near, r->far, h->rays_mutated ? 0 : 1, B, N, h->white_bkgd, out->rgb, out->distance, out->acc, out->fine_w, out->t_vals, out->s_vals, flags, st, raw_out));
 }
 
 // Training tape of one stage (caller-owned): everything the backward needs from the forward.
 struct TapeLayout {
-    size_t t, feat, act[8], total;
-    int layers;
+    size_t t, feat, act[8], raw, total;  // raw: the head sums [B*N][1 or 4] as the forward's finisher formed them (round 6: the backward's finisher
+    int layers;                          // starts from them instead of re-reading the last layer's rows for the head dot products)
 };
 static TapeLayout tape_for(int B, int N, const m360_model_t *m, int stage) {
     TapeLayout T;
@@ -300,6 +300,7 @@ static TapeLayout tape_for(int B, int N, const m360_model_t *m, int stage) {
     T.feat = take(S * m->in_pad * sizeof(float));  // bf16 mode: [hi | lo] pairs of in_pad bf16 each - the same 4 bytes per value
     const size_t el = m->mlp_bf16 == 1 ? sizeof(unsigned short) : sizeof(float);  // bf16 mode: every layer's output as bf16 rows
     for (int l = 0; l < 8; ++l) T.act[l] = l < T.layers ? take(S * width * el) : 0;
+    T.raw = take(S * (stage == 0 ? 1 : 4) * sizeof(float));
     T.total = off;
     return T;
 }
@@ -345,7 +346,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         for (int l = 1; l < 3; ++l)
             M360_TRY(p_linear_bf16(h, 1, act[l - 1], S, m->prop_w[l], m->prop_b[l], hp, hp, M360_ACT_RELU, act[l], 0, st));
         M360_TRY(p_linear_heads(h, 1, act[2], S, hp, m->prop_w[3], m->prop_b[3], hp, hp, act[3], hp, 1, m->prop_head_w, 1, hpart, st));
-        return p_prop_finish_fused(h, act[3], 1, hp, hpart, m360_linear_heads_fused_rows(S, hp, 1), m360_linear_heads_slots_bf16(hp, hp, 1, 1), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st, flags);
+        return p_prop_finish_fused(h, act[3], 1, hp, hpart, m360_linear_heads_fused_rows(S, hp, 1), m360_linear_heads_slots_bf16(hp, hp, 1, 1), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st, flags, reinterpret_cast<float *>(tape + T.raw));
     }
     if (tape) {  // training, fp32: every layer output kept
         const TapeLayout T = tape_for(B, N, m, 0);
@@ -363,7 +364,7 @@ static int prop_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
             M360_TRY(p_linear(h, &tq, act[l - 1], S, hp, m->prop_w[l], m->prop_b[l], hp, hp, M360_ACT_RELU, act[l], hp, st));
         // last hidden layer + head fused; the tape keeps the layer output (store_y = 1), same partial sums as when rendering
         M360_TRY(p_linear_heads(h, 0, act[2], S, hp, m->prop_w[3], m->prop_b[3], hp, hp, act[3], hp, 1, m->prop_head_w, 1, hpart, st));
-        return p_prop_finish_fused(h, act[3], 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp, 0), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st);
+        return p_prop_finish_fused(h, act[3], 0, hp, hpart, m360_linear_heads_fused_rows(S, hp, 0), m360_linear_heads_slots(hp, 0), m->prop_head_w, m->prop_head_b, hp, tt, r->directions, B, N, w_hat, t_new, st, nullptr, reinterpret_cast<float *>(tape + T.raw));
     }
     if (parts == 0) {
         if (!ext_norm) M360_TRY(sample_t_any(r->near, r->far, t_rand, B, N, t_hat, rng_jitter(h, t_rand), st));  // sharded batch: t_hat is given
@@ -427,7 +428,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         for (int l = 1; l < 7; ++l)
             M360_TRY(p_linear_bf16(h, 1, act[l - 1], S, m->nerf_w[l], m->nerf_b[l], hn, hn, M360_ACT_RELU, act[l], 0, st));
         M360_TRY(p_linear_heads(h, 1, act[6], S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, act[7], hn, 1, m->nerf_head_w, 4, hpart, st));
-        M360_TRY(p_nerf_finish_fused(h, act[7], 1, hn, hpart, m360_linear_heads_fused_rows(S, hn, 1), m360_linear_heads_slots_bf16(hn, hn, 1, 1), m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st, flags));
+        M360_TRY(p_nerf_finish_fused(h, act[7], 1, hn, hpart, m360_linear_heads_fused_rows(S, hn, 1), m360_linear_heads_slots_bf16(hn, hn, 1, 1), m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st, flags, reinterpret_cast<float *>(tape + T.raw)));
     } else if (tape) {  // training, fp32: every layer output kept (t1 already lives in the tape)
         const TapeLayout T = tape_for(B, N, m, 1);
         float *tf = reinterpret_cast<float *>(tape + T.feat);
@@ -438,7 +439,7 @@ static int nerf_stage(const m360_rays_t *r, const m360_model_t *m, const m360_hy
         for (int l = 1; l < 7; ++l)
             M360_TRY(p_linear(h, &tq, act[l - 1], S, hn, m->nerf_w[l], m->nerf_b[l], hn, hn, M360_ACT_RELU, act[l], hn, st));
         M360_TRY(p_linear_heads(h, 0, act[6], S, hn, m->nerf_w[7], m->nerf_b[7], hn, hn, act[7], hn, 1, m->nerf_head_w, 4, hpart, st));
-        M360_TRY(p_nerf_finish_fused(h, act[7], 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st));
+        M360_TRY(p_nerf_finish_fused(h, act[7], 0, hn, hpart, m360_linear_heads_fused_rows(S, hn, 0), slots, m->nerf_head_w, m->nerf_head_b, hn, t1, r, B, N, out, st, nullptr, reinterpret_cast<float *>(tape + T.raw)));
     } else if (m->mlp_bf16) {
         const int mode = m->mlp_bf16;
         M360_TRY(p_encode(h, t1, r, vdenc, vd_ch, B, N, feat, m->in_pad, first_row_format(mode), ext_norm ? 0 : h->norm_group_rays, ext_norm, 0, flags, ws + L.norm, m360_contract_workspace_bytes(), st));
@@ -836,10 +837,10 @@ int m360_prop_backward(const m360_rays_t *rays, const m360_model_t *model, const
     if (model->mlp_bf16 == 1) {
         void *actb[4];
         for (int l = 0; l < 4; ++l) actb[l] = tp + T.act[l];
-        M360_TRY(prop_finish_backward_bf16(actb[3], hp, model->prop_head_w, model->prop_head_b, hp, hyper->density_bias, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, grad_w_hat, dz, grads->head_w, grads->head_b, ws + L.finish, L.feat_wide - L.finish, stream));
+        M360_TRY(prop_finish_backward_stage(actb[3], 1, hp, model->prop_head_w, model->prop_head_b, hp, hyper->density_bias, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, grad_w_hat, dz, grads->head_w, grads->head_b, ws + L.finish, L.feat_wide - L.finish, reinterpret_cast<const float *>(tp + T.raw), stream));
         return mlp_backward_bf16(hyper, 4, wt->w_t, grads->w, grads->b, tp + T.feat, model->in_pad, actb, hp, (long)B * N, dz, dz2, ws, L, stream, "m360_prop_backward");
     }
-    M360_TRY(m360_prop_finish_backward(act[3], hp, model->prop_head_w, model->prop_head_b, hp, hyper->density_bias, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, grad_w_hat, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, stream));
+    M360_TRY(prop_finish_backward_stage(act[3], 0, hp, model->prop_head_w, model->prop_head_b, hp, hyper->density_bias, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, grad_w_hat, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, reinterpret_cast<const float *>(tp + T.raw), stream));
     return mlp_backward(hyper, 4, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hp, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_prop_backward");
 }
 
@@ -864,10 +865,10 @@ int m360_nerf_backward(const m360_rays_t *rays, const m360_model_t *model, const
     if (model->mlp_bf16 == 1) {
         void *actb[8];
         for (int l = 0; l < 8; ++l) actb[l] = tp + T.act[l];
-        M360_TRY(nerf_finish_backward_bf16(actb[7], hn, model->nerf_head_w, model->nerf_head_b, hn, hyper->density_bias, hyper->rgb_padding, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, hyper->white_bkgd, grad_rgb, grad_distance, grad_acc, grad_weights, dz, grads->head_w, grads->head_b, ws + L.finish, L.feat_wide - L.finish, stream));
+        M360_TRY(nerf_finish_backward_stage(actb[7], 1, hn, model->nerf_head_w, model->nerf_head_b, hn, hyper->density_bias, hyper->rgb_padding, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, hyper->white_bkgd, grad_rgb, grad_distance, grad_acc, grad_weights, dz, grads->head_w, grads->head_b, ws + L.finish, L.feat_wide - L.finish, reinterpret_cast<const float *>(tp + T.raw), stream));
         return mlp_backward_bf16(hyper, 8, wt->w_t, grads->w, grads->b, tp + T.feat, model->in_pad, actb, hn, (long)B * N, dz, dz2, ws, L, stream, "m360_nerf_backward");
     }
-    M360_TRY(m360_nerf_finish_backward(act[7], hn, model->nerf_head_w, model->nerf_head_b, hn, hyper->density_bias, hyper->rgb_padding, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, hyper->white_bkgd, grad_rgb, grad_distance, grad_acc, grad_weights, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, stream));
+    M360_TRY(nerf_finish_backward_stage(act[7], 0, hn, model->nerf_head_w, model->nerf_head_b, hn, hyper->density_bias, hyper->rgb_padding, reinterpret_cast<const float *>(tp + T.t), rays->directions, B, N, hyper->white_bkgd, grad_rgb, grad_distance, grad_acc, grad_weights, dz, grads->head_w, grads->head_b, ws + L.finish, L.total - L.finish, reinterpret_cast<const float *>(tp + T.raw), stream));
     return mlp_backward(hyper, 8, wt->w_t, grads->w, grads->b, reinterpret_cast<const float *>(tp + T.feat), model->in_pad, act, hn, (long)B * N, dz, dz2, ws + L.gemm, L.finish - L.gemm, stream, "m360_nerf_backward");
 }
 

@@ -529,7 +529,8 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
     const float *__restrict__ t_vals, const float *__restrict__ dirs, const float *__restrict__ u_rand, int B, int N, int ns,
     float padding, float *__restrict__ weights, float *__restrict__ t_new, int rpb /* rays per workgroup: kFinishRays, or 1 when four rays' buffers exceed the LDS */,
     const unsigned char *__restrict__ nanflag /* bf16 modes: 1 = the sample had a NaN feature (encode_features_wave_kernel), or NULL */,
-    rng_t rng /* randomized inverse CDF drawn here (u_rand == NULL and rng.on) */) {
+    rng_t rng /* randomized inverse CDF drawn here (u_rand == NULL and rng.on) */,
+    float *__restrict__ raw_out /* [B*N]: the head sums as formed here, for finish_backward_kernel (tape-keeping forward), or NULL */) {
     extern __shared__ float smem[];
     const int l = lane_id(), wave = threadIdx.x >> 6;
     const int nb = N + 1;
@@ -540,6 +541,7 @@ __global__ __launch_bounds__(kFinishThreads) void prop_finish_kernel(
         // bf16 modes: the head output of a sample with a NaN feature is NaN, as nn.ReLU would have carried it here (the bf16 pipe's
         // ReLU drops every NaN: see the encoder)
         for (int i = l; i < N; i += kWave) {
+            if (raw_out != nullptr) raw_out[(long)b * N + i] = rho[i];
             const float raw = (nanflag != nullptr && nanflag[(long)b * N + i]) ? __builtin_nanf("") : rho[i];
             rho[i] = softplusf_(raw + density_bias);
         }
@@ -581,7 +583,8 @@ __global__ __launch_bounds__(kFinishThreads, 4) void nerf_finish_kernel(
     float rgb_padding, const float *__restrict__ t_vals, const float *__restrict__ dirs, int B, int N, int white_bkgd,
     float *__restrict__ comp_rgb, float *__restrict__ distance, float *__restrict__ acc,
     float *__restrict__ weights, float *__restrict__ t_out, float *__restrict__ s_out, const float *__restrict__ near,
-    const float *__restrict__ far, int ts_calls, int rpb, const unsigned char *__restrict__ nanflag) {
+    const float *__restrict__ far, int ts_calls, int rpb, const unsigned char *__restrict__ nanflag,
+    float *__restrict__ raw_out /* [B*N][4]: the head sums as formed here, for finish_backward_kernel (tape-keeping forward), or NULL */) {
     extern __shared__ float smem[];
     const int l = lane_id(), wave = threadIdx.x >> 6;
     const int nb = N + 1;
@@ -592,6 +595,7 @@ __global__ __launch_bounds__(kFinishThreads, 4) void nerf_finish_kernel(
     // s_vals = t_to_s(t_vals, near, far) - until round 3 two more launches (add_eps_kernel, t_to_s_kernel), same arithmetic
     auto finish_ray = [&](int b, float *t, float *raw, float *w) __attribute__((always_inline)) {
         for (int i = l; i < N; i += kWave) {
+            if (raw_out != nullptr) *reinterpret_cast<float4 *>(raw_out + ((long)b * N + i) * 4) = make_float4(raw[4 * i], raw[4 * i + 1], raw[4 * i + 2], raw[4 * i + 3]);
             if (nanflag != nullptr && nanflag[(long)b * N + i]) {  // bf16 modes: see prop_finish_kernel
 #pragma unroll
                 for (int c = 0; c < 4; ++c) raw[4 * i + c] = __builtin_nanf("");
@@ -644,7 +648,8 @@ __global__ __launch_bounds__(kFinishThreads, 4) void nerf_finish_kernel(
 // ------------------------------------------------------------------------------------------
 // Backward of the stage finishers: what autograd does for model.py:52,92-93 (H = 1) and
 // model.py:150-158,180-186 + intern/ray.py:171-191 (H = 4) under train.py:62,80.  One 256-thread workgroup per ray.
-//   phase 1  re-evaluate the H head dot products of the ray's N samples (head_dots, as in the forward)
+//   phase 1  the H head sums of the ray's N samples: the forward's own, kept on the training tape (raw_in; round 6: the stage backwards of
+//            m360_capi.hip - one pass over the ray's activation rows less), or re-evaluated (head_dots; the stand-alone C-ABI entry points)
 //   phase 2  wave 0: activations, transmittance scan, then the reverse scan
 //              x_i = rho_i delta_i,  w_i = (1 - e^{-x_i}) T_i,  T_i = exp(-sum_{j<i} x_j)
 //              dL/dx_i = g_i T_{i+1} - sum_{k>i} g_k w_k      (g = total gradient reaching w)
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(kFinishThreads) void finish_backward_kernel(
     const float *__restrict__ dirs, int N, int white_bkgd, const float *__restrict__ g_rgb,
     const float *__restrict__ g_dist, const float *__restrict__ g_acc, const float *__restrict__ g_w,
     T *__restrict__ dz, float *__restrict__ part_hw /*[B*groups][H*k_pad]*/,
-    float *__restrict__ part_hb /*[B][H]*/, int groups) {
+    float *__restrict__ part_hb /*[B][H]*/, int groups, const float *__restrict__ raw_in /*[B*N][H]: the forward's head sums, or NULL*/) {
     extern __shared__ float smem[];
     const int b = blockIdx.x, l = lane_id();
     const int nb = N + 1;
@@ -685,7 +690,11 @@ __global__ __launch_bounds__(kFinishThreads) void finish_backward_kernel(
     for (int i = threadIdx.x; i < nb; i += blockDim.x) t[i] = t_vals[(long)b * nb + i];
     __syncthreads();
     const T *act_ray = act + (long)b * N * ld;
-    head_dots<H, T>(act_ray, ld, hw, head_b, k_pad, N, raw);
+    if (raw_in != nullptr) {
+        for (int i = threadIdx.x; i < N * H; i += blockDim.x) raw[i] = raw_in[(long)b * N * H + i];
+    } else {
+        head_dots<H, T>(act_ray, ld, hw, head_b, k_pad, N, raw);
+    }
     __syncthreads();
     if (threadIdx.x < kWave) {
         const float dnorm = dir_norm(dirs, b);
@@ -909,7 +918,7 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
                            float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                            int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
                            m360_stream_t stream, const float *head_part = nullptr, long fused_rows = 0, int slots = 0,
-                           const unsigned char *nanflag = nullptr, const rng_t &rng = rng_t{0, 0, 0});
+                           const unsigned char *nanflag = nullptr, const rng_t &rng = rng_t{0, 0, 0}, float *raw_out = nullptr);
 
 int m360_prop_finish_n(const float *act, int ld, const float *head_w, const float *head_b, int k_pad,
                        float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
@@ -937,7 +946,7 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
                            float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                            int B, int N, int num_out, float resample_padding, float *weights, float *t_new,
                            m360_stream_t stream, const float *head_part, long fused_rows, int slots, const unsigned char *nanflag,
-                           const rng_t &rng) {
+                           const rng_t &rng, float *raw_out) {
     if (num_out < 1) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: num_out=%d", num_out);
     const int align = bf16 ? 8 : 4;
     if (!act || !head_w || !head_b || !t_vals || !dirs || !weights || B < 0 || N < 1 || k_pad < align || k_pad % align != 0 || ld < (bf16 == 2 ? 2 * k_pad : k_pad) || ld % align != 0)
@@ -949,9 +958,9 @@ static int prop_finish_any(const void *act, int bf16, int ld, const float *head_
     const size_t lds = rpb == 1 ? lds_wg : (lds_wg > lds_wave ? lds_wg : lds_wave);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
     const dim3 grid((unsigned)((B + rpb - 1) / rpb));
-    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag, rng);
-    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag, rng);
-    else hipLaunchKernelGGL(prop_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag, rng);
+    if (bf16 == 2) hipLaunchKernelGGL((prop_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag, rng, raw_out);
+    else if (bf16) hipLaunchKernelGGL(prop_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag, rng, raw_out);
+    else hipLaunchKernelGGL(prop_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, rpb, nanflag, rng, raw_out);
     return check_launch("prop_finish");
 }
 
@@ -960,6 +969,7 @@ struct FinishExtras {  // what nerf_net.forward returns beside the composite (mo
     const float *near = nullptr, *far = nullptr;
     int calls = 1;  // applications of the reference's in-place g() that near / far have behind them (t_to_s_kernel)
     const unsigned char *nanflag = nullptr;  // bf16 modes: per-sample NaN flags of the encoder
+    float *raw_out = nullptr;                // tape-keeping forward: the head sums [B*N][4] for the backward
 };
 static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_w, const float *head_b, int k_pad,
                            float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
@@ -1015,9 +1025,9 @@ static int nerf_finish_any(const void *act, int bf16, int ld, const float *head_
     const size_t lds = rpb == 1 ? lds_wg : (lds_wg > lds_wave ? lds_wg : lds_wave);
     if (lds > kMaxDynLds) return fail(M360_ERR_INVALID_ARGUMENT, "m360_nerf_finish: k_pad=%d N=%d too large for LDS", k_pad, N);
     const dim3 grid((unsigned)((B + rpb - 1) / rpb));
-    if (bf16 == 2) hipLaunchKernelGGL((nerf_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb, ex.nanflag);
-    else if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb, ex.nanflag);
-    else hipLaunchKernelGGL(nerf_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb, ex.nanflag);
+    if (bf16 == 2) hipLaunchKernelGGL((nerf_finish_kernel<__bf16, true>), grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb, ex.nanflag, ex.raw_out);
+    else if (bf16) hipLaunchKernelGGL(nerf_finish_kernel<__bf16>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const __bf16 *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb, ex.nanflag, ex.raw_out);
+    else hipLaunchKernelGGL(nerf_finish_kernel<float>, grid, dim3(kFinishThreads), lds, S_(stream), static_cast<const float *>(act), ld, head_part, fused_rows, slots, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, ex.t_out, ex.s_out, ex.near, ex.far, ex.calls, rpb, ex.nanflag, ex.raw_out);
     return check_launch("nerf_finish");
 }
 
@@ -1042,7 +1052,7 @@ static int finish_backward_any(const T *act, int ld, const float *head_w, const 
                                float density_bias, float rgb_padding, const float *t_vals, const float *dirs, int B,
                                int N, int white_bkgd, const float *g_rgb, const float *g_dist, const float *g_acc,
                                const float *g_w, T *dz, float *grad_head_w, float *grad_head_b, void *workspace,
-                               size_t workspace_bytes, m360_stream_t stream, const char *who) {
+                               size_t workspace_bytes, m360_stream_t stream, const char *who, const float *raw_in = nullptr) {
     constexpr int kAlign = sizeof(T) == 2 ? 8 : 4;  // bf16 rows are read in 16-byte chunks by head_dots
     if (!act || !head_w || !head_b || !t_vals || !dirs || !dz || !grad_head_w || !grad_head_b || B < 0 || N < 1 || k_pad < kAlign || k_pad % kAlign || ld < k_pad || ld % kAlign)
         return fail(M360_ERR_INVALID_ARGUMENT, "%s: bad argument", who);
@@ -1056,7 +1066,7 @@ static int finish_backward_any(const T *act, int ld, const float *head_w, const 
     float *part_hw = reinterpret_cast<float *>(ws);
     float *part_hb = reinterpret_cast<float *>(ws + fb_up((size_t)B * groups * C * sizeof(float)));
     float *slices = reinterpret_cast<float *>(reinterpret_cast<char *>(part_hb) + fb_up((size_t)B * H * sizeof(float)));
-    hipLaunchKernelGGL((finish_backward_kernel<H, T>), dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, g_rgb, g_dist, g_acc, g_w, dz, part_hw, part_hb, groups);
+    hipLaunchKernelGGL((finish_backward_kernel<H, T>), dim3(B), dim3(kFinishThreads), lds, S_(stream), act, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, N, white_bkgd, g_rgb, g_dist, g_acc, g_w, dz, part_hw, part_hb, groups, raw_in);
     const int rc = check_launch(who);
     if (rc != M360_OK) return rc;
     M360_RAY_TRY(launch_colsum(part_hw, (long)B * groups, C, C, slices, kFinishSlices, grad_head_w, S_(stream)));
@@ -1083,29 +1093,36 @@ int m360_nerf_finish_backward(const float *act, int ld, const float *head_w, con
 }  // extern "C"
 
 namespace m360 {
-// bf16 training path (m360_capi.hip): the finishers' backward on bf16 activations, dz written in bf16
-int prop_finish_backward_bf16(const void *act, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, const float *t_vals,
-                              const float *dirs, int B, int N, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b,
-                              void *workspace, size_t workspace_bytes, m360_stream_t stream) {
+// Stage backwards (m360_capi.hip; not part of the C-ABI): the finishers' backward on the activations of the training tape - fp32, or bf16
+// (act_bf16 = 1: dz written in bf16 as well) - with the head sums the forward's finisher left on the tape (raw_in; NULL: re-evaluated)
+int prop_finish_backward_stage(const void *act, int act_bf16, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, const float *t_vals,
+                               const float *dirs, int B, int N, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b,
+                               void *workspace, size_t workspace_bytes, const float *raw_in, m360_stream_t stream) {
     if (!grad_weights) return fail(M360_ERR_INVALID_ARGUMENT, "m360_prop_backward: grad_w_hat is required");
-    return finish_backward_any<1, __bf16>(static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, 0.0f, t_vals, dirs, B, N, 0, nullptr, nullptr, nullptr, grad_weights,
-                                          static_cast<__bf16 *>(dz), grad_head_w, grad_head_b, workspace, workspace_bytes, stream, "m360_prop_backward (bf16 finisher)");
+    if (act_bf16)
+        return finish_backward_any<1, __bf16>(static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, 0.0f, t_vals, dirs, B, N, 0, nullptr, nullptr, nullptr, grad_weights,
+                                              static_cast<__bf16 *>(dz), grad_head_w, grad_head_b, workspace, workspace_bytes, stream, "m360_prop_backward (bf16 finisher)", raw_in);
+    return finish_backward_any<1, float>(static_cast<const float *>(act), ld, head_w, head_b, k_pad, density_bias, 0.0f, t_vals, dirs, B, N, 0, nullptr, nullptr, nullptr, grad_weights,
+                                         static_cast<float *>(dz), grad_head_w, grad_head_b, workspace, workspace_bytes, stream, "m360_prop_backward (finisher)", raw_in);
 }
-int nerf_finish_backward_bf16(const void *act, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, float rgb_padding,
-                              const float *t_vals, const float *dirs, int B, int N, int white_bkgd, const float *grad_rgb, const float *grad_distance,
-                              const float *grad_acc, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b, void *workspace,
-                              size_t workspace_bytes, m360_stream_t stream) {
-    return finish_backward_any<4, __bf16>(static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, grad_rgb, grad_distance,
-                                          grad_acc, grad_weights, static_cast<__bf16 *>(dz), grad_head_w, grad_head_b, workspace, workspace_bytes, stream, "m360_nerf_backward (bf16 finisher)");
+int nerf_finish_backward_stage(const void *act, int act_bf16, int ld, const float *head_w, const float *head_b, int k_pad, float density_bias, float rgb_padding,
+                               const float *t_vals, const float *dirs, int B, int N, int white_bkgd, const float *grad_rgb, const float *grad_distance,
+                               const float *grad_acc, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b, void *workspace,
+                               size_t workspace_bytes, const float *raw_in, m360_stream_t stream) {
+    if (act_bf16)
+        return finish_backward_any<4, __bf16>(static_cast<const __bf16 *>(act), ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, grad_rgb, grad_distance,
+                                              grad_acc, grad_weights, static_cast<__bf16 *>(dz), grad_head_w, grad_head_b, workspace, workspace_bytes, stream, "m360_nerf_backward (bf16 finisher)", raw_in);
+    return finish_backward_any<4, float>(static_cast<const float *>(act), ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, grad_rgb, grad_distance,
+                                         grad_acc, grad_weights, static_cast<float *>(dz), grad_head_w, grad_head_b, workspace, workspace_bytes, stream, "m360_nerf_backward (finisher)", raw_in);
 }
 // Stage drivers only (m360_capi.hip; not part of the C-ABI): the fused finishers with the encoder's per-sample NaN flags (bf16 / bf16x3
 // modes; NULL = none) - and, for the NeRF stage, the t_vals + 1e-6 / s_vals outputs of m360_nerf_finish_outputs.
 int prop_finish_stage(const void *act, int act_bf16, int ld, const float *head_part, long fused_rows, int slots, const float *head_w,
                       const float *head_b, int k_pad, float density_bias, const float *t_vals, const float *dirs, const float *u_rand,
                       int B, int N, int num_out, float resample_padding, float *weights, float *t_new, const unsigned char *nanflag,
-                      m360_stream_t stream, const rng_t &rng) {
+                      m360_stream_t stream, const rng_t &rng, float *raw_out) {
     if (fused_rows < 0 || (fused_rows > 0 && (!head_part || slots < 1))) return fail(M360_ERR_INVALID_ARGUMENT, "prop_finish_stage: fused_rows=%ld slots=%d", fused_rows, slots);
-    return prop_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, stream, head_part, fused_rows, slots, nanflag, rng);
+    return prop_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, t_vals, dirs, u_rand, B, N, num_out, resample_padding, weights, t_new, stream, head_part, fused_rows, slots, nanflag, rng, raw_out);
 }
 // m360_resample_t_n with the inverse CDF's uniforms from a tensor (u_rand), from the Philox stream (rng.on) or deterministic
 int resample_t_any(const float *t_vals, const float *weights, const float *u_rand, int B, int N, int num_out, float resample_padding, float *t_new,
@@ -1130,11 +1147,11 @@ int nerf_finish_stage(const void *act, int act_bf16, int ld, const float *head_p
                       const float *head_b, int k_pad, float density_bias, float rgb_padding, const float *t_vals, const float *dirs,
                       const float *near, const float *far, int near_far_calls, int B, int N, int white_bkgd, float *comp_rgb,
                       float *distance, float *acc, float *weights, float *t_vals_out, float *s_vals_out, const unsigned char *nanflag,
-                      m360_stream_t stream) {
+                      m360_stream_t stream, float *raw_out) {
     if (fused_rows < 0 || (fused_rows > 0 && (!head_part || slots < 1))) return fail(M360_ERR_INVALID_ARGUMENT, "nerf_finish_stage: fused_rows=%ld slots=%d", fused_rows, slots);
     if (s_vals_out && (!near || !far || near_far_calls < 0)) return fail(M360_ERR_INVALID_ARGUMENT, "nerf_finish_stage: s_vals needs near, far and near_far_calls >= 0");
     FinishExtras ex;
-    ex.t_out = t_vals_out, ex.s_out = s_vals_out, ex.near = near, ex.far = far, ex.calls = near_far_calls, ex.nanflag = nanflag;
+    ex.t_out = t_vals_out, ex.s_out = s_vals_out, ex.near = near, ex.far = far, ex.calls = near_far_calls, ex.nanflag = nanflag, ex.raw_out = raw_out;
     return nerf_finish_any(act, act_bf16, ld, head_w, head_b, k_pad, density_bias, rgb_padding, t_vals, dirs, B, N, white_bkgd, comp_rgb, distance, acc, weights, stream, head_part, fused_rows, slots, ex);
 }
 }  // namespace m360
