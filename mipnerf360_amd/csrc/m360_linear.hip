@@ -990,11 +990,18 @@ bool relu_mask_bf16_sums_ok(long M, int k_pad, int blocks) {
     return k_pad % 8 == 0 && c8 >= 1 && c8 <= 256 && 256 % c8 == 0 && blocks > 0 && (M * c8 + 255) / 256 > blocks;
 }
 // bytes of its part[blocks * 256 / (k_pad / 8)][k_pad] (one row of sums per thread group: 8 floats per thread)
-size_t relu_mask_bf16_sums_bytes(int blocks) { return (size_t)blocks * 256 * 8 * sizeof(float); }
+constexpr int kMaskSumGroups = 32;  // row groups of the first reduction level
+size_t relu_mask_bf16_sums_bytes(int blocks) { return (size_t)blocks * 256 * 8 * sizeof(float) + (size_t)kMaskSumGroups * 2048 * sizeof(float); }
 // ... and the reduction of those rows into grad_b[k_pad] (ascending)
 int relu_mask_bf16_sums_reduce(const float *part, int blocks, int k_pad, float *grad_b, m360_stream_t stream) {
     if (!part || !grad_b || blocks < 1 || k_pad < 8) return fail(M360_ERR_INVALID_ARGUMENT, "relu_mask_bf16_sums_reduce: bad argument");
-    hipLaunchKernelGGL(tn16::tn16_bias_reduce_kernel, dim3((unsigned)((k_pad + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), part, blocks * (256 / (k_pad / 8)), k_pad, static_cast<const __bf16 *>(nullptr), 0, 0l, 0l, grad_b);
+    // two levels (round 6): kMaskSumGroups groups of rows by as many workgroups per 256 columns, then those sums - one thread per column over all
+    // 1024 - 2048 rows was 70 us of dependent load rounds at the end of the second stream, which the caller's stream waits for
+    const int rows = blocks * (256 / (k_pad / 8)), per = (rows + kMaskSumGroups - 1) / kMaskSumGroups;
+    float *level1 = const_cast<float *>(part) + (size_t)blocks * 256 * 8;  // behind the mask kernel's rows (relu_mask_bf16_sums_bytes)
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(tn16::tn16_bias_reduce_rows_kernel, dim3((unsigned)((k_pad + 255) / 256), (unsigned)kMaskSumGroups), dim3(256), 0, st, part, rows, per, k_pad, level1);
+    hipLaunchKernelGGL(tn16::tn16_bias_reduce_kernel, dim3((unsigned)((k_pad + 255) / 256)), dim3(256), 0, st, static_cast<const float *>(level1), kMaskSumGroups, k_pad, static_cast<const __bf16 *>(nullptr), 0, 0l, 0l, grad_b);
     return check_launch("linear_dgrad_bf16 (column sums of the masked rows)");
 }
 int relu_mask_bf16(void *dx, const void *relu_out, long M, int k_pad, int ldx, m360_stream_t stream, int blocks, float *sums_part) {

@@ -276,6 +276,26 @@ __global__ __launch_bounds__(256) void tn16_bias_reduce_kernel(const float *__re
     grad_b[n] = s;
 }
 
+// First level of a two-level column sum of part[rows][Np] (the throttled mask kernel leaves 1024 - 2048 rows; one thread per column walking all of
+// them is a 70 us chain of dependent load rounds at the end of the second stream): workgroup (x, y) adds rows [y per, (y + 1) per) of its 256
+// columns in ascending order into out[y][Np]; tn16_bias_reduce_kernel then adds the gridDim.y rows of `out`.  No LDS (it runs beside a kernel
+// that owns all of it), fixed order: deterministic.
+__global__ __launch_bounds__(256) void tn16_bias_reduce_rows_kernel(const float *__restrict__ part, int rows, int per, int Np, float *__restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Np) return;
+    const int r0 = blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s = 0.0f;
+    for (int r = r0; r < r1; r += 16) {
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = r + e < r1 ? part[(long)(r + e) * Np + n] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (r + e < r1) s += v[e];
+    }
+    out[(long)blockIdx.y * Np + n] = s;
+}
+
 // shapes the MFMA kernel does not take (reduced-width test models: pads of 64 / 128): the operands widened to fp32 for the fp32 kernel
 __global__ __launch_bounds__(256) void widen_bf16_kernel(const __bf16 *__restrict__ in, long rows, int cols, int ld, float *__restrict__ out) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -46,8 +46,16 @@ __global__ __launch_bounds__(kColWaves *kWave) void prop_colsum_kernel(const flo
     const int wave = threadIdx.x >> 6, l = lane_id();
     const int i = blockIdx.x * kWave + l;
     double acc = 0.0;
-    if (i < Np)
-        for (int b = wave; b < B; b += kColWaves) acc += (double)per_ray[(long)b * Np + i];
+    if (i < Np) {  // 8 loads in flight per wave, added in the same ascending order (one dependent load per add took 74 us at B = 4096)
+        for (int b = wave; b < B; b += 8 * kColWaves) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = b + e * kColWaves < B ? per_ray[(long)(b + e * kColWaves) * Np + i] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (b + e * kColWaves < B) acc += (double)v[e];
+        }
+    }
     red[wave][l] = acc;
     __syncthreads();
     if (wave == 0 && i < Np) {
