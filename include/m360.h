@@ -319,6 +319,31 @@ int m360_linear_bf16x3_bf16out(const void *x_hi_lo_bf16 /*[M, ldx >= 2 k_pad]*/,
                                m360_stream_t stream);
 int m360_pack_linear_bf16x6(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad,
                             void *w_packed6_bf16 /*[n_pad, 6 k_pad]*/, float *b_packed, m360_stream_t stream);
+
+/* Every packing of a parameter set in ONE launch (round 6).  A training step re-packs both networks on every forward and their transposes on
+ * every backward: a 4 us kernel per layer behind a NaN scan of the same tensors, each with its launch gap, in front of a 6 ms forward.  An item
+ * is the argument list of one per-layer entry point: M360_PACK_F32 = m360_pack_linear, _BF16 = m360_pack_linear_bf16, _BF16X3 =
+ * m360_pack_linear_bf16x3, _BF16X6 = m360_pack_linear_bf16x6 (w_packed [n_pad, k_pad] / [n_pad, 3 k_pad] / [n_pad, 6 k_pad]; b NULL = zero bias,
+ * b_packed NULL = none written), _F32_T = m360_pack_linear_transposed, _BF16_T = m360_pack_linear_bf16_transposed (w_packed [k_pad, n_pad]; no
+ * bias).  Same pads required, same bits written as by those calls.  nan_flag (device, or NULL): set to 1 when any source weight or bias read is
+ * NaN, else 0 - what m360_params_nan_flag reports for the same tensors (the bf16 modes refuse NaN parameters).  The list is checked as a whole
+ * before anything is launched; lists longer than 16 items take one launch per 16. */
+#define M360_PACK_F32 0
+#define M360_PACK_BF16 1
+#define M360_PACK_BF16X3 2
+#define M360_PACK_BF16X6 3
+#define M360_PACK_F32_T 4
+#define M360_PACK_BF16_T 5
+typedef struct m360_pack_item {
+    const float *w;   /* [n_out, k_in] fp32, row-major (nn.Linear.weight) */
+    const float *b;   /* [n_out] or NULL */
+    void *w_packed;
+    float *b_packed;  /* [n_pad] or NULL */
+    int n_out, k_in, n_pad, k_pad;
+    int format;       /* M360_PACK_* */
+    int reserved;     /* 0 */
+} m360_pack_item_t;
+int m360_pack_many(const m360_pack_item_t *items_host, int count, unsigned *nan_flag, m360_stream_t stream);
 int m360_linear_bf16_split(const void *x_bf16 /*[M, ldx >= k_pad]*/, long M, int ldx, const void *w_packed_bf16,
                            const float *b_packed, int n_pad, int k_pad, int act, void *y_hi_lo_bf16 /*[M, ldy >= 2 n_pad]*/,
                            int ldy, m360_stream_t stream);

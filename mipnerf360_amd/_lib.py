@@ -44,6 +44,14 @@ PACKED_LAYOUT = 2  # include/m360.h: M360_PACKED_LAYOUT
 TUNE_NO_HIDDEN_CHAIN, TUNE_PLAIN_ROWS, TUNE_WGRAD_FORM0, TUNE_CHAIN_COOPERATIVE, TUNE_CHAIN_UNGATED = 1, 2, 4, 8, 16
 
 
+PACK_F32, PACK_BF16, PACK_BF16X3, PACK_BF16X6, PACK_F32_T, PACK_BF16_T = range(6)  # include/m360.h: M360_PACK_*
+
+
+class PackItem(C.Structure):  # include/m360.h: m360_pack_item_t
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("w_packed", C.c_void_p), ("b_packed", C.c_void_p),
+                ("n_out", C.c_int), ("k_in", C.c_int), ("n_pad", C.c_int), ("k_pad", C.c_int), ("format", C.c_int), ("reserved", C.c_int)]
+
+
 class HyperStruct(C.Structure):  # m360_hyper_t
     _fields_ = [("num_samples", C.c_int), ("viewdir_min_deg", C.c_int), ("viewdir_max_deg", C.c_int),
                 ("white_bkgd", C.c_int), ("density_bias", C.c_float), ("rgb_padding", C.c_float),
@@ -103,6 +111,7 @@ SIGNATURES = {
     "m360_side_create": (_i, [_P(_vp)]),
     "m360_side_destroy": (None, [_vp]),
     "m360_params_nan_flag": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "m360_pack_many": (_i, [_vp, _i, _vp, _vp]),
     "m360_pack_linear_bf16_transposed": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "m360_linear_dgrad_bf16": (_i, [_vp, _l, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "m360_linear_wgrad_bf16_workspace_bytes": (_sz, [_l, _i, _i]),

@@ -125,17 +125,33 @@ class _PackedMLP:
         self.bf16 = bf16
         self.in_pad = ops.round_up(first.in_features, pad)
         self.h_pad = ops.round_up(first.out_features, pad)
-        pack = {0: ops.pack_linear, 1: ops.pack_linear_bf16, 2: ops.pack_linear_bf16x3}[bf16]
+        # ONE launch for every packing of the sub-network and (bf16 modes) the NaN scan of the tensors it reads anyway (m360_pack_many; until
+        # round 6 a kernel per layer behind a 56 us scan: 0.1 - 0.15 ms of small launches in front of every forward of a training step)
+        hidden_fmt = {0: _lib.PACK_F32, 1: _lib.PACK_BF16, 2: _lib.PACK_BF16X3}[bf16]
+        # first layers: bf16x3: all 24 bits of features and weights ("x6"); bf16: 16 bits of each (two bf16 terms, three products), one term out
+        first_fmt = {0: _lib.PACK_F32, 1: _lib.PACK_BF16X3, 2: _lib.PACK_BF16X6}[bf16]
+        items = [(lin.weight, lin.bias, self.h_pad, self.in_pad if i == 0 else self.h_pad, first_fmt if i == 0 else hidden_fmt)
+                 for i, lin in enumerate(hidden_layers)]
+        n_heads = sum(h.weight.shape[0] for h in heads)
+        dev0 = first.weight.device
+        head_w = torch.empty(n_heads, self.h_pad, device=dev0)
+        head_b = torch.empty(n_heads, device=dev0)
+        row = 0
+        for h in heads:  # the heads' rows side by side: [n_heads, h_pad] and [n_heads], fp32
+            r = h.weight.shape[0]
+            items.append((h.weight, h.bias, r, self.h_pad, _lib.PACK_F32, head_w[row:row + r], head_b[row:row + r]))
+            row += r
         if bf16:
             self.key = None  # a refused packing must not look current to the next call
+        outs, flag = ops.pack_many(items, nan_flag=bool(bf16))
+        if bf16:
             # The bf16 matrix pipe answers a NaN operand with the default NaN 0xFFC00000 (sign bit set), which its packed integer-max
             # ReLU reads as a negative number: no NaN survives a ReLU layer.  NaN FEATURES are carried around the MLP by per-sample
             # flags (the finishers poison those samples, as nn.ReLU would have); a NaN PARAMETER cannot be - refuse it loudly.
-            # ONE launch over all tensors.  Rendering (the key decides: a re-pack is rare; any forward without a tape counts) waits for it
-            # here.  A training step (`defer_nan`: the tape-keeping forward in training mode) re-packs on every forward: the flag travels to
-            # pinned memory behind an event and is looked at by the NEXT re-pack - by then it has long arrived, so a training step never stalls on it and a NaN
-            # parameter is still refused, one forward late.
-            flag = ops.params_nan_flag(params)  # one launch over all tensors
+            # Rendering (the key decides: a re-pack is rare; any forward without a tape counts) waits for the flag here.  A training step
+            # (`defer_nan`: the tape-keeping forward in training mode) re-packs on every forward: the flag travels to pinned memory behind
+            # an event and is looked at by the NEXT re-pack and by this forward's backward - by then it has long arrived, so a training
+            # step never stalls on it and a NaN parameter still never reaches the optimizer.
             msg = ("mlp_dtype='bf16' / 'bf16x3': the parameters hold NaN values; the bf16 matrix pipe cannot propagate them "
                    "the way nn.ReLU does (the reference renders NaN) - use mlp_dtype='fp32' for this checkpoint")
             if always and defer_nan:  # the tape-keeping forward of a training step: it must not stall on the flag
@@ -146,23 +162,15 @@ class _PackedMLP:
                 host = torch.empty(1, dtype=torch.int32, pin_memory=True)
                 host.copy_(flag, non_blocking=True)
                 ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(first.weight.device))
+                ev.record(torch.cuda.current_stream(dev0))
                 self._nan_pending = (host, ev, msg)
             elif int(flag.item()) != 0:
                 raise RuntimeError(msg)
-        self.w, self.b = [], []
-        for i, lin in enumerate(hidden_layers):
-            if i == 0 and bf16 == 2:  # bf16x3: the first layer multiplies all 24 bits of features and weights ("x6")
-                wp, bp = ops.pack_linear_bf16x6(lin.weight, lin.bias, self.h_pad, self.in_pad)
-            elif i == 0 and bf16 == 1:  # bf16: 16 bits of each (two bf16 terms, three products), one bf16 term out
-                wp, bp = ops.pack_linear_bf16x3(lin.weight, lin.bias, self.h_pad, self.in_pad)
-            else:
-                wp, bp = pack(lin.weight, lin.bias, self.h_pad, self.in_pad if i == 0 else self.h_pad)
-            self.w.append(wp), self.b.append(bp)
-        hw = torch.cat([h.weight.detach() for h in heads], 0).float()
-        hb = torch.cat([h.bias.detach() for h in heads], 0).float().contiguous()
-        self.head_w, _ = ops.pack_linear(hw, None, hw.shape[0], self.h_pad)
-        self.head_b = hb
+        self.w = [o[0] for o in outs[:len(hidden_layers)]]
+        self.b = [o[1] for o in outs[:len(hidden_layers)]]
+        self.head_w = head_w
+        self.head_b = head_b
+        hw = head_w
         self.key = key
         # a forward on a different stream must not read the packing before the kernels that write it have run
         self.pack_stream = torch.cuda.current_stream(hw.device)
@@ -277,8 +285,9 @@ class _TrainCtx:
         # transposed packings for the input-gradient GEMMs (layer 0 needs none), made from the same parameter
         # versions as the forward packing (bf16 mode: bf16 transposes for m360_linear_dgrad_bf16)
         self.bf16 = int(getattr(packed, "bf16", 0))
-        pack_t = ops.pack_linear_bf16_transposed if self.bf16 else ops.pack_linear_transposed
-        self.w_t = [None] + [pack_t(lin.weight, packed.h_pad, packed.h_pad) for lin in layers[1:]]
+        fmt_t = _lib.PACK_BF16_T if self.bf16 else _lib.PACK_F32_T
+        outs_t, _ = ops.pack_many([(lin.weight, None, packed.h_pad, packed.h_pad, fmt_t) for lin in layers[1:]])  # one launch
+        self.w_t = [None] + [o[0] for o in outs_t]
         self.in_pad = packed.in_pad
         self.overlap = ops.backward_overlap_wanted()  # decided on the forward's thread, like hyper.tuning
         self.versions = [p._version for p in module.parameters()]

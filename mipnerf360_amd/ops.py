@@ -523,6 +523,46 @@ def params_nan_flag(tensors) -> torch.Tensor:
     return flag
 
 
+_PACK_COLS = {_lib.PACK_F32: 1, _lib.PACK_BF16: 1, _lib.PACK_BF16X3: 3, _lib.PACK_BF16X6: 6}
+
+
+def pack_many(items, nan_flag: bool = False):
+    """Every packing of a parameter set in ONE launch (m360_pack_many): `items` is a list of
+    (weight, bias or None, n_pad, k_pad, format[, w_out, b_out]) with format one of _lib.PACK_*; the per-layer calls' pads, the same bits.
+    Returns ([(w_packed, b_packed or None), ...], flag) - flag: int32[1] on the device, 1 when a source value is NaN (None unless asked for).
+    w_out / b_out: write into these (views of a larger buffer: the output heads side by side) instead of fresh tensors."""
+    import ctypes
+    arr = (_lib.PackItem * max(len(items), 1))()
+    outs, keep = [], []
+    for i, item in enumerate(items):
+        weight, bias, n_pad, k_pad, fmt = item[:5]
+        w_out, b_out = (item[5], item[6]) if len(item) > 5 else (None, None)
+        weight = dev(weight.detach(), "weight")
+        n_out, k_in = weight.shape
+        transposed = fmt in (_lib.PACK_F32_T, _lib.PACK_BF16_T)
+        dt = torch.float32 if fmt in (_lib.PACK_F32, _lib.PACK_F32_T) else torch.bfloat16
+        if w_out is None:
+            shape = (k_pad, n_pad) if transposed else (n_pad, _PACK_COLS[fmt] * k_pad)
+            w_out = torch.empty(*shape, device=weight.device, dtype=dt)
+        elif w_out.dtype != dt or not w_out.is_contiguous() or w_out.device != weight.device:
+            raise RuntimeError("pack_many: w_out must be a contiguous tensor of the packing's dtype on the weight's device")
+        b = None if bias is None else dev(bias.detach(), "bias")
+        if b_out is None and not transposed and (len(item) <= 5):
+            b_out = torch.empty(n_pad, device=weight.device)
+        if b_out is not None:
+            b_out = dev(b_out, "b_out")
+        arr[i] = _lib.PackItem(weight.data_ptr(), 0 if b is None else b.data_ptr(), w_out.data_ptr(), 0 if b_out is None else b_out.data_ptr(),
+                               n_out, k_in, n_pad, k_pad, fmt, 0)
+        outs.append((w_out, b_out))
+        keep.append((weight, b))
+    if not items:
+        return [], None
+    flag = torch.empty(1, dtype=torch.int32, device=keep[0][0].device) if nan_flag else None
+    _call("m360_pack_many", ctypes.cast(arr, ctypes.c_void_p), len(items), flag, STREAM, device=keep[0][0].device)
+    del keep  # (alive until the launch is queued)
+    return outs, flag
+
+
 def pack_linear_bf16(weight, bias=None, n_pad: Optional[int] = None, k_pad: Optional[int] = None):
     """fp32 Linear -> zero-padded bf16 weight [n_pad,k_pad] (k_pad multiple of 64) + fp32 bias [n_pad]."""
     weight = dev(weight.detach(), "weight")

@@ -387,6 +387,66 @@ def test_params_nan_flag_one_launch(dev):
     assert int(ops.params_nan_flag(ts).item()) == 0
 
 
+def test_pack_many_same_bits_as_the_per_layer_calls(dev):
+    """m360_pack_many (round 6): every packing of a parameter set in ONE launch - each format against its per-layer entry point bit for bit
+    (ragged sizes, with and without bias, the heads written side by side into one buffer, more than 16 items = two launches), the NaN flag
+    against m360_params_nan_flag, and a bad item anywhere in the list refusing the whole list."""
+    from mipnerf360_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    neg_nan = float(np.frombuffer(np.uint32(0xFFC00000).tobytes(), dtype=np.float32)[0])
+
+    def lin(n, k, bias=True):
+        return torch.randn(n, k, generator=g).to(dev), (torch.randn(n, generator=g).to(dev) if bias else None)
+
+    single = {_lib.PACK_F32: ops.pack_linear, _lib.PACK_BF16: ops.pack_linear_bf16, _lib.PACK_BF16X3: ops.pack_linear_bf16x3,
+              _lib.PACK_BF16X6: ops.pack_linear_bf16x6}
+    single_t = {_lib.PACK_F32_T: ops.pack_linear_transposed, _lib.PACK_BF16_T: ops.pack_linear_bf16_transposed}
+    items, want = [], []
+    for fmt in single:
+        for (n, k, n_pad, k_pad, bias) in ((5, 58, 64, 64, True), (256, 256, 256, 256, True), (33, 100, 64, 128, False), (1, 1, 32, 64, True)):
+            w, b = lin(n, k, bias)
+            items.append((w, b, n_pad, k_pad, fmt))
+            want.append(single[fmt](w, b, n_pad, k_pad))
+    for fmt in single_t:
+        for (n, k, n_pad, k_pad) in ((5, 58, 64, 64), (256, 256, 256, 256), (100, 33, 128, 64)):
+            w, _ = lin(n, k, False)
+            items.append((w, None, n_pad, k_pad, fmt))
+            want.append((single_t[fmt](w, n_pad, k_pad), None))
+    assert len(items) > 16
+    outs, flag = ops.pack_many(items, nan_flag=True)
+    assert int(flag.item()) == 0
+    for i, ((gw, gb), (ww, wb)) in enumerate(zip(outs, want)):
+        assert gw.shape == ww.shape and gw.dtype == ww.dtype and torch.equal(gw.view(torch.uint8), ww.view(torch.uint8)), i
+        if wb is not None:
+            assert torch.equal(gb.view(torch.int32), wb.view(torch.int32)), i
+        else:
+            assert gb is None, i
+    # the heads side by side in one buffer, as model.py packs them
+    (w1, b1), (w3, b3) = lin(1, 200), lin(3, 200)
+    hw, hb = torch.full((4, 256), 7.0, device=dev), torch.full((4,), 7.0, device=dev)
+    ops.pack_many([(w1, b1, 1, 256, _lib.PACK_F32, hw[0:1], hb[0:1]), (w3, b3, 3, 256, _lib.PACK_F32, hw[1:4], hb[1:4])])
+    ww, wb = ops.pack_linear(torch.cat([w1, w3]), torch.cat([b1, b3]), 4, 256)
+    assert torch.equal(hw, ww) and torch.equal(hb, wb)
+    # NaN of either sign in a weight or a bias raises the flag (and is packed as the per-layer calls pack it); an infinity does not
+    for what, val in (("w", float("nan")), ("w", neg_nan), ("b", neg_nan), ("inf", float("inf"))):
+        w, b = lin(40, 70)
+        (w if what != "b" else b).reshape(-1)[-1] = val
+        for fmt in (_lib.PACK_F32, _lib.PACK_BF16, _lib.PACK_BF16X3, _lib.PACK_BF16X6):
+            (o,), f = ops.pack_many([(w, b, 64, 128, fmt)], nan_flag=True)
+            assert int(f.item()) == (0 if what == "inf" else 1), (what, fmt)
+            ww, wb = single[fmt](w, b, 64, 128)
+            assert torch.equal(o[0].view(torch.uint8), ww.view(torch.uint8)) and torch.equal(o[1].view(torch.int32), wb.view(torch.int32)), (what, fmt)
+        assert int(ops.params_nan_flag([w, b]).item()) == (0 if what == "inf" else 1)
+    # a NaN OUTSIDE what an item reads is not reported; a bad item (k_pad not a multiple of 64 for a bf16 packing) refuses the list as a whole
+    w, b = lin(8, 64)
+    canary = torch.full((64, 64), 3.0, device=dev)
+    with pytest.raises(RuntimeError, match="item 1"):
+        ops.pack_many([(w, b, 64, 64, _lib.PACK_F32, canary, None), (w, b, 64, 96, _lib.PACK_BF16)])
+    torch.cuda.synchronize()
+    assert bool((canary == 3.0).all()), "a refused list must pack nothing"
+    assert ops.pack_many([]) == ([], None)
+
+
 def test_backward_overlap_same_bits(dev):
     """m360_hyper_t.side (ops.set_backward_overlap): the ReLU mask of a layer's input gradient on a CALLER-OWNED second stream (m360_side_t) beside the weight gradient (the
     default; one striding workgroup per CU) against everything on the caller's stream - the same weight gradients bit for bit (bias gradients: the
