@@ -667,7 +667,8 @@ def named_workloads(sd_np, dev, _lib):
             (ln + 0.01 * ld).backward()
             opt.step()
 
-        prop_ms, nerf_ms = timed(prop_step, 2 if b16 else 1), timed(nerf_step, 3 if b16 else 2)
+        # (bf16: 8 updates each - a timed region starts behind a synchronize, and the host needs ~1 ms to queue the first update's launches)
+        prop_ms, nerf_ms = timed(prop_step, 8 if b16 else 1), timed(nerf_step, 8 if b16 else 2)
         it_ms = 2 * prop_ms + nerf_ms
         finite = all(bool(torch.isfinite(p).all()) for p in model.parameters())
         del model, opt
