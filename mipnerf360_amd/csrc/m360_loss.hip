@@ -38,22 +38,25 @@ __global__ __launch_bounds__(kLossWaves *kWave) void prop_overlap_kernel(
 }
 
 // Step 2: the reference indexes fine_weights[..., mask] with a [B, Nf] mask (distillation.py:29), which flattens over
-// the rays: every ray receives the BATCH TOTAL.  Column sums in fp64, fixed order (16 row classes, then 0..15).
-constexpr int kColWaves = 16;
+// the rays: every ray receives the BATCH TOTAL.  Column sums in fp64, fixed order, in two levels (round 6): workgroup (x, g) adds the rays
+// b = g, g + kColGroups, ... of its 64 columns (16 row classes by its waves, then 0..15) into part[g][Np]; prop_colsum_final_kernel adds the
+// kColGroups rows.  (One workgroup per 64 columns over all 4096 rays was 76 us: 1 MB through ONE CU's loads in flight.)
+constexpr int kColWaves = 16, kColGroups = 32;
 __global__ __launch_bounds__(kColWaves *kWave) void prop_colsum_kernel(const float *__restrict__ per_ray, int B, int Np,
-                                                                       float *__restrict__ total) {
+                                                                       double *__restrict__ part) {
     __shared__ double red[kColWaves][kWave];
     const int wave = threadIdx.x >> 6, l = lane_id();
     const int i = blockIdx.x * kWave + l;
+    const int stride = kColGroups * kColWaves;
     double acc = 0.0;
-    if (i < Np) {  // 8 loads in flight per wave, added in the same ascending order (one dependent load per add took 74 us at B = 4096)
-        for (int b = wave; b < B; b += 8 * kColWaves) {
+    if (i < Np) {  // 8 loads in flight per wave, added in ascending order
+        for (int b = blockIdx.y + kColGroups * wave; b < B; b += 8 * stride) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = b + e * kColWaves < B ? per_ray[(long)(b + e * kColWaves) * Np + i] : 0.0f;
+            for (int e = 0; e < 8; ++e) v[e] = b + e * stride < B ? per_ray[(long)(b + e * stride) * Np + i] : 0.0f;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (b + e * kColWaves < B) acc += (double)v[e];
+                if (b + e * stride < B) acc += (double)v[e];
         }
     }
     red[wave][l] = acc;
@@ -61,8 +64,18 @@ __global__ __launch_bounds__(kColWaves *kWave) void prop_colsum_kernel(const flo
     if (wave == 0 && i < Np) {
         double s = 0.0;
         for (int k = 0; k < kColWaves; ++k) s += red[k][l];
-        total[i] = (float)s;
+        part[(long)blockIdx.y * Np + i] = s;
     }
+}
+__global__ __launch_bounds__(kWave) void prop_colsum_final_kernel(const double *__restrict__ part, int Np, float *__restrict__ total) {
+    const int i = blockIdx.x * kWave + threadIdx.x;
+    if (i >= Np) return;
+    double v[kColGroups], s = 0.0;
+#pragma unroll
+    for (int g = 0; g < kColGroups; ++g) v[g] = part[(long)g * Np + i];
+#pragma unroll
+    for (int g = 0; g < kColGroups; ++g) s += v[g];
+    total[i] = (float)s;
 }
 
 // Step 3 (distillation.py:35-51): ray loss = sum_i relu(bounds_i - what_i)^2 / (what_i + 1e-6); bounds row stride 0 =
@@ -199,7 +212,7 @@ extern "C" {
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t m360_loss_workspace_bytes(int B, int N) {
     const size_t b = B > 0 ? B : 0, n = N > 0 ? N : 0;
-    return up256(sizeof(SumScratch)) + up256(b * sizeof(float)) + up256(n * sizeof(float)) + up256(b * n * sizeof(float));
+    return up256(sizeof(SumScratch)) + up256(b * sizeof(float)) + up256(n * sizeof(float)) + up256(b * n * sizeof(float)) + up256((size_t)kColGroups * n * sizeof(double));
 }
 static inline float *ws_loss_ray(void *ws) { return reinterpret_cast<float *>(static_cast<char *>(ws) + up256(sizeof(SumScratch))); }
 
@@ -218,7 +231,9 @@ int m360_loss_prop(const float *t, const float *w, const float *t_hat, const flo
         float *total = reinterpret_cast<float *>(reinterpret_cast<char *>(loss_ray) + up256((size_t)B * sizeof(float)));
         float *per_ray = reinterpret_cast<float *>(reinterpret_cast<char *>(total) + up256((size_t)Np * sizeof(float)));
         hipLaunchKernelGGL(prop_overlap_kernel, grid, block, lds, S_(stream), t, w, t_hat, B, Nf, Np, per_ray);
-        hipLaunchKernelGGL(prop_colsum_kernel, dim3((Np + kWave - 1) / kWave), dim3(kColWaves * kWave), 0, S_(stream), per_ray, B, Np, total);
+        double *part = reinterpret_cast<double *>(reinterpret_cast<char *>(per_ray) + up256((size_t)B * Np * sizeof(float)));
+        hipLaunchKernelGGL(prop_colsum_kernel, dim3((Np + kWave - 1) / kWave, kColGroups), dim3(kColWaves * kWave), 0, S_(stream), per_ray, B, Np, part);
+        hipLaunchKernelGGL(prop_colsum_final_kernel, dim3((Np + kWave - 1) / kWave), dim3(kWave), 0, S_(stream), part, Np, total);
         bnd = total;
         bnd_stride = 0;
     }
