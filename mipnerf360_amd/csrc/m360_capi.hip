@@ -77,6 +77,9 @@ int nerf_finish_backward_stage(const void *act, int act_bf16, int ld, const floa
                                const float *t_vals, const float *dirs, int B, int N, int white_bkgd, const float *grad_rgb, const float *grad_distance,
                                const float *grad_acc, const float *grad_weights, void *dz, float *grad_head_w, float *grad_head_b, void *workspace,
                                size_t workspace_bytes, const float *raw_in, m360_stream_t stream);
+// m360_linear.hip: m360_linear_wgrad_bf16 with operand rows that overlap (the first layer: see mlp_backward_bf16)
+int linear_wgrad_bf16_rows(const void *dz, int ldz, const void *x, int ldx, long M, int n_pad, int k_pad, float *grad_w, float *grad_b,
+                           void *workspace, size_t workspace_bytes, unsigned tuning, m360_stream_t stream, bool x_rows_overlap);
 // m360_linear.hip: the hidden-layer chain of the bf16 mode (one launch) and its gated layer-by-layer re-run
 int mlp_chain_bf16_launch(const void *x_in, void *act0, void *act1, long M, int ld, const void *const *w_packed, const float *const *b_packed,
                           int layers, int width, void *ws, m360_stream_t stream, const m360_hyper_t *opts, bool x3);
@@ -635,8 +638,8 @@ struct BwdLayout {
     int first_k;  // bf16 mode: columns of the first layer's operand as the weight-gradient kernel sees it (see mlp_backward_bf16)
 };
 // bf16 mode, first layer: the features are [hi | lo] pair rows of 2 in_pad columns.  The MFMA weight-gradient kernel takes contractions over
-// 256-column tiles, so the rows are copied into a zero-padded [S, 256] operand for it (widths it does not take go through the fp32 kernel as
-// they are); either way the result [n_pad, first_k] is folded into grad_w[0][n][k] = r[n][k] + r[n][in_pad + k]
+// 256-column tiles, so the rows are handed over as overlapping 256-column rows (linear_wgrad_bf16_rows; widths it does not take go through the
+// fp32 kernel as they are); either way the result [n_pad, first_k] is folded into grad_w[0][n][k] = r[n][k] + r[n][in_pad + k]
 static int bf16_first_k(const m360_model_t *m, int width) { return (width % 256 == 0 && 2 * m->in_pad <= 256) ? 256 : 2 * m->in_pad; }
 static BwdLayout bwd_layout_for(int B, int N, const m360_model_t *m, int stage) {
     BwdLayout L;
@@ -657,7 +660,7 @@ static BwdLayout bwd_layout_for(int B, int N, const m360_model_t *m, int stage) 
         L.gemm = take(m360_linear_wgrad_workspace_bytes((long)S, width, kmax));
     }
     L.finish = take(m360_finish_backward_workspace_bytes(B, stage == 0 ? 1 : 4, width));
-    L.feat_wide = take(b16 && L.first_k != 2 * m->in_pad ? S * (size_t)L.first_k * 2 : 0);
+    L.feat_wide = take(0);  // (until round 6: a zero-padded [S, first_k] copy of the feature rows; the offset still ends the finishers' scratch)
     L.first = take(b16 ? (size_t)width * L.first_k * sizeof(float) : 0);
     L.total = off;
     return L;
@@ -797,19 +800,13 @@ static int mlp_backward_bf16(const m360_hyper_t *h, int layers, const float *con
             M360_PROF(h, st, M360_K_DGRAD, S, width, -width, m360_linear_dgrad_bf16(dz, S, width, w_t[l], width, width, act[l - 1], dz_other, width, st));
             void *tmp = dz; dz = dz_other; dz_other = tmp;
         } else {
-            const void *x0 = feat;
-            int ld0 = 2 * in_pad;
             hipStream_t hs = reinterpret_cast<hipStream_t>(st);
-            if (L.first_k != 2 * in_pad) {  // zero-padded [S, first_k] copy of the [hi | lo] rows for the 256-column tiles of the MFMA kernel
-                void *wide = ws + L.feat_wide;
-                if (hipMemsetAsync(wide, 0, (size_t)S * L.first_k * 2, hs) != hipSuccess ||
-                    hipMemcpy2DAsync(wide, (size_t)L.first_k * 2, feat, (size_t)2 * in_pad * 2, (size_t)2 * in_pad * 2, (size_t)S, hipMemcpyDeviceToDevice, hs) != hipSuccess)
-                    return fail(M360_ERR_LAUNCH, "%s: widening the feature rows failed: %s", who, hipGetErrorString(hipGetLastError()));
-                x0 = wide;
-                ld0 = L.first_k;
-            }
+            // The [hi | lo] feature rows are 2 in_pad = 128 bf16 wide; the MFMA kernels tile the contraction in 256 columns.  first_k = 256: the rows are
+            // handed over as they lie, OVERLAPPING (linear_wgrad_bf16_rows: columns 128 .. 255 of a row are the next row's features; behind the last
+            // row lies the tape's first layer output) - the fold below reads columns < 2 in_pad of the result only.  (Until round 6: a zero-padded
+            // [S, 256] copy per backward, a 268 MB memset + a strided copy.)
             float *r = reinterpret_cast<float *>(ws + L.first);
-            M360_PROF(h, st, M360_K_WGRAD, S, width, -L.first_k, m360_linear_wgrad_bf16(dz, width, x0, ld0, S, width, L.first_k, r, gb, gemm_ws, gemm_bytes, tuning, st));
+            M360_PROF(h, st, M360_K_WGRAD, S, width, -L.first_k, linear_wgrad_bf16_rows(dz, width, feat, 2 * in_pad, S, width, L.first_k, r, gb, gemm_ws, gemm_bytes, tuning, st, L.first_k != 2 * in_pad));
             hipLaunchKernelGGL(fold_first_layer_kernel, dim3((unsigned)((width * in_pad + 255) / 256)), dim3(256), 0, hs, r, width, L.first_k, in_pad, grad_w[0]);
             M360_TRY(check_launch(who));
         }

@@ -982,6 +982,8 @@ int m360_linear_bf16_split(const void *x, long M, int ldx, const void *w_packed,
 // ---- bf16 training path (round 5): transposed bf16 packing, input gradient, weight gradient
 }  // extern "C"
 namespace m360 {
+int linear_wgrad_bf16_rows(const void *dz, int ldz, const void *x, int ldx, long M, int n_pad, int k_pad, float *grad_w, float *grad_b,
+                           void *workspace, size_t workspace_bytes, unsigned tuning, m360_stream_t stream, bool x_rows_overlap);
 // dx[m, k] = relu_out[m, k] > 0 ? dx[m, k] : 0 in place (the second half of m360_linear_dgrad_bf16; m360_capi.hip runs it on a second stream
 // beside the layer's weight gradient, which does not read dx)
 // can the throttled form with `blocks` workgroups also form the column sums of the masked rows (mlp_backward_bf16: the next layer's bias gradient)?
@@ -1076,7 +1078,19 @@ size_t m360_linear_wgrad_bf16_workspace_bytes(long M, int n_pad, int k_pad) {
 
 int m360_linear_wgrad_bf16(const void *dz, int ldz, const void *x, int ldx, long M, int n_pad, int k_pad, float *grad_w, float *grad_b,
                            void *workspace, size_t workspace_bytes, unsigned tuning, m360_stream_t stream) {
-    if (!dz || !x || !grad_w || M < 0 || n_pad < 32 || k_pad < 32 || n_pad % 32 || k_pad % 32 || ldz < n_pad || ldx < k_pad)
+    return m360::linear_wgrad_bf16_rows(dz, ldz, x, ldx, M, n_pad, k_pad, grad_w, grad_b, workspace, workspace_bytes, tuning, stream, false);
+}
+}  // extern "C"
+namespace m360 {
+// m360_linear_wgrad_bf16 - and, for the stage backwards (m360_capi.hip: the first layer, whose operand rows are 2 in_pad = 128 bf16 where the MFMA
+// kernels tile the contraction in 256 columns), x_rows_overlap: ldx < k_pad is allowed, columns ldx .. k_pad - 1 of a row ARE
+// the next row's first columns.  The caller owns the (k_pad - ldx) elements behind the last row and ignores columns >= ldx of grad_w (each
+// element of dW depends on its own column of X only).  Round 6: until then a zero-padded [M, 256] copy was made for every backward - a 268 MB
+// memset and a strided copy, 0.1 ms - for the same number of MFMAs; the overlapped rows' second halves are the lines the next row reads anyway.
+int linear_wgrad_bf16_rows(const void *dz, int ldz, const void *x, int ldx, long M, int n_pad, int k_pad, float *grad_w, float *grad_b,
+                           void *workspace, size_t workspace_bytes, unsigned tuning, m360_stream_t stream, bool x_rows_overlap) {
+    if (x_rows_overlap && ldx < 8) return fail(M360_ERR_INVALID_ARGUMENT, "linear_wgrad_bf16_rows: ldx=%d", ldx);
+    if (!dz || !x || !grad_w || M < 0 || n_pad < 32 || k_pad < 32 || n_pad % 32 || k_pad % 32 || ldz < n_pad || (ldx < k_pad && !x_rows_overlap))
         return fail(M360_ERR_INVALID_ARGUMENT, "m360_linear_wgrad_bf16: bad argument (M=%ld n_pad=%d k_pad=%d ldz=%d ldx=%d)", M, n_pad, k_pad, ldz, ldx);
     const size_t need = m360_linear_wgrad_bf16_workspace_bytes(M, n_pad, k_pad);
     if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) return fail(M360_ERR_WORKSPACE_TOO_SMALL, "m360_linear_wgrad_bf16: workspace %zu < %zu bytes (or not 256-byte aligned)", workspace_bytes, need);
@@ -1147,6 +1161,8 @@ int m360_linear_wgrad_bf16(const void *dz, int ldz, const void *x, int ldx, long
     if (rc != M360_OK) return rc;
     return m360_linear_wgrad(dzf, n_pad, xf, k_pad, M, n_pad, k_pad, grad_w, grad_b, rest, workspace_bytes - used, stream);
 }
+}  // namespace m360
+extern "C" {
 
 int m360_pack_linear_bf16x3(const float *w, const float *b, int n_out, int k_in, int n_pad, int k_pad, void *w_packed3,
                             float *b_packed, m360_stream_t stream) {

@@ -242,11 +242,14 @@ def test_g22_randomized_training_steps_bf16(golden, dev, tag):
 NERF_REL, PROP_REL = 3e-2, 8e-2  # full width against the fp32 mirrors (measured 1.2e-2 / 1.8e-2: wide layers average the rounding noise)
 
 
-@pytest.mark.parametrize("B,N,Nf", [(77, 37, None), (130, 32, 48)])
+@pytest.mark.parametrize("B,N,Nf", [(77, 37, None), (130, 32, 48), (3, 11, None)])
 def test_ragged_full_width_gradients_bf16_vs_fp32_mirrors(dev, B, N, Nf):
     """Row counts that are no multiple of anything (77 x 37 = 2849 rows: 11 full 256-row tiles + 33 ragged rows; the weight-gradient
-    kernel's 64-row stages + a tail added by its reduce kernel) and a NeRF stage with its own sample count (`num_samples_fine`): the bf16
-    gradients against the fp32 mirrors', full width."""
+    kernel's 64-row stages + a tail added by its reduce kernel), a NeRF stage with its own sample count (`num_samples_fine`), and fewer rows
+    than one stage of the MFMA weight-gradient kernel (3 x 11 = 33: the fp32 kernel on widened operands): the bf16 gradients against the fp32
+    mirrors', full width.  The first layer's weight gradient reads the 128-wide [hi | lo] feature rows as OVERLAPPING 256-wide rows
+    (linear_wgrad_bf16_rows, round 6) on every one of these paths: its last row runs into the tape's next buffer, its result's upper columns
+    are never read."""
     from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf
     from mipnerf360_amd.model import mipNeRF360
     sd = synthetic.make_state_dict(256, 1024, seed=14)
@@ -272,7 +275,7 @@ def test_ragged_full_width_gradients_bf16_vs_fp32_mirrors(dev, B, N, Nf):
 
 
 def test_full_width_gradients_bf16_vs_fp32_mirrors(dev):
-    """Full width (256 / 1024: the MFMA weight-gradient kernel, the zero-padded first-layer operand, the ring kernel as input-gradient
+    """Full width (256 / 1024: the MFMA weight-gradient kernel, the first layer's overlapping operand rows, the ring kernel as input-gradient
     kernel) at 512 rays x 64 samples: the bf16 gradients of one NeRF update and one proposal update against the fp32 mirrors' (which
     G13 / G21 pin to the reference), tensor by tensor."""
     from mipnerf360_amd.intern.loss import Loss_dist, Loss_nerf, Loss_prop
