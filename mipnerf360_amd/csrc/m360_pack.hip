@@ -87,6 +87,7 @@ int m360_pack_many(const m360_pack_item_t *items, int count, unsigned *nan_flag,
     if (count < 0 || (count > 0 && !items)) return fail(M360_ERR_INVALID_ARGUMENT, "m360_pack_many: null item list or negative count");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (nan_flag && hipMemsetAsync(nan_flag, 0, sizeof(unsigned), st) != hipSuccess) return fail(M360_ERR_LAUNCH, "m360_pack_many: memset of the flag failed");
+    if (count == 0) return M360_OK;  // (the flag, if any, is cleared: nothing read, nothing NaN)
     // every item is checked before the first launch: a refused list packs nothing
     for (int i = 0; i < count; ++i) {
         const m360_pack_item_t &it = items[i];

@@ -103,6 +103,18 @@ def test_argument_validation_without_gpu(lib):
     assert lib.m360_linear_wgrad_bf16_workspace_bytes(524288, 1024, 1024) >= 16 * 1024 * 1024 * 4
     assert lib.m360_side_create(None) == -1 and "m360_side_create" in _lib.last_error()
     lib.m360_side_destroy(None)  # a no-op, like free(NULL)
+    # round 6: m360_pack_many checks its whole list before it launches anything (no nan_flag: not even a memset)
+    import ctypes as C
+    assert lib.m360_pack_many(None, 2, None, None) == -1 and "m360_pack_many" in _lib.last_error()
+    assert lib.m360_pack_many(None, 0, None, None) == 0  # an empty list packs nothing
+    items = (_lib.PackItem * 2)()
+    items[0] = _lib.PackItem(0x1000, 0, 0x2000, 0, 8, 8, 64, 64, _lib.PACK_BF16, 0)
+    items[1] = _lib.PackItem(0x1000, 0, 0x2000, 0, 8, 8, 64, 96, _lib.PACK_BF16, 0)   # k_pad not a multiple of 64
+    assert lib.m360_pack_many(C.cast(items, C.c_void_p), 2, None, None) == -1 and "item 1" in _lib.last_error()
+    items[1] = _lib.PackItem(0x1000, 0x1000, 0x2000, 0, 8, 8, 64, 64, _lib.PACK_BF16_T, 0)  # a transposed packing has no bias
+    assert lib.m360_pack_many(C.cast(items, C.c_void_p), 2, None, None) == -1 and "no bias" in _lib.last_error()
+    items[1] = _lib.PackItem(0x1000, 0, 0x2000, 0, 8, 8, 64, 64, 9, 0)
+    assert lib.m360_pack_many(C.cast(items, C.c_void_p), 2, None, None) == -1 and "format 9" in _lib.last_error()
     with pytest.raises(RuntimeError, match="m360_ipe"):
         _lib.check(lib.m360_ipe(None, None, 5, None, None), "m360_ipe")
     m = _lib.ModelStruct()
